@@ -1,0 +1,224 @@
+/*
+ * sadvio_ba.h — C ABI of the MI355X-native sliding-window bundle-adjustment backend.
+ *
+ * This is the drop-in boundary for SaDVIO's optimizer hot path. Every entry point names the
+ * reference interface it replaces (paths relative to the reference checkout, `cpp/...`).
+ * The reference has no FFI of its own (100 % C++); what a maintainer binds is
+ * an `isae::AOptimizer` subclass that flattens the object graph into `sadvio_flat_window`,
+ * calls these functions and applies the returned *deltas* with the reference's own
+ * composition rules (AOptimizer.cpp:329-340,391-434). See INTEGRATION.md.
+ *
+ * Conventions
+ *   - All floating point is IEEE FP64 (the reference is FP64 throughout).
+ *   - A rigid transform is 12 doubles: R row-major (9) followed by t (3).
+ *     `T_f_w` = world->frame (frame.h:48-51), `T_s_f` = frame->sensor (ASensor.h:43-44).
+ *   - Optimisation variables are deltas initialised to zero and composed on the right:
+ *     T_f_w = T_f_w0 * (exp(w), t)  (geometry.h:198-203; parametersBlock.hpp:34-37 — NOT the
+ *     SE3 exponential), p = p0 + dl (geometry.h:205-210).
+ *   - Return value 0 = OK, negative = SADVIO_E_*; nothing throws across the boundary.
+ *   - A handle owns one HIP stream and all device mirrors; it is not re-entrant. Two handles
+ *     (front-end / back-end optimizer instances, slamParameters.cpp:273-275) may be used
+ *     concurrently from different host threads.
+ *   - The library has NO CPU fallback: every compute entry point fails with
+ *     SADVIO_E_NO_DEVICE / SADVIO_E_HIP when no gfx950 device is usable.
+ */
+#ifndef SADVIO_BA_H
+#define SADVIO_BA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SADVIO_OK 0
+#define SADVIO_E_INVALID_ARG (-1)
+#define SADVIO_E_NOT_USABLE (-2) /* solver produced no usable solution (AOptimizer.cpp:259) */
+#define SADVIO_E_HIP (-3)
+#define SADVIO_E_RCCL (-4)
+#define SADVIO_E_NO_DEVICE (-5)
+#define SADVIO_E_STATE (-6)   /* call order violated (e.g. solve before set_window) */
+#define SADVIO_E_REFUSED (-7) /* marginalisation refused: n < 4 (marginalization.cpp:215-216) */
+
+/* Visual factor flavour of a window. */
+#define SADVIO_FACTOR_PIXEL 0   /* ReprojectionErrCeres_pointxd_dx, BundleAdjustmentCERESAnalytic.h:41-98 */
+#define SADVIO_FACTOR_ANGULAR 1 /* AngularErrCeres_pointxd_dx, AngularAdjustmentCERESAnalytic.h:45-120 */
+
+/* Termination codes in sadvio_solve_summary.termination (Ceres TerminationType semantics). */
+#define SADVIO_TERM_NO_CONVERGENCE 0 /* max_num_iterations reached */
+#define SADVIO_TERM_FUNCTION_TOL 1
+#define SADVIO_TERM_PARAMETER_TOL 2
+#define SADVIO_TERM_GRADIENT_TOL 3
+#define SADVIO_TERM_MIN_RADIUS 4
+#define SADVIO_TERM_FAILURE 5 /* too many consecutive invalid steps */
+
+typedef struct sadvio_ba_handle sadvio_ba_handle;
+
+typedef struct sadvio_ba_config {
+    int32_t device;          /* HIP device ordinal */
+    int32_t profile_kernels; /* 1: bracket every kernel class with hipEvents (see get_kernel_times) */
+    int32_t use_graph;       /* 1: replay the iteration sequence from a captured hipGraph */
+    int32_t reserved;
+} sadvio_ba_config;
+
+/*
+ * One sliding window, flattened (SoA, index based). Replaces the object-graph walk of
+ * BundleAdjustmentCERESAnalytic::addResidualsLocalMap (BundleAdjustmentCERESAnalytic.cpp:197-314)
+ * / AngularAdjustmentCERESAnalytic::addResidualsLocalMap (…Angular….cpp:212-339).
+ * Inclusion rules the flattener must apply (the adapter side owns them):
+ *   - key-frames in the order of LocalMap::getLastNFramesIn, newest first (amap.h:28-32);
+ *     kf_const[i] = 1 iff i > n_kf - fixed - 1 (…Analytic.cpp:219);
+ *   - landmark included iff isInitialized && !isOutlier (…Analytic.cpp:239);
+ *   - observation included iff its sensor's frame is a key-frame of the window (…Analytic.cpp:256-258).
+ * Observations are CSR by landmark. All arrays are caller-owned; set_window copies them.
+ */
+typedef struct sadvio_flat_window {
+    int32_t n_kf;
+    int32_t n_cam;
+    int32_t n_lmk;
+    int32_t n_obs;
+    int32_t factor_type; /* SADVIO_FACTOR_* */
+    int32_t has_imu;     /* 1: every key-frame carries (v, ba, bg) states (AOptimizer.cpp:29-53) */
+
+    const int64_t *kf_id;    /* [n_kf] opaque ids, echoed unchanged (frame.h:21-22) */
+    const double *kf_T_f_w;  /* [n_kf][12] */
+    const uint8_t *kf_const; /* [n_kf] */
+    const double *kf_vel;    /* [n_kf][3] or NULL (IMU.h:77-100) */
+    const double *kf_ba;     /* [n_kf][3] or NULL */
+    const double *kf_bg;     /* [n_kf][3] or NULL */
+
+    const double *cam_K;     /* [n_cam][4] fx fy cx cy (ASensor.cpp:17) */
+    const double *cam_T_s_f; /* [n_cam][12] (ASensor.h:44) */
+    const double *cam_sigma; /* [n_cam] measurement sigma: 1.0 pixel (…Analytic.h:46);
+                                1.5/f angular window BA (…Angular….cpp:283) */
+
+    const int64_t *lmk_id;      /* [n_lmk] opaque ids, echoed unchanged (ALandmark.h:18-19) */
+    const double *lmk_p;        /* [n_lmk][3] T_w_lmk.translation() (ALandmark.h:36-39) */
+    const uint8_t *lmk_const;   /* [n_lmk] or NULL = all free */
+    const int32_t *lmk_obs_ptr; /* [n_lmk+1] CSR offsets into obs_* */
+    const int32_t *obs_kf;      /* [n_obs] index into kf_* */
+    const int32_t *obs_cam;     /* [n_obs] index into cam_* */
+    const double *obs_meas;     /* [n_obs][2] pixel uv (AFeature2D.h:21) | [n_obs][3] unit bearing (AFeature2D.h:80) */
+} sadvio_flat_window;
+
+/* Constants of one IMUFactor + IMUBiasFactor pair (residuals.hpp:133-300); pairing rule
+ * AOptimizer::addIMUResiduals (AOptimizer.cpp:55-92): consecutive KFs, dt <= 1 s. kf_i is the
+ * older frame (imu_j->getLastKF()). All 3x3 are row-major. */
+typedef struct sadvio_imu_factor {
+    int32_t kf_i, kf_j;
+    double dt;            /* (ts_j - ts_i) * 1e-9 */
+    double delta_R[9];    /* IMU::getDeltaR of imu_j */
+    double delta_v[3];
+    double delta_p[3];
+    double J_dR_bg[9];    /* IMU.h:141-145 */
+    double J_dv_ba[9];
+    double J_dv_bg[9];
+    double J_dp_ba[9];
+    double J_dp_bg[9];
+    double cov[81];       /* IMU::getCov of imu_j, 9x9 row-major */
+    double bacc_noise;    /* imu_i->getbAccNoise() (residuals.hpp:259) */
+    double bgyr_noise;    /* imu_i->getbGyrNoise() (residuals.hpp:261) */
+} sadvio_imu_factor;
+
+/* PosePriordx (residuals.hpp:601-632); sqrt_inf = diag(inf_diag) (…Analytic.cpp:226). */
+typedef struct sadvio_pose_prior {
+    int32_t kf;
+    int32_t pad;
+    double T_prior[12];
+    double inf_diag[6];
+} sadvio_pose_prior;
+
+/* Solver options. sadvio_ba_default_options() fills the reference's hard-coded values
+ * (AOptimizer.cpp:315-323) and, for everything the reference leaves unset, the defaults of
+ * Ceres Solver 2.2.0 (docker/Dockerfile:50), the version the reference pins. */
+typedef struct sadvio_solve_options {
+    int32_t max_num_iterations;            /* 20 */
+    int32_t jacobi_scaling;                /* 1 */
+    int32_t max_num_consecutive_invalid_steps; /* 5 */
+    int32_t reserved;
+    double function_tolerance;             /* 1e-3 */
+    double gradient_tolerance;             /* 1e-10 */
+    double parameter_tolerance;            /* 1e-8 */
+    double initial_trust_region_radius;    /* 1e4 */
+    double max_trust_region_radius;        /* 1e16 */
+    double min_trust_region_radius;        /* 1e-32 */
+    double min_lm_diagonal;                /* 1e-6 */
+    double max_lm_diagonal;                /* 1e32 */
+    double min_relative_decrease;          /* 1e-3 */
+} sadvio_solve_options;
+
+typedef struct sadvio_solve_summary {
+    int32_t iterations;             /* step attempts performed (Ceres iteration count, excl. iteration 0) */
+    int32_t num_successful_steps;
+    int32_t num_unsuccessful_steps;
+    int32_t termination;            /* SADVIO_TERM_* */
+    double initial_cost;            /* 1/2 sum r^2 over the reduced program at x0 */
+    double final_cost;
+    double fixed_cost;              /* cost of residual blocks whose parameters are all constant */
+    double final_radius;
+} sadvio_solve_summary;
+
+/* Number of usable gfx950 devices (0 when none: every compute call then fails). */
+int sadvio_ba_device_count(void);
+
+/* Fill `opts` with the reference's options for localMapBA (AOptimizer.cpp:315-323). */
+void sadvio_ba_default_options(sadvio_solve_options *opts);
+
+/* Create / destroy a backend instance. Replaces constructing one optimizer object
+ * (slamParameters.cpp:263-282). */
+int sadvio_ba_create(const sadvio_ba_config *cfg, sadvio_ba_handle **out);
+void sadvio_ba_destroy(sadvio_ba_handle *h);
+
+/* Upload `n_windows` independent windows (a batch: independent sub-windows solved
+ * concurrently; n_windows = 1 is the reference's case). Replaces addResidualsLocalMap
+ * (…Analytic.cpp:197-314). Clears any factors set by earlier set_* calls. */
+int sadvio_ba_set_windows(sadvio_ba_handle *h, int32_t n_windows, const sadvio_flat_window *windows);
+
+/* PosePriordx blocks of window `w` (…Analytic.cpp:224-228). */
+int sadvio_ba_set_pose_priors(sadvio_ba_handle *h, int32_t w, int32_t n, const sadvio_pose_prior *priors);
+
+/* IMUFactor + IMUBiasFactor blocks of window `w` (AOptimizer.cpp:55-92). */
+int sadvio_ba_set_imu_factors(sadvio_ba_handle *h, int32_t w, int32_t n, const sadvio_imu_factor *factors);
+
+/* Dense marginalisation prior of window `w` = MarginalizationFactor (marginalization.hpp:88-218,
+ * added by addMarginalizationResiduals, …Analytic.cpp:316-360): r = r0 + J dx, J is
+ * n_full x n row-major. `kf_keep` (or -1 in pure VO) is the key-frame whose 15 states occupy
+ * columns [kf_col, kf_col+15) (pose6, v3, ba3, bg3); kept landmark `lmk_index[i]` occupies
+ * columns [lmk_col[i], lmk_col[i]+3); lmk_col[i] = -1 means "skipped" (marginalization.hpp:138). */
+int sadvio_ba_set_dense_prior(sadvio_ba_handle *h, int32_t w, int32_t n_full, int32_t n,
+                              const double *J, const double *r0, int32_t kf_keep, int32_t kf_col,
+                              int32_t n_keep, const int32_t *lmk_index, const int32_t *lmk_col);
+
+/* Run the Levenberg-Marquardt solve of every uploaded window: replaces the body of
+ * AOptimizer::localMapBA / localMapVIOptimization from ceres::Solve on (AOptimizer.cpp:326,388).
+ * `summaries` has n_windows entries (may be NULL). */
+int sadvio_ba_solve(sadvio_ba_handle *h, const sadvio_solve_options *opts, sadvio_solve_summary *summaries);
+
+/* Read back the solved deltas of window `w`; arrays are index-aligned with the window's input
+ * arrays (landmark / key-frame order is never permuted). Any pointer may be NULL.
+ * The adapter applies them as AOptimizer.cpp:329-340 (poses, landmarks) and :391-418 (v, ba, bg). */
+int sadvio_ba_get_deltas(sadvio_ba_handle *h, int32_t w, double *pose_delta6, double *lmk_delta3,
+                         double *dv3, double *dba3, double *dbg3);
+
+/* Echo of the opaque ids of window `w` in output order (bit-exact identity check). */
+int sadvio_ba_get_ids(sadvio_ba_handle *h, int32_t w, int64_t *kf_id, int64_t *lmk_id);
+
+/* Linearise window `w` at zero deltas and return per-observation residuals/Jacobians
+ * (row-major r[2], J_pose[2x6], J_lmk[2x3]): the GPU counterpart of calling
+ * CostFunction::Evaluate on every block (…Analytic.h:52-90 / …Angular….h:55-111). Parity probe. */
+int sadvio_ba_linearize(sadvio_ba_handle *h, int32_t w, const double *pose_delta6, const double *lmk_delta3,
+                        double *r2, double *J_pose12, double *J_lmk6);
+
+/* Average device time in microseconds per kernel class since the last set_windows, measured
+ * with hipEvents on the handle's stream (cfg.profile_kernels = 1). `names` receives pointers
+ * to static strings. Returns the number of classes written (<= cap). */
+int sadvio_ba_get_kernel_times(sadvio_ba_handle *h, int32_t cap, const char **names, double *avg_us,
+                               int64_t *launches);
+
+const char *sadvio_ba_last_error(sadvio_ba_handle *h);
+const char *sadvio_ba_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SADVIO_BA_H */

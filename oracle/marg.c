@@ -1,0 +1,282 @@
+/*
+ * oracle/marg.c — TEST INFRASTRUCTURE ONLY (CPU oracle). Not part of the product path.
+ *
+ * Restatement of the dense marginalisation prior of the reference:
+ *   Marginalization::preMarginalize index layout      (marginalization.cpp:38-113)
+ *   computeInformationAndGradient  A = sum J^T J, b = + sum J^T r   (:145-211, quirk B.7)
+ *   computeSchurComplement  Amm symmetrised, eigen pseudo-inverse with 1e-12 cut,
+ *                           Ak = Arr - Arm Amm^+ Arm^T, bk = brr - Arm Amm^+ bmm   (:213-265)
+ *   rankReveallingDecomposition  Ak = U Lambda U^T keeping lambda > 1e-12   (:318-342)
+ *   computeJacobiansAndResiduals  J = Lambda^{1/2} U^T, r0 = -Lambda^{-1/2} U^T bk   (:516-530)
+ * and of the block list built by BundleAdjustmentCERESAnalytic::marginalize (…Analytic.cpp:431-617)
+ * / AngularAdjustmentCERESAnalytic::marginalize (…Angular….cpp:488-693): IMUFactor + IMUBiasFactor,
+ * reprojection factors of kept and marginalised landmarks seen from frame0, the previous
+ * MarginalizationFactor, PosePriordx blocks. Every block is evaluated at zero deltas.
+ * Eigen's SelfAdjointEigenSolver is replaced by a cyclic Jacobi eigen-solver: the prior (J^T J,
+ * J^T r0) is invariant to the eigenvector sign / ordering conventions.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include "factors.h"
+#include "sadvio_oracle.h"
+
+#define MARG_EPS 1e-12 /* marginalization.hpp:56 */
+
+void oracle_sym_eig(const double *Ain, int32_t n, double *evals, double *V) {
+    double *A = (double *)malloc(sizeof(double) * (size_t)n * n);
+    memcpy(A, Ain, sizeof(double) * (size_t)n * n);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) V[(size_t)i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 100; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; i++) {
+            diag += A[(size_t)i * n + i] * A[(size_t)i * n + i];
+            for (int j = i + 1; j < n; j++) off += A[(size_t)i * n + j] * A[(size_t)i * n + j];
+        }
+        if (off <= 1e-60 || off <= 1e-32 * diag) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double apq = A[(size_t)p * n + q];
+                if (apq == 0.0) continue;
+                double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+                double theta = (aqq - app) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+                    A[(size_t)k * n + p] = c * akp - s * akq;
+                    A[(size_t)k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+                    A[(size_t)p * n + k] = c * apk - s * aqk;
+                    A[(size_t)q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+                    V[(size_t)k * n + p] = c * vkp - s * vkq;
+                    V[(size_t)k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; i++) evals[i] = A[(size_t)i * n + i];
+    /* ascending order, like Eigen::SelfAdjointEigenSolver */
+    for (int i = 0; i < n - 1; i++) {
+        int m = i;
+        for (int j = i + 1; j < n; j++)
+            if (evals[j] < evals[m]) m = j;
+        if (m != i) {
+            double t = evals[i]; evals[i] = evals[m]; evals[m] = t;
+            for (int k = 0; k < n; k++) {
+                double v = V[(size_t)k * n + i]; V[(size_t)k * n + i] = V[(size_t)k * n + m]; V[(size_t)k * n + m] = v;
+            }
+        }
+    }
+    free(A);
+}
+
+/* A += J^T J over index-mapped blocks, b += J^T r  (marginalization.cpp:153-190) */
+static void accumulate(double *A, double *b, int N, const double *J, const double *r, int rows, int ncols,
+                       const int *col) {
+    for (int a = 0; a < ncols; a++) {
+        if (col[a] < 0) continue;
+        double g = 0;
+        for (int q = 0; q < rows; q++) g += J[q * ncols + a] * r[q];
+        b[col[a]] += g;
+        for (int c2 = 0; c2 < ncols; c2++) {
+            if (col[c2] < 0) continue;
+            double h = 0;
+            for (int q = 0; q < rows; q++) h += J[q * ncols + a] * J[q * ncols + c2];
+            A[(size_t)col[a] * N + col[c2]] += h;
+        }
+    }
+}
+
+int oracle_marginalize(const oracle_marg_request *rq, oracle_marg_result *res, int32_t *lmk_col_out, double *A_full,
+                       double *b_full, double *Ak_out, double *bk_out, double *U_out, double *Lambda_out, double *J_out,
+                       double *r0_out) {
+    const sadvio_flat_window *w = rq->win;
+    /* index layout, marginalization.cpp:38-113 */
+    int m = 6 + (rq->marg_has_imu ? 9 : 0) + 3 * rq->n_marg;
+    int n = (rq->kf_keep >= 0 ? 15 : 0) + 3 * rq->n_keep;
+    int N = m + n;
+    int *lcol = (int *)malloc(sizeof(int) * (size_t)(w->n_lmk > 0 ? w->n_lmk : 1));
+    for (int l = 0; l < w->n_lmk; l++) lcol[l] = -1;
+    int idx = 6 + (rq->marg_has_imu ? 9 : 0);
+    for (int k = 0; k < rq->n_marg; k++) { lcol[rq->lmk_marg[k]] = idx; idx += 3; }
+    int kf_keep_col = -1;
+    if (rq->kf_keep >= 0) { kf_keep_col = idx; idx += 15; }
+    for (int k = 0; k < rq->n_keep; k++) { lcol[rq->lmk_keep[k]] = idx; idx += 3; }
+    if (res) { res->m = m; res->n = n; res->n_full = 0; res->kf_col = kf_keep_col >= 0 ? kf_keep_col - m : -1; }
+    if (lmk_col_out)
+        for (int k = 0; k < rq->n_keep; k++) lmk_col_out[k] = lcol[rq->lmk_keep[k]] - m;
+    if (n < 4) { free(lcol); return SADVIO_E_REFUSED; } /* :215-216 */
+
+    double *A = (double *)calloc((size_t)N * N, sizeof(double));
+    double *b = (double *)calloc((size_t)N, sizeof(double));
+    static const double z[24] = {0};
+
+    /* IMUFactor + IMUBiasFactor (frame0, frame1), …Analytic.cpp:451-508 */
+    if (rq->imu && rq->kf_keep >= 0 && rq->marg_has_imu) {
+        const sadvio_imu_factor *f = rq->imu;
+        int i = rq->kf_marg, j = rq->kf_keep;
+        double W[81], r[9], Jpi[54], Jpj[54], Jvi[27], Jvj[27], Jba[27], Jbg[27], J[9 * 24];
+        imu_sqrt_information(f->cov, W);
+        imu_consts ic = {f->dt, f->delta_R, f->delta_v, f->delta_p, f->J_dR_bg, f->J_dv_ba, f->J_dv_bg, f->J_dp_ba,
+                         f->J_dp_bg, W};
+        const double *vi = w->kf_vel ? w->kf_vel + 3 * i : z, *vj = w->kf_vel ? w->kf_vel + 3 * j : z;
+        factor_imu(&ic, w->kf_T_f_w + 12 * i, w->kf_T_f_w + 12 * j, vi, vj, z, z, z, z, z, z, r, Jpi, Jpj, Jvi, Jvj,
+                   Jba, Jbg);
+        int col[24];
+        for (int q = 0; q < 9; q++) {
+            for (int a = 0; a < 6; a++) { J[q * 24 + a] = Jpi[q * 6 + a]; J[q * 24 + 6 + a] = Jpj[q * 6 + a]; }
+            for (int a = 0; a < 3; a++) {
+                J[q * 24 + 12 + a] = Jvi[q * 3 + a]; J[q * 24 + 15 + a] = Jvj[q * 3 + a];
+                J[q * 24 + 18 + a] = Jba[q * 3 + a]; J[q * 24 + 21 + a] = Jbg[q * 3 + a];
+            }
+        }
+        for (int a = 0; a < 6; a++) { col[a] = a; col[6 + a] = kf_keep_col + a; }
+        for (int a = 0; a < 3; a++) {
+            col[12 + a] = 6 + a; col[15 + a] = kf_keep_col + 6 + a; col[18 + a] = 9 + a; col[21 + a] = 12 + a;
+        }
+        accumulate(A, b, N, J, r, 9, 24, col);
+        double rb[6], Jb[72], sa, sg;
+        const double *bai = w->kf_ba ? w->kf_ba + 3 * i : z, *bgi = w->kf_bg ? w->kf_bg + 3 * i : z;
+        const double *baj = w->kf_ba ? w->kf_ba + 3 * j : z, *bgj = w->kf_bg ? w->kf_bg + 3 * j : z;
+        factor_imu_bias(f->dt, f->bacc_noise, f->bgyr_noise, bai, bgi, baj, bgj, z, z, z, z, rb, &sa, &sg);
+        memset(Jb, 0, sizeof(Jb));
+        int colb[12];
+        for (int a = 0; a < 3; a++) {
+            Jb[a * 12 + a] = -sa; Jb[(3 + a) * 12 + 3 + a] = -sg; Jb[a * 12 + 6 + a] = sa; Jb[(3 + a) * 12 + 9 + a] = sg;
+            colb[a] = 9 + a; colb[3 + a] = 12 + a; colb[6 + a] = kf_keep_col + 9 + a; colb[9 + a] = kf_keep_col + 12 + a;
+        }
+        accumulate(A, b, N, Jb, rb, 6, 12, colb);
+    }
+
+    /* reprojection factors of kept then marginalised landmarks seen from frame0, …Analytic.cpp:510-572 */
+    for (int pass = 0; pass < 2; pass++) {
+        int cnt = pass == 0 ? rq->n_keep : rq->n_marg;
+        const int32_t *list = pass == 0 ? rq->lmk_keep : rq->lmk_marg;
+        for (int k = 0; k < cnt; k++) {
+            int l = list[k];
+            for (int o = w->lmk_obs_ptr[l]; o < w->lmk_obs_ptr[l + 1]; o++) {
+                if (w->obs_kf[o] != rq->kf_marg) continue;
+                int cam = w->obs_cam[o];
+                double r[2], Jp[12], Jl[6], J[18];
+                double sigma = w->cam_sigma ? w->cam_sigma[cam] : 1.0;
+                if (w->factor_type == SADVIO_FACTOR_PIXEL)
+                    factor_pixel(w->kf_T_f_w + 12 * rq->kf_marg, w->cam_K + 4 * cam, w->cam_T_s_f + 12 * cam,
+                                 w->lmk_p + 3 * l, w->obs_meas + 2 * o, sigma, z, z, r, Jp, Jl);
+                else
+                    factor_angular(w->kf_T_f_w + 12 * rq->kf_marg, w->cam_T_s_f + 12 * cam, w->lmk_p + 3 * l,
+                                   w->obs_meas + 3 * o, sigma, z, z, r, Jp, Jl);
+                int col[9];
+                for (int q = 0; q < 2; q++) {
+                    for (int a = 0; a < 6; a++) J[q * 9 + a] = Jp[q * 6 + a];
+                    for (int a = 0; a < 3; a++) J[q * 9 + 6 + a] = Jl[q * 3 + a];
+                }
+                for (int a = 0; a < 6; a++) col[a] = a;
+                for (int a = 0; a < 3; a++) col[6 + a] = lcol[l] + a;
+                accumulate(A, b, N, J, r, 2, 9, col);
+            }
+        }
+    }
+
+    /* previous prior, …Analytic.cpp:574-603: evaluated at zero deltas => r = r0, J = column slices */
+    if (rq->last_n_full > 0) {
+        int nl = rq->last_n, nf = rq->last_n_full;
+        int *col = (int *)malloc(sizeof(int) * (size_t)nl);
+        for (int a = 0; a < nl; a++) col[a] = -1;
+        if (rq->last_kf >= 0) {
+            int base = (rq->last_kf == rq->kf_marg) ? 0 : ((rq->last_kf == rq->kf_keep) ? kf_keep_col : -1);
+            int width = (rq->last_kf == rq->kf_marg) ? (rq->marg_has_imu ? 15 : 6) : 15;
+            if (base >= 0)
+                for (int a = 0; a < width; a++) col[rq->last_kf_col + a] = base + a;
+        }
+        for (int k = 0; k < rq->last_n_keep; k++) {
+            if (rq->last_lmk_col[k] < 0) continue;
+            int lc = lcol[rq->last_lmk_index[k]];
+            if (lc < 0) continue;
+            for (int a = 0; a < 3; a++) col[rq->last_lmk_col[k] + a] = lc + a;
+        }
+        accumulate(A, b, N, rq->last_J, rq->last_r0, nf, nl, col);
+        free(col);
+    }
+
+    /* PosePriordx blocks, …Analytic.cpp:605-617 (+ frame1's in the Angular variant, …Angular….cpp:682-693) */
+    for (int k = 0; k < rq->n_prior; k++) {
+        const sadvio_pose_prior *pr = rq->priors + k;
+        int base = pr->kf == rq->kf_marg ? 0 : (pr->kf == rq->kf_keep ? kf_keep_col : -1);
+        if (base < 0) continue;
+        double r[6], J[36];
+        int col[6];
+        factor_pose_prior(w->kf_T_f_w + 12 * pr->kf, pr->T_prior, pr->inf_diag, z, r, J);
+        for (int a = 0; a < 6; a++) col[a] = base + a;
+        accumulate(A, b, N, J, r, 6, 6, col);
+    }
+    if (A_full) memcpy(A_full, A, sizeof(double) * (size_t)N * N);
+    if (b_full) memcpy(b_full, b, sizeof(double) * (size_t)N);
+
+    /* Schur complement with eigen pseudo-inverse, :234-248 */
+    double *Amm = (double *)malloc(sizeof(double) * (size_t)m * m);
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < m; j++) Amm[(size_t)i * m + j] = 0.5 * (A[(size_t)i * N + j] + A[(size_t)j * N + i]);
+    double *ev = (double *)malloc(sizeof(double) * (size_t)m), *V = (double *)malloc(sizeof(double) * (size_t)m * m);
+    oracle_sym_eig(Amm, m, ev, V);
+    double *Ainv = (double *)calloc((size_t)m * m, sizeof(double));
+    for (int k = 0; k < m; k++) {
+        if (!(ev[k] > MARG_EPS)) continue;
+        double iv = 1.0 / ev[k];
+        for (int i = 0; i < m; i++)
+            for (int j = 0; j < m; j++) Ainv[(size_t)i * m + j] += V[(size_t)i * m + k] * iv * V[(size_t)j * m + k];
+    }
+    /* T = Arm * Ainv (n x m) */
+    double *T = (double *)calloc((size_t)n * m, sizeof(double));
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < m; k++) {
+            double a = A[(size_t)(m + i) * N + k];
+            if (a == 0.0) continue;
+            for (int j = 0; j < m; j++) T[(size_t)i * m + j] += a * Ainv[(size_t)k * m + j];
+        }
+    double *Ak = (double *)malloc(sizeof(double) * (size_t)n * n), *bk = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        double s = b[m + i];
+        for (int k = 0; k < m; k++) s -= T[(size_t)i * m + k] * b[k];
+        bk[i] = s;
+        for (int j = 0; j < n; j++) {
+            double h = A[(size_t)(m + i) * N + m + j];
+            for (int k = 0; k < m; k++) h -= T[(size_t)i * m + k] * A[(size_t)(m + j) * N + k]; /* Arm^T */
+            Ak[(size_t)i * n + j] = h;
+        }
+    }
+    if (Ak_out) memcpy(Ak_out, Ak, sizeof(double) * (size_t)n * n);
+    if (bk_out) memcpy(bk_out, bk, sizeof(double) * (size_t)n);
+
+    /* rank revealing decomposition, :318-342. Eigen reads the lower triangle of Ak. */
+    double *Aks = (double *)malloc(sizeof(double) * (size_t)n * n);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j <= i; j++) Aks[(size_t)i * n + j] = Aks[(size_t)j * n + i] = Ak[(size_t)i * n + j];
+    double *ev2 = (double *)malloc(sizeof(double) * (size_t)n), *V2 = (double *)malloc(sizeof(double) * (size_t)n * n);
+    oracle_sym_eig(Aks, n, ev2, V2);
+    int nf = 0;
+    for (int k = 0; k < n; k++)
+        if (ev2[k] > MARG_EPS) nf++;
+    if (res) res->n_full = nf;
+    int c = 0;
+    for (int k = 0; k < n; k++) {
+        if (!(ev2[k] > MARG_EPS)) continue;
+        double lam = ev2[k];
+        if (Lambda_out) Lambda_out[c] = lam;
+        double dot = 0;
+        for (int i = 0; i < n; i++) {
+            if (U_out) U_out[(size_t)i * nf + c] = V2[(size_t)i * n + k];
+            dot += V2[(size_t)i * n + k] * bk[i];
+            if (J_out) J_out[(size_t)c * n + i] = sqrt(lam) * V2[(size_t)i * n + k]; /* :525 */
+        }
+        if (r0_out) r0_out[c] = -sqrt(1.0 / lam) * dot;                             /* :526-527 */
+        c++;
+    }
+    free(A); free(b); free(lcol); free(Amm); free(ev); free(V); free(Ainv); free(T); free(Ak); free(bk);
+    free(Aks); free(ev2); free(V2);
+    return SADVIO_OK;
+}

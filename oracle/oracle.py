@@ -1,0 +1,241 @@
+"""ctypes wrapper of the CPU oracle — TEST INFRASTRUCTURE ONLY.
+
+Imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg (as the checker /
+reported baseline, never as the thing shipped). The product path (sadvio_amd/) never imports this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from sadvio_amd.capi import (FlatWindow, FlatWindowC, ImuFactorC, PosePriorC, SolveOptions, SolveSummary,
+                             fill_imu_factor, reference_options)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "_build", "libsadvio_oracle.so")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class OracleProblem(C.Structure):
+    _fields_ = [("win", C.POINTER(FlatWindowC)), ("n_prior", C.c_int32), ("priors", C.POINTER(PosePriorC)),
+                ("n_imu", C.c_int32), ("imus", C.POINTER(ImuFactorC)),
+                ("dp_n_full", C.c_int32), ("dp_n", C.c_int32), ("dp_J", _dp), ("dp_r0", _dp),
+                ("dp_kf_keep", C.c_int32), ("dp_kf_col", C.c_int32), ("dp_n_keep", C.c_int32),
+                ("dp_lmk_index", _ip), ("dp_lmk_col", _ip), ("n_threads", C.c_int32)]
+
+
+class ImuState(C.Structure):
+    _fields_ = [("acc", C.c_double * 3), ("gyr", C.c_double * 3), ("ba", C.c_double * 3), ("bg", C.c_double * 3),
+                ("v", C.c_double * 3), ("T_f_w", C.c_double * 12), ("delta_R", C.c_double * 9),
+                ("delta_v", C.c_double * 3), ("delta_p", C.c_double * 3), ("cov", C.c_double * 81),
+                ("J_dR_bg", C.c_double * 9), ("J_dv_ba", C.c_double * 9), ("J_dv_bg", C.c_double * 9),
+                ("J_dp_ba", C.c_double * 9), ("J_dp_bg", C.c_double * 9), ("ts_ns", C.c_double),
+                ("is_keyframe", C.c_int32), ("pad", C.c_int32)]
+
+
+class MargRequest(C.Structure):
+    _fields_ = [("win", C.POINTER(FlatWindowC)), ("kf_marg", C.c_int32), ("kf_keep", C.c_int32),
+                ("marg_has_imu", C.c_int32), ("n_marg", C.c_int32), ("lmk_marg", _ip), ("n_keep", C.c_int32),
+                ("lmk_keep", _ip), ("imu", C.POINTER(ImuFactorC)), ("n_prior", C.c_int32),
+                ("priors", C.POINTER(PosePriorC)), ("last_n_full", C.c_int32), ("last_n", C.c_int32),
+                ("last_J", _dp), ("last_r0", _dp), ("last_kf", C.c_int32), ("last_kf_col", C.c_int32),
+                ("last_n_keep", C.c_int32), ("last_lmk_index", _ip), ("last_lmk_col", _ip)]
+
+
+class MargResult(C.Structure):
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("n_full", C.c_int32), ("kf_col", C.c_int32)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = C.CDLL(LIB)
+        _lib.oracle_solve.argtypes = [C.POINTER(OracleProblem), C.POINTER(SolveOptions), C.POINTER(SolveSummary),
+                                      _dp, _dp, _dp, _dp, _dp, _dp, C.c_int32]
+        _lib.oracle_linearize.argtypes = [C.POINTER(FlatWindowC), _dp, _dp, _dp, _dp, _dp, _ip]
+        _lib.oracle_first_step.argtypes = [C.POINTER(OracleProblem), C.POINTER(SolveOptions), _dp, _dp, _dp, _dp,
+                                           C.c_int32]
+        _lib.oracle_imu_process.argtypes = [C.POINTER(ImuState), C.POINTER(ImuState), _dp, _dp, C.c_double,
+                                            C.c_double, C.c_double]
+        _lib.oracle_imu_bias_correction.argtypes = [C.POINTER(ImuState), _dp, _dp]
+        _lib.oracle_factor_imu.argtypes = [C.POINTER(ImuFactorC), _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        _lib.oracle_factor_imu_bias.argtypes = [C.POINTER(ImuFactorC), _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        _lib.oracle_marginalize.argtypes = [C.POINTER(MargRequest), C.POINTER(MargResult), _ip, _dp, _dp, _dp, _dp,
+                                            _dp, _dp, _dp, _dp]
+        _lib.oracle_sym_eig.argtypes = [_dp, C.c_int32, _dp, _dp]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else _dp()
+
+
+def _arr(x, n=None):
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float64).ravel())
+    assert n is None or a.size == n, (a.size, n)
+    return a
+
+
+def make_problem(w: FlatWindow, dense_prior=None, n_threads=1):
+    wc = w.to_c()
+    pa, npri = w.priors_c()
+    ia, nimu = w.imus_c()
+    P = OracleProblem()
+    P.win = C.pointer(wc)
+    P.n_prior, P.priors = npri, pa
+    P.n_imu, P.imus = nimu, ia
+    P.n_threads = n_threads
+    keep = [wc, pa, ia]
+    if dense_prior is not None:
+        J = np.ascontiguousarray(dense_prior["J"], dtype=np.float64)
+        r0 = np.ascontiguousarray(dense_prior["r0"], dtype=np.float64)
+        li = np.ascontiguousarray(dense_prior["lmk_index"], dtype=np.int32)
+        lc = np.ascontiguousarray(dense_prior["lmk_col"], dtype=np.int32)
+        P.dp_n_full, P.dp_n = J.shape
+        P.dp_J, P.dp_r0 = _p(J), _p(r0)
+        P.dp_kf_keep, P.dp_kf_col = int(dense_prior.get("kf_keep", -1)), int(dense_prior.get("kf_col", 0))
+        P.dp_n_keep = len(li)
+        P.dp_lmk_index, P.dp_lmk_col = li.ctypes.data_as(_ip), lc.ctypes.data_as(_ip)
+        keep += [J, r0, li, lc]
+    return P, keep
+
+
+def solve(w: FlatWindow, opts: SolveOptions = None, dense_prior=None, n_threads=1, log_cap=64):
+    opts = opts or reference_options()
+    P, keep = make_problem(w, dense_prior, n_threads)
+    pose = np.zeros((w.n_kf, 6)); lmk = np.zeros((w.n_lmk, 3))
+    dv = np.zeros((w.n_kf, 3)); dba = np.zeros((w.n_kf, 3)); dbg = np.zeros((w.n_kf, 3))
+    log = np.zeros((log_cap, 8))
+    s = SolveSummary()
+    rc = lib().oracle_solve(C.byref(P), C.byref(opts), C.byref(s), _p(pose), _p(lmk), _p(dv), _p(dba), _p(dbg),
+                            _p(log), log_cap)
+    return {"rc": rc, "summary": s, "pose": pose, "lmk": lmk, "dv": dv, "dba": dba, "dbg": dbg,
+            "log": log[: s.iterations + 1]}
+
+
+def linearize(w: FlatWindow, pose_delta=None, lmk_delta=None):
+    wc = w.to_c()
+    r = np.zeros((w.n_obs, 2)); Jp = np.zeros((w.n_obs, 2, 6)); Jl = np.zeros((w.n_obs, 2, 3))
+    valid = np.zeros(w.n_obs, dtype=np.int32)
+    pd = None if pose_delta is None else _arr(pose_delta, 6 * w.n_kf)
+    ld = None if lmk_delta is None else _arr(lmk_delta, 3 * w.n_lmk)
+    lib().oracle_linearize(C.byref(wc), _p(pd), _p(ld), _p(r), _p(Jp), _p(Jl), valid.ctypes.data_as(_ip))
+    return r, Jp, Jl, valid
+
+
+def first_step(w: FlatWindow, opts: SolveOptions = None):
+    """(delta_pose, delta_lmk, H_full, g_full) of the first LM step at zero deltas."""
+    opts = opts or reference_options()
+    P, keep = make_problem(w)
+    dp = np.zeros((w.n_kf, 6)); dl = np.zeros((w.n_lmk, 3))
+    N = lib().oracle_first_step(C.byref(P), C.byref(opts), _dp(), _dp(), _p(np.zeros(1)), _p(np.zeros(1)), -1)
+    H = np.zeros((N, N)); g = np.zeros(N)
+    rc = lib().oracle_first_step(C.byref(P), C.byref(opts), _p(dp), _p(dl), _p(H), _p(g), N)
+    assert rc == 0, rc
+    return dp, dl, H, g
+
+
+# ---- factor probes ----
+def factor_pixel(T0, K, Tsf, p0, uv, sigma, dpose, dl):
+    r = np.zeros(2); Jp = np.zeros((2, 6)); Jl = np.zeros((2, 3)); v = C.c_int32(0)
+    f = lib().oracle_factor_pixel
+    f.argtypes = [_dp] * 5 + [C.c_double] + [_dp] * 5 + [C.POINTER(C.c_int32)]
+    f(_p(_arr(T0, 12)), _p(_arr(K, 4)), _p(_arr(Tsf, 12)), _p(_arr(p0, 3)), _p(_arr(uv, 2)), float(sigma),
+      _p(_arr(dpose, 6)), _p(_arr(dl, 3)), _p(r), _p(Jp), _p(Jl), C.byref(v))
+    return r, Jp, Jl, v.value
+
+
+def factor_angular(T0, Tsf, p0, b, sigma, dpose, dl):
+    r = np.zeros(2); Jp = np.zeros((2, 6)); Jl = np.zeros((2, 3))
+    f = lib().oracle_factor_angular
+    f.argtypes = [_dp] * 4 + [C.c_double] + [_dp] * 5
+    f(_p(_arr(T0, 12)), _p(_arr(Tsf, 12)), _p(_arr(p0, 3)), _p(_arr(b, 3)), float(sigma), _p(_arr(dpose, 6)),
+      _p(_arr(dl, 3)), _p(r), _p(Jp), _p(Jl))
+    return r, Jp, Jl
+
+
+def factor_pose_prior(T0, Tprior, inf_diag, dpose):
+    r = np.zeros(6); J = np.zeros((6, 6))
+    f = lib().oracle_factor_pose_prior
+    f.argtypes = [_dp] * 6
+    f(_p(_arr(T0, 12)), _p(_arr(Tprior, 12)), _p(_arr(inf_diag, 6)), _p(_arr(dpose, 6)), _p(r), _p(J))
+    return r, J
+
+
+def factor_imu(fdict, Ti0, Tj0, vi0, vj0, params24):
+    fc = ImuFactorC()
+    fill_imu_factor(fc, fdict)
+    r = np.zeros(9); J = np.zeros((9, 24))
+    rc = lib().oracle_factor_imu(C.byref(fc), _p(_arr(Ti0, 12)), _p(_arr(Tj0, 12)), _p(_arr(vi0, 3)),
+                                 _p(_arr(vj0, 3)), _p(_arr(params24, 24)), _p(r), _p(J))
+    assert rc == 0, rc
+    return r, J
+
+
+def factor_imu_bias(fdict, bai, bgi, baj, bgj, params12):
+    fc = ImuFactorC()
+    fill_imu_factor(fc, fdict)
+    r = np.zeros(6); J = np.zeros((6, 12))
+    lib().oracle_factor_imu_bias(C.byref(fc), _p(_arr(bai, 3)), _p(_arr(bgi, 3)), _p(_arr(baj, 3)), _p(_arr(bgj, 3)),
+                                 _p(_arr(params12, 12)), _p(r), _p(J))
+    return r, J
+
+
+def so3_exp(w):
+    R = np.zeros((3, 3)); f = lib().oracle_so3_exp; f.argtypes = [_dp, _dp]; f(_p(_arr(w, 3)), _p(R)); return R
+
+
+def so3_log(R):
+    w = np.zeros(3); f = lib().oracle_so3_log; f.argtypes = [_dp, _dp]; f(_p(_arr(R, 9)), _p(w)); return w
+
+
+def so3_right_jacobian(w):
+    J = np.zeros((3, 3)); f = lib().oracle_so3_right_jacobian; f.argtypes = [_dp, _dp]; f(_p(_arr(w, 3)), _p(J))
+    return J
+
+
+# ---- IMU pre-integration helpers ----
+def new_imu_state(acc, gyr, ts_ns, T_f_w=None, keyframe=False, ba=(0, 0, 0), bg=(0, 0, 0), v=(0, 0, 0)) -> ImuState:
+    s = ImuState()
+    s.acc[:] = list(acc); s.gyr[:] = list(gyr)
+    s.ba[:] = list(ba); s.bg[:] = list(bg); s.v[:] = list(v)
+    T = np.concatenate([np.eye(3).ravel(), np.zeros(3)]) if T_f_w is None else np.asarray(T_f_w, dtype=np.float64)
+    s.T_f_w[:] = list(T)
+    s.delta_R[:] = list(np.eye(3).ravel())  # IMU.h:36 (config constructor)
+    s.ts_ns = float(ts_ns)
+    s.is_keyframe = int(keyframe)
+    return s
+
+
+def imu_process(cur: ImuState, last: ImuState, kf: ImuState, gyr_noise, acc_noise, rate_hz) -> bool:
+    kb = _arr(list(kf.ba)); kg = _arr(list(kf.bg))
+    return bool(lib().oracle_imu_process(C.byref(cur), C.byref(last), _p(kb), _p(kg), gyr_noise, acc_noise, rate_hz))
+
+
+def imu_factor_dict(kf_i, kf_j, last: ImuState, dt, bacc_noise, bgyr_noise) -> dict:
+    g = lambda name: np.array(list(getattr(last, name)))
+    return {"kf_i": kf_i, "kf_j": kf_j, "dt": dt, "delta_R": g("delta_R"), "delta_v": g("delta_v"),
+            "delta_p": g("delta_p"), "J_dR_bg": g("J_dR_bg"), "J_dv_ba": g("J_dv_ba"), "J_dv_bg": g("J_dv_bg"),
+            "J_dp_ba": g("J_dp_ba"), "J_dp_bg": g("J_dp_bg"), "cov": g("cov"), "bacc_noise": bacc_noise,
+            "bgyr_noise": bgyr_noise}
+
+
+def sym_eig(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = A.shape[0]
+    ev = np.zeros(n); V = np.zeros((n, n))
+    lib().oracle_sym_eig(_p(A), n, _p(ev), _p(V))
+    return ev, V

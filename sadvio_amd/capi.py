@@ -1,0 +1,317 @@
+"""ctypes binding of the C ABI declared in include/sadvio_ba.h.
+
+This module is harness plumbing (tests, bench, smoke): the product is `libsadvio_ba.so`, whose
+entry points are what a SaDVIO `isae::AOptimizer` adapter binds. There is no CPU
+fallback: loading fails loudly when the HIP library has not been built, and every compute call
+returns SADVIO_E_NO_DEVICE / SADVIO_E_HIP when no gfx950 device is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsadvio_ba.so")
+
+SADVIO_OK = 0
+E_INVALID_ARG, E_NOT_USABLE, E_HIP, E_RCCL, E_NO_DEVICE, E_STATE, E_REFUSED = -1, -2, -3, -4, -5, -6, -7
+FACTOR_PIXEL, FACTOR_ANGULAR = 0, 1
+TERM_NAMES = {0: "NO_CONVERGENCE", 1: "FUNCTION_TOL", 2: "PARAMETER_TOL", 3: "GRADIENT_TOL", 4: "MIN_RADIUS",
+              5: "FAILURE"}
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+_bp = C.POINTER(C.c_uint8)
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("profile_kernels", C.c_int32), ("use_graph", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class FlatWindowC(C.Structure):
+    _fields_ = [
+        ("n_kf", C.c_int32), ("n_cam", C.c_int32), ("n_lmk", C.c_int32), ("n_obs", C.c_int32),
+        ("factor_type", C.c_int32), ("has_imu", C.c_int32),
+        ("kf_id", _lp), ("kf_T_f_w", _dp), ("kf_const", _bp), ("kf_vel", _dp), ("kf_ba", _dp), ("kf_bg", _dp),
+        ("cam_K", _dp), ("cam_T_s_f", _dp), ("cam_sigma", _dp),
+        ("lmk_id", _lp), ("lmk_p", _dp), ("lmk_const", _bp), ("lmk_obs_ptr", _ip),
+        ("obs_kf", _ip), ("obs_cam", _ip), ("obs_meas", _dp),
+    ]
+
+
+class ImuFactorC(C.Structure):
+    _fields_ = [
+        ("kf_i", C.c_int32), ("kf_j", C.c_int32), ("dt", C.c_double),
+        ("delta_R", C.c_double * 9), ("delta_v", C.c_double * 3), ("delta_p", C.c_double * 3),
+        ("J_dR_bg", C.c_double * 9), ("J_dv_ba", C.c_double * 9), ("J_dv_bg", C.c_double * 9),
+        ("J_dp_ba", C.c_double * 9), ("J_dp_bg", C.c_double * 9), ("cov", C.c_double * 81),
+        ("bacc_noise", C.c_double), ("bgyr_noise", C.c_double),
+    ]
+
+
+class PosePriorC(C.Structure):
+    _fields_ = [("kf", C.c_int32), ("pad", C.c_int32), ("T_prior", C.c_double * 12), ("inf_diag", C.c_double * 6)]
+
+
+class SolveOptions(C.Structure):
+    _fields_ = [
+        ("max_num_iterations", C.c_int32), ("jacobi_scaling", C.c_int32),
+        ("max_num_consecutive_invalid_steps", C.c_int32), ("reserved", C.c_int32),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double), ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
+        ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double), ("min_relative_decrease", C.c_double),
+    ]
+
+
+class SolveSummary(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32), ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
+        ("termination", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("fixed_cost", C.c_double), ("final_radius", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def reference_options() -> SolveOptions:
+    """The reference's hard-coded options (AOptimizer.cpp:315-323) + Ceres 2.2.0 defaults."""
+    o = SolveOptions()
+    o.max_num_iterations = 20
+    o.jacobi_scaling = 1
+    o.max_num_consecutive_invalid_steps = 5
+    o.function_tolerance = 1e-3
+    o.gradient_tolerance = 1e-10
+    o.parameter_tolerance = 1e-8
+    o.initial_trust_region_radius = 1e4
+    o.max_trust_region_radius = 1e16
+    o.min_trust_region_radius = 1e-32
+    o.min_lm_diagonal = 1e-6
+    o.max_lm_diagonal = 1e32
+    o.min_relative_decrease = 1e-3
+    return o
+
+
+def gn_options(iters: int = 10) -> SolveOptions:
+    """BASELINE.json config 2 wording, "GN 10 iters": a fixed number of step attempts with every
+    early-exit test disabled (trust-region schedule unchanged; at radius 1e4 the damping is ~1e-4
+    relative, i.e. Gauss-Newton steps)."""
+    o = reference_options()
+    o.max_num_iterations = iters
+    o.function_tolerance = 0.0
+    o.gradient_tolerance = 0.0
+    o.parameter_tolerance = 0.0
+    return o
+
+
+def _c(a: Optional[np.ndarray], dtype, ptr):
+    if a is None:
+        return None, ptr()
+    arr = np.ascontiguousarray(a, dtype=dtype)
+    return arr, arr.ctypes.data_as(ptr)
+
+
+@dataclass
+class FlatWindow:
+    """Numpy-side holder of one flattened window (see sadvio_flat_window in include/sadvio_ba.h)."""
+    kf_T_f_w: np.ndarray           # [n_kf,12]
+    kf_const: np.ndarray           # [n_kf] uint8
+    cam_K: np.ndarray              # [n_cam,4]
+    cam_T_s_f: np.ndarray          # [n_cam,12]
+    cam_sigma: np.ndarray          # [n_cam]
+    lmk_p: np.ndarray              # [n_lmk,3]
+    lmk_obs_ptr: np.ndarray        # [n_lmk+1] int32
+    obs_kf: np.ndarray             # [n_obs] int32
+    obs_cam: np.ndarray            # [n_obs] int32
+    obs_meas: np.ndarray           # [n_obs,2|3]
+    factor_type: int = FACTOR_PIXEL
+    has_imu: int = 0
+    kf_id: Optional[np.ndarray] = None
+    lmk_id: Optional[np.ndarray] = None
+    lmk_const: Optional[np.ndarray] = None
+    kf_vel: Optional[np.ndarray] = None
+    kf_ba: Optional[np.ndarray] = None
+    kf_bg: Optional[np.ndarray] = None
+    pose_priors: List[tuple] = field(default_factory=list)   # (kf, T_prior[12], inf_diag[6])
+    imu_factors: List[dict] = field(default_factory=list)    # dicts with the ImuFactorC fields
+    truth: dict = field(default_factory=dict)                # generator ground truth (not uploaded)
+    _keep: list = field(default_factory=list, repr=False)
+
+    @property
+    def n_kf(self): return int(self.kf_T_f_w.shape[0])
+    @property
+    def n_cam(self): return int(self.cam_K.shape[0])
+    @property
+    def n_lmk(self): return int(self.lmk_p.shape[0])
+    @property
+    def n_obs(self): return int(self.obs_kf.shape[0])
+
+    def to_c(self) -> FlatWindowC:
+        if self.kf_id is None:
+            self.kf_id = np.arange(self.n_kf, dtype=np.int64)
+        if self.lmk_id is None:
+            self.lmk_id = np.arange(self.n_lmk, dtype=np.int64)
+        w = FlatWindowC()
+        w.n_kf, w.n_cam, w.n_lmk, w.n_obs = self.n_kf, self.n_cam, self.n_lmk, self.n_obs
+        w.factor_type, w.has_imu = int(self.factor_type), int(self.has_imu)
+        keep = []
+        for name, dt, ptr in [("kf_id", np.int64, _lp), ("kf_T_f_w", np.float64, _dp), ("kf_const", np.uint8, _bp),
+                              ("kf_vel", np.float64, _dp), ("kf_ba", np.float64, _dp), ("kf_bg", np.float64, _dp),
+                              ("cam_K", np.float64, _dp), ("cam_T_s_f", np.float64, _dp),
+                              ("cam_sigma", np.float64, _dp), ("lmk_id", np.int64, _lp), ("lmk_p", np.float64, _dp),
+                              ("lmk_const", np.uint8, _bp), ("lmk_obs_ptr", np.int32, _ip),
+                              ("obs_kf", np.int32, _ip), ("obs_cam", np.int32, _ip), ("obs_meas", np.float64, _dp)]:
+            arr, p = _c(getattr(self, name), dt, ptr)
+            keep.append(arr)
+            setattr(w, name, p)
+        self._keep = keep  # keep the contiguous copies alive as long as this object lives
+        return w
+
+    def priors_c(self):
+        arr = (PosePriorC * max(1, len(self.pose_priors)))()
+        for i, (kf, T, inf) in enumerate(self.pose_priors):
+            arr[i].kf = int(kf)
+            arr[i].T_prior[:] = list(np.asarray(T, dtype=np.float64).ravel())
+            arr[i].inf_diag[:] = list(np.asarray(inf, dtype=np.float64).ravel())
+        return arr, len(self.pose_priors)
+
+    def imus_c(self):
+        arr = (ImuFactorC * max(1, len(self.imu_factors)))()
+        for i, f in enumerate(self.imu_factors):
+            fill_imu_factor(arr[i], f)
+        return arr, len(self.imu_factors)
+
+
+def fill_imu_factor(dst: ImuFactorC, f: dict) -> None:
+    dst.kf_i, dst.kf_j, dst.dt = int(f["kf_i"]), int(f["kf_j"]), float(f["dt"])
+    for k in ("delta_R", "delta_v", "delta_p", "J_dR_bg", "J_dv_ba", "J_dv_bg", "J_dp_ba", "J_dp_bg", "cov"):
+        getattr(dst, k)[:] = list(np.asarray(f[k], dtype=np.float64).ravel())
+    dst.bacc_noise, dst.bgyr_noise = float(f["bacc_noise"]), float(f["bgyr_noise"])
+
+
+class SadvioError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """Load libsadvio_ba.so. Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise SadvioError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.sadvio_ba_device_count.restype = C.c_int
+    lib.sadvio_ba_default_options.argtypes = [C.POINTER(SolveOptions)]
+    lib.sadvio_ba_default_options.restype = None
+    lib.sadvio_ba_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    lib.sadvio_ba_destroy.argtypes = [C.c_void_p]
+    lib.sadvio_ba_destroy.restype = None
+    lib.sadvio_ba_set_windows.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FlatWindowC)]
+    lib.sadvio_ba_set_pose_priors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(PosePriorC)]
+    lib.sadvio_ba_set_imu_factors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ImuFactorC)]
+    lib.sadvio_ba_set_dense_prior.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.c_int32,
+                                              C.c_int32, C.c_int32, _ip, _ip]
+    lib.sadvio_ba_solve.argtypes = [C.c_void_p, C.POINTER(SolveOptions), C.POINTER(SolveSummary)]
+    lib.sadvio_ba_get_deltas.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
+    lib.sadvio_ba_get_ids.argtypes = [C.c_void_p, C.c_int32, _lp, _lp]
+    lib.sadvio_ba_linearize.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
+    lib.sadvio_ba_get_kernel_times.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), _dp, _lp]
+    lib.sadvio_ba_last_error.argtypes = [C.c_void_p]
+    lib.sadvio_ba_last_error.restype = C.c_char_p
+    lib.sadvio_ba_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return a.ctypes.data_as(_dp) if a is not None else _dp()
+
+
+class Backend:
+    """Thin OO wrapper of one `sadvio_ba_handle` (one HIP stream, device-resident windows)."""
+
+    def __init__(self, device: int = 0, profile_kernels: bool = False, use_graph: bool = False):
+        self.lib = load_library()
+        cfg = Config(device=device, profile_kernels=int(profile_kernels), use_graph=int(use_graph), reserved=0)
+        self.h = C.c_void_p()
+        rc = self.lib.sadvio_ba_create(C.byref(cfg), C.byref(self.h))
+        if rc != SADVIO_OK:
+            raise SadvioError(f"sadvio_ba_create failed: rc={rc} (no gfx950 device? there is no CPU fallback)")
+        self.windows: List[FlatWindow] = []
+
+    def _check(self, rc: int, what: str):
+        if rc != SADVIO_OK:
+            msg = self.lib.sadvio_ba_last_error(self.h)
+            raise SadvioError(f"{what} failed: rc={rc}: {msg.decode() if msg else ''}")
+
+    def set_windows(self, windows: Sequence[FlatWindow]):
+        self.windows = list(windows)
+        arr = (FlatWindowC * len(windows))()
+        for i, w in enumerate(windows):
+            arr[i] = w.to_c()
+        self._check(self.lib.sadvio_ba_set_windows(self.h, len(windows), arr), "set_windows")
+        for i, w in enumerate(windows):
+            if w.pose_priors:
+                pa, n = w.priors_c()
+                self._check(self.lib.sadvio_ba_set_pose_priors(self.h, i, n, pa), "set_pose_priors")
+            if w.imu_factors:
+                ia, n = w.imus_c()
+                self._check(self.lib.sadvio_ba_set_imu_factors(self.h, i, n, ia), "set_imu_factors")
+
+    def solve(self, opts: Optional[SolveOptions] = None) -> List[SolveSummary]:
+        opts = opts or reference_options()
+        sums = (SolveSummary * len(self.windows))()
+        self._check(self.lib.sadvio_ba_solve(self.h, C.byref(opts), sums), "solve")
+        return list(sums)
+
+    def get_deltas(self, w: int = 0):
+        win = self.windows[w]
+        pose = np.zeros((win.n_kf, 6)); lmk = np.zeros((win.n_lmk, 3))
+        dv = np.zeros((win.n_kf, 3)); dba = np.zeros((win.n_kf, 3)); dbg = np.zeros((win.n_kf, 3))
+        self._check(self.lib.sadvio_ba_get_deltas(self.h, w, _ptr(pose), _ptr(lmk), _ptr(dv), _ptr(dba), _ptr(dbg)),
+                    "get_deltas")
+        return {"pose": pose, "lmk": lmk, "dv": dv, "dba": dba, "dbg": dbg}
+
+    def get_ids(self, w: int = 0):
+        win = self.windows[w]
+        kf = np.zeros(win.n_kf, dtype=np.int64); lm = np.zeros(win.n_lmk, dtype=np.int64)
+        self._check(self.lib.sadvio_ba_get_ids(self.h, w, kf.ctypes.data_as(_lp), lm.ctypes.data_as(_lp)), "get_ids")
+        return kf, lm
+
+    def linearize(self, w: int = 0, pose_delta=None, lmk_delta=None):
+        win = self.windows[w]
+        r = np.zeros((win.n_obs, 2)); Jp = np.zeros((win.n_obs, 2, 6)); Jl = np.zeros((win.n_obs, 2, 3))
+        pd = None if pose_delta is None else np.ascontiguousarray(pose_delta, dtype=np.float64)
+        ld = None if lmk_delta is None else np.ascontiguousarray(lmk_delta, dtype=np.float64)
+        self._check(self.lib.sadvio_ba_linearize(self.h, w, _ptr(pd), _ptr(ld), _ptr(r), _ptr(Jp), _ptr(Jl)),
+                    "linearize")
+        return r, Jp, Jl
+
+    def kernel_times(self):
+        cap = 32
+        names = (C.c_char_p * cap)(); us = np.zeros(cap); n = np.zeros(cap, dtype=np.int64)
+        k = self.lib.sadvio_ba_get_kernel_times(self.h, cap, names, _ptr(us), n.ctypes.data_as(_lp))
+        return {names[i].decode(): {"avg_us": float(us[i]), "launches": int(n[i])} for i in range(max(k, 0))}
+
+    def close(self):
+        if self.h:
+            self.lib.sadvio_ba_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

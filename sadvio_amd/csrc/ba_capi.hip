@@ -1,0 +1,593 @@
+// ba_capi.hip — host driver + C ABI (include/sadvio_ba.h) of the MI355X BA backend.
+//
+// Replaces, behind the reference's optimizer boundary, the body of AOptimizer::localMapBA /
+// localMapVIOptimization from `ceres::Solve` on (AOptimizer.cpp:326,388): the windows are uploaded
+// once (set_windows), the whole LM solve is enqueued on the handle's stream without host round
+// trips, and deltas are read back for the adapter to apply (AOptimizer.cpp:329-340).
+// There is no CPU fallback: without a gfx950 device every compute call fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sadvio_ba.h"
+#include "kernels.h"
+
+using namespace sadvio;
+
+namespace {
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            h->err = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+            return SADVIO_E_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct KernelClass {
+    const char* name;
+    double total_ms = 0;
+    long long launches = 0;
+};
+
+struct HostWin {
+    WinDev d;
+    std::vector<int64_t> kf_id, lmk_id;
+};
+
+}  // namespace
+
+struct sadvio_ba_handle {
+    sadvio_ba_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // host mirrors
+    std::vector<HostWin> wins;
+    std::vector<Tile> tiles;
+    std::vector<PriorDev> priors;
+    std::vector<std::vector<PriorDev>> priors_per_win;
+    int n_kf_tot = 0, n_cam_tot = 0, n_lmk_tot = 0, n_obs_tot = 0, np_tot = 0;
+    long long s_tot = 0;
+    int factor_type = 0;
+    int max_n_kf = 0, max_npose = 0, max_np = 0;
+    bool lds_tile = true;
+    bool uploaded = false, solved = false;
+    int slots_cap = 0;
+    int last_slots = 0;
+    // device buffers
+    DevBuf<WinDev> d_win;
+    DevBuf<Tile> d_tiles;
+    DevBuf<double> d_kf_T0, d_xp, d_xv, d_xba, d_xbg, d_kf_vel, d_kf_ba, d_kf_bg;
+    DevBuf<int> d_kf_fidx;
+    DevBuf<double> d_cam_K, d_cam_T, d_cam_isig;
+    DevBuf<double> d_lmk_p, d_xl, d_s_lmk;
+    DevBuf<unsigned char> d_lmk_const;
+    DevBuf<int> d_lmk_ob, d_lmk_oe, d_obs_kf, d_obs_cam;
+    DevBuf<double> d_obs_meas;
+    DevBuf<PriorDev> d_priors;
+    DevBuf<double> d_S, d_gred, d_gfull, d_hdiag, d_delta, d_s_pose;
+    DevBuf<LmState> d_states;
+    DevBuf<IterAcc> d_acc;
+    DevBuf<double> d_probe;
+    bool has_lmk_const = false;
+    // profiling
+    std::vector<KernelClass> kclasses;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<std::pair<int, int>> ev_used;  // (class, pool index)
+    size_t ev_next = 0;
+};
+
+namespace {
+
+int kclass_id(sadvio_ba_handle* h, const char* name) {
+    for (size_t i = 0; i < h->kclasses.size(); i++)
+        if (!strcmp(h->kclasses[i].name, name)) return (int)i;
+    KernelClass k; k.name = name;
+    h->kclasses.push_back(k);
+    return (int)h->kclasses.size() - 1;
+}
+
+struct ScopedTimer {
+    sadvio_ba_handle* h;
+    int pool = -1;
+    ScopedTimer(sadvio_ba_handle* h_, const char* name) : h(h_) {
+        if (!h->cfg.profile_kernels) return;
+        if (h->ev_next == h->ev_pool.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            h->ev_pool.push_back({a, b});
+        }
+        pool = (int)h->ev_next++;
+        h->ev_used.push_back({kclass_id(h, name), pool});
+        (void)hipEventRecord(h->ev_pool[pool].first, h->stream);
+    }
+    ~ScopedTimer() {
+        if (pool >= 0) (void)hipEventRecord(h->ev_pool[pool].second, h->stream);
+    }
+};
+
+void collect_timers(sadvio_ba_handle* h) {
+    for (auto& u : h->ev_used) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->ev_pool[u.second].first, h->ev_pool[u.second].second) == hipSuccess) {
+            h->kclasses[u.first].total_ms += ms;
+            h->kclasses[u.first].launches += 1;
+        }
+    }
+    h->ev_used.clear();
+    h->ev_next = 0;
+}
+
+DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
+    DevPtrs P{};
+    P.win = h->d_win.p; P.tiles = h->d_tiles.p;
+    P.kf_T0 = h->d_kf_T0.p; P.kf_fidx = h->d_kf_fidx.p;
+    P.xp = h->d_xp.p; P.xv = h->d_xv.p; P.xba = h->d_xba.p; P.xbg = h->d_xbg.p;
+    P.xp_stride = 6LL * h->n_kf_tot; P.xv_stride = 3LL * h->n_kf_tot; P.xl_stride = 3LL * h->n_lmk_tot;
+    P.kf_vel = h->d_kf_vel.p; P.kf_ba = h->d_kf_ba.p; P.kf_bg = h->d_kf_bg.p;
+    P.cam_K = h->d_cam_K.p; P.cam_T = h->d_cam_T.p; P.cam_isig = h->d_cam_isig.p;
+    P.lmk_p = h->d_lmk_p.p; P.xl = h->d_xl.p; P.s_lmk = h->d_s_lmk.p;
+    P.lmk_const = h->has_lmk_const ? h->d_lmk_const.p : nullptr;
+    P.lmk_ob = h->d_lmk_ob.p; P.lmk_oe = h->d_lmk_oe.p;
+    P.obs_kf = h->d_obs_kf.p; P.obs_cam = h->d_obs_cam.p; P.obs_meas = h->d_obs_meas.p;
+    P.priors = h->d_priors.p;
+    P.S = h->d_S.p; P.gred = h->d_gred.p; P.gfull = h->d_gfull.p; P.hdiag = h->d_hdiag.p;
+    P.delta = h->d_delta.p; P.s_pose = h->d_s_pose.p;
+    P.states = h->d_states.p; P.acc = h->d_acc.p;
+    P.state_stride = state_stride;
+    P.n_win = (int)h->wins.size();
+    P.o = o;
+    return P;
+}
+
+int upload_priors(sadvio_ba_handle* h) {
+    h->priors.clear();
+    for (size_t w = 0; w < h->wins.size(); w++) {
+        h->wins[w].d.prior_begin = (int)h->priors.size();
+        for (auto& p : h->priors_per_win[w]) h->priors.push_back(p);
+        h->wins[w].d.prior_end = (int)h->priors.size();
+    }
+    HIP_TRY(h->d_priors.alloc(h->priors.size()));
+    if (!h->priors.empty())
+        HIP_TRY(hipMemcpyAsync(h->d_priors.p, h->priors.data(), h->priors.size() * sizeof(PriorDev), hipMemcpyHostToDevice, h->stream));
+    std::vector<WinDev> wd(h->wins.size());
+    for (size_t w = 0; w < h->wins.size(); w++) wd[w] = h->wins[w].d;
+    HIP_TRY(hipMemcpyAsync(h->d_win.p, wd.data(), wd.size() * sizeof(WinDev), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SADVIO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sadvio_ba_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strstr(p.gcnArchName, "gfx950")) ok++;
+    }
+    return ok;
+}
+
+void sadvio_ba_default_options(sadvio_solve_options* o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->max_num_iterations = 20;   // AOptimizer.cpp:319
+    o->function_tolerance = 1e-3; // AOptimizer.cpp:322
+    // everything the reference leaves unset: Ceres Solver 2.2.0 defaults
+    o->jacobi_scaling = 1;
+    o->max_num_consecutive_invalid_steps = 5;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->min_relative_decrease = 1e-3;
+}
+
+int sadvio_ba_create(const sadvio_ba_config* cfg, sadvio_ba_handle** out) {
+    if (!out) return SADVIO_E_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return SADVIO_E_NO_DEVICE;
+    int dev = cfg ? cfg->device : 0;
+    if (dev < 0 || dev >= n) return SADVIO_E_INVALID_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return SADVIO_E_HIP;
+    if (!strstr(prop.gcnArchName, "gfx950")) return SADVIO_E_NO_DEVICE;  // kernels are built for gfx950 only
+    if (hipSetDevice(dev) != hipSuccess) return SADVIO_E_HIP;
+    auto* h = new sadvio_ba_handle();
+    if (cfg) h->cfg = *cfg;
+    h->device = dev;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return SADVIO_E_HIP; }
+    *out = h;
+    return SADVIO_OK;
+}
+
+void sadvio_ba_destroy(sadvio_ba_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    h->d_win.release(); h->d_tiles.release(); h->d_kf_T0.release(); h->d_xp.release(); h->d_xv.release();
+    h->d_xba.release(); h->d_xbg.release(); h->d_kf_vel.release(); h->d_kf_ba.release(); h->d_kf_bg.release();
+    h->d_kf_fidx.release(); h->d_cam_K.release(); h->d_cam_T.release(); h->d_cam_isig.release();
+    h->d_lmk_p.release(); h->d_xl.release(); h->d_s_lmk.release(); h->d_lmk_const.release();
+    h->d_lmk_ob.release(); h->d_lmk_oe.release(); h->d_obs_kf.release(); h->d_obs_cam.release();
+    h->d_obs_meas.release(); h->d_priors.release(); h->d_S.release(); h->d_gred.release(); h->d_gfull.release();
+    h->d_hdiag.release(); h->d_delta.release(); h->d_s_pose.release(); h->d_states.release(); h->d_acc.release();
+    h->d_probe.release();
+    delete h;
+}
+
+int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_flat_window* wins) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (n_windows <= 0 || !wins) { h->err = "set_windows: no windows"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    h->uploaded = false; h->solved = false;
+    h->wins.assign(n_windows, HostWin());
+    h->priors_per_win.assign(n_windows, {});
+    h->tiles.clear();
+    h->factor_type = wins[0].factor_type;
+    int kf_b = 0, cam_b = 0, lmk_b = 0, obs_b = 0, red_b = 0;
+    long long s_b = 0;
+    h->max_n_kf = h->max_npose = h->max_np = 0;
+    h->has_lmk_const = false;
+    for (int w = 0; w < n_windows; w++) {
+        const sadvio_flat_window& F = wins[w];
+        if (F.n_kf <= 0 || F.n_cam <= 0 || F.n_lmk < 0 || F.n_obs < 0 || !F.kf_T_f_w || !F.cam_K || !F.cam_T_s_f ||
+            (F.n_lmk > 0 && (!F.lmk_p || !F.lmk_obs_ptr)) || (F.n_obs > 0 && (!F.obs_kf || !F.obs_cam || !F.obs_meas))) {
+            h->err = "set_windows: missing array in window " + std::to_string(w);
+            return SADVIO_E_INVALID_ARG;
+        }
+        if (F.factor_type != h->factor_type || (F.factor_type != SADVIO_FACTOR_PIXEL && F.factor_type != SADVIO_FACTOR_ANGULAR)) {
+            h->err = "set_windows: all windows of a batch must share one factor_type";
+            return SADVIO_E_INVALID_ARG;
+        }
+        if (F.n_lmk > 0 && (F.lmk_obs_ptr[0] != 0 || F.lmk_obs_ptr[F.n_lmk] != F.n_obs)) {
+            h->err = "set_windows: lmk_obs_ptr is not a CSR over n_obs";
+            return SADVIO_E_INVALID_ARG;
+        }
+        for (int o = 0; o < F.n_obs; o++)
+            if (F.obs_kf[o] < 0 || F.obs_kf[o] >= F.n_kf || F.obs_cam[o] < 0 || F.obs_cam[o] >= F.n_cam) {
+                h->err = "set_windows: observation index out of range";
+                return SADVIO_E_INVALID_ARG;
+            }
+        if (F.lmk_const) h->has_lmk_const = true;
+        HostWin& H = h->wins[w];
+        WinDev& d = H.d;
+        memset(&d, 0, sizeof(d));
+        d.n_kf = F.n_kf; d.n_cam = F.n_cam; d.n_lmk = F.n_lmk; d.n_obs = F.n_obs;
+        d.kf_base = kf_b; d.cam_base = cam_b; d.lmk_base = lmk_b; d.obs_base = obs_b;
+        d.factor_type = F.factor_type; d.has_imu = F.has_imu;
+        d.dpf = F.has_imu ? 15 : 6;
+        int nfree = 0;
+        for (int k = 0; k < F.n_kf; k++)
+            if (!(F.kf_const && F.kf_const[k])) nfree++;
+        d.n_free_kf = nfree;
+        d.Npose = nfree * 6;
+        d.Np = nfree * d.dpf;
+        d.S_off = s_b; d.red_off = red_b;
+        H.kf_id.assign(F.n_kf, 0); H.lmk_id.assign(F.n_lmk, 0);
+        for (int k = 0; k < F.n_kf; k++) H.kf_id[k] = F.kf_id ? F.kf_id[k] : k;
+        for (int l = 0; l < F.n_lmk; l++) H.lmk_id[l] = F.lmk_id ? F.lmk_id[l] : l;
+        kf_b += F.n_kf; cam_b += F.n_cam; lmk_b += F.n_lmk; obs_b += F.n_obs;
+        red_b += d.Np; s_b += (long long)d.Np * d.Np;
+        h->max_n_kf = std::max(h->max_n_kf, F.n_kf);
+        h->max_npose = std::max(h->max_npose, d.Npose);
+        h->max_np = std::max(h->max_np, d.Np);
+    }
+    h->n_kf_tot = kf_b; h->n_cam_tot = cam_b; h->n_lmk_tot = lmk_b; h->n_obs_tot = obs_b; h->np_tot = red_b; h->s_tot = s_b;
+    if (h->max_n_kf > MAX_LDS_KF) { h->err = "set_windows: more than 64 key-frames per window not supported yet"; return SADVIO_E_INVALID_ARG; }
+    if (h->max_np > MAX_LDS_NP) { h->err = "set_windows: reduced dimension > 192 not supported yet"; return SADVIO_E_INVALID_ARG; }
+    h->lds_tile = h->max_npose <= MAX_LDS_NPOSE;
+
+    // concatenate
+    std::vector<double> kf_T0(12 * (size_t)kf_b), kf_vel(3 * (size_t)kf_b, 0.0), kf_ba(3 * (size_t)kf_b, 0.0), kf_bg(3 * (size_t)kf_b, 0.0);
+    std::vector<int> kf_fidx(kf_b);
+    std::vector<double> cam_K(4 * (size_t)cam_b), cam_T(12 * (size_t)cam_b), cam_isig(cam_b);
+    std::vector<double> lmk_p(3 * (size_t)lmk_b);
+    std::vector<unsigned char> lmk_const(std::max(lmk_b, 1), 0);
+    std::vector<int> lmk_ob(std::max(lmk_b, 1)), lmk_oe(std::max(lmk_b, 1)), obs_kf(std::max(obs_b, 1)), obs_cam(std::max(obs_b, 1));
+    const int ms = h->factor_type == SADVIO_FACTOR_PIXEL ? 2 : 3;
+    std::vector<double> obs_meas((size_t)ms * std::max(obs_b, 1));
+    // tile size: aim at >= ~2 workgroups per CU over the whole batch, one observation per thread at most
+    int tile_obs = MAX_TILE_OBS;
+    {
+        long long target_tiles = 512;
+        long long per = (obs_b + target_tiles - 1) / target_tiles;
+        tile_obs = (int)std::min<long long>(MAX_TILE_OBS, std::max<long long>(64, per));
+    }
+    for (int w = 0; w < n_windows; w++) {
+        const sadvio_flat_window& F = wins[w];
+        WinDev& d = h->wins[w].d;
+        memcpy(&kf_T0[12 * (size_t)d.kf_base], F.kf_T_f_w, sizeof(double) * 12 * F.n_kf);
+        if (F.kf_vel) memcpy(&kf_vel[3 * (size_t)d.kf_base], F.kf_vel, sizeof(double) * 3 * F.n_kf);
+        if (F.kf_ba) memcpy(&kf_ba[3 * (size_t)d.kf_base], F.kf_ba, sizeof(double) * 3 * F.n_kf);
+        if (F.kf_bg) memcpy(&kf_bg[3 * (size_t)d.kf_base], F.kf_bg, sizeof(double) * 3 * F.n_kf);
+        int fi = 0;
+        for (int k = 0; k < F.n_kf; k++) kf_fidx[d.kf_base + k] = (F.kf_const && F.kf_const[k]) ? -1 : fi++;
+        memcpy(&cam_K[4 * (size_t)d.cam_base], F.cam_K, sizeof(double) * 4 * F.n_cam);
+        memcpy(&cam_T[12 * (size_t)d.cam_base], F.cam_T_s_f, sizeof(double) * 12 * F.n_cam);
+        for (int c = 0; c < F.n_cam; c++) cam_isig[d.cam_base + c] = 1.0 / (F.cam_sigma ? F.cam_sigma[c] : 1.0);
+        if (F.n_lmk) memcpy(&lmk_p[3 * (size_t)d.lmk_base], F.lmk_p, sizeof(double) * 3 * F.n_lmk);
+        for (int l = 0; l < F.n_lmk; l++) {
+            lmk_const[d.lmk_base + l] = F.lmk_const ? F.lmk_const[l] : 0;
+            lmk_ob[d.lmk_base + l] = d.obs_base + F.lmk_obs_ptr[l];
+            lmk_oe[d.lmk_base + l] = d.obs_base + F.lmk_obs_ptr[l + 1];
+            if (F.lmk_obs_ptr[l + 1] < F.lmk_obs_ptr[l]) { h->err = "set_windows: CSR not monotone"; return SADVIO_E_INVALID_ARG; }
+        }
+        for (int o = 0; o < F.n_obs; o++) {
+            obs_kf[d.obs_base + o] = d.kf_base + F.obs_kf[o];
+            obs_cam[d.obs_base + o] = d.cam_base + F.obs_cam[o];
+        }
+        if (F.n_obs) memcpy(&obs_meas[(size_t)ms * d.obs_base], F.obs_meas, sizeof(double) * ms * F.n_obs);
+        // tiles: greedy landmark ranges
+        d.tile_begin = (int)h->tiles.size();
+        int l = 0;
+        while (l < F.n_lmk) {
+            Tile t{};
+            t.w = w; t.lmk0 = d.lmk_base + l; t.obs0 = d.obs_base + F.lmk_obs_ptr[l]; t.kmax = 1;
+            int cnt = 0, nl = 0;
+            while (l < F.n_lmk && nl < MAX_TILE_LMK) {
+                int k = F.lmk_obs_ptr[l + 1] - F.lmk_obs_ptr[l];
+                if (k > MAX_TILE_OBS) { h->err = "set_windows: a landmark has more than 256 observations"; return SADVIO_E_INVALID_ARG; }
+                if (nl > 0 && cnt + k > tile_obs) break;
+                cnt += k; nl++; l++;
+                t.kmax = std::max(t.kmax, k);
+            }
+            t.lmk1 = d.lmk_base + l; t.obs1 = t.obs0 + cnt;
+            h->tiles.push_back(t);
+        }
+        if ((int)h->tiles.size() == d.tile_begin) {  // window without landmarks: one empty tile carries the LM state
+            Tile t{}; t.w = w; t.lmk0 = t.lmk1 = d.lmk_base; t.obs0 = t.obs1 = d.obs_base; t.kmax = 1;
+            h->tiles.push_back(t);
+        }
+        d.tile_end = (int)h->tiles.size();
+    }
+    HIP_TRY(h->d_win.alloc(n_windows)); HIP_TRY(h->d_tiles.alloc(h->tiles.size()));
+    HIP_TRY(h->d_kf_T0.alloc(kf_T0.size())); HIP_TRY(h->d_kf_fidx.alloc(kf_fidx.size()));
+    HIP_TRY(h->d_xp.alloc(2 * 6 * (size_t)kf_b)); HIP_TRY(h->d_xv.alloc(2 * 3 * (size_t)kf_b));
+    HIP_TRY(h->d_xba.alloc(2 * 3 * (size_t)kf_b)); HIP_TRY(h->d_xbg.alloc(2 * 3 * (size_t)kf_b));
+    HIP_TRY(h->d_kf_vel.alloc(kf_vel.size())); HIP_TRY(h->d_kf_ba.alloc(kf_ba.size())); HIP_TRY(h->d_kf_bg.alloc(kf_bg.size()));
+    HIP_TRY(h->d_cam_K.alloc(cam_K.size())); HIP_TRY(h->d_cam_T.alloc(cam_T.size())); HIP_TRY(h->d_cam_isig.alloc(cam_isig.size()));
+    HIP_TRY(h->d_lmk_p.alloc(lmk_p.size())); HIP_TRY(h->d_xl.alloc(2 * 3 * (size_t)std::max(lmk_b, 1)));
+    HIP_TRY(h->d_s_lmk.alloc(3 * (size_t)std::max(lmk_b, 1))); HIP_TRY(h->d_lmk_const.alloc(lmk_const.size()));
+    HIP_TRY(h->d_lmk_ob.alloc(lmk_ob.size())); HIP_TRY(h->d_lmk_oe.alloc(lmk_oe.size()));
+    HIP_TRY(h->d_obs_kf.alloc(obs_kf.size())); HIP_TRY(h->d_obs_cam.alloc(obs_cam.size())); HIP_TRY(h->d_obs_meas.alloc(obs_meas.size()));
+    HIP_TRY(h->d_S.alloc((size_t)std::max<long long>(s_b, 1))); HIP_TRY(h->d_gred.alloc(std::max(red_b, 1)));
+    HIP_TRY(h->d_gfull.alloc(std::max(red_b, 1))); HIP_TRY(h->d_hdiag.alloc(std::max(red_b, 1)));
+    HIP_TRY(h->d_delta.alloc(std::max(red_b, 1))); HIP_TRY(h->d_s_pose.alloc(std::max(red_b, 1)));
+#define UP(dst, src) HIP_TRY(hipMemcpyAsync((dst).p, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, h->stream))
+    UP(h->d_tiles, h->tiles); UP(h->d_kf_T0, kf_T0); UP(h->d_kf_fidx, kf_fidx); UP(h->d_kf_vel, kf_vel);
+    UP(h->d_kf_ba, kf_ba); UP(h->d_kf_bg, kf_bg); UP(h->d_cam_K, cam_K); UP(h->d_cam_T, cam_T); UP(h->d_cam_isig, cam_isig);
+    if (lmk_b) { UP(h->d_lmk_p, lmk_p); }
+    UP(h->d_lmk_const, lmk_const); UP(h->d_lmk_ob, lmk_ob); UP(h->d_lmk_oe, lmk_oe); UP(h->d_obs_kf, obs_kf);
+    UP(h->d_obs_cam, obs_cam); UP(h->d_obs_meas, obs_meas);
+#undef UP
+    HIP_TRY(hipMemsetAsync(h->d_S.p, 0, sizeof(double) * (size_t)std::max<long long>(s_b, 1), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_gred.p, 0, sizeof(double) * std::max(red_b, 1), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_gfull.p, 0, sizeof(double) * std::max(red_b, 1), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_hdiag.p, 0, sizeof(double) * std::max(red_b, 1), h->stream));
+    int rc = upload_priors(h);  // also uploads the window descriptors and synchronises (host vectors go out of scope)
+    if (rc != SADVIO_OK) return rc;
+    h->uploaded = true;
+    for (auto& k : h->kclasses) { k.total_ms = 0; k.launches = 0; }
+    return SADVIO_OK;
+}
+
+int sadvio_ba_set_pose_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const sadvio_pose_prior* pr) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (!h->uploaded) { h->err = "set_pose_priors before set_windows"; return SADVIO_E_STATE; }
+    if (w < 0 || w >= (int)h->wins.size() || n < 0 || (n > 0 && !pr)) { h->err = "set_pose_priors: bad argument"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    auto& v = h->priors_per_win[w];
+    v.clear();
+    for (int i = 0; i < n; i++) {
+        if (pr[i].kf < 0 || pr[i].kf >= h->wins[w].d.n_kf) { h->err = "set_pose_priors: kf out of range"; return SADVIO_E_INVALID_ARG; }
+        PriorDev d{};
+        d.kf = h->wins[w].d.kf_base + pr[i].kf;
+        memcpy(d.T_prior, pr[i].T_prior, sizeof(d.T_prior));
+        memcpy(d.inf, pr[i].inf_diag, sizeof(d.inf));
+        v.push_back(d);
+    }
+    return upload_priors(h);
+}
+
+int sadvio_ba_set_imu_factors(sadvio_ba_handle* h, int32_t, int32_t n, const sadvio_imu_factor*) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (n == 0) return SADVIO_OK;
+    h->err = "set_imu_factors: IMU factors are not implemented on the device yet";
+    return SADVIO_E_INVALID_ARG;
+}
+
+int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t, int32_t n_full, int32_t, const double*, const double*, int32_t,
+                              int32_t, int32_t, const int32_t*, const int32_t*) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (n_full == 0) return SADVIO_OK;
+    h->err = "set_dense_prior: dense marginalisation prior is not implemented on the device yet";
+    return SADVIO_E_INVALID_ARG;
+}
+
+int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvio_solve_summary* summaries) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (!h->uploaded) { h->err = "solve before set_windows"; return SADVIO_E_STATE; }
+    sadvio_solve_options defo;
+    if (!opts) { sadvio_ba_default_options(&defo); opts = &defo; }
+    if (opts->max_num_iterations < 0 || opts->max_num_iterations > 1000) { h->err = "solve: max_num_iterations out of range"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    SolveOpts o{};
+    o.max_num_iterations = opts->max_num_iterations; o.jacobi_scaling = opts->jacobi_scaling;
+    o.max_num_consecutive_invalid_steps = opts->max_num_consecutive_invalid_steps;
+    o.function_tolerance = opts->function_tolerance; o.gradient_tolerance = opts->gradient_tolerance;
+    o.parameter_tolerance = opts->parameter_tolerance; o.initial_radius = opts->initial_trust_region_radius;
+    o.max_radius = opts->max_trust_region_radius; o.min_radius = opts->min_trust_region_radius;
+    o.min_lm_diagonal = opts->min_lm_diagonal; o.max_lm_diagonal = opts->max_lm_diagonal;
+    o.min_relative_decrease = opts->min_relative_decrease;
+    const int n_win = (int)h->wins.size();
+    // Slot s (s = 0 .. slots-1) is one step attempt; with max_num_iterations = 0 Ceres still evaluates
+    // iteration 0, so at least one slot is always run and the final decision is taken by k_final.
+    const int slots = std::max(1, o.max_num_iterations);
+    const int stride = slots + 2;
+    HIP_TRY(h->d_states.alloc((size_t)n_win * stride));
+    HIP_TRY(h->d_acc.alloc((size_t)n_win * stride));
+    HIP_TRY(hipMemsetAsync(h->d_states.p, 0, sizeof(LmState) * (size_t)n_win * stride, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_acc.p, 0, sizeof(IterAcc) * (size_t)n_win * stride, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_xp.p, 0, sizeof(double) * h->d_xp.n, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_xv.p, 0, sizeof(double) * h->d_xv.n, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_xba.p, 0, sizeof(double) * h->d_xba.n, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_xbg.p, 0, sizeof(double) * h->d_xbg.n, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_xl.p, 0, sizeof(double) * h->d_xl.n, h->stream));
+    std::vector<LmState> st0((size_t)n_win * stride);
+    memset(st0.data(), 0, st0.size() * sizeof(LmState));
+    for (int w = 0; w < n_win; w++) {
+        LmState& s = st0[(size_t)w * stride];
+        s.radius = o.initial_radius; s.decrease_factor = 2.0;
+        if (o.max_num_iterations == 0) { /* handled after slot 0 by k_final: iter >= max */ }
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_states.p, st0.data(), st0.size() * sizeof(LmState), hipMemcpyHostToDevice, h->stream));
+    DevPtrs P = make_ptrs(h, o, stride);
+    const int n_tiles = (int)h->tiles.size();
+    const size_t lds_tile_extra = h->lds_tile ? sizeof(double) * ((size_t)h->max_npose * (h->max_npose + 1) / 2 + 3 * (size_t)h->max_npose) : 0;
+    const size_t lds_build = tile_lds_bytes(h->max_n_kf) + lds_tile_extra;
+    const size_t lds_back = tile_lds_bytes(h->max_n_kf) + sizeof(double) * ((size_t)h->max_n_kf * 12 + MAX_TILE_LMK * 3);
+    const size_t lds_solve = sizeof(double) * ((size_t)h->max_np * (h->max_np + 1) / 2 + 4 * (size_t)h->max_np);
+    auto kb = h->factor_type == SADVIO_FACTOR_PIXEL ? (h->lds_tile ? k_build<0, true> : k_build<0, false>)
+                                                    : (h->lds_tile ? k_build<1, true> : k_build<1, false>);
+    auto kk = h->factor_type == SADVIO_FACTOR_PIXEL ? k_backsub<0> : k_backsub<1>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
+    HIP_TRY(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
+    for (int s = 0; s < slots; s++) {
+        { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s); }
+        { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(k_solve, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
+        { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s); }
+    }
+    { ScopedTimer t(h, "k_final"); hipLaunchKernelGGL(k_final, dim3((n_win + 63) / 64), dim3(64), 0, h->stream, P, slots); }
+    HIP_TRY(hipGetLastError());
+    std::vector<LmState> fin(n_win);
+    std::vector<IterAcc> acc0(n_win);
+    for (int w = 0; w < n_win; w++) {
+        HIP_TRY(hipMemcpyAsync(&fin[w], h->d_states.p + (size_t)w * stride + slots, sizeof(LmState), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(&acc0[w], h->d_acc.p + (size_t)w * stride, sizeof(IterAcc), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->cfg.profile_kernels) collect_timers(h);
+    h->last_slots = slots;
+    h->solved = true;
+    int rc = SADVIO_OK;
+    for (int w = 0; w < n_win; w++) {
+        const LmState& s = fin[w];
+        if (summaries) {
+            sadvio_solve_summary& S = summaries[w];
+            S.iterations = s.iter; S.num_successful_steps = s.n_success; S.num_unsuccessful_steps = s.n_unsuccess;
+            S.termination = s.termination; S.initial_cost = s.initial_cost; S.final_cost = s.x_cost;
+            S.fixed_cost = 0.5 * acc0[w].fixed_cost; S.final_radius = s.radius;
+        }
+        if (s.termination == SADVIO_TERM_FAILURE) rc = SADVIO_E_NOT_USABLE;
+    }
+    // remember which buffer holds x for each window
+    (void)h->d_probe.alloc(1);
+    return rc;
+}
+
+int sadvio_ba_get_deltas(sadvio_ba_handle* h, int32_t w, double* pose, double* lmk, double* dv, double* dba, double* dbg) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (!h->solved) { h->err = "get_deltas before solve"; return SADVIO_E_STATE; }
+    if (w < 0 || w >= (int)h->wins.size()) { h->err = "get_deltas: window out of range"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    const WinDev& d = h->wins[w].d;
+    const int stride = h->last_slots + 2;
+    LmState s;
+    HIP_TRY(hipMemcpy(&s, h->d_states.p + (size_t)w * stride + h->last_slots, sizeof(LmState), hipMemcpyDeviceToHost));
+    const int cur = s.cur;
+    if (pose) HIP_TRY(hipMemcpy(pose, h->d_xp.p + (size_t)cur * 6 * h->n_kf_tot + 6 * (size_t)d.kf_base, sizeof(double) * 6 * d.n_kf, hipMemcpyDeviceToHost));
+    if (lmk && d.n_lmk) HIP_TRY(hipMemcpy(lmk, h->d_xl.p + (size_t)cur * 3 * h->n_lmk_tot + 3 * (size_t)d.lmk_base, sizeof(double) * 3 * d.n_lmk, hipMemcpyDeviceToHost));
+    double* outs[3] = {dv, dba, dbg};
+    double* srcs[3] = {h->d_xv.p, h->d_xba.p, h->d_xbg.p};
+    for (int q = 0; q < 3; q++)
+        if (outs[q]) HIP_TRY(hipMemcpy(outs[q], srcs[q] + (size_t)cur * 3 * h->n_kf_tot + 3 * (size_t)d.kf_base, sizeof(double) * 3 * d.n_kf, hipMemcpyDeviceToHost));
+    return SADVIO_OK;
+}
+
+int sadvio_ba_get_ids(sadvio_ba_handle* h, int32_t w, int64_t* kf_id, int64_t* lmk_id) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (w < 0 || w >= (int)h->wins.size()) { h->err = "get_ids: window out of range"; return SADVIO_E_INVALID_ARG; }
+    if (kf_id) memcpy(kf_id, h->wins[w].kf_id.data(), sizeof(int64_t) * h->wins[w].kf_id.size());
+    if (lmk_id) memcpy(lmk_id, h->wins[w].lmk_id.data(), sizeof(int64_t) * h->wins[w].lmk_id.size());
+    return SADVIO_OK;
+}
+
+int sadvio_ba_linearize(sadvio_ba_handle* h, int32_t w, const double* pose_delta6, const double* lmk_delta3, double* r2,
+                        double* Jp12, double* Jl6) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (!h->uploaded) { h->err = "linearize before set_windows"; return SADVIO_E_STATE; }
+    if (w < 0 || w >= (int)h->wins.size()) { h->err = "linearize: window out of range"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    const WinDev& d = h->wins[w].d;
+    HIP_TRY(hipMemsetAsync(h->d_xp.p, 0, sizeof(double) * h->d_xp.n, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_xl.p, 0, sizeof(double) * h->d_xl.n, h->stream));
+    if (pose_delta6) HIP_TRY(hipMemcpyAsync(h->d_xp.p + 6 * (size_t)d.kf_base, pose_delta6, sizeof(double) * 6 * d.n_kf, hipMemcpyHostToDevice, h->stream));
+    if (lmk_delta3 && d.n_lmk) HIP_TRY(hipMemcpyAsync(h->d_xl.p + 3 * (size_t)d.lmk_base, lmk_delta3, sizeof(double) * 3 * d.n_lmk, hipMemcpyHostToDevice, h->stream));
+    if (d.n_obs == 0) { HIP_TRY(hipStreamSynchronize(h->stream)); return SADVIO_OK; }
+    HIP_TRY(h->d_probe.alloc(20 * (size_t)d.n_obs));
+    SolveOpts o{};
+    DevPtrs P = make_ptrs(h, o, 1);
+    double* pr = h->d_probe.p; double* pj = pr + 2 * (size_t)d.n_obs; double* pl = pj + 12 * (size_t)d.n_obs;
+    int blocks = (d.n_obs + 255) / 256;
+    if (h->factor_type == SADVIO_FACTOR_PIXEL) hipLaunchKernelGGL(k_linearize_probe<0>, dim3(blocks), dim3(256), 0, h->stream, P, w, pr, pj, pl);
+    else hipLaunchKernelGGL(k_linearize_probe<1>, dim3(blocks), dim3(256), 0, h->stream, P, w, pr, pj, pl);
+    HIP_TRY(hipGetLastError());
+    if (r2) HIP_TRY(hipMemcpyAsync(r2, pr, sizeof(double) * 2 * d.n_obs, hipMemcpyDeviceToHost, h->stream));
+    if (Jp12) HIP_TRY(hipMemcpyAsync(Jp12, pj, sizeof(double) * 12 * d.n_obs, hipMemcpyDeviceToHost, h->stream));
+    if (Jl6) HIP_TRY(hipMemcpyAsync(Jl6, pl, sizeof(double) * 6 * d.n_obs, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->solved = false;
+    return SADVIO_OK;
+}
+
+int sadvio_ba_get_kernel_times(sadvio_ba_handle* h, int32_t cap, const char** names, double* avg_us, int64_t* launches) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    int n = 0;
+    for (auto& k : h->kclasses) {
+        if (n >= cap) break;
+        if (names) names[n] = k.name;
+        if (avg_us) avg_us[n] = k.launches ? 1e3 * k.total_ms / (double)k.launches : 0.0;
+        if (launches) launches[n] = k.launches;
+        n++;
+    }
+    return n;
+}
+
+const char* sadvio_ba_last_error(sadvio_ba_handle* h) { return h ? h->err.c_str() : "null handle"; }
+const char* sadvio_ba_version(void) { return "sadvio-ba-mi355x 0.1 (gfx950)"; }
+
+}  // extern "C"

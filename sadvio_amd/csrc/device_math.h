@@ -1,0 +1,296 @@
+// device_math.h — gfx950 device-side SO3 / factor arithmetic of the BA hot path (FP64).
+//
+// Restates the reference's closed forms with the SAME small-angle branches
+// (cpp/include/utilities/geometry.h:17-23,30-37,131-147,149-166) and the reference's factor
+// algebra (BundleAdjustmentCERESAnalytic.h:52-90 + Camera.cpp:84-139;
+// AngularAdjustmentCERESAnalytic.h:55-111), simplified where the simplification is an identity:
+//   * the pixel factor's J_pose rotation block is A * (-R [p]x Jr(log R)) * Jr(log R)^-1 * Jr(w)
+//     in the reference (Camera.cpp:108-109 x …Analytic.h:73-77); Jr Jr^-1 = I, so the device
+//     evaluates -J_lmk [p]x Jr(w) directly (no log / inverse per observation);
+//   * J_h * K = (1/z) [[fx, 0, -fx x/z], [0, fy, -fy y/z]].
+// Matrices are row-major double[9]; a rigid transform is R(9) | t(3).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sadvio {
+
+struct V3 {
+    double x, y, z;
+};
+
+__device__ __forceinline__ void m3_mul(const double* A, const double* B, double* C) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+__device__ __forceinline__ void m3_vec(const double* A, const double* v, double* o) {
+    double x = A[0] * v[0] + A[1] * v[1] + A[2] * v[2];
+    double y = A[3] * v[0] + A[4] * v[1] + A[5] * v[2];
+    double z = A[6] * v[0] + A[7] * v[1] + A[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+__device__ __forceinline__ void m3_tvec(const double* A, const double* v, double* o) {
+    double x = A[0] * v[0] + A[3] * v[1] + A[6] * v[2];
+    double y = A[1] * v[0] + A[4] * v[1] + A[7] * v[2];
+    double z = A[2] * v[0] + A[5] * v[1] + A[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+__device__ __forceinline__ double v3_norm(const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+// geometry.h:17-23
+__device__ __forceinline__ void so3_skew(const double* w, double* S) {
+    S[0] = 0; S[1] = -w[2]; S[2] = w[1];
+    S[3] = w[2]; S[4] = 0; S[5] = -w[0];
+    S[6] = -w[1]; S[7] = w[0]; S[8] = 0;
+}
+// geometry.h:30-37 (exactly I below 1e-5)
+__device__ __forceinline__ void so3_right_jacobian(const double* w, double* J) {
+    double n = v3_norm(w);
+    J[0] = 1; J[1] = 0; J[2] = 0; J[3] = 0; J[4] = 1; J[5] = 0; J[6] = 0; J[7] = 0; J[8] = 1;
+    if (n < 1e-5) return;
+    double S[9], S2[9];
+    so3_skew(w, S);
+    m3_mul(S, S, S2);
+    double a = (1 - cos(n)) / (n * n);
+    double b = (n - sin(n)) / (n * n * n);
+#pragma unroll
+    for (int i = 0; i < 9; i++) J[i] = J[i] - a * S[i] + b * S2[i];
+}
+// geometry.h:131-147 (first order below 1e-9)
+__device__ __forceinline__ void so3_exp(const double* v, double* R) {
+    double angle = v3_norm(v);
+    double S[9];
+    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+    if (angle < 1e-9) {
+        so3_skew(v, S);
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] += S[i];
+        return;
+    }
+    double axis[3] = {v[0] / angle, v[1] / angle, v[2] / angle};
+    double S2[9];
+    so3_skew(axis, S);
+    m3_mul(S, S, S2);
+    double c = 1. - cos(angle), s = sin(angle);
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] += c * S2[i] + s * S[i];
+}
+// geometry.h:149-166 (first order if |sin| < 1e-9 or angle < 1e-9 — also near pi)
+__device__ __forceinline__ void so3_log(const double* M, double* phi) {
+    double cos_angle = 0.5 * (M[0] + M[4] + M[8]) - 0.5;
+    cos_angle = fmin(fmax(cos_angle, -1.), 1.);
+    double angle = acos(cos_angle);
+    double k = (fabs(sin(angle)) < 1e-9 || angle < 1e-9) ? 0.5 : 0.5 * angle / sin(angle);
+    phi[0] = k * (M[7] - M[5]);
+    phi[1] = k * (M[2] - M[6]);
+    phi[2] = k * (M[3] - M[1]);
+}
+// Inverse of a symmetric positive-definite 3x3 given as (a00,a01,a02,a11,a12,a22); returns det.
+__device__ __forceinline__ double sym3_inverse(const double* a, double* inv) {
+    double c00 = a[3] * a[5] - a[4] * a[4];
+    double c01 = a[2] * a[4] - a[1] * a[5];
+    double c02 = a[1] * a[4] - a[2] * a[3];
+    double det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+    double id = 1.0 / det;
+    inv[0] = c00 * id;
+    inv[1] = c01 * id;
+    inv[2] = c02 * id;
+    inv[3] = (a[0] * a[5] - a[2] * a[2]) * id;
+    inv[4] = (a[1] * a[2] - a[0] * a[4]) * id;
+    inv[5] = (a[0] * a[3] - a[1] * a[1]) * id;
+    return det;
+}
+__device__ __forceinline__ void m3_inverse(const double* A, double* I) {
+    double c00 = A[4] * A[8] - A[5] * A[7];
+    double c01 = A[5] * A[6] - A[3] * A[8];
+    double c02 = A[3] * A[7] - A[4] * A[6];
+    double id = 1.0 / (A[0] * c00 + A[1] * c01 + A[2] * c02);
+    I[0] = c00 * id; I[1] = (A[2] * A[7] - A[1] * A[8]) * id; I[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    I[3] = c01 * id; I[4] = (A[0] * A[8] - A[2] * A[6]) * id; I[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    I[6] = c02 * id; I[7] = (A[1] * A[6] - A[0] * A[7]) * id; I[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+// Per-key-frame quantities at the current deltas, staged once per workgroup.
+//   R = R0 exp(w), t = R0 td + t0   (T_f_w = T_f_w0 * (exp(w), td), geometry.h:198-203)
+//   Jr = so3_rightJacobian(w); dR = exp(w)
+constexpr int POSE_TAB = 42;  // R[9] t[3] Jr[9] R0[9] dR[9] td[3]
+__device__ __forceinline__ void pose_table_entry(const double* T0, const double* d6, double* tab) {
+    double dR[9], Jr[9], R[9], t[3];
+    so3_exp(d6, dR);
+    so3_right_jacobian(d6, Jr);
+    m3_mul(T0, dR, R);
+    m3_vec(T0, d6 + 3, t);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        tab[i] = R[i];
+        tab[12 + i] = Jr[i];
+        tab[21 + i] = T0[i];
+        tab[30 + i] = dR[i];
+    }
+    tab[9] = t[0] + T0[9]; tab[10] = t[1] + T0[10]; tab[11] = t[2] + T0[11];
+    tab[39] = d6[3]; tab[40] = d6[4]; tab[41] = d6[5];
+}
+
+// Pixel reprojection residual (+ Jacobians). cam = K[4] | Tsf[12]. Returns validity
+// (Camera.cpp:128-136); invalid => r = 0, Jacobians kept (…Analytic.h:63-65).
+template <bool WANT_J>
+__device__ __forceinline__ bool pixel_factor(const double* tab, const double* K, const double* Tsf, const double* pw,
+                                             double u_meas, double v_meas, double inv_sigma, double* r, double* Jp,
+                                             double* Jl) {
+    double pf[3], tc[3];
+    m3_vec(tab, pw, pf);
+    pf[0] += tab[9]; pf[1] += tab[10]; pf[2] += tab[11];
+    m3_vec(Tsf, pf, tc);
+    tc[0] += Tsf[9]; tc[1] += Tsf[10]; tc[2] += Tsf[11];
+    double iz = 1.0 / tc[2];
+    double u = (K[0] * tc[0] + K[2] * tc[2]) * iz;
+    double v = (K[1] * tc[1] + K[3] * tc[2]) * iz;
+    bool valid = !(tc[2] < 0.1) && !(u < 0 || v < 0 || u > 2 * K[2] || v > 2 * K[3]) && isfinite(u) && isfinite(v);
+    r[0] = valid ? inv_sigma * (u - u_meas) : 0.0;
+    r[1] = valid ? inv_sigma * (v - v_meas) : 0.0;
+    if (WANT_J) {
+        double a0 = inv_sigma * K[0] * iz, a1 = inv_sigma * K[1] * iz;
+        double JhK[6] = {a0, 0.0, -a0 * tc[0] * iz, 0.0, a1, -a1 * tc[1] * iz};
+        double A[6];  // JhK * Rsf
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            A[j] = JhK[0] * Tsf[j] + JhK[2] * Tsf[6 + j];
+            A[3 + j] = JhK[4] * Tsf[3 + j] + JhK[5] * Tsf[6 + j];
+        }
+        // Jl = A * R
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Jl[3 * q + j] = A[3 * q] * tab[j] + A[3 * q + 1] * tab[3 + j] + A[3 * q + 2] * tab[6 + j];
+        // Jp[:,0:3] = -Jl [pw]x Jr(w);  Jp[:,3:6] = A * R0
+        const double* Jr = tab + 12;
+        const double* R0 = tab + 21;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            double l0 = Jl[3 * q], l1 = Jl[3 * q + 1], l2 = Jl[3 * q + 2];
+            // row * skew(p) = (l1 p2 - l2 p1, l2 p0 - l0 p2, l0 p1 - l1 p0)
+            double s0 = l1 * pw[2] - l2 * pw[1];
+            double s1 = l2 * pw[0] - l0 * pw[2];
+            double s2 = l0 * pw[1] - l1 * pw[0];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                Jp[6 * q + j] = -(s0 * Jr[j] + s1 * Jr[3 + j] + s2 * Jr[6 + j]);
+                Jp[6 * q + 3 + j] = A[3 * q] * R0[j] + A[3 * q + 1] * R0[3 + j] + A[3 * q + 2] * R0[6 + j];
+            }
+        }
+    }
+    return valid;
+}
+
+// Angular (bearing) residual (+ Jacobians), AngularAdjustmentCERESAnalytic.h:55-111.
+// The reference evaluates Jr(log(exp(w))); log(exp(w)) = w for |w| < pi, so Jr(w) from the table is used.
+template <bool WANT_J>
+__device__ __forceinline__ void angular_factor(const double* tab, const double* Tsf, const double* pw,
+                                               const double* b, double inv_sigma, double* r, double* Jp, double* Jl) {
+    const double* R0 = tab + 21;
+    const double* dR = tab + 30;
+    // t_s = Tsf * T_f_w0 * dT * pw = Rsf (R pw + t) + tsf with R = R0 dR, t = R0 td + t0 (:62)
+    double pf[3], ts[3];
+    m3_vec(tab, pw, pf);
+    pf[0] += tab[9]; pf[1] += tab[10]; pf[2] += tab[11];
+    m3_vec(Tsf, pf, ts);
+    ts[0] += Tsf[9]; ts[1] += Tsf[10]; ts[2] += Tsf[11];
+    double nrm = v3_norm(ts);
+    double inrm = 1.0 / nrm;
+    double bs[3] = {ts[0] * inrm, ts[1] * inrm, ts[2] * inrm};
+    // tangent basis (:66-77)
+    double d[3] = {b[0] - 1, b[1], b[2]};
+    double b1[3];
+    if (v3_norm(d) > 1e-5) { b1[0] = 0; b1[1] = b[2]; b1[2] = -b[1]; }
+    else { b1[0] = b[1]; b1[1] = -b[0]; b1[2] = 0; }
+    double n1 = 1.0 / v3_norm(b1);
+    b1[0] *= n1; b1[1] *= n1; b1[2] *= n1;
+    double b2[3] = {b1[1] * b[2] - b1[2] * b[1], b1[2] * b[0] - b1[0] * b[2], b1[0] * b[1] - b1[1] * b[0]};
+    double n2 = 1.0 / v3_norm(b2);
+    b2[0] *= n2; b2[1] *= n2; b2[2] *= n2;
+    double e[3] = {bs[0] - b[0], bs[1] - b[1], bs[2] - b[2]};
+    r[0] = inv_sigma * (b1[0] * e[0] + b1[1] * e[1] + b1[2] * e[2]);
+    r[1] = inv_sigma * (b2[0] * e[0] + b2[1] * e[1] + b2[2] * e[2]);
+    if (WANT_J) {
+        // Je = Pt (I - bs bs^T) Rsf R0 / |t_s|
+        double Pt[6] = {b1[0], b1[1], b1[2], b2[0], b2[1], b2[2]};
+        double PtM[6];
+#pragma unroll
+        for (int qq = 0; qq < 2; qq++) {
+            double dot = Pt[3 * qq] * bs[0] + Pt[3 * qq + 1] * bs[1] + Pt[3 * qq + 2] * bs[2];
+#pragma unroll
+            for (int j = 0; j < 3; j++) PtM[3 * qq + j] = Pt[3 * qq + j] - dot * bs[j];
+        }
+        double Rsw0[9];
+        m3_mul(Tsf, R0, Rsw0);
+        double Je[6];
+#pragma unroll
+        for (int qq = 0; qq < 2; qq++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                Je[3 * qq + j] = inv_sigma * inrm *
+                                 (PtM[3 * qq] * Rsw0[j] + PtM[3 * qq + 1] * Rsw0[3 + j] + PtM[3 * qq + 2] * Rsw0[6 + j]);
+        const double* Jr = tab + 12;
+        // Jl = Je dR ; Jp[:,0:3] = -Je dR [pw]x Jr = -Jl [pw]x Jr ; Jp[:,3:6] = Je
+#pragma unroll
+        for (int qq = 0; qq < 2; qq++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                Jl[3 * qq + j] = Je[3 * qq] * dR[j] + Je[3 * qq + 1] * dR[3 + j] + Je[3 * qq + 2] * dR[6 + j];
+            double l0 = Jl[3 * qq], l1 = Jl[3 * qq + 1], l2 = Jl[3 * qq + 2];
+            double s0 = l1 * pw[2] - l2 * pw[1];
+            double s1 = l2 * pw[0] - l0 * pw[2];
+            double s2 = l0 * pw[1] - l1 * pw[0];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                Jp[6 * qq + j] = -(s0 * Jr[j] + s1 * Jr[3 + j] + s2 * Jr[6 + j]);
+                Jp[6 * qq + 3 + j] = Je[3 * qq + j];
+            }
+        }
+    }
+}
+
+// PosePriordx (residuals.hpp:601-632), sqrt_inf = diag(inf).
+__device__ __forceinline__ void pose_prior_factor(const double* T0, const double* Tp, const double* inf,
+                                                  const double* d6, double* r, double* J /*6x6 or nullptr*/) {
+    double dR[9], R[9], t[3];
+    so3_exp(d6, dR);
+    m3_mul(T0, dR, R);
+    m3_vec(T0, d6 + 3, t);
+    t[0] += T0[9]; t[1] += T0[10]; t[2] += T0[11];
+    // E = T * Tp^-1 : R_E = R Rp^T, t_E = t - R_E tp
+    double RE[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) RE[3 * i + j] = R[3 * i] * Tp[3 * j] + R[3 * i + 1] * Tp[3 * j + 1] + R[3 * i + 2] * Tp[3 * j + 2];
+    double w[3], REtp[3];
+    so3_log(RE, w);
+    m3_vec(RE, Tp + 9, REtp);
+    r[0] = inf[0] * w[0]; r[1] = inf[1] * w[1]; r[2] = inf[2] * w[2];
+    r[3] = inf[3] * (t[0] - REtp[0]); r[4] = inf[4] * (t[1] - REtp[1]); r[5] = inf[5] * (t[2] - REtp[2]);
+    if (J) {
+        double Jrw[9], Jrwi[9], Jrd[9], A[9], B00[9], v[3], S[9], RS[9], B10[9];
+        so3_right_jacobian(w, Jrw);
+        m3_inverse(Jrw, Jrwi);
+        so3_right_jacobian(d6, Jrd);
+        m3_mul(Jrwi, Tp, A);
+        m3_mul(A, Jrd, B00);
+        m3_tvec(Tp, Tp + 9, v);
+        so3_skew(v, S);
+        m3_mul(R, S, RS);
+        m3_mul(RS, Jrd, B10);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                J[6 * i + j] = inf[i] * B00[3 * i + j];
+                J[6 * i + 3 + j] = 0.0;
+                J[6 * (3 + i) + j] = inf[3 + i] * B10[3 * i + j];
+                J[6 * (3 + i) + 3 + j] = inf[3 + i] * T0[3 * i + j];
+            }
+    }
+}
+
+}  // namespace sadvio
