@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py — BA iterations/s + ms/solve on BASELINE.json config 2 (synthetic 20 KF x 8 000 landmarks x
+40 000 reprojection factors, GN 10 iters) through the C ABI of the HIP backend.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N)
+
+A "step" is one complete solve (10 LM step attempts, every early exit disabled) of the windows resident on this
+GPU; the windows are uploaded to HBM before the timed region. N > 1 shards independent windows (one set per
+GPU, weak scaling, no data-path collective — BASELINE.json north_star: "independent sub-windows / keyframe
+batches shard across the 8 GPUs"); torch.distributed (backend "nccl" = RCCL) is used only for the barriers and
+the max-over-ranks of the elapsed time.
+
+One JSON line is printed by rank 0. Besides the contract's fields it carries
+  roofline      the dominant kernel's achieved algorithmic GB/s vs the 8 TB/s HBM peak; kernel durations are
+                measured live with hipEvents on the backend's stream in a separate (untimed) profiled pass
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm, the reference itself cannot be built
+                here) timed on this box's host cores on the same window
+  batched       the same metric with 64 independent windows per launch (the bandwidth-bound regime)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
+GN_ITERS = 10
+
+
+def algorithmic_bytes(n_obs, n_lmk, n_p):
+    """SURVEY.md §8(d) / BASELINE.md §4: B_iter = 120 N_obs + 96 N_lmk + 16 (N_p^2 + N_p), split per kernel:
+    k_build = linearise/eliminate pass, k_backsub = back-substitution + candidate-cost passes (fused)."""
+    red = 8 * (n_p * n_p + n_p)
+    return {"k_build": 40 * n_obs + 24 * n_lmk + red, "k_solve": red, "k_backsub": 80 * n_obs + 72 * n_lmk}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=1, help="independent config-2 windows per GPU in the timed run")
+    ap.add_argument("--batch", type=int, default=64, help="windows per GPU of the extra batched measurement (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as ge
+    ge.build_hip()
+    from sadvio_amd import capi, synthetic
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed_solves(be, opts, steps, warmup):
+        for _ in range(warmup):
+            be.solve(opts)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            be.solve(opts)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    opts = capi.gn_options(GN_ITERS)
+    # every rank owns its own windows (different seeds): weak scaling over independent sub-windows
+    base_seed = 20250404 + 1000 * rank
+    wins = [synthetic.make_window(seed=base_seed + i) for i in range(args.windows)]
+    be = capi.Backend(device=local_rank)
+    be.set_windows(wins)
+    dt = timed_solves(be, opts, args.steps, args.warmup)
+    sums = be.solve(opts)
+    be.close()
+    iters_per_step = sum(s.iterations for s in sums)
+    total_iters = iters_per_step * args.steps * world
+    value = total_iters / dt
+    ms_per_step = 1e3 * dt / args.steps
+
+    out = None
+    if rank == 0:
+        w0 = wins[0]
+        n_p = 6 * int((w0.kf_const == 0).sum())
+        # --- live per-kernel durations (hipEvents on the backend's stream), untimed profiled pass ---
+        bp = capi.Backend(device=local_rank, profile_kernels=True)
+        bp.set_windows(wins)
+        for _ in range(3):
+            bp.solve(opts)
+        bp.set_windows(wins)  # resets the per-class accumulators
+        for _ in range(10):
+            bp.solve(opts)
+        kt = bp.kernel_times()
+        bp.close()
+        ab = algorithmic_bytes(w0.n_obs * len(wins), w0.n_lmk * len(wins), n_p)
+        ab["k_solve"] = len(wins) * 8 * (n_p * n_p + n_p)
+        ab["k_build"] = len(wins) * (40 * w0.n_obs + 24 * w0.n_lmk + 8 * (n_p * n_p + n_p))
+        dom = max((k for k in kt if k in ab), key=lambda k: kt[k]["avg_us"] * kt[k]["launches"])
+        achieved = ab[dom] / (kt[dom]["avg_us"] * 1e-6) / 1e9
+        iter_us = sum(kt[k]["avg_us"] for k in ("k_build", "k_solve", "k_backsub") if k in kt)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": ab[dom], "avg_kernel_us": round(kt[dom]["avg_us"], 3),
+                    "kernels_us": {k: round(v["avg_us"], 3) for k, v in kt.items()},
+                    "iteration_achieved_GBps": round(sum(ab.values()) / (iter_us * 1e-6) / 1e9, 2)}
+        # --- batched throughput (independent windows in one submission) ---
+        batched = None
+        if args.batch > 0:
+            bw = [synthetic.make_window(seed=base_seed + 100 + i) for i in range(min(args.batch, 8))]
+            bw = [bw[i % len(bw)] for i in range(args.batch)]
+            bb = capi.Backend(device=local_rank)
+            bb.set_windows(bw)
+            for _ in range(2):
+                bb.solve(opts)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                bs = bb.solve(opts)
+            torch.cuda.synchronize()
+            bdt = time.perf_counter() - t0
+            bb.close()
+            biters = sum(s.iterations for s in bs) * reps
+            per_iter_bytes = 120 * w0.n_obs + 96 * w0.n_lmk + 16 * (n_p * n_p + n_p)
+            batched = {"windows": args.batch, "value": round(biters / bdt, 1), "unit": "BA iterations/s",
+                       "ms_per_solve_batch": round(1e3 * bdt / reps, 3),
+                       "algorithmic_GBps": round(biters * per_iter_bytes / bdt / 1e9, 1),
+                       "frac_of_hbm_peak": round(biters * per_iter_bytes / bdt / 1e9 / HBM_PEAK_GBS, 4)}
+        # --- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores ---
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle
+            oracle.build()
+            ncores = os.cpu_count() or 1
+            res = {}
+            for thr in (1, 4):  # 4 = the reference's Ceres num_threads (AOptimizer.cpp:323)
+                oracle.solve(w0, opts, n_threads=thr)
+                t0 = time.perf_counter()
+                n = 0
+                while time.perf_counter() - t0 < 6.0:
+                    r = oracle.solve(w0, opts, n_threads=thr)
+                    n += r["summary"].iterations
+                res[thr] = n / (time.perf_counter() - t0)
+            best = max(res, key=res.get)
+            cpu = {"value": round(res[best], 2), "unit": "BA iterations/s", "cores": best, "kind": "port",
+                   "sample": f"config-2 window, GN-{GN_ITERS} solves repeated for ~6 s per thread count "
+                             f"(1 thread: {res[1]:.1f} it/s, 4 threads: {res[4]:.1f} it/s); host has {ncores} cores",
+                   "note": "reference (Ceres/Eigen) cannot be built here; oracle = C restatement, explicit Schur"}
+        out = {
+            "metric": "BA iterations/sec (ms/solve in ms_per_step), 20-KF/8k-landmark window",
+            "value": round(value, 1), "unit": "BA iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic 20 KF x 8000 landmarks x 40000 reprojection factors (pixel), "
+                                   f"GN {GN_ITERS} iters (LM step attempts, early exits disabled)",
+                       "windows_per_gpu": args.windows, "iterations_per_solve": iters_per_step // max(1, args.windows),
+                       "parallelism": f"independent windows x{world}" if world > 1 else "single window",
+                       "n_kf": w0.n_kf, "n_lmk": w0.n_lmk, "n_obs": w0.n_obs, "reduced_dim": n_p},
+            "roofline": roofline, "cpu_baseline": cpu, "batched": batched,
+        }
+        if cpu:
+            out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,6 +22,18 @@
 
 #define MARG_EPS 1e-12 /* marginalization.hpp:56 */
 
+/* Eigenvalue cut of the pseudo-inverse / rank-revealing decomposition. The reference keeps
+ * lambda > 1e-12 (absolute, marginalization.cpp:237,322). On its own test fixture
+ * (marginalization_test.cpp, |Amm| ~ 1e5) the null eigenvalue computes to +-1e-11 — rounding noise
+ * ABOVE that absolute cut — so the reference's result there depends on the sign of a rounding error.
+ * The restatement keeps the reference's constant and adds the standard noise floor n*eps*lambda_max,
+ * i.e. what the reference's cut is meant to do (drop the null space). */
+static double marg_cut(const double *ev, int n) {
+    double mx = 0;
+    for (int i = 0; i < n; i++) mx = fmax(mx, fabs(ev[i]));
+    return fmax(MARG_EPS, (double)n * 2.220446049250313e-16 * mx);
+}
+
 void oracle_sym_eig(const double *Ain, int32_t n, double *evals, double *V) {
     double *A = (double *)malloc(sizeof(double) * (size_t)n * n);
     memcpy(A, Ain, sizeof(double) * (size_t)n * n);
@@ -224,8 +236,9 @@ int oracle_marginalize(const oracle_marg_request *rq, oracle_marg_result *res, i
     double *ev = (double *)malloc(sizeof(double) * (size_t)m), *V = (double *)malloc(sizeof(double) * (size_t)m * m);
     oracle_sym_eig(Amm, m, ev, V);
     double *Ainv = (double *)calloc((size_t)m * m, sizeof(double));
+    double cut_m = marg_cut(ev, m);
     for (int k = 0; k < m; k++) {
-        if (!(ev[k] > MARG_EPS)) continue;
+        if (!(ev[k] > cut_m)) continue;
         double iv = 1.0 / ev[k];
         for (int i = 0; i < m; i++)
             for (int j = 0; j < m; j++) Ainv[(size_t)i * m + j] += V[(size_t)i * m + k] * iv * V[(size_t)j * m + k];
@@ -259,12 +272,13 @@ int oracle_marginalize(const oracle_marg_request *rq, oracle_marg_result *res, i
     double *ev2 = (double *)malloc(sizeof(double) * (size_t)n), *V2 = (double *)malloc(sizeof(double) * (size_t)n * n);
     oracle_sym_eig(Aks, n, ev2, V2);
     int nf = 0;
+    double cut_n = marg_cut(ev2, n);
     for (int k = 0; k < n; k++)
-        if (ev2[k] > MARG_EPS) nf++;
+        if (ev2[k] > cut_n) nf++;
     if (res) res->n_full = nf;
     int c = 0;
     for (int k = 0; k < n; k++) {
-        if (!(ev2[k] > MARG_EPS)) continue;
+        if (!(ev2[k] > cut_n)) continue;
         double lam = ev2[k];
         if (Lambda_out) Lambda_out[c] = lam;
         double dot = 0;

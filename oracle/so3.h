@@ -131,9 +131,12 @@ static inline void se3_apply(const double *T, const double *p, double *o) {
     m3_vec(T, p, q);
     o[0] = q[0] + T[9]; o[1] = q[1] + T[10]; o[2] = q[2] + T[11];
 }
+/* Eigen::Affine3d::inverse() (Mode = Affine) inverts the linear part as a GENERAL 3x3 matrix, not by
+ * transposition; this matters for the reference's tests that feed 8-digit rotation literals
+ * (imu_test.cpp:367-369) through 1000 inverse round trips. */
 static inline void se3_inverse(const double *T, double *I) {
     double Rt[9], t[3];
-    m3_transpose(T, Rt);
+    m3_inverse(T, Rt);
     m3_vec(Rt, T + 9, t);
     for (int i = 0; i < 9; i++) I[i] = Rt[i];
     I[9] = -t[0]; I[10] = -t[1]; I[11] = -t[2];

@@ -78,7 +78,7 @@ def _body_poses(n_kf, length, rng):
 
 def make_window(n_kf=20, n_lmk=8000, obs_per_lmk=5, seed=20250404, factor=FACTOR_PIXEL, pixel_noise=1.0,
                 rot_perturb_deg=0.5, trans_perturb=0.02, lmk_perturb=0.05, length=10.0, fixed=1,
-                width=752, height=480, min_depth=1.0, max_depth=15.0) -> FlatWindow:
+                width=752, height=480, min_depth=1.0, max_depth=15.0, border=5.0) -> FlatWindow:
     """One VO window (config 2 of BASELINE.json at the defaults: 20 KF x 8 000 landmarks x 40 000 factors)."""
     rng = np.random.default_rng(seed)
     T_w_b = _body_poses(n_kf, length, rng)  # oldest first
@@ -107,7 +107,10 @@ def make_window(n_kf=20, n_lmk=8000, obs_per_lmk=5, seed=20250404, factor=FACTOR
         z = pcam[:, :, 2]
         uu = Kv[None, :, 0] * pcam[:, :, 0] / z + Kv[None, :, 2]
         vv = Kv[None, :, 1] * pcam[:, :, 1] / z + Kv[None, :, 3]
-        valid = (z > 0.5) & (uu > 5) & (uu < width - 5) & (vv > 5) & (vv < height - 5)
+        # keep measurements inside the reference's validity window [0, 2cx] x [0, 2cy] (Camera.cpp:131-133)
+        umax = np.minimum(width, 2 * Kv[None, :, 2]) - border
+        vmax = np.minimum(height, 2 * Kv[None, :, 3]) - border
+        valid = (z > 0.5) & (uu > border) & (uu < umax) & (vv > border) & (vv < vmax)
         ok = valid.sum(axis=1) >= obs_per_lmk
         lmk = np.concatenate([lmk, pw[ok]])
         valid_all = np.concatenate([valid_all, valid[ok]])

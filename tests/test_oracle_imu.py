@@ -1,0 +1,222 @@
+"""Oracle IMU pre-integration + IMU factor + VI solve, pinned against the known answers of the reference's
+own test-suite (cpp/tests/imu_test.cpp). Line numbers cite that file."""
+import numpy as np
+import pytest
+
+from imu_helpers import CFG, Chain, arr, factor_dict, frame_to_world
+from sadvio_amd import capi
+from sadvio_amd.synthetic import T12_to_4, T_to_12, exp_so3, inv4
+
+ACC = np.array([0.5, 1.0, 10.81])  # :66
+GYR = np.array([0.1, 0.3, 0.1])    # :67
+G = np.array([0, 0, -9.81])
+
+
+def test_ImuTestBase(oracle_lib):  # :103-143
+    ch = Chain(ACC, GYR, 1e9)
+    s1 = ch.step(ACC, GYR, 1.5e9)
+    dR = oracle_lib.so3_exp(GYR / 2)
+    assert abs((dR @ arr(s1.delta_R).reshape(3, 3).T).trace() - 3) < 1e-15
+    assert np.linalg.norm(ACC / 2 - arr(s1.delta_v)) == 0
+    assert np.linalg.norm(0.5 * ACC * 0.5 * 0.5 - arr(s1.delta_p)) == 0
+    dT = ch.estimate_transform(s1)
+    assert abs((dR @ dT[:3, :3].T).trace() - 3) < 1e-15
+    assert np.linalg.norm(dT[:3, 3] - (0.5 * ACC * 0.25 + 0.5 * G * 0.25)) == 0
+    ba, bg = np.array([0.1, 0.2, 0.3]), np.array([0.2, 0.3, 0.1])
+    ch = Chain(ACC, GYR, 1e9, ba=ba, bg=bg)
+    s1 = ch.step(ACC, GYR, 1.5e9)
+    dR = oracle_lib.so3_exp((GYR - bg) * 0.5)
+    assert abs((dR @ arr(s1.delta_R).reshape(3, 3).T).trace() - 3) < 1e-15
+    assert np.linalg.norm((ACC - ba) / 2 - arr(s1.delta_v)) == 0
+    assert np.linalg.norm(0.5 * (ACC - ba) * 0.5 * 0.5 - arr(s1.delta_p)) == 0
+
+
+def test_ImuNewMeas(oracle_lib):  # :145-159
+    ch = Chain(ACC, GYR, 1e9)
+    s1 = ch.step(ACC, GYR, 1.5e9)
+    s2 = ch.step(ACC, GYR, 2e9)
+    R1 = arr(s1.delta_R).reshape(3, 3)
+    assert abs((oracle_lib.so3_exp(GYR) @ arr(s2.delta_R).reshape(3, 3).T).trace() - 3) < 1e-14
+    dv = ACC * 0.5 + R1 @ ACC * 0.5
+    assert np.linalg.norm(dv - arr(s2.delta_v)) < 1e-15
+    dp = 0.5 * ACC * 0.25 + arr(s1.delta_v) * 0.5 + 0.5 * R1 @ ACC * 0.25
+    assert np.linalg.norm(dp - arr(s2.delta_p)) < 1e-15
+
+
+def test_checkCov_gtsam_literal(oracle_lib):  # :164-193
+    cfg = dict(CFG); cfg["rate_hz"] = 2
+    ch = Chain(np.array([0.1, 0, 0]), np.array([np.pi / 100, 0, 0]), 1e9, cfg=cfg)
+    s1 = ch.step(ACC, GYR, 1.5e9)
+    expected = np.zeros((9, 9))
+    for i in range(3):
+        expected[i, i] = 1.0577e-08
+        expected[3 + i, 3 + i] = 1.38889e-06
+        expected[6 + i, 6 + i] = 5.00868e-05
+        expected[3 + i, 6 + i] = expected[6 + i, 3 + i] = 3.47222e-07
+    cov = arr(s1.cov).reshape(9, 9)
+    assert abs((expected - cov).trace()) < 1e-9        # the reference's assertion
+    assert np.allclose(cov, expected, rtol=2e-4, atol=1e-12)  # and element-wise to the literal's precision
+
+
+def test_checkJacobiansBiasGyr(oracle_lib):  # :328-361
+    ch = Chain(ACC, GYR, 1e9)
+    s1 = ch.step(ACC, GYR, 1.5e9)
+    dt = 0.5
+    Jrk = oracle_lib.so3_right_jacobian(GYR * dt)
+    assert np.allclose(arr(s1.J_dR_bg).reshape(3, 3), -Jrk * dt, atol=1e-15)
+    assert np.allclose(arr(s1.J_dv_ba).reshape(3, 3), -np.eye(3) * dt, atol=0)
+    assert not arr(s1.J_dv_bg).any() and not arr(s1.J_dp_bg).any()
+    assert np.allclose(arr(s1.J_dp_ba).reshape(3, 3), -0.5 * np.eye(3) * dt * dt, atol=0)
+    s2 = ch.step(ACC, GYR, 2e9)
+    dR = oracle_lib.so3_exp(GYR * dt)
+    R1 = arr(s1.delta_R).reshape(3, 3)
+    J1 = arr(s1.J_dR_bg).reshape(3, 3)
+    S = np.array([[0, -ACC[2], ACC[1]], [ACC[2], 0, -ACC[0]], [-ACC[1], ACC[0], 0]])
+    assert np.allclose(arr(s2.J_dR_bg).reshape(3, 3), dR.T @ J1 - Jrk * dt, atol=1e-14)
+    assert np.allclose(arr(s2.J_dv_ba).reshape(3, 3), -np.eye(3) * dt - R1 * dt, atol=1e-15)
+    assert np.allclose(arr(s2.J_dv_bg).reshape(3, 3), -R1 @ S @ J1 * dt, atol=1e-13)
+    assert np.allclose(arr(s2.J_dp_ba).reshape(3, 3),
+                       -0.5 * np.eye(3) * dt * dt + arr(s1.J_dv_ba).reshape(3, 3) * dt - 0.5 * R1 * dt * dt, atol=1e-15)
+    assert np.allclose(arr(s2.J_dp_bg).reshape(3, 3), -0.5 * R1 @ S @ J1 * dt * dt, atol=1e-13)
+
+
+def test_TestPreInteg(oracle_lib):  # :948-995
+    a, w = 0.1, np.pi / 100.0
+    acc, gyr = np.array([a, 0, 0]), np.array([w, 0, 0])
+    ch = Chain(acc, gyr, 1e9)
+    s1 = ch.step(acc, gyr, 1.5e9)
+    assert (arr(s1.delta_R).reshape(3, 3) - oracle_lib.so3_exp(np.array([w * 0.5, 0, 0]))).sum() == 0
+    assert np.linalg.norm(arr(s1.delta_p) - np.array([0.5 * a * 0.25, 0, 0])) == 0
+    assert np.linalg.norm(arr(s1.delta_v) - np.array([0.05, 0, 0])) == 0
+    s2 = ch.step(acc, gyr, 2e9)
+    assert abs((arr(s2.delta_R).reshape(3, 3) - oracle_lib.so3_exp(np.array([w, 0, 0]))).sum()) < 1e-6
+    assert np.linalg.norm(arr(s2.delta_p) - np.array([0.025 + 0.5 * a * 0.25 + 0.5 * 0.1 * 0.25, 0, 0])) < 1e-16
+    ev2 = np.array([0.05, 0, 0]) + oracle_lib.so3_exp(np.array([w * 0.5, 0, 0])) @ acc * 0.5
+    assert np.linalg.norm(arr(s2.delta_v) - ev2) < 1e-16
+
+
+def _free_fall_chain():  # :363-407
+    T_i_f = np.eye(4)
+    T_i_f[:3, :3] = np.array([[0.38001193, 0.16469125, 0.91020202], [0.03067918, -0.9857245, 0.16554758],
+                              [0.92447267, -0.0349858, -0.37963966]])
+    T_i_f[:3, 3] = 1.0
+    acc = T_i_f[:3, :3].T @ np.array([0, 0, 10.81])
+    gyr = np.zeros(3)
+    cfg = dict(CFG); cfg["rate_hz"] = 1000
+    # the literal rotation is only orthonormal to 8 digits; Eigen's Affine inverse() is the rigid inverse formula
+    ch = Chain(acc, gyr, 1e9, T_f_w=T_to_12(inv4(T_i_f)), cfg=cfg)
+    cur = None
+    for i in range(1, 1001):
+        cur = ch.step(acc, gyr, 1e9 + (0.001 * i) * 1e9)
+    return T_i_f, ch, cur, cfg
+
+
+def test_predictionPositionVelocity_free_integration(oracle_lib):  # :363-411
+    T_i_f, ch, cur, _ = _free_fall_chain()
+    T_w_f = frame_to_world(cur)
+    assert np.linalg.norm(T_w_f[:3, 3] - np.array([1, 1, 1.5])) < 1e-5
+    assert np.linalg.norm(arr(cur.v) - np.array([0, 0, 1])) < 1e-5
+    assert abs((T_w_f[:3, :3].T @ T_i_f[:3, :3]).trace() - 3) < 1e-5
+
+
+def test_IMUFactor_residual_and_jacobians(oracle_lib):  # :413-462
+    T_i_f, ch, cur, cfg = _free_fall_chain()
+    f = factor_dict(0, 1, cur, 1.0, cfg)
+    Ti0, Tj0 = arr(ch.kf.T_f_w), arr(cur.T_f_w)
+    vi, vj = arr(ch.kf.v), arr(cur.v)
+    r, J = oracle_lib.factor_imu(f, Ti0, Tj0, vi, vj, np.zeros(24))
+    assert np.linalg.norm(r) < 1e-3  # :447
+    h = 1e-6
+    Jn = np.zeros((9, 24))
+    for k in range(24):
+        a = np.zeros(24); a[k] = h
+        Jn[:, k] = (oracle_lib.factor_imu(f, Ti0, Tj0, vi, vj, a)[0] - oracle_lib.factor_imu(f, Ti0, Tj0, vi, vj, -a)[0]) / (2 * h)
+    blocks = [(0, 6), (6, 12), (12, 15), (15, 18), (18, 21), (21, 24)]
+    for lo, hi in blocks:  # :457-462, the reference's criterion on each of the 6 blocks
+        assert abs((J[:, lo:hi] - Jn[:, lo:hi]).sum()) < 1e-5 * max(1.0, np.abs(Jn[:, lo:hi]).max())
+
+
+def _vio_window(states, priors, imu_factors):
+    """Flat window of key-frames only (no landmarks), newest first."""
+    n = len(states)
+    w = capi.FlatWindow(
+        kf_T_f_w=np.stack([arr(s.T_f_w) for s in states]), kf_const=np.zeros(n, dtype=np.uint8),
+        cam_K=np.array([[100.0, 100, 400, 400]]), cam_T_s_f=T_to_12(np.eye(4))[None], cam_sigma=np.array([1.0]),
+        lmk_p=np.zeros((0, 3)), lmk_obs_ptr=np.zeros(1, dtype=np.int32), obs_kf=np.zeros(0, dtype=np.int32),
+        obs_cam=np.zeros(0, dtype=np.int32), obs_meas=np.zeros((0, 2)), has_imu=1,
+        kf_vel=np.stack([arr(s.v) for s in states]), kf_ba=np.stack([arr(s.ba) for s in states]),
+        kf_bg=np.stack([arr(s.bg) for s in states]))
+    w.pose_priors = priors
+    w.imu_factors = imu_factors
+    return w
+
+
+def test_localMapVIOptimization_recovers_pose(oracle_lib):  # :464-487
+    T_i_f, ch, cur, cfg = _free_fall_chain()
+    prior_kf = T_to_12(inv4(T_i_f))
+    prior_cur = arr(cur.T_f_w).copy()
+    # perturb the newest frame (:474-478)
+    err = np.array([0, 0, 0, 0.1, 0.05, -0.01])
+    D = np.eye(4); D[:3, :3] = exp_so3(err[:3]); D[:3, 3] = err[3:]
+    cur.T_f_w[:] = list(T_to_12(T12_to_4(arr(cur.T_f_w)) @ D))
+    cur.v[:] = list(arr(cur.v) + np.array([0.04, 0.02, -0.02]))
+    f = factor_dict(1, 0, cur, 1.0, cfg)  # kf_i = older frame (index 1), kf_j = newest (index 0)
+    w = _vio_window([cur, ch.kf], [(0, prior_cur, 100 * np.ones(6)), (1, prior_kf, 100 * np.ones(6))], [f])
+    res = oracle_lib.solve(w, capi.reference_options())
+    assert res["rc"] == 0
+    # write-back (AOptimizer.cpp:391-418)
+    D = np.eye(4); D[:3, :3] = exp_so3(res["pose"][0][:3]); D[:3, 3] = res["pose"][0][3:]
+    T_f_w = T12_to_4(arr(cur.T_f_w)) @ D
+    T_w_f = inv4(T_f_w)
+    v = arr(cur.v) + res["dv"][0]
+    assert np.linalg.norm(T_w_f[:3, 3] - np.array([1, 1, 1.5])) < 1e-2
+    assert np.linalg.norm(v - np.array([0, 0, 1])) < 1e-2
+    assert abs((T_w_f[:3, :3].T @ T_i_f[:3, :3]).trace() - 3) < 1e-5
+
+
+def test_biasEstimation(oracle_lib):  # :545-568
+    ba, bg = np.array([0.5, 1.0, 1.0]), np.array([0.1, 0.3, 0.1])
+    ch = Chain(ACC, GYR, 1e9, ba=ba, bg=bg)
+    s1 = ch.step(ACC, GYR, 1.5e9)
+    f = factor_dict(1, 0, s1, 0.5)
+    I12 = T_to_12(np.eye(4))
+    w = _vio_window([s1, ch.kf], [(0, I12, 100 * np.ones(6)), (1, I12, 100 * np.ones(6))], [f])
+    res = oracle_lib.solve(w, capi.reference_options())
+    assert np.linalg.norm(bg + res["dbg"][1] - bg) < 1e-5
+    assert np.linalg.norm(ba + res["dba"][1] - ba) < 1e-5
+
+
+def test_predictionWithRotation_gnss_ins_sim(oracle_lib):  # :573-651 (free-integration numbers of gnss-ins-sim)
+    T_i_f = np.diag([1.0, -1.0, -1.0, 1.0])
+    gyr, acc = np.array([0.5, 0, 0]), np.array([-1, 0, -9.81])
+    ch = Chain(acc, gyr, 1e9, T_f_w=T_to_12(inv4(T_i_f)))
+    cur = None
+    for i in range(1, 202):
+        cur = ch.step(acc, gyr, 1e9 + (0.005 * i) * 1e9)
+        ch.estimate_transform(cur)
+    Tinv = inv4(T_i_f)
+    pos = Tinv[:3, :3] @ frame_to_world(cur)[:3, 3] + Tinv[:3, 3]
+    assert np.linalg.norm(pos - np.array([-0.505, 0.813, 0.1])) < 1e-2
+    assert np.linalg.norm(Tinv[:3, :3] @ arr(cur.v) - np.array([-1, 2.41, 0.4])) < 1e-2
+    ch.set_keyframe(cur)
+    gyr, acc = np.array([0.5, 0.2, 0.04]), np.array([-1, 0.05, -9.81])
+    for i in range(202, 401):
+        cur = ch.step(acc, gyr, 1e9 + (0.005 * i) * 1e9)
+        ch.estimate_transform(cur)
+    pos = Tinv[:3, :3] @ frame_to_world(cur)[:3, 3] + Tinv[:3, 3]
+    assert np.linalg.norm(pos - np.array([-2.31, 6.18, 1.62])) < 1e-2
+    assert np.linalg.norm(Tinv[:3, :3] @ arr(cur.v) - np.array([-2.95, 8.91, 3.24])) < 1e-2
+
+
+def test_predictionWithRotation2(oracle_lib):  # :654-703
+    T_i_f = np.diag([1.0, -1.0, -1.0, 1.0])
+    gyr, acc = np.array([0.5, 0.2, 0.04]), np.array([-1, 0.05, -9.81])
+    ch = Chain(acc, gyr, 1e9, T_f_w=T_to_12(inv4(T_i_f)))
+    cur = None
+    for i in range(1, 201):
+        cur = ch.step(acc, gyr, 1e9 + (0.005 * i) * 1e9)
+        ch.estimate_transform(cur)
+    Tinv = inv4(T_i_f)
+    pos = Tinv[:3, :3] @ frame_to_world(cur)[:3, 3] + Tinv[:3, 3]
+    assert np.linalg.norm(pos - np.array([-0.82143062, 0.80412303, 0.15357111])) < 1e-2
+    assert np.linalg.norm(Tinv[:3, :3] @ arr(cur.v) - np.array([-1.97810799, 2.38035184, 0.5780088])) < 1e-2

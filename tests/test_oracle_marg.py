@@ -1,0 +1,141 @@
+"""Oracle marginalisation vs the deterministic toy graph of the reference's marginalization_test.cpp
+(2 stereo frames, 3 landmarks; constants at :26-168, assertions at :213-224, :300-317, :321-335)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sadvio_amd import capi
+from sadvio_amd.synthetic import T_to_12, inv4
+
+_ip = C.POINTER(C.c_int32)
+_dp = C.POINTER(C.c_double)
+
+
+def toy_window():
+    K = np.array([100.0, 100.0, 400.0, 400.0])              # :35-39
+    T_s_f = [np.eye(4), np.eye(4)]
+    T_s_f[1][1, 3] = 0.2                                     # :49-51 right camera, y = 0.2
+    T_w_f1 = np.eye(4); T_w_f1[2, 3] = 1.0                   # :66-68
+    T_f_w = [np.eye(4), inv4(T_w_f1)]                        # frame0 = I, frame1
+    lmk = np.array([[0.5, 0, 2], [-1, 0, 2], [1, 0, 2.0]])   # :72,80,91
+    seen = {0: [0], 1: [0, 1], 2: [0, 1]}                    # lmk0 only in frame0; lmk1, lmk2 in both
+    obs_kf, obs_cam, meas, ptr = [], [], [], [0]
+    for l in range(3):
+        for kf in seen[l]:
+            for cam in range(2):
+                pc = (T_s_f[cam] @ T_f_w[kf] @ np.append(lmk[l], 1))[:3]  # Camera::project :27-52 (exact, no noise)
+                meas.append([K[0] * pc[0] / pc[2] + K[2], K[1] * pc[1] / pc[2] + K[3]])
+                obs_kf.append(kf); obs_cam.append(cam)
+        ptr.append(len(obs_kf))
+    w = capi.FlatWindow(
+        kf_T_f_w=np.stack([T_to_12(T) for T in T_f_w]), kf_const=np.zeros(2, dtype=np.uint8),
+        cam_K=np.stack([K, K]), cam_T_s_f=np.stack([T_to_12(T) for T in T_s_f]), cam_sigma=np.ones(2),
+        lmk_p=lmk, lmk_obs_ptr=np.array(ptr, dtype=np.int32), obs_kf=np.array(obs_kf, dtype=np.int32),
+        obs_cam=np.array(obs_cam, dtype=np.int32), obs_meas=np.array(meas))
+    return w
+
+
+def pre_marginalize(w, kf0):
+    """Selection rule of Marginalization::preMarginalize (marginalization.cpp:50-88) on a flat window:
+    a landmark of frame0 is ignored unless it has exactly 2 features in frame0 (stereo); it is marginalised
+    when all its features are in frame0 ("lonely"), kept otherwise."""
+    keep, marg = [], []
+    for l in range(w.n_lmk):
+        o = slice(w.lmk_obs_ptr[l], w.lmk_obs_ptr[l + 1])
+        kfs = w.obs_kf[o]
+        if not (kfs == kf0).any():
+            continue
+        if (kfs == kf0).sum() != 2:
+            continue
+        (marg if (kfs == kf0).all() else keep).append(l)
+    return keep, marg
+
+
+def run_marg(oracle_lib, w, kf_marg, keep, marg, kf_keep=-1):
+    wc = w.to_c()
+    rq = oracle_lib.MargRequest()
+    rq.win = C.pointer(wc)
+    rq.kf_marg, rq.kf_keep, rq.marg_has_imu = kf_marg, kf_keep, 0
+    mk = np.array(marg, dtype=np.int32); kp = np.array(keep, dtype=np.int32)
+    rq.n_marg, rq.lmk_marg = len(marg), mk.ctypes.data_as(_ip)
+    rq.n_keep, rq.lmk_keep = len(keep), kp.ctypes.data_as(_ip)
+    m = 6 + 3 * len(marg); n = 3 * len(keep) + (15 if kf_keep >= 0 else 0)
+    res = oracle_lib.MargResult()
+    N = m + n
+    out = dict(lmk_col=np.zeros(max(len(keep), 1), dtype=np.int32), A=np.zeros((N, N)), b=np.zeros(N),
+               Ak=np.zeros((max(n, 1), max(n, 1))), bk=np.zeros(max(n, 1)), U=np.zeros(max(n * n, 1)),
+               Lam=np.zeros(max(n, 1)), J=np.zeros(max(n * n, 1)), r0=np.zeros(max(n, 1)))
+    p = lambda a: a.ctypes.data_as(_dp)
+    rc = oracle_lib.lib().oracle_marginalize(C.byref(rq), C.byref(res), out["lmk_col"].ctypes.data_as(_ip), p(out["A"]),
+                                             p(out["b"]), p(out["Ak"]), p(out["bk"]), p(out["U"]), p(out["Lam"]),
+                                             p(out["J"]), p(out["r0"]))
+    out["rc"], out["m"], out["n"], out["n_full"] = rc, res.m, res.n, res.n_full
+    if rc == 0:
+        nf = res.n_full
+        out["U"] = out["U"][: n * nf].reshape(n, nf)
+        out["J"] = out["J"][: nf * n].reshape(nf, n)
+        out["Lam"] = out["Lam"][:nf]; out["r0"] = out["r0"][:nf]
+    return out
+
+
+def test_preMargTest(oracle_lib):  # :213-224
+    w = toy_window()
+    keep, marg = pre_marginalize(w, 0)
+    assert marg == [0] and keep == [1, 2]
+    out = run_marg(oracle_lib, w, 0, keep, marg)
+    assert out["n"] == 6 and out["m"] == 9
+
+
+def test_margTest_layout_and_schur(oracle_lib):  # :227-318
+    w = toy_window()
+    keep, marg = pre_marginalize(w, 0)
+    out = run_marg(oracle_lib, w, 0, keep, marg)
+    assert out["rc"] == 0
+    # layout before the shift: frame0 -> 0, l0 -> 6, l1 -> 9, l2 -> 12 (:300-303); after: l1 -> 0, l2 -> 3 (:308-309)
+    assert list(out["lmk_col"]) == [0, 3]
+    A = out["A"]
+    assert np.abs(A[6:9, 9:15]).max() == 0 and np.abs(A[9:12, 12:15]).max() == 0  # landmarks only couple via frame0
+    assert np.abs(A[0:6, 6:9]).max() > 0 and np.abs(A[0:6, 9:15]).max() > 0
+    Ak = out["Ak"]
+    assert Ak.shape == (6, 6)                                  # :312
+    assert np.linalg.norm(Ak - Ak.T) < 1e-8                    # :313
+    assert abs(np.trace(Ak[0:3, 3:6])) > 0                     # computeOffDiag(l1, l2) > 0, :316-317
+    # independent numpy check of the Schur complement with eigen pseudo-inverse (marginalization.cpp:234-248)
+    m = 9
+    Amm = 0.5 * (A[:m, :m] + A[:m, :m].T)
+    ev, V = np.linalg.eigh(Amm)
+    inv = V @ np.diag(np.where(ev > 1e-12, 1 / np.where(ev > 1e-12, ev, 1), 0)) @ V.T
+    Ak_np = A[m:, m:] - A[m:, :m] @ inv @ A[m:, :m].T
+    assert np.allclose(Ak, Ak_np, rtol=1e-9, atol=1e-7 * np.abs(Ak_np).max())
+    # exact measurements => zero residuals => zero gradient and zero prior residual
+    assert np.abs(out["b"]).max() < 1e-9 and np.abs(out["r0"]).max() < 1e-9
+    # J^T J reproduces Ak on its range (marginalization.cpp:516-527)
+    J = out["J"]
+    assert np.allclose(J.T @ J, 0.5 * (Ak + Ak.T), rtol=1e-8, atol=1e-8 * np.abs(Ak).max())
+
+
+def test_prior_residual_sign_convention(oracle_lib):
+    # Quirk B.7: b = +sum J^T r and r0 = -Lambda^-1/2 U^T bk => J^T r0 = -U U^T bk
+    w = toy_window()
+    w.obs_meas = w.obs_meas + np.random.default_rng(0).standard_normal(w.obs_meas.shape)
+    keep, marg = pre_marginalize(w, 0)
+    out = run_marg(oracle_lib, w, 0, keep, marg)
+    U = out["U"]
+    assert np.allclose(out["J"].T @ out["r0"], -U @ U.T @ out["bk"], rtol=1e-8, atol=1e-8)
+    assert np.allclose(U.T @ U, np.eye(out["n_full"]), atol=1e-10)
+
+
+def test_margFailTest(oracle_lib):  # :321-335 frame without landmarks: n < 4 => refused
+    w = toy_window()
+    out = run_marg(oracle_lib, w, 0, [], [])
+    assert out["rc"] == capi.E_REFUSED
+
+
+def test_sym_eig_against_numpy(oracle_lib):
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 5, 12, 40):
+        B = rng.standard_normal((n, n)); A = B @ B.T
+        ev, V = oracle_lib.sym_eig(A)
+        assert np.allclose(ev, np.linalg.eigvalsh(A), rtol=1e-10, atol=1e-10 * max(1, ev.max()))
+        assert np.allclose(V @ np.diag(ev) @ V.T, A, rtol=1e-9, atol=1e-9 * np.abs(A).max())
