@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -73,7 +74,6 @@ struct sadvio_ba_handle {
     long long s_tot = 0;
     int factor_type = 0;
     int max_n_kf = 0, max_npose = 0, max_np = 0;
-    bool lds_tile = true;
     bool uploaded = false, solved = false;
     int slots_cap = 0;
     int last_slots = 0;
@@ -85,12 +85,17 @@ struct sadvio_ba_handle {
     DevBuf<double> d_cam_K, d_cam_T, d_cam_isig;
     DevBuf<double> d_lmk_p, d_xl, d_s_lmk;
     DevBuf<unsigned char> d_lmk_const;
-    DevBuf<int> d_lmk_ob, d_lmk_oe, d_obs_kf, d_obs_cam;
+    DevBuf<int> d_lmk_ob, d_lmk_oe, d_obs_kf, d_obs_cam, d_tile_kf, d_tile_row;
+    DevBuf<unsigned char> d_obs_slot;
+    DevBuf<double> d_ptab;
+    int max_tile_kf = 1, max_tile_free = 0;
     DevBuf<double> d_obs_meas;
     DevBuf<PriorDev> d_priors;
     DevBuf<double> d_S, d_gred, d_gfull, d_hdiag, d_delta, d_s_pose;
     DevBuf<LmState> d_states;
     DevBuf<IterAcc> d_acc;
+    DevBuf<TileAcc> d_tacc;
+    DevBuf<long long> d_dbg;
     DevBuf<double> d_probe;
     bool has_lmk_const = false;
     // profiling
@@ -153,12 +158,16 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.lmk_const = h->has_lmk_const ? h->d_lmk_const.p : nullptr;
     P.lmk_ob = h->d_lmk_ob.p; P.lmk_oe = h->d_lmk_oe.p;
     P.obs_kf = h->d_obs_kf.p; P.obs_cam = h->d_obs_cam.p; P.obs_meas = h->d_obs_meas.p;
+    P.obs_slot = h->d_obs_slot.p; P.tile_kf = h->d_tile_kf.p; P.tile_row = h->d_tile_row.p;
+    P.ptab = h->d_ptab.p; P.ptab_stride = (long long)POSE_TAB * h->n_kf_tot;
     P.priors = h->d_priors.p;
     P.S = h->d_S.p; P.gred = h->d_gred.p; P.gfull = h->d_gfull.p; P.hdiag = h->d_hdiag.p;
     P.delta = h->d_delta.p; P.s_pose = h->d_s_pose.p;
-    P.states = h->d_states.p; P.acc = h->d_acc.p;
+    P.dbg_ts = h->d_dbg.p;
+    P.states = h->d_states.p; P.acc = h->d_acc.p; P.tacc = h->d_tacc.p; P.n_tiles = (int)h->tiles.size();
     P.state_stride = state_stride;
     P.n_win = (int)h->wins.size();
+    { const char* e = getenv("SADVIO_DEBUG"); P.debug = e ? atoi(e) : 0; }
     P.o = o;
     return P;
 }
@@ -244,7 +253,7 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     h->d_lmk_ob.release(); h->d_lmk_oe.release(); h->d_obs_kf.release(); h->d_obs_cam.release();
     h->d_obs_meas.release(); h->d_priors.release(); h->d_S.release(); h->d_gred.release(); h->d_gfull.release();
     h->d_hdiag.release(); h->d_delta.release(); h->d_s_pose.release(); h->d_states.release(); h->d_acc.release();
-    h->d_probe.release();
+    h->d_probe.release(); h->d_tile_kf.release(); h->d_tile_row.release(); h->d_obs_slot.release(); h->d_ptab.release(); h->d_tacc.release(); h->d_dbg.release();
     delete h;
 }
 
@@ -300,15 +309,13 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
         for (int k = 0; k < F.n_kf; k++) H.kf_id[k] = F.kf_id ? F.kf_id[k] : k;
         for (int l = 0; l < F.n_lmk; l++) H.lmk_id[l] = F.lmk_id ? F.lmk_id[l] : l;
         kf_b += F.n_kf; cam_b += F.n_cam; lmk_b += F.n_lmk; obs_b += F.n_obs;
-        red_b += d.Np; s_b += (long long)d.Np * d.Np;
+        red_b += d.Np; s_b += ((long long)d.Np * (d.Np + 1) / 2 + 1) & ~1LL;  // packed lower triangle, 16-byte aligned
         h->max_n_kf = std::max(h->max_n_kf, F.n_kf);
         h->max_npose = std::max(h->max_npose, d.Npose);
         h->max_np = std::max(h->max_np, d.Np);
     }
     h->n_kf_tot = kf_b; h->n_cam_tot = cam_b; h->n_lmk_tot = lmk_b; h->n_obs_tot = obs_b; h->np_tot = red_b; h->s_tot = s_b;
-    if (h->max_n_kf > MAX_LDS_KF) { h->err = "set_windows: more than 64 key-frames per window not supported yet"; return SADVIO_E_INVALID_ARG; }
-    if (h->max_np > MAX_LDS_NP) { h->err = "set_windows: reduced dimension > 192 not supported yet"; return SADVIO_E_INVALID_ARG; }
-    h->lds_tile = h->max_npose <= MAX_LDS_NPOSE;
+    if (h->max_np > MAX_LDS_NP) { h->err = "set_windows: reduced dimension > 174 not supported yet"; return SADVIO_E_INVALID_ARG; }
 
     // concatenate
     std::vector<double> kf_T0(12 * (size_t)kf_b), kf_vel(3 * (size_t)kf_b, 0.0), kf_ba(3 * (size_t)kf_b, 0.0), kf_bg(3 * (size_t)kf_b, 0.0);
@@ -319,13 +326,9 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
     std::vector<int> lmk_ob(std::max(lmk_b, 1)), lmk_oe(std::max(lmk_b, 1)), obs_kf(std::max(obs_b, 1)), obs_cam(std::max(obs_b, 1));
     const int ms = h->factor_type == SADVIO_FACTOR_PIXEL ? 2 : 3;
     std::vector<double> obs_meas((size_t)ms * std::max(obs_b, 1));
-    // tile size: aim at >= ~2 workgroups per CU over the whole batch, one observation per thread at most
-    int tile_obs = MAX_TILE_OBS;
-    {
-        long long target_tiles = 512;
-        long long per = (obs_b + target_tiles - 1) / target_tiles;
-        tile_obs = (int)std::min<long long>(MAX_TILE_OBS, std::max<long long>(64, per));
-    }
+    std::vector<int> tile_kf, tile_row;
+    std::vector<unsigned char> obs_slot(std::max(obs_b, 1), 0);
+    h->max_tile_kf = 1; h->max_tile_free = 0;
     for (int w = 0; w < n_windows; w++) {
         const sadvio_flat_window& F = wins[w];
         WinDev& d = h->wins[w].d;
@@ -350,30 +353,85 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
             obs_cam[d.obs_base + o] = d.cam_base + F.obs_cam[o];
         }
         if (F.n_obs) memcpy(&obs_meas[(size_t)ms * d.obs_base], F.obs_meas, sizeof(double) * ms * F.n_obs);
-        // tiles: greedy landmark ranges
+        // tiles: runs of consecutive landmarks. Every landmark gets a group of G lanes (G = pow2 >= the
+        // tile's largest observation count); a workgroup of BUILD_WAVES waves holds BUILD_WAVES * 64 / G
+        // landmarks per round. A tile is cut when its key-frame list would exceed the LDS tile capacity.
+        if (F.n_cam > MAX_WIN_CAM) { h->err = "set_windows: more than 8 cameras per window"; return SADVIO_E_INVALID_ARG; }
         d.tile_begin = (int)h->tiles.size();
-        int l = 0;
-        while (l < F.n_lmk) {
-            Tile t{};
-            t.w = w; t.lmk0 = d.lmk_base + l; t.obs0 = d.obs_base + F.lmk_obs_ptr[l]; t.kmax = 1;
-            int cnt = 0, nl = 0;
-            while (l < F.n_lmk && nl < MAX_TILE_LMK) {
-                int k = F.lmk_obs_ptr[l + 1] - F.lmk_obs_ptr[l];
-                if (k > MAX_TILE_OBS) { h->err = "set_windows: a landmark has more than 256 observations"; return SADVIO_E_INVALID_ARG; }
-                if (nl > 0 && cnt + k > tile_obs) break;
-                cnt += k; nl++; l++;
-                t.kmax = std::max(t.kmax, k);
+        {
+            int l = 0;
+            std::vector<int> mark(F.n_kf, -1);
+            while (l < F.n_lmk || (int)h->tiles.size() == d.tile_begin) {
+                Tile t{};
+                t.w = w; t.lmk0 = d.lmk_base + l; t.kmax = 1; t.G = 8;
+                t.dpf = d.dpf; t.Np = d.Np; t.red_off = d.red_off; t.S_off = d.S_off;
+                t.cam_base = d.cam_base; t.n_cam = F.n_cam;
+                t.first_of_window = ((int)h->tiles.size() == d.tile_begin) ? 1 : 0;
+                std::vector<int> kfs;
+                int nfree = 0;
+                const int l_begin = l;
+                while (l < F.n_lmk) {
+                    const int k = F.lmk_obs_ptr[l + 1] - F.lmk_obs_ptr[l];
+                    if (k > MAX_LMK_OBS) { h->err = "set_windows: a landmark has more than 64 observations"; return SADVIO_E_INVALID_ARG; }
+                    int G = t.G;
+                    while (G < k) G <<= 1;
+                    const int cap = BUILD_WAVES * (64 / G);  // landmarks per tile (one round per wave)
+                    if (l - l_begin + 1 > cap && l > l_begin) break;
+                    // key-frames this landmark would add
+                    std::vector<int> add;
+                    int add_free = 0;
+                    for (int o = F.lmk_obs_ptr[l]; o < F.lmk_obs_ptr[l + 1]; o++) {
+                        const int kf = F.obs_kf[o];
+                        if (mark[kf] != (int)h->tiles.size()) {
+                            mark[kf] = (int)h->tiles.size();
+                            add.push_back(kf);
+                            if (!(F.kf_const && F.kf_const[kf])) add_free++;
+                        }
+                    }
+                    const bool fits = (int)(kfs.size() + add.size()) <= MAX_TILE_KF && nfree + add_free <= MAX_TILE_FREE_KF;
+                    if (!fits && l > l_begin) {
+                        for (int kf : add) mark[kf] = -1;  // roll back
+                        break;
+                    }
+                    for (int kf : add) kfs.push_back(kf);
+                    nfree += add_free;
+                    t.G = G;
+                    t.kmax = std::max(t.kmax, k);
+                    l++;
+                    if (!fits) break;  // a single landmark exceeding the capacity: global-atomics tile
+                }
+                t.lmk1 = d.lmk_base + l;
+                std::sort(kfs.begin(), kfs.end());
+                t.lds_mode = ((int)kfs.size() <= MAX_TILE_KF && nfree <= MAX_TILE_FREE_KF) ? 1 : 0;
+                if ((int)kfs.size() > 64) { h->err = "set_windows: a landmark is observed from more than 64 key-frames"; return SADVIO_E_INVALID_ARG; }
+                t.kf_off = (int)tile_kf.size(); t.n_kf = (int)kfs.size(); t.n_free = t.lds_mode ? nfree : 0;
+                std::vector<int> slot_of(F.n_kf, -1);
+                int rank = 0;
+                for (size_t i = 0; i < kfs.size(); i++) {
+                    const int kf = kfs[i];
+                    slot_of[kf] = (int)i;
+                    tile_kf.push_back(d.kf_base + kf);
+                    const bool is_const = F.kf_const && F.kf_const[kf];
+                    if (is_const) tile_row.push_back(-1);
+                    else if (t.lds_mode) tile_row.push_back(6 * rank++);
+                    else tile_row.push_back(6 * kf_fidx[d.kf_base + kf]);  // global mode: 6 * free index of the window
+                }
+                for (int ll = l_begin; ll < l; ll++)
+                    for (int o = F.lmk_obs_ptr[ll]; o < F.lmk_obs_ptr[ll + 1]; o++)
+                        obs_slot[d.obs_base + o] = (unsigned char)slot_of[F.obs_kf[o]];
+                h->max_tile_kf = std::max(h->max_tile_kf, t.n_kf);
+                h->max_tile_free = std::max(h->max_tile_free, t.n_free);
+                h->tiles.push_back(t);
+                if (F.n_lmk == 0) break;
             }
-            t.lmk1 = d.lmk_base + l; t.obs1 = t.obs0 + cnt;
-            h->tiles.push_back(t);
-        }
-        if ((int)h->tiles.size() == d.tile_begin) {  // window without landmarks: one empty tile carries the LM state
-            Tile t{}; t.w = w; t.lmk0 = t.lmk1 = d.lmk_base; t.obs0 = t.obs1 = d.obs_base; t.kmax = 1;
-            h->tiles.push_back(t);
         }
         d.tile_end = (int)h->tiles.size();
+        for (int ti = d.tile_begin; ti < d.tile_end; ti++) { h->tiles[ti].win_tile0 = d.tile_begin; h->tiles[ti].win_ntiles = d.tile_end - d.tile_begin; }
     }
-    HIP_TRY(h->d_win.alloc(n_windows)); HIP_TRY(h->d_tiles.alloc(h->tiles.size()));
+    HIP_TRY(h->d_win.alloc(n_windows)); HIP_TRY(h->d_tiles.alloc(h->tiles.size())); HIP_TRY(h->d_tacc.alloc(2 * h->tiles.size()));
+    if (tile_kf.empty()) { tile_kf.push_back(0); tile_row.push_back(-1); }
+    HIP_TRY(h->d_tile_kf.alloc(tile_kf.size())); HIP_TRY(h->d_tile_row.alloc(tile_row.size()));
+    HIP_TRY(h->d_obs_slot.alloc(obs_slot.size())); HIP_TRY(h->d_ptab.alloc(2 * (size_t)POSE_TAB * kf_b));
     HIP_TRY(h->d_kf_T0.alloc(kf_T0.size())); HIP_TRY(h->d_kf_fidx.alloc(kf_fidx.size()));
     HIP_TRY(h->d_xp.alloc(2 * 6 * (size_t)kf_b)); HIP_TRY(h->d_xv.alloc(2 * 3 * (size_t)kf_b));
     HIP_TRY(h->d_xba.alloc(2 * 3 * (size_t)kf_b)); HIP_TRY(h->d_xbg.alloc(2 * 3 * (size_t)kf_b));
@@ -391,7 +449,7 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
     UP(h->d_kf_ba, kf_ba); UP(h->d_kf_bg, kf_bg); UP(h->d_cam_K, cam_K); UP(h->d_cam_T, cam_T); UP(h->d_cam_isig, cam_isig);
     if (lmk_b) { UP(h->d_lmk_p, lmk_p); }
     UP(h->d_lmk_const, lmk_const); UP(h->d_lmk_ob, lmk_ob); UP(h->d_lmk_oe, lmk_oe); UP(h->d_obs_kf, obs_kf);
-    UP(h->d_obs_cam, obs_cam); UP(h->d_obs_meas, obs_meas);
+    UP(h->d_obs_cam, obs_cam); UP(h->d_obs_meas, obs_meas); UP(h->d_tile_kf, tile_kf); UP(h->d_tile_row, tile_row); UP(h->d_obs_slot, obs_slot);
 #undef UP
     HIP_TRY(hipMemsetAsync(h->d_S.p, 0, sizeof(double) * (size_t)std::max<long long>(s_b, 1), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_gred.p, 0, sizeof(double) * std::max(red_b, 1), h->stream));
@@ -457,10 +515,12 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     // iteration 0, so at least one slot is always run and the final decision is taken by k_final.
     const int slots = std::max(1, o.max_num_iterations);
     const int stride = slots + 2;
+    HIP_TRY(h->d_dbg.alloc(64));
     HIP_TRY(h->d_states.alloc((size_t)n_win * stride));
     HIP_TRY(h->d_acc.alloc((size_t)n_win * stride));
     HIP_TRY(hipMemsetAsync(h->d_states.p, 0, sizeof(LmState) * (size_t)n_win * stride, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_acc.p, 0, sizeof(IterAcc) * (size_t)n_win * stride, h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_tacc.p, 0, sizeof(TileAcc) * 2 * h->tiles.size(), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_xp.p, 0, sizeof(double) * h->d_xp.n, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_xv.p, 0, sizeof(double) * h->d_xv.n, h->stream));
     HIP_TRY(hipMemsetAsync(h->d_xba.p, 0, sizeof(double) * h->d_xba.n, h->stream));
@@ -476,22 +536,24 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     HIP_TRY(hipMemcpyAsync(h->d_states.p, st0.data(), st0.size() * sizeof(LmState), hipMemcpyHostToDevice, h->stream));
     DevPtrs P = make_ptrs(h, o, stride);
     const int n_tiles = (int)h->tiles.size();
-    const size_t lds_tile_extra = h->lds_tile ? sizeof(double) * ((size_t)h->max_npose * (h->max_npose + 1) / 2 + 3 * (size_t)h->max_npose) : 0;
-    const size_t lds_build = tile_lds_bytes(h->max_n_kf) + lds_tile_extra;
-    const size_t lds_back = tile_lds_bytes(h->max_n_kf) + sizeof(double) * ((size_t)h->max_n_kf * 12 + MAX_TILE_LMK * 3);
-    const size_t lds_solve = sizeof(double) * ((size_t)h->max_np * (h->max_np + 1) / 2 + 4 * (size_t)h->max_np);
-    auto kb = h->factor_type == SADVIO_FACTOR_PIXEL ? (h->lds_tile ? k_build<0, true> : k_build<0, false>)
-                                                    : (h->lds_tile ? k_build<1, true> : k_build<1, false>);
+    const int mtk = h->max_tile_kf;
+    const size_t nt = 6 * (size_t)h->max_tile_free;
+    const size_t lds_build = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)BUILD_WAVES * STAGE_VALS * 64 + nt * (nt + 1) / 2 + 3 * nt) + 16;
+    const size_t lds_back = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)mtk * 18) + 16;
+    const size_t lds_solve = sizeof(double) * ((size_t)(h->max_np + 2) * 6 + (size_t)(h->max_np + 1) * (h->max_np + 2) / 2 +
+                                               4 * (size_t)h->max_np + (size_t)(h->max_np / 5 + 1) * 36) + 64;
+    auto kb = h->factor_type == SADVIO_FACTOR_PIXEL ? k_build<0> : k_build<1>;
     auto kk = h->factor_type == SADVIO_FACTOR_PIXEL ? k_backsub<0> : k_backsub<1>;
     HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
     HIP_TRY(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back));
     HIP_TRY(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
+    { ScopedTimer t(h, "k_init_tables"); hipLaunchKernelGGL(k_init_tables, dim3((h->n_kf_tot + 63) / 64), dim3(64), 0, h->stream, P, h->n_kf_tot); }
     for (int s = 0; s < slots; s++) {
-        { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s); }
+        { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk); }
         { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(k_solve, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
-        { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s); }
+        { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
     }
-    { ScopedTimer t(h, "k_final"); hipLaunchKernelGGL(k_final, dim3((n_win + 63) / 64), dim3(64), 0, h->stream, P, slots); }
+    { ScopedTimer t(h, "k_final"); hipLaunchKernelGGL(k_final, dim3(n_win), dim3(64), 0, h->stream, P, slots); }
     HIP_TRY(hipGetLastError());
     std::vector<LmState> fin(n_win);
     std::vector<IterAcc> acc0(n_win);
@@ -501,6 +563,14 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->cfg.profile_kernels) collect_timers(h);
+    if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 4096)) {
+        long long ts[64];
+        if (hipMemcpy(ts, h->d_dbg.p, sizeof(ts), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[sadvio dbg] phase dt (us):");
+            for (int i = 1; i < 16; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[0]) * 0.01);
+            fprintf(stderr, "  shader clock %.3f GHz\n", (double)(ts[21] - ts[20]) / ((ts[15] - ts[0]) * 10.0));
+        }
+    }
     h->last_slots = slots;
     h->solved = true;
     int rc = SADVIO_OK;

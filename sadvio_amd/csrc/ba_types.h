@@ -38,11 +38,26 @@ struct WinDev {
     int factor_type, has_imu;
 };
 
+// One workgroup of k_build / k_backsub: a run of consecutive landmarks of one window. Each landmark is
+// processed by a group of G consecutive lanes of one wave (lane q of the group owns the landmark's q-th
+// observation), so per-landmark reductions are lane shuffles. The key-frames the tile touches are listed
+// (sorted by global index) in tile_kf[kf_off .. kf_off + n_kf); obs_slot[o] indexes that list. The free
+// ones among them span the tile's private LDS copy of the reduced system (6 rows each).
 struct Tile {
-    int w;           // window
-    int lmk0, lmk1;  // global landmark range
-    int obs0, obs1;  // global observation range
-    int kmax;        // max observations of one landmark in the tile
+    int w;
+    int lmk0, lmk1;   // global landmark range
+    int G;            // lanes per landmark: power of two, 8 .. 64
+    int kf_off, n_kf; // slice of tile_kf / tile_row
+    int n_free;       // free key-frames in the slice: LDS tile dimension = 6 * n_free
+    int lds_mode;     // 1: accumulate in the LDS tile and flush; 0: global atomics (too many key-frames)
+    int dpf, Np;      // window's reduced layout
+    int red_off;
+    int cam_base, n_cam;
+    int first_of_window;
+    int kmax;         // max observations of one landmark in the tile (<= G)
+    int win_tile0, win_ntiles;  // the window's tile range (for summing per-tile partials)
+    int pad;
+    long long S_off;
 };
 
 struct PriorDev {
@@ -73,14 +88,22 @@ struct IterAcc {
     int pad;
 };
 
-constexpr int BUILD_THREADS = 256;
-constexpr int MAX_TILE_OBS = 256;  // one observation per thread
-constexpr int MAX_TILE_LMK = 64;
-constexpr int MAX_LDS_NPOSE = 120;  // 20 free key-frames x 6: lower triangle = 7260 doubles = 58 KB
-constexpr int MAX_LDS_KF = 64;      // key-frame table staged in LDS
-constexpr int OBS_STAGE = 26;       // Jp[12] Jl[6] r[2] N[6]
-constexpr int LMK_STAGE = 12;       // Minv[6] gl[3] pad[3]
-constexpr int SOLVE_THREADS = 256;
-constexpr int MAX_LDS_NP = 192;     // packed lower triangle 18528 doubles = 148 KB
+// Per-tile partial sums of one slot, written with plain stores by the tile's workgroup and summed by the
+// consumers (same-address FP64 atomics from ~1000 waves cost ~12 ns each, i.e. tens of microseconds).
+struct TileAcc {
+    double lin_cost, fixed_cost, gmax;          // k_build
+    double cand_cost, mcc, step_norm2, cand_norm2;  // k_backsub
+    double pad;
+};
+
+constexpr int BUILD_THREADS = 256;  // 4 waves; each wave owns 64 / G landmarks per round
+constexpr int BUILD_WAVES = BUILD_THREADS / 64;
+constexpr int MAX_TILE_KF = 24;      // key-frames (free + constant) a tile may touch
+constexpr int MAX_TILE_FREE_KF = 20; // free ones: LDS tile <= 120 x 121 / 2 doubles = 58 KB
+constexpr int MAX_WIN_CAM = 8;       // cameras per window staged in LDS
+constexpr int STAGE_VALS = 18;       // Jp[12] Jl[6] exchanged between the lanes of a landmark group
+constexpr int MAX_LMK_OBS = 64;      // observations per landmark (one lane each)
+constexpr int SOLVE_THREADS = 512;
+constexpr int MAX_LDS_NP = 174;     // packed lower triangle incl. rhs row + panel strip: ~150 KB
 
 }  // namespace sadvio

@@ -38,6 +38,43 @@ __device__ __forceinline__ void m3_tvec(const double* A, const double* v, double
 }
 __device__ __forceinline__ double v3_norm(const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
+// sin / cos of a double in registers. The ROCm device-library sin()/cos() cost ~20 us per call site on
+// gfx950 in this kernel mix (measured: 79 us for one pose table), far above the whole reduced solve, so the
+// closed forms are evaluated with the classic fdlibm kernels: Cody-Waite reduction by pi/2 (exact for
+// |x| < ~1e5, BA deltas are << 1 rad) + the degree-13/14 minimax polynomials on [-pi/4, pi/4] (< 1 ulp).
+__device__ __forceinline__ void sincos_f64(double x, double* sn, double* cs) {
+    const double invpio2 = 6.36619772367581382433e-01;
+    const double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+    const double pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21;
+    const double fn = rint(x * invpio2);
+    double t = x - fn * pio2_1;
+    double w = fn * pio2_2;
+    double r = t - w;
+    w = fn * pio2_2t - ((t - r) - w);
+    const double y0 = r - w;
+    const double y1 = (r - y0) - w;
+    (void)pio2_1t;
+    const double z = y0 * y0;
+    // kernel sin
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double v = z * y0;
+    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    // kernel cos
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double hz = 0.5 * z;
+    const double wc = 1.0 - hz;
+    const double kc = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+    const int q = ((int)fn) & 3;
+    const double s0 = (q & 1) ? kc : ks;
+    const double c0 = (q & 1) ? ks : kc;
+    *sn = (q & 2) ? -s0 : s0;
+    *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
 // geometry.h:17-23
 __device__ __forceinline__ void so3_skew(const double* w, double* S) {
     S[0] = 0; S[1] = -w[2]; S[2] = w[1];
@@ -52,8 +89,10 @@ __device__ __forceinline__ void so3_right_jacobian(const double* w, double* J) {
     double S[9], S2[9];
     so3_skew(w, S);
     m3_mul(S, S, S2);
-    double a = (1 - cos(n)) / (n * n);
-    double b = (n - sin(n)) / (n * n * n);
+    double sn, cs;
+    sincos_f64(n, &sn, &cs);
+    double a = (1 - cs) / (n * n);
+    double b = (n - sn) / (n * n * n);
 #pragma unroll
     for (int i = 0; i < 9; i++) J[i] = J[i] - a * S[i] + b * S2[i];
 }
@@ -72,7 +111,9 @@ __device__ __forceinline__ void so3_exp(const double* v, double* R) {
     double S2[9];
     so3_skew(axis, S);
     m3_mul(S, S, S2);
-    double c = 1. - cos(angle), s = sin(angle);
+    double sn_, cs_;
+    sincos_f64(angle, &sn_, &cs_);
+    double c = 1. - cs_, s = sn_;
 #pragma unroll
     for (int i = 0; i < 9; i++) R[i] += c * S2[i] + s * S[i];
 }
@@ -81,7 +122,9 @@ __device__ __forceinline__ void so3_log(const double* M, double* phi) {
     double cos_angle = 0.5 * (M[0] + M[4] + M[8]) - 0.5;
     cos_angle = fmin(fmax(cos_angle, -1.), 1.);
     double angle = acos(cos_angle);
-    double k = (fabs(sin(angle)) < 1e-9 || angle < 1e-9) ? 0.5 : 0.5 * angle / sin(angle);
+    double sa, ca;
+    sincos_f64(angle, &sa, &ca);
+    double k = (fabs(sa) < 1e-9 || angle < 1e-9) ? 0.5 : 0.5 * angle / sa;
     phi[0] = k * (M[7] - M[5]);
     phi[1] = k * (M[2] - M[6]);
     phi[2] = k * (M[3] - M[1]);

@@ -31,14 +31,25 @@ struct DevPtrs {
     const unsigned char* lmk_const;
     const int* lmk_ob; const int* lmk_oe;
     const int* obs_kf; const int* obs_cam; const double* obs_meas;
+    const unsigned char* obs_slot;  // index of the observation's key-frame in its tile's list
+    const int* tile_kf;             // per-tile key-frame lists (global indices)
+    const int* tile_row;            // matching row in the tile's LDS system (6 * rank among free) or -1
+    double* ptab;                   // [2][n_kf_tot][POSE_TAB] pose tables of the two delta buffers
+    long long ptab_stride;
     const PriorDev* priors;
     double* S; double* gred; double* gfull; double* hdiag; double* delta; double* s_pose;
     LmState* states;  // [n_win][slots+2]
-    IterAcc* acc;     // [n_win][slots+1]
+    IterAcc* acc;     // [n_win][slots+1] window totals (written by single workgroups only)
+    TileAcc* tacc;    // [2][n_tiles] per-tile partials, double-buffered by slot parity (no atomics)
+    int n_tiles;
     int state_stride;
     int n_win;
+    long long* dbg_ts;  // [64] phase timestamps (wall_clock64, 100 MHz) of workgroup 0 when debug & 4096
+    int debug;  // timing experiments only (SADVIO_DEBUG env): bit0 skip S blocks, bit1 skip flush, bit2 skip gradient
     SolveOpts o;
 };
+
+#define SADVIO_TS(slot_, idx_) do { if ((P.debug & 4096) && blockIdx.x == 0 && threadIdx.x == 0 && slot == (slot_)) P.dbg_ts[idx_] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
 
@@ -101,297 +112,318 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
-// ---- shared tile prologue: per-observation linearisation + per-landmark elimination -------------
-// LDS carve used by k_build and k_backsub.
-struct TileLds {
-    double* poseTab;   // [n_kf][POSE_TAB] at x
-    double* obsStage;  // [MAX_TILE_OBS][OBS_STAGE]
-    double* lmkStage;  // [MAX_TILE_LMK][LMK_STAGE]
-    int* obsPa;        // [MAX_TILE_OBS] pose tile row (free_kf*6) or -1
-    int* obsLmk;       // [MAX_TILE_OBS] local landmark index
-    double* red;       // [16] reduction scratch
+
+// Sum the k_backsub partials of a window's tiles (slot parity `par`) into `a`: executed by one wave.
+__device__ __forceinline__ void wave_sum_backsub_partials(const DevPtrs& P, int par, int tile0, int ntiles, int ln,
+                                                          double* out4) {
+    double c = 0.0, m = 0.0, sn = 0.0, cn = 0.0;
+    const TileAcc* ta = P.tacc + (long long)par * P.n_tiles + tile0;
+    for (int t = ln; t < ntiles; t += 64) {
+        c += ta[t].cand_cost; m += ta[t].mcc; sn += ta[t].step_norm2; cn += ta[t].cand_norm2;
+    }
+    c = wave_sum(c); m = wave_sum(m); sn = wave_sum(sn); cn = wave_sum(cn);
+    if (ln == 0) { out4[0] = c; out4[1] = m; out4[2] = sn; out4[3] = cn; }
+}
+
+// ---- landmark-group machinery shared by k_build and k_backsub ------------------------------------
+// Sum over the G lanes of a landmark group (G = power of two <= 64, groups aligned to G lanes).
+__device__ __forceinline__ double group_sum(double v, int G) {
+    for (int off = 1; off < G; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct ObsLin {
+    double r[2], Jp[12], Jl[6];
+    int row;      // row of the observing key-frame in the tile's LDS system, -1 if constant
+    int slot;     // index into the tile's key-frame list
+    bool valid;   // this lane owns an observation
+    bool counted; // the residual block belongs to the reduced program (some parameter block is free)
 };
 
+// Lane-local linearisation of observation `o` of landmark `gl` from LDS tables.
 template <int FACTOR>
-__device__ __forceinline__ void linearize_obs(const DevPtrs& P, const WinDev& W, const double* poseTab, int o,
-                                              int lmk, const double* pw, double* r, double* Jp, double* Jl,
-                                              bool lmk_free) {
-    int kf = P.obs_kf[o], cam = P.obs_cam[o];
-    const double* tab = poseTab + (kf - W.kf_base) * POSE_TAB;
-    const double* K = P.cam_K + 4 * cam;
-    const double* Tsf = P.cam_T + 12 * cam;
-    double isig = P.cam_isig[cam];
+__device__ __forceinline__ void lane_linearize(const DevPtrs& P, const double* poseTab, const double* camTab,
+                                               const int* rowTab, int cam_base, int o, const double* pw, bool lfree,
+                                               ObsLin& L) {
+    const int slot = P.obs_slot[o];
+    const int cam = P.obs_cam[o] - cam_base;
+    const double* tab = poseTab + slot * POSE_TAB;
+    const double* ct = camTab + cam * 17;  // K[4] Tsf[12] isig
+    L.slot = slot;
+    L.row = rowTab[slot];
     if (FACTOR == 0) {
         const double* m = P.obs_meas + 2 * (long long)o;
-        pixel_factor<true>(tab, K, Tsf, pw, m[0], m[1], isig, r, Jp, Jl);
+        pixel_factor<true>(tab, ct, ct + 4, pw, m[0], m[1], ct[16], L.r, L.Jp, L.Jl);
     } else {
         const double* m = P.obs_meas + 3 * (long long)o;
         double b[3] = {m[0], m[1], m[2]};
-        angular_factor<true>(tab, Tsf, pw, b, isig, r, Jp, Jl);
+        angular_factor<true>(tab, ct + 4, pw, b, ct[16], L.r, L.Jp, L.Jl);
     }
-    if (P.kf_fidx[kf] < 0) {
+    if (L.row < 0) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) Jp[i] = 0.0;
+        for (int i = 0; i < 12; i++) L.Jp[i] = 0.0;
     }
-    if (!lmk_free) {
+    if (!lfree) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) Jl[i] = 0.0;
+        for (int i = 0; i < 6; i++) L.Jl[i] = 0.0;
     }
+    L.counted = (L.row >= 0) || lfree;
+    if (!L.counted) { /* fixed cost: caller accounts r, then it leaves the program */ }
 }
 
-// Stage pose table, linearise the tile's observations into LDS, eliminate its landmarks.
-// After this: obsStage[a] = {Jp, Jl, r, N = Jl Minv}, lmkStage[l] = {Minv(6), gl(3)}.
-// Returns this thread's partial (sum r^2, fixed r^2, max |g_l|) through out params.
-template <int FACTOR>
-__device__ __forceinline__ void tile_prologue(const DevPtrs& P, const WinDev& W, const Tile& T, const TileLds& L,
-                                              int cur, double radius, bool write_scale, double& cost_part,
-                                              double& fixed_part, double& gmax_part) {
+// Per-landmark elimination, every lane of the group redundantly: H_ll, g_l (group sums), LM damping,
+// Minv (symmetric 6-vector). Returns whether the landmark has a parameter block in the program.
+__device__ __forceinline__ bool group_eliminate(const DevPtrs& P, const ObsLin& L, int G, int gl, bool lmk_valid,
+                                                bool lfree, int nobs, double radius, bool write_scale, bool leader,
+                                                double* Mi, double* g) {
+    double H[6];
+    H[0] = L.Jl[0] * L.Jl[0] + L.Jl[3] * L.Jl[3];
+    H[1] = L.Jl[0] * L.Jl[1] + L.Jl[3] * L.Jl[4];
+    H[2] = L.Jl[0] * L.Jl[2] + L.Jl[3] * L.Jl[5];
+    H[3] = L.Jl[1] * L.Jl[1] + L.Jl[4] * L.Jl[4];
+    H[4] = L.Jl[1] * L.Jl[2] + L.Jl[4] * L.Jl[5];
+    H[5] = L.Jl[2] * L.Jl[2] + L.Jl[5] * L.Jl[5];
+    g[0] = L.Jl[0] * L.r[0] + L.Jl[3] * L.r[1];
+    g[1] = L.Jl[1] * L.r[0] + L.Jl[4] * L.r[1];
+    g[2] = L.Jl[2] * L.r[0] + L.Jl[5] * L.r[1];
+#pragma unroll
+    for (int i = 0; i < 6; i++) H[i] = group_sum(H[i], G);
+#pragma unroll
+    for (int i = 0; i < 3; i++) g[i] = group_sum(g[i], G);
+    const bool active = lmk_valid && lfree && nobs > 0;
+    if (!active) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) Mi[i] = 0.0;
+        return false;
+    }
+    double s[3];
+    if (write_scale) {
+        s[0] = P.o.jacobi_scaling ? 1.0 / (1.0 + sqrt(H[0])) : 1.0;
+        s[1] = P.o.jacobi_scaling ? 1.0 / (1.0 + sqrt(H[3])) : 1.0;
+        s[2] = P.o.jacobi_scaling ? 1.0 / (1.0 + sqrt(H[5])) : 1.0;
+        if (leader) {
+            P.s_lmk[3 * (long long)gl] = s[0]; P.s_lmk[3 * (long long)gl + 1] = s[1]; P.s_lmk[3 * (long long)gl + 2] = s[2];
+        }
+    } else {
+        s[0] = P.s_lmk[3 * (long long)gl]; s[1] = P.s_lmk[3 * (long long)gl + 1]; s[2] = P.s_lmk[3 * (long long)gl + 2];
+    }
+    const double ir = 1.0 / radius;
+    const double s0 = s[0] * s[0], s1 = s[1] * s[1], s2 = s[2] * s[2];
+    double M[6] = {H[0], H[1], H[2], H[3], H[4], H[5]};
+    M[0] += fmin(fmax(s0 * H[0], P.o.min_lm_diagonal), P.o.max_lm_diagonal) * ir / s0;
+    M[3] += fmin(fmax(s1 * H[3], P.o.min_lm_diagonal), P.o.max_lm_diagonal) * ir / s1;
+    M[5] += fmin(fmax(s2 * H[5], P.o.min_lm_diagonal), P.o.max_lm_diagonal) * ir / s2;
+    sym3_inverse(M, Mi);
+    return true;
+}
+
+// Stage the tile's key-frame pose tables (buffer `buf`) and the window's cameras into LDS.
+__device__ __forceinline__ void stage_tables(const DevPtrs& P, const Tile& T, int buf, double* poseTab, double* camTab,
+                                             int* rowTab) {
     const int tid = threadIdx.x;
-    const double* xp = P.xp + (long long)cur * P.xp_stride;
-    const double* xl = P.xl + (long long)cur * P.xl_stride;
-    for (int k = tid; k < W.n_kf; k += blockDim.x) {
-        int g = W.kf_base + k;
-        double d6[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) d6[i] = xp[6 * (long long)g + i];
-        pose_table_entry(P.kf_T0 + 12 * (long long)g, d6, L.poseTab + k * POSE_TAB);
+    const double* src = P.ptab + (long long)buf * P.ptab_stride;
+    for (int i = tid; i < T.n_kf * POSE_TAB; i += blockDim.x) {
+        const int k = i / POSE_TAB, e = i - k * POSE_TAB;
+        poseTab[i] = src[(long long)P.tile_kf[T.kf_off + k] * POSE_TAB + e];
     }
-    // map observation -> local landmark (thread per landmark writes its range)
-    int nl = T.lmk1 - T.lmk0;
-    for (int l = tid; l < nl; l += blockDim.x) {
-        int gl = T.lmk0 + l;
-        for (int o = P.lmk_ob[gl]; o < P.lmk_oe[gl]; o++) L.obsLmk[o - T.obs0] = l;
+    for (int i = tid; i < T.n_cam * 17; i += blockDim.x) {
+        const int c = i / 17, e = i - 17 * c;
+        const int gc = T.cam_base + c;
+        camTab[i] = e < 4 ? P.cam_K[4 * (long long)gc + e] : (e < 16 ? P.cam_T[12 * (long long)gc + e - 4] : P.cam_isig[gc]);
     }
-    __syncthreads();
-    int no = T.obs1 - T.obs0;
-    cost_part = 0; fixed_part = 0; gmax_part = 0;
-    for (int a = tid; a < no; a += blockDim.x) {
-        int o = T.obs0 + a;
-        int l = L.obsLmk[a];
-        int gl = T.lmk0 + l;
-        bool lfree = !(P.lmk_const && P.lmk_const[gl]);
-        double pw[3] = {P.lmk_p[3 * (long long)gl] + xl[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1] + xl[3 * (long long)gl + 1],
-                        P.lmk_p[3 * (long long)gl + 2] + xl[3 * (long long)gl + 2]};
-        double r[2], Jp[12], Jl[6];
-        linearize_obs<FACTOR>(P, W, L.poseTab, o, gl, pw, r, Jp, Jl, lfree);
-        int fi = P.kf_fidx[P.obs_kf[o]];
-        L.obsPa[a] = fi < 0 ? -1 : fi * 6;
-        double* st = L.obsStage + a * OBS_STAGE;
-        if (fi < 0 && !lfree) {  // every parameter block constant: fixed cost, not part of the program
-            fixed_part += r[0] * r[0] + r[1] * r[1];
-            r[0] = 0; r[1] = 0;
-        } else {
-            cost_part += r[0] * r[0] + r[1] * r[1];
-        }
-#pragma unroll
-        for (int i = 0; i < 12; i++) st[i] = Jp[i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) st[12 + i] = Jl[i];
-        st[18] = r[0]; st[19] = r[1];
-    }
-    __syncthreads();
-    // per landmark: H_ll, g_l, LM damping, inverse
-    for (int l = tid; l < nl; l += blockDim.x) {
-        int gl = T.lmk0 + l;
-        double H[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-        int o0 = P.lmk_ob[gl] - T.obs0, o1 = P.lmk_oe[gl] - T.obs0;
-        for (int a = o0; a < o1; a++) {
-            const double* st = L.obsStage + a * OBS_STAGE;
-            const double* Jl = st + 12;
-            double r0 = st[18], r1 = st[19];
-            H[0] += Jl[0] * Jl[0] + Jl[3] * Jl[3];
-            H[1] += Jl[0] * Jl[1] + Jl[3] * Jl[4];
-            H[2] += Jl[0] * Jl[2] + Jl[3] * Jl[5];
-            H[3] += Jl[1] * Jl[1] + Jl[4] * Jl[4];
-            H[4] += Jl[1] * Jl[2] + Jl[4] * Jl[5];
-            H[5] += Jl[2] * Jl[2] + Jl[5] * Jl[5];
-            g[0] += Jl[0] * r0 + Jl[3] * r1;
-            g[1] += Jl[1] * r0 + Jl[4] * r1;
-            g[2] += Jl[2] * r0 + Jl[5] * r1;
-        }
-        bool active = (o1 > o0) && !(P.lmk_const && P.lmk_const[gl]);
-        double* ls = L.lmkStage + l * LMK_STAGE;
-        if (active) {
-            double s[3];
-            if (write_scale) {
-                s[0] = P.o.jacobi_scaling ? 1.0 / (1.0 + sqrt(H[0])) : 1.0;
-                s[1] = P.o.jacobi_scaling ? 1.0 / (1.0 + sqrt(H[3])) : 1.0;
-                s[2] = P.o.jacobi_scaling ? 1.0 / (1.0 + sqrt(H[5])) : 1.0;
-                P.s_lmk[3 * (long long)gl] = s[0]; P.s_lmk[3 * (long long)gl + 1] = s[1]; P.s_lmk[3 * (long long)gl + 2] = s[2];
-            } else {
-                s[0] = P.s_lmk[3 * (long long)gl]; s[1] = P.s_lmk[3 * (long long)gl + 1]; s[2] = P.s_lmk[3 * (long long)gl + 2];
-            }
-            double ir = 1.0 / radius;
-            double s0 = s[0] * s[0], s1 = s[1] * s[1], s2 = s[2] * s[2];
-            double M[6] = {H[0], H[1], H[2], H[3], H[4], H[5]};
-            M[0] += fmin(fmax(s0 * H[0], P.o.min_lm_diagonal), P.o.max_lm_diagonal) * ir / s0;
-            M[3] += fmin(fmax(s1 * H[3], P.o.min_lm_diagonal), P.o.max_lm_diagonal) * ir / s1;
-            M[5] += fmin(fmax(s2 * H[5], P.o.min_lm_diagonal), P.o.max_lm_diagonal) * ir / s2;
-            double Mi[6];
-            sym3_inverse(M, Mi);
-#pragma unroll
-            for (int i = 0; i < 6; i++) ls[i] = Mi[i];
-            gmax_part = fmax(gmax_part, fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2]))));
-        } else {
-#pragma unroll
-            for (int i = 0; i < 6; i++) ls[i] = 0.0;
-        }
-        ls[6] = g[0]; ls[7] = g[1]; ls[8] = g[2];
-    }
-    __syncthreads();
-    // N_a = Jl_a Minv (2x3)
-    for (int a = tid; a < no; a += blockDim.x) {
-        double* st = L.obsStage + a * OBS_STAGE;
-        const double* Mi = L.lmkStage + L.obsLmk[a] * LMK_STAGE;
-        const double* Jl = st + 12;
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            double j0 = Jl[3 * q], j1 = Jl[3 * q + 1], j2 = Jl[3 * q + 2];
-            st[20 + 3 * q] = j0 * Mi[0] + j1 * Mi[1] + j2 * Mi[2];
-            st[20 + 3 * q + 1] = j0 * Mi[1] + j1 * Mi[3] + j2 * Mi[4];
-            st[20 + 3 * q + 2] = j0 * Mi[2] + j1 * Mi[4] + j2 * Mi[5];
-        }
-    }
-    __syncthreads();
+    for (int i = tid; i < T.n_kf; i += blockDim.x) rowTab[i] = P.tile_row[T.kf_off + i];
 }
 
-__device__ __forceinline__ size_t tile_lds_carve(char* smem, int n_kf, TileLds& L) {
-    size_t off = 0;
-    L.poseTab = (double*)(smem + off); off += sizeof(double) * (size_t)n_kf * POSE_TAB;
-    L.obsStage = (double*)(smem + off); off += sizeof(double) * MAX_TILE_OBS * OBS_STAGE;
-    L.lmkStage = (double*)(smem + off); off += sizeof(double) * MAX_TILE_LMK * LMK_STAGE;
-    L.red = (double*)(smem + off); off += sizeof(double) * 16;
-    L.obsPa = (int*)(smem + off); off += sizeof(int) * MAX_TILE_OBS;
-    L.obsLmk = (int*)(smem + off); off += sizeof(int) * MAX_TILE_OBS;
-    off = (off + 15) & ~(size_t)15;
-    return off;
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS traffic between lanes of ONE wave: order this wave's stores before its later loads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-inline size_t tile_lds_bytes(int n_kf) {
-    size_t off = sizeof(double) * ((size_t)n_kf * POSE_TAB + MAX_TILE_OBS * OBS_STAGE + MAX_TILE_LMK * LMK_STAGE + 16) +
-                 sizeof(int) * 2 * MAX_TILE_OBS;
-    return (off + 15) & ~(size_t)15;
+
+__host__ __device__ inline size_t tile_tables_bytes(int n_kf) {
+    size_t b = sizeof(double) * ((size_t)n_kf * POSE_TAB + MAX_WIN_CAM * 17) + sizeof(int) * (size_t)MAX_TILE_KF;
+    return (b + 15) & ~(size_t)15;
 }
 
 // ---- K5: build the reduced system ----------------------------------------------------------------
-// LDS_TILE = true : the window's pose block (<= MAX_LDS_NPOSE) is accumulated in an LDS lower-triangular
-//                   tile with ds_add_f64 and flushed once per workgroup;
-// LDS_TILE = false: contributions go straight to HBM with global_atomic_add_f64 (large windows).
-template <int FACTOR, bool LDS_TILE>
-__global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot) {
+template <int FACTOR>
+__global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, int max_tile_kf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Tile T = P.tiles[blockIdx.x];
-    const WinDev W = P.win[T.w];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    __shared__ double s_part[BUILD_WAVES * 4];
     LmState st;
     if (slot == 0) st = P.states[(long long)T.w * P.state_stride];
-    else st = lm_decide(P.states[(long long)T.w * P.state_stride + slot - 1], P.acc[(long long)T.w * P.state_stride + slot - 1], P.o);
-    if (slot > 0 && (int)blockIdx.x == W.tile_begin && tid == 0) P.states[(long long)T.w * P.state_stride + slot] = st;
-    if (st.done) return;
-
-    TileLds L;
-    size_t off = tile_lds_carve(smem, W.n_kf, L);
-    double* Stile = (double*)(smem + off);
-    const int Nt = W.Npose;
-    const int tri_n = Nt * (Nt + 1) / 2;
-    double* gT = Stile + (LDS_TILE ? tri_n : 0);  // reduced gradient
-    double* gfT = gT + (LDS_TILE ? Nt : 0);       // full gradient
-    double* hdT = gfT + (LDS_TILE ? Nt : 0);      // diag(H_pp)
-    if (LDS_TILE)
-        for (int i = tid; i < tri_n + 3 * Nt; i += blockDim.x) Stile[i] = 0.0;
-
-    double cost_part, fixed_part, gmax_part;
-    tile_prologue<FACTOR>(P, W, T, L, st.cur, st.radius, slot == 0, cost_part, fixed_part, gmax_part);
-
-    double* Sg = P.S + W.S_off;
-    double* gredg = P.gred + W.red_off;
-    double* gfullg = P.gfull + W.red_off;
-    double* hdg = P.hdiag + W.red_off;
-    const int dpf = W.dpf, Np = W.Np;
-    const int no = T.obs1 - T.obs0;
-
-    // gradient + diag(H_pp): thread per (obs, i)
-    for (int it = tid; it < no * 6; it += blockDim.x) {
-        int a = it / 6, i = it - 6 * a;
-        int pa = L.obsPa[a];
-        if (pa < 0) continue;
-        const double* s = L.obsStage + a * OBS_STAGE;
-        const double* gl = L.lmkStage + L.obsLmk[a] * LMK_STAGE + 6;
-        double j0 = s[i], j1 = s[6 + i];
-        // r~ = r - N g_l
-        double rt0 = s[18] - (s[20] * gl[0] + s[21] * gl[1] + s[22] * gl[2]);
-        double rt1 = s[19] - (s[23] * gl[0] + s[24] * gl[1] + s[25] * gl[2]);
-        double gr = j0 * rt0 + j1 * rt1;
-        double gf = j0 * s[18] + j1 * s[19];
-        double hd = j0 * j0 + j1 * j1;
-        if (LDS_TILE) {
-            atomic_add_f64(&gT[pa + i], gr);
-            atomic_add_f64(&gfT[pa + i], gf);
-            atomic_add_f64(&hdT[pa + i], hd);
-        } else {
-            int row = (pa / 6) * dpf + i;
-            atomic_add_f64(&gredg[row], gr);
-            atomic_add_f64(&gfullg[row], gf);
-            atomic_add_f64(&hdg[row], hd);
-        }
-    }
-    // S blocks: item = (a, b-offset, row i): row i of Jp_a^T W_ab Jp_b, W_ab = delta_ab I - N_a Jl_b^T
-    const int kmax = T.kmax;
-    const int items = no * kmax * 6;
-    for (int it = tid; it < items; it += blockDim.x) {
-        int a = it / (kmax * 6);
-        int rem = it - a * kmax * 6;
-        int bo = rem / 6, i = rem - 6 * bo;
-        int pa = L.obsPa[a];
-        if (pa < 0) continue;
-        int gl = T.lmk0 + L.obsLmk[a];
-        int b = P.lmk_ob[gl] - T.obs0 + bo;
-        if (b >= P.lmk_oe[gl] - T.obs0) continue;
-        int pb = L.obsPa[b];
-        if (pb < 0 || pb > pa) continue;  // lower triangle only (block row >= block col)
-        const double* sa = L.obsStage + a * OBS_STAGE;
-        const double* sb = L.obsStage + b * OBS_STAGE;
-        const double* Na = sa + 20;
-        const double* Jlb = sb + 12;
-        double w00 = -(Na[0] * Jlb[0] + Na[1] * Jlb[1] + Na[2] * Jlb[2]);
-        double w01 = -(Na[0] * Jlb[3] + Na[1] * Jlb[4] + Na[2] * Jlb[5]);
-        double w10 = -(Na[3] * Jlb[0] + Na[4] * Jlb[1] + Na[5] * Jlb[2]);
-        double w11 = -(Na[3] * Jlb[3] + Na[4] * Jlb[4] + Na[5] * Jlb[5]);
-        if (a == b) { w00 += 1.0; w11 += 1.0; }
-        double c0 = sa[i] * w00 + sa[6 + i] * w10;
-        double c1 = sa[i] * w01 + sa[6 + i] * w11;
-        int row = pa + i;
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            int col = pb + j;
-            if (col > row) continue;  // within a diagonal block keep the lower part
-            double v = c0 * sb[j] + c1 * sb[6 + j];
-            if (LDS_TILE) atomic_add_f64(&Stile[tri(row, col)], v);
-            else atomic_add_f64(&Sg[(long long)((pa / 6) * dpf + i) * Np + (pb / 6) * dpf + j], v);
-        }
-    }
-    // cost / gradient-max reduction
-    double c = wave_sum(cost_part), f = wave_sum(fixed_part), gm = wave_max(gmax_part);
-    IterAcc* acc = P.acc + (long long)T.w * P.state_stride + slot;
-    if ((tid & 63) == 0) {
-        if (c != 0.0) atomic_add_f64(&acc->lin_cost, c);
-        if (slot == 0 && f != 0.0) atomic_add_f64(&acc->fixed_cost, f);
-        atomic_max_u64(&acc->gmax_bits, (unsigned long long)__double_as_longlong(gm));
-    }
-    if (LDS_TILE) {
+    else {
+        // totals of the previous slot = window part (k_solve) + the tiles' k_backsub partials
+        if (wv == 0) wave_sum_backsub_partials(P, (slot - 1) & 1, T.win_tile0, T.win_ntiles, ln, s_part);
         __syncthreads();
-        // flush non-zeros: tile (row, col) -> global (row/6*dpf + row%6, col/6*dpf + col%6)
-        for (int idx = tid; idx < tri_n; idx += blockDim.x) {
-            double v = Stile[idx];
-            if (v == 0.0) continue;
-            // invert tri(): row = floor((sqrt(8 idx + 1) - 1) / 2)
-            int row = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-            while (tri(row + 1, 0) <= idx) row++;
-            while (tri(row, 0) > idx) row--;
-            int col = idx - tri(row, 0);
-            atomic_add_f64(&Sg[(long long)((row / 6) * dpf + row % 6) * Np + (col / 6) * dpf + col % 6], v);
+        IterAcc a = P.acc[(long long)T.w * P.state_stride + slot - 1];
+        a.cand_cost += s_part[0]; a.mcc += s_part[1]; a.step_norm2 += s_part[2]; a.cand_norm2 += s_part[3];
+        st = lm_decide(P.states[(long long)T.w * P.state_stride + slot - 1], a, P.o);
+        __syncthreads();  // s_part is reused below
+    }
+    if (slot > 0 && T.first_of_window && tid == 0) P.states[(long long)T.w * P.state_stride + slot] = st;
+    if (st.done) return;
+    // LDS carve
+    double* poseTab = (double*)smem;
+    double* camTab = poseTab + (size_t)max_tile_kf * POSE_TAB;
+    int* rowTab = (int*)(camTab + MAX_WIN_CAM * 17);
+    double* stage = (double*)(smem + tile_tables_bytes(max_tile_kf));  // [BUILD_WAVES][STAGE_VALS][64]
+    double* Stile = stage + BUILD_WAVES * STAGE_VALS * 64;
+    const int Nt = 6 * T.n_free;
+    const int tri_n = Nt * (Nt + 1) / 2;
+    double* gT = Stile + tri_n;
+    double* gfT = gT + Nt;
+    double* hdT = gfT + Nt;
+    const bool lds_mode = T.lds_mode != 0;
+    stage_tables(P, T, st.cur, poseTab, camTab, rowTab);
+    if (lds_mode)
+        for (int i = tid; i < tri_n + 3 * Nt; i += blockDim.x) Stile[i] = 0.0;
+    __syncthreads();
+
+    double* Sg = P.S + T.S_off;
+    double* gredg = P.gred + T.red_off;
+    double* gfullg = P.gfull + T.red_off;
+    double* hdg = P.hdiag + T.red_off;
+    const int dpf = T.dpf, Np = T.Np;
+    const int G = T.G, lpw = 64 / G;
+    const int grp = ln / G, q = ln - grp * G;
+    const int nl = T.lmk1 - T.lmk0;
+    const double* xl = P.xl + (long long)st.cur * P.xl_stride;
+    double* wstage = stage + wv * STAGE_VALS * 64;
+    double cost_part = 0.0, fixed_part = 0.0, gmax_part = 0.0;
+    for (int base = wv * lpw; base < nl; base += BUILD_WAVES * lpw) {
+        const int lm = base + grp;
+        const bool lmk_valid = lm < nl;
+        const int gl = T.lmk0 + (lmk_valid ? lm : 0);
+        const int ob = P.lmk_ob[gl], oe = P.lmk_oe[gl];
+        const int nobs = lmk_valid ? oe - ob : 0;
+        const bool lfree = !(P.lmk_const && P.lmk_const[gl]);
+        ObsLin L;
+        L.valid = q < nobs;
+        L.row = -1; L.slot = 0; L.counted = false;
+        if (L.valid) {
+            const double pw[3] = {P.lmk_p[3 * (long long)gl] + xl[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1] + xl[3 * (long long)gl + 1],
+                                  P.lmk_p[3 * (long long)gl + 2] + xl[3 * (long long)gl + 2]};
+            lane_linearize<FACTOR>(P, poseTab, camTab, rowTab, T.cam_base, ob + q, pw, lfree, L);
+            const double c = L.r[0] * L.r[0] + L.r[1] * L.r[1];
+            if (L.counted) cost_part += c;
+            else { fixed_part += c; L.r[0] = 0.0; L.r[1] = 0.0; }
+        } else {
+            L.r[0] = L.r[1] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 12; i++) L.Jp[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) L.Jl[i] = 0.0;
+        }
+        double Mi[6], g[3];
+        const bool active = group_eliminate(P, L, G, gl, lmk_valid, lfree, nobs, st.radius, slot == 0, q == 0, Mi, g);
+        if (active && q == 0) gmax_part = fmax(gmax_part, fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2]))));
+        // N = Jl Minv (2x3), reduced residual r~ = r - N g_l
+        double N[6];
+#pragma unroll
+        for (int qq = 0; qq < 2; qq++) {
+            const double j0 = L.Jl[3 * qq], j1 = L.Jl[3 * qq + 1], j2 = L.Jl[3 * qq + 2];
+            N[3 * qq] = j0 * Mi[0] + j1 * Mi[1] + j2 * Mi[2];
+            N[3 * qq + 1] = j0 * Mi[1] + j1 * Mi[3] + j2 * Mi[4];
+            N[3 * qq + 2] = j0 * Mi[2] + j1 * Mi[4] + j2 * Mi[5];
+        }
+        // exchange Jp / Jl with the other lanes of the group through the wave's private LDS strip
+#pragma unroll
+        for (int i = 0; i < 12; i++) wstage[i * 64 + ln] = L.Jp[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) wstage[(12 + i) * 64 + ln] = L.Jl[i];
+        wave_lds_fence();
+        if (L.valid && L.row >= 0) {
+            const double rt0 = L.r[0] - (N[0] * g[0] + N[1] * g[1] + N[2] * g[2]);
+            const double rt1 = L.r[1] - (N[3] * g[0] + N[4] * g[1] + N[5] * g[2]);
+            const int pa = L.row;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double j0 = L.Jp[i], j1 = L.Jp[6 + i];
+                const double gr = j0 * rt0 + j1 * rt1;
+                const double gf = j0 * L.r[0] + j1 * L.r[1];
+                const double hd = j0 * j0 + j1 * j1;
+                if (lds_mode) {
+                    atomic_add_f64(&gT[pa + i], gr); atomic_add_f64(&gfT[pa + i], gf); atomic_add_f64(&hdT[pa + i], hd);
+                } else {
+                    const int row = (pa / 6) * dpf + i;
+                    atomic_add_f64(&gredg[row], gr); atomic_add_f64(&gfullg[row], gf); atomic_add_f64(&hdg[row], hd);
+                }
+            }
+        }
+        // S blocks: lane a adds rows of Jp_a^T W_ab Jp_b for every partner b of its landmark whose block is
+        // on or below the diagonal; W_ab = delta_ab I - N_a Jl_b^T
+        if (!(P.debug & 1)) {
+            for (int b = 0; b < T.kmax; b++) {  // wave-uniform bound: the shuffle below is convergent
+                const int lb = grp * G + b;  // partner lane
+                const int pb = __shfl(L.row, lb, 64);
+                if (!(L.valid && L.row >= 0) || b >= nobs || pb < 0 || pb > L.row) continue;
+                double Jpb[12], Jlb[6];
+#pragma unroll
+                for (int i = 0; i < 12; i++) Jpb[i] = wstage[i * 64 + lb];
+#pragma unroll
+                for (int i = 0; i < 6; i++) Jlb[i] = wstage[(12 + i) * 64 + lb];
+                double w00 = -(N[0] * Jlb[0] + N[1] * Jlb[1] + N[2] * Jlb[2]);
+                double w01 = -(N[0] * Jlb[3] + N[1] * Jlb[4] + N[2] * Jlb[5]);
+                double w10 = -(N[3] * Jlb[0] + N[4] * Jlb[1] + N[5] * Jlb[2]);
+                double w11 = -(N[3] * Jlb[3] + N[4] * Jlb[4] + N[5] * Jlb[5]);
+                if (b == q) { w00 += 1.0; w11 += 1.0; }
+                const int pa = L.row;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const double c0 = L.Jp[i] * w00 + L.Jp[6 + i] * w10;
+                    const double c1 = L.Jp[i] * w01 + L.Jp[6 + i] * w11;
+                    const int row = pa + i;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        const int col = pb + j;
+                        if (col > row) continue;
+                        const double v = c0 * Jpb[j] + c1 * Jpb[6 + j];
+                        if (lds_mode) atomic_add_f64(&Stile[tri(row, col)], v);
+                        else atomic_add_f64(&Sg[tri((pa / 6) * dpf + i, (pb / 6) * dpf + j)], v);
+                    }
+                }
+            }
+        }
+        wave_lds_fence();  // the strip is reused by the next round
+    }
+    // cost / gradient-max: per-tile partial, plain store (no same-address atomics across the chip)
+    const double c = wave_sum(cost_part), f = wave_sum(fixed_part), gm = wave_max(gmax_part);
+    if (ln == 0) { s_part[wv * 4] = c; s_part[wv * 4 + 1] = f; s_part[wv * 4 + 2] = gm; }
+    __syncthreads();
+    if (tid == 0) {
+        double cs = 0.0, fs = 0.0, gs = 0.0;
+        for (int k = 0; k < BUILD_WAVES; k++) { cs += s_part[k * 4]; fs += s_part[k * 4 + 1]; gs = fmax(gs, s_part[k * 4 + 2]); }
+        TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + blockIdx.x;
+        ta->lin_cost = cs; ta->fixed_cost = fs; ta->gmax = gs;
+    }
+    if (lds_mode) {
+        if (P.debug & 2) return;
+        // flush non-zeros; in lds_mode rowTab rows are 6*rank with the list sorted by global index, so the
+        // local lower triangle maps onto the global lower triangle. One wave per row, lanes along the row.
+        int* growTab = (int*)stage;  // local row -> global row (stage strip is free now)
+        for (int k = tid; k < T.n_kf; k += blockDim.x) {
+            const int r = rowTab[k];
+            if (r >= 0) {
+                const int fi = P.kf_fidx[P.tile_kf[T.kf_off + k]];
+#pragma unroll
+                for (int i = 0; i < 6; i++) growTab[r + i] = fi * dpf + i;
+            }
+        }
+        __syncthreads();
+        for (int row = wv; row < Nt; row += BUILD_WAVES) {
+            const int grow = tri(growTab[row], 0);
+            const double* srow = Stile + tri(row, 0);
+            for (int col = ln; col <= row; col += 64) {
+                const double v = srow[col];
+                if (v != 0.0) atomic_add_f64(&Sg[grow + growTab[col]], v);
+            }
         }
         for (int i = tid; i < Nt; i += blockDim.x) {
-            int row = (i / 6) * dpf + i % 6;
+            const int row = growTab[i];
             if (gT[i] != 0.0) atomic_add_f64(&gredg[row], gT[i]);
             if (gfT[i] != 0.0) atomic_add_f64(&gfullg[row], gfT[i]);
             if (hdT[i] != 0.0) atomic_add_f64(&hdg[row], hdT[i]);
@@ -399,49 +431,292 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot) {
     }
 }
 
+// Blocked right-looking Cholesky of the packed lower-triangular matrix P ((N+1) rows: row N is the
+// right-hand side, so the forward substitution comes for free) followed by block back-substitution.
+// The scalar sqrt / divide chain of the pivots bounds the latency, so it gets a wave of its own:
+//   * wave 0 ("pivot wave") works one block column AHEAD: while waves 1.. apply the trailing update of
+//     block column k, it updates pivot k+1 (one lane per element, gathered with v_readlane), factors it
+//     with a hand-rolled rsqrt (v_rsq_f64 + 2 Newton steps) and publishes the inverse factor;
+//   * the panel L_rk = A_rk Linv^T is also written to a transposed strip LpT[c][row] that the trailing
+//     update reads with unit stride; 4x2 register micro-tiles;
+//   * two workgroup barriers per block column, one per back-substitution step.
+// On return xs = S^-1 rhs. Returns false if a pivot is not positive.
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    // two Newton steps: y <- y + y * (1 - d y^2) / 2
+    double e = __builtin_fma(-d * y, y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    e = __builtin_fma(-d * y, y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    return y;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int NBP = 6;  // rows of the transposed panel strip (max NB)
+
+template <int NB>
+__device__ __forceinline__ void factor_pivot(double (&Lk)[NB][NB], double (&Li)[NB][NB], bool& bad) {
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+        double d = Lk[j][j];
+#pragma unroll
+        for (int q = 0; q < j; q++) d -= Lk[j][q] * Lk[j][q];
+        if (!(d > 0.0) || !isfinite(d)) bad = true;
+        double inv = rsqrt_nr(d);
+        Lk[j][j] = d * inv;
+        Li[j][j] = inv;
+#pragma unroll
+        for (int i = j + 1; i < NB; i++) {
+            double t = Lk[i][j];
+#pragma unroll
+            for (int q = 0; q < j; q++) t -= Lk[i][q] * Lk[j][q];
+            Lk[i][j] = t * inv;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; j++)
+#pragma unroll
+        for (int i = j + 1; i < NB; i++) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = j; q < i; q++) t -= Lk[i][q] * Li[q][j];
+            Li[i][j] = t * Li[i][i];
+        }
+}
+
+// Pivot wave: element (i, j), i >= j, of the NB x NB block at row/col `s0`, optionally minus the rank-NB
+// update from the panel strip; one lane per element, then every lane gets all elements (uniform).
+template <int NB, bool UPDATE>
+__device__ __forceinline__ void pivot_gather_factor(const double* P, const double* LpT, int ldp, int s0, int ln,
+                                                    double* linv_out, bool& bad) {
+    constexpr int NE = NB * (NB + 1) / 2;
+    // lane -> (i, j)
+    int i = 0, j = 0;
+    {
+        int e = ln < NE ? ln : 0, r = 0;
+        while (e >= r + 1) { e -= r + 1; r++; }
+        i = r; j = e;
+    }
+    double acc = P[tri(s0 + i, s0 + j)];
+    if (UPDATE) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) acc -= LpT[c * ldp + i] * LpT[c * ldp + j];
+    }
+    double Lk[NB][NB], Li[NB][NB];
+    {
+        int e = 0;
+#pragma unroll
+        for (int ii = 0; ii < NB; ii++)
+#pragma unroll
+            for (int jj = 0; jj <= ii; jj++) { Lk[ii][jj] = readlane_f64(acc, e); e++; }
+    }
+    factor_pivot<NB>(Lk, Li, bad);
+    // publish the inverse factor: lane e stores element e (values are wave-uniform, select by lane)
+    {
+        double v = 0.0;
+        int e = 0;
+#pragma unroll
+        for (int ii = 0; ii < NB; ii++)
+#pragma unroll
+            for (int jj = 0; jj <= ii; jj++) { if (ln == e) v = Li[ii][jj]; e++; }
+        if (ln < NE) linv_out[i * NB + j] = v;
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, double* xs, double* LpT,
+                                                  double* linvTab, long long* ts) {
+    const int tid = threadIdx.x, nt = blockDim.x, ln = tid & 63;
+    const int nblk = N / NB;
+    const int ldp = N + 2;
+    __shared__ int s_bad;
+    if (tid == 0) s_bad = 0;
+    for (int i = tid; i < nblk * NB * NB; i += nt) linvTab[i] = 0.0;
+    __syncthreads();
+    if (tid < 64) {
+        bool bad = false;
+        pivot_gather_factor<NB, false>(P, LpT, ldp, 0, ln, linvTab, bad);
+        if (bad && ln == 0) s_bad = 1;
+    }
+    __syncthreads();
+    for (int k = 0; k < nblk; k++) {
+        const int c0 = k * NB;
+        const int s = c0 + NB;
+        const int m = N + 1 - s;  // trailing rows s .. N (row N = rhs)
+        if (ts && k == 2 && tid == 0) ts[9] = wall_clock64();
+        // --- panel: L_rk = A_rk Linv^T for the rows below the pivot, also into the transposed strip;
+        //     one thread per output element (row r, column c): short chains, all loads unconditional ---
+        {
+            const double* lt = linvTab + k * NB * NB;
+            for (int e = tid; e < m * NB; e += nt) {
+                const int r = e / NB, c = e - r * NB;
+                const double* row = P + tri(s + r, c0);
+                double a[NB], lc[NB];
+#pragma unroll
+                for (int q = 0; q < NB; q++) { a[q] = row[q]; lc[q] = lt[c * NB + q]; }  // lt is zero above the diagonal
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < NB; q++) t += a[q] * lc[q];
+                LpT[c * ldp + r] = t;
+            }
+        }
+        __syncthreads();
+        if (ts && k == 2 && tid == 0) ts[10] = wall_clock64();
+        if (tid < 64) {
+            // --- look-ahead: the pivot wave updates + factors pivot k+1 ---
+            if (k + 1 < nblk) {
+                bool bad = false;
+                pivot_gather_factor<NB, true>(P, LpT, ldp, s, ln, linvTab + (k + 1) * NB * NB, bad);
+                if (bad && ln == 0) s_bad = 1;
+            }
+            if (ts && k == 2 && tid == 0) ts[11] = wall_clock64();
+        } else {
+            // --- trailing update by the other waves on the FP64 matrix cores: one 16x16 tile of
+            //     C -= Lp_i Lp_j^T per v_mfma_f64_16x16x4_f64 pair (K = NB <= 8); pivot block k+1 excluded ---
+            // file the panel (still in the strip) into the packed matrix, where the back-substitution reads it
+            // (nobody touches these columns during the trailing update)
+            for (int e = tid - 64; e < m * NB; e += nt - 64) {
+                const int r = e / NB, c = e - r * NB;
+                P[tri(s + r, c0 + c)] = LpT[c * ldp + r];
+            }
+            typedef double d4 __attribute__((ext_vector_type(4)));
+            const int nbw = (nt >> 6) - 1;                              // bulk waves
+            const int bw = __builtin_amdgcn_readfirstlane(tid >> 6) - 1;  // this wave's index among them
+            const int nt16 = (m + 15) >> 4;
+            const int npair = nt16 * (nt16 + 1) / 2;
+            const int lr = ln & 15, lk = ln >> 4;
+            for (int pp = bw; pp < npair; pp += nbw) {
+                int ta = 0, rem = pp;
+                while (rem >= ta + 1) { rem -= ta + 1; ta++; }
+                const int i0 = ta << 4, j0 = rem << 4;
+                // every LDS load is unconditional (clamped address) so that they issue back to back; the
+                // masking happens on the loaded values
+                const int ai = i0 + lr, bj = j0 + lr;
+                const int aic = ai < m ? ai : m - 1, bjc = bj < m ? bj : m - 1;
+                const int k1 = lk + 4 < NB ? lk + 4 : 0;
+                double a0 = LpT[lk * ldp + aic], b0 = LpT[lk * ldp + bjc];
+                double a1 = LpT[k1 * ldp + aic], b1 = LpT[k1 * ldp + bjc];
+                const int col = j0 + lr;
+                int addr[4];
+                bool okr[4];
+                d4 c;
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    const int row = i0 + lk + 4 * rg;
+                    okr[rg] = row < m && row >= NB && col <= row && col < m - 1;
+                    const int rowc = row < m ? row : m - 1;
+                    const int colc = col <= rowc ? col : rowc;
+                    addr[rg] = tri(s + rowc, s + colc);
+                    c[rg] = P[addr[rg]];
+                }
+                a0 = (ai < m) ? -a0 : 0.0; b0 = (bj < m) ? b0 : 0.0;
+                a1 = (ai < m && lk + 4 < NB) ? -a1 : 0.0; b1 = (bj < m && lk + 4 < NB) ? b1 : 0.0;
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++)
+                    if (okr[rg]) P[addr[rg]] = c[rg];
+            }
+            if (ts && k == 2 && tid == 64) ts[12] = wall_clock64();
+        }
+        __syncthreads();
+        if (ts && k == 2 && tid == 0) ts[13] = wall_clock64();
+    }
+    if (ts && tid == 0) ts[14] = wall_clock64();
+    if (s_bad) return false;
+    // --- block back-substitution: xs = L^-T y, y = row N of P; one barrier per block ---
+    for (int i = tid; i < N; i += nt) x[i] = P[tri(N, i)];
+    __syncthreads();
+    for (int k = nblk - 1; k >= 0; k--) {
+        const int c0 = k * NB;
+        double xk[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = c; q < NB; q++) t += linvTab[k * NB * NB + q * NB + c] * x[c0 + q];
+            xk[c] = t;
+        }
+        if (tid < NB) {
+            double v = xk[0];
+#pragma unroll
+            for (int c = 1; c < NB; c++) if (tid == c) v = xk[c];
+            xs[c0 + tid] = v;
+        }
+        for (int j = tid; j < c0; j += nt) {
+            double t = x[j];
+#pragma unroll
+            for (int c = 0; c < NB; c++) t -= P[tri(c0 + c, j)] * xk[c];
+            x[j] = t;
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
 // ---- K6: reduced solve, one workgroup per window -------------------------------------------------
-// Packed lower-triangular S in LDS; right-looking Cholesky; forward/backward substitution.
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int w = blockIdx.x;
     const WinDev W = P.win[w];
     const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63, nwv = blockDim.x >> 6;  // wv in an SGPR: row tests below are scalar branches
     LmState* stp = P.states + (long long)w * P.state_stride + slot;
     IterAcc* acc = P.acc + (long long)w * P.state_stride + slot;
     __shared__ LmState st;
-    __shared__ int s_fail;
-    __shared__ double s_red[8];
-    if (tid == 0) { st = *stp; s_fail = 0; }
+    __shared__ double s_red[SOLVE_THREADS / 64 * 4];
+    SADVIO_TS(3, 0);
+    if ((P.debug & 4096) && blockIdx.x == 0 && tid == 0 && slot == 3) P.dbg_ts[20] = clock64();
+    if (tid == 0) st = *stp;
     __syncthreads();
+    if (st.done) return;
     const int Np = W.Np;
     double* Sg = P.S + W.S_off;
     double* gredg = P.gred + W.red_off;
     double* gfullg = P.gfull + W.red_off;
     double* hdg = P.hdiag + W.red_off;
-    const int tri_n = Np * (Np + 1) / 2;
-    double* A = (double*)smem;   // packed lower
-    double* y = A + tri_n;       // rhs / solution
-    double* gf = y + Np;         // full gradient
-    double* hd = gf + Np;        // diag(H)
-    double* lam = hd + Np;       // LM diagonal
-    if (st.done) {
-        // keep the accumulators clean for whoever runs next
-        return;
-    }
+    const int tri_n = (Np + 1) * (Np + 2) / 2;  // packed lower triangle incl. the right-hand-side row Np
+    double* LpT = (double*)smem;                // [NBP][Np+2] transposed panel strip
+    double* A = LpT + (size_t)(Np + 2) * NBP;   // packed lower
+    double* y = A + tri_n;                      // rhs -> work vector of the back-substitution
+    double* gf = y + Np;                        // full gradient
+    double* hd = gf + Np;                       // diag(H)
+    double* xs = hd + Np;                       // solution
+    double* linvTab = xs + Np;                  // [Np/NB][NB*NB] inverse pivot blocks
     const int cur = st.cur;
-    // load + clear global accumulators
-    for (int idx = tid; idx < Np * Np; idx += blockDim.x) {
-        int row = idx / Np, col = idx - row * Np;
-        if (col <= row) {
-            A[tri(row, col)] = Sg[idx];
+    // load + clear the global accumulator: S is kept in HBM in the same packed lower-triangular layout as in
+    // LDS, so this is a linear, fully coalesced 16-byte copy; all loads are issued before the first use.
+    {
+        const int n_s = Np * (Np + 1) / 2;
+        const int n2 = n_s >> 1;
+        constexpr int MAXV = (MAX_LDS_NP * (MAX_LDS_NP + 1) / 4 + SOLVE_THREADS - 1) / SOLVE_THREADS;
+        double2 v[MAXV];
+        const double2* g2 = (const double2*)Sg;
+#pragma unroll
+        for (int q = 0; q < MAXV; q++) {
+            const int i = tid + q * SOLVE_THREADS;
+            if (q * SOLVE_THREADS < n2) v[q] = (i < n2) ? g2[i] : make_double2(0.0, 0.0);
         }
-        Sg[idx] = 0.0;
+        const double2 z2 = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int q = 0; q < MAXV; q++) {
+            const int i = tid + q * SOLVE_THREADS;
+            if (q * SOLVE_THREADS < n2 && i < n2) { ((double2*)A)[i] = v[q]; ((double2*)Sg)[i] = z2; }
+        }
+        if (tid == 0 && (n_s & 1)) { A[n_s - 1] = Sg[n_s - 1]; Sg[n_s - 1] = 0.0; }
     }
     for (int i = tid; i < Np; i += blockDim.x) {
         y[i] = gredg[i]; gf[i] = gfullg[i]; hd[i] = hdg[i];
         gredg[i] = 0.0; gfullg[i] = 0.0; hdg[i] = 0.0;
     }
     __syncthreads();
+    SADVIO_TS(3, 1);
     // pose-only factors at x: PosePriordx (K4). One thread per prior; LDS atomics.
     double cost_part = 0.0, fixed_part = 0.0;
     const double* xp = P.xp + (long long)cur * P.xp_stride;
@@ -471,106 +746,91 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
         }
     }
-    if (cost_part != 0.0) atomic_add_f64(&acc->lin_cost, cost_part);
-    if (slot == 0 && fixed_part != 0.0) atomic_add_f64(&acc->fixed_cost, fixed_part);
+    // window totals of the linearisation: tiles' k_build partials + the pose-only factors evaluated here
+    double gm = 0.0;
+    {
+        const TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + W.tile_begin;
+        for (int t = tid; t < W.tile_end - W.tile_begin; t += blockDim.x) {
+            cost_part += ta[t].lin_cost; fixed_part += ta[t].fixed_cost; gm = fmax(gm, ta[t].gmax);
+        }
+    }
     __syncthreads();
     // gradient tolerance (TrustRegionMinimizer::GradientToleranceReached) on the gradient at x
-    double gm = 0.0;
     for (int i = tid; i < Np; i += blockDim.x) gm = fmax(gm, fabs(gf[i]));
-    gm = wave_max(gm);
-    if ((tid & 63) == 0) s_red[tid >> 6] = gm;
+    gm = wave_max(gm); cost_part = wave_sum(cost_part); fixed_part = wave_sum(fixed_part);
+    if (ln == 0) { s_red[wv * 3] = gm; s_red[wv * 3 + 1] = cost_part; s_red[wv * 3 + 2] = fixed_part; }
     __syncthreads();
     if (tid == 0) {
-        double g = 0;
-        for (int k = 0; k < (int)(blockDim.x >> 6); k++) g = fmax(g, s_red[k]);
-        g = fmax(g, __longlong_as_double((long long)acc->gmax_bits));
+        double g = 0, cs = 0, fs = 0;
+        for (int k = 0; k < nwv; k++) { g = fmax(g, s_red[k * 3]); cs += s_red[k * 3 + 1]; fs += s_red[k * 3 + 2]; }
         acc->gmax_bits = (unsigned long long)__double_as_longlong(g);
+        acc->lin_cost = cs;
+        acc->fixed_cost = fs;
+        acc->cand_cost = 0.0; acc->mcc = 0.0; acc->step_norm2 = 0.0; acc->cand_norm2 = 0.0;
         if (g <= P.o.gradient_tolerance) {
             st.done = 1; st.termination = 3;
-            st.x_cost = 0.5 * acc->lin_cost;
+            st.x_cost = 0.5 * cs;
             if (st.iter == 0) st.initial_cost = st.x_cost;
             *stp = st;
         }
     }
     __syncthreads();
     if (st.done) return;
-    // Jacobi scaling (iteration 0) and LM diagonal
+    if (P.debug & 128) return;
+    SADVIO_TS(3, 2);
+    // Jacobi scaling (iteration 0) and LM diagonal; right-hand side into row Np of the packed matrix
     double* sp = P.s_pose + W.red_off;
     for (int i = tid; i < Np; i += blockDim.x) {
         double s;
         if (slot == 0) { s = P.o.jacobi_scaling ? 1.0 / (1.0 + sqrt(hd[i])) : 1.0; sp[i] = s; }
         else s = sp[i];
         double s2 = s * s;
-        double l = fmin(fmax(s2 * hd[i], P.o.min_lm_diagonal), P.o.max_lm_diagonal) / st.radius / s2;
-        lam[i] = l;
-        A[tri(i, i)] += l;
+        A[tri(i, i)] += fmin(fmax(s2 * hd[i], P.o.min_lm_diagonal), P.o.max_lm_diagonal) / st.radius / s2;
+        A[tri(Np, i)] = y[i];
     }
+    if (tid == 0) A[tri(Np, Np)] = 0.0;
     __syncthreads();
-    // right-looking Cholesky (packed lower, in place)
-    for (int k = 0; k < Np; k++) {
-        double d = A[tri(k, k)];
-        if (!(d > 0.0) || !isfinite(d)) {
-            if (tid == 0) s_fail = 1;
-            __syncthreads();
-            break;
-        }
-        double inv = 1.0 / sqrt(d);
-        __syncthreads();
-        for (int i = k + tid; i < Np; i += blockDim.x) A[tri(i, k)] *= inv;  // i == k gives sqrt(d)
-        __syncthreads();
-        int rem = Np - k - 1;
-        // trailing update: thread per (i, j), k < j <= i
-        int cnt = rem * (rem + 1) / 2;
-        for (int e = tid; e < cnt; e += blockDim.x) {
-            int ii = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-            while (tri(ii + 1, 0) <= e) ii++;
-            while (tri(ii, 0) > e) ii--;
-            int jj = e - tri(ii, 0);
-            int i = k + 1 + ii, j = k + 1 + jj;
-            A[tri(i, j)] -= A[tri(i, k)] * A[tri(j, k)];
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    if (s_fail) {
+    SADVIO_TS(3, 3);
+    bool ok;
+    long long* ts = ((P.debug & 4096) && blockIdx.x == 0 && slot == 3) ? P.dbg_ts : nullptr;
+    if (W.dpf == 6) ok = chol_solve_packed<6>(A, Np, y, xs, LpT, linvTab, ts);
+    else ok = chol_solve_packed<5>(A, Np, y, xs, LpT, linvTab, ts);
+    if (!ok) {
         if (tid == 0) acc->chol_fail = 1;
         return;
     }
-    // forward / backward substitution (thread 0..: column-oriented, Np syncs each)
-    for (int k = 0; k < Np; k++) {
-        if (tid == 0) y[k] = y[k] / A[tri(k, k)];
-        __syncthreads();
-        double yk = y[k];
-        for (int i = k + 1 + tid; i < Np; i += blockDim.x) y[i] -= A[tri(i, k)] * yk;
-        __syncthreads();
-    }
-    for (int k = Np - 1; k >= 0; k--) {
-        if (tid == 0) y[k] = y[k] / A[tri(k, k)];
-        __syncthreads();
-        double yk = y[k];
-        for (int i = tid; i < k; i += blockDim.x) y[i] -= A[tri(k, i)] * yk;
-        __syncthreads();
-    }
+    if (P.debug & 256) return;
+    SADVIO_TS(3, 4);
     // delta = -y ; candidate poses ; norms ; pose-only model cost
     double* dl = P.delta + W.red_off;
     double sn = 0.0, cn = 0.0;
     bool bad = false;
     for (int i = tid; i < Np; i += blockDim.x) {
-        double d = -y[i];
+        double d = -xs[i];
         dl[i] = d;
         y[i] = d;
         sn += d * d;
         if (!isfinite(d)) bad = true;
     }
     __syncthreads();
+    SADVIO_TS(3, 5);
     double* xpc = P.xp + (long long)(1 - cur) * P.xp_stride;
     for (int k = tid; k < W.n_kf; k += blockDim.x) {
         int g = W.kf_base + k;
         int fi = P.kf_fidx[g];
+        double d6[6], tab[POSE_TAB];
         for (int i = 0; i < 6; i++) {
             double v = xp[6 * (long long)g + i] + (fi < 0 ? 0.0 : y[fi * W.dpf + i]);
             xpc[6 * (long long)g + i] = v;
+            d6[i] = v;
             if (fi >= 0) cn += v * v;
+        }
+        // pose table of the candidate buffer (k_backsub reads it now, k_build reads it if the step is accepted)
+        if (P.debug & 512) { for (int i = 0; i < POSE_TAB; i++) tab[i] = d6[i % 6]; } else
+        pose_table_entry(P.kf_T0 + 12 * (long long)g, d6, tab);
+        {
+            double* dst = P.ptab + (long long)(1 - cur) * P.ptab_stride + (long long)g * POSE_TAB;
+            for (int i = 0; i < POSE_TAB; i++) dst[i] = tab[i];
         }
         if (W.dpf == 15) {
             double* xs[3] = {P.xv, P.xba, P.xbg};
@@ -585,6 +845,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
         }
     }
+    SADVIO_TS(3, 6);
     // priors: model cost change and candidate cost
     double mcc = 0.0, cc = 0.0;
     for (int k = W.prior_begin + tid; k < W.prior_end; k += blockDim.x) {
@@ -603,131 +864,168 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         pose_prior_factor(P.kf_T0 + 12 * (long long)pr.kf, pr.T_prior, pr.inf, d6, rc, nullptr);
         for (int q = 0; q < 6; q++) cc += rc[q] * rc[q];
     }
+    SADVIO_TS(3, 7);
     sn = wave_sum(sn); cn = wave_sum(cn); mcc = wave_sum(mcc); cc = wave_sum(cc);
-    if ((tid & 63) == 0) {
-        if (sn != 0.0) atomic_add_f64(&acc->step_norm2, sn);
-        if (cn != 0.0) atomic_add_f64(&acc->cand_norm2, cn);
-        if (mcc != 0.0) atomic_add_f64(&acc->mcc, mcc);
-        if (cc != 0.0) atomic_add_f64(&acc->cand_cost, cc);
-    }
     if (bad) acc->chol_fail = 1;
+    __syncthreads();
+    if (ln == 0) { s_red[wv * 4] = sn; s_red[wv * 4 + 1] = cn; s_red[wv * 4 + 2] = mcc; s_red[wv * 4 + 3] = cc; }
+    __syncthreads();
+    if (tid == 0) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int k = 0; k < nwv; k++) { a0 += s_red[k * 4]; a1 += s_red[k * 4 + 1]; a2 += s_red[k * 4 + 2]; a3 += s_red[k * 4 + 3]; }
+        acc->step_norm2 = a0; acc->cand_norm2 = a1; acc->mcc = a2; acc->cand_cost = a3;
+    }
+    SADVIO_TS(3, 8);
+    if (ts && tid == 0) { ts[15] = wall_clock64(); ts[21] = clock64(); }
 }
 
 // ---- K7: back-substitution + candidate cost -------------------------------------------------------
 template <int FACTOR>
-__global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot) {
+__global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, int max_tile_kf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Tile T = P.tiles[blockIdx.x];
-    const WinDev W = P.win[T.w];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
     const LmState st = P.states[(long long)T.w * P.state_stride + slot];
     IterAcc* acc = P.acc + (long long)T.w * P.state_stride + slot;
-    if (st.done || acc->chol_fail) return;
-    TileLds L;
-    size_t off = tile_lds_carve(smem, W.n_kf, L);
-    double* candTab = (double*)(smem + off);  // [n_kf][12] R|t at the candidate poses
-    double* dlStage = candTab + W.n_kf * 12;  // [MAX_TILE_LMK][3]
-    const int cur = st.cur;
-    double cost_part, fixed_part, gmax_part;
-    tile_prologue<FACTOR>(P, W, T, L, cur, st.radius, false, cost_part, fixed_part, gmax_part);
-    const double* xpc = P.xp + (long long)(1 - cur) * P.xp_stride;
-    for (int k = tid; k < W.n_kf; k += blockDim.x) {
-        int g = W.kf_base + k;
-        double d6[6], tab[POSE_TAB];
-        for (int i = 0; i < 6; i++) d6[i] = xpc[6 * (long long)g + i];
-        pose_table_entry(P.kf_T0 + 12 * (long long)g, d6, tab);
-        for (int i = 0; i < POSE_TAB; i++) (void)0;
-        for (int i = 0; i < 12; i++) candTab[k * 12 + i] = tab[i];
-    }
-    const double* dp = P.delta + W.red_off;
-    const double* xl = P.xl + (long long)cur * P.xl_stride;
-    double* xlc = P.xl + (long long)(1 - cur) * P.xl_stride;
-    const int nl = T.lmk1 - T.lmk0, no = T.obs1 - T.obs0;
-    // predicted residual e_a = r_a + Jp_a dp_a  -> stored over r in the stage (keep r in [18..19], e in regs)
-    // per landmark: dl = -Minv sum_a Jl_a^T e_a
-    double sn = 0.0, cn = 0.0;
-    for (int l = tid; l < nl; l += blockDim.x) {
-        int gl = T.lmk0 + l;
-        int o0 = P.lmk_ob[gl] - T.obs0, o1 = P.lmk_oe[gl] - T.obs0;
-        const double* Mi = L.lmkStage + l * LMK_STAGE;
-        double t[3] = {0, 0, 0};
-        for (int a = o0; a < o1; a++) {
-            const double* s = L.obsStage + a * OBS_STAGE;
-            int pa = L.obsPa[a];
-            double e0 = s[18], e1 = s[19];
-            if (pa >= 0) {
-                const double* d = dp + (pa / 6) * W.dpf;
-#pragma unroll
-                for (int i = 0; i < 6; i++) { e0 += s[i] * d[i]; e1 += s[6 + i] * d[i]; }
-            }
-            t[0] += s[12] * e0 + s[15] * e1;
-            t[1] += s[13] * e0 + s[16] * e1;
-            t[2] += s[14] * e0 + s[17] * e1;
+    if (st.done || acc->chol_fail) {
+        if (tid == 0) {
+            TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + blockIdx.x;
+            ta->cand_cost = 0.0; ta->mcc = 0.0; ta->step_norm2 = 0.0; ta->cand_norm2 = 0.0;
         }
-        double d0 = -(Mi[0] * t[0] + Mi[1] * t[1] + Mi[2] * t[2]);
-        double d1 = -(Mi[1] * t[0] + Mi[3] * t[1] + Mi[4] * t[2]);
-        double d2 = -(Mi[2] * t[0] + Mi[4] * t[1] + Mi[5] * t[2]);
-        dlStage[3 * l] = d0; dlStage[3 * l + 1] = d1; dlStage[3 * l + 2] = d2;
-        double c0 = xl[3 * (long long)gl] + d0, c1 = xl[3 * (long long)gl + 1] + d1, c2 = xl[3 * (long long)gl + 2] + d2;
-        xlc[3 * (long long)gl] = c0; xlc[3 * (long long)gl + 1] = c1; xlc[3 * (long long)gl + 2] = c2;
-        bool active = (o1 > o0) && !(P.lmk_const && P.lmk_const[gl]);
-        if (active) {
-            sn += d0 * d0 + d1 * d1 + d2 * d2;
-            cn += c0 * c0 + c1 * c1 + c2 * c2;
+        return;
+    }
+    double* poseTab = (double*)smem;
+    double* camTab = poseTab + (size_t)max_tile_kf * POSE_TAB;
+    int* rowTab = (int*)(camTab + MAX_WIN_CAM * 17);
+    double* candTab = (double*)(smem + tile_tables_bytes(max_tile_kf));  // [n_kf][12] R|t at the candidate poses
+    double* dpTab = candTab + (size_t)max_tile_kf * 12;                  // [n_kf][6] pose step of each listed key-frame
+    const int cur = st.cur;
+    stage_tables(P, T, cur, poseTab, camTab, rowTab);
+    {
+        const double* src = P.ptab + (long long)(1 - cur) * P.ptab_stride;
+        for (int i = tid; i < T.n_kf * 12; i += blockDim.x) {
+            const int k = i / 12, e = i - 12 * k;
+            candTab[i] = src[(long long)P.tile_kf[T.kf_off + k] * POSE_TAB + e];
+        }
+        const double* dp = P.delta + T.red_off;
+        for (int i = tid; i < T.n_kf * 6; i += blockDim.x) {
+            const int k = i / 6, e = i - 6 * k;
+            const int fi = P.kf_fidx[P.tile_kf[T.kf_off + k]];
+            dpTab[i] = fi < 0 ? 0.0 : dp[fi * T.dpf + e];
         }
     }
     __syncthreads();
-    // per observation: model cost and candidate residual
-    double mcc = 0.0, cc = 0.0;
-    for (int a = tid; a < no; a += blockDim.x) {
-        const double* s = L.obsStage + a * OBS_STAGE;
-        int pa = L.obsPa[a];
-        int l = L.obsLmk[a];
-        int gl = T.lmk0 + l;
-        bool lfree = !(P.lmk_const && P.lmk_const[gl]);
-        if (pa < 0 && !lfree) continue;
-        const double* dlv = dlStage + 3 * l;
-        double m0 = s[12] * dlv[0] + s[13] * dlv[1] + s[14] * dlv[2];
-        double m1 = s[15] * dlv[0] + s[16] * dlv[1] + s[17] * dlv[2];
-        if (pa >= 0) {
-            const double* d = dp + (pa / 6) * W.dpf;
-#pragma unroll
-            for (int i = 0; i < 6; i++) { m0 += s[i] * d[i]; m1 += s[6 + i] * d[i]; }
-        }
-        mcc += -m0 * (s[18] + 0.5 * m0) - m1 * (s[19] + 0.5 * m1);
-        // candidate residual
-        int o = T.obs0 + a;
-        int kf = P.obs_kf[o], cam = P.obs_cam[o];
-        double pw[3] = {P.lmk_p[3 * (long long)gl] + xlc[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1] + xlc[3 * (long long)gl + 1],
-                        P.lmk_p[3 * (long long)gl + 2] + xlc[3 * (long long)gl + 2]};
-        double r[2];
-        const double* ctab = candTab + (kf - W.kf_base) * 12;
-        if (FACTOR == 0) {
-            const double* m = P.obs_meas + 2 * (long long)o;
-            pixel_factor<false>(ctab, P.cam_K + 4 * cam, P.cam_T + 12 * cam, pw, m[0], m[1], P.cam_isig[cam], r, nullptr, nullptr);
+    const int G = T.G, lpw = 64 / G;
+    const int grp = ln / G, q = ln - grp * G;
+    const int nl = T.lmk1 - T.lmk0;
+    const double* xl = P.xl + (long long)cur * P.xl_stride;
+    double* xlc = P.xl + (long long)(1 - cur) * P.xl_stride;
+    double sn = 0.0, cn = 0.0, mcc = 0.0, cc = 0.0;
+    for (int base = wv * lpw; base < nl; base += BUILD_WAVES * lpw) {
+        const int lm = base + grp;
+        const bool lmk_valid = lm < nl;
+        const int gl = T.lmk0 + (lmk_valid ? lm : 0);
+        const int ob = P.lmk_ob[gl], oe = P.lmk_oe[gl];
+        const int nobs = lmk_valid ? oe - ob : 0;
+        const bool lfree = !(P.lmk_const && P.lmk_const[gl]);
+        const double p0[3] = {P.lmk_p[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1], P.lmk_p[3 * (long long)gl + 2]};
+        const double x0[3] = {xl[3 * (long long)gl], xl[3 * (long long)gl + 1], xl[3 * (long long)gl + 2]};
+        ObsLin L;
+        L.valid = q < nobs;
+        L.row = -1; L.slot = 0; L.counted = false;
+        if (L.valid) {
+            const double pw[3] = {p0[0] + x0[0], p0[1] + x0[1], p0[2] + x0[2]};
+            lane_linearize<FACTOR>(P, poseTab, camTab, rowTab, T.cam_base, ob + q, pw, lfree, L);
+            if (!L.counted) { L.r[0] = 0.0; L.r[1] = 0.0; }
         } else {
-            const double* m = P.obs_meas + 3 * (long long)o;
-            double b[3] = {m[0], m[1], m[2]};
-            // angular_factor<false> only reads tab[0..11]
-            angular_factor<false>(ctab, P.cam_T + 12 * cam, pw, b, P.cam_isig[cam], r, nullptr, nullptr);
+            L.r[0] = L.r[1] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 12; i++) L.Jp[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) L.Jl[i] = 0.0;
         }
-        cc += r[0] * r[0] + r[1] * r[1];
+        double Mi[6], g[3];
+        const bool active = group_eliminate(P, L, G, gl, lmk_valid, lfree, nobs, st.radius, false, false, Mi, g);
+
+        // predicted residual e = r + Jp dp of this lane's observation
+        double e0 = L.r[0], e1 = L.r[1];
+        const double* d = dpTab + L.slot * 6;
+        if (L.valid && L.row >= 0) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) { e0 += L.Jp[i] * d[i]; e1 += L.Jp[6 + i] * d[i]; }
+        }
+        // delta_l = -Minv sum_a Jl_a^T e_a   (every lane of the group)
+        double t0 = group_sum(L.Jl[0] * e0 + L.Jl[3] * e1, G);
+        double t1 = group_sum(L.Jl[1] * e0 + L.Jl[4] * e1, G);
+        double t2 = group_sum(L.Jl[2] * e0 + L.Jl[5] * e1, G);
+        const double d0 = -(Mi[0] * t0 + Mi[1] * t1 + Mi[2] * t2);
+        const double d1 = -(Mi[1] * t0 + Mi[3] * t1 + Mi[4] * t2);
+        const double d2 = -(Mi[2] * t0 + Mi[4] * t1 + Mi[5] * t2);
+        const double c0 = x0[0] + d0, c1 = x0[1] + d1, c2 = x0[2] + d2;
+        if (lmk_valid && q == 0) {
+            xlc[3 * (long long)gl] = c0; xlc[3 * (long long)gl + 1] = c1; xlc[3 * (long long)gl + 2] = c2;
+            if (active) {
+                sn += d0 * d0 + d1 * d1 + d2 * d2;
+                cn += c0 * c0 + c1 * c1 + c2 * c2;
+            }
+        }
+        if (L.valid && L.counted) {
+            // model cost change of this residual block: -(J d)^T (r + J d / 2)
+            const double m0 = (e0 - L.r[0]) + L.Jl[0] * d0 + L.Jl[1] * d1 + L.Jl[2] * d2;
+            const double m1 = (e1 - L.r[1]) + L.Jl[3] * d0 + L.Jl[4] * d1 + L.Jl[5] * d2;
+            mcc += -m0 * (L.r[0] + 0.5 * m0) - m1 * (L.r[1] + 0.5 * m1);
+            // residual at the candidate point
+            const int o = ob + q;
+            const int cam = P.obs_cam[o] - T.cam_base;
+            const double* ct = camTab + cam * 17;
+            const double pw[3] = {p0[0] + c0, p0[1] + c1, p0[2] + c2};
+            const double* ctab = candTab + L.slot * 12;
+            double r[2];
+            if (FACTOR == 0) {
+                const double* m = P.obs_meas + 2 * (long long)o;
+                pixel_factor<false>(ctab, ct, ct + 4, pw, m[0], m[1], ct[16], r, nullptr, nullptr);
+            } else {
+                const double* m = P.obs_meas + 3 * (long long)o;
+                double bb[3] = {m[0], m[1], m[2]};
+                angular_factor<false>(ctab, ct + 4, pw, bb, ct[16], r, nullptr, nullptr);
+            }
+            cc += r[0] * r[0] + r[1] * r[1];
+        }
     }
     sn = wave_sum(sn); cn = wave_sum(cn); mcc = wave_sum(mcc); cc = wave_sum(cc);
-    if ((tid & 63) == 0) {
-        if (sn != 0.0) atomic_add_f64(&acc->step_norm2, sn);
-        if (cn != 0.0) atomic_add_f64(&acc->cand_norm2, cn);
-        if (mcc != 0.0) atomic_add_f64(&acc->mcc, mcc);
-        if (cc != 0.0) atomic_add_f64(&acc->cand_cost, cc);
+    __shared__ double s_part[BUILD_WAVES * 4];
+    if (ln == 0) { s_part[wv * 4] = cc; s_part[wv * 4 + 1] = mcc; s_part[wv * 4 + 2] = sn; s_part[wv * 4 + 3] = cn; }
+    __syncthreads();
+    if (tid == 0) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int k = 0; k < BUILD_WAVES; k++) { a0 += s_part[k * 4]; a1 += s_part[k * 4 + 1]; a2 += s_part[k * 4 + 2]; a3 += s_part[k * 4 + 3]; }
+        TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + blockIdx.x;
+        ta->cand_cost = a0; ta->mcc = a1; ta->step_norm2 = a2; ta->cand_norm2 = a3;
     }
 }
 
-// Last decision of the solve: state[slots] = decide(state[slots-1], acc[slots-1]).
+// Pose tables of delta buffer 0 at the start of a solve (all deltas zero).
+__global__ void k_init_tables(DevPtrs P, int n_kf_tot) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_kf_tot) return;
+    double d6[6], tab[POSE_TAB];
+    for (int i = 0; i < 6; i++) d6[i] = P.xp[6 * (long long)g + i];
+    pose_table_entry(P.kf_T0 + 12 * (long long)g, d6, tab);
+    for (int i = 0; i < POSE_TAB; i++) P.ptab[(long long)g * POSE_TAB + i] = tab[i];
+}
+
+// Last decision of the solve: state[slots] = decide(state[slots-1], totals[slots-1]); one wave per window.
 __global__ void k_final(DevPtrs P, int slots) {
-    int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= P.n_win) return;
-    LmState s = lm_decide(P.states[(long long)w * P.state_stride + slots - 1], P.acc[(long long)w * P.state_stride + slots - 1], P.o);
-    P.states[(long long)w * P.state_stride + slots] = s;
+    const int w = blockIdx.x, ln = threadIdx.x;
+    __shared__ double s4[4];
+    const WinDev W = P.win[w];
+    wave_sum_backsub_partials(P, (slots - 1) & 1, W.tile_begin, W.tile_end - W.tile_begin, ln, s4);
+    __syncthreads();
+    if (ln == 0) {
+        IterAcc a = P.acc[(long long)w * P.state_stride + slots - 1];
+        a.cand_cost += s4[0]; a.mcc += s4[1]; a.step_norm2 += s4[2]; a.cand_norm2 += s4[3];
+        P.states[(long long)w * P.state_stride + slots] = lm_decide(P.states[(long long)w * P.state_stride + slots - 1], a, P.o);
+    }
 }
 
 // Parity probe: per-observation residual / Jacobians at deltas held in buffer 0.

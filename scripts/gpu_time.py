@@ -1,0 +1,25 @@
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from sadvio_amd import capi, synthetic
+nw = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+ws = [synthetic.make_window(seed=20250404 + i) for i in range(min(nw, 4))]
+ws = [ws[i % len(ws)] for i in range(nw)]
+opts = capi.gn_options(10); opts.max_num_consecutive_invalid_steps = 1000
+be = capi.Backend(device=0, profile_kernels=True)
+be.set_windows(ws)
+for _ in range(3): be.solve(opts)
+be.set_windows(ws)
+t=time.perf_counter()
+for _ in range(10): s = be.solve(opts)
+dt=(time.perf_counter()-t)/10
+kt = be.kernel_times()
+print(f"debug={os.environ.get('SADVIO_DEBUG','0')} windows={nw} wall/solve {dt*1e3:.3f} ms (profiled) ", {k: round(v['avg_us'],2) for k,v in kt.items()}, "final cost", s[0].final_cost)
+be.close()
+be = capi.Backend(device=0)
+be.set_windows(ws)
+for _ in range(3): be.solve(opts)
+t=time.perf_counter()
+for _ in range(20): s = be.solve(opts)
+dt=(time.perf_counter()-t)/20
+print(f"   unprofiled wall/solve {dt*1e3:.3f} ms -> {nw*10/dt:.0f} it/s")
