@@ -70,6 +70,8 @@ struct sadvio_ba_handle {
     std::vector<Tile> tiles;
     std::vector<PriorDev> priors;
     std::vector<std::vector<PriorDev>> priors_per_win;
+    std::vector<std::vector<ImuDev>> imus_per_win;
+    std::vector<ImuDev> imus;
     int n_kf_tot = 0, n_cam_tot = 0, n_lmk_tot = 0, n_obs_tot = 0, np_tot = 0;
     long long s_tot = 0;
     int factor_type = 0;
@@ -91,6 +93,8 @@ struct sadvio_ba_handle {
     int max_tile_kf = 1, max_tile_free = 0;
     DevBuf<double> d_obs_meas;
     DevBuf<PriorDev> d_priors;
+    DevBuf<ImuDev> d_imus;
+    DevBuf<double> d_imu_scratch;
     DevBuf<double> d_S, d_gred, d_gfull, d_hdiag, d_delta, d_s_pose;
     DevBuf<LmState> d_states;
     DevBuf<IterAcc> d_acc;
@@ -160,7 +164,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.obs_kf = h->d_obs_kf.p; P.obs_cam = h->d_obs_cam.p; P.obs_meas = h->d_obs_meas.p;
     P.obs_slot = h->d_obs_slot.p; P.tile_kf = h->d_tile_kf.p; P.tile_row = h->d_tile_row.p;
     P.ptab = h->d_ptab.p; P.ptab_stride = (long long)POSE_TAB * h->n_kf_tot;
-    P.priors = h->d_priors.p;
+    P.priors = h->d_priors.p; P.imus = h->d_imus.p; P.imu_scratch = h->d_imu_scratch.p;
     P.S = h->d_S.p; P.gred = h->d_gred.p; P.gfull = h->d_gfull.p; P.hdiag = h->d_hdiag.p;
     P.delta = h->d_delta.p; P.s_pose = h->d_s_pose.p;
     P.dbg_ts = h->d_dbg.p;
@@ -182,6 +186,16 @@ int upload_priors(sadvio_ba_handle* h) {
     HIP_TRY(h->d_priors.alloc(h->priors.size()));
     if (!h->priors.empty())
         HIP_TRY(hipMemcpyAsync(h->d_priors.p, h->priors.data(), h->priors.size() * sizeof(PriorDev), hipMemcpyHostToDevice, h->stream));
+    h->imus.clear();
+    for (size_t w = 0; w < h->wins.size(); w++) {
+        h->wins[w].d.imu_begin = (int)h->imus.size();
+        for (auto& f : h->imus_per_win[w]) h->imus.push_back(f);
+        h->wins[w].d.imu_end = (int)h->imus.size();
+    }
+    HIP_TRY(h->d_imus.alloc(h->imus.size()));
+    HIP_TRY(h->d_imu_scratch.alloc(h->imus.size() * (size_t)(IMU_J + 6)));
+    if (!h->imus.empty())
+        HIP_TRY(hipMemcpyAsync(h->d_imus.p, h->imus.data(), h->imus.size() * sizeof(ImuDev), hipMemcpyHostToDevice, h->stream));
     std::vector<WinDev> wd(h->wins.size());
     for (size_t w = 0; w < h->wins.size(); w++) wd[w] = h->wins[w].d;
     HIP_TRY(hipMemcpyAsync(h->d_win.p, wd.data(), wd.size() * sizeof(WinDev), hipMemcpyHostToDevice, h->stream));
@@ -253,7 +267,7 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     h->d_lmk_ob.release(); h->d_lmk_oe.release(); h->d_obs_kf.release(); h->d_obs_cam.release();
     h->d_obs_meas.release(); h->d_priors.release(); h->d_S.release(); h->d_gred.release(); h->d_gfull.release();
     h->d_hdiag.release(); h->d_delta.release(); h->d_s_pose.release(); h->d_states.release(); h->d_acc.release();
-    h->d_probe.release(); h->d_tile_kf.release(); h->d_tile_row.release(); h->d_obs_slot.release(); h->d_ptab.release(); h->d_tacc.release(); h->d_dbg.release();
+    h->d_probe.release(); h->d_tile_kf.release(); h->d_tile_row.release(); h->d_obs_slot.release(); h->d_ptab.release(); h->d_tacc.release(); h->d_dbg.release(); h->d_imus.release(); h->d_imu_scratch.release();
     delete h;
 }
 
@@ -264,6 +278,7 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
     h->uploaded = false; h->solved = false;
     h->wins.assign(n_windows, HostWin());
     h->priors_per_win.assign(n_windows, {});
+    h->imus_per_win.assign(n_windows, {});
     h->tiles.clear();
     h->factor_type = wins[0].factor_type;
     int kf_b = 0, cam_b = 0, lmk_b = 0, obs_b = 0, red_b = 0;
@@ -480,11 +495,74 @@ int sadvio_ba_set_pose_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const s
     return upload_priors(h);
 }
 
-int sadvio_ba_set_imu_factors(sadvio_ba_handle* h, int32_t, int32_t n, const sadvio_imu_factor*) {
+// 9x9 square-root information W = L^T with L L^T = cov^-1 (residuals.hpp:151-154): Gauss-Jordan inverse with
+// partial pivoting + Cholesky, on the host, once per factor.
+static bool imu_sqrt_information(const double* cov, double* W) {
+    double A[81], I[81];
+    memcpy(A, cov, sizeof(A));
+    memset(I, 0, sizeof(I));
+    for (int i = 0; i < 9; i++) I[i * 9 + i] = 1.0;
+    for (int c = 0; c < 9; c++) {
+        int piv = c;
+        double best = fabs(A[c * 9 + c]);
+        for (int r = c + 1; r < 9; r++)
+            if (fabs(A[r * 9 + c]) > best) { best = fabs(A[r * 9 + c]); piv = r; }
+        if (best == 0.0) return false;
+        if (piv != c)
+            for (int j = 0; j < 9; j++) { std::swap(A[c * 9 + j], A[piv * 9 + j]); std::swap(I[c * 9 + j], I[piv * 9 + j]); }
+        double d = 1.0 / A[c * 9 + c];
+        for (int j = 0; j < 9; j++) { A[c * 9 + j] *= d; I[c * 9 + j] *= d; }
+        for (int r = 0; r < 9; r++) {
+            if (r == c) continue;
+            double f = A[r * 9 + c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < 9; j++) { A[r * 9 + j] -= f * A[c * 9 + j]; I[r * 9 + j] -= f * I[c * 9 + j]; }
+        }
+    }
+    double L[81];
+    memset(L, 0, sizeof(L));
+    for (int j = 0; j < 9; j++) {
+        double s = I[j * 9 + j];
+        for (int k = 0; k < j; k++) s -= L[j * 9 + k] * L[j * 9 + k];
+        if (!(s > 0.0)) return false;
+        double d = sqrt(s);
+        L[j * 9 + j] = d;
+        for (int i = j + 1; i < 9; i++) {
+            double t = I[i * 9 + j];
+            for (int k = 0; k < j; k++) t -= L[i * 9 + k] * L[j * 9 + k];
+            L[i * 9 + j] = t / d;
+        }
+    }
+    for (int i = 0; i < 9; i++)
+        for (int j = 0; j < 9; j++) W[i * 9 + j] = L[j * 9 + i];
+    return true;
+}
+
+int sadvio_ba_set_imu_factors(sadvio_ba_handle* h, int32_t w, int32_t n, const sadvio_imu_factor* fs) {
     if (!h) return SADVIO_E_INVALID_ARG;
-    if (n == 0) return SADVIO_OK;
-    h->err = "set_imu_factors: IMU factors are not implemented on the device yet";
-    return SADVIO_E_INVALID_ARG;
+    if (!h->uploaded) { h->err = "set_imu_factors before set_windows"; return SADVIO_E_STATE; }
+    if (w < 0 || w >= (int)h->wins.size() || n < 0 || (n > 0 && !fs)) { h->err = "set_imu_factors: bad argument"; return SADVIO_E_INVALID_ARG; }
+    const WinDev& d = h->wins[w].d;
+    if (n > 0 && !d.has_imu) { h->err = "set_imu_factors: the window was uploaded with has_imu = 0"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    auto& v = h->imus_per_win[w];
+    v.clear();
+    for (int k = 0; k < n; k++) {
+        const sadvio_imu_factor& f = fs[k];
+        if (f.kf_i < 0 || f.kf_i >= d.n_kf || f.kf_j < 0 || f.kf_j >= d.n_kf || f.kf_i == f.kf_j || !(f.dt > 0)) {
+            h->err = "set_imu_factors: key-frame index / dt out of range"; return SADVIO_E_INVALID_ARG;
+        }
+        ImuDev o{};
+        o.kf_i = d.kf_base + f.kf_i; o.kf_j = d.kf_base + f.kf_j; o.dt = f.dt;
+        memcpy(o.dR, f.delta_R, sizeof(o.dR)); memcpy(o.dv, f.delta_v, sizeof(o.dv)); memcpy(o.dp, f.delta_p, sizeof(o.dp));
+        memcpy(o.J_dR_bg, f.J_dR_bg, 72); memcpy(o.J_dv_ba, f.J_dv_ba, 72); memcpy(o.J_dv_bg, f.J_dv_bg, 72);
+        memcpy(o.J_dp_ba, f.J_dp_ba, 72); memcpy(o.J_dp_bg, f.J_dp_bg, 72);
+        if (!imu_sqrt_information(f.cov, o.W)) { h->err = "set_imu_factors: covariance is not positive definite"; return SADVIO_E_INVALID_ARG; }
+        o.sa = 1.0 / sqrt(f.dt * f.bacc_noise * f.bacc_noise);
+        o.sg = 1.0 / sqrt(f.dt * f.bgyr_noise * f.bgyr_noise);
+        v.push_back(o);
+    }
+    return upload_priors(h);
 }
 
 int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t, int32_t n_full, int32_t, const double*, const double*, int32_t,

@@ -67,6 +67,19 @@ struct PriorDev {
     double inf[6];
 };
 
+// IMUFactor + IMUBiasFactor constants of one consecutive key-frame pair (residuals.hpp:133-300). The 9x9
+// square-root information W = L^T, L L^T = cov^-1 (residuals.hpp:151-154) is computed once on the host at
+// set_imu_factors time instead of at every evaluation.
+struct ImuDev {
+    int kf_i, kf_j;  // global key-frame indices (i = older frame)
+    double dt;
+    double dR[9], dv[3], dp[3];
+    double J_dR_bg[9], J_dv_ba[9], J_dv_bg[9], J_dp_ba[9], J_dp_bg[9];
+    double W[81];
+    double sa, sg;   // 1 / sqrt(dt * bacc_noise^2), 1 / sqrt(dt * bgyr_noise^2)
+};
+constexpr int IMU_J = 9 * 24 + 9;  // whitened Jacobian + residual kept in HBM scratch between phases
+
 // Levenberg-Marquardt control state at the beginning of a slot (one step attempt).
 struct LmState {
     double radius, decrease_factor, x_cost, x_norm, initial_cost;

@@ -36,6 +36,19 @@ __device__ __forceinline__ void m3_tvec(const double* A, const double* v, double
     double z = A[2] * v[0] + A[5] * v[1] + A[8] * v[2];
     o[0] = x; o[1] = y; o[2] = z;
 }
+__device__ __forceinline__ void m3_mul_t(const double* A, const double* B, double* C) {  // C = A B^T
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[3 * j] + A[3 * i + 1] * B[3 * j + 1] + A[3 * i + 2] * B[3 * j + 2];
+}
+__device__ __forceinline__ void m3_tmul(const double* A, const double* B, double* C) {  // C = A^T B
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) C[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+
 __device__ __forceinline__ double v3_norm(const double* v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
 // sin / cos of a double in registers. The ROCm device-library sin()/cos() cost ~20 us per call site on
@@ -302,20 +315,21 @@ __device__ __forceinline__ void pose_prior_factor(const double* T0, const double
     m3_mul(T0, dR, R);
     m3_vec(T0, d6 + 3, t);
     t[0] += T0[9]; t[1] += T0[10]; t[2] += T0[11];
-    // E = T * Tp^-1 : R_E = R Rp^T, t_E = t - R_E tp
-    double RE[9];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) RE[3 * i + j] = R[3 * i] * Tp[3 * j] + R[3 * i + 1] * Tp[3 * j + 1] + R[3 * i + 2] * Tp[3 * j + 2];
+    // E = T * Tp^-1 with Eigen::Affine3d::inverse() semantics (general 3x3 inverse of the linear part,
+    // residuals.hpp:610): R_E = R Rp^-1, t_E = t - R_E tp
+    double Rpi[9], RE[9];
+    m3_inverse(Tp, Rpi);
+    m3_mul(R, Rpi, RE);
     double w[3], REtp[3];
     so3_log(RE, w);
     m3_vec(RE, Tp + 9, REtp);
     r[0] = inf[0] * w[0]; r[1] = inf[1] * w[1]; r[2] = inf[2] * w[2];
     r[3] = inf[3] * (t[0] - REtp[0]); r[4] = inf[4] * (t[1] - REtp[1]); r[5] = inf[5] * (t[2] - REtp[2]);
     if (J) {
-        double Jrw[9], Jrwi[9], Jrd[9], A[9], B00[9], v[3], S[9], RS[9], B10[9];
-        so3_right_jacobian(w, Jrw);
+        double Jrw[9], Jrwi[9], Jrd[9], A[9], B00[9], v[3], S[9], RS[9], B10[9], RRpT[9], wj[3];
+        m3_mul_t(R, Tp, RRpT);  // the Jacobian uses R Rp^T (residuals.hpp:617)
+        so3_log(RRpT, wj);
+        so3_right_jacobian(wj, Jrw);
         m3_inverse(Jrw, Jrwi);
         so3_right_jacobian(d6, Jrd);
         m3_mul(Jrwi, Tp, A);
@@ -334,6 +348,103 @@ __device__ __forceinline__ void pose_prior_factor(const double* T0, const double
                 J[6 * (3 + i) + 3 + j] = inf[3 + i] * T0[3 * i + j];
             }
     }
+}
+
+// IMUFactor (residuals.hpp:133-245). Blocks [pose_i 6 | pose_j 6 | dv_i 3 | dv_j 3 | dba_i 3 | dbg_i 3];
+// J (optional) is the whitened 9x24 Jacobian, row-major. Quirks kept as coded: the pose_i translation block
+// uses the UNperturbed R_i0 (:185), [6:9,0:3] of pose_i uses p_j instead of p_j - p_i (:181-184), pose_j's
+// translation block uses exp(w_j)^T (:198).
+template <typename ImuT>
+__device__ __noinline__ void imu_factor(const ImuT& f, const double* Ti0, const double* Tj0, const double* vi0,
+                                        const double* vj0, const double* dpi, const double* dpj, const double* dvi,
+                                        const double* dvj, const double* dba, const double* dbg, double* r, double* J) {
+    const double G[3] = {0.0, 0.0, -9.81};  // IMU.h:8
+    double dRi[9], dRj[9], Ri[9], Rj[9], ti[3], tj[3];
+    so3_exp(dpi, dRi); so3_exp(dpj, dRj);
+    m3_mul(Ti0, dRi, Ri); m3_mul(Tj0, dRj, Rj);
+    m3_vec(Ti0, dpi + 3, ti); m3_vec(Tj0, dpj + 3, tj);
+    for (int k = 0; k < 3; k++) { ti[k] += Ti0[9 + k]; tj[k] += Tj0[9 + k]; }
+    double vi[3], vj[3];
+    for (int k = 0; k < 3; k++) { vi[k] = vi0[k] + dvi[k]; vj[k] = vj0[k] + dvj[k]; }
+    const double dt = f.dt;
+    // dR = (DeltaR exp(J_dR_bg dbg))^T R_i R_j^T  (:157-158)
+    double jb[3], Eb[9], DRc[9], RiRjT[9], dR[9], r_dr[3];
+    m3_vec(f.J_dR_bg, dbg, jb);
+    so3_exp(jb, Eb);
+    m3_mul(f.dR, Eb, DRc);
+    m3_mul_t(Ri, Rj, RiRjT);
+    m3_tmul(DRc, RiRjT, dR);
+    so3_log(dR, r_dr);
+    double a[3], Ra[3], t1[3], t2[3];
+    for (int k = 0; k < 3; k++) a[k] = vj[k] - vi[k] - G[k] * dt;
+    m3_vec(Ri, a, Ra);
+    m3_vec(f.J_dv_bg, dbg, t1); m3_vec(f.J_dv_ba, dba, t2);
+    double e[9];
+    for (int k = 0; k < 3; k++) { e[k] = r_dr[k]; e[3 + k] = Ra[k] - (f.dv[k] + t1[k] + t2[k]); }
+    // positions in world: p = -R^T t
+    double pi[3], pj[3], b[3], Rb[3];
+    // T.inverse().translation() with Eigen::Affine3d semantics: the linear part is inverted as a general 3x3
+    {
+        double Rii[9], Rji[9];
+        m3_inverse(Ri, Rii); m3_inverse(Rj, Rji);
+        m3_vec(Rii, ti, pi); m3_vec(Rji, tj, pj);
+    }
+    for (int k = 0; k < 3; k++) { pi[k] = -pi[k]; pj[k] = -pj[k]; }
+    for (int k = 0; k < 3; k++) b[k] = pj[k] - pi[k] - vi[k] * dt - 0.5 * G[k] * dt * dt;
+    m3_vec(Ri, b, Rb);
+    m3_vec(f.J_dp_bg, dbg, t1); m3_vec(f.J_dp_ba, dba, t2);
+    for (int k = 0; k < 3; k++) e[6 + k] = Rb[k] - (f.dp[k] + t1[k] + t2[k]);
+    for (int q = 0; q < 9; q++) {
+        double s = 0;
+        for (int k = 0; k < 9; k++) s += f.W[9 * q + k] * e[k];
+        r[q] = s;
+    }
+    if (!J) return;
+    double U[9 * 24];  // un-whitened Jacobian
+    for (int i = 0; i < 9 * 24; i++) U[i] = 0.0;
+    double Jr_r[9], Jr_ri[9], Jrwi[9], Jrwj[9], A[9], B[9], S[9], RS[9];
+    so3_right_jacobian(r_dr, Jr_r);
+    m3_inverse(Jr_r, Jr_ri);
+    so3_right_jacobian(dpi, Jrwi);
+    so3_right_jacobian(dpj, Jrwj);
+    // pose_i (:174-187)
+    m3_mul(Jr_ri, Rj, A); m3_mul(A, Jrwi, B);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[i * 24 + j] = B[3 * i + j];
+    so3_skew(a, S); m3_mul(Ri, S, RS); m3_mul(RS, Jrwi, B);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[(3 + i) * 24 + j] = -B[3 * i + j];
+    double cc[3];
+    for (int k = 0; k < 3; k++) cc[k] = pj[k] - vi[k] * dt - 0.5 * G[k] * dt * dt;
+    so3_skew(cc, S); m3_mul(Ri, S, RS); m3_mul(RS, Jrwi, B);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { U[(6 + i) * 24 + j] = -B[3 * i + j]; U[(6 + i) * 24 + 3 + j] = Ti0[3 * i + j]; }
+    // pose_j (:190-200)
+    m3_mul(Jr_ri, Rj, A); m3_mul(A, Jrwj, B);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[i * 24 + 6 + j] = -B[3 * i + j];
+    double C1[9], C2[9];
+    so3_skew(tj, S); m3_mul(RiRjT, S, C1); m3_mul(C1, Rj, C2); m3_mul(C2, Jrwj, B);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[(6 + i) * 24 + 6 + j] = -B[3 * i + j];
+    m3_mul_t(Ri, dRj, B);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[(6 + i) * 24 + 9 + j] = -B[3 * i + j];
+    // dv_i, dv_j, dba, dbg (:203-237)
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        U[(3 + i) * 24 + 12 + j] = -Ri[3 * i + j];
+        U[(6 + i) * 24 + 12 + j] = -Ri[3 * i + j] * dt;
+        U[(3 + i) * 24 + 15 + j] = Ri[3 * i + j];
+        U[(3 + i) * 24 + 18 + j] = -f.J_dv_ba[3 * i + j];
+        U[(6 + i) * 24 + 18 + j] = -f.J_dp_ba[3 * i + j];
+        U[(3 + i) * 24 + 21 + j] = -f.J_dv_bg[3 * i + j];
+        U[(6 + i) * 24 + 21 + j] = -f.J_dp_bg[3 * i + j];
+    }
+    double Jrb[9], D1[9], D2[9];
+    so3_right_jacobian(jb, Jrb);
+    m3_mul_t(Jr_ri, dR, A);  // Jr^-1 dR^T
+    m3_mul(A, Jrb, D1); m3_mul(D1, f.J_dR_bg, D2);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[i * 24 + 21 + j] = -D2[3 * i + j];
+    for (int q = 0; q < 9; q++)
+        for (int c = 0; c < 24; c++) {
+            double s = 0;
+            for (int k = 0; k < 9; k++) s += f.W[9 * q + k] * U[k * 24 + c];
+            J[q * 24 + c] = s;
+        }
 }
 
 }  // namespace sadvio

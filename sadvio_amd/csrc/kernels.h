@@ -37,6 +37,8 @@ struct DevPtrs {
     double* ptab;                   // [2][n_kf_tot][POSE_TAB] pose tables of the two delta buffers
     long long ptab_stride;
     const PriorDev* priors;
+    const ImuDev* imus;
+    double* imu_scratch;  // [n_imu_tot][IMU_J + 6] whitened J (9x24), r (9), bias residual (6)
     double* S; double* gred; double* gfull; double* hdiag; double* delta; double* s_pose;
     LmState* states;  // [n_win][slots+2]
     IterAcc* acc;     // [n_win][slots+1] window totals (written by single workgroups only)
@@ -660,6 +662,16 @@ __device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, d
     return true;
 }
 
+// reduced-vector column of Jacobian column `a` of an IMUFactor, blocks [pose_i 6|pose_j 6|dv_i 3|dv_j 3|dba_i 3|dbg_i 3]
+__device__ __forceinline__ int imu_col(int a, int fi, int fj) {
+    if (a < 6) return fi < 0 ? -1 : fi * 15 + a;
+    if (a < 12) return fj < 0 ? -1 : fj * 15 + a - 6;
+    if (a < 15) return fi < 0 ? -1 : fi * 15 + 6 + a - 12;
+    if (a < 18) return fj < 0 ? -1 : fj * 15 + 6 + a - 15;
+    if (a < 21) return fi < 0 ? -1 : fi * 15 + 9 + a - 18;
+    return fi < 0 ? -1 : fi * 15 + 12 + a - 21;
+}
+
 // ---- K6: reduced solve, one workgroup per window -------------------------------------------------
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -744,6 +756,72 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
                 for (int q = 0; q < 6; q++) hh += J[6 * q + a] * J[6 * q + b];
                 atomic_add_f64(&A[tri(base + a, base + b)], hh);
             }
+        }
+    }
+    // IMUFactor + IMUBiasFactor (K3): one thread per factor evaluates r and the whitened 9x24 Jacobian into an
+    // HBM scratch row; the J^T J accumulation is then spread over all threads (LDS atomics into A).
+    const int n_imu = W.imu_end - W.imu_begin;
+    if (n_imu > 0) {
+        const double* xv = P.xv + (long long)cur * P.xv_stride;
+        const double* xba = P.xba + (long long)cur * P.xv_stride;
+        const double* xbg = P.xbg + (long long)cur * P.xv_stride;
+        for (int k = tid; k < n_imu; k += blockDim.x) {
+            const ImuDev& f = P.imus[W.imu_begin + k];
+            double* sc = P.imu_scratch + (long long)(W.imu_begin + k) * (IMU_J + 6);
+            const int i = f.kf_i, j = f.kf_j;
+            const bool all_const = P.kf_fidx[i] < 0 && P.kf_fidx[j] < 0;
+            double dpi[6], dpj[6], r[9];
+            for (int q = 0; q < 6; q++) { dpi[q] = xp[6 * (long long)i + q]; dpj[q] = xp[6 * (long long)j + q]; }
+            imu_factor(f, P.kf_T0 + 12 * (long long)i, P.kf_T0 + 12 * (long long)j, P.kf_vel + 3 * (long long)i,
+                       P.kf_vel + 3 * (long long)j, dpi, dpj, xv + 3 * (long long)i, xv + 3 * (long long)j,
+                       xba + 3 * (long long)i, xbg + 3 * (long long)i, r, all_const ? nullptr : sc);
+            double c = 0.0;
+            for (int q = 0; q < 9; q++) { sc[9 * 24 + q] = r[q]; c += r[q] * r[q]; }
+            for (int q = 0; q < 3; q++) {
+                const double rb_a = f.sa * (P.kf_ba[3 * (long long)j + q] + xba[3 * (long long)j + q] - P.kf_ba[3 * (long long)i + q] - xba[3 * (long long)i + q]);
+                const double rb_g = f.sg * (P.kf_bg[3 * (long long)j + q] + xbg[3 * (long long)j + q] - P.kf_bg[3 * (long long)i + q] - xbg[3 * (long long)i + q]);
+                sc[IMU_J + q] = rb_a; sc[IMU_J + 3 + q] = rb_g;
+                c += rb_a * rb_a + rb_g * rb_g;
+            }
+            if (all_const) fixed_part += c; else cost_part += c;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // J^T J of the IMU factors: item = (factor, a, b <= a)
+        for (int it = tid; it < n_imu * 300; it += blockDim.x) {
+            const int k = it / 300;
+            int e = it - 300 * k, a = 0;
+            while (e >= a + 1) { e -= a + 1; a++; }
+            const int b = e;
+            const ImuDev& f = P.imus[W.imu_begin + k];
+            const int fi = P.kf_fidx[f.kf_i], fj = P.kf_fidx[f.kf_j];
+            if (fi < 0 && fj < 0) continue;
+            const int ca = imu_col(a, fi, fj), cb = imu_col(b, fi, fj);
+            if (ca < 0 || cb < 0) continue;
+            const double* sc = P.imu_scratch + (long long)(W.imu_begin + k) * (IMU_J + 6);
+            double h = 0.0;
+#pragma unroll
+            for (int q = 0; q < 9; q++) h += sc[q * 24 + a] * sc[q * 24 + b];
+            atomic_add_f64(&A[ca >= cb ? tri(ca, cb) : tri(cb, ca)], h);
+            if (a == b) {
+                double g = 0.0;
+#pragma unroll
+                for (int q = 0; q < 9; q++) g += sc[q * 24 + a] * sc[9 * 24 + q];
+                atomic_add_f64(&y[ca], g); atomic_add_f64(&gf[ca], g); atomic_add_f64(&hd[ca], h);
+            }
+        }
+        // bias random walk: item = (factor, axis, ba|bg): Jacobians are -/+ s I
+        for (int it = tid; it < n_imu * 6; it += blockDim.x) {
+            const int k = it / 6, e = it - 6 * k, ax = e % 3, gy = e / 3;
+            const ImuDev& f = P.imus[W.imu_begin + k];
+            const int fi = P.kf_fidx[f.kf_i], fj = P.kf_fidx[f.kf_j];
+            const double sgm = gy ? f.sg : f.sa;
+            const double rb = P.imu_scratch[(long long)(W.imu_begin + k) * (IMU_J + 6) + IMU_J + 3 * gy + ax];
+            const int ci = fi < 0 ? -1 : fi * 15 + 9 + 3 * gy + ax, cj = fj < 0 ? -1 : fj * 15 + 9 + 3 * gy + ax;
+            const double s2 = sgm * sgm;
+            if (ci >= 0) { atomic_add_f64(&A[tri(ci, ci)], s2); atomic_add_f64(&hd[ci], s2); atomic_add_f64(&y[ci], -sgm * rb); atomic_add_f64(&gf[ci], -sgm * rb); }
+            if (cj >= 0) { atomic_add_f64(&A[tri(cj, cj)], s2); atomic_add_f64(&hd[cj], s2); atomic_add_f64(&y[cj], sgm * rb); atomic_add_f64(&gf[cj], sgm * rb); }
+            if (ci >= 0 && cj >= 0) atomic_add_f64(&A[ci >= cj ? tri(ci, cj) : tri(cj, ci)], -s2);
         }
     }
     // window totals of the linearisation: tiles' k_build partials + the pose-only factors evaluated here
@@ -863,6 +941,59 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         for (int i = 0; i < 6; i++) d6[i] += y[fi * W.dpf + i];
         pose_prior_factor(P.kf_T0 + 12 * (long long)pr.kf, pr.T_prior, pr.inf, d6, rc, nullptr);
         for (int q = 0; q < 6; q++) cc += rc[q] * rc[q];
+    }
+    if (n_imu > 0) {
+        const double* xv = P.xv + (long long)cur * P.xv_stride;
+        const double* xba = P.xba + (long long)cur * P.xv_stride;
+        const double* xbg = P.xbg + (long long)cur * P.xv_stride;
+        // model cost change, item = (factor, residual row); y holds delta
+        for (int it = tid; it < n_imu * 15; it += blockDim.x) {
+            const int k = it / 15, q = it - 15 * k;
+            const ImuDev& f = P.imus[W.imu_begin + k];
+            const int fi = P.kf_fidx[f.kf_i], fj = P.kf_fidx[f.kf_j];
+            if (fi < 0 && fj < 0) continue;
+            const double* sc = P.imu_scratch + (long long)(W.imu_begin + k) * (IMU_J + 6);
+            double m = 0.0, r;
+            if (q < 9) {
+                for (int a = 0; a < 24; a++) { const int ca = imu_col(a, fi, fj); if (ca >= 0) m += sc[q * 24 + a] * y[ca]; }
+                r = sc[9 * 24 + q];
+            } else {
+                const int e = q - 9, ax = e % 3, gy = e / 3;
+                const double sgm = gy ? f.sg : f.sa;
+                if (fi >= 0) m -= sgm * y[fi * 15 + 9 + 3 * gy + ax];
+                if (fj >= 0) m += sgm * y[fj * 15 + 9 + 3 * gy + ax];
+                r = sc[IMU_J + e];
+            }
+            mcc += -m * (r + 0.5 * m);
+        }
+        // candidate cost: one thread per factor at x + delta
+        for (int k = tid; k < n_imu; k += blockDim.x) {
+            const ImuDev& f = P.imus[W.imu_begin + k];
+            const int i = f.kf_i, j = f.kf_j;
+            const int fi = P.kf_fidx[i], fj = P.kf_fidx[j];
+            if (fi < 0 && fj < 0) continue;
+            double dpi[6], dpj[6], dvi[3], dvj[3], dbai[3], dbgi[3], dbaj[3], dbgj[3], r[9];
+            for (int q = 0; q < 6; q++) {
+                dpi[q] = xp[6 * (long long)i + q] + (fi < 0 ? 0.0 : y[fi * 15 + q]);
+                dpj[q] = xp[6 * (long long)j + q] + (fj < 0 ? 0.0 : y[fj * 15 + q]);
+            }
+            for (int q = 0; q < 3; q++) {
+                dvi[q] = xv[3 * (long long)i + q] + (fi < 0 ? 0.0 : y[fi * 15 + 6 + q]);
+                dvj[q] = xv[3 * (long long)j + q] + (fj < 0 ? 0.0 : y[fj * 15 + 6 + q]);
+                dbai[q] = xba[3 * (long long)i + q] + (fi < 0 ? 0.0 : y[fi * 15 + 9 + q]);
+                dbgi[q] = xbg[3 * (long long)i + q] + (fi < 0 ? 0.0 : y[fi * 15 + 12 + q]);
+                dbaj[q] = xba[3 * (long long)j + q] + (fj < 0 ? 0.0 : y[fj * 15 + 9 + q]);
+                dbgj[q] = xbg[3 * (long long)j + q] + (fj < 0 ? 0.0 : y[fj * 15 + 12 + q]);
+            }
+            imu_factor(f, P.kf_T0 + 12 * (long long)i, P.kf_T0 + 12 * (long long)j, P.kf_vel + 3 * (long long)i,
+                       P.kf_vel + 3 * (long long)j, dpi, dpj, dvi, dvj, dbai, dbgi, r, nullptr);
+            for (int q = 0; q < 9; q++) cc += r[q] * r[q];
+            for (int q = 0; q < 3; q++) {
+                const double ra = f.sa * (P.kf_ba[3 * (long long)j + q] + dbaj[q] - P.kf_ba[3 * (long long)i + q] - dbai[q]);
+                const double rg = f.sg * (P.kf_bg[3 * (long long)j + q] + dbgj[q] - P.kf_bg[3 * (long long)i + q] - dbgi[q]);
+                cc += ra * ra + rg * rg;
+            }
+        }
     }
     SADVIO_TS(3, 7);
     sn = wave_sum(sn); cn = wave_sum(cn); mcc = wave_sum(mcc); cc = wave_sum(cc);
