@@ -273,7 +273,9 @@ class Backend:
     def solve(self, opts: Optional[SolveOptions] = None) -> List[SolveSummary]:
         opts = opts or reference_options()
         sums = (SolveSummary * len(self.windows))()
-        self._check(self.lib.sadvio_ba_solve(self.h, C.byref(opts), sums), "solve")
+        rc = self.lib.sadvio_ba_solve(self.h, C.byref(opts), sums)
+        if rc != E_NOT_USABLE:  # "not usable" (Ceres FAILURE of some window) is reported through summary.termination
+            self._check(rc, "solve")
         return list(sums)
 
     def get_deltas(self, w: int = 0):

@@ -69,6 +69,7 @@ struct sadvio_ba_handle {
     std::vector<HostWin> wins;
     std::vector<Tile> tiles;
     std::vector<PriorDev> priors;
+    std::vector<int> obs_perm;  // device observation position -> caller's observation index (within window)
     std::vector<std::vector<PriorDev>> priors_per_win;
     std::vector<std::vector<ImuDev>> imus_per_win;
     std::vector<ImuDev> imus;
@@ -90,7 +91,7 @@ struct sadvio_ba_handle {
     DevBuf<int> d_lmk_ob, d_lmk_oe, d_obs_kf, d_obs_cam, d_tile_kf, d_tile_row;
     DevBuf<unsigned char> d_obs_slot;
     DevBuf<double> d_ptab;
-    int max_tile_kf = 1, max_tile_free = 0;
+    int max_tile_kf = 1, max_tile_free = 0, max_gemm_free = 0;
     DevBuf<double> d_obs_meas;
     DevBuf<PriorDev> d_priors;
     DevBuf<ImuDev> d_imus;
@@ -343,7 +344,8 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
     std::vector<double> obs_meas((size_t)ms * std::max(obs_b, 1));
     std::vector<int> tile_kf, tile_row;
     std::vector<unsigned char> obs_slot(std::max(obs_b, 1), 0);
-    h->max_tile_kf = 1; h->max_tile_free = 0;
+    h->obs_perm.assign(std::max(obs_b, 1), 0);
+    h->max_tile_kf = 1; h->max_tile_free = 0; h->max_gemm_free = 0;
     for (int w = 0; w < n_windows; w++) {
         const sadvio_flat_window& F = wins[w];
         WinDev& d = h->wins[w].d;
@@ -363,11 +365,28 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
             lmk_oe[d.lmk_base + l] = d.obs_base + F.lmk_obs_ptr[l + 1];
             if (F.lmk_obs_ptr[l + 1] < F.lmk_obs_ptr[l]) { h->err = "set_windows: CSR not monotone"; return SADVIO_E_INVALID_ARG; }
         }
-        for (int o = 0; o < F.n_obs; o++) {
-            obs_kf[d.obs_base + o] = d.kf_base + F.obs_kf[o];
-            obs_cam[d.obs_base + o] = d.cam_base + F.obs_cam[o];
+        // Observations of a landmark are stored sorted by key-frame (stable), so that the (at most two) cameras
+        // of one key-frame sit in adjacent lanes; the landmark / key-frame order of the window is untouched and
+        // obs_perm maps device position -> caller position for the per-observation probe.
+        std::vector<int> pkf(F.n_obs), pcam(F.n_obs);
+        std::vector<int> run_max(F.n_lmk, 0);
+        for (int l = 0; l < F.n_lmk; l++) {
+            const int o0 = F.lmk_obs_ptr[l], o1 = F.lmk_obs_ptr[l + 1];
+            std::vector<int> idx(o1 - o0);
+            for (int k = 0; k < o1 - o0; k++) idx[k] = o0 + k;
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return F.obs_kf[a] < F.obs_kf[b]; });
+            int run = 0;
+            for (int k = 0; k < o1 - o0; k++) {
+                const int src = idx[k], dst = o0 + k;
+                pkf[dst] = F.obs_kf[src]; pcam[dst] = F.obs_cam[src];
+                h->obs_perm[d.obs_base + dst] = src;
+                obs_kf[d.obs_base + dst] = d.kf_base + F.obs_kf[src];
+                obs_cam[d.obs_base + dst] = d.cam_base + F.obs_cam[src];
+                memcpy(&obs_meas[(size_t)ms * (d.obs_base + dst)], F.obs_meas + (size_t)ms * src, sizeof(double) * ms);
+                run = (k > 0 && pkf[dst] == pkf[dst - 1]) ? run + 1 : 1;
+                run_max[l] = std::max(run_max[l], run);
+            }
         }
-        if (F.n_obs) memcpy(&obs_meas[(size_t)ms * d.obs_base], F.obs_meas, sizeof(double) * ms * F.n_obs);
         // tiles: runs of consecutive landmarks. Every landmark gets a group of G lanes (G = pow2 >= the
         // tile's largest observation count); a workgroup of BUILD_WAVES waves holds BUILD_WAVES * 64 / G
         // landmarks per round. A tile is cut when its key-frame list would exceed the LDS tile capacity.
@@ -383,7 +402,7 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
                 t.cam_base = d.cam_base; t.n_cam = F.n_cam;
                 t.first_of_window = ((int)h->tiles.size() == d.tile_begin) ? 1 : 0;
                 std::vector<int> kfs;
-                int nfree = 0;
+                int nfree = 0, tile_run_max = 0;
                 const int l_begin = l;
                 while (l < F.n_lmk) {
                     const int k = F.lmk_obs_ptr[l + 1] - F.lmk_obs_ptr[l];
@@ -396,7 +415,7 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
                     std::vector<int> add;
                     int add_free = 0;
                     for (int o = F.lmk_obs_ptr[l]; o < F.lmk_obs_ptr[l + 1]; o++) {
-                        const int kf = F.obs_kf[o];
+                        const int kf = pkf[o];
                         if (mark[kf] != (int)h->tiles.size()) {
                             mark[kf] = (int)h->tiles.size();
                             add.push_back(kf);
@@ -412,12 +431,14 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
                     nfree += add_free;
                     t.G = G;
                     t.kmax = std::max(t.kmax, k);
+                    tile_run_max = std::max(tile_run_max, run_max[l]);
                     l++;
                     if (!fits) break;  // a single landmark exceeding the capacity: global-atomics tile
                 }
                 t.lmk1 = d.lmk_base + l;
                 std::sort(kfs.begin(), kfs.end());
-                t.lds_mode = ((int)kfs.size() <= MAX_TILE_KF && nfree <= MAX_TILE_FREE_KF) ? 1 : 0;
+                t.lds_mode = ((int)kfs.size() <= MAX_TILE_KF && nfree <= MAX_TILE_FREE_KF) ? ((nfree <= MAX_GEMM_FREE_KF && tile_run_max <= 2 && t.G == 8) ? 2 : 1) : 0;
+                if (t.lds_mode == 2) h->max_gemm_free = std::max(h->max_gemm_free, nfree);
                 if ((int)kfs.size() > 64) { h->err = "set_windows: a landmark is observed from more than 64 key-frames"; return SADVIO_E_INVALID_ARG; }
                 t.kf_off = (int)tile_kf.size(); t.n_kf = (int)kfs.size(); t.n_free = t.lds_mode ? nfree : 0;
                 std::vector<int> slot_of(F.n_kf, -1);
@@ -433,7 +454,7 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
                 }
                 for (int ll = l_begin; ll < l; ll++)
                     for (int o = F.lmk_obs_ptr[ll]; o < F.lmk_obs_ptr[ll + 1]; o++)
-                        obs_slot[d.obs_base + o] = (unsigned char)slot_of[F.obs_kf[o]];
+                        obs_slot[d.obs_base + o] = (unsigned char)slot_of[pkf[o]];
                 h->max_tile_kf = std::max(h->max_tile_kf, t.n_kf);
                 h->max_tile_free = std::max(h->max_tile_free, t.n_free);
                 h->tiles.push_back(t);
@@ -616,7 +637,20 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     const int n_tiles = (int)h->tiles.size();
     const int mtk = h->max_tile_kf;
     const size_t nt = 6 * (size_t)h->max_tile_free;
-    const size_t lds_build = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)BUILD_WAVES * STAGE_VALS * 64 + nt * (nt + 1) / 2 + 3 * nt) + 16;
+    int Rp = 16 * ((6 * h->max_gemm_free + 15) / 16);                          // padded rows of the Y / E strips
+    int strip_doubles = std::max(STAGE_VALS * 64, 2 * Rp * (32 + 2));          // per wave (also holds the wave's tile copy)
+    size_t lds_build = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)BUILD_WAVES * strip_doubles + nt * (nt + 1) / 2 + 3 * nt +
+                                                                   BUILD_WAVES * MAX_GEMM_FREE_KF * 33) + 16;
+    if (lds_build > 160 * 1024 && h->max_gemm_free > 0) {
+        // a window mixing short tracks with very long ones: the MFMA strips + the large atomic tile do not fit
+        // together; run every tile on the ds_add_f64 path instead
+        for (auto& t : h->tiles) if (t.lds_mode == 2) t.lds_mode = 1;
+        HIP_TRY(hipMemcpyAsync(h->d_tiles.p, h->tiles.data(), h->tiles.size() * sizeof(Tile), hipMemcpyHostToDevice, h->stream));
+        h->max_gemm_free = 0;
+        Rp = 0; strip_doubles = STAGE_VALS * 64;
+        lds_build = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)BUILD_WAVES * strip_doubles + nt * (nt + 1) / 2 + 3 * nt +
+                                                               BUILD_WAVES * MAX_GEMM_FREE_KF * 33) + 16;
+    }
     const size_t lds_back = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)mtk * 18) + 16;
     const size_t lds_solve = sizeof(double) * ((size_t)(h->max_np + 2) * 6 + (size_t)(h->max_np + 1) * (h->max_np + 2) / 2 +
                                                4 * (size_t)h->max_np + (size_t)(h->max_np / 5 + 1) * 36) + 64;
@@ -627,7 +661,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     HIP_TRY(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
     { ScopedTimer t(h, "k_init_tables"); hipLaunchKernelGGL(k_init_tables, dim3((h->n_kf_tot + 63) / 64), dim3(64), 0, h->stream, P, h->n_kf_tot); }
     for (int s = 0; s < slots; s++) {
-        { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk); }
+        { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
         { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(k_solve, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
         { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
     }
@@ -646,7 +680,9 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         if (hipMemcpy(ts, h->d_dbg.p, sizeof(ts), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[sadvio dbg] phase dt (us):");
             for (int i = 1; i < 16; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[0]) * 0.01);
-            fprintf(stderr, "  shader clock %.3f GHz\n", (double)(ts[21] - ts[20]) / ((ts[15] - ts[0]) * 10.0));
+            fprintf(stderr, "  shader clock %.3f GHz\n[sadvio dbg] k_build:", (double)(ts[21] - ts[20]) / ((ts[15] - ts[0]) * 10.0));
+            for (int i = 33; i < 43; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[32]) * 0.01);
+            fprintf(stderr, "\n");
         }
     }
     h->last_slots = slots;
@@ -714,10 +750,15 @@ int sadvio_ba_linearize(sadvio_ba_handle* h, int32_t w, const double* pose_delta
     if (h->factor_type == SADVIO_FACTOR_PIXEL) hipLaunchKernelGGL(k_linearize_probe<0>, dim3(blocks), dim3(256), 0, h->stream, P, w, pr, pj, pl);
     else hipLaunchKernelGGL(k_linearize_probe<1>, dim3(blocks), dim3(256), 0, h->stream, P, w, pr, pj, pl);
     HIP_TRY(hipGetLastError());
-    if (r2) HIP_TRY(hipMemcpyAsync(r2, pr, sizeof(double) * 2 * d.n_obs, hipMemcpyDeviceToHost, h->stream));
-    if (Jp12) HIP_TRY(hipMemcpyAsync(Jp12, pj, sizeof(double) * 12 * d.n_obs, hipMemcpyDeviceToHost, h->stream));
-    if (Jl6) HIP_TRY(hipMemcpyAsync(Jl6, pl, sizeof(double) * 6 * d.n_obs, hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> hb(20 * (size_t)d.n_obs);
+    HIP_TRY(hipMemcpyAsync(hb.data(), pr, sizeof(double) * 20 * (size_t)d.n_obs, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int a = 0; a < d.n_obs; a++) {
+        const int src = h->obs_perm[d.obs_base + a];  // caller's index of the observation stored at position a
+        if (r2) memcpy(r2 + 2 * (size_t)src, &hb[2 * (size_t)a], 16);
+        if (Jp12) memcpy(Jp12 + 12 * (size_t)src, &hb[2 * (size_t)d.n_obs + 12 * (size_t)a], 96);
+        if (Jl6) memcpy(Jl6 + 6 * (size_t)src, &hb[14 * (size_t)d.n_obs + 6 * (size_t)a], 48);
+    }
     h->solved = false;
     return SADVIO_OK;
 }

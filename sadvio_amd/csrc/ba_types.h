@@ -49,7 +49,7 @@ struct Tile {
     int G;            // lanes per landmark: power of two, 8 .. 64
     int kf_off, n_kf; // slice of tile_kf / tile_row
     int n_free;       // free key-frames in the slice: LDS tile dimension = 6 * n_free
-    int lds_mode;     // 1: accumulate in the LDS tile and flush; 0: global atomics (too many key-frames)
+    int lds_mode;     // 2: LDS tile, MFMA contraction over landmarks; 1: LDS tile, per-pair ds_add_f64; 0: global atomics
     int dpf, Np;      // window's reduced layout
     int red_off;
     int cam_base, n_cam;
@@ -113,6 +113,7 @@ constexpr int BUILD_THREADS = 256;  // 4 waves; each wave owns 64 / G landmarks 
 constexpr int BUILD_WAVES = BUILD_THREADS / 64;
 constexpr int MAX_TILE_KF = 24;      // key-frames (free + constant) a tile may touch
 constexpr int MAX_TILE_FREE_KF = 20; // free ones: LDS tile <= 120 x 121 / 2 doubles = 58 KB
+constexpr int MAX_GEMM_FREE_KF = 8;  // tiles touching <= 8 free key-frames accumulate through the MFMA contraction
 constexpr int MAX_WIN_CAM = 8;       // cameras per window staged in LDS
 constexpr int STAGE_VALS = 18;       // Jp[12] Jl[6] exchanged between the lanes of a landmark group
 constexpr int MAX_LMK_OBS = 64;      // observations per landmark (one lane each)

@@ -128,10 +128,57 @@ __device__ __forceinline__ void wave_sum_backsub_partials(const DevPtrs& P, int 
 }
 
 // ---- landmark-group machinery shared by k_build and k_backsub ------------------------------------
-// Sum over the G lanes of a landmark group (G = power of two <= 64, groups aligned to G lanes).
+// ---- cross-lane primitives without the LDS pipe -------------------------------------------------------
+// ds_bpermute / ds_swizzle shuffles and ds_add_f64 cost ~100-170 cycles per wave-instruction here (measured),
+// DPP modifiers and the gfx950 v_permlane{16,32}_swap are plain VALU. dpp_ctrl: quad_perm 0x00-0xFF,
+// row_shl:n 0x100+n, row_shr:n 0x110+n, row_ror:n 0x120+n, row_mirror 0x140, row_half_mirror 0x141.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+// v[lane] + v[lane ^ 16] / v[lane ^ 32] in every lane
+__device__ __forceinline__ double xor16_sum(double v) {
+    unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double xor32_sum(double v) {
+    unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ int xor16_other(int v) {  // the value held by lane ^ 16
+    auto a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((threadIdx.x & 16) ? a[0] : a[1]);
+}
+__device__ __forceinline__ int xor32_other(int v) {
+    auto a = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((threadIdx.x & 32) ? a[0] : a[1]);
+}
+
+// Sum over the G lanes of a landmark group (G = power of two, 8 <= G <= 64, groups aligned to G lanes);
+// every lane of the group receives the total.
 __device__ __forceinline__ double group_sum(double v, int G) {
-    for (int off = 1; off < G; off <<= 1) v += __shfl_xor(v, off, 64);
+    v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]  (xor 1)
+    v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]  (xor 2)
+    v += dpp_f64<0x141>(v);  // row_half_mirror: the other quad of the 8-lane group
+    if (G >= 16) v += dpp_f64<0x140>(v);  // row_mirror: the other half of the 16-lane row
+    if (G >= 32) v = xor16_sum(v);
+    if (G >= 64) v = xor32_sum(v);
     return v;
+}
+// Sum over the 64 / 8 groups of a wave, lane q of every group receives the total of lanes q (G = 8 only).
+__device__ __forceinline__ double across_groups8_sum(double v) {
+    v += dpp_f64<0x128>(v);  // row_ror:8 (xor 8)
+    v = xor16_sum(v);
+    return xor32_sum(v);
 }
 
 struct ObsLin {
@@ -250,10 +297,11 @@ __host__ __device__ inline size_t tile_tables_bytes(int n_kf) {
 
 // ---- K5: build the reduced system ----------------------------------------------------------------
 template <int FACTOR>
-__global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, int max_tile_kf) {
+__global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, int max_tile_kf, int strip_doubles, int Rp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Tile T = P.tiles[blockIdx.x];
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    SADVIO_TS(3, 32);
     __shared__ double s_part[BUILD_WAVES * 4];
     LmState st;
     if (slot == 0) st = P.states[(long long)T.w * P.state_stride];
@@ -268,23 +316,28 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, in
     }
     if (slot > 0 && T.first_of_window && tid == 0) P.states[(long long)T.w * P.state_stride + slot] = st;
     if (st.done) return;
+    SADVIO_TS(3, 33);
     // LDS carve
     double* poseTab = (double*)smem;
     double* camTab = poseTab + (size_t)max_tile_kf * POSE_TAB;
     int* rowTab = (int*)(camTab + MAX_WIN_CAM * 17);
-    double* stage = (double*)(smem + tile_tables_bytes(max_tile_kf));  // [BUILD_WAVES][STAGE_VALS][64]
-    double* Stile = stage + BUILD_WAVES * STAGE_VALS * 64;
+    double* stage = (double*)(smem + tile_tables_bytes(max_tile_kf));  // [BUILD_WAVES][strip_doubles] wave-private strips
+    double* Stile = stage + BUILD_WAVES * strip_doubles;
     const int Nt = 6 * T.n_free;
     const int tri_n = Nt * (Nt + 1) / 2;
     double* gT = Stile + tri_n;
     double* gfT = gT + Nt;
     double* hdT = gfT + Nt;
+    double* waveD = hdT + Nt;                         // [BUILD_WAVES][MAX_GEMM_FREE_KF][33] per-wave D / gradients (gemm tiles)
     const bool lds_mode = T.lds_mode != 0;
     stage_tables(P, T, st.cur, poseTab, camTab, rowTab);
-    if (lds_mode)
-        for (int i = tid; i < tri_n + 3 * Nt; i += blockDim.x) Stile[i] = 0.0;
+    if (lds_mode) {
+        const int nz = tri_n + 3 * Nt + (T.lds_mode == 2 ? BUILD_WAVES * MAX_GEMM_FREE_KF * 33 : 0);
+        for (int i = tid; i < nz; i += blockDim.x) Stile[i] = 0.0;
+    }
     __syncthreads();
 
+    SADVIO_TS(3, 34);
     double* Sg = P.S + T.S_off;
     double* gredg = P.gred + T.red_off;
     double* gfullg = P.gfull + T.red_off;
@@ -294,7 +347,8 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, in
     const int grp = ln / G, q = ln - grp * G;
     const int nl = T.lmk1 - T.lmk0;
     const double* xl = P.xl + (long long)st.cur * P.xl_stride;
-    double* wstage = stage + wv * STAGE_VALS * 64;
+    double* wstage = stage + wv * strip_doubles;
+    const bool gemm_mode = T.lds_mode == 2;
     double cost_part = 0.0, fixed_part = 0.0, gmax_part = 0.0;
     for (int base = wv * lpw; base < nl; base += BUILD_WAVES * lpw) {
         const int lm = base + grp;
@@ -320,9 +374,11 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, in
 #pragma unroll
             for (int i = 0; i < 6; i++) L.Jl[i] = 0.0;
         }
+    SADVIO_TS(3, 35);
         double Mi[6], g[3];
         const bool active = group_eliminate(P, L, G, gl, lmk_valid, lfree, nobs, st.radius, slot == 0, q == 0, Mi, g);
         if (active && q == 0) gmax_part = fmax(gmax_part, fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2]))));
+    SADVIO_TS(3, 36);
         // N = Jl Minv (2x3), reduced residual r~ = r - N g_l
         double N[6];
 #pragma unroll
@@ -332,6 +388,133 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, in
             N[3 * qq + 1] = j0 * Mi[1] + j1 * Mi[3] + j2 * Mi[4];
             N[3 * qq + 2] = j0 * Mi[2] + j1 * Mi[4] + j2 * Mi[5];
         }
+        if (gemm_mode) {
+            // ---- Schur accumulation without LDS atomics ---------------------------------------------------
+            //   S_tile = sum_a Jp_a^T Jp_a - sum_l Y_l E_l^T,  Y_l[KF] = sum_{a in KF} Jp_a^T (Jl_a Minv),
+            //   E_l[KF] = sum_{a in KF} Jp_a^T Jl_a.
+            // (1) the (at most two, adjacent) observations of a landmark in one key-frame are pre-summed with DPP;
+            // (2) Y / E go with plain stores into wave-private strips [row][k], k = 4 * landmark + c: distinct
+            //     landmarks own distinct k, so nothing collides; sum_l Y_l E_l^T is then a K-contraction on the
+            //     FP64 matrix cores (one v_mfma_f64_16x16x4_f64 chain per 16x16 block);
+            // (3) the block-diagonal part and the gradients are summed across the wave's 8 landmarks with DPP /
+            //     v_permlane swaps when all of them see the same key-frames in the same lanes (the common case for
+            //     landmarks created together), else with ds_add_f64.
+            const int Kw = 4 * lpw, KS = Kw + 2;
+            double* Yb = wstage;
+            double* Eb = wstage + Rp * KS;
+            {
+                double2* z = (double2*)wstage;
+                const double2 zero2 = make_double2(0.0, 0.0);
+                for (int i = ln; i < Rp * KS; i += 64) z[i] = zero2;  // 2 * Rp * KS doubles
+            }
+            const bool vrow = L.valid && L.row >= 0;
+            const int myrow = vrow ? L.row : -2 - ln;           // unique negative: never equal to a neighbour's
+            const int row_prev = dpp_i32<0x111>(myrow);         // lane - 1
+            const int row_next = dpp_i32<0x101>(myrow);         // lane + 1
+            const bool follower = vrow && q > 0 && row_prev == myrow;
+            const bool has_follower = vrow && q + 1 < G && row_next == myrow;
+            const bool head = vrow && !follower;
+            const double rt0 = L.r[0] - (N[0] * g[0] + N[1] * g[1] + N[2] * g[2]);
+            const double rt1 = L.r[1] - (N[3] * g[0] + N[4] * g[1] + N[5] * g[2]);
+            wave_lds_fence();
+    SADVIO_TS(3, 37);
+            // Y, E rows of this lane's key-frame (pair-summed), plain 16-byte stores by the run heads
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double j0 = vrow ? L.Jp[i] : 0.0, j1 = vrow ? L.Jp[6 + i] : 0.0;
+                double y[3], e[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    y[c] = j0 * N[c] + j1 * N[3 + c];
+                    e[c] = j0 * L.Jl[c] + j1 * L.Jl[3 + c];
+                    const double yn = dpp_f64<0x101>(y[c]), en = dpp_f64<0x101>(e[c]);
+                    if (has_follower) { y[c] += yn; e[c] += en; }
+                }
+                if (head) {
+                    double2* yp = (double2*)(Yb + (myrow + i) * KS + 4 * grp);
+                    double2* ep = (double2*)(Eb + (myrow + i) * KS + 4 * grp);
+                    yp[0] = make_double2(y[0], y[1]); yp[1] = make_double2(y[2], 0.0);
+                    ep[0] = make_double2(e[0], e[1]); ep[1] = make_double2(e[2], 0.0);
+                }
+            }
+            // block-diagonal part D = Jp^T Jp (21) + reduced / full gradient (6 + 6)
+            {
+                const int rowu = vrow ? L.row : -1;
+                int mism = (dpp_i32<0x128>(rowu) != rowu) | (xor16_other(rowu) != rowu) | (xor32_other(rowu) != rowu);
+                const bool uniform = (G == 8) && (__ballot(mism) == 0ull);
+                double* wD = waveD + (wv * MAX_GEMM_FREE_KF + (head ? myrow / 6 : 0)) * 33;
+                int e = 0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const double j0 = vrow ? L.Jp[i] : 0.0, j1 = vrow ? L.Jp[6 + i] : 0.0;
+#pragma unroll
+                    for (int j = 0; j <= i; j++) {
+                        double v = j0 * L.Jp[j] + j1 * L.Jp[6 + j];
+                        if (!vrow) v = 0.0;
+                        const double vn = dpp_f64<0x101>(v);
+                        if (has_follower) v += vn;
+                        if (uniform) { v = across_groups8_sum(v); if (head && grp == 0) wD[e] = v; }
+                        else if (head) { atomic_add_f64(&Stile[tri(myrow + i, myrow + j)], v); if (i == j) atomic_add_f64(&hdT[myrow + i], v); }
+                        e++;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const double j0 = vrow ? L.Jp[i] : 0.0, j1 = vrow ? L.Jp[6 + i] : 0.0;
+                    double gr = j0 * rt0 + j1 * rt1, gf = j0 * L.r[0] + j1 * L.r[1];
+                    const double grn = dpp_f64<0x101>(gr), gfn = dpp_f64<0x101>(gf);
+                    if (has_follower) { gr += grn; gf += gfn; }
+                    if (uniform) {
+                        gr = across_groups8_sum(gr); gf = across_groups8_sum(gf);
+                        if (head && grp == 0) { wD[21 + i] = gr; wD[27 + i] = gf; }
+                    } else if (head) { atomic_add_f64(&gT[myrow + i], gr); atomic_add_f64(&gfT[myrow + i], gf); }
+                }
+            }
+            wave_lds_fence();
+    SADVIO_TS(3, 38);
+            {
+                typedef double d4 __attribute__((ext_vector_type(4)));
+                const int lr = ln & 15, lk = ln >> 4;
+                const int nt16 = (Nt + 15) >> 4;
+                d4 accs[6];  // <= 3 x 3 lower tile pairs (Nt <= 48); results stay in registers until every
+                             // operand has been read, then overwrite this wave's strip (waveS aliases it)
+#pragma unroll
+                for (int pp = 0; pp < 6; pp++) {
+                    const int tr = pp < 1 ? 0 : (pp < 3 ? 1 : 2), tc = pp - (tr * (tr + 1)) / 2;
+                    accs[pp] = (d4){0.0, 0.0, 0.0, 0.0};
+                    if (tr < nt16) {
+                        double av[8], bv[8];
+#pragma unroll
+                        for (int kk = 0; kk < 8; kk++) {  // all operand loads first, then the MFMA chain
+                            const int k = (4 * kk < Kw) ? 4 * kk + lk : lk;
+                            av[kk] = Yb[(16 * tr + lr) * KS + k];
+                            bv[kk] = Eb[(16 * tc + lr) * KS + k];
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < 8; kk++)
+                            if (4 * kk < Kw) accs[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], accs[pp], 0, 0, 0);
+                    }
+                }
+                wave_lds_fence();
+                double* wS = wstage;  // per-wave copy of the tile's lower triangle
+                for (int i = ln; i < tri_n; i += 64) wS[i] = 0.0;
+                wave_lds_fence();
+#pragma unroll
+                for (int pp = 0; pp < 6; pp++) {
+                    const int tr = pp < 1 ? 0 : (pp < 3 ? 1 : 2), tc = pp - (tr * (tr + 1)) / 2;
+                    if (tr < nt16) {
+                        const int col = 16 * tc + lr;
+#pragma unroll
+                        for (int rg = 0; rg < 4; rg++) {
+                            const int row = 16 * tr + lk + 4 * rg;
+                            if (row < Nt && col <= row) wS[tri(row, col)] = -accs[pp][rg];
+                        }
+                    }
+                }
+            }
+    SADVIO_TS(3, 39);
+            wave_lds_fence();
+        } else {
         // exchange Jp / Jl with the other lanes of the group through the wave's private LDS strip
 #pragma unroll
         for (int i = 0; i < 12; i++) wstage[i * 64 + ln] = L.Jp[i];
@@ -392,6 +575,8 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, in
         }
         wave_lds_fence();  // the strip is reused by the next round
     }
+        }
+    SADVIO_TS(3, 40);
     // cost / gradient-max: per-tile partial, plain store (no same-address atomics across the chip)
     const double c = wave_sum(cost_part), f = wave_sum(fixed_part), gm = wave_max(gmax_part);
     if (ln == 0) { s_part[wv * 4] = c; s_part[wv * 4 + 1] = f; s_part[wv * 4 + 2] = gm; }
@@ -401,6 +586,30 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, in
         for (int k = 0; k < BUILD_WAVES; k++) { cs += s_part[k * 4]; fs += s_part[k * 4 + 1]; gs = fmax(gs, s_part[k * 4 + 2]); }
         TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + blockIdx.x;
         ta->lin_cost = cs; ta->fixed_cost = fs; ta->gmax = gs;
+    }
+    SADVIO_TS(3, 41);
+    if (T.lds_mode == 2) {
+        // merge the per-wave results into the tile (plain adds: one thread per element)
+        for (int e = tid; e < tri_n; e += blockDim.x) {
+            double v = 0.0;
+            for (int w = 0; w < BUILD_WAVES; w++)
+                if (w * lpw < nl) v += stage[w * strip_doubles + e];  // waves without landmarks never wrote their strip
+            Stile[e] += v;
+        }
+        __syncthreads();  // the plain read-modify-writes above must land before the adds below touch the diagonal blocks
+        for (int it = tid; it < T.n_free * 33; it += blockDim.x) {
+            const int sl = it / 33, e = it - 33 * sl;
+            double v = 0.0;
+            for (int w = 0; w < BUILD_WAVES; w++) v += waveD[(w * MAX_GEMM_FREE_KF + sl) * 33 + e];
+            if (e < 21) {
+                int i = 0, r = e;
+                while (r >= i + 1) { r -= i + 1; i++; }
+                atomic_add_f64(&Stile[tri(6 * sl + i, 6 * sl + r)], v);  // LDS, distinct addresses per thread, few
+                if (i == r) atomic_add_f64(&hdT[6 * sl + i], v);
+            } else if (e < 27) atomic_add_f64(&gT[6 * sl + e - 21], v);
+            else atomic_add_f64(&gfT[6 * sl + e - 27], v);
+        }
+        __syncthreads();
     }
     if (lds_mode) {
         if (P.debug & 2) return;
@@ -431,6 +640,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, in
             if (hdT[i] != 0.0) atomic_add_f64(&hdg[row], hdT[i]);
         }
     }
+    SADVIO_TS(3, 42);
 }
 
 // Blocked right-looking Cholesky of the packed lower-triangular matrix P ((N+1) rows: row N is the
