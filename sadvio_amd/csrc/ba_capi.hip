@@ -422,7 +422,9 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
                             if (!(F.kf_const && F.kf_const[kf])) add_free++;
                         }
                     }
-                    const bool fits = (int)(kfs.size() + add.size()) <= MAX_TILE_KF && nfree + add_free <= MAX_TILE_FREE_KF;
+                    const bool fits_hard = (int)(kfs.size() + add.size()) <= MAX_TILE_KF && nfree + add_free <= MAX_TILE_FREE_KF;
+                    // soft limit: keep tiles on the MFMA path (<= MAX_GEMM_FREE_KF free key-frames) whenever a cut achieves it
+                    const bool fits = fits_hard && (nfree + add_free <= MAX_GEMM_FREE_KF || l == l_begin);
                     if (!fits && l > l_begin) {
                         for (int kf : add) mark[kf] = -1;  // roll back
                         break;
@@ -433,7 +435,7 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
                     t.kmax = std::max(t.kmax, k);
                     tile_run_max = std::max(tile_run_max, run_max[l]);
                     l++;
-                    if (!fits) break;  // a single landmark exceeding the capacity: global-atomics tile
+                    if (!fits_hard) break;  // a single landmark exceeding the capacity: global-atomics tile
                 }
                 t.lmk1 = d.lmk_base + l;
                 std::sort(kfs.begin(), kfs.end());
@@ -463,6 +465,13 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
         }
         d.tile_end = (int)h->tiles.size();
         for (int ti = d.tile_begin; ti < d.tile_end; ti++) { h->tiles[ti].win_tile0 = d.tile_begin; h->tiles[ti].win_ntiles = d.tile_end - d.tile_begin; }
+    }
+    if (getenv("SADVIO_DEBUG")) {
+        int hist[32] = {0}, modes[3] = {0};
+        for (auto& t : h->tiles) { hist[std::min(t.n_free, 31)]++; modes[t.lds_mode]++; }
+        fprintf(stderr, "[sadvio dbg] %zu tiles, modes global/atomic/gemm = %d/%d/%d, max_tile_kf %d, n_free histogram:", h->tiles.size(), modes[0], modes[1], modes[2], h->max_tile_kf);
+        for (int i = 0; i < 32; i++) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]);
+        fprintf(stderr, "\n");
     }
     HIP_TRY(h->d_win.alloc(n_windows)); HIP_TRY(h->d_tiles.alloc(h->tiles.size())); HIP_TRY(h->d_tacc.alloc(2 * h->tiles.size()));
     if (tile_kf.empty()) { tile_kf.push_back(0); tile_row.push_back(-1); }
@@ -640,7 +649,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     int Rp = 16 * ((6 * h->max_gemm_free + 15) / 16);                          // padded rows of the Y / E strips
     int strip_doubles = std::max(STAGE_VALS * 64, 2 * Rp * (32 + 2));          // per wave (also holds the wave's tile copy)
     size_t lds_build = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)BUILD_WAVES * strip_doubles + nt * (nt + 1) / 2 + 3 * nt +
-                                                                   BUILD_WAVES * MAX_GEMM_FREE_KF * 33) + 16;
+                                                                   0) + 16;
     if (lds_build > 160 * 1024 && h->max_gemm_free > 0) {
         // a window mixing short tracks with very long ones: the MFMA strips + the large atomic tile do not fit
         // together; run every tile on the ds_add_f64 path instead
@@ -649,8 +658,9 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         h->max_gemm_free = 0;
         Rp = 0; strip_doubles = STAGE_VALS * 64;
         lds_build = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)BUILD_WAVES * strip_doubles + nt * (nt + 1) / 2 + 3 * nt +
-                                                               BUILD_WAVES * MAX_GEMM_FREE_KF * 33) + 16;
+                                                               0) + 16;
     }
+    if (getenv("SADVIO_DEBUG")) fprintf(stderr, "[sadvio dbg] lds_build %zu B, Rp %d, strip_doubles %d, max_tile_kf %d, max_tile_free %d, tiles %d\n", lds_build, Rp, strip_doubles, mtk, h->max_tile_free, n_tiles);
     const size_t lds_back = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)mtk * 18) + 16;
     const size_t lds_solve = sizeof(double) * ((size_t)(h->max_np + 2) * 6 + (size_t)(h->max_np + 1) * (h->max_np + 2) / 2 +
                                                4 * (size_t)h->max_np + (size_t)(h->max_np / 5 + 1) * 36) + 64;

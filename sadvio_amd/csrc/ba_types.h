@@ -113,7 +113,7 @@ constexpr int BUILD_THREADS = 256;  // 4 waves; each wave owns 64 / G landmarks 
 constexpr int BUILD_WAVES = BUILD_THREADS / 64;
 constexpr int MAX_TILE_KF = 24;      // key-frames (free + constant) a tile may touch
 constexpr int MAX_TILE_FREE_KF = 20; // free ones: LDS tile <= 120 x 121 / 2 doubles = 58 KB
-constexpr int MAX_GEMM_FREE_KF = 8;  // tiles touching <= 8 free key-frames accumulate through the MFMA contraction
+constexpr int MAX_GEMM_FREE_KF = 5;  // tiles touching <= 8 free key-frames accumulate through the MFMA contraction
 constexpr int MAX_WIN_CAM = 8;       // cameras per window staged in LDS
 constexpr int STAGE_VALS = 18;       // Jp[12] Jl[6] exchanged between the lanes of a landmark group
 constexpr int MAX_LMK_OBS = 64;      // observations per landmark (one lane each)

@@ -297,7 +297,7 @@ __host__ __device__ inline size_t tile_tables_bytes(int n_kf) {
 
 // ---- K5: build the reduced system ----------------------------------------------------------------
 template <int FACTOR>
-__global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, int max_tile_kf, int strip_doubles, int Rp) {
+__global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot, int max_tile_kf, int strip_doubles, int Rp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Tile T = P.tiles[blockIdx.x];
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
@@ -328,11 +328,10 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, in
     double* gT = Stile + tri_n;
     double* gfT = gT + Nt;
     double* hdT = gfT + Nt;
-    double* waveD = hdT + Nt;                         // [BUILD_WAVES][MAX_GEMM_FREE_KF][33] per-wave D / gradients (gemm tiles)
     const bool lds_mode = T.lds_mode != 0;
     stage_tables(P, T, st.cur, poseTab, camTab, rowTab);
     if (lds_mode) {
-        const int nz = tri_n + 3 * Nt + (T.lds_mode == 2 ? BUILD_WAVES * MAX_GEMM_FREE_KF * 33 : 0);
+        const int nz = tri_n + 3 * Nt;
         for (int i = tid; i < nz; i += blockDim.x) Stile[i] = 0.0;
     }
     __syncthreads();
@@ -437,12 +436,54 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, in
                     ep[0] = make_double2(e[0], e[1]); ep[1] = make_double2(e[2], 0.0);
                 }
             }
+            wave_lds_fence();
+    SADVIO_TS(3, 38);
+            {
+                typedef double d4 __attribute__((ext_vector_type(4)));
+                const int lr = ln & 15, lk = ln >> 4;
+                const int nt16 = (Nt + 15) >> 4;
+                d4 accs[3];  // <= 2 x 2 lower tile pairs (Nt <= 32); results stay in registers until every
+                             // operand has been read, then overwrite this wave's strip (waveS aliases it)
+#pragma unroll
+                for (int pp = 0; pp < 3; pp++) {
+                    const int tr = pp < 1 ? 0 : 1, tc = pp - tr;
+                    accs[pp] = (d4){0.0, 0.0, 0.0, 0.0};
+                    if (tr < nt16) {
+                        double av[8], bv[8];
+#pragma unroll
+                        for (int kk = 0; kk < 8; kk++) {  // all operand loads first, then the MFMA chain
+                            const int k = (4 * kk < Kw) ? 4 * kk + lk : lk;
+                            av[kk] = Yb[(16 * tr + lr) * KS + k];
+                            bv[kk] = Eb[(16 * tc + lr) * KS + k];
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < 8; kk++)
+                            if (4 * kk < Kw) accs[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], accs[pp], 0, 0, 0);
+                    }
+                }
+                wave_lds_fence();
+                double* wS = wstage;  // per-wave copy of the tile's lower triangle
+                for (int i = ln; i < tri_n + MAX_GEMM_FREE_KF * 33; i += 64) wS[i] = 0.0;  // tile copy + D / gradient block
+                wave_lds_fence();
+#pragma unroll
+                for (int pp = 0; pp < 3; pp++) {
+                    const int tr = pp < 1 ? 0 : 1, tc = pp - tr;
+                    if (tr < nt16) {
+                        const int col = 16 * tc + lr;
+#pragma unroll
+                        for (int rg = 0; rg < 4; rg++) {
+                            const int row = 16 * tr + lk + 4 * rg;
+                            if (row < Nt && col <= row) wS[tri(row, col)] = -accs[pp][rg];
+                        }
+                    }
+                }
+            }
             // block-diagonal part D = Jp^T Jp (21) + reduced / full gradient (6 + 6)
             {
                 const int rowu = vrow ? L.row : -1;
                 int mism = (dpp_i32<0x128>(rowu) != rowu) | (xor16_other(rowu) != rowu) | (xor32_other(rowu) != rowu);
                 const bool uniform = (G == 8) && (__ballot(mism) == 0ull);
-                double* wD = waveD + (wv * MAX_GEMM_FREE_KF + (head ? myrow / 6 : 0)) * 33;
+                double* wD = wstage + tri_n + (head ? myrow / 6 : 0) * 33;  // after the wave's tile copy, inside its strip
                 int e = 0;
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
@@ -468,48 +509,6 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, in
                         gr = across_groups8_sum(gr); gf = across_groups8_sum(gf);
                         if (head && grp == 0) { wD[21 + i] = gr; wD[27 + i] = gf; }
                     } else if (head) { atomic_add_f64(&gT[myrow + i], gr); atomic_add_f64(&gfT[myrow + i], gf); }
-                }
-            }
-            wave_lds_fence();
-    SADVIO_TS(3, 38);
-            {
-                typedef double d4 __attribute__((ext_vector_type(4)));
-                const int lr = ln & 15, lk = ln >> 4;
-                const int nt16 = (Nt + 15) >> 4;
-                d4 accs[6];  // <= 3 x 3 lower tile pairs (Nt <= 48); results stay in registers until every
-                             // operand has been read, then overwrite this wave's strip (waveS aliases it)
-#pragma unroll
-                for (int pp = 0; pp < 6; pp++) {
-                    const int tr = pp < 1 ? 0 : (pp < 3 ? 1 : 2), tc = pp - (tr * (tr + 1)) / 2;
-                    accs[pp] = (d4){0.0, 0.0, 0.0, 0.0};
-                    if (tr < nt16) {
-                        double av[8], bv[8];
-#pragma unroll
-                        for (int kk = 0; kk < 8; kk++) {  // all operand loads first, then the MFMA chain
-                            const int k = (4 * kk < Kw) ? 4 * kk + lk : lk;
-                            av[kk] = Yb[(16 * tr + lr) * KS + k];
-                            bv[kk] = Eb[(16 * tc + lr) * KS + k];
-                        }
-#pragma unroll
-                        for (int kk = 0; kk < 8; kk++)
-                            if (4 * kk < Kw) accs[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], accs[pp], 0, 0, 0);
-                    }
-                }
-                wave_lds_fence();
-                double* wS = wstage;  // per-wave copy of the tile's lower triangle
-                for (int i = ln; i < tri_n; i += 64) wS[i] = 0.0;
-                wave_lds_fence();
-#pragma unroll
-                for (int pp = 0; pp < 6; pp++) {
-                    const int tr = pp < 1 ? 0 : (pp < 3 ? 1 : 2), tc = pp - (tr * (tr + 1)) / 2;
-                    if (tr < nt16) {
-                        const int col = 16 * tc + lr;
-#pragma unroll
-                        for (int rg = 0; rg < 4; rg++) {
-                            const int row = 16 * tr + lk + 4 * rg;
-                            if (row < Nt && col <= row) wS[tri(row, col)] = -accs[pp][rg];
-                        }
-                    }
                 }
             }
     SADVIO_TS(3, 39);
@@ -600,7 +599,8 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_build(DevPtrs P, int slot, in
         for (int it = tid; it < T.n_free * 33; it += blockDim.x) {
             const int sl = it / 33, e = it - 33 * sl;
             double v = 0.0;
-            for (int w = 0; w < BUILD_WAVES; w++) v += waveD[(w * MAX_GEMM_FREE_KF + sl) * 33 + e];
+            for (int w = 0; w < BUILD_WAVES; w++)
+                if (w * lpw < nl) v += stage[w * strip_doubles + tri_n + sl * 33 + e];
             if (e < 21) {
                 int i = 0, r = e;
                 while (r >= i + 1) { r -= i + 1; i++; }
