@@ -92,7 +92,7 @@ def main():
     # every rank owns its own windows (different seeds): weak scaling over independent sub-windows
     base_seed = 20250404 + 1000 * rank
     wins = [synthetic.make_window(seed=base_seed + i) for i in range(args.windows)]
-    be = capi.Backend(device=local_rank)
+    be = capi.Backend(device=local_rank, use_graph=True)  # one hipGraph launch per solve
     be.set_windows(wins)
     dt = timed_solves(be, opts, args.steps, args.warmup)
     sums = be.solve(opts)
@@ -122,8 +122,20 @@ def main():
         dom = max((k for k in kt if k in ab), key=lambda k: kt[k]["avg_us"] * kt[k]["launches"])
         achieved = ab[dom] / (kt[dom]["avg_us"] * 1e-6) / 1e9
         iter_us = sum(kt[k]["avg_us"] for k in ("k_build", "k_solve", "k_backsub") if k in kt)
+        # HBM traffic per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+        # command (scripts/prof_bench.sh -> profiles/*_summary.json); null if no summary is committed
+        traffic, traffic_src = None, None
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+            try:
+                kk = json.load(open(f))["kernels"].get(dom, {})
+                if "hbm_traffic_bytes_per_launch" in kk and len(wins) == 1:
+                    traffic, traffic_src = round(kk["hbm_traffic_bytes_per_launch"]), os.path.relpath(f, ROOT)
+            except Exception:
+                pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": ab[dom], "avg_kernel_us": round(kt[dom]["avg_us"], 3),
                     "kernels_us": {k: round(v["avg_us"], 3) for k, v in kt.items()},
                     "iteration_achieved_GBps": round(sum(ab.values()) / (iter_us * 1e-6) / 1e9, 2)}
@@ -132,7 +144,7 @@ def main():
         if args.batch > 0:
             bw = [synthetic.make_window(seed=base_seed + 100 + i) for i in range(min(args.batch, 8))]
             bw = [bw[i % len(bw)] for i in range(args.batch)]
-            bb = capi.Backend(device=local_rank)
+            bb = capi.Backend(device=local_rank, use_graph=True)
             bb.set_windows(bw)
             for _ in range(2):
                 bb.solve(opts)

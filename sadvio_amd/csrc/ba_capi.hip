@@ -99,8 +99,15 @@ struct sadvio_ba_handle {
     DevBuf<double> d_S, d_gred, d_gfull, d_hdiag, d_delta, d_s_pose;
     DevBuf<LmState> d_states;
     DevBuf<IterAcc> d_acc;
+    DevBuf<FinalRec> d_final;
+    FinalRec* h_final = nullptr;  // pinned
+    size_t h_final_n = 0;
+    std::vector<FinalRec> fin;    // last solve's records
     DevBuf<TileAcc> d_tacc;
     DevBuf<long long> d_dbg;
+    // hipGraph of one complete solve (all slots), re-captured whenever the launch parameters change
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<unsigned char> graph_key;
     DevBuf<double> d_probe;
     bool has_lmk_const = false;
     // profiling
@@ -171,6 +178,8 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.dbg_ts = h->d_dbg.p;
     P.states = h->d_states.p; P.acc = h->d_acc.p; P.tacc = h->d_tacc.p; P.n_tiles = (int)h->tiles.size();
     P.state_stride = state_stride;
+    P.final_out = h->d_final.p;
+    P.n_xp = (long long)h->d_xp.n; P.n_xv = (long long)h->d_xv.n; P.n_xl = (long long)h->d_xl.n;
     P.n_win = (int)h->wins.size();
     { const char* e = getenv("SADVIO_DEBUG"); P.debug = e ? atoi(e) : 0; }
     P.o = o;
@@ -259,7 +268,10 @@ int sadvio_ba_create(const sadvio_ba_config* cfg, sadvio_ba_handle** out) {
 void sadvio_ba_destroy(sadvio_ba_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); }
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->h_final) (void)hipHostFree(h->h_final);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     h->d_win.release(); h->d_tiles.release(); h->d_kf_T0.release(); h->d_xp.release(); h->d_xv.release();
     h->d_xba.release(); h->d_xbg.release(); h->d_kf_vel.release(); h->d_kf_ba.release(); h->d_kf_bg.release();
@@ -626,22 +638,13 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     HIP_TRY(h->d_dbg.alloc(64));
     HIP_TRY(h->d_states.alloc((size_t)n_win * stride));
     HIP_TRY(h->d_acc.alloc((size_t)n_win * stride));
-    HIP_TRY(hipMemsetAsync(h->d_states.p, 0, sizeof(LmState) * (size_t)n_win * stride, h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_acc.p, 0, sizeof(IterAcc) * (size_t)n_win * stride, h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_tacc.p, 0, sizeof(TileAcc) * 2 * h->tiles.size(), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_xp.p, 0, sizeof(double) * h->d_xp.n, h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_xv.p, 0, sizeof(double) * h->d_xv.n, h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_xba.p, 0, sizeof(double) * h->d_xba.n, h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_xbg.p, 0, sizeof(double) * h->d_xbg.n, h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_xl.p, 0, sizeof(double) * h->d_xl.n, h->stream));
-    std::vector<LmState> st0((size_t)n_win * stride);
-    memset(st0.data(), 0, st0.size() * sizeof(LmState));
-    for (int w = 0; w < n_win; w++) {
-        LmState& s = st0[(size_t)w * stride];
-        s.radius = o.initial_radius; s.decrease_factor = 2.0;
-        if (o.max_num_iterations == 0) { /* handled after slot 0 by k_final: iter >= max */ }
+    HIP_TRY(h->d_final.alloc((size_t)n_win));
+    if (h->h_final_n < (size_t)n_win) {
+        if (h->h_final) (void)hipHostFree(h->h_final);
+        h->h_final = nullptr; h->h_final_n = 0;
+        HIP_TRY(hipHostMalloc((void**)&h->h_final, sizeof(FinalRec) * (size_t)n_win, hipHostMallocDefault));
+        h->h_final_n = (size_t)n_win;
     }
-    HIP_TRY(hipMemcpyAsync(h->d_states.p, st0.data(), st0.size() * sizeof(LmState), hipMemcpyHostToDevice, h->stream));
     DevPtrs P = make_ptrs(h, o, stride);
     const int n_tiles = (int)h->tiles.size();
     const int mtk = h->max_tile_kf;
@@ -669,20 +672,42 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
     HIP_TRY(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back));
     HIP_TRY(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
-    { ScopedTimer t(h, "k_init_tables"); hipLaunchKernelGGL(k_init_tables, dim3((h->n_kf_tot + 63) / 64), dim3(64), 0, h->stream, P, h->n_kf_tot); }
-    for (int s = 0; s < slots; s++) {
-        { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
-        { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(k_solve, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
-        { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
+    const int reset_blocks = (int)std::min<long long>(1024, std::max<long long>(1, (P.n_xl + P.n_xp + 255) / 256));
+    auto enqueue = [&]() {
+        { ScopedTimer t(h, "k_reset"); hipLaunchKernelGGL(k_reset, dim3(reset_blocks), dim3(256), 0, h->stream, P); }
+        { ScopedTimer t(h, "k_init_tables"); hipLaunchKernelGGL(k_init_tables, dim3((h->n_kf_tot + 63) / 64), dim3(64), 0, h->stream, P, h->n_kf_tot); }
+        for (int s = 0; s < slots; s++) {
+            { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
+            { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(k_solve, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
+            { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
+        }
+        { ScopedTimer t(h, "k_final"); hipLaunchKernelGGL(k_final, dim3(n_win), dim3(64), 0, h->stream, P, slots); }
+    };
+    if (h->cfg.use_graph && !h->cfg.profile_kernels) {
+        // the whole <= 20-iteration solve is one graph launch; the key covers every kernel argument
+        std::vector<unsigned char> key(sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t));
+        unsigned char* kp = key.data();
+        memcpy(kp, &P, sizeof(DevPtrs)); kp += sizeof(DevPtrs);
+        const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type};
+        memcpy(kp, ints, sizeof(ints)); kp += sizeof(ints);
+        const size_t szs[3] = {lds_build, lds_back, lds_solve};
+        memcpy(kp, szs, sizeof(szs));
+        if (!h->graph_exec || key != h->graph_key) {
+            if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+            hipGraph_t g = nullptr;
+            HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            enqueue();
+            HIP_TRY(hipStreamEndCapture(h->stream, &g));
+            HIP_TRY(hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            h->graph_key = key;
+        }
+        HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
+    } else {
+        enqueue();
     }
-    { ScopedTimer t(h, "k_final"); hipLaunchKernelGGL(k_final, dim3(n_win), dim3(64), 0, h->stream, P, slots); }
     HIP_TRY(hipGetLastError());
-    std::vector<LmState> fin(n_win);
-    std::vector<IterAcc> acc0(n_win);
-    for (int w = 0; w < n_win; w++) {
-        HIP_TRY(hipMemcpyAsync(&fin[w], h->d_states.p + (size_t)w * stride + slots, sizeof(LmState), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(&acc0[w], h->d_acc.p + (size_t)w * stride, sizeof(IterAcc), hipMemcpyDeviceToHost, h->stream));
-    }
+    HIP_TRY(hipMemcpyAsync(h->h_final, h->d_final.p, sizeof(FinalRec) * (size_t)n_win, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->cfg.profile_kernels) collect_timers(h);
     if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 4096)) {
@@ -695,16 +720,17 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             fprintf(stderr, "\n");
         }
     }
+    h->fin.assign(h->h_final, h->h_final + n_win);
     h->last_slots = slots;
     h->solved = true;
     int rc = SADVIO_OK;
     for (int w = 0; w < n_win; w++) {
-        const LmState& s = fin[w];
+        const LmState& s = h->fin[w].s;
         if (summaries) {
             sadvio_solve_summary& S = summaries[w];
             S.iterations = s.iter; S.num_successful_steps = s.n_success; S.num_unsuccessful_steps = s.n_unsuccess;
             S.termination = s.termination; S.initial_cost = s.initial_cost; S.final_cost = s.x_cost;
-            S.fixed_cost = 0.5 * acc0[w].fixed_cost; S.final_radius = s.radius;
+            S.fixed_cost = 0.5 * h->fin[w].fixed_cost; S.final_radius = s.radius;
         }
         if (s.termination == SADVIO_TERM_FAILURE) rc = SADVIO_E_NOT_USABLE;
     }
@@ -719,10 +745,7 @@ int sadvio_ba_get_deltas(sadvio_ba_handle* h, int32_t w, double* pose, double* l
     if (w < 0 || w >= (int)h->wins.size()) { h->err = "get_deltas: window out of range"; return SADVIO_E_INVALID_ARG; }
     HIP_TRY(hipSetDevice(h->device));
     const WinDev& d = h->wins[w].d;
-    const int stride = h->last_slots + 2;
-    LmState s;
-    HIP_TRY(hipMemcpy(&s, h->d_states.p + (size_t)w * stride + h->last_slots, sizeof(LmState), hipMemcpyDeviceToHost));
-    const int cur = s.cur;
+    const int cur = h->fin[w].s.cur;
     if (pose) HIP_TRY(hipMemcpy(pose, h->d_xp.p + (size_t)cur * 6 * h->n_kf_tot + 6 * (size_t)d.kf_base, sizeof(double) * 6 * d.n_kf, hipMemcpyDeviceToHost));
     if (lmk && d.n_lmk) HIP_TRY(hipMemcpy(lmk, h->d_xl.p + (size_t)cur * 3 * h->n_lmk_tot + 3 * (size_t)d.lmk_base, sizeof(double) * 3 * d.n_lmk, hipMemcpyDeviceToHost));
     double* outs[3] = {dv, dba, dbg};

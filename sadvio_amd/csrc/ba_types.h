@@ -88,6 +88,12 @@ struct LmState {
     int n_success, n_unsuccess, n_invalid, pad;
 };
 
+// What the host reads back after a solve (one record per window, written by k_final).
+struct FinalRec {
+    LmState s;
+    double fixed_cost;
+};
+
 // Per-slot accumulators (zeroed before the solve; filled with atomics by the slot's kernels).
 struct IterAcc {
     double lin_cost;    // sum r^2 at the linearisation point (all non-fixed residual blocks)

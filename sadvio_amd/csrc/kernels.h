@@ -43,6 +43,8 @@ struct DevPtrs {
     LmState* states;  // [n_win][slots+2]
     IterAcc* acc;     // [n_win][slots+1] window totals (written by single workgroups only)
     TileAcc* tacc;    // [2][n_tiles] per-tile partials, double-buffered by slot parity (no atomics)
+    FinalRec* final_out;  // [n_win]
+    long long n_xp, n_xv, n_xl;  // doubles in the (double-buffered) delta arrays, zeroed by k_reset
     int n_tiles;
     int state_stride;
     int n_win;
@@ -1345,12 +1347,33 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
     }
 }
 
+// Start of a solve: zero the delta buffers and every accumulator, write the initial LM state of each window
+// (one launch instead of eight memsets and a host-to-device copy).
+__global__ void k_reset(DevPtrs P) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long long)gridDim.x * blockDim.x;
+    for (long long i = t; i < P.n_xp; i += nt) P.xp[i] = 0.0;
+    for (long long i = t; i < P.n_xv; i += nt) { P.xv[i] = 0.0; P.xba[i] = 0.0; P.xbg[i] = 0.0; }
+    for (long long i = t; i < P.n_xl; i += nt) P.xl[i] = 0.0;
+    unsigned long long* a = (unsigned long long*)P.acc;
+    const long long na = (long long)P.n_win * P.state_stride * (long long)(sizeof(IterAcc) / 8);
+    for (long long i = t; i < na; i += nt) a[i] = 0ull;
+    unsigned long long* ta = (unsigned long long*)P.tacc;
+    const long long nta = 2LL * P.n_tiles * (long long)(sizeof(TileAcc) / 8);
+    for (long long i = t; i < nta; i += nt) ta[i] = 0ull;
+    const long long ns = (long long)P.n_win * P.state_stride;
+    for (long long i = t; i < ns; i += nt) {
+        LmState z{};
+        if (i % P.state_stride == 0) { z.radius = P.o.initial_radius; z.decrease_factor = 2.0; }
+        P.states[i] = z;
+    }
+}
+
 // Pose tables of delta buffer 0 at the start of a solve (all deltas zero).
 __global__ void k_init_tables(DevPtrs P, int n_kf_tot) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_kf_tot) return;
     double d6[6], tab[POSE_TAB];
-    for (int i = 0; i < 6; i++) d6[i] = P.xp[6 * (long long)g + i];
+    for (int i = 0; i < 6; i++) d6[i] = 0.0;
     pose_table_entry(P.kf_T0 + 12 * (long long)g, d6, tab);
     for (int i = 0; i < POSE_TAB; i++) P.ptab[(long long)g * POSE_TAB + i] = tab[i];
 }
@@ -1365,7 +1388,12 @@ __global__ void k_final(DevPtrs P, int slots) {
     if (ln == 0) {
         IterAcc a = P.acc[(long long)w * P.state_stride + slots - 1];
         a.cand_cost += s4[0]; a.mcc += s4[1]; a.step_norm2 += s4[2]; a.cand_norm2 += s4[3];
-        P.states[(long long)w * P.state_stride + slots] = lm_decide(P.states[(long long)w * P.state_stride + slots - 1], a, P.o);
+        const LmState f = lm_decide(P.states[(long long)w * P.state_stride + slots - 1], a, P.o);
+        P.states[(long long)w * P.state_stride + slots] = f;
+        FinalRec rec;
+        rec.s = f;
+        rec.fixed_cost = P.acc[(long long)w * P.state_stride].fixed_cost;
+        P.final_out[w] = rec;
     }
 }
 

@@ -23,3 +23,11 @@ t=time.perf_counter()
 for _ in range(20): s = be.solve(opts)
 dt=(time.perf_counter()-t)/20
 print(f"   unprofiled wall/solve {dt*1e3:.3f} ms -> {nw*10/dt:.0f} it/s")
+be.close()
+be = capi.Backend(device=0, use_graph=True)
+be.set_windows(ws)
+for _ in range(3): be.solve(opts)
+t=time.perf_counter()
+for _ in range(20): s = be.solve(opts)
+dt=(time.perf_counter()-t)/20
+print(f"   hipGraph   wall/solve {dt*1e3:.3f} ms -> {nw*10/dt:.0f} it/s   final cost {s[0].final_cost}")

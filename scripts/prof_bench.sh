@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage: scripts/prof_bench.sh <tag>   (run on the GPU box, from the repo root)
+# bench line + rocprofv3 kernel trace of the same command + HBM-traffic PMC passes (FETCH_SIZE and WRITE_SIZE
+# in separate passes, MI355X_MICROARCH.md "HBM": they do not fit one pass; FETCH_SIZE x2 on gfx950).
+TAG=$1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+cd /tmp && export TMPDIR=/tmp
+CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --batch 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $CMD > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $CMD > $OUT/pmc_write.log 2>&1
+cd $GRAFT_REPO_ROOT
+python scripts/summarize_prof.py $OUT > $OUT/summary.json
+cat $OUT/bench.json; cat $OUT/summary.json
