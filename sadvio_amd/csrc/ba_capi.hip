@@ -6,6 +6,7 @@
 // trips, and deltas are read back for the adapter to apply (AOptimizer.cpp:329-340).
 // There is no CPU fallback: without a gfx950 device every compute call fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -60,6 +61,19 @@ struct HostWin {
 
 }  // namespace
 
+// rocSOLVER (potrf / potrs, FP64) for reduced systems too large for the LDS-resident solver; loaded on first
+// use so that the common small-window path does not pay for the library.
+struct DenseSolver {
+    void* lib = nullptr;
+    void* handle = nullptr;  // rocblas_handle
+    int (*create)(void**) = nullptr;
+    int (*destroy)(void*) = nullptr;
+    int (*set_stream)(void*, hipStream_t) = nullptr;
+    int (*potrf)(void*, int, int, double*, int, int*) = nullptr;
+    int (*potrs)(void*, int, int, int, double*, int, double*, int) = nullptr;
+};
+constexpr int ROCBLAS_FILL_UPPER = 121;  // rocblas_fill_upper
+
 struct sadvio_ba_handle {
     sadvio_ba_config cfg{};
     int device = 0;
@@ -76,7 +90,9 @@ struct sadvio_ba_handle {
     int n_kf_tot = 0, n_cam_tot = 0, n_lmk_tot = 0, n_obs_tot = 0, np_tot = 0;
     long long s_tot = 0;
     int factor_type = 0;
-    int max_n_kf = 0, max_npose = 0, max_np = 0;
+    int max_n_kf = 0, max_npose = 0, max_np = 0, n_big = 0;
+    DevBuf<int> d_big_info;
+    DenseSolver dense;
     bool uploaded = false, solved = false;
     int slots_cap = 0;
     int last_slots = 0;
@@ -158,6 +174,23 @@ void collect_timers(sadvio_ba_handle* h) {
     h->ev_next = 0;
 }
 
+std::string load_dense_solver(sadvio_ba_handle* h) {
+    DenseSolver& D = h->dense;
+    if (D.handle) return "";
+    if (!D.lib) D.lib = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
+    if (!D.lib) D.lib = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!D.lib) return std::string("dlopen librocsolver: ") + dlerror();
+    D.create = (int (*)(void**))dlsym(D.lib, "rocblas_create_handle");
+    D.destroy = (int (*)(void*))dlsym(D.lib, "rocblas_destroy_handle");
+    D.set_stream = (int (*)(void*, hipStream_t))dlsym(D.lib, "rocblas_set_stream");
+    D.potrf = (int (*)(void*, int, int, double*, int, int*))dlsym(D.lib, "rocsolver_dpotrf");
+    D.potrs = (int (*)(void*, int, int, int, double*, int, double*, int))dlsym(D.lib, "rocsolver_dpotrs");
+    if (!D.create || !D.destroy || !D.set_stream || !D.potrf || !D.potrs) return "missing rocblas / rocsolver symbol";
+    if (D.create(&D.handle) != 0) { D.handle = nullptr; return "rocblas_create_handle failed"; }
+    if (D.set_stream(D.handle, h->stream) != 0) return "rocblas_set_stream failed";
+    return "";
+}
+
 DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     DevPtrs P{};
     P.win = h->d_win.p; P.tiles = h->d_tiles.p;
@@ -179,6 +212,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.states = h->d_states.p; P.acc = h->d_acc.p; P.tacc = h->d_tacc.p; P.n_tiles = (int)h->tiles.size();
     P.state_stride = state_stride;
     P.final_out = h->d_final.p;
+    P.big_info = h->d_big_info.p;
     P.n_xp = (long long)h->d_xp.n; P.n_xv = (long long)h->d_xv.n; P.n_xl = (long long)h->d_xl.n;
     P.n_win = (int)h->wins.size();
     { const char* e = getenv("SADVIO_DEBUG"); P.debug = e ? atoi(e) : 0; }
@@ -270,6 +304,7 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); }
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->dense.handle) (void)h->dense.destroy(h->dense.handle);
     if (h->h_final) (void)hipHostFree(h->h_final);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -296,7 +331,7 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
     h->factor_type = wins[0].factor_type;
     int kf_b = 0, cam_b = 0, lmk_b = 0, obs_b = 0, red_b = 0;
     long long s_b = 0;
-    h->max_n_kf = h->max_npose = h->max_np = 0;
+    h->max_n_kf = h->max_npose = h->max_np = 0; h->n_big = 0;
     h->has_lmk_const = false;
     for (int w = 0; w < n_windows; w++) {
         const sadvio_flat_window& F = wins[w];
@@ -337,13 +372,19 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
         for (int k = 0; k < F.n_kf; k++) H.kf_id[k] = F.kf_id ? F.kf_id[k] : k;
         for (int l = 0; l < F.n_lmk; l++) H.lmk_id[l] = F.lmk_id ? F.lmk_id[l] : l;
         kf_b += F.n_kf; cam_b += F.n_cam; lmk_b += F.n_lmk; obs_b += F.n_obs;
-        red_b += d.Np; s_b += ((long long)d.Np * (d.Np + 1) / 2 + 1) & ~1LL;  // packed lower triangle, 16-byte aligned
+        // reduced systems that fit LDS are kept as a packed lower triangle (16-byte aligned); larger ones as a
+        // full row-major matrix (lower triangle used) that the library factorisation works on in place
+        d.ld = d.Np > MAX_LDS_NP ? d.Np : 0;
+        red_b += d.Np; s_b += d.ld ? (((long long)d.Np * d.Np + 1) & ~1LL) : (((long long)d.Np * (d.Np + 1) / 2 + 1) & ~1LL);
         h->max_n_kf = std::max(h->max_n_kf, F.n_kf);
         h->max_npose = std::max(h->max_npose, d.Npose);
-        h->max_np = std::max(h->max_np, d.Np);
+        if (d.ld) h->n_big++; else h->max_np = std::max(h->max_np, d.Np);
     }
     h->n_kf_tot = kf_b; h->n_cam_tot = cam_b; h->n_lmk_tot = lmk_b; h->n_obs_tot = obs_b; h->np_tot = red_b; h->s_tot = s_b;
-    if (h->max_np > MAX_LDS_NP) { h->err = "set_windows: reduced dimension > 174 not supported yet"; return SADVIO_E_INVALID_ARG; }
+    if (h->n_big) {
+        std::string e = load_dense_solver(h);
+        if (!e.empty()) { h->err = "set_windows: reduced dimension > 174 needs rocSOLVER: " + e; return SADVIO_E_HIP; }
+    }
 
     // concatenate
     std::vector<double> kf_T0(12 * (size_t)kf_b), kf_vel(3 * (size_t)kf_b, 0.0), kf_ba(3 * (size_t)kf_b, 0.0), kf_bg(3 * (size_t)kf_b, 0.0);
@@ -410,7 +451,7 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
             while (l < F.n_lmk || (int)h->tiles.size() == d.tile_begin) {
                 Tile t{};
                 t.w = w; t.lmk0 = d.lmk_base + l; t.kmax = 1; t.G = 8;
-                t.dpf = d.dpf; t.Np = d.Np; t.red_off = d.red_off; t.S_off = d.S_off;
+                t.dpf = d.dpf; t.Np = d.Np; t.red_off = d.red_off; t.S_off = d.S_off; t.ld = d.ld;
                 t.cam_base = d.cam_base; t.n_cam = F.n_cam;
                 t.first_of_window = ((int)h->tiles.size() == d.tile_begin) ? 1 : 0;
                 std::vector<int> kfs;
@@ -639,6 +680,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     HIP_TRY(h->d_states.alloc((size_t)n_win * stride));
     HIP_TRY(h->d_acc.alloc((size_t)n_win * stride));
     HIP_TRY(h->d_final.alloc((size_t)n_win));
+    HIP_TRY(h->d_big_info.alloc((size_t)n_win));
     if (h->h_final_n < (size_t)n_win) {
         if (h->h_final) (void)hipHostFree(h->h_final);
         h->h_final = nullptr; h->h_final_n = 0;
@@ -671,19 +713,39 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     auto kk = h->factor_type == SADVIO_FACTOR_PIXEL ? k_backsub<0> : k_backsub<1>;
     HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
     HIP_TRY(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_solve<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
     const int reset_blocks = (int)std::min<long long>(1024, std::max<long long>(1, (P.n_xl + P.n_xp + 255) / 256));
+    bool dense_failed = false;
     auto enqueue = [&]() {
         { ScopedTimer t(h, "k_reset"); hipLaunchKernelGGL(k_reset, dim3(reset_blocks), dim3(256), 0, h->stream, P); }
         { ScopedTimer t(h, "k_init_tables"); hipLaunchKernelGGL(k_init_tables, dim3((h->n_kf_tot + 63) / 64), dim3(64), 0, h->stream, P, h->n_kf_tot); }
         for (int s = 0; s < slots; s++) {
             { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
-            { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(k_solve, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
+            if (h->n_big < n_win) { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(k_solve<0>, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
+            if (h->n_big) {
+                { ScopedTimer t(h, "k_solve_front"); hipLaunchKernelGGL(k_solve<1>, dim3(n_win), dim3(SOLVE_THREADS), 64, h->stream, P, s); }
+                {
+                    ScopedTimer t(h, "dense_potrf_potrs");
+                    for (int w = 0; w < n_win; w++) {
+                        const WinDev& d = h->wins[w].d;
+                        if (!d.ld) continue;
+                        // row-major lower triangle == column-major upper triangle: S = U^T U
+                        if (h->dense.potrf(h->dense.handle, ROCBLAS_FILL_UPPER, d.Np, h->d_S.p + d.S_off, d.ld, h->d_big_info.p + w) != 0 ||
+                            h->dense.potrs(h->dense.handle, ROCBLAS_FILL_UPPER, d.Np, 1, h->d_S.p + d.S_off, d.ld, h->d_gred.p + d.red_off, d.Np) != 0)
+                            dense_failed = true;
+                    }
+                }
+                { ScopedTimer t(h, "k_solve_back"); hipLaunchKernelGGL(k_solve<2>, dim3(n_win), dim3(SOLVE_THREADS), 64, h->stream, P, s); }
+                for (int w = 0; w < n_win; w++) {
+                    const WinDev& d = h->wins[w].d;
+                    if (d.ld) (void)hipMemsetAsync(h->d_S.p + d.S_off, 0, sizeof(double) * (size_t)d.Np * d.Np, h->stream);
+                }
+            }
             { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
         }
         { ScopedTimer t(h, "k_final"); hipLaunchKernelGGL(k_final, dim3(n_win), dim3(64), 0, h->stream, P, slots); }
     };
-    if (h->cfg.use_graph && !h->cfg.profile_kernels) {
+    if (h->cfg.use_graph && !h->cfg.profile_kernels && !h->n_big) {
         // the whole <= 20-iteration solve is one graph launch; the key covers every kernel argument
         std::vector<unsigned char> key(sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t));
         unsigned char* kp = key.data();
@@ -707,6 +769,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         enqueue();
     }
     HIP_TRY(hipGetLastError());
+    if (dense_failed) { h->err = "solve: rocSOLVER potrf / potrs call failed"; return SADVIO_E_HIP; }
     HIP_TRY(hipMemcpyAsync(h->h_final, h->d_final.p, sizeof(FinalRec) * (size_t)n_win, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->cfg.profile_kernels) collect_timers(h);

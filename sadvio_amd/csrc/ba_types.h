@@ -36,6 +36,7 @@ struct WinDev {
     int prior_begin, prior_end;
     int imu_begin, imu_end;
     int factor_type, has_imu;
+    int ld;           // 0: packed S solved in LDS; Np: full row-major S in HBM (Np > MAX_LDS_NP)
 };
 
 // One workgroup of k_build / k_backsub: a run of consecutive landmarks of one window. Each landmark is
@@ -56,7 +57,7 @@ struct Tile {
     int first_of_window;
     int kmax;         // max observations of one landmark in the tile (<= G)
     int win_tile0, win_ntiles;  // the window's tile range (for summing per-tile partials)
-    int pad;
+    int ld;           // 0: S packed lower triangle; else full row-major with this leading dimension
     long long S_off;
 };
 

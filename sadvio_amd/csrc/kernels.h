@@ -44,6 +44,7 @@ struct DevPtrs {
     IterAcc* acc;     // [n_win][slots+1] window totals (written by single workgroups only)
     TileAcc* tacc;    // [2][n_tiles] per-tile partials, double-buffered by slot parity (no atomics)
     FinalRec* final_out;  // [n_win]
+    int* big_info;        // [n_win] potrf info of the windows solved out of LDS
     long long n_xp, n_xv, n_xl;  // doubles in the (double-buffered) delta arrays, zeroed by k_reset
     int n_tiles;
     int state_stride;
@@ -56,6 +57,8 @@ struct DevPtrs {
 #define SADVIO_TS(slot_, idx_) do { if ((P.debug & 4096) && blockIdx.x == 0 && threadIdx.x == 0 && slot == (slot_)) P.dbg_ts[idx_] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
+// element (i >= j) of a window's reduced matrix in HBM: packed lower triangle (ld == 0) or full row-major
+__device__ __forceinline__ long long s_index(int ld, int i, int j) { return ld ? (long long)i * ld + j : (long long)tri(i, j); }
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
                         if (col > row) continue;
                         const double v = c0 * Jpb[j] + c1 * Jpb[6 + j];
                         if (lds_mode) atomic_add_f64(&Stile[tri(row, col)], v);
-                        else atomic_add_f64(&Sg[tri((pa / 6) * dpf + i, (pb / 6) * dpf + j)], v);
+                        else atomic_add_f64(&Sg[s_index(T.ld, (pa / 6) * dpf + i, (pb / 6) * dpf + j)], v);
                     }
                 }
             }
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
         }
         __syncthreads();
         for (int row = wv; row < Nt; row += BUILD_WAVES) {
-            const int grow = tri(growTab[row], 0);
+            const long long grow = s_index(T.ld, growTab[row], 0);
             const double* srow = Stile + tri(row, 0);
             for (int col = ln; col <= row; col += 64) {
                 const double v = srow[col];
@@ -885,10 +888,16 @@ __device__ __forceinline__ int imu_col(int a, int fi, int fj) {
 }
 
 // ---- K6: reduced solve, one workgroup per window -------------------------------------------------
+// MODE 0: the whole step in LDS (Np <= MAX_LDS_NP): gather S, pose-only factors, damping, Cholesky, candidate.
+// Windows whose reduced system does not fit LDS (W.ld != 0, S kept as a full row-major lower triangle in HBM)
+// run the same front (MODE 1) and back (MODE 2) halves around a library factorisation of S in place.
+template <int MODE>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool BIG = MODE != 0;
     const int w = blockIdx.x;
     const WinDev W = P.win[w];
+    if (BIG != (W.ld != 0)) return;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63, nwv = blockDim.x >> 6;  // wv in an SGPR: row tests below are scalar branches
     LmState* stp = P.states + (long long)w * P.state_stride + slot;
@@ -901,22 +910,27 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     __syncthreads();
     if (st.done) return;
     const int Np = W.Np;
+    const long long ld = W.ld;
     double* Sg = P.S + W.S_off;
     double* gredg = P.gred + W.red_off;
     double* gfullg = P.gfull + W.red_off;
     double* hdg = P.hdiag + W.red_off;
     const int tri_n = (Np + 1) * (Np + 2) / 2;  // packed lower triangle incl. the right-hand-side row Np
     double* LpT = (double*)smem;                // [NBP][Np+2] transposed panel strip
-    double* A = LpT + (size_t)(Np + 2) * NBP;   // packed lower
-    double* y = A + tri_n;                      // rhs -> work vector of the back-substitution
-    double* gf = y + Np;                        // full gradient
-    double* hd = gf + Np;                       // diag(H)
-    double* xs = hd + Np;                       // solution
+    double* A = BIG ? Sg : LpT + (size_t)(Np + 2) * NBP;   // packed lower (LDS) | full row-major lower (HBM)
+    double* y = BIG ? gredg : A + tri_n;        // rhs -> work vector of the back-substitution
+    double* gf = BIG ? gfullg : y + Np;         // full gradient
+    double* hd = BIG ? hdg : gf + Np;           // diag(H)
+    double* xs = BIG ? gredg : hd + Np;         // solution (BIG: potrs overwrites the right-hand side)
     double* linvTab = xs + Np;                  // [Np/NB][NB*NB] inverse pivot blocks
+    auto aidx = [&](int i, int j) -> long long { return BIG ? (long long)i * ld + j : (long long)tri(i, j); };  // i >= j
     const int cur = st.cur;
+    const double* xp = P.xp + (long long)cur * P.xp_stride;
+    const int n_imu = W.imu_end - W.imu_begin;
+    if (MODE != 2) {
     // load + clear the global accumulator: S is kept in HBM in the same packed lower-triangular layout as in
     // LDS, so this is a linear, fully coalesced 16-byte copy; all loads are issued before the first use.
-    {
+    if (!BIG) {
         const int n_s = Np * (Np + 1) / 2;
         const int n2 = n_s >> 1;
         constexpr int MAXV = (MAX_LDS_NP * (MAX_LDS_NP + 1) / 4 + SOLVE_THREADS - 1) / SOLVE_THREADS;
@@ -935,6 +949,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         }
         if (tid == 0 && (n_s & 1)) { A[n_s - 1] = Sg[n_s - 1]; Sg[n_s - 1] = 0.0; }
     }
+    if (!BIG)
     for (int i = tid; i < Np; i += blockDim.x) {
         y[i] = gredg[i]; gf[i] = gfullg[i]; hd[i] = hdg[i];
         gredg[i] = 0.0; gfullg[i] = 0.0; hdg[i] = 0.0;
@@ -943,7 +958,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     SADVIO_TS(3, 1);
     // pose-only factors at x: PosePriordx (K4). One thread per prior; LDS atomics.
     double cost_part = 0.0, fixed_part = 0.0;
-    const double* xp = P.xp + (long long)cur * P.xp_stride;
     for (int k = W.prior_begin + tid; k < W.prior_end; k += blockDim.x) {
         const PriorDev pr = P.priors[k];
         int fi = P.kf_fidx[pr.kf];
@@ -966,13 +980,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             for (int b = 0; b <= a; b++) {
                 double hh = 0;
                 for (int q = 0; q < 6; q++) hh += J[6 * q + a] * J[6 * q + b];
-                atomic_add_f64(&A[tri(base + a, base + b)], hh);
+                atomic_add_f64(&A[aidx(base + a, base + b)], hh);
             }
         }
     }
     // IMUFactor + IMUBiasFactor (K3): one thread per factor evaluates r and the whitened 9x24 Jacobian into an
     // HBM scratch row; the J^T J accumulation is then spread over all threads (LDS atomics into A).
-    const int n_imu = W.imu_end - W.imu_begin;
     if (n_imu > 0) {
         const double* xv = P.xv + (long long)cur * P.xv_stride;
         const double* xba = P.xba + (long long)cur * P.xv_stride;
@@ -1014,7 +1027,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             double h = 0.0;
 #pragma unroll
             for (int q = 0; q < 9; q++) h += sc[q * 24 + a] * sc[q * 24 + b];
-            atomic_add_f64(&A[ca >= cb ? tri(ca, cb) : tri(cb, ca)], h);
+            atomic_add_f64(&A[ca >= cb ? aidx(ca, cb) : aidx(cb, ca)], h);
             if (a == b) {
                 double g = 0.0;
 #pragma unroll
@@ -1031,9 +1044,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             const double rb = P.imu_scratch[(long long)(W.imu_begin + k) * (IMU_J + 6) + IMU_J + 3 * gy + ax];
             const int ci = fi < 0 ? -1 : fi * 15 + 9 + 3 * gy + ax, cj = fj < 0 ? -1 : fj * 15 + 9 + 3 * gy + ax;
             const double s2 = sgm * sgm;
-            if (ci >= 0) { atomic_add_f64(&A[tri(ci, ci)], s2); atomic_add_f64(&hd[ci], s2); atomic_add_f64(&y[ci], -sgm * rb); atomic_add_f64(&gf[ci], -sgm * rb); }
-            if (cj >= 0) { atomic_add_f64(&A[tri(cj, cj)], s2); atomic_add_f64(&hd[cj], s2); atomic_add_f64(&y[cj], sgm * rb); atomic_add_f64(&gf[cj], sgm * rb); }
-            if (ci >= 0 && cj >= 0) atomic_add_f64(&A[ci >= cj ? tri(ci, cj) : tri(cj, ci)], -s2);
+            if (ci >= 0) { atomic_add_f64(&A[aidx(ci, ci)], s2); atomic_add_f64(&hd[ci], s2); atomic_add_f64(&y[ci], -sgm * rb); atomic_add_f64(&gf[ci], -sgm * rb); }
+            if (cj >= 0) { atomic_add_f64(&A[aidx(cj, cj)], s2); atomic_add_f64(&hd[cj], s2); atomic_add_f64(&y[cj], sgm * rb); atomic_add_f64(&gf[cj], sgm * rb); }
+            if (ci >= 0 && cj >= 0) atomic_add_f64(&A[ci >= cj ? aidx(ci, cj) : aidx(cj, ci)], -s2);
         }
     }
     // window totals of the linearisation: tiles' k_build partials + the pose-only factors evaluated here
@@ -1075,19 +1088,31 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         if (slot == 0) { s = P.o.jacobi_scaling ? 1.0 / (1.0 + sqrt(hd[i])) : 1.0; sp[i] = s; }
         else s = sp[i];
         double s2 = s * s;
-        A[tri(i, i)] += fmin(fmax(s2 * hd[i], P.o.min_lm_diagonal), P.o.max_lm_diagonal) / st.radius / s2;
-        A[tri(Np, i)] = y[i];
+        A[aidx(i, i)] += fmin(fmax(s2 * hd[i], P.o.min_lm_diagonal), P.o.max_lm_diagonal) / st.radius / s2;
+        if (!BIG) A[tri(Np, i)] = y[i];
     }
-    if (tid == 0) A[tri(Np, Np)] = 0.0;
+    if (!BIG && tid == 0) A[tri(Np, Np)] = 0.0;
     __syncthreads();
     SADVIO_TS(3, 3);
-    bool ok;
+    if (MODE == 1) return;  // the host enqueues potrf / potrs on S, gred next
+    }  // MODE != 2
     long long* ts = ((P.debug & 4096) && blockIdx.x == 0 && slot == 3) ? P.dbg_ts : nullptr;
-    if (W.dpf == 6) ok = chol_solve_packed<6>(A, Np, y, xs, LpT, linvTab, ts);
-    else ok = chol_solve_packed<5>(A, Np, y, xs, LpT, linvTab, ts);
-    if (!ok) {
-        if (tid == 0) acc->chol_fail = 1;
-        return;
+    if (MODE == 0) {
+        bool ok;
+        if (W.dpf == 6) ok = chol_solve_packed<6>(A, Np, y, xs, LpT, linvTab, ts);
+        else ok = chol_solve_packed<5>(A, Np, y, xs, LpT, linvTab, ts);
+        if (!ok) {
+            if (tid == 0) acc->chol_fail = 1;
+            return;
+        }
+    } else {
+        // potrf / potrs ran on S / gred in place; info > 0 = leading minor not positive definite
+        y = P.delta + W.red_off;
+        if (P.big_info[w] != 0) {
+            for (int i = tid; i < Np; i += blockDim.x) { gredg[i] = 0.0; gfullg[i] = 0.0; hdg[i] = 0.0; }
+            if (tid == 0) acc->chol_fail = 1;
+            return;
+        }
     }
     if (P.debug & 256) return;
     SADVIO_TS(3, 4);
@@ -1101,6 +1126,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         y[i] = d;
         sn += d * d;
         if (!isfinite(d)) bad = true;
+        if (BIG) { gredg[i] = 0.0; gfullg[i] = 0.0; hdg[i] = 0.0; }
     }
     __syncthreads();
     SADVIO_TS(3, 5);

@@ -78,8 +78,11 @@ def _body_poses(n_kf, length, rng):
 
 def make_window(n_kf=20, n_lmk=8000, obs_per_lmk=5, seed=20250404, factor=FACTOR_PIXEL, pixel_noise=1.0,
                 rot_perturb_deg=0.5, trans_perturb=0.02, lmk_perturb=0.05, length=10.0, fixed=1,
-                width=752, height=480, min_depth=1.0, max_depth=15.0, border=5.0) -> FlatWindow:
-    """One VO window (config 2 of BASELINE.json at the defaults: 20 KF x 8 000 landmarks x 40 000 factors)."""
+                width=752, height=480, min_depth=1.0, max_depth=15.0, border=5.0, band=None) -> FlatWindow:
+    """One VO window (config 2 of BASELINE.json at the defaults: 20 KF x 8 000 landmarks x 40 000 factors).
+
+    band: if set, a landmark seeded in key-frame k is only observed from key-frames within k +- band (the
+    co-visibility band of a long trajectory, configs 4 / 5); candidates are then projected in bounded chunks."""
     rng = np.random.default_rng(seed)
     T_w_b = _body_poses(n_kf, length, rng)  # oldest first
     T_s_f = [inv4(_T_BS0), inv4(_T_BS1)]     # frame(body) -> sensor
@@ -92,8 +95,11 @@ def make_window(n_kf=20, n_lmk=8000, obs_per_lmk=5, seed=20250404, factor=FACTOR
     lmk = np.zeros((0, 3))
     runs = np.zeros((0,), dtype=np.int64)
     valid_all = np.zeros((0, n_views), dtype=bool)
+    chunk = None if band is None else max(512, int(2e6 // n_views))
     while lmk.shape[0] < n_lmk:
         n_try = int(1.6 * (n_lmk - lmk.shape[0])) + 64
+        if chunk is not None:
+            n_try = min(n_try, chunk)
         k = rng.integers(0, n_kf, n_try)
         u = rng.uniform(20, width - 20, n_try)
         v = rng.uniform(20, height - 20, n_try)
@@ -111,6 +117,9 @@ def make_window(n_kf=20, n_lmk=8000, obs_per_lmk=5, seed=20250404, factor=FACTOR
         umax = np.minimum(width, 2 * Kv[None, :, 2]) - border
         vmax = np.minimum(height, 2 * Kv[None, :, 3]) - border
         valid = (z > 0.5) & (uu > border) & (uu < umax) & (vv > border) & (vv < vmax)
+        if band is not None:
+            view_kf = np.arange(n_views) // 2
+            valid &= np.abs(view_kf[None, :] - k[:, None]) <= band
         ok = valid.sum(axis=1) >= obs_per_lmk
         lmk = np.concatenate([lmk, pw[ok]])
         valid_all = np.concatenate([valid_all, valid[ok]])
