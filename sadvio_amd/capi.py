@@ -141,6 +141,7 @@ class FlatWindow:
     kf_bg: Optional[np.ndarray] = None
     pose_priors: List[tuple] = field(default_factory=list)   # (kf, T_prior[12], inf_diag[6])
     imu_factors: List[dict] = field(default_factory=list)    # dicts with the ImuFactorC fields
+    dense_prior: Optional[dict] = None   # MarginalizationFactor: J [n_full,n], r0, kf_keep, kf_col, lmk_index, lmk_col
     truth: dict = field(default_factory=dict)                # generator ground truth (not uploaded)
     _keep: list = field(default_factory=list, repr=False)
 
@@ -269,6 +270,21 @@ class Backend:
             if w.imu_factors:
                 ia, n = w.imus_c()
                 self._check(self.lib.sadvio_ba_set_imu_factors(self.h, i, n, ia), "set_imu_factors")
+            if w.dense_prior is not None:
+                self.set_dense_prior(i, w.dense_prior)
+
+    def set_dense_prior(self, w: int, dp: Optional[dict]):
+        """Dense marginalisation prior of window w (None clears it)."""
+        if dp is None:
+            self._check(self.lib.sadvio_ba_set_dense_prior(self.h, w, 0, 0, None, None, -1, 0, 0, None, None), "set_dense_prior")
+            return
+        J = np.ascontiguousarray(dp["J"], dtype=np.float64)
+        r0 = np.ascontiguousarray(dp["r0"], dtype=np.float64)
+        li = np.ascontiguousarray(dp.get("lmk_index", []), dtype=np.int32)
+        lc = np.ascontiguousarray(dp.get("lmk_col", []), dtype=np.int32)
+        self._check(self.lib.sadvio_ba_set_dense_prior(self.h, w, J.shape[0], J.shape[1], _ptr(J), _ptr(r0),
+                                                       int(dp.get("kf_keep", -1)), int(dp.get("kf_col", 0)), len(li),
+                                                       li.ctypes.data_as(_ip), lc.ctypes.data_as(_ip)), "set_dense_prior")
 
     def solve(self, opts: Optional[SolveOptions] = None) -> List[SolveSummary]:
         opts = opts or reference_options()

@@ -6,7 +6,6 @@
 // trips, and deltas are read back for the adapter to apply (AOptimizer.cpp:329-340).
 // There is no CPU fallback: without a gfx950 device every compute call fails.
 #include <hip/hip_runtime.h>
-#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -19,6 +18,7 @@
 
 #include "../../include/sadvio_ba.h"
 #include "kernels.h"
+#include "dense_chol.h"
 
 using namespace sadvio;
 
@@ -57,22 +57,16 @@ struct KernelClass {
 struct HostWin {
     WinDev d;
     std::vector<int64_t> kf_id, lmk_id;
+    int hb_lmk = 0;  // max distance (in free key-frame index) between two key-frames observing one landmark
 };
 
 }  // namespace
 
-// rocSOLVER (potrf / potrs, FP64) for reduced systems too large for the LDS-resident solver; loaded on first
-// use so that the common small-window path does not pay for the library.
-struct DenseSolver {
-    void* lib = nullptr;
-    void* handle = nullptr;  // rocblas_handle
-    int (*create)(void**) = nullptr;
-    int (*destroy)(void*) = nullptr;
-    int (*set_stream)(void*, hipStream_t) = nullptr;
-    int (*potrf)(void*, int, int, double*, int, int*) = nullptr;
-    int (*potrs)(void*, int, int, int, double*, int, double*, int) = nullptr;
+struct DensePriorHost {
+    int n_full = 0, n = 0, kf_keep = -1, kf_col = 0;
+    std::vector<double> J, r0;
+    std::vector<int> lmk_index, lmk_col;
 };
-constexpr int ROCBLAS_FILL_UPPER = 121;  // rocblas_fill_upper
 
 struct sadvio_ba_handle {
     sadvio_ba_config cfg{};
@@ -92,8 +86,15 @@ struct sadvio_ba_handle {
     int factor_type = 0;
     int max_n_kf = 0, max_npose = 0, max_np = 0, n_big = 0;
     DevBuf<int> d_big_info;
-    DenseSolver dense;
     bool uploaded = false, solved = false;
+    // dense marginalisation priors (host copies, one per window) and the layout they induce
+    std::vector<DensePriorHost> dprior_per_win;
+    std::vector<unsigned char> h_lmk_const_user;  // as given by the caller
+    std::vector<int> h_lmk_ob, h_lmk_oe, h_kf_fidx;
+    bool user_lmk_const = false;
+    int n_kept = 0;
+    DevBuf<int> d_lmk_red, d_kept_obs, d_dp_ints;
+    DevBuf<double> d_dp_data;
     int slots_cap = 0;
     int last_slots = 0;
     // device buffers
@@ -174,23 +175,6 @@ void collect_timers(sadvio_ba_handle* h) {
     h->ev_next = 0;
 }
 
-std::string load_dense_solver(sadvio_ba_handle* h) {
-    DenseSolver& D = h->dense;
-    if (D.handle) return "";
-    if (!D.lib) D.lib = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
-    if (!D.lib) D.lib = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!D.lib) return std::string("dlopen librocsolver: ") + dlerror();
-    D.create = (int (*)(void**))dlsym(D.lib, "rocblas_create_handle");
-    D.destroy = (int (*)(void*))dlsym(D.lib, "rocblas_destroy_handle");
-    D.set_stream = (int (*)(void*, hipStream_t))dlsym(D.lib, "rocblas_set_stream");
-    D.potrf = (int (*)(void*, int, int, double*, int, int*))dlsym(D.lib, "rocsolver_dpotrf");
-    D.potrs = (int (*)(void*, int, int, int, double*, int, double*, int))dlsym(D.lib, "rocsolver_dpotrs");
-    if (!D.create || !D.destroy || !D.set_stream || !D.potrf || !D.potrs) return "missing rocblas / rocsolver symbol";
-    if (D.create(&D.handle) != 0) { D.handle = nullptr; return "rocblas_create_handle failed"; }
-    if (D.set_stream(D.handle, h->stream) != 0) return "rocblas_set_stream failed";
-    return "";
-}
-
 DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     DevPtrs P{};
     P.win = h->d_win.p; P.tiles = h->d_tiles.p;
@@ -213,11 +197,131 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.state_stride = state_stride;
     P.final_out = h->d_final.p;
     P.big_info = h->d_big_info.p;
+    P.lmk_red = h->d_lmk_red.p; P.kept_obs = h->d_kept_obs.p; P.n_kept = h->n_kept;
+    P.dp_data = h->d_dp_data.p; P.dp_ints = h->d_dp_ints.p;
     P.n_xp = (long long)h->d_xp.n; P.n_xv = (long long)h->d_xv.n; P.n_xl = (long long)h->d_xl.n;
     P.n_win = (int)h->wins.size();
     { const char* e = getenv("SADVIO_DEBUG"); P.debug = e ? atoi(e) : 0; }
     P.o = o;
     return P;
+}
+
+// H = J^T J and J^T of a dense prior, once per upload (J is constant during the solve).
+__global__ void k_dense_prior_prepare(const double* J, double* Jt, double* H, int nf, int n) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long long)nf * n) {
+        const int i = (int)(idx / n), a = (int)(idx - (long long)i * n);
+        Jt[(size_t)a * nf + i] = J[idx];
+    }
+    if (idx < (long long)n * n) {
+        const int a = (int)(idx / n), b = (int)(idx - (long long)a * n);
+        double s = 0.0;
+        for (int i = 0; i < nf; i++) s += J[(size_t)i * n + a] * J[(size_t)i * n + b];
+        H[idx] = s;
+    }
+}
+
+// Layout of the reduced systems of all windows: [free key-frames (dpf each) | prior-kept landmarks (3 each)].
+// Called by set_windows and again by set_dense_prior (kept landmarks enlarge the reduced system).
+int layout_reduced(sadvio_ba_handle* h) {
+    const int n_windows = (int)h->wins.size();
+    int red_b = 0; long long s_b = 0;
+    h->max_np = 0; h->n_big = 0;
+    std::vector<int> lmk_red(std::max(h->n_lmk_tot, 1), -1);
+    std::vector<unsigned char> lmk_const = h->h_lmk_const_user;
+    std::vector<int> kept, dp_ints;
+    std::vector<double> dp_data;
+    bool any_red = false;
+    struct Prep { long long off; int nf, n; };
+    std::vector<Prep> preps;
+    for (int w = 0; w < n_windows; w++) {
+        WinDev& d = h->wins[w].d;
+        const DensePriorHost& D = h->dprior_per_win[w];
+        int n_red = 0;
+        d.dp_n_full = d.dp_n = 0; d.dp_off = 0; d.dp_int_off = 0;
+        d.kept_begin = (int)kept.size() / 3;
+        if (D.n_full > 0) {
+            const int n = D.n, nf = D.n_full;
+            std::vector<int> kind(n, -1), index(n, 0), col(n, -1);
+            if (D.kf_keep >= 0) {
+                const int g = d.kf_base + D.kf_keep, fi = h->h_kf_fidx[g];
+                for (int q = 0; q < 15; q++) {
+                    const int a = D.kf_col + q;
+                    if (q < 6) { kind[a] = 0; index[a] = 6 * g + q; }
+                    else { kind[a] = 1 + (q - 6) / 3; index[a] = 3 * g + (q - 6) % 3; }
+                    col[a] = (fi >= 0 && q < d.dpf) ? fi * d.dpf + q : -1;
+                }
+            }
+            for (size_t i = 0; i < D.lmk_index.size(); i++) {
+                if (D.lmk_col[i] < 0) continue;
+                const int gl = d.lmk_base + D.lmk_index[i];
+                const bool is_const = lmk_const[gl] == 1;
+                if (!is_const) {
+                    lmk_red[gl] = d.dpf * d.n_free_kf + 3 * n_red; n_red++;
+                    lmk_const[gl] = 2; any_red = true;
+                    for (int o = h->h_lmk_ob[gl]; o < h->h_lmk_oe[gl]; o++) { kept.push_back(o); kept.push_back(gl); kept.push_back(w); }
+                }
+                for (int a = 0; a < 3; a++) {
+                    kind[D.lmk_col[i] + a] = 4; index[D.lmk_col[i] + a] = 3 * gl + a;
+                    col[D.lmk_col[i] + a] = is_const ? -1 : lmk_red[gl] + a;
+                }
+            }
+            d.dp_n_full = nf; d.dp_n = n;
+            d.dp_int_off = (int)dp_ints.size();
+            dp_ints.insert(dp_ints.end(), kind.begin(), kind.end());
+            dp_ints.insert(dp_ints.end(), index.begin(), index.end());
+            dp_ints.insert(dp_ints.end(), col.begin(), col.end());
+            d.dp_off = (long long)dp_data.size();
+            preps.push_back({d.dp_off, nf, n});
+            dp_data.insert(dp_data.end(), D.J.begin(), D.J.end());
+            dp_data.resize(dp_data.size() + (size_t)n * nf + (size_t)n * n, 0.0);  // Jt, H: filled on the device
+            dp_data.insert(dp_data.end(), D.r0.begin(), D.r0.end());
+            dp_data.resize(dp_data.size() + (size_t)n + nf, 0.0);                 // dx, r scratch
+            if (dp_data.size() & 1) dp_data.push_back(0.0);
+        }
+        d.kept_end = (int)kept.size() / 3;
+        d.n_red = n_red;
+        d.Np = d.n_free_kf * d.dpf + 3 * n_red;
+        // reduced systems that fit LDS are kept as a packed lower triangle (16-byte aligned); larger ones as a
+        // full row-major matrix (lower triangle used) that the library factorisation works on in place
+        d.ld = d.Np > MAX_LDS_NP ? d.Np : 0;
+        d.S_off = s_b; d.red_off = red_b;
+        red_b += d.Np; s_b += d.ld ? (((long long)d.Np * d.Np + 1) & ~1LL) : (((long long)d.Np * (d.Np + 1) / 2 + 1) & ~1LL);
+        if (d.ld) h->n_big++; else h->max_np = std::max(h->max_np, d.Np);
+        for (int ti = d.tile_begin; ti < d.tile_end; ti++) {
+            Tile& t = h->tiles[ti];
+            t.Np = d.Np; t.red_off = d.red_off; t.S_off = d.S_off; t.ld = d.ld;
+        }
+    }
+    h->np_tot = red_b; h->s_tot = s_b;
+    h->n_kept = (int)kept.size() / 3;
+    h->has_lmk_const = h->user_lmk_const || any_red;
+    HIP_TRY(h->d_S.alloc((size_t)std::max<long long>(s_b, 1)));
+    HIP_TRY(h->d_gred.alloc((size_t)std::max(red_b, 1))); HIP_TRY(h->d_gfull.alloc((size_t)std::max(red_b, 1)));
+    HIP_TRY(h->d_hdiag.alloc((size_t)std::max(red_b, 1))); HIP_TRY(h->d_delta.alloc((size_t)std::max(red_b, 1)));
+    HIP_TRY(h->d_s_pose.alloc((size_t)std::max(red_b, 1)));
+    HIP_TRY(hipMemsetAsync(h->d_S.p, 0, sizeof(double) * (size_t)std::max<long long>(s_b, 1), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_gred.p, 0, sizeof(double) * std::max(red_b, 1), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_gfull.p, 0, sizeof(double) * std::max(red_b, 1), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_hdiag.p, 0, sizeof(double) * std::max(red_b, 1), h->stream));
+    if (kept.empty()) kept.assign(3, 0);
+    if (dp_ints.empty()) dp_ints.push_back(0);
+    if (dp_data.empty()) dp_data.push_back(0.0);
+    HIP_TRY(h->d_tiles.alloc(h->tiles.size())); HIP_TRY(h->d_lmk_red.alloc(lmk_red.size())); HIP_TRY(h->d_lmk_const.alloc(lmk_const.size()));
+    HIP_TRY(h->d_kept_obs.alloc(kept.size())); HIP_TRY(h->d_dp_ints.alloc(dp_ints.size())); HIP_TRY(h->d_dp_data.alloc(dp_data.size()));
+#define UP(dst, src) HIP_TRY(hipMemcpyAsync((dst).p, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, h->stream))
+    UP(h->d_tiles, h->tiles); UP(h->d_lmk_red, lmk_red); UP(h->d_lmk_const, lmk_const); UP(h->d_kept_obs, kept);
+    UP(h->d_dp_ints, dp_ints); UP(h->d_dp_data, dp_data);
+#undef UP
+    for (const Prep& pr : preps) {
+        double* J = h->d_dp_data.p + pr.off;
+        double* Jt = J + (size_t)pr.nf * pr.n;
+        double* H = Jt + (size_t)pr.n * pr.nf;
+        const long long items = std::max((long long)pr.nf * pr.n, (long long)pr.n * pr.n);
+        hipLaunchKernelGGL(k_dense_prior_prepare, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, J, Jt, H, pr.nf, pr.n);
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));  // host vectors go out of scope
+    return SADVIO_OK;
 }
 
 int upload_priors(sadvio_ba_handle* h) {
@@ -304,7 +408,6 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); }
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    if (h->dense.handle) (void)h->dense.destroy(h->dense.handle);
     if (h->h_final) (void)hipHostFree(h->h_final);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -327,10 +430,10 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
     h->wins.assign(n_windows, HostWin());
     h->priors_per_win.assign(n_windows, {});
     h->imus_per_win.assign(n_windows, {});
+    h->dprior_per_win.assign(n_windows, {});
     h->tiles.clear();
     h->factor_type = wins[0].factor_type;
-    int kf_b = 0, cam_b = 0, lmk_b = 0, obs_b = 0, red_b = 0;
-    long long s_b = 0;
+    int kf_b = 0, cam_b = 0, lmk_b = 0, obs_b = 0;
     h->max_n_kf = h->max_npose = h->max_np = 0; h->n_big = 0;
     h->has_lmk_const = false;
     for (int w = 0; w < n_windows; w++) {
@@ -367,24 +470,14 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
         d.n_free_kf = nfree;
         d.Npose = nfree * 6;
         d.Np = nfree * d.dpf;
-        d.S_off = s_b; d.red_off = red_b;
         H.kf_id.assign(F.n_kf, 0); H.lmk_id.assign(F.n_lmk, 0);
         for (int k = 0; k < F.n_kf; k++) H.kf_id[k] = F.kf_id ? F.kf_id[k] : k;
         for (int l = 0; l < F.n_lmk; l++) H.lmk_id[l] = F.lmk_id ? F.lmk_id[l] : l;
         kf_b += F.n_kf; cam_b += F.n_cam; lmk_b += F.n_lmk; obs_b += F.n_obs;
-        // reduced systems that fit LDS are kept as a packed lower triangle (16-byte aligned); larger ones as a
-        // full row-major matrix (lower triangle used) that the library factorisation works on in place
-        d.ld = d.Np > MAX_LDS_NP ? d.Np : 0;
-        red_b += d.Np; s_b += d.ld ? (((long long)d.Np * d.Np + 1) & ~1LL) : (((long long)d.Np * (d.Np + 1) / 2 + 1) & ~1LL);
         h->max_n_kf = std::max(h->max_n_kf, F.n_kf);
         h->max_npose = std::max(h->max_npose, d.Npose);
-        if (d.ld) h->n_big++; else h->max_np = std::max(h->max_np, d.Np);
     }
-    h->n_kf_tot = kf_b; h->n_cam_tot = cam_b; h->n_lmk_tot = lmk_b; h->n_obs_tot = obs_b; h->np_tot = red_b; h->s_tot = s_b;
-    if (h->n_big) {
-        std::string e = load_dense_solver(h);
-        if (!e.empty()) { h->err = "set_windows: reduced dimension > 174 needs rocSOLVER: " + e; return SADVIO_E_HIP; }
-    }
+    h->n_kf_tot = kf_b; h->n_cam_tot = cam_b; h->n_lmk_tot = lmk_b; h->n_obs_tot = obs_b;
 
     // concatenate
     std::vector<double> kf_T0(12 * (size_t)kf_b), kf_vel(3 * (size_t)kf_b, 0.0), kf_ba(3 * (size_t)kf_b, 0.0), kf_bg(3 * (size_t)kf_b, 0.0);
@@ -440,6 +533,18 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
                 run_max[l] = std::max(run_max[l], run);
             }
         }
+        {
+            int hb = 0;
+            for (int l = 0; l < F.n_lmk; l++) {
+                int lo = 1 << 30, hi = -1;
+                for (int o = F.lmk_obs_ptr[l]; o < F.lmk_obs_ptr[l + 1]; o++) {
+                    const int fi = kf_fidx[d.kf_base + F.obs_kf[o]];
+                    if (fi >= 0) { lo = std::min(lo, fi); hi = std::max(hi, fi); }
+                }
+                if (hi >= 0) hb = std::max(hb, hi - lo);
+            }
+            h->wins[w].hb_lmk = hb;
+        }
         // tiles: runs of consecutive landmarks. Every landmark gets a group of G lanes (G = pow2 >= the
         // tile's largest observation count); a workgroup of BUILD_WAVES waves holds BUILD_WAVES * 64 / G
         // landmarks per round. A tile is cut when its key-frame list would exceed the LDS tile capacity.
@@ -451,7 +556,7 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
             while (l < F.n_lmk || (int)h->tiles.size() == d.tile_begin) {
                 Tile t{};
                 t.w = w; t.lmk0 = d.lmk_base + l; t.kmax = 1; t.G = 8;
-                t.dpf = d.dpf; t.Np = d.Np; t.red_off = d.red_off; t.S_off = d.S_off; t.ld = d.ld;
+                t.dpf = d.dpf;  // Np, red_off, S_off, ld: layout_reduced
                 t.cam_base = d.cam_base; t.n_cam = F.n_cam;
                 t.first_of_window = ((int)h->tiles.size() == d.tile_begin) ? 1 : 0;
                 std::vector<int> kfs;
@@ -526,7 +631,7 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
         for (int i = 0; i < 32; i++) if (hist[i]) fprintf(stderr, " %d:%d", i, hist[i]);
         fprintf(stderr, "\n");
     }
-    HIP_TRY(h->d_win.alloc(n_windows)); HIP_TRY(h->d_tiles.alloc(h->tiles.size())); HIP_TRY(h->d_tacc.alloc(2 * h->tiles.size()));
+    HIP_TRY(h->d_win.alloc(n_windows)); HIP_TRY(h->d_tacc.alloc(2 * h->tiles.size()));
     if (tile_kf.empty()) { tile_kf.push_back(0); tile_row.push_back(-1); }
     HIP_TRY(h->d_tile_kf.alloc(tile_kf.size())); HIP_TRY(h->d_tile_row.alloc(tile_row.size()));
     HIP_TRY(h->d_obs_slot.alloc(obs_slot.size())); HIP_TRY(h->d_ptab.alloc(2 * (size_t)POSE_TAB * kf_b));
@@ -536,24 +641,21 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
     HIP_TRY(h->d_kf_vel.alloc(kf_vel.size())); HIP_TRY(h->d_kf_ba.alloc(kf_ba.size())); HIP_TRY(h->d_kf_bg.alloc(kf_bg.size()));
     HIP_TRY(h->d_cam_K.alloc(cam_K.size())); HIP_TRY(h->d_cam_T.alloc(cam_T.size())); HIP_TRY(h->d_cam_isig.alloc(cam_isig.size()));
     HIP_TRY(h->d_lmk_p.alloc(lmk_p.size())); HIP_TRY(h->d_xl.alloc(2 * 3 * (size_t)std::max(lmk_b, 1)));
-    HIP_TRY(h->d_s_lmk.alloc(3 * (size_t)std::max(lmk_b, 1))); HIP_TRY(h->d_lmk_const.alloc(lmk_const.size()));
+    HIP_TRY(h->d_s_lmk.alloc(3 * (size_t)std::max(lmk_b, 1)));
     HIP_TRY(h->d_lmk_ob.alloc(lmk_ob.size())); HIP_TRY(h->d_lmk_oe.alloc(lmk_oe.size()));
     HIP_TRY(h->d_obs_kf.alloc(obs_kf.size())); HIP_TRY(h->d_obs_cam.alloc(obs_cam.size())); HIP_TRY(h->d_obs_meas.alloc(obs_meas.size()));
-    HIP_TRY(h->d_S.alloc((size_t)std::max<long long>(s_b, 1))); HIP_TRY(h->d_gred.alloc(std::max(red_b, 1)));
-    HIP_TRY(h->d_gfull.alloc(std::max(red_b, 1))); HIP_TRY(h->d_hdiag.alloc(std::max(red_b, 1)));
-    HIP_TRY(h->d_delta.alloc(std::max(red_b, 1))); HIP_TRY(h->d_s_pose.alloc(std::max(red_b, 1)));
 #define UP(dst, src) HIP_TRY(hipMemcpyAsync((dst).p, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, h->stream))
-    UP(h->d_tiles, h->tiles); UP(h->d_kf_T0, kf_T0); UP(h->d_kf_fidx, kf_fidx); UP(h->d_kf_vel, kf_vel);
+    UP(h->d_kf_T0, kf_T0); UP(h->d_kf_fidx, kf_fidx); UP(h->d_kf_vel, kf_vel);
     UP(h->d_kf_ba, kf_ba); UP(h->d_kf_bg, kf_bg); UP(h->d_cam_K, cam_K); UP(h->d_cam_T, cam_T); UP(h->d_cam_isig, cam_isig);
     if (lmk_b) { UP(h->d_lmk_p, lmk_p); }
-    UP(h->d_lmk_const, lmk_const); UP(h->d_lmk_ob, lmk_ob); UP(h->d_lmk_oe, lmk_oe); UP(h->d_obs_kf, obs_kf);
+    UP(h->d_lmk_ob, lmk_ob); UP(h->d_lmk_oe, lmk_oe); UP(h->d_obs_kf, obs_kf);
     UP(h->d_obs_cam, obs_cam); UP(h->d_obs_meas, obs_meas); UP(h->d_tile_kf, tile_kf); UP(h->d_tile_row, tile_row); UP(h->d_obs_slot, obs_slot);
 #undef UP
-    HIP_TRY(hipMemsetAsync(h->d_S.p, 0, sizeof(double) * (size_t)std::max<long long>(s_b, 1), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_gred.p, 0, sizeof(double) * std::max(red_b, 1), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_gfull.p, 0, sizeof(double) * std::max(red_b, 1), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_hdiag.p, 0, sizeof(double) * std::max(red_b, 1), h->stream));
-    int rc = upload_priors(h);  // also uploads the window descriptors and synchronises (host vectors go out of scope)
+    h->h_lmk_const_user = lmk_const; h->user_lmk_const = h->has_lmk_const;
+    h->h_lmk_ob = lmk_ob; h->h_lmk_oe = lmk_oe; h->h_kf_fidx = kf_fidx;
+    int rc = layout_reduced(h);
+    if (rc != SADVIO_OK) return rc;
+    rc = upload_priors(h);  // also uploads the window descriptors and synchronises (host vectors go out of scope)
     if (rc != SADVIO_OK) return rc;
     h->uploaded = true;
     for (auto& k : h->kclasses) { k.total_ms = 0; k.launches = 0; }
@@ -648,12 +750,35 @@ int sadvio_ba_set_imu_factors(sadvio_ba_handle* h, int32_t w, int32_t n, const s
     return upload_priors(h);
 }
 
-int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t, int32_t n_full, int32_t, const double*, const double*, int32_t,
-                              int32_t, int32_t, const int32_t*, const int32_t*) {
+int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t w, int32_t n_full, int32_t n, const double* J, const double* r0,
+                              int32_t kf_keep, int32_t kf_col, int32_t n_keep, const int32_t* lmk_index, const int32_t* lmk_col) {
     if (!h) return SADVIO_E_INVALID_ARG;
-    if (n_full == 0) return SADVIO_OK;
-    h->err = "set_dense_prior: dense marginalisation prior is not implemented on the device yet";
-    return SADVIO_E_INVALID_ARG;
+    if (!h->uploaded) { h->err = "set_dense_prior before set_windows"; return SADVIO_E_STATE; }
+    if (w < 0 || w >= (int)h->wins.size() || n_full < 0 || n < 0 || n_keep < 0) { h->err = "set_dense_prior: bad argument"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    const WinDev& d = h->wins[w].d;
+    DensePriorHost D;
+    if (n_full > 0) {
+        if (!J || !r0 || n <= 0 || (n_keep > 0 && (!lmk_index || !lmk_col))) { h->err = "set_dense_prior: missing array"; return SADVIO_E_INVALID_ARG; }
+        if (kf_keep >= d.n_kf || (kf_keep >= 0 && (kf_col < 0 || kf_col + 15 > n))) { h->err = "set_dense_prior: kept key-frame block out of range"; return SADVIO_E_INVALID_ARG; }
+        std::vector<char> used(n, 0);
+        if (kf_keep >= 0) for (int q = 0; q < 15; q++) used[kf_col + q] = 1;
+        for (int i = 0; i < n_keep; i++) {
+            if (lmk_col[i] < 0) continue;
+            if (lmk_index[i] < 0 || lmk_index[i] >= d.n_lmk || lmk_col[i] + 3 > n) { h->err = "set_dense_prior: kept landmark out of range"; return SADVIO_E_INVALID_ARG; }
+            for (int a = 0; a < 3; a++) {
+                if (used[lmk_col[i] + a]) { h->err = "set_dense_prior: overlapping column blocks"; return SADVIO_E_INVALID_ARG; }
+                used[lmk_col[i] + a] = 1;
+            }
+        }
+        D.n_full = n_full; D.n = n; D.kf_keep = kf_keep; D.kf_col = kf_col;
+        D.J.assign(J, J + (size_t)n_full * n); D.r0.assign(r0, r0 + n_full);
+        D.lmk_index.assign(lmk_index, lmk_index + n_keep); D.lmk_col.assign(lmk_col, lmk_col + n_keep);
+    }
+    h->dprior_per_win[w] = std::move(D);
+    int rc = layout_reduced(h);
+    if (rc != SADVIO_OK) return rc;
+    return upload_priors(h);
 }
 
 int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvio_solve_summary* summaries) {
@@ -711,28 +836,56 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                                                4 * (size_t)h->max_np + (size_t)(h->max_np / 5 + 1) * 36) + 64;
     auto kb = h->factor_type == SADVIO_FACTOR_PIXEL ? k_build<0> : k_build<1>;
     auto kk = h->factor_type == SADVIO_FACTOR_PIXEL ? k_backsub<0> : k_backsub<1>;
+    auto kbk = h->factor_type == SADVIO_FACTOR_PIXEL ? k_build_kept<0> : k_build_kept<1>;
     HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
     HIP_TRY(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back));
     HIP_TRY(hipFuncSetAttribute((const void*)k_solve<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
     const int reset_blocks = (int)std::min<long long>(1024, std::max<long long>(1, (P.n_xl + P.n_xp + 255) / 256));
-    bool dense_failed = false;
+    // rows below a block column of S that can be non-zero: (block half-bandwidth + 1) * dpf from the co-visibility
+    // structure and the IMU pairs; a dense prior fills the kept-landmark block, so those windows are dense
+    std::vector<int> big_bw(n_win, 0);
+    for (int w = 0; w < n_win; w++) {
+        const WinDev& d = h->wins[w].d;
+        if (!d.ld) continue;
+        int hb = h->wins[w].hb_lmk;
+        for (const ImuDev& f : h->imus_per_win[w]) {
+            const int fi = h->h_kf_fidx[f.kf_i], fj = h->h_kf_fidx[f.kf_j];
+            if (fi >= 0 && fj >= 0) hb = std::max(hb, std::abs(fi - fj));
+        }
+        big_bw[w] = (d.n_red > 0 || d.dp_n_full > 0) ? d.Np : std::min(d.Np, (hb + 1) * d.dpf);
+    }
     auto enqueue = [&]() {
         { ScopedTimer t(h, "k_reset"); hipLaunchKernelGGL(k_reset, dim3(reset_blocks), dim3(256), 0, h->stream, P); }
         { ScopedTimer t(h, "k_init_tables"); hipLaunchKernelGGL(k_init_tables, dim3((h->n_kf_tot + 63) / 64), dim3(64), 0, h->stream, P, h->n_kf_tot); }
         for (int s = 0; s < slots; s++) {
             { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
+            if (h->n_kept) { ScopedTimer t(h, "k_build_kept"); hipLaunchKernelGGL(kbk, dim3((h->n_kept + 127) / 128), dim3(128), 0, h->stream, P, s); }
             if (h->n_big < n_win) { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(k_solve<0>, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
             if (h->n_big) {
                 { ScopedTimer t(h, "k_solve_front"); hipLaunchKernelGGL(k_solve<1>, dim3(n_win), dim3(SOLVE_THREADS), 64, h->stream, P, s); }
                 {
-                    ScopedTimer t(h, "dense_potrf_potrs");
+                    // blocked Cholesky + solve of S, gred in place (dense_chol.h): two launches per 32 columns
+                    ScopedTimer t(h, "k_chol_panel+update+backsolve");
                     for (int w = 0; w < n_win; w++) {
                         const WinDev& d = h->wins[w].d;
                         if (!d.ld) continue;
-                        // row-major lower triangle == column-major upper triangle: S = U^T U
-                        if (h->dense.potrf(h->dense.handle, ROCBLAS_FILL_UPPER, d.Np, h->d_S.p + d.S_off, d.ld, h->d_big_info.p + w) != 0 ||
-                            h->dense.potrs(h->dense.handle, ROCBLAS_FILL_UPPER, d.Np, 1, h->d_S.p + d.S_off, d.ld, h->d_gred.p + d.red_off, d.Np) != 0)
-                            dense_failed = true;
+                        double* Sw = h->d_S.p + d.S_off;
+                        double* yw = h->d_gred.p + d.red_off;
+                        int* info = h->d_big_info.p + w;
+                        const int* skip = (const int*)((const char*)(h->d_states.p + (size_t)w * stride + s) + offsetof(LmState, done));
+                        const int N = d.Np, bw = big_bw[w];
+                        for (int k0 = 0; k0 < N; k0 += CH_NB) {
+                            const int nb = std::min(CH_NB, N - k0), s0 = k0 + nb;
+                            const int rows_end = std::min(N, s0 + bw), m = rows_end - s0;
+                            hipLaunchKernelGGL(k_chol_panel, dim3((m + 1 + CH_THREADS - 1) / CH_THREADS), dim3(CH_THREADS), 0, h->stream,
+                                               Sw, (long long)d.ld, yw, N, k0, rows_end, info, skip, (P.debug & 4096) && s == 3 && k0 == 64 ? h->d_dbg.p + 44 : nullptr);
+                            if (m > 0) {
+                                const int nt = (m + CH_TS - 1) / CH_TS;
+                                hipLaunchKernelGGL(k_chol_update, dim3(nt * (nt + 1) / 2 + (m + CH_THREADS - 1) / CH_THREADS), dim3(CH_THREADS), 0,
+                                                   h->stream, Sw, (long long)d.ld, yw, N, k0, rows_end, info, skip);
+                            }
+                        }
+                        hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(CH_THREADS), 0, h->stream, Sw, (long long)d.ld, yw, N, bw, info, skip);
                     }
                 }
                 { ScopedTimer t(h, "k_solve_back"); hipLaunchKernelGGL(k_solve<2>, dim3(n_win), dim3(SOLVE_THREADS), 64, h->stream, P, s); }
@@ -745,10 +898,14 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         }
         { ScopedTimer t(h, "k_final"); hipLaunchKernelGGL(k_final, dim3(n_win), dim3(64), 0, h->stream, P, slots); }
     };
-    if (h->cfg.use_graph && !h->cfg.profile_kernels && !h->n_big) {
+    if (h->cfg.use_graph && !h->cfg.profile_kernels) {
         // the whole <= 20-iteration solve is one graph launch; the key covers every kernel argument
-        std::vector<unsigned char> key(sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t));
+        std::vector<int> lay;  // layout-dependent launch parameters of the out-of-LDS windows
+        for (int w = 0; w < n_win; w++) { lay.push_back(h->wins[w].d.Np); lay.push_back(h->wins[w].d.ld); lay.push_back(big_bw[w]); }
+        lay.push_back(h->n_kept); lay.push_back(h->n_big);
+        std::vector<unsigned char> key(sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t) + lay.size() * sizeof(int));
         unsigned char* kp = key.data();
+        memcpy(kp + sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t), lay.data(), lay.size() * sizeof(int));
         memcpy(kp, &P, sizeof(DevPtrs)); kp += sizeof(DevPtrs);
         const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type};
         memcpy(kp, ints, sizeof(ints)); kp += sizeof(ints);
@@ -769,7 +926,6 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         enqueue();
     }
     HIP_TRY(hipGetLastError());
-    if (dense_failed) { h->err = "solve: rocSOLVER potrf / potrs call failed"; return SADVIO_E_HIP; }
     HIP_TRY(hipMemcpyAsync(h->h_final, h->d_final.p, sizeof(FinalRec) * (size_t)n_win, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->cfg.profile_kernels) collect_timers(h);
@@ -780,6 +936,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             for (int i = 1; i < 16; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[0]) * 0.01);
             fprintf(stderr, "  shader clock %.3f GHz\n[sadvio dbg] k_build:", (double)(ts[21] - ts[20]) / ((ts[15] - ts[0]) * 10.0));
             for (int i = 33; i < 43; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[32]) * 0.01);
+            fprintf(stderr, "\n[sadvio dbg] k_chol_panel:");
+            for (int i = 45; i < 51; i++) fprintf(stderr, " %d:%.2f", i - 44, (ts[i] - ts[44]) * 0.01);
             fprintf(stderr, "\n");
         }
     }

@@ -37,6 +37,12 @@ struct WinDev {
     int imu_begin, imu_end;
     int factor_type, has_imu;
     int ld;           // 0: packed S solved in LDS; Np: full row-major S in HBM (Np > MAX_LDS_NP)
+    // dense marginalisation prior (MarginalizationFactor, marginalization.hpp:88-218): r = r0 + J dx
+    int n_red;        // landmarks kept in the reduced system (the prior couples them): 3 columns each after the poses
+    int dp_n_full, dp_n;   // rows / columns of J (0 = no prior)
+    int dp_int_off;   // into dp_ints: kind[n] index[n] col[n]
+    long long dp_off; // into dp_data: J[nf*n] Jt[n*nf] H[n*n] r0[nf] dx[n] r[nf]
+    int kept_begin, kept_end;  // slice of kept_obs (observations of the reduced landmarks)
 };
 
 // One workgroup of k_build / k_backsub: a run of consecutive landmarks of one window. Each landmark is

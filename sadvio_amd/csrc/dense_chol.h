@@ -1,0 +1,252 @@
+// dense_chol.h — blocked right-looking Cholesky + solve of a reduced system that lives in HBM (N_p > 174).
+//
+// Storage: full row-major N x N, lower triangle used (element (i >= j) at A[i * ld + j]); the right-hand side y
+// is a separate vector that is carried through the factorisation as an extra matrix row (forward substitution
+// for free), so after the last block column y = L^-1 y; k_chol_backsolve then overwrites it with L^-T y.
+//
+// Per block column k0 (NB = 32 columns), two launches:
+//   k_chol_panel   every workgroup loads the 32x32 diagonal block into LDS and factors it redundantly (one wave,
+//                  rows in registers, v_readlane broadcasts: ~1.5 us), then solves its 256 panel rows
+//                  L_rk = A_rk L_kk^-T by forward substitution against the LDS copy; workgroup 0 also files
+//                  L_kk and substitutes the right-hand-side row.
+//   k_chol_update  trailing update C -= L_ik L_jk^T on 64x64 tiles (lower-triangular tile pairs), K = 32, on the
+//                  FP64 matrix cores (v_mfma_f64_16x16x4_f64, 8 per 16x16 sub-tile); a second set of workgroups
+//                  updates the right-hand-side row.
+// `rows_end` bounds the rows below the block column that can be non-zero (half bandwidth known on the host from
+// the co-visibility structure; = N for a dense system): the work per step is O(bw^2), not O(N^2), for the
+// block-banded systems of long trajectories (configs 4 / 5).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace sadvio {
+
+constexpr int CH_NB = 32;
+constexpr int CH_TS = 64;
+constexpr int CH_THREADS = 256;
+
+__device__ __forceinline__ double ch_readlane(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// In-register Cholesky of an nb x nb (nb <= 32) block held one ROW per lane (lane r: a[c] = D[r][c], c <= r).
+// Returns false in all lanes if a pivot is not positive. On return a[] holds row r of L.
+__device__ __forceinline__ bool ch_factor_rows(double (&a)[CH_NB], int nb, int ln) {
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < CH_NB; c++) {
+        if (c < nb) {
+            const double d = ch_readlane(a[c], c);  // pivot (row c, column c), wave-uniform
+            if (!(d > 0.0)) ok = false;
+            const double inv = rsqrt_nr(d);  // v_rsq_f64 + 2 Newton steps (kernels.h): ~4x shorter chain than sqrt + divide
+            a[c] = (ln == c) ? d * inv : a[c] * inv;  // column c of L (rows >= c)
+#pragma unroll
+            for (int j = c + 1; j < CH_NB; j++) {
+                if (j < nb) {
+                    const double ljc = ch_readlane(a[c], j);  // L[j][c], wave-uniform
+                    a[j] -= a[c] * ljc;                       // rows r >= j matter; others hold garbage never read
+                }
+            }
+        }
+    }
+    return ok;
+}
+
+// One block column: diagonal factor + panel solve (+ right-hand-side row).
+__global__ __launch_bounds__(CH_THREADS) void k_chol_panel(double* __restrict__ A, long long ld, double* __restrict__ y,
+                                                           int N, int k0, int rows_end, int* info, const int* skip, long long* ts) {
+    if (skip && *skip) return;
+    if (*info != 0) return;
+#define CH_TS_MARK(i_) do { if (ts && blockIdx.x == 0 && threadIdx.x == 0) ts[i_] = wall_clock64(); } while (0)
+    CH_TS_MARK(0);
+    __shared__ double Ld[CH_NB][CH_NB + 1];
+    __shared__ double dinv[CH_NB];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    const int nb = min(CH_NB, N - k0);
+    if (wv == 0) {
+        double a[CH_NB];
+        const int r = ln < nb ? ln : nb - 1;
+#pragma unroll
+        for (int c = 0; c < CH_NB; c++) a[c] = (c < nb && c <= r) ? A[(long long)(k0 + r) * ld + k0 + c] : 0.0;
+        CH_TS_MARK(1);
+        const bool ok = ch_factor_rows(a, nb, ln);
+        CH_TS_MARK(2);
+        if (ln < nb) {
+#pragma unroll
+            for (int c = 0; c < CH_NB; c++)
+                if (c < nb) Ld[ln][c] = (c <= ln) ? a[c] : 0.0;
+        }
+        if (ln == 0) s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_ok) {
+        if (blockIdx.x == 0 && tid == 0) *info = k0 + 1;
+        return;
+    }
+    if (tid < nb) dinv[tid] = 1.0 / Ld[tid][tid];
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        // file L_kk (lower triangle) into A
+        for (int e = tid; e < nb * nb; e += CH_THREADS) {
+            const int r = e / nb, c = e - r * nb;
+            if (c <= r) A[(long long)(k0 + r) * ld + k0 + c] = Ld[r][c];
+        }
+    }
+    CH_TS_MARK(3);
+    // panel rows (and, as the last "row", the right-hand side)
+    const int s = k0 + nb;
+    const int m = rows_end - s;
+    const int idx = blockIdx.x * CH_THREADS + tid;  // 0 .. m-1 panel rows, m = rhs row (workgroup that owns it)
+    const bool is_rhs = idx == m;
+    if (idx > m) return;
+    double x[CH_NB];
+    double* row = is_rhs ? y + k0 : A + (long long)(s + idx) * ld + k0;
+#pragma unroll
+    for (int c = 0; c < CH_NB; c++) x[c] = c < nb ? row[c] : 0.0;
+    CH_TS_MARK(4);
+#pragma unroll
+    for (int c = 0; c < CH_NB; c++) {
+        if (c < nb) {
+            const double xc = x[c] * dinv[c];
+            x[c] = xc;
+#pragma unroll
+            for (int j = c + 1; j < CH_NB; j++)
+                if (j < nb) x[j] -= xc * Ld[j][c];
+        }
+    }
+    CH_TS_MARK(5);
+#pragma unroll
+    for (int c = 0; c < CH_NB; c++)
+        if (c < nb) row[c] = x[c];
+    CH_TS_MARK(6);
+}
+
+// Trailing update of the rows / columns [s, rows_end) by the panel of block column k0, and of the rhs row.
+__global__ __launch_bounds__(CH_THREADS) void k_chol_update(double* __restrict__ A, long long ld, double* __restrict__ y,
+                                                            int N, int k0, int rows_end, const int* info, const int* skip) {
+    if (skip && *skip) return;
+    if (*info != 0) return;
+    const int nb = min(CH_NB, N - k0);
+    const int s = k0 + nb;
+    const int m = rows_end - s;
+    if (m <= 0) return;
+    const int nt = (m + CH_TS - 1) / CH_TS;
+    const int npair = nt * (nt + 1) / 2;
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    __shared__ double Pi[CH_TS][CH_NB + 1];
+    __shared__ double Pj[CH_TS][CH_NB + 1];
+    if ((int)blockIdx.x >= npair) {
+        // rhs row: y[s + j] -= sum_c z_c L[s + j][k0 + c], one thread per j
+        const int t = blockIdx.x - npair;
+        const int j = t * CH_TS * 4 + tid;  // 256 entries per workgroup
+        if (j < m) {
+            const double* lrow = A + (long long)(s + j) * ld + k0;
+            double acc = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < nb; c++) acc += y[k0 + c] * lrow[c];
+            y[s + j] -= acc;
+        }
+        return;
+    }
+    int ti = 0, rem = blockIdx.x;
+    while (rem >= ti + 1) { rem -= ti + 1; ti++; }
+    const int tj = rem;
+    const int i0 = ti * CH_TS, j0 = tj * CH_TS;
+    // stage the two panel slabs (64 rows x nb columns each; zero beyond the edge)
+    for (int e = tid; e < CH_TS * CH_NB; e += CH_THREADS) {
+        const int r = e / CH_NB, c = e - r * CH_NB;
+        const int gi = i0 + r, gj = j0 + r;
+        Pi[r][c] = (gi < m && c < nb) ? A[(long long)(s + gi) * ld + k0 + c] : 0.0;
+        Pj[r][c] = (gj < m && c < nb) ? A[(long long)(s + gj) * ld + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int lr = ln & 15, lk = ln >> 4;
+    // wave wv owns the 16-row band wv of the tile; 4 column sub-tiles (skipping those above the diagonal)
+    const int ib = wv;
+    for (int jb = 0; jb < 4; jb++) {
+        if (ti == tj && jb > ib) continue;
+        const int rbase = i0 + 16 * ib, cbase = j0 + 16 * jb;
+        if (rbase >= m || cbase >= m) continue;
+        d4 c;
+        long long addr[4];
+        bool ok[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int row = rbase + lk + 4 * rg, col = cbase + lr;
+            ok[rg] = row < m && col < m && col <= row;
+            addr[rg] = (long long)(s + (row < m ? row : m - 1)) * ld + s + (col < m ? col : m - 1);
+            c[rg] = ok[rg] ? A[addr[rg]] : 0.0;
+        }
+#pragma unroll
+        for (int kk = 0; kk < CH_NB; kk += 4) {
+            const double a = -Pi[16 * ib + lr][kk + lk];
+            const double b = Pj[16 * jb + lr][kk + lk];
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+            if (ok[rg]) A[addr[rg]] = c[rg];
+    }
+}
+
+// x = L^-T y (in place), block by block from the bottom; one workgroup. `bw` = number of rows below a block
+// column that can be non-zero (N for dense).
+__global__ __launch_bounds__(CH_THREADS) void k_chol_backsolve(const double* __restrict__ A, long long ld,
+                                                               double* __restrict__ y, int N, int bw, const int* info,
+                                                               const int* skip) {
+    if (skip && *skip) return;
+    if (*info != 0) return;
+    __shared__ double part[CH_THREADS / CH_NB][CH_NB];
+    __shared__ double xk[CH_NB];
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    const int c = tid & (CH_NB - 1), g = tid / CH_NB;  // column within the block, row group
+    constexpr int NG = CH_THREADS / CH_NB;
+    const int nblk = (N + CH_NB - 1) / CH_NB;
+    for (int k = nblk - 1; k >= 0; k--) {
+        const int k0 = k * CH_NB;
+        const int nb = min(CH_NB, N - k0);
+        const int s = k0 + nb;
+        const int rows_end = min(N, s + bw);
+        // t_c = sum_{i >= s} L[i][k0 + c] x_i
+        double acc = 0.0;
+        if (c < nb)
+            for (int i = s + g; i < rows_end; i += NG) acc += A[(long long)i * ld + k0 + c] * y[i];
+        part[g][c] = acc;
+        // the diagonal block, one column per lane of wave 0: l[j] = L[k0 + j][k0 + lane]
+        double l[CH_NB];
+        if (wv == 0) {
+#pragma unroll
+            for (int j = 0; j < CH_NB; j++) l[j] = (j < nb && ln < nb && ln <= j) ? A[(long long)(k0 + j) * ld + k0 + ln] : 0.0;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            double t = 0.0;
+            if (ln < nb) {
+                t = y[k0 + ln];
+#pragma unroll
+                for (int q = 0; q < NG; q++) t -= part[q][ln];
+            }
+            // solve L_kk^T x = t: x_j for j = nb-1 .. 0; lane c keeps t_c
+#pragma unroll
+            for (int j = CH_NB - 1; j >= 0; j--) {
+                if (j < nb) {
+                    const double tj = ch_readlane(t, j);
+                    const double ljj = ch_readlane(l[j], j);
+                    const double xj = tj / ljj;
+                    if (ln == j) t = xj;
+                    else if (ln < j) t -= l[j] * xj;  // L[k0 + j][k0 + ln]
+                }
+            }
+            if (ln < nb) y[k0 + ln] = t;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace sadvio

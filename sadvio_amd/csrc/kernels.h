@@ -45,6 +45,11 @@ struct DevPtrs {
     TileAcc* tacc;    // [2][n_tiles] per-tile partials, double-buffered by slot parity (no atomics)
     FinalRec* final_out;  // [n_win]
     int* big_info;        // [n_win] potrf info of the windows solved out of LDS
+    const int* lmk_red;   // [n_lmk_tot] offset of a prior-kept landmark in its window's reduced vector, else -1 (may be null)
+    const int* kept_obs;  // [n_kept][3] (device observation index, global landmark, window)
+    int n_kept;
+    double* dp_data;      // dense priors, see WinDev::dp_off
+    const int* dp_ints;
     long long n_xp, n_xv, n_xl;  // doubles in the (double-buffered) delta arrays, zeroed by k_reset
     int n_tiles;
     int state_stride;
@@ -197,8 +202,8 @@ struct ObsLin {
 // Lane-local linearisation of observation `o` of landmark `gl` from LDS tables.
 template <int FACTOR>
 __device__ __forceinline__ void lane_linearize(const DevPtrs& P, const double* poseTab, const double* camTab,
-                                               const int* rowTab, int cam_base, int o, const double* pw, bool lfree,
-                                               ObsLin& L) {
+                                               const int* rowTab, int cam_base, int o, const double* pw, bool keep_jl,
+                                               bool lcounted, ObsLin& L) {
     const int slot = P.obs_slot[o];
     const int cam = P.obs_cam[o] - cam_base;
     const double* tab = poseTab + slot * POSE_TAB;
@@ -217,11 +222,11 @@ __device__ __forceinline__ void lane_linearize(const DevPtrs& P, const double* p
 #pragma unroll
         for (int i = 0; i < 12; i++) L.Jp[i] = 0.0;
     }
-    if (!lfree) {
+    if (!keep_jl) {
 #pragma unroll
         for (int i = 0; i < 6; i++) L.Jl[i] = 0.0;
     }
-    L.counted = (L.row >= 0) || lfree;
+    L.counted = (L.row >= 0) || lcounted;
     if (!L.counted) { /* fixed cost: caller accounts r, then it leaves the program */ }
 }
 
@@ -360,14 +365,17 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
         const int gl = T.lmk0 + (lmk_valid ? lm : 0);
         const int ob = P.lmk_ob[gl], oe = P.lmk_oe[gl];
         const int nobs = lmk_valid ? oe - ob : 0;
-        const bool lfree = !(P.lmk_const && P.lmk_const[gl]);
+        // 0 free (eliminated here), 1 constant, 2 kept in the reduced system by a dense prior: its pose-pose part
+        // goes the usual way, the landmark rows / columns are added by k_build_kept
+        const int lcode = P.lmk_const ? P.lmk_const[gl] : 0;
+        const bool lfree = lcode == 0;
         ObsLin L;
         L.valid = q < nobs;
         L.row = -1; L.slot = 0; L.counted = false;
         if (L.valid) {
             const double pw[3] = {P.lmk_p[3 * (long long)gl] + xl[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1] + xl[3 * (long long)gl + 1],
                                   P.lmk_p[3 * (long long)gl + 2] + xl[3 * (long long)gl + 2]};
-            lane_linearize<FACTOR>(P, poseTab, camTab, rowTab, T.cam_base, ob + q, pw, lfree, L);
+            lane_linearize<FACTOR>(P, poseTab, camTab, rowTab, T.cam_base, ob + q, pw, lfree, lcode != 1, L);
             const double c = L.r[0] * L.r[0] + L.r[1] * L.r[1];
             if (L.counted) cost_part += c;
             else { fixed_part += c; L.r[0] = 0.0; L.r[1] = 0.0; }
@@ -832,7 +840,7 @@ __device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, d
                     addr[rg] = tri(s + rowc, s + colc);
                     c[rg] = P[addr[rg]];
                 }
-                a0 = (ai < m) ? -a0 : 0.0; b0 = (bj < m) ? b0 : 0.0;
+                a0 = (ai < m && lk < NB) ? -a0 : 0.0; b0 = (bj < m && lk < NB) ? b0 : 0.0;
                 a1 = (ai < m && lk + 4 < NB) ? -a1 : 0.0; b1 = (bj < m && lk + 4 < NB) ? b1 : 0.0;
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
@@ -908,6 +916,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     if ((P.debug & 4096) && blockIdx.x == 0 && tid == 0 && slot == 3) P.dbg_ts[20] = clock64();
     if (tid == 0) st = *stp;
     __syncthreads();
+    if (MODE == 1 && tid == 0) P.big_info[w] = 0;
     if (st.done) return;
     const int Np = W.Np;
     const long long ld = W.ld;
@@ -1049,6 +1058,49 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             if (ci >= 0 && cj >= 0) atomic_add_f64(&A[ci >= cj ? aidx(ci, cj) : aidx(cj, ci)], -s2);
         }
     }
+    // dense marginalisation prior (K4 / a9): r = r0 + J dx, J constant. H = J^T J and J^T were formed once
+    // at upload; per step two wave-per-row GEMVs (r, J^T r) and the scatter of H through the column map.
+    if (W.dp_n_full > 0) {
+        __syncthreads();
+        const int n = W.dp_n, nf = W.dp_n_full;
+        double* D = P.dp_data + W.dp_off;
+        const double* Jm = D;
+        const double* Jt = Jm + (size_t)nf * n;
+        const double* Hm = Jt + (size_t)n * nf;
+        const double* r0 = Hm + (size_t)n * n;
+        double* dxv = D + 2 * (size_t)nf * n + (size_t)n * n + nf;
+        double* rv = dxv + n;
+        const int* kind = P.dp_ints + W.dp_int_off;
+        const int* index = kind + n;
+        const int* col = index + n;
+        const double* srcs[5] = {xp, P.xv + (long long)cur * P.xv_stride, P.xba + (long long)cur * P.xv_stride,
+                                 P.xbg + (long long)cur * P.xv_stride, P.xl + (long long)cur * P.xl_stride};
+        for (int a = tid; a < n; a += blockDim.x) dxv[a] = kind[a] < 0 ? 0.0 : srcs[kind[a]][index[a]];
+        __syncthreads();
+        for (int i = wv; i < nf; i += nwv) {
+            double s = 0.0;
+            for (int a = ln; a < n; a += 64) s += Jm[(size_t)i * n + a] * dxv[a];
+            s = wave_sum(s);
+            if (ln == 0) { s += r0[i]; rv[i] = s; cost_part += s * s; }
+        }
+        __syncthreads();
+        for (int a = wv; a < n; a += nwv) {
+            const int ca = col[a];
+            if (ca < 0) continue;
+            double g = 0.0;
+            for (int i = ln; i < nf; i += 64) g += Jt[(size_t)a * nf + i] * rv[i];
+            g = wave_sum(g);
+            if (ln == 0) { y[ca] += g; gf[ca] += g; hd[ca] += Hm[(size_t)a * n + a]; }
+        }
+        for (long long idx = tid; idx < (long long)n * n; idx += blockDim.x) {
+            const int a = (int)(idx / n), b = (int)(idx - (long long)a * n);
+            if (b > a) continue;
+            const int ca = col[a], cb = col[b];
+            if (ca < 0 || cb < 0) continue;
+            A[ca >= cb ? aidx(ca, cb) : aidx(cb, ca)] += Hm[idx];
+        }
+        __syncthreads();
+    }
     // window totals of the linearisation: tiles' k_build partials + the pose-only factors evaluated here
     double gm = 0.0;
     {
@@ -1099,7 +1151,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     long long* ts = ((P.debug & 4096) && blockIdx.x == 0 && slot == 3) ? P.dbg_ts : nullptr;
     if (MODE == 0) {
         bool ok;
-        if (W.dpf == 6) ok = chol_solve_packed<6>(A, Np, y, xs, LpT, linvTab, ts);
+        if (W.n_red > 0) ok = chol_solve_packed<3>(A, Np, y, xs, LpT, linvTab, ts);  // Np = dpf n_free + 3 n_red
+        else if (W.dpf == 6) ok = chol_solve_packed<6>(A, Np, y, xs, LpT, linvTab, ts);
         else ok = chol_solve_packed<5>(A, Np, y, xs, LpT, linvTab, ts);
         if (!ok) {
             if (tid == 0) acc->chol_fail = 1;
@@ -1233,6 +1286,23 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
         }
     }
+    if (W.dp_n_full > 0) {
+        // model cost change and candidate cost of the dense prior: m = J delta, r_cand = r + m
+        const int n = W.dp_n, nf = W.dp_n_full;
+        double* D = P.dp_data + W.dp_off;
+        const double* Jm = D;
+        double* dxv = D + 2 * (size_t)nf * n + (size_t)n * n + nf;
+        const double* rv = dxv + n;
+        const int* col = P.dp_ints + W.dp_int_off + 2 * n;
+        for (int a = tid; a < n; a += blockDim.x) dxv[a] = col[a] >= 0 ? y[col[a]] : 0.0;
+        __syncthreads();
+        for (int i = wv; i < nf; i += nwv) {
+            double m = 0.0;
+            for (int a = ln; a < n; a += 64) m += Jm[(size_t)i * n + a] * dxv[a];
+            m = wave_sum(m);
+            if (ln == 0) { mcc += -m * (rv[i] + 0.5 * m); cc += (rv[i] + m) * (rv[i] + m); }
+        }
+    }
     SADVIO_TS(3, 7);
     sn = wave_sum(sn); cn = wave_sum(cn); mcc = wave_sum(mcc); cc = wave_sum(cc);
     if (bad) acc->chol_fail = 1;
@@ -1296,7 +1366,8 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
         const int gl = T.lmk0 + (lmk_valid ? lm : 0);
         const int ob = P.lmk_ob[gl], oe = P.lmk_oe[gl];
         const int nobs = lmk_valid ? oe - ob : 0;
-        const bool lfree = !(P.lmk_const && P.lmk_const[gl]);
+        const int lcode = P.lmk_const ? P.lmk_const[gl] : 0;
+        const bool lfree = lcode == 0;
         const double p0[3] = {P.lmk_p[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1], P.lmk_p[3 * (long long)gl + 2]};
         const double x0[3] = {xl[3 * (long long)gl], xl[3 * (long long)gl + 1], xl[3 * (long long)gl + 2]};
         ObsLin L;
@@ -1304,7 +1375,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
         L.row = -1; L.slot = 0; L.counted = false;
         if (L.valid) {
             const double pw[3] = {p0[0] + x0[0], p0[1] + x0[1], p0[2] + x0[2]};
-            lane_linearize<FACTOR>(P, poseTab, camTab, rowTab, T.cam_base, ob + q, pw, lfree, L);
+            lane_linearize<FACTOR>(P, poseTab, camTab, rowTab, T.cam_base, ob + q, pw, lcode != 1, lcode != 1, L);
             if (!L.counted) { L.r[0] = 0.0; L.r[1] = 0.0; }
         } else {
             L.r[0] = L.r[1] = 0.0;
@@ -1327,16 +1398,20 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
         double t0 = group_sum(L.Jl[0] * e0 + L.Jl[3] * e1, G);
         double t1 = group_sum(L.Jl[1] * e0 + L.Jl[4] * e1, G);
         double t2 = group_sum(L.Jl[2] * e0 + L.Jl[5] * e1, G);
-        const double d0 = -(Mi[0] * t0 + Mi[1] * t1 + Mi[2] * t2);
-        const double d1 = -(Mi[1] * t0 + Mi[3] * t1 + Mi[4] * t2);
-        const double d2 = -(Mi[2] * t0 + Mi[4] * t1 + Mi[5] * t2);
+        double d0 = -(Mi[0] * t0 + Mi[1] * t1 + Mi[2] * t2);
+        double d1 = -(Mi[1] * t0 + Mi[3] * t1 + Mi[4] * t2);
+        double d2 = -(Mi[2] * t0 + Mi[4] * t1 + Mi[5] * t2);
+        if (lcode == 2) {  // kept landmark: its step is part of the reduced solution (|step|^2 is counted there)
+            const double* dr = P.delta + T.red_off + P.lmk_red[gl];
+            d0 = dr[0]; d1 = dr[1]; d2 = dr[2];
+        }
         const double c0 = x0[0] + d0, c1 = x0[1] + d1, c2 = x0[2] + d2;
         if (lmk_valid && q == 0) {
             xlc[3 * (long long)gl] = c0; xlc[3 * (long long)gl + 1] = c1; xlc[3 * (long long)gl + 2] = c2;
             if (active) {
                 sn += d0 * d0 + d1 * d1 + d2 * d2;
                 cn += c0 * c0 + c1 * c1 + c2 * c2;
-            }
+            } else if (lcode == 2) cn += c0 * c0 + c1 * c1 + c2 * c2;
         }
         if (L.valid && L.counted) {
             // model cost change of this residual block: -(J d)^T (r + J d / 2)
@@ -1370,6 +1445,45 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
         for (int k = 0; k < BUILD_WAVES; k++) { a0 += s_part[k * 4]; a1 += s_part[k * 4 + 1]; a2 += s_part[k * 4 + 2]; a3 += s_part[k * 4 + 3]; }
         TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + blockIdx.x;
         ta->cand_cost = a0; ta->mcc = a1; ta->step_norm2 = a2; ta->cand_norm2 = a3;
+    }
+}
+
+// Rows / columns of the prior-kept landmarks in the reduced system: one thread per observation adds
+// Jl^T Jp (3x6), Jl^T Jl (3x3, lower), Jl^T r and the diagonal; few hundred landmarks per window at most.
+template <int FACTOR>
+__global__ void k_build_kept(DevPtrs P, int slot) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.n_kept) return;
+    const int o = P.kept_obs[3 * e], gl = P.kept_obs[3 * e + 1], w = P.kept_obs[3 * e + 2];
+    const LmState st = P.states[(long long)w * P.state_stride + slot];
+    if (st.done) return;
+    const WinDev W = P.win[w];
+    const int cur = st.cur;
+    const int kf = P.obs_kf[o], cam = P.obs_cam[o];
+    const double* tab = P.ptab + (long long)cur * P.ptab_stride + (long long)kf * POSE_TAB;
+    const double* xl = P.xl + (long long)cur * P.xl_stride + 3 * (long long)gl;
+    const double pw[3] = {P.lmk_p[3 * (long long)gl] + xl[0], P.lmk_p[3 * (long long)gl + 1] + xl[1], P.lmk_p[3 * (long long)gl + 2] + xl[2]};
+    double r[2], Jp[12], Jl[6];
+    if (FACTOR == 0) {
+        const double* m = P.obs_meas + 2 * (long long)o;
+        pixel_factor<true>(tab, P.cam_K + 4 * (long long)cam, P.cam_T + 12 * (long long)cam, pw, m[0], m[1], P.cam_isig[cam], r, Jp, Jl);
+    } else {
+        const double* m = P.obs_meas + 3 * (long long)o;
+        double b[3] = {m[0], m[1], m[2]};
+        angular_factor<true>(tab, P.cam_T + 12 * (long long)cam, pw, b, P.cam_isig[cam], r, Jp, Jl);
+    }
+    const int fi = P.kf_fidx[kf];
+    const int lr = P.lmk_red[gl];
+    double* Sg = P.S + W.S_off;
+    for (int a = 0; a < 3; a++) {
+        const int row = lr + a;
+        if (fi >= 0)
+            for (int i = 0; i < 6; i++) atomic_add_f64(&Sg[s_index(W.ld, row, fi * W.dpf + i)], Jl[a] * Jp[i] + Jl[3 + a] * Jp[6 + i]);
+        for (int b = 0; b <= a; b++) atomic_add_f64(&Sg[s_index(W.ld, row, lr + b)], Jl[a] * Jl[b] + Jl[3 + a] * Jl[3 + b]);
+        const double g = Jl[a] * r[0] + Jl[3 + a] * r[1];
+        atomic_add_f64(&P.gred[W.red_off + row], g);
+        atomic_add_f64(&P.gfull[W.red_off + row], g);
+        atomic_add_f64(&P.hdiag[W.red_off + row], Jl[a] * Jl[a] + Jl[3 + a] * Jl[3 + a]);
     }
 }
 

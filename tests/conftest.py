@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the oracle's OpenMP threads must not spin when the box gives the process fewer cores than threads
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -4,6 +4,7 @@ LM control as the small path. BASELINE.json configs 4 (100 KF x 50 k landmarks) 
 import numpy as np
 import pytest
 
+from golden_util import cached_oracle_solve
 from sadvio_amd import capi, synthetic
 
 pytestmark = pytest.mark.gpu
@@ -12,7 +13,7 @@ POSE_TOL = 1e-6
 LMK_TOL = 1e-5
 
 
-def _compare(backend_cls, oracle_lib, w, opts, check_iters=True, n_threads=8):
+def _compare(backend_cls, oracle_lib, w, opts, check_iters=True, n_threads=2, golden=None):
     be = backend_cls(device=0)
     try:
         be.set_windows([w])
@@ -21,7 +22,7 @@ def _compare(backend_cls, oracle_lib, w, opts, check_iters=True, n_threads=8):
         ids = be.get_ids(0)
     finally:
         be.close()
-    ref = oracle_lib.solve(w, opts, n_threads=n_threads)
+    ref = cached_oracle_solve(golden, oracle_lib, w, opts, n_threads=n_threads) if golden else oracle_lib.solve(w, opts, n_threads=n_threads)
     rs = ref["summary"]
     assert np.isclose(s.initial_cost, rs.initial_cost, rtol=1e-10)
     assert np.isclose(s.final_cost, rs.final_cost, rtol=1e-9)
@@ -46,7 +47,7 @@ def test_config4_100kf_50k_landmarks(backend_cls, oracle_lib):
     """BASELINE.json config 4 on one GPU: 100 KF x 50 000 landmarks x 250 000 factors, N_p = 594."""
     w = synthetic.make_window(n_kf=100, n_lmk=50000, length=50.0, band=6, seed=4)
     assert (w.n_kf, w.n_lmk, w.n_obs) == (100, 50000, 250000)
-    _compare(backend_cls, oracle_lib, w, capi.reference_options())
+    _compare(backend_cls, oracle_lib, w, capi.reference_options(), golden="config4_ref_solve")
 
 
 def test_mixed_batch_small_and_large(backend_cls, oracle_lib):
