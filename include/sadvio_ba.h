@@ -189,6 +189,23 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle *h, int32_t w, int32_t n_full, in
                               const double *J, const double *r0, int32_t kf_keep, int32_t kf_col,
                               int32_t n_keep, const int32_t *lmk_index, const int32_t *lmk_col);
 
+/* ---- one window spanning several GPUs (no reference counterpart: the reference is one process) ----
+ * The landmarks of a window (with all their observations) are partitioned over `world` processes, one GPU each;
+ * key-frames, cameras, pose priors and IMU factors are replicated (a dense prior is not supported on a
+ * sharded window yet: set_dense_prior refuses). Every rank calls set_windows with ITS landmarks, then solve(); per LM step the library all-reduces [S | g | diag | per-rank cost partials] once and the
+ * step's candidate-cost partials once; every rank then solves the identical reduced system redundantly
+ * (no broadcast) and back-substitutes its own landmarks. Pose deltas and summaries are identical on all ranks.
+ *
+ * set_collective installs a caller-provided in-place sum all-reduce over device memory, enqueued on
+ * `hip_stream` (returns 0 on success); comm_init_rccl installs the built-in one (ncclAllReduce, ncclDouble,
+ * ncclSum over RCCL / xGMI) from a 128-byte ncclUniqueId created by rank 0 with rccl_unique_id and
+ * distributed by the caller. Both must be called before set_windows. */
+typedef int (*sadvio_allreduce_fn)(void *ctx, double *device_buf, int64_t count, void *hip_stream);
+int sadvio_ba_set_collective(sadvio_ba_handle *h, int32_t rank, int32_t world, sadvio_allreduce_fn fn, void *ctx);
+#define SADVIO_RCCL_ID_BYTES 128
+int sadvio_ba_rccl_unique_id(void *id128);
+int sadvio_ba_comm_init_rccl(sadvio_ba_handle *h, int32_t rank, int32_t world, const void *id128);
+
 /* Run the Levenberg-Marquardt solve of every uploaded window: replaces the body of
  * AOptimizer::localMapBA / localMapVIOptimization from ceres::Solve on (AOptimizer.cpp:326,388).
  * `summaries` has n_windows entries (may be NULL). */

@@ -34,6 +34,11 @@ class Config(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+# int fn(void* ctx, double* device_buf, int64 count, void* hip_stream): in-place sum all-reduce, enqueued on the stream
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+RCCL_ID_BYTES = 128
+
+
 class FlatWindowC(C.Structure):
     _fields_ = [
         ("n_kf", C.c_int32), ("n_cam", C.c_int32), ("n_lmk", C.c_int32), ("n_obs", C.c_int32),
@@ -224,6 +229,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.sadvio_ba_set_imu_factors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ImuFactorC)]
     lib.sadvio_ba_set_dense_prior.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.c_int32,
                                               C.c_int32, C.c_int32, _ip, _ip]
+    lib.sadvio_ba_set_collective.argtypes = [C.c_void_p, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p]
+    lib.sadvio_ba_rccl_unique_id.argtypes = [C.c_void_p]
+    lib.sadvio_ba_comm_init_rccl.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.sadvio_ba_solve.argtypes = [C.c_void_p, C.POINTER(SolveOptions), C.POINTER(SolveSummary)]
     lib.sadvio_ba_get_deltas.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
     lib.sadvio_ba_get_ids.argtypes = [C.c_void_p, C.c_int32, _lp, _lp]
@@ -256,6 +264,21 @@ class Backend:
         if rc != SADVIO_OK:
             msg = self.lib.sadvio_ba_last_error(self.h)
             raise SadvioError(f"{what} failed: rc={rc}: {msg.decode() if msg else ''}")
+
+    # ---- one window spanning several GPUs (must precede set_windows) ----
+    def set_collective(self, rank: int, world: int, fn):
+        """fn(ctx, device_ptr, count, hip_stream) -> 0: caller-provided in-place sum all-reduce."""
+        self._coll = ALLREDUCE_FN(fn) if fn is not None else ALLREDUCE_FN()
+        self._check(self.lib.sadvio_ba_set_collective(self.h, rank, world, self._coll, None), "set_collective")
+
+    def rccl_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(RCCL_ID_BYTES)
+        self._check(self.lib.sadvio_ba_rccl_unique_id(buf), "rccl_unique_id")
+        return buf.raw
+
+    def comm_init_rccl(self, rank: int, world: int, unique_id: bytes):
+        assert len(unique_id) == RCCL_ID_BYTES
+        self._check(self.lib.sadvio_ba_comm_init_rccl(self.h, rank, world, C.c_char_p(unique_id)), "comm_init_rccl")
 
     def set_windows(self, windows: Sequence[FlatWindow]):
         self.windows = list(windows)

@@ -6,6 +6,7 @@
 // trips, and deltas are read back for the adapter to apply (AOptimizer.cpp:329-340).
 // There is no CPU fallback: without a gfx950 device every compute call fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -38,14 +39,17 @@ struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
     hipError_t alloc(size_t count) {
-        if (count <= n && p) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (count <= n && p && !view) return hipSuccess;
+        if (p && !view) (void)hipFree(p);
+        view = false;
         p = nullptr; n = 0;
         hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
         if (e == hipSuccess) n = count;
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    bool view = false;  // non-owning window into another buffer
+    void set_view(T* ptr, size_t count) { if (p && !view) (void)hipFree(p); p = ptr; n = count; view = true; }
+    void release() { if (p && !view) (void)hipFree(p); p = nullptr; n = 0; view = false; }
 };
 
 struct KernelClass {
@@ -61,6 +65,18 @@ struct HostWin {
 };
 
 }  // namespace
+
+// RCCL (all-reduce of the reduced system over xGMI), loaded on first use: single-GPU solves never touch it.
+struct NcclId { char internal[128]; };
+struct RcclLib {
+    void* lib = nullptr;
+    void* comm = nullptr;
+    int (*get_id)(NcclId*) = nullptr;
+    int (*init_rank)(void**, int, NcclId, int) = nullptr;
+    int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*destroy)(void*) = nullptr;
+    const char* (*err_string)(int) = nullptr;
+};
 
 struct DensePriorHost {
     int n_full = 0, n = 0, kf_keep = -1, kf_col = 0;
@@ -87,6 +103,13 @@ struct sadvio_ba_handle {
     int max_n_kf = 0, max_npose = 0, max_np = 0, n_big = 0;
     DevBuf<int> d_big_info;
     bool uploaded = false, solved = false;
+    // window sharded over several GPUs: collective hook (user callback or the built-in RCCL one)
+    int world = 1, rank = 0;
+    sadvio_allreduce_fn coll_fn = nullptr;
+    void* coll_ctx = nullptr;
+    RcclLib rccl;
+    long long red_total = 0;  // doubles in [S | gred | gfull | hdiag | rank_b], the buffer of the per-step all-reduce
+    DevBuf<double> d_rank_b, d_rank_s;
     // dense marginalisation priors (host copies, one per window) and the layout they induce
     std::vector<DensePriorHost> dprior_per_win;
     std::vector<unsigned char> h_lmk_const_user;  // as given by the caller
@@ -197,6 +220,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.state_stride = state_stride;
     P.final_out = h->d_final.p;
     P.big_info = h->d_big_info.p;
+    P.world = h->world; P.rank = h->rank; P.rank_b = h->d_rank_b.p; P.rank_s = h->d_rank_s.p;
     P.lmk_red = h->d_lmk_red.p; P.kept_obs = h->d_kept_obs.p; P.n_kept = h->n_kept;
     P.dp_data = h->d_dp_data.p; P.dp_ints = h->d_dp_ints.p;
     P.n_xp = (long long)h->d_xp.n; P.n_xv = (long long)h->d_xv.n; P.n_xl = (long long)h->d_xl.n;
@@ -296,14 +320,16 @@ int layout_reduced(sadvio_ba_handle* h) {
     h->np_tot = red_b; h->s_tot = s_b;
     h->n_kept = (int)kept.size() / 3;
     h->has_lmk_const = h->user_lmk_const || any_red;
-    HIP_TRY(h->d_S.alloc((size_t)std::max<long long>(s_b, 1)));
-    HIP_TRY(h->d_gred.alloc((size_t)std::max(red_b, 1))); HIP_TRY(h->d_gfull.alloc((size_t)std::max(red_b, 1)));
-    HIP_TRY(h->d_hdiag.alloc((size_t)std::max(red_b, 1))); HIP_TRY(h->d_delta.alloc((size_t)std::max(red_b, 1)));
-    HIP_TRY(h->d_s_pose.alloc((size_t)std::max(red_b, 1)));
-    HIP_TRY(hipMemsetAsync(h->d_S.p, 0, sizeof(double) * (size_t)std::max<long long>(s_b, 1), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_gred.p, 0, sizeof(double) * std::max(red_b, 1), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_gfull.p, 0, sizeof(double) * std::max(red_b, 1), h->stream));
-    HIP_TRY(hipMemsetAsync(h->d_hdiag.p, 0, sizeof(double) * std::max(red_b, 1), h->stream));
+    // one allocation [S | gred | gfull | hdiag | rank_b]: a window sharded over several GPUs all-reduces it whole
+    const long long nrb = (long long)n_windows * h->world * 4;
+    h->red_total = s_b + 3LL * red_b + nrb;
+    HIP_TRY(h->d_S.alloc((size_t)std::max<long long>(h->red_total, 1)));
+    h->d_gred.set_view(h->d_S.p + s_b, (size_t)red_b); h->d_gfull.set_view(h->d_gred.p + red_b, (size_t)red_b);
+    h->d_hdiag.set_view(h->d_gfull.p + red_b, (size_t)red_b); h->d_rank_b.set_view(h->d_hdiag.p + red_b, (size_t)nrb);
+    HIP_TRY(h->d_rank_s.alloc((size_t)nrb));
+    HIP_TRY(h->d_delta.alloc((size_t)std::max(red_b, 1))); HIP_TRY(h->d_s_pose.alloc((size_t)std::max(red_b, 1)));
+    HIP_TRY(hipMemsetAsync(h->d_S.p, 0, sizeof(double) * (size_t)std::max<long long>(h->red_total, 1), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_rank_s.p, 0, sizeof(double) * (size_t)nrb, h->stream));
     if (kept.empty()) kept.assign(3, 0);
     if (dp_ints.empty()) dp_ints.push_back(0);
     if (dp_data.empty()) dp_data.push_back(0.0);
@@ -408,6 +434,7 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); }
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->rccl.comm) (void)h->rccl.destroy(h->rccl.comm);
     if (h->h_final) (void)hipHostFree(h->h_final);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -416,7 +443,7 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     h->d_kf_fidx.release(); h->d_cam_K.release(); h->d_cam_T.release(); h->d_cam_isig.release();
     h->d_lmk_p.release(); h->d_xl.release(); h->d_s_lmk.release(); h->d_lmk_const.release();
     h->d_lmk_ob.release(); h->d_lmk_oe.release(); h->d_obs_kf.release(); h->d_obs_cam.release();
-    h->d_obs_meas.release(); h->d_priors.release(); h->d_S.release(); h->d_gred.release(); h->d_gfull.release();
+    h->d_obs_meas.release(); h->d_priors.release(); h->d_S.release(); h->d_rank_s.release(); h->d_gred.release(); h->d_gfull.release();
     h->d_hdiag.release(); h->d_delta.release(); h->d_s_pose.release(); h->d_states.release(); h->d_acc.release();
     h->d_probe.release(); h->d_tile_kf.release(); h->d_tile_row.release(); h->d_obs_slot.release(); h->d_ptab.release(); h->d_tacc.release(); h->d_dbg.release(); h->d_imus.release(); h->d_imu_scratch.release();
     delete h;
@@ -756,6 +783,7 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t w, int32_t n_full, in
     if (!h->uploaded) { h->err = "set_dense_prior before set_windows"; return SADVIO_E_STATE; }
     if (w < 0 || w >= (int)h->wins.size() || n_full < 0 || n < 0 || n_keep < 0) { h->err = "set_dense_prior: bad argument"; return SADVIO_E_INVALID_ARG; }
     HIP_TRY(hipSetDevice(h->device));
+    if (h->world > 1 && n_full > 0) { h->err = "set_dense_prior: not supported on a window sharded over several GPUs"; return SADVIO_E_INVALID_ARG; }
     const WinDev& d = h->wins[w].d;
     DensePriorHost D;
     if (n_full > 0) {
@@ -779,6 +807,65 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t w, int32_t n_full, in
     int rc = layout_reduced(h);
     if (rc != SADVIO_OK) return rc;
     return upload_priors(h);
+}
+
+int sadvio_ba_set_collective(sadvio_ba_handle* h, int32_t rank, int32_t world, sadvio_allreduce_fn fn, void* ctx) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) { h->err = "set_collective: bad rank / world / callback"; return SADVIO_E_INVALID_ARG; }
+    if (h->uploaded) { h->err = "set_collective must precede set_windows (the buffer layout depends on the world size)"; return SADVIO_E_STATE; }
+    h->rank = rank; h->world = world; h->coll_fn = fn; h->coll_ctx = ctx;
+    return SADVIO_OK;
+}
+
+namespace {
+std::string load_rccl(RcclLib& R) {
+    if (R.lib) return "";
+    R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!R.lib) R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!R.lib) return std::string("dlopen librccl: ") + dlerror();
+    R.get_id = (int (*)(NcclId*))dlsym(R.lib, "ncclGetUniqueId");
+    R.init_rank = (int (*)(void**, int, NcclId, int))dlsym(R.lib, "ncclCommInitRank");
+    R.all_reduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(R.lib, "ncclAllReduce");
+    R.destroy = (int (*)(void*))dlsym(R.lib, "ncclCommDestroy");
+    R.err_string = (const char* (*)(int))dlsym(R.lib, "ncclGetErrorString");
+    if (!R.get_id || !R.init_rank || !R.all_reduce || !R.destroy) return "missing RCCL symbol";
+    return "";
+}
+int rccl_allreduce(void* ctx, double* buf, int64_t count, void* stream) {
+    sadvio_ba_handle* h = (sadvio_ba_handle*)ctx;
+    // ncclDouble = 8, ncclSum = 0; in place
+    return h->rccl.all_reduce(buf, buf, (size_t)count, 8, 0, h->rccl.comm, (hipStream_t)stream);
+}
+}  // namespace
+
+int sadvio_ba_rccl_unique_id(void* id128) {
+    if (!id128) return SADVIO_E_INVALID_ARG;
+    RcclLib R;
+    const std::string e = load_rccl(R);
+    if (!e.empty()) return SADVIO_E_RCCL;
+    NcclId id;
+    if (R.get_id(&id) != 0) return SADVIO_E_RCCL;
+    memcpy(id128, &id, sizeof(id));
+    return SADVIO_OK;  // the library stays loaded (process lifetime)
+}
+
+int sadvio_ba_comm_init_rccl(sadvio_ba_handle* h, int32_t rank, int32_t world, const void* id128) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (!id128 || world < 1 || rank < 0 || rank >= world) { h->err = "comm_init_rccl: bad argument"; return SADVIO_E_INVALID_ARG; }
+    if (h->uploaded) { h->err = "comm_init_rccl must precede set_windows"; return SADVIO_E_STATE; }
+    HIP_TRY(hipSetDevice(h->device));
+    const std::string e = load_rccl(h->rccl);
+    if (!e.empty()) { h->err = "comm_init_rccl: " + e; return SADVIO_E_RCCL; }
+    NcclId id;
+    memcpy(&id, id128, sizeof(id));
+    const int rc = h->rccl.init_rank(&h->rccl.comm, world, id, rank);
+    if (rc != 0) {
+        h->err = std::string("comm_init_rccl: ncclCommInitRank: ") + (h->rccl.err_string ? h->rccl.err_string(rc) : "error");
+        h->rccl.comm = nullptr;
+        return SADVIO_E_RCCL;
+    }
+    h->rank = rank; h->world = world; h->coll_fn = rccl_allreduce; h->coll_ctx = h;
+    return SADVIO_OK;
 }
 
 int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvio_solve_summary* summaries) {
@@ -854,12 +941,30 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         }
         big_bw[w] = (d.n_red > 0 || d.dp_n_full > 0) ? d.Np : std::min(d.Np, (hb + 1) * d.dpf);
     }
+    if (h->coll_fn && h->world > 1 && h->n_big) {
+        // every rank must factor the all-reduced S with the same (largest) bandwidth: gather the local ones
+        std::vector<double> slots((size_t)n_win * h->world * 4, 0.0);
+        for (int w = 0; w < n_win; w++) slots[((size_t)w * h->world + h->rank) * 4] = (double)big_bw[w];
+        HIP_TRY(hipMemcpyAsync(h->d_rank_s.p, slots.data(), slots.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (h->coll_fn(h->coll_ctx, h->d_rank_s.p, (int64_t)slots.size(), (void*)h->stream) != 0) { h->err = "solve: all-reduce failed"; return SADVIO_E_RCCL; }
+        HIP_TRY(hipMemcpyAsync(slots.data(), h->d_rank_s.p, slots.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int w = 0; w < n_win; w++)
+            for (int r = 0; r < h->world; r++) big_bw[w] = std::max(big_bw[w], (int)slots[((size_t)w * h->world + r) * 4]);
+    }
+    bool coll_failed = false;
     auto enqueue = [&]() {
         { ScopedTimer t(h, "k_reset"); hipLaunchKernelGGL(k_reset, dim3(reset_blocks), dim3(256), 0, h->stream, P); }
         { ScopedTimer t(h, "k_init_tables"); hipLaunchKernelGGL(k_init_tables, dim3((h->n_kf_tot + 63) / 64), dim3(64), 0, h->stream, P, h->n_kf_tot); }
         for (int s = 0; s < slots; s++) {
             { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
             if (h->n_kept) { ScopedTimer t(h, "k_build_kept"); hipLaunchKernelGGL(kbk, dim3((h->n_kept + 127) / 128), dim3(128), 0, h->stream, P, s); }
+            if (h->coll_fn) {
+                // the window spans devices: gather the per-rank partial sums and all-reduce the reduced system
+                { ScopedTimer t(h, "k_rank_partials"); hipLaunchKernelGGL(k_rank_partials, dim3(n_win), dim3(64), 0, h->stream, P, s, 0); }
+                ScopedTimer t(h, "allreduce_reduced_system");
+                if (h->coll_fn(h->coll_ctx, h->d_S.p, (int64_t)h->red_total, (void*)h->stream) != 0) coll_failed = true;
+            }
             if (h->n_big < n_win) { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(k_solve<0>, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
             if (h->n_big) {
                 { ScopedTimer t(h, "k_solve_front"); hipLaunchKernelGGL(k_solve<1>, dim3(n_win), dim3(SOLVE_THREADS), 64, h->stream, P, s); }
@@ -895,10 +1000,15 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 }
             }
             { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
+            if (h->coll_fn) {
+                { ScopedTimer t(h, "k_rank_partials"); hipLaunchKernelGGL(k_rank_partials, dim3(n_win), dim3(64), 0, h->stream, P, s, 1); }
+                ScopedTimer t(h, "allreduce_step_partials");
+                if (h->coll_fn(h->coll_ctx, h->d_rank_s.p, (int64_t)n_win * h->world * 4, (void*)h->stream) != 0) coll_failed = true;
+            }
         }
         { ScopedTimer t(h, "k_final"); hipLaunchKernelGGL(k_final, dim3(n_win), dim3(64), 0, h->stream, P, slots); }
     };
-    if (h->cfg.use_graph && !h->cfg.profile_kernels) {
+    if (h->cfg.use_graph && !h->cfg.profile_kernels && !h->coll_fn) {
         // the whole <= 20-iteration solve is one graph launch; the key covers every kernel argument
         std::vector<int> lay;  // layout-dependent launch parameters of the out-of-LDS windows
         for (int w = 0; w < n_win; w++) { lay.push_back(h->wins[w].d.Np); lay.push_back(h->wins[w].d.ld); lay.push_back(big_bw[w]); }
@@ -926,6 +1036,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         enqueue();
     }
     HIP_TRY(hipGetLastError());
+    if (coll_failed) { h->err = "solve: the all-reduce of the reduced system failed"; return SADVIO_E_RCCL; }
     HIP_TRY(hipMemcpyAsync(h->h_final, h->d_final.p, sizeof(FinalRec) * (size_t)n_win, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->cfg.profile_kernels) collect_timers(h);

@@ -45,6 +45,11 @@ struct DevPtrs {
     TileAcc* tacc;    // [2][n_tiles] per-tile partials, double-buffered by slot parity (no atomics)
     FinalRec* final_out;  // [n_win]
     int* big_info;        // [n_win] potrf info of the windows solved out of LDS
+    // a window sharded over `world` GPUs (landmark partition): per-rank partial sums, exchanged with the reduced
+    // system by one all-reduce per phase; rank r writes slot r and zeroes the others (sum == gather)
+    int world, rank;
+    double* rank_b;       // [n_win][world][4] lin_cost, fixed_cost, gmax, -      (after k_build)
+    double* rank_s;       // [n_win][world][4] cand_cost, mcc, step_norm2, cand_norm2 (after k_backsub)
     const int* lmk_red;   // [n_lmk_tot] offset of a prior-kept landmark in its window's reduced vector, else -1 (may be null)
     const int* kept_obs;  // [n_kept][3] (device observation index, global landmark, window)
     int n_kept;
@@ -126,12 +131,17 @@ __device__ __forceinline__ double wave_max(double v) {
 
 
 // Sum the k_backsub partials of a window's tiles (slot parity `par`) into `a`: executed by one wave.
-__device__ __forceinline__ void wave_sum_backsub_partials(const DevPtrs& P, int par, int tile0, int ntiles, int ln,
+__device__ __forceinline__ void wave_sum_backsub_partials(const DevPtrs& P, int par, int w, int tile0, int ntiles, int ln,
                                                           double* out4) {
     double c = 0.0, m = 0.0, sn = 0.0, cn = 0.0;
-    const TileAcc* ta = P.tacc + (long long)par * P.n_tiles + tile0;
-    for (int t = ln; t < ntiles; t += 64) {
-        c += ta[t].cand_cost; m += ta[t].mcc; sn += ta[t].step_norm2; cn += ta[t].cand_norm2;
+    if (P.world > 1) {
+        const double* rs = P.rank_s + (long long)w * P.world * 4;
+        for (int r = ln; r < P.world; r += 64) { c += rs[4 * r]; m += rs[4 * r + 1]; sn += rs[4 * r + 2]; cn += rs[4 * r + 3]; }
+    } else {
+        const TileAcc* ta = P.tacc + (long long)par * P.n_tiles + tile0;
+        for (int t = ln; t < ntiles; t += 64) {
+            c += ta[t].cand_cost; m += ta[t].mcc; sn += ta[t].step_norm2; cn += ta[t].cand_norm2;
+        }
     }
     c = wave_sum(c); m = wave_sum(m); sn = wave_sum(sn); cn = wave_sum(cn);
     if (ln == 0) { out4[0] = c; out4[1] = m; out4[2] = sn; out4[3] = cn; }
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
     if (slot == 0) st = P.states[(long long)T.w * P.state_stride];
     else {
         // totals of the previous slot = window part (k_solve) + the tiles' k_backsub partials
-        if (wv == 0) wave_sum_backsub_partials(P, (slot - 1) & 1, T.win_tile0, T.win_ntiles, ln, s_part);
+        if (wv == 0) wave_sum_backsub_partials(P, (slot - 1) & 1, T.w, T.win_tile0, T.win_ntiles, ln, s_part);
         __syncthreads();
         IterAcc a = P.acc[(long long)T.w * P.state_stride + slot - 1];
         a.cand_cost += s_part[0]; a.mcc += s_part[1]; a.step_norm2 += s_part[2]; a.cand_norm2 += s_part[3];
@@ -1103,7 +1113,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     }
     // window totals of the linearisation: tiles' k_build partials + the pose-only factors evaluated here
     double gm = 0.0;
-    {
+    if (P.world > 1) {
+        const double* rb = P.rank_b + (long long)w * P.world * 4;
+        for (int r = tid; r < P.world; r += blockDim.x) { cost_part += rb[4 * r]; fixed_part += rb[4 * r + 1]; gm = fmax(gm, rb[4 * r + 2]); }
+    } else {
         const TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + W.tile_begin;
         for (int t = tid; t < W.tile_end - W.tile_begin; t += blockDim.x) {
             cost_part += ta[t].lin_cost; fixed_part += ta[t].fixed_cost; gm = fmax(gm, ta[t].gmax);
@@ -1487,6 +1500,25 @@ __global__ void k_build_kept(DevPtrs P, int slot) {
     }
 }
 
+// Sharded window: this rank's sums over its own tiles into its slot of rank_b (which = 0, after k_build) or
+// rank_s (which = 1, after k_backsub); the other ranks' slots are zeroed so that the all-reduce gathers.
+__global__ void k_rank_partials(DevPtrs P, int slot, int which) {
+    const int w = blockIdx.x, ln = threadIdx.x;
+    const WinDev W = P.win[w];
+    const TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + W.tile_begin;
+    const int nt = W.tile_end - W.tile_begin;
+    double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+    for (int t = ln; t < nt; t += 64) {
+        if (which == 0) { a += ta[t].lin_cost; b += ta[t].fixed_cost; c = fmax(c, ta[t].gmax); }
+        else { a += ta[t].cand_cost; b += ta[t].mcc; c += ta[t].step_norm2; d += ta[t].cand_norm2; }
+    }
+    a = wave_sum(a); b = wave_sum(b); c = which == 0 ? wave_max(c) : wave_sum(c); d = wave_sum(d);
+    double* dst = (which == 0 ? P.rank_b : P.rank_s) + (long long)w * P.world * 4;
+    for (int i = ln; i < P.world * 4; i += 64) dst[i] = 0.0;
+    __syncthreads();
+    if (ln == 0) { double* m = dst + 4 * P.rank; m[0] = a; m[1] = b; m[2] = c; m[3] = d; }
+}
+
 // Start of a solve: zero the delta buffers and every accumulator, write the initial LM state of each window
 // (one launch instead of eight memsets and a host-to-device copy).
 __global__ void k_reset(DevPtrs P) {
@@ -1523,7 +1555,7 @@ __global__ void k_final(DevPtrs P, int slots) {
     const int w = blockIdx.x, ln = threadIdx.x;
     __shared__ double s4[4];
     const WinDev W = P.win[w];
-    wave_sum_backsub_partials(P, (slots - 1) & 1, W.tile_begin, W.tile_end - W.tile_begin, ln, s4);
+    wave_sum_backsub_partials(P, (slots - 1) & 1, w, W.tile_begin, W.tile_end - W.tile_begin, ln, s4);
     __syncthreads();
     if (ln == 0) {
         IterAcc a = P.acc[(long long)w * P.state_stride + slots - 1];
