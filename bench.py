@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--windows", type=int, default=1, help="independent config-2 windows per GPU in the timed run")
     ap.add_argument("--batch", type=int, default=64, help="windows per GPU of the extra batched measurement (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-window", action="store_true",
+                    help="instead of independent windows: ONE config-4 window (100 KF x 50k landmarks) landmark-sharded "
+                         "over the ranks, reduced system all-reduced over RCCL per LM step (strong scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,6 +90,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
+
+    if args.shard_window:
+        return bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves)
 
     opts = capi.gn_options(GN_ITERS)
     # every rank owns its own windows (different seeds): weak scaling over independent sub-windows
@@ -197,6 +203,38 @@ def main():
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
         print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves):
+    """BASELINE.json config 4: one 100-KF / 50k-landmark window spanning the GPUs of the node."""
+    import torch
+    from sadvio_amd import capi, sharding, synthetic
+    opts = capi.gn_options(GN_ITERS)
+    w = synthetic.make_window(n_kf=100, n_lmk=50000, length=50.0, band=6, seed=4)  # same seed on every rank
+    be = capi.Backend(device=local_rank)
+    uid = [be.rccl_unique_id() if rank == 0 else None]
+    if dist is not None:
+        dist.broadcast_object_list(uid, src=0)
+    be.comm_init_rccl(rank, world, uid[0])
+    be.set_windows([sharding.shard_window(w, rank, world)])
+    dt = timed_solves(be, opts, args.steps, args.warmup)
+    s = be.solve(opts)[0]
+    be.close()
+    if rank == 0:
+        n_p = 6 * int((w.kf_const == 0).sum())
+        print(json.dumps({
+            "metric": "BA iterations/sec, ONE 100-KF/50k-landmark window sharded over the GPUs",
+            "value": round(s.iterations * args.steps / dt, 1), "unit": "BA iterations/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic 100 KF x 50000 landmarks x 250000 reprojection factors, GN 10 iters, "
+                                   "landmark-sharded, RCCL all-reduce of the reduced system per LM step",
+                       "parallelism": f"window sharded x{world}", "reduced_dim": n_p,
+                       "allreduce_bytes_per_step": 8 * (n_p * n_p + 3 * n_p + 4 * world) + 32 * world},
+            "final_cost": s.final_cost}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
