@@ -145,6 +145,10 @@ typedef struct sadvio_solve_options {
     double min_lm_diagonal;                /* 1e-6 */
     double max_lm_diagonal;                /* 1e32 */
     double min_relative_decrease;          /* 1e-3 */
+    /* ceres::HuberLoss(a) on the visual factors (0 = no loss function, as localMapBA / singleFrameOptimization):
+     * landmarkOptimization and singleFrameVIOptimization use a = sqrt(1.345) (AOptimizer.cpp:102,223). Applied
+     * the way Ceres' Corrector does for rho'' <= 0: residual and Jacobian scaled by sqrt(rho'), cost = rho / 2. */
+    double huber_a;                        /* 0 */
 } sadvio_solve_options;
 
 typedef struct sadvio_solve_summary {

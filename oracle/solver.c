@@ -32,6 +32,7 @@ typedef struct {
 typedef struct {
     const oracle_problem *P;
     const sadvio_flat_window *w;
+    double huber_a;   /* ceres::HuberLoss(a) on the visual factors, 0 = none */
     int dpf;          /* per-KF reduced block: 6 (VO) or 15 (VIO) */
     int Nr;           /* reduced dimension */
     int *kf_off;      /* [n_kf] offset in reduced vector or -1 */
@@ -96,6 +97,21 @@ static void eval_obs(const sadvio_flat_window *w, int l, int o, const double *xp
     if (valid) *valid = v;
 }
 
+/* ceres::HuberLoss(a)::Evaluate + Corrector (public Ceres 2.2 semantics: rho'' <= 0 => residual and Jacobian
+ * scaled by sqrt(rho'), cost = rho / 2). a = 0: no loss function. Returns rho(|r|^2). */
+static double apply_loss(double a, double *r, double *Jp, double *Jl) {
+    double s = r[0] * r[0] + r[1] * r[1];
+    if (!(a > 0.0) || s <= a * a) return s;
+    double rr = sqrt(s);
+    double rho1 = a / rr;
+    if (rho1 < 2.2250738585072014e-308) rho1 = 2.2250738585072014e-308;
+    double sc = sqrt(rho1);
+    r[0] *= sc; r[1] *= sc;
+    if (Jp) for (int i = 0; i < 12; i++) Jp[i] *= sc;
+    if (Jl) for (int i = 0; i < 6; i++) Jl[i] *= sc;
+    return 2.0 * a * rr - a * a;
+}
+
 /* cost only (candidate evaluation). Returns 1/2 sum r^2 over the reduced program. */
 static double eval_cost(ctx_t *c, const state_t *x) {
     const sadvio_flat_window *w = c->w;
@@ -106,7 +122,7 @@ static double eval_cost(ctx_t *c, const state_t *x) {
             if (c->kf_off[kf] < 0 && !c->lmk_active[l]) continue; /* constant block: fixed cost */
             double r[2];
             eval_obs(w, l, o, x->xp, x->xl, r, NULL, NULL, NULL);
-            cost += r[0] * r[0] + r[1] * r[1];
+            cost += apply_loss(c->huber_a, r, NULL, NULL);
         }
     }
     const oracle_problem *P = c->P;
@@ -202,7 +218,7 @@ static double eval_full(ctx_t *c, const state_t *x) {
                 continue;
             }
             eval_obs(w, l, o, x->xp, x->xl, r, Jp, Jl, NULL);
-            cost += r[0] * r[0] + r[1] * r[1];
+            cost += apply_loss(c->huber_a, r, Jp, Jl);
             if (c->kf_off[kf] < 0) memset(Jp, 0, 96);
             if (!c->lmk_active[l]) memset(Jl, 0, 48);
             for (int a = 0; a < 6; a++)
@@ -660,6 +676,7 @@ int oracle_solve(const oracle_problem *P, const sadvio_solve_options *o, sadvio_
     const sadvio_flat_window *w = P->win;
     ctx_t c;
     ctx_init(&c, P);
+    c.huber_a = o ? o->huber_a : 0.0;
     size_t np = (size_t)w->n_kf * 6, nl = (size_t)w->n_lmk * 3, nv = (size_t)w->n_kf * 3;
     double *xp = (double *)xcalloc(np, 8), *xl = (double *)xcalloc(nl, 8), *xv = (double *)xcalloc(nv, 8),
            *xba = (double *)xcalloc(nv, 8), *xbg = (double *)xcalloc(nv, 8);
@@ -794,6 +811,7 @@ int oracle_first_step(const oracle_problem *P, const sadvio_solve_options *o, do
     const sadvio_flat_window *w = P->win;
     ctx_t c;
     ctx_init(&c, P);
+    c.huber_a = o ? o->huber_a : 0.0;
     size_t np = (size_t)w->n_kf * 6, nl = (size_t)w->n_lmk * 3, nv = (size_t)w->n_kf * 3;
     double *z = (double *)xcalloc(np + nl + 3 * nv, 8);
     state_t X = {z, z + np, z + np + nl, z + np + nl + nv, z + np + nl + 2 * nv};

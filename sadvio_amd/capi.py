@@ -72,6 +72,7 @@ class SolveOptions(C.Structure):
         ("parameter_tolerance", C.c_double), ("initial_trust_region_radius", C.c_double),
         ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
         ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double), ("min_relative_decrease", C.c_double),
+        ("huber_a", C.c_double),
     ]
 
 
@@ -101,6 +102,24 @@ def reference_options() -> SolveOptions:
     o.min_lm_diagonal = 1e-6
     o.max_lm_diagonal = 1e32
     o.min_relative_decrease = 1e-3
+    return o
+
+
+def landmark_optimization_options() -> SolveOptions:
+    """AOptimizer::landmarkOptimization (AOptimizer.cpp:98-119): Huber(sqrt(1.345)), 10 iterations; the caller marks
+    every key-frame constant."""
+    o = reference_options()
+    o.max_num_iterations = 10
+    o.huber_a = 1.345 ** 0.5
+    return o
+
+
+def single_frame_options(vi: bool = False) -> SolveOptions:
+    """singleFrameOptimization (AOptimizer.cpp:152-174: no loss, 5 iterations) / singleFrameVIOptimization
+    (:219-257: Huber on the visual factors, 5 iterations; its 5 ms wall-clock cap is not reproduced)."""
+    o = reference_options()
+    o.max_num_iterations = 5
+    o.huber_a = 1.345 ** 0.5 if vi else 0.0
     return o
 
 

@@ -883,6 +883,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     o.max_radius = opts->max_trust_region_radius; o.min_radius = opts->min_trust_region_radius;
     o.min_lm_diagonal = opts->min_lm_diagonal; o.max_lm_diagonal = opts->max_lm_diagonal;
     o.min_relative_decrease = opts->min_relative_decrease;
+    o.huber_a = opts->huber_a;
+    if (!(o.huber_a >= 0.0)) { h->err = "solve: huber_a must be >= 0"; return SADVIO_E_INVALID_ARG; }
     const int n_win = (int)h->wins.size();
     // Slot s (s = 0 .. slots-1) is one step attempt; with max_num_iterations = 0 Ceres still evaluates
     // iteration 0, so at least one slot is always run and the final decision is taken by k_final.

@@ -24,6 +24,7 @@ struct SolveOpts {
     double function_tolerance, gradient_tolerance, parameter_tolerance;
     double initial_radius, max_radius, min_radius;
     double min_lm_diagonal, max_lm_diagonal, min_relative_decrease;
+    double huber_a;  // ceres::HuberLoss(a) on the visual factors, 0 = none
 };
 
 struct WinDev {

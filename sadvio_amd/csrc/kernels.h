@@ -201,8 +201,20 @@ __device__ __forceinline__ double across_groups8_sum(double v) {
     return xor32_sum(v);
 }
 
+// ceres::HuberLoss(a) + Corrector (rho'' <= 0 branch): returns rho(|r|^2) and the scale sqrt(rho') for r and J.
+__device__ __forceinline__ double huber_rho(double a, double s, double& scale) {
+    scale = 1.0;
+    if (a > 0.0 && s > a * a) {
+        const double rr = sqrt(s);
+        scale = sqrt(fmax(2.2250738585072014e-308, a / rr));
+        return 2.0 * a * rr - a * a;
+    }
+    return s;
+}
+
 struct ObsLin {
     double r[2], Jp[12], Jl[6];
+    double rho;   // loss-corrected cost of the block (= |r|^2 without a loss function)
     int row;      // row of the observing key-frame in the tile's LDS system, -1 if constant
     int slot;     // index into the tile's key-frame list
     bool valid;   // this lane owns an observation
@@ -227,6 +239,17 @@ __device__ __forceinline__ void lane_linearize(const DevPtrs& P, const double* p
         const double* m = P.obs_meas + 3 * (long long)o;
         double b[3] = {m[0], m[1], m[2]};
         angular_factor<true>(tab, ct + 4, pw, b, ct[16], L.r, L.Jp, L.Jl);
+    }
+    {
+        double sc;
+        L.rho = huber_rho(P.o.huber_a, L.r[0] * L.r[0] + L.r[1] * L.r[1], sc);
+        if (sc != 1.0) {
+            L.r[0] *= sc; L.r[1] *= sc;
+#pragma unroll
+            for (int i = 0; i < 12; i++) L.Jp[i] *= sc;
+#pragma unroll
+            for (int i = 0; i < 6; i++) L.Jl[i] *= sc;
+        }
     }
     if (L.row < 0) {
 #pragma unroll
@@ -386,7 +409,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
             const double pw[3] = {P.lmk_p[3 * (long long)gl] + xl[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1] + xl[3 * (long long)gl + 1],
                                   P.lmk_p[3 * (long long)gl + 2] + xl[3 * (long long)gl + 2]};
             lane_linearize<FACTOR>(P, poseTab, camTab, rowTab, T.cam_base, ob + q, pw, lfree, lcode != 1, L);
-            const double c = L.r[0] * L.r[0] + L.r[1] * L.r[1];
+            const double c = L.rho;
             if (L.counted) cost_part += c;
             else { fixed_part += c; L.r[0] = 0.0; L.r[1] = 0.0; }
         } else {
@@ -1163,8 +1186,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     }  // MODE != 2
     long long* ts = ((P.debug & 4096) && blockIdx.x == 0 && slot == 3) ? P.dbg_ts : nullptr;
     if (MODE == 0) {
-        bool ok;
-        if (W.n_red > 0) ok = chol_solve_packed<3>(A, Np, y, xs, LpT, linvTab, ts);  // Np = dpf n_free + 3 n_red
+        bool ok = true;  // Np == 0 (every key-frame constant, landmarkOptimization): nothing to factor
+        if (Np == 0) {}
+        else if (W.n_red > 0) ok = chol_solve_packed<3>(A, Np, y, xs, LpT, linvTab, ts);  // Np = dpf n_free + 3 n_red
         else if (W.dpf == 6) ok = chol_solve_packed<6>(A, Np, y, xs, LpT, linvTab, ts);
         else ok = chol_solve_packed<5>(A, Np, y, xs, LpT, linvTab, ts);
         if (!ok) {
@@ -1446,7 +1470,8 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
                 double bb[3] = {m[0], m[1], m[2]};
                 angular_factor<false>(ctab, ct + 4, pw, bb, ct[16], r, nullptr, nullptr);
             }
-            cc += r[0] * r[0] + r[1] * r[1];
+            double sc_unused;
+            cc += huber_rho(P.o.huber_a, r[0] * r[0] + r[1] * r[1], sc_unused);
         }
     }
     sn = wave_sum(sn); cn = wave_sum(cn); mcc = wave_sum(mcc); cc = wave_sum(cc);
@@ -1484,6 +1509,15 @@ __global__ void k_build_kept(DevPtrs P, int slot) {
         const double* m = P.obs_meas + 3 * (long long)o;
         double b[3] = {m[0], m[1], m[2]};
         angular_factor<true>(tab, P.cam_T + 12 * (long long)cam, pw, b, P.cam_isig[cam], r, Jp, Jl);
+    }
+    {
+        double sc;
+        (void)huber_rho(P.o.huber_a, r[0] * r[0] + r[1] * r[1], sc);
+        if (sc != 1.0) {
+            r[0] *= sc; r[1] *= sc;
+            for (int i = 0; i < 12; i++) Jp[i] *= sc;
+            for (int i = 0; i < 6; i++) Jl[i] *= sc;
+        }
     }
     const int fi = P.kf_fidx[kf];
     const int lr = P.lmk_red[gl];

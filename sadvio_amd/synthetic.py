@@ -88,6 +88,8 @@ def make_window(n_kf=20, n_lmk=8000, obs_per_lmk=5, seed=20250404, factor=FACTOR
     T_s_f = [inv4(_T_BS0), inv4(_T_BS1)]     # frame(body) -> sensor
     Ks = [_K0, _K1]
     n_views = 2 * n_kf
+    if obs_per_lmk > n_views:
+        raise ValueError(f"obs_per_lmk={obs_per_lmk} exceeds the {n_views} views of {n_kf} stereo key-frames")
     # world -> sensor transforms per (kf, cam), kf index here = oldest-first position
     T_s_w = np.stack([T_s_f[c] @ inv4(T_w_b[k]) for k in range(n_kf) for c in range(2)])  # [n_views,4,4]
     Kv = np.stack([Ks[c] for k in range(n_kf) for c in range(2)])

@@ -1,0 +1,61 @@
+"""GPU parity of the front-end solves (landmarkOptimization, singleFrameOptimization,
+singleFrameVIOptimization, AOptimizer.cpp:98-297): the window-BA kernels with masks + the Huber loss."""
+import numpy as np
+import pytest
+
+from frontend_helpers import landmark_optimization_window, single_frame_window, with_outliers
+from sadvio_amd import capi, synthetic
+from vio_helpers import make_vio_window
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-6
+LMK_TOL = 1e-5
+
+
+def compare(backend_cls, oracle_lib, w, opts, vio=False):
+    be = backend_cls(device=0)
+    try:
+        be.set_windows([w])
+        s = be.solve(opts)[0]
+        d = be.get_deltas(0)
+    finally:
+        be.close()
+    ref = oracle_lib.solve(w, opts)
+    rs = ref["summary"]
+    assert np.isclose(s.initial_cost, rs.initial_cost, rtol=1e-10, atol=1e-12)
+    assert np.isclose(s.final_cost, rs.final_cost, rtol=1e-9, atol=1e-12)
+    assert (s.iterations, s.termination, s.num_successful_steps) == (rs.iterations, rs.termination, rs.num_successful_steps)
+    assert np.abs(d["pose"] - ref["pose"]).max() <= POSE_TOL and np.abs(d["lmk"] - ref["lmk"]).max() <= LMK_TOL
+    if vio:
+        for k in ("dv", "dba", "dbg"):
+            assert np.abs(d[k] - ref[k]).max() <= POSE_TOL
+    return s, d
+
+
+@pytest.mark.parametrize("factor", [capi.FACTOR_PIXEL, capi.FACTOR_ANGULAR])
+def test_landmark_optimization(backend_cls, oracle_lib, factor):
+    w = landmark_optimization_window(factor=factor) if factor == capi.FACTOR_PIXEL else landmark_optimization_window(factor=factor, seed=54)
+    if factor == capi.FACTOR_ANGULAR:   # bearing outliers: rotate some bearings instead of shifting pixels
+        w.obs_meas /= np.linalg.norm(w.obs_meas, axis=1, keepdims=True)
+    s, d = compare(backend_cls, oracle_lib, w, capi.landmark_optimization_options())
+    assert np.abs(d["pose"]).max() == 0.0
+
+
+def test_single_frame_optimization(backend_cls, oracle_lib):
+    s, d = compare(backend_cls, oracle_lib, single_frame_window(), capi.single_frame_options())
+    assert np.abs(d["lmk"]).max() == 0.0
+
+
+def test_single_frame_vi_optimization(backend_cls, oracle_lib):
+    """Moving frame + last key-frame free, landmarks constant, one IMU factor, Huber on the visual factors."""
+    w = with_outliers(make_vio_window(n_kf=2, n_lmk=300, seed=55, fixed=0, obs_per_lmk=4), frac=0.05, seed=3)
+    w.lmk_const = np.ones(w.n_lmk, dtype=np.uint8)
+    w.pose_priors = []
+    compare(backend_cls, oracle_lib, w, capi.single_frame_options(vi=True), vio=True)
+
+
+def test_window_ba_with_huber_loss(backend_cls, oracle_lib):
+    w = with_outliers(synthetic.make_window(n_kf=8, n_lmk=800, seed=56), frac=0.08, seed=4)
+    o = capi.reference_options(); o.huber_a = 1.345 ** 0.5
+    compare(backend_cls, oracle_lib, w, o)
