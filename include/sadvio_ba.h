@@ -128,6 +128,29 @@ typedef struct sadvio_pose_prior {
     double inf_diag[6];
 } sadvio_pose_prior;
 
+/* One factor of the sparsified (NFR) marginalisation prior, added by the sparse branch of
+ * addMarginalizationResiduals (BundleAdjustmentCERESAnalytic.cpp:363-426). Every landmark such a factor touches
+ * stays in the reduced system (it is coupled to other variables than its own observations).
+ *   SADVIO_SPARSE_IMU_PRIOR      IMUPriordx               (residuals.hpp:649-695)  kf; T_prior, v/ba/bg_prior, sqrt_inf 15x15
+ *   SADVIO_SPARSE_POSE_TO_LMK    PoseToLandmarkFactor     (residuals.hpp:570-595)  kf, lmk0; delta, sqrt_inf 3x3
+ *   SADVIO_SPARSE_LMK_PRIOR      Landmark3DPrior          (residuals.hpp:512-522)  lmk0; delta = prior, sqrt_inf 3x3
+ *   SADVIO_SPARSE_LMK_TO_LMK     LandmarkToLandmarkFactor (residuals.hpp:537-556)  lmk0, lmk1; delta, sqrt_inf 3x3
+ * The linearisation-point values the reference copies into the factor (_T, _v, _ba, _bg, _lmk, _t_w_lmk) are the
+ * window's own kf_* / lmk_p entries. sqrt_inf is row-major; 3x3 matrices use the first 9 entries. */
+#define SADVIO_SPARSE_IMU_PRIOR 0
+#define SADVIO_SPARSE_POSE_TO_LMK 1
+#define SADVIO_SPARSE_LMK_PRIOR 2
+#define SADVIO_SPARSE_LMK_TO_LMK 3
+typedef struct sadvio_sparse_prior {
+    int32_t type;
+    int32_t kf;          /* key-frame index in the window, or -1 */
+    int32_t lmk0, lmk1;  /* landmark indices in the window, or -1 */
+    double T_prior[12];  /* IMUPriordx */
+    double v_prior[3], ba_prior[3], bg_prior[3];
+    double delta[3];
+    double sqrt_inf[225];
+} sadvio_sparse_prior;
+
 /* Solver options. sadvio_ba_default_options() fills the reference's hard-coded values
  * (AOptimizer.cpp:315-323) and, for everything the reference leaves unset, the defaults of
  * Ceres Solver 2.2.0 (docker/Dockerfile:50), the version the reference pins. */
@@ -209,6 +232,9 @@ int sadvio_ba_set_collective(sadvio_ba_handle *h, int32_t rank, int32_t world, s
 #define SADVIO_RCCL_ID_BYTES 128
 int sadvio_ba_rccl_unique_id(void *id128);
 int sadvio_ba_comm_init_rccl(sadvio_ba_handle *h, int32_t rank, int32_t world, const void *id128);
+
+/* Sparse (NFR) prior factors of window `w`; replaces the previous list (n = 0 clears it). */
+int sadvio_ba_set_sparse_priors(sadvio_ba_handle *h, int32_t w, int32_t n, const sadvio_sparse_prior *factors);
 
 /* Run the Levenberg-Marquardt solve of every uploaded window: replaces the body of
  * AOptimizer::localMapBA / localMapVIOptimization from ceres::Solve on (AOptimizer.cpp:326,388).

@@ -215,6 +215,82 @@ static inline void factor_pose_prior(const double *T0, const double *Tprior, con
     }
 }
 
+/* IMUPriordx::Evaluate (residuals.hpp:649-695). params: pose6 | dv3 | dba3 | dbg3. r = W e (15), e = [log(R Rp^-1);
+ * trans(T Tp^-1); v + dv - vp; ba + dba - bap; bg + dbg - bgp]. Jacobian 15x15 row-major [pose6|v3|ba3|bg3]: the pose
+ * block is W * [J6; 0] (:676), the v / ba / bg blocks are plain identities at rows 6 / 9 / 12 -- NOT multiplied by
+ * the sqrt information (:679-693, reproduced as coded). */
+static inline void factor_imu_prior(const double *T0, const double *v0, const double *ba0, const double *bg0,
+                                    const double *Tp, const double *vp, const double *bap, const double *bgp,
+                                    const double *W /*15x15*/, const double *params /*15*/, double *r /*15*/,
+                                    double *J /*15x15 or NULL*/) {
+    static const double ones[6] = {1, 1, 1, 1, 1, 1};
+    double e[15], J6[36];
+    factor_pose_prior(T0, Tp, ones, params, e, J ? J6 : NULL);
+    for (int a = 0; a < 3; a++) {
+        e[6 + a] = v0[a] + params[6 + a] - vp[a];
+        e[9 + a] = ba0[a] + params[9 + a] - bap[a];
+        e[12 + a] = bg0[a] + params[12 + a] - bgp[a];
+    }
+    for (int i = 0; i < 15; i++) {
+        double s = 0;
+        for (int k = 0; k < 15; k++) s += W[i * 15 + k] * e[k];
+        r[i] = s;
+    }
+    if (J) {
+        memset(J, 0, sizeof(double) * 225);
+        for (int i = 0; i < 15; i++)
+            for (int a = 0; a < 6; a++) {
+                double s = 0;
+                for (int k = 0; k < 6; k++) s += W[i * 15 + k] * J6[k * 6 + a];
+                J[i * 15 + a] = s;
+            }
+        for (int a = 0; a < 9; a++) J[(6 + a) * 15 + 6 + a] = 1.0;
+    }
+}
+
+/* PoseToLandmarkFactor::Evaluate (residuals.hpp:570-595): r = W (T_f_w (exp w, t) (p + dl) - delta). */
+static inline void factor_pose_to_landmark(const double *T0, const double *p0, const double *delta, const double *W /*3x3*/,
+                                           const double *dpose, const double *dl, double *r, double *Jp /*3x6*/,
+                                           double *Jl /*3x3*/) {
+    double dT[12], T[12], q[3], Tq[3], e[3];
+    se3_from_delta6(dpose, dT);
+    se3_mul(T0, dT, T);
+    for (int a = 0; a < 3; a++) q[a] = p0[a] + dl[a];
+    se3_apply(T, q, Tq);
+    for (int a = 0; a < 3; a++) e[a] = Tq[a] - delta[a];
+    m3_vec(W, e, r);
+    if (Jp) {
+        double Sq[9], Jr[9], A[9], B[9], C[9], WR0[9];
+        so3_skew(q, Sq);
+        so3_right_jacobian(dpose, Jr);
+        m3_mul(dT, Sq, A);      /* dR [q]x */
+        m3_mul(A, Jr, B);       /* dR [q]x Jr(w) */
+        m3_mul(W, T0, WR0);     /* W R0 */
+        m3_mul(WR0, B, C);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) { Jp[i * 6 + j] = -C[3 * i + j]; Jp[i * 6 + 3 + j] = WR0[3 * i + j]; }
+    }
+    if (Jl) m3_mul(W, T, Jl);   /* W (R0 dR) */
+}
+
+/* Landmark3DPrior (residuals.hpp:512-522): r = W (l + dl - prior), J = W. */
+static inline void factor_landmark_prior(const double *p0, const double *prior, const double *W, const double *dl,
+                                         double *r, double *J) {
+    double e[3] = {p0[0] + dl[0] - prior[0], p0[1] + dl[1] - prior[1], p0[2] + dl[2] - prior[2]};
+    m3_vec(W, e, r);
+    if (J) memcpy(J, W, 72);
+}
+
+/* LandmarkToLandmarkFactor (residuals.hpp:537-556): r = W ((l0 + d0) - (l1 + d1) - delta), J0 = W, J1 = -W. */
+static inline void factor_landmark_to_landmark(const double *p0, const double *p1, const double *delta, const double *W,
+                                               const double *d0, const double *d1, double *r, double *J0, double *J1) {
+    double e[3];
+    for (int a = 0; a < 3; a++) e[a] = (p0[a] + d0[a]) - (p1[a] + d1[a]) - delta[a];
+    m3_vec(W, e, r);
+    if (J0) memcpy(J0, W, 72);
+    if (J1) for (int a = 0; a < 9; a++) J1[a] = -W[a];
+}
+
 /* Cholesky-based sqrt information of a 9x9 covariance: W = L^T with L L^T = cov^-1
  * (residuals.hpp:151-154). Dense Gauss-Jordan inverse then LLT. Returns 0 on success. */
 static inline int imu_sqrt_information(const double *cov, double *W /*9x9 row-major, upper*/) {

@@ -11,7 +11,7 @@ import subprocess
 
 import numpy as np
 
-from sadvio_amd.capi import (FlatWindow, FlatWindowC, ImuFactorC, PosePriorC, SolveOptions, SolveSummary,
+from sadvio_amd.capi import (FlatWindow, FlatWindowC, ImuFactorC, PosePriorC, SolveOptions, SolveSummary, SparsePriorC,
                              fill_imu_factor, reference_options)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -25,7 +25,8 @@ class OracleProblem(C.Structure):
                 ("n_imu", C.c_int32), ("imus", C.POINTER(ImuFactorC)),
                 ("dp_n_full", C.c_int32), ("dp_n", C.c_int32), ("dp_J", _dp), ("dp_r0", _dp),
                 ("dp_kf_keep", C.c_int32), ("dp_kf_col", C.c_int32), ("dp_n_keep", C.c_int32),
-                ("dp_lmk_index", _ip), ("dp_lmk_col", _ip), ("n_threads", C.c_int32)]
+                ("dp_lmk_index", _ip), ("dp_lmk_col", _ip), ("n_threads", C.c_int32),
+                ("n_sparse", C.c_int32), ("sparse", C.POINTER(SparsePriorC))]
 
 
 class ImuState(C.Structure):
@@ -98,7 +99,9 @@ def make_problem(w: FlatWindow, dense_prior=None, n_threads=1):
     P.n_prior, P.priors = npri, pa
     P.n_imu, P.imus = nimu, ia
     P.n_threads = n_threads
-    keep = [wc, pa, ia]
+    sa, nsp = w.sparse_c()
+    P.n_sparse, P.sparse = nsp, sa
+    keep = [wc, pa, ia, sa]
     if dense_prior is not None:
         J = np.ascontiguousarray(dense_prior["J"], dtype=np.float64)
         r0 = np.ascontiguousarray(dense_prior["r0"], dtype=np.float64)
@@ -146,6 +149,18 @@ def first_step(w: FlatWindow, opts: SolveOptions = None):
     rc = lib().oracle_first_step(C.byref(P), C.byref(opts), _p(dp), _p(dl), _p(H), _p(g), N)
     assert rc == 0, rc
     return dp, dl, H, g
+
+
+def sparse_factor(w: FlatWindow, k: int, xp=None, xv=None, xba=None, xbg=None, xl=None):
+    """(r[rows], J[rows,15]) of sparse prior factor k of the window at the given deltas."""
+    wc = w.to_c()
+    sa, _ = w.sparse_c()
+    r = np.zeros(15); J = np.zeros((15, 15))
+    arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (xp, xv, xba, xbg, xl)]
+    f = lib().oracle_sparse_factor
+    f.argtypes = [C.c_void_p, C.c_void_p] + [_dp] * 7
+    rows = f(C.byref(wc), C.byref(sa[k]), *[_p(a) for a in arrs], _p(r), _p(J))
+    return r[:rows].copy(), J[:rows].copy()
 
 
 # ---- factor probes ----

@@ -37,6 +37,9 @@ typedef struct oracle_problem {
     const int32_t *dp_lmk_index;
     const int32_t *dp_lmk_col;
     int32_t n_threads; /* landmark-parallel evaluation threads (reference: num_threads = 4) */
+    /* sparse (NFR) prior factors, addMarginalizationResiduals sparse branch (…Analytic.cpp:363-426) */
+    int32_t n_sparse;
+    const sadvio_sparse_prior *sparse;
 } oracle_problem;
 
 /* Per-observation linearisation at the given deltas (NULL = zeros). Any output may be NULL. */
@@ -68,6 +71,10 @@ int oracle_factor_imu(const sadvio_imu_factor *f, const double *Ti0, const doubl
                       double *J /*9x24 row-major, blocks side by side*/);
 void oracle_factor_imu_bias(const sadvio_imu_factor *f, const double *bai, const double *bgi, const double *baj,
                             const double *bgj, const double *params /*12*/, double *r6, double *J /*6x12*/);
+
+/* Probe of one sparse prior factor (oracle/solver.c). */
+int oracle_sparse_factor(const sadvio_flat_window *w, const sadvio_sparse_prior *s, const double *xp, const double *xv,
+                         const double *xba, const double *xbg, const double *xl, double *r, double *J);
 
 /* SO3 probes */
 void oracle_so3_exp(const double *w, double *R);

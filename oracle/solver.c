@@ -97,6 +97,63 @@ static void eval_obs(const sadvio_flat_window *w, int l, int o, const double *xp
     if (valid) *valid = v;
 }
 
+/* One sparse prior factor as a small dense block over the reduced vector. Returns 0 when every parameter block
+ * of the factor is constant (the block then leaves the program: fixed cost). */
+static int sparse_small(const ctx_t *c, const state_t *x, const sadvio_sparse_prior *s, small_factor *f, int want_J) {
+    const sadvio_flat_window *w = c->w;
+    static const double z3[3] = {0, 0, 0};
+    memset(f->col, 0xff, sizeof(f->col));
+    if (s->type == SADVIO_SPARSE_IMU_PRIOR) {
+        int k = s->kf, po = c->kf_off[k];
+        if (po < 0) return 0;
+        double params[15], J[225];
+        for (int q = 0; q < 6; q++) params[q] = x->xp[6 * k + q];
+        for (int q = 0; q < 3; q++) { params[6 + q] = x->xv[3 * k + q]; params[9 + q] = x->xba[3 * k + q]; params[12 + q] = x->xbg[3 * k + q]; }
+        factor_imu_prior(w->kf_T_f_w + 12 * k, vec3_or_zero(w->kf_vel, k), vec3_or_zero(w->kf_ba, k), vec3_or_zero(w->kf_bg, k),
+                         s->T_prior, s->v_prior, s->ba_prior, s->bg_prior, s->sqrt_inf, params, f->r, want_J ? J : NULL);
+        f->rows = 15; f->ncols = 15;
+        for (int q = 0; q < 15; q++) f->col[q] = q < c->dpf ? po + q : -1;
+        if (want_J) for (int i = 0; i < 15; i++) for (int a = 0; a < 15; a++) f->J[i * 15 + a] = J[i * 15 + a];
+        return 1;
+    }
+    f->rows = 3;
+    if (s->type == SADVIO_SPARSE_POSE_TO_LMK) {
+        int k = s->kf, l = s->lmk0, po = c->kf_off[k], lo = c->lmk_red[l];
+        if (po < 0 && lo < 0) return 0;
+        double Jp[18], Jl[9];
+        factor_pose_to_landmark(w->kf_T_f_w + 12 * k, w->lmk_p + 3 * l, s->delta, s->sqrt_inf, x->xp + 6 * k, x->xl + 3 * l,
+                                f->r, want_J ? Jp : NULL, want_J ? Jl : NULL);
+        f->ncols = 9;
+        for (int q = 0; q < 6; q++) f->col[q] = po < 0 ? -1 : po + q;
+        for (int q = 0; q < 3; q++) f->col[6 + q] = lo < 0 ? -1 : lo + q;
+        if (want_J) for (int i = 0; i < 3; i++) {
+            for (int a = 0; a < 6; a++) f->J[i * 9 + a] = Jp[i * 6 + a];
+            for (int a = 0; a < 3; a++) f->J[i * 9 + 6 + a] = Jl[i * 3 + a];
+        }
+        return 1;
+    }
+    if (s->type == SADVIO_SPARSE_LMK_PRIOR) {
+        int l = s->lmk0, lo = c->lmk_red[l];
+        if (lo < 0) return 0;
+        factor_landmark_prior(w->lmk_p + 3 * l, s->delta, s->sqrt_inf, x->xl + 3 * l, f->r, want_J ? f->J : NULL);
+        f->ncols = 3;
+        for (int q = 0; q < 3; q++) f->col[q] = lo + q;
+        return 1;
+    }
+    {
+        int l0 = s->lmk0, l1 = s->lmk1, o0 = c->lmk_red[l0], o1 = c->lmk_red[l1];
+        if (o0 < 0 && o1 < 0) return 0;
+        double J0[9], J1[9];
+        factor_landmark_to_landmark(w->lmk_p + 3 * l0, w->lmk_p + 3 * l1, s->delta, s->sqrt_inf, x->xl + 3 * l0, x->xl + 3 * l1,
+                                    f->r, J0, J1);
+        (void)z3;
+        f->ncols = 6;
+        for (int q = 0; q < 3; q++) { f->col[q] = o0 < 0 ? -1 : o0 + q; f->col[3 + q] = o1 < 0 ? -1 : o1 + q; }
+        if (want_J) for (int i = 0; i < 3; i++) for (int a = 0; a < 3; a++) { f->J[i * 6 + a] = J0[i * 3 + a]; f->J[i * 6 + 3 + a] = J1[i * 3 + a]; }
+        return 1;
+    }
+}
+
 /* ceres::HuberLoss(a)::Evaluate + Corrector (public Ceres 2.2 semantics: rho'' <= 0 => residual and Jacobian
  * scaled by sqrt(rho'), cost = rho / 2). a = 0: no loss function. Returns rho(|r|^2). */
 static double apply_loss(double a, double *r, double *Jp, double *Jl) {
@@ -132,6 +189,11 @@ static double eval_cost(ctx_t *c, const state_t *x) {
         double r[6];
         factor_pose_prior(w->kf_T_f_w + 12 * pr->kf, pr->T_prior, pr->inf_diag, x->xp + 6 * pr->kf, r, NULL);
         for (int i = 0; i < 6; i++) cost += r[i] * r[i];
+    }
+    for (int k = 0; k < P->n_sparse; k++) {
+        small_factor sf;
+        if (!sparse_small(c, x, P->sparse + k, &sf, 0)) continue;
+        for (int q = 0; q < sf.rows; q++) cost += sf.r[q] * sf.r[q];
     }
     for (int k = 0; k < P->n_imu; k++) {
         const sadvio_imu_factor *f = P->imus + k;
@@ -270,6 +332,12 @@ static double eval_full(ctx_t *c, const state_t *x) {
         for (int q = 0; q < 6; q++) f.col[q] = po + q;
         factor_pose_prior(w->kf_T_f_w + 12 * pr->kf, pr->T_prior, pr->inf_diag, x->xp + 6 * pr->kf, f.r, f.J);
         for (int q = 0; q < 6; q++) cost += f.r[q] * f.r[q];
+        push_sf(c, &f);
+    }
+    for (int k = 0; k < P->n_sparse; k++) {
+        small_factor f;
+        if (!sparse_small(c, x, P->sparse + k, &f, 1)) continue;
+        for (int q = 0; q < f.rows; q++) cost += f.r[q] * f.r[q];
         push_sf(c, &f);
     }
     for (int k = 0; k < P->n_imu; k++) {
@@ -543,6 +611,18 @@ static void ctx_init(ctx_t *c, const oracle_problem *P) {
         c->lmk_red[l] = off; off += 3;
         c->lmk_active[l] = 1;
         c->lmk_elim[l] = 0;
+    }
+    for (int k = 0; k < P->n_sparse; k++) {
+        const sadvio_sparse_prior *s = P->sparse + k;
+        int ls[2] = {s->type == SADVIO_SPARSE_IMU_PRIOR ? -1 : s->lmk0, s->type == SADVIO_SPARSE_LMK_TO_LMK ? s->lmk1 : -1};
+        for (int q = 0; q < 2; q++) {
+            int l = ls[q];
+            if (l < 0 || c->lmk_red[l] >= 0) continue;
+            if (w->lmk_const && w->lmk_const[l]) continue;
+            c->lmk_red[l] = off; off += 3;
+            c->lmk_active[l] = 1;
+            c->lmk_elim[l] = 0;
+        }
     }
     c->Nr = off;
     int Nr = off;
@@ -930,3 +1010,45 @@ void oracle_factor_imu_bias(const sadvio_imu_factor *f, const double *bai, const
 void oracle_so3_exp(const double *w, double *R) { so3_exp(w, R); }
 void oracle_so3_log(const double *R, double *w) { so3_log(R, w); }
 void oracle_so3_right_jacobian(const double *w, double *J) { so3_right_jacobian(w, J); }
+
+/* Probe of one sparse prior factor at the given deltas (arrays indexed like the window; NULL = zeros):
+ * r[rows], J[rows x 15] in the factor's own column order (type 0: pose6 v3 ba3 bg3; 1: pose6 lmk3; 2: lmk3;
+ * 3: lmk0 3, lmk1 3). Returns the number of residual rows. */
+int oracle_sparse_factor(const sadvio_flat_window *w, const sadvio_sparse_prior *s, const double *xp, const double *xv,
+                         const double *xba, const double *xbg, const double *xl, double *r, double *J) {
+    static const double z[15] = {0};
+    if (s->type == SADVIO_SPARSE_IMU_PRIOR) {
+        int k = s->kf;
+        double params[15], Jf[225];
+        for (int q = 0; q < 6; q++) params[q] = xp ? xp[6 * k + q] : 0.0;
+        for (int q = 0; q < 3; q++) {
+            params[6 + q] = xv ? xv[3 * k + q] : 0.0; params[9 + q] = xba ? xba[3 * k + q] : 0.0; params[12 + q] = xbg ? xbg[3 * k + q] : 0.0;
+        }
+        factor_imu_prior(w->kf_T_f_w + 12 * k, vec3_or_zero(w->kf_vel, k), vec3_or_zero(w->kf_ba, k), vec3_or_zero(w->kf_bg, k),
+                         s->T_prior, s->v_prior, s->ba_prior, s->bg_prior, s->sqrt_inf, params, r, J ? Jf : NULL);
+        if (J) memcpy(J, Jf, sizeof(Jf));
+        return 15;
+    }
+    const double *d0 = xl ? xl + 3 * s->lmk0 : z;
+    if (J) memset(J, 0, sizeof(double) * 45);
+    if (s->type == SADVIO_SPARSE_POSE_TO_LMK) {
+        double Jp[18], Jl[9];
+        factor_pose_to_landmark(w->kf_T_f_w + 12 * s->kf, w->lmk_p + 3 * s->lmk0, s->delta, s->sqrt_inf,
+                                xp ? xp + 6 * s->kf : z, d0, r, J ? Jp : NULL, J ? Jl : NULL);
+        if (J) for (int i = 0; i < 3; i++) { for (int a = 0; a < 6; a++) J[i * 15 + a] = Jp[i * 6 + a]; for (int a = 0; a < 3; a++) J[i * 15 + 6 + a] = Jl[i * 3 + a]; }
+        return 3;
+    }
+    if (s->type == SADVIO_SPARSE_LMK_PRIOR) {
+        double Jl[9];
+        factor_landmark_prior(w->lmk_p + 3 * s->lmk0, s->delta, s->sqrt_inf, d0, r, J ? Jl : NULL);
+        if (J) for (int i = 0; i < 3; i++) for (int a = 0; a < 3; a++) J[i * 15 + a] = Jl[i * 3 + a];
+        return 3;
+    }
+    {
+        const double *d1 = xl ? xl + 3 * s->lmk1 : z;
+        double J0[9], J1[9];
+        factor_landmark_to_landmark(w->lmk_p + 3 * s->lmk0, w->lmk_p + 3 * s->lmk1, s->delta, s->sqrt_inf, d0, d1, r, J0, J1);
+        if (J) for (int i = 0; i < 3; i++) for (int a = 0; a < 3; a++) { J[i * 15 + a] = J0[i * 3 + a]; J[i * 15 + 3 + a] = J1[i * 3 + a]; }
+        return 3;
+    }
+}

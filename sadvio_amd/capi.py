@@ -64,6 +64,15 @@ class PosePriorC(C.Structure):
     _fields_ = [("kf", C.c_int32), ("pad", C.c_int32), ("T_prior", C.c_double * 12), ("inf_diag", C.c_double * 6)]
 
 
+class SparsePriorC(C.Structure):
+    _fields_ = [("type", C.c_int32), ("kf", C.c_int32), ("lmk0", C.c_int32), ("lmk1", C.c_int32),
+                ("T_prior", C.c_double * 12), ("v_prior", C.c_double * 3), ("ba_prior", C.c_double * 3),
+                ("bg_prior", C.c_double * 3), ("delta", C.c_double * 3), ("sqrt_inf", C.c_double * 225)]
+
+
+SPARSE_IMU_PRIOR, SPARSE_POSE_TO_LMK, SPARSE_LMK_PRIOR, SPARSE_LMK_TO_LMK = 0, 1, 2, 3
+
+
 class SolveOptions(C.Structure):
     _fields_ = [
         ("max_num_iterations", C.c_int32), ("jacobi_scaling", C.c_int32),
@@ -165,6 +174,7 @@ class FlatWindow:
     kf_bg: Optional[np.ndarray] = None
     pose_priors: List[tuple] = field(default_factory=list)   # (kf, T_prior[12], inf_diag[6])
     imu_factors: List[dict] = field(default_factory=list)    # dicts with the ImuFactorC fields
+    sparse_priors: List[dict] = field(default_factory=list)  # dicts with the SparsePriorC fields (NFR factors)
     dense_prior: Optional[dict] = None   # MarginalizationFactor: J [n_full,n], r0, kf_keep, kf_col, lmk_index, lmk_col
     truth: dict = field(default_factory=dict)                # generator ground truth (not uploaded)
     _keep: list = field(default_factory=list, repr=False)
@@ -198,6 +208,19 @@ class FlatWindow:
             setattr(w, name, p)
         self._keep = keep  # keep the contiguous copies alive as long as this object lives
         return w
+
+    def sparse_c(self):
+        arr = (SparsePriorC * max(1, len(self.sparse_priors)))()
+        for i, f in enumerate(self.sparse_priors):
+            a = arr[i]
+            a.type = int(f["type"]); a.kf = int(f.get("kf", -1)); a.lmk0 = int(f.get("lmk0", -1)); a.lmk1 = int(f.get("lmk1", -1))
+            for k, n in (("T_prior", 12), ("v_prior", 3), ("ba_prior", 3), ("bg_prior", 3), ("delta", 3)):
+                v = np.zeros(n) if f.get(k) is None else np.asarray(f[k], dtype=np.float64).ravel()
+                getattr(a, k)[:] = list(v)
+            W = np.asarray(f["sqrt_inf"], dtype=np.float64).ravel()
+            buf = np.zeros(225); buf[: len(W)] = W
+            a.sqrt_inf[:] = list(buf)
+        return arr, len(self.sparse_priors)
 
     def priors_c(self):
         arr = (PosePriorC * max(1, len(self.pose_priors)))()
@@ -248,6 +271,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.sadvio_ba_set_imu_factors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ImuFactorC)]
     lib.sadvio_ba_set_dense_prior.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.c_int32,
                                               C.c_int32, C.c_int32, _ip, _ip]
+    lib.sadvio_ba_set_sparse_priors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SparsePriorC)]
     lib.sadvio_ba_set_collective.argtypes = [C.c_void_p, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p]
     lib.sadvio_ba_rccl_unique_id.argtypes = [C.c_void_p]
     lib.sadvio_ba_comm_init_rccl.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
@@ -312,6 +336,9 @@ class Backend:
             if w.imu_factors:
                 ia, n = w.imus_c()
                 self._check(self.lib.sadvio_ba_set_imu_factors(self.h, i, n, ia), "set_imu_factors")
+            if w.sparse_priors:
+                sa, n = w.sparse_c()
+                self._check(self.lib.sadvio_ba_set_sparse_priors(self.h, i, n, sa), "set_sparse_priors")
             if w.dense_prior is not None:
                 self.set_dense_prior(i, w.dense_prior)
 

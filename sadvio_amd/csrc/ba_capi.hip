@@ -112,6 +112,9 @@ struct sadvio_ba_handle {
     DevBuf<double> d_rank_b, d_rank_s;
     // dense marginalisation priors (host copies, one per window) and the layout they induce
     std::vector<DensePriorHost> dprior_per_win;
+    std::vector<std::vector<sadvio_sparse_prior>> sparse_per_win;
+    DevBuf<SparseDev> d_sparse;
+    DevBuf<double> d_sp_scratch;
     std::vector<unsigned char> h_lmk_const_user;  // as given by the caller
     std::vector<int> h_lmk_ob, h_lmk_oe, h_kf_fidx;
     bool user_lmk_const = false;
@@ -223,6 +226,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.world = h->world; P.rank = h->rank; P.rank_b = h->d_rank_b.p; P.rank_s = h->d_rank_s.p;
     P.lmk_red = h->d_lmk_red.p; P.kept_obs = h->d_kept_obs.p; P.n_kept = h->n_kept;
     P.dp_data = h->d_dp_data.p; P.dp_ints = h->d_dp_ints.p;
+    P.sparse = h->d_sparse.p; P.sp_scratch = h->d_sp_scratch.p;
     P.n_xp = (long long)h->d_xp.n; P.n_xv = (long long)h->d_xv.n; P.n_xl = (long long)h->d_xl.n;
     P.n_win = (int)h->wins.size();
     { const char* e = getenv("SADVIO_DEBUG"); P.debug = e ? atoi(e) : 0; }
@@ -254,6 +258,7 @@ int layout_reduced(sadvio_ba_handle* h) {
     std::vector<int> lmk_red(std::max(h->n_lmk_tot, 1), -1);
     std::vector<unsigned char> lmk_const = h->h_lmk_const_user;
     std::vector<int> kept, dp_ints;
+    std::vector<SparseDev> sparse;
     std::vector<double> dp_data;
     bool any_red = false;
     struct Prep { long long off; int nf, n; };
@@ -303,6 +308,29 @@ int layout_reduced(sadvio_ba_handle* h) {
             dp_data.resize(dp_data.size() + (size_t)n + nf, 0.0);                 // dx, r scratch
             if (dp_data.size() & 1) dp_data.push_back(0.0);
         }
+        // landmarks touched by sparse prior factors stay in the reduced system as well
+        d.sp_begin = (int)sparse.size();
+        for (const sadvio_sparse_prior& s : h->sparse_per_win[w]) {
+            SparseDev o{};
+            o.type = s.type;
+            o.kf = s.kf >= 0 ? d.kf_base + s.kf : -1;
+            const int ls[2] = {s.type == SADVIO_SPARSE_IMU_PRIOR ? -1 : s.lmk0, s.type == SADVIO_SPARSE_LMK_TO_LMK ? s.lmk1 : -1};
+            int gls[2] = {-1, -1};
+            for (int q = 0; q < 2; q++) {
+                if (ls[q] < 0) continue;
+                const int gl = d.lmk_base + ls[q];
+                gls[q] = gl;
+                if (lmk_const[gl] == 1 || lmk_red[gl] >= 0) continue;
+                lmk_red[gl] = d.dpf * d.n_free_kf + 3 * n_red; n_red++;
+                lmk_const[gl] = 2; any_red = true;
+                for (int ob = h->h_lmk_ob[gl]; ob < h->h_lmk_oe[gl]; ob++) { kept.push_back(ob); kept.push_back(gl); kept.push_back(w); }
+            }
+            o.lmk0 = gls[0]; o.lmk1 = gls[1];
+            memcpy(o.T_prior, s.T_prior, sizeof(o.T_prior)); memcpy(o.v_prior, s.v_prior, 24); memcpy(o.ba_prior, s.ba_prior, 24);
+            memcpy(o.bg_prior, s.bg_prior, 24); memcpy(o.delta, s.delta, 24); memcpy(o.W, s.sqrt_inf, sizeof(o.W));
+            sparse.push_back(o);
+        }
+        d.sp_end = (int)sparse.size();
         d.kept_end = (int)kept.size() / 3;
         d.n_red = n_red;
         d.Np = d.n_free_kf * d.dpf + 3 * n_red;
@@ -330,6 +358,8 @@ int layout_reduced(sadvio_ba_handle* h) {
     HIP_TRY(h->d_delta.alloc((size_t)std::max(red_b, 1))); HIP_TRY(h->d_s_pose.alloc((size_t)std::max(red_b, 1)));
     HIP_TRY(hipMemsetAsync(h->d_S.p, 0, sizeof(double) * (size_t)std::max<long long>(h->red_total, 1), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_rank_s.p, 0, sizeof(double) * (size_t)nrb, h->stream));
+    HIP_TRY(h->d_sparse.alloc(std::max<size_t>(sparse.size(), 1))); HIP_TRY(h->d_sp_scratch.alloc(std::max<size_t>(sparse.size(), 1) * SPARSE_J));
+    if (!sparse.empty()) HIP_TRY(hipMemcpyAsync(h->d_sparse.p, sparse.data(), sparse.size() * sizeof(SparseDev), hipMemcpyHostToDevice, h->stream));
     if (kept.empty()) kept.assign(3, 0);
     if (dp_ints.empty()) dp_ints.push_back(0);
     if (dp_data.empty()) dp_data.push_back(0.0);
@@ -458,6 +488,7 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
     h->priors_per_win.assign(n_windows, {});
     h->imus_per_win.assign(n_windows, {});
     h->dprior_per_win.assign(n_windows, {});
+    h->sparse_per_win.assign(n_windows, {});
     h->tiles.clear();
     h->factor_type = wins[0].factor_type;
     int kf_b = 0, cam_b = 0, lmk_b = 0, obs_b = 0;
@@ -804,6 +835,29 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t w, int32_t n_full, in
         D.lmk_index.assign(lmk_index, lmk_index + n_keep); D.lmk_col.assign(lmk_col, lmk_col + n_keep);
     }
     h->dprior_per_win[w] = std::move(D);
+    int rc = layout_reduced(h);
+    if (rc != SADVIO_OK) return rc;
+    return upload_priors(h);
+}
+
+int sadvio_ba_set_sparse_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const sadvio_sparse_prior* f) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (!h->uploaded) { h->err = "set_sparse_priors before set_windows"; return SADVIO_E_STATE; }
+    if (w < 0 || w >= (int)h->wins.size() || n < 0 || (n > 0 && !f)) { h->err = "set_sparse_priors: bad argument"; return SADVIO_E_INVALID_ARG; }
+    if (h->world > 1 && n > 0) { h->err = "set_sparse_priors: not supported on a window sharded over several GPUs"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    const WinDev& d = h->wins[w].d;
+    for (int i = 0; i < n; i++) {
+        const sadvio_sparse_prior& s = f[i];
+        const bool need_kf = s.type == SADVIO_SPARSE_IMU_PRIOR || s.type == SADVIO_SPARSE_POSE_TO_LMK;
+        const bool need_l0 = s.type != SADVIO_SPARSE_IMU_PRIOR, need_l1 = s.type == SADVIO_SPARSE_LMK_TO_LMK;
+        if (s.type < 0 || s.type > 3 || (need_kf && (s.kf < 0 || s.kf >= d.n_kf)) || (need_l0 && (s.lmk0 < 0 || s.lmk0 >= d.n_lmk)) ||
+            (need_l1 && (s.lmk1 < 0 || s.lmk1 >= d.n_lmk || s.lmk1 == s.lmk0))) {
+            h->err = "set_sparse_priors: factor " + std::to_string(i) + " has a bad type or index";
+            return SADVIO_E_INVALID_ARG;
+        }
+    }
+    h->sparse_per_win[w].assign(f, f + n);
     int rc = layout_reduced(h);
     if (rc != SADVIO_OK) return rc;
     return upload_priors(h);

@@ -44,6 +44,7 @@ struct WinDev {
     int dp_int_off;   // into dp_ints: kind[n] index[n] col[n]
     long long dp_off; // into dp_data: J[nf*n] Jt[n*nf] H[n*n] r0[nf] dx[n] r[nf]
     int kept_begin, kept_end;  // slice of kept_obs (observations of the reduced landmarks)
+    int sp_begin, sp_end;      // slice of the sparse prior factors
 };
 
 // One workgroup of k_build / k_backsub: a run of consecutive landmarks of one window. Each landmark is
@@ -86,6 +87,13 @@ struct ImuDev {
     double W[81];
     double sa, sg;   // 1 / sqrt(dt * bacc_noise^2), 1 / sqrt(dt * bgyr_noise^2)
 };
+// One factor of the sparsified marginalisation prior (sadvio_sparse_prior with global indices).
+struct SparseDev {
+    int type, kf, lmk0, lmk1;
+    double T_prior[12], v_prior[3], ba_prior[3], bg_prior[3], delta[3];
+    double W[225];
+};
+constexpr int SPARSE_J = 15 * 15 + 15;  // J (rows x 15) + r kept in HBM scratch between phases
 constexpr int IMU_J = 9 * 24 + 9;  // whitened Jacobian + residual kept in HBM scratch between phases
 
 // Levenberg-Marquardt control state at the beginning of a slot (one step attempt).

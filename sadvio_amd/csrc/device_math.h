@@ -350,6 +350,67 @@ __device__ __forceinline__ void pose_prior_factor(const double* T0, const double
     }
 }
 
+// ---- sparse (NFR) prior factors, addMarginalizationResiduals sparse branch (…Analytic.cpp:363-426) ----
+// Output layout for all four: r[rows], J[rows][15] row-major (columns beyond the factor's width untouched).
+
+// IMUPriordx (residuals.hpp:649-695): params pose6 | dv3 | dba3 | dbg3; r = W e. The pose block of the Jacobian is
+// W [J6; 0]; the v / ba / bg blocks are plain identities at rows 6 / 9 / 12, NOT whitened (as coded, :679-693).
+__device__ __noinline__ void imu_prior_factor(const double* T0, const double* v0, const double* ba0, const double* bg0,
+                                              const double* Tp, const double* vp, const double* bap, const double* bgp,
+                                              const double* W, const double* prm, double* r, double* J) {
+    const double ones[6] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
+    double e[15], J6[36];
+    pose_prior_factor(T0, Tp, ones, prm, e, J ? J6 : nullptr);
+    for (int a = 0; a < 3; a++) {
+        e[6 + a] = v0[a] + prm[6 + a] - vp[a];
+        e[9 + a] = ba0[a] + prm[9 + a] - bap[a];
+        e[12 + a] = bg0[a] + prm[12 + a] - bgp[a];
+    }
+    for (int i = 0; i < 15; i++) {
+        double s = 0.0;
+        for (int k = 0; k < 15; k++) s += W[i * 15 + k] * e[k];
+        r[i] = s;
+    }
+    if (J) {
+        for (int i = 0; i < 15; i++) {
+            for (int a = 0; a < 6; a++) {
+                double s = 0.0;
+                for (int k = 0; k < 6; k++) s += W[i * 15 + k] * J6[k * 6 + a];
+                J[i * 15 + a] = s;
+            }
+            for (int a = 6; a < 15; a++) J[i * 15 + a] = (i == a) ? 1.0 : 0.0;
+        }
+    }
+}
+
+// PoseToLandmarkFactor (residuals.hpp:570-595): r = W (T_f_w (exp w, t) (p + dl) - delta); columns pose6 | lmk3.
+__device__ __forceinline__ void pose_to_landmark_factor(const double* T0, const double* q /*p + dl*/, const double* delta,
+                                                        const double* W, const double* d6, double* r, double* J) {
+    double dR[9], R[9], t[3], Rq[3], e[3];
+    so3_exp(d6, dR);
+    m3_mul(T0, dR, R);
+    m3_vec(T0, d6 + 3, t);
+    m3_vec(R, q, Rq);
+    for (int a = 0; a < 3; a++) e[a] = Rq[a] + t[a] + T0[9 + a] - delta[a];
+    m3_vec(W, e, r);
+    if (J) {
+        double Sq[9], Jr[9], A[9], B[9], C[9], WR0[9], WR[9];
+        so3_skew(q, Sq);
+        so3_right_jacobian(d6, Jr);
+        m3_mul(dR, Sq, A);
+        m3_mul(A, Jr, B);
+        m3_mul(W, T0, WR0);
+        m3_mul(WR0, B, C);
+        m3_mul(W, R, WR);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                J[i * 15 + j] = -C[3 * i + j];
+                J[i * 15 + 3 + j] = WR0[3 * i + j];
+                J[i * 15 + 6 + j] = WR[3 * i + j];
+            }
+    }
+}
+
 // IMUFactor (residuals.hpp:133-245). Blocks [pose_i 6 | pose_j 6 | dv_i 3 | dv_j 3 | dba_i 3 | dbg_i 3];
 // J (optional) is the whitened 9x24 Jacobian, row-major. Quirks kept as coded: the pose_i translation block
 // uses the UNperturbed R_i0 (:185), [6:9,0:3] of pose_i uses p_j instead of p_j - p_i (:181-184), pose_j's

@@ -54,6 +54,8 @@ struct DevPtrs {
     const int* kept_obs;  // [n_kept][3] (device observation index, global landmark, window)
     int n_kept;
     double* dp_data;      // dense priors, see WinDev::dp_off
+    const SparseDev* sparse;  // sparse prior factors
+    double* sp_scratch;       // [n_sparse][SPARSE_J]
     const int* dp_ints;
     long long n_xp, n_xv, n_xl;  // doubles in the (double-buffered) delta arrays, zeroed by k_reset
     int n_tiles;
@@ -928,6 +930,61 @@ __device__ __forceinline__ int imu_col(int a, int fi, int fj) {
     return fi < 0 ? -1 : fi * 15 + 12 + a - 21;
 }
 
+// ---- sparse prior factors inside the reduced solve --------------------------------------------------------
+// reduced-vector column of Jacobian column a (0..14) of sparse factor f; -1 = constant / unused
+__device__ __forceinline__ int sparse_col(const SparseDev& f, int a, int fi, int dpf, int lr0, int lr1) {
+    if (f.type == 0) return (fi >= 0 && a < dpf) ? fi * dpf + a : -1;
+    if (f.type == 1) return a < 6 ? (fi < 0 ? -1 : fi * dpf + a) : (a < 9 ? (lr0 < 0 ? -1 : lr0 + a - 6) : -1);
+    if (f.type == 2) return (a < 3 && lr0 >= 0) ? lr0 + a : -1;
+    return a < 3 ? (lr0 < 0 ? -1 : lr0 + a) : (a < 6 ? (lr1 < 0 ? -1 : lr1 + a - 3) : -1);
+}
+__device__ __forceinline__ int sparse_rows(const SparseDev& f) { return f.type == 0 ? 15 : 3; }
+
+// Evaluate sparse factor f at the state (xp, xv, xba, xbg, xl) + optional step `y` (reduced vector, may be null).
+// J (rows x 15) may be null. Returns false if every parameter block is constant.
+__device__ __noinline__ bool sparse_eval(const DevPtrs& P, const WinDev& W, const SparseDev& f, const double* xp, const double* xv,
+                                        const double* xba, const double* xbg, const double* xl, const double* y,
+                                        double* r, double* J) {
+    const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
+    const int lr0 = (f.lmk0 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk0] : -1;
+    const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
+    if (fi < 0 && lr0 < 0 && lr1 < 0) return false;
+    const int dpf = W.dpf;
+    if (f.type == 0) {
+        double prm[15];
+        const long long k = f.kf;
+        for (int q = 0; q < 6; q++) prm[q] = xp[6 * k + q] + ((y && fi >= 0) ? y[fi * dpf + q] : 0.0);
+        for (int q = 0; q < 3; q++) {
+            const bool st = y && fi >= 0 && dpf == 15;
+            prm[6 + q] = xv[3 * k + q] + (st ? y[fi * 15 + 6 + q] : 0.0);
+            prm[9 + q] = xba[3 * k + q] + (st ? y[fi * 15 + 9 + q] : 0.0);
+            prm[12 + q] = xbg[3 * k + q] + (st ? y[fi * 15 + 12 + q] : 0.0);
+        }
+        imu_prior_factor(P.kf_T0 + 12 * k, P.kf_vel + 3 * k, P.kf_ba + 3 * k, P.kf_bg + 3 * k, f.T_prior, f.v_prior,
+                         f.ba_prior, f.bg_prior, f.W, prm, r, J);
+        return true;
+    }
+    double q0[3], q1[3] = {0.0, 0.0, 0.0};
+    for (int a = 0; a < 3; a++) {
+        q0[a] = P.lmk_p[3 * (long long)f.lmk0 + a] + xl[3 * (long long)f.lmk0 + a] + ((y && lr0 >= 0) ? y[lr0 + a] : 0.0);
+        if (f.type == 3) q1[a] = P.lmk_p[3 * (long long)f.lmk1 + a] + xl[3 * (long long)f.lmk1 + a] + ((y && lr1 >= 0) ? y[lr1 + a] : 0.0);
+    }
+    if (f.type == 1) {
+        double d6[6];
+        for (int q = 0; q < 6; q++) d6[q] = xp[6 * (long long)f.kf + q] + ((y && fi >= 0) ? y[fi * dpf + q] : 0.0);
+        pose_to_landmark_factor(P.kf_T0 + 12 * (long long)f.kf, q0, f.delta, f.W, d6, r, J);
+        return true;
+    }
+    double e[3];
+    for (int a = 0; a < 3; a++) e[a] = q0[a] - q1[a] - f.delta[a];  // type 2: q1 = 0, delta = the prior position
+    m3_vec(f.W, e, r);
+    if (J) {
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) { J[i * 15 + j] = f.W[3 * i + j]; J[i * 15 + 3 + j] = -f.W[3 * i + j]; }
+    }
+    return true;
+}
+
 // ---- K6: reduced solve, one workgroup per window -------------------------------------------------
 // MODE 0: the whole step in LDS (Np <= MAX_LDS_NP): gather S, pose-only factors, damping, Cholesky, candidate.
 // Windows whose reduced system does not fit LDS (W.ld != 0, S kept as a full row-major lower triangle in HBM)
@@ -1089,6 +1146,50 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             if (ci >= 0) { atomic_add_f64(&A[aidx(ci, ci)], s2); atomic_add_f64(&hd[ci], s2); atomic_add_f64(&y[ci], -sgm * rb); atomic_add_f64(&gf[ci], -sgm * rb); }
             if (cj >= 0) { atomic_add_f64(&A[aidx(cj, cj)], s2); atomic_add_f64(&hd[cj], s2); atomic_add_f64(&y[cj], sgm * rb); atomic_add_f64(&gf[cj], sgm * rb); }
             if (ci >= 0 && cj >= 0) atomic_add_f64(&A[ci >= cj ? aidx(ci, cj) : aidx(cj, ci)], -s2);
+        }
+    }
+    // sparse (NFR) prior factors: one thread per factor evaluates r, J into an HBM scratch row, then the J^T J
+    // accumulation is spread over all threads (same scheme as the IMU factors)
+    const int n_sp = W.sp_end - W.sp_begin;
+    if (n_sp > 0) {
+        const double* xv = P.xv + (long long)cur * P.xv_stride;
+        const double* xba = P.xba + (long long)cur * P.xv_stride;
+        const double* xbg = P.xbg + (long long)cur * P.xv_stride;
+        const double* xl = P.xl + (long long)cur * P.xl_stride;
+        __syncthreads();
+        for (int k = tid; k < n_sp; k += blockDim.x) {
+            const SparseDev& f = P.sparse[W.sp_begin + k];
+            double* sc = P.sp_scratch + (long long)(W.sp_begin + k) * SPARSE_J;
+            double r[15];
+            const bool in_program = sparse_eval(P, W, f, xp, xv, xba, xbg, xl, nullptr, r, sc);
+            const int rows = sparse_rows(f);
+            double c = 0.0;
+            for (int q = 0; q < rows; q++) { sc[225 + q] = r[q]; c += r[q] * r[q]; }
+            if (in_program) cost_part += c; else fixed_part += c;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int it = tid; it < n_sp * 120; it += blockDim.x) {
+            const int k = it / 120;
+            int e = it - 120 * k, a = 0;
+            while (e >= a + 1) { e -= a + 1; a++; }
+            const int b = e;
+            const SparseDev& f = P.sparse[W.sp_begin + k];
+            const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
+            const int lr0 = (f.lmk0 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk0] : -1;
+            const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
+            const int ca = sparse_col(f, a, fi, W.dpf, lr0, lr1), cb = sparse_col(f, b, fi, W.dpf, lr0, lr1);
+            if (ca < 0 || cb < 0) continue;
+            const double* sc = P.sp_scratch + (long long)(W.sp_begin + k) * SPARSE_J;
+            const int rows = sparse_rows(f);
+            double h = 0.0;
+            for (int q = 0; q < rows; q++) h += sc[q * 15 + a] * sc[q * 15 + b];
+            atomic_add_f64(&A[ca >= cb ? aidx(ca, cb) : aidx(cb, ca)], h);
+            if (a == b) {
+                double g = 0.0;
+                for (int q = 0; q < rows; q++) g += sc[q * 15 + a] * sc[225 + q];
+                atomic_add_f64(&y[ca], g); atomic_add_f64(&gf[ca], g); atomic_add_f64(&hd[ca], h);
+            }
         }
     }
     // dense marginalisation prior (K4 / a9): r = r0 + J dx, J constant. H = J^T J and J^T were formed once
@@ -1321,6 +1422,38 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
                 const double rg = f.sg * (P.kf_bg[3 * (long long)j + q] + dbgj[q] - P.kf_bg[3 * (long long)i + q] - dbgi[q]);
                 cc += ra * ra + rg * rg;
             }
+        }
+    }
+    if (W.sp_end > W.sp_begin) {
+        const int n_sp = W.sp_end - W.sp_begin;
+        const double* xv = P.xv + (long long)cur * P.xv_stride;
+        const double* xba = P.xba + (long long)cur * P.xv_stride;
+        const double* xbg = P.xbg + (long long)cur * P.xv_stride;
+        const double* xl = P.xl + (long long)cur * P.xl_stride;
+        // model cost change, item = (factor, residual row)
+        for (int it = tid; it < n_sp * 15; it += blockDim.x) {
+            const int k = it / 15, q = it - 15 * k;
+            const SparseDev& f = P.sparse[W.sp_begin + k];
+            if (q >= sparse_rows(f)) continue;
+            const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
+            const int lr0 = (f.lmk0 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk0] : -1;
+            const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
+            if (fi < 0 && lr0 < 0 && lr1 < 0) continue;
+            const double* sc = P.sp_scratch + (long long)(W.sp_begin + k) * SPARSE_J;
+            double m = 0.0;
+            for (int a = 0; a < 15; a++) {
+                const int ca = sparse_col(f, a, fi, W.dpf, lr0, lr1);
+                if (ca >= 0) m += sc[q * 15 + a] * y[ca];
+            }
+            mcc += -m * (sc[225 + q] + 0.5 * m);
+        }
+        // candidate cost: one thread per factor at x + delta
+        for (int k = tid; k < n_sp; k += blockDim.x) {
+            double r[15];
+            const SparseDev& f = P.sparse[W.sp_begin + k];
+            if (!sparse_eval(P, W, f, xp, xv, xba, xbg, xl, y, r, nullptr)) continue;
+            const int rows = sparse_rows(f);
+            for (int q = 0; q < rows; q++) cc += r[q] * r[q];
         }
     }
     if (W.dp_n_full > 0) {
