@@ -216,6 +216,46 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle *h, int32_t w, int32_t n_full, in
                               const double *J, const double *r0, int32_t kf_keep, int32_t kf_col,
                               int32_t n_keep, const int32_t *lmk_index, const int32_t *lmk_col);
 
+/* ---- marginalisation of the oldest key-frame into a dense prior (K8) --------------------------------------
+ * Replaces BundleAdjustmentCERESAnalytic::marginalize / Marginalization::{computeInformationAndGradient,
+ * computeSchurComplement, rankReveallingDecomposition, computeJacobiansAndResiduals}
+ * (…Analytic.cpp:431-663, marginalization.cpp:145-265,318-342,516-530) on window `w` as uploaded by set_windows.
+ * The selection of marginalised / kept landmarks (preMarginalize, marginalization.cpp:23-143) is object-graph
+ * logic and stays with the caller, who passes the two index lists in the reference's order.
+ * Column layout (marginalization.cpp:38-113): marginalised = [frame0 pose 6 (+ v, ba, bg 9 if marg_has_imu) |
+ * lmk_marg 3 each]; kept = [frame1 15 states if kf_keep >= 0 | lmk_keep 3 each]. */
+typedef struct sadvio_marg_request {
+    int32_t kf_marg;                 /* frame0 */
+    int32_t kf_keep;                 /* frame1 when it carries an IMU (15 columns), else -1 */
+    int32_t marg_has_imu;            /* frame0->getIMU() */
+    int32_t n_marg;
+    const int32_t *lmk_marg;         /* window landmark indices, order of _lmk_to_marg */
+    int32_t n_keep;
+    const int32_t *lmk_keep;         /* order of _lmk_to_keep */
+    const sadvio_imu_factor *imu;    /* IMUFactor + IMUBiasFactor(frame0, frame1) or NULL (…Analytic.cpp:451-508) */
+    int32_t n_prior;                 /* PosePriordx blocks (<= 4), .kf = kf_marg or kf_keep (:605-617) */
+    const sadvio_pose_prior *priors;
+    int32_t last_n_full, last_n;     /* previous MarginalizationFactor (:574-603); last_n_full = 0 if none */
+    const double *last_J, *last_r0;
+    int32_t last_kf, last_kf_col;    /* window index of its kept frame (= kf_marg now) or -1, its first column */
+    int32_t last_n_keep;
+    const int32_t *last_lmk_index;   /* window landmark indices of its kept landmarks */
+    const int32_t *last_lmk_col;     /* their columns (-1 = skipped) */
+} sadvio_marg_request;
+
+typedef struct sadvio_marg_result {
+    int32_t m, n, n_full;
+    int32_t kf_col;   /* column of kf_keep's 15 states in the new prior, -1 if none */
+    int32_t sweeps_mm, sweeps_k;  /* Jacobi sweeps of the two eigen-decompositions */
+} sadvio_marg_result;
+
+/* Returns SADVIO_E_REFUSED when n < 4 (marginalization.cpp:215-216; the reference then clears its prior).
+ * Outputs (caller-allocated): lmk_col[n_keep] column of each kept landmark in the new prior; J[n*n] receives the
+ * n_full x n prior Jacobian (row-major, packed); r0[n] the n_full prior residuals. Feed them to
+ * sadvio_ba_set_dense_prior of the next window. */
+int sadvio_ba_marginalize(sadvio_ba_handle *h, int32_t w, const sadvio_marg_request *rq, sadvio_marg_result *res,
+                          int32_t *lmk_col, double *J, double *r0);
+
 /* ---- one window spanning several GPUs (no reference counterpart: the reference is one process) ----
  * The landmarks of a window (with all their observations) are partitioned over `world` processes, one GPU each;
  * key-frames, cameras, pose priors and IMU factors are replicated (a dense prior is not supported on a

@@ -163,6 +163,46 @@ def sparse_factor(w: FlatWindow, k: int, xp=None, xv=None, xba=None, xbg=None, x
     return r[:rows].copy(), J[:rows].copy()
 
 
+def marginalize(w: FlatWindow, kf_marg, lmk_marg, lmk_keep, kf_keep=-1, marg_has_imu=False, imu=None, priors=(), last=None):
+    """oracle_marginalize with the same calling convention as capi.Backend.marginalize. Returns None when refused."""
+    wc = w.to_c()
+    rq = MargRequest()
+    rq.win = C.pointer(wc)
+    mk = np.ascontiguousarray(lmk_marg, dtype=np.int32); kp = np.ascontiguousarray(lmk_keep, dtype=np.int32)
+    rq.kf_marg, rq.kf_keep, rq.marg_has_imu = kf_marg, kf_keep, int(bool(marg_has_imu))
+    rq.n_marg, rq.lmk_marg = len(mk), mk.ctypes.data_as(_ip)
+    rq.n_keep, rq.lmk_keep = len(kp), kp.ctypes.data_as(_ip)
+    keep = [wc, mk, kp]
+    if imu is not None:
+        ia = (ImuFactorC * 1)()
+        fill_imu_factor(ia[0], imu)
+        rq.imu = ia
+        keep.append(ia)
+    pa = (PosePriorC * max(1, len(priors)))()
+    for i, (kf, T, inf) in enumerate(priors):
+        pa[i].kf = int(kf); pa[i].T_prior[:] = list(np.asarray(T, dtype=np.float64).ravel()); pa[i].inf_diag[:] = list(np.asarray(inf, dtype=np.float64).ravel())
+    rq.n_prior, rq.priors = len(priors), pa
+    if last is not None:
+        J = np.ascontiguousarray(last["J"], dtype=np.float64); r0 = np.ascontiguousarray(last["r0"], dtype=np.float64)
+        li = np.ascontiguousarray(last.get("lmk_index", []), dtype=np.int32); lc = np.ascontiguousarray(last.get("lmk_col", []), dtype=np.int32)
+        rq.last_n_full, rq.last_n = J.shape
+        rq.last_J, rq.last_r0 = _p(J), _p(r0)
+        rq.last_kf, rq.last_kf_col = int(last.get("kf_keep", -1)), int(last.get("kf_col", 0))
+        rq.last_n_keep, rq.last_lmk_index, rq.last_lmk_col = len(li), li.ctypes.data_as(_ip), lc.ctypes.data_as(_ip)
+        keep += [J, r0, li, lc]
+    n = (15 if kf_keep >= 0 else 0) + 3 * len(kp)
+    res = MargResult()
+    lmk_col = np.zeros(max(len(kp), 1), dtype=np.int32); Jo = np.zeros(max(n * n, 1)); r0o = np.zeros(max(n, 1))
+    Ak = np.zeros((max(n, 1), max(n, 1))); bk = np.zeros(max(n, 1))
+    rc = lib().oracle_marginalize(C.byref(rq), C.byref(res), lmk_col.ctypes.data_as(_ip), _dp(), _dp(), _p(Ak), _p(bk), _dp(), _dp(),
+                                  _p(Jo), _p(r0o))
+    if rc != 0:
+        return None
+    nf = res.n_full
+    return {"J": Jo[: nf * n].reshape(nf, n).copy(), "r0": r0o[:nf].copy(), "kf_keep": kf_keep, "kf_col": res.kf_col,
+            "lmk_index": kp.copy(), "lmk_col": lmk_col[: len(kp)].copy(), "m": res.m, "n": res.n, "n_full": nf, "Ak": Ak, "bk": bk}
+
+
 # ---- factor probes ----
 def factor_pixel(T0, K, Tsf, p0, uv, sigma, dpose, dl):
     r = np.zeros(2); Jp = np.zeros((2, 6)); Jl = np.zeros((2, 3)); v = C.c_int32(0)

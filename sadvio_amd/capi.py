@@ -73,6 +73,19 @@ class SparsePriorC(C.Structure):
 SPARSE_IMU_PRIOR, SPARSE_POSE_TO_LMK, SPARSE_LMK_PRIOR, SPARSE_LMK_TO_LMK = 0, 1, 2, 3
 
 
+class MargRequestC(C.Structure):
+    _fields_ = [("kf_marg", C.c_int32), ("kf_keep", C.c_int32), ("marg_has_imu", C.c_int32), ("n_marg", C.c_int32),
+                ("lmk_marg", _ip), ("n_keep", C.c_int32), ("lmk_keep", _ip), ("imu", C.POINTER(ImuFactorC)),
+                ("n_prior", C.c_int32), ("priors", C.POINTER(PosePriorC)), ("last_n_full", C.c_int32), ("last_n", C.c_int32),
+                ("last_J", _dp), ("last_r0", _dp), ("last_kf", C.c_int32), ("last_kf_col", C.c_int32),
+                ("last_n_keep", C.c_int32), ("last_lmk_index", _ip), ("last_lmk_col", _ip)]
+
+
+class MargResultC(C.Structure):
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("n_full", C.c_int32), ("kf_col", C.c_int32),
+                ("sweeps_mm", C.c_int32), ("sweeps_k", C.c_int32)]
+
+
 class SolveOptions(C.Structure):
     _fields_ = [
         ("max_num_iterations", C.c_int32), ("jacobi_scaling", C.c_int32),
@@ -272,6 +285,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.sadvio_ba_set_dense_prior.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.c_int32,
                                               C.c_int32, C.c_int32, _ip, _ip]
     lib.sadvio_ba_set_sparse_priors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SparsePriorC)]
+    lib.sadvio_ba_marginalize.argtypes = [C.c_void_p, C.c_int32, C.POINTER(MargRequestC), C.POINTER(MargResultC), _ip, _dp, _dp]
     lib.sadvio_ba_set_collective.argtypes = [C.c_void_p, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p]
     lib.sadvio_ba_rccl_unique_id.argtypes = [C.c_void_p]
     lib.sadvio_ba_comm_init_rccl.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
@@ -354,6 +368,46 @@ class Backend:
         self._check(self.lib.sadvio_ba_set_dense_prior(self.h, w, J.shape[0], J.shape[1], _ptr(J), _ptr(r0),
                                                        int(dp.get("kf_keep", -1)), int(dp.get("kf_col", 0)), len(li),
                                                        li.ctypes.data_as(_ip), lc.ctypes.data_as(_ip)), "set_dense_prior")
+
+    def marginalize(self, w: int, kf_marg: int, lmk_marg, lmk_keep, kf_keep: int = -1, marg_has_imu: bool = False,
+                    imu: Optional[dict] = None, priors=(), last: Optional[dict] = None):
+        """Dense prior from marginalising key-frame kf_marg of window w (sadvio_ba_marginalize). `last` = previous
+        prior as a dense_prior dict. Returns None when refused (n < 4), else a dense_prior dict for the NEXT window
+        (landmark indices still refer to this window) + bookkeeping."""
+        rq = MargRequestC()
+        mk = np.ascontiguousarray(lmk_marg, dtype=np.int32); kp = np.ascontiguousarray(lmk_keep, dtype=np.int32)
+        rq.kf_marg, rq.kf_keep, rq.marg_has_imu = kf_marg, kf_keep, int(bool(marg_has_imu))
+        rq.n_marg, rq.lmk_marg = len(mk), mk.ctypes.data_as(_ip)
+        rq.n_keep, rq.lmk_keep = len(kp), kp.ctypes.data_as(_ip)
+        keep = [mk, kp]
+        if imu is not None:
+            ia = (ImuFactorC * 1)()
+            fill_imu_factor(ia[0], imu)
+            rq.imu = ia
+            keep.append(ia)
+        pa = (PosePriorC * max(1, len(priors)))()
+        for i, (kf, T, inf) in enumerate(priors):
+            pa[i].kf = int(kf); pa[i].T_prior[:] = list(np.asarray(T, dtype=np.float64).ravel()); pa[i].inf_diag[:] = list(np.asarray(inf, dtype=np.float64).ravel())
+        rq.n_prior, rq.priors = len(priors), pa
+        if last is not None:
+            J = np.ascontiguousarray(last["J"], dtype=np.float64); r0 = np.ascontiguousarray(last["r0"], dtype=np.float64)
+            li = np.ascontiguousarray(last.get("lmk_index", []), dtype=np.int32); lc = np.ascontiguousarray(last.get("lmk_col", []), dtype=np.int32)
+            rq.last_n_full, rq.last_n = J.shape
+            rq.last_J, rq.last_r0 = _ptr(J), _ptr(r0)
+            rq.last_kf, rq.last_kf_col = int(last.get("kf_keep", -1)), int(last.get("kf_col", 0))
+            rq.last_n_keep, rq.last_lmk_index, rq.last_lmk_col = len(li), li.ctypes.data_as(_ip), lc.ctypes.data_as(_ip)
+            keep += [J, r0, li, lc]
+        n = (15 if kf_keep >= 0 else 0) + 3 * len(kp)
+        res = MargResultC()
+        lmk_col = np.zeros(max(len(kp), 1), dtype=np.int32); Jo = np.zeros(max(n * n, 1)); r0o = np.zeros(max(n, 1))
+        rc = self.lib.sadvio_ba_marginalize(self.h, w, C.byref(rq), C.byref(res), lmk_col.ctypes.data_as(_ip), _ptr(Jo), _ptr(r0o))
+        if rc == E_REFUSED:
+            return None
+        self._check(rc, "marginalize")
+        nf = res.n_full
+        return {"J": Jo[: nf * n].reshape(nf, n).copy(), "r0": r0o[:nf].copy(), "kf_keep": kf_keep, "kf_col": res.kf_col,
+                "lmk_index": kp.copy(), "lmk_col": lmk_col[: len(kp)].copy(), "m": res.m, "n": res.n, "n_full": nf,
+                "sweeps": (res.sweeps_mm, res.sweeps_k)}
 
     def solve(self, opts: Optional[SolveOptions] = None) -> List[SolveSummary]:
         opts = opts or reference_options()

@@ -20,6 +20,7 @@
 #include "../../include/sadvio_ba.h"
 #include "kernels.h"
 #include "dense_chol.h"
+#include "marg_kernels.h"
 
 using namespace sadvio;
 
@@ -50,6 +51,10 @@ struct DevBuf {
     bool view = false;  // non-owning window into another buffer
     void set_view(T* ptr, size_t count) { if (p && !view) (void)hipFree(p); p = ptr; n = count; view = true; }
     void release() { if (p && !view) (void)hipFree(p); p = nullptr; n = 0; view = false; }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
 };
 
 struct KernelClass {
@@ -116,7 +121,7 @@ struct sadvio_ba_handle {
     DevBuf<SparseDev> d_sparse;
     DevBuf<double> d_sp_scratch;
     std::vector<unsigned char> h_lmk_const_user;  // as given by the caller
-    std::vector<int> h_lmk_ob, h_lmk_oe, h_kf_fidx;
+    std::vector<int> h_lmk_ob, h_lmk_oe, h_kf_fidx, h_obs_kf;
     bool user_lmk_const = false;
     int n_kept = 0;
     DevBuf<int> d_lmk_red, d_kept_obs, d_dp_ints;
@@ -710,7 +715,7 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
     UP(h->d_obs_cam, obs_cam); UP(h->d_obs_meas, obs_meas); UP(h->d_tile_kf, tile_kf); UP(h->d_tile_row, tile_row); UP(h->d_obs_slot, obs_slot);
 #undef UP
     h->h_lmk_const_user = lmk_const; h->user_lmk_const = h->has_lmk_const;
-    h->h_lmk_ob = lmk_ob; h->h_lmk_oe = lmk_oe; h->h_kf_fidx = kf_fidx;
+    h->h_lmk_ob = lmk_ob; h->h_lmk_oe = lmk_oe; h->h_kf_fidx = kf_fidx; h->h_obs_kf = obs_kf;
     int rc = layout_reduced(h);
     if (rc != SADVIO_OK) return rc;
     rc = upload_priors(h);  // also uploads the window descriptors and synchronises (host vectors go out of scope)
@@ -861,6 +866,218 @@ int sadvio_ba_set_sparse_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const
     int rc = layout_reduced(h);
     if (rc != SADVIO_OK) return rc;
     return upload_priors(h);
+}
+
+namespace {
+// one-sided Jacobi eigen-decomposition of the symmetric n x n block at A (leading dimension lda): G, V (n x n each)
+// and ev (n) are device buffers; returns the number of sweeps (negative = HIP error)
+int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int lower_only, double* G, double* V, double* ev, int* flag) {
+    const long long nn = (long long)n * n;
+    hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, A, lda, n, G, V, lower_only);
+    const int npad = n + (n & 1);
+    int sweeps = 0;
+    for (; sweeps < 40 && npad >= 2; sweeps++) {
+        if (hipMemsetAsync(flag, 0, sizeof(int), h->stream) != hipSuccess) return -1;
+        for (int s = 0; s < npad - 1; s++)
+            hipLaunchKernelGGL(k_jacobi_step, dim3(npad / 2), dim3(JAC_THREADS), 0, h->stream, G, V, n, npad, s, 1e-14, flag);
+        int f = 0;
+        if (hipMemcpyAsync(&f, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+        if (!f) { sweeps++; break; }
+    }
+    hipLaunchKernelGGL(k_jacobi_eigenvalues, dim3(n), dim3(JAC_THREADS), 0, h->stream, G, V, n, ev);
+    return sweeps;
+}
+
+// eigenvalue cut of the pseudo-inverse / rank-revealing decomposition: the reference's absolute 1e-12
+// (marginalization.hpp:56) with the rounding-noise floor n eps lambda_max (see oracle/marg.c)
+double marg_cut(const std::vector<double>& ev) {
+    double mx = 0.0;
+    for (double v : ev) mx = std::max(mx, std::fabs(v));
+    return std::max(1e-12, (double)ev.size() * 2.220446049250313e-16 * mx);
+}
+
+bool make_imu_dev(const sadvio_imu_factor& f, int kf_base, ImuDev& o) {
+    o.kf_i = kf_base + f.kf_i; o.kf_j = kf_base + f.kf_j; o.dt = f.dt;
+    memcpy(o.dR, f.delta_R, sizeof(o.dR)); memcpy(o.dv, f.delta_v, sizeof(o.dv)); memcpy(o.dp, f.delta_p, sizeof(o.dp));
+    memcpy(o.J_dR_bg, f.J_dR_bg, 72); memcpy(o.J_dv_ba, f.J_dv_ba, 72); memcpy(o.J_dv_bg, f.J_dv_bg, 72);
+    memcpy(o.J_dp_ba, f.J_dp_ba, 72); memcpy(o.J_dp_bg, f.J_dp_bg, 72);
+    if (!imu_sqrt_information(f.cov, o.W)) return false;
+    o.sa = 1.0 / sqrt(f.dt * f.bacc_noise * f.bacc_noise);
+    o.sg = 1.0 / sqrt(f.dt * f.bgyr_noise * f.bgyr_noise);
+    return true;
+}
+}  // namespace
+
+int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_request* rq, sadvio_marg_result* res, int32_t* lmk_col_out,
+                          double* J_out, double* r0_out) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (!h->uploaded) { h->err = "marginalize before set_windows"; return SADVIO_E_STATE; }
+    if (!rq || w < 0 || w >= (int)h->wins.size()) { h->err = "marginalize: bad argument"; return SADVIO_E_INVALID_ARG; }
+    const WinDev& d = h->wins[w].d;
+    if (rq->kf_marg < 0 || rq->kf_marg >= d.n_kf || rq->kf_keep >= d.n_kf || rq->n_marg < 0 || rq->n_keep < 0 || rq->n_prior < 0 ||
+        rq->n_prior > 4 || (rq->n_marg > 0 && !rq->lmk_marg) || (rq->n_keep > 0 && !rq->lmk_keep) || (rq->n_prior > 0 && !rq->priors)) {
+        h->err = "marginalize: request out of range"; return SADVIO_E_INVALID_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    // index layout, marginalization.cpp:38-113
+    const int m = 6 + (rq->marg_has_imu ? 9 : 0) + 3 * rq->n_marg;
+    const int n = (rq->kf_keep >= 0 ? 15 : 0) + 3 * rq->n_keep;
+    const int N = m + n;
+    std::vector<int> lcol(std::max(d.n_lmk, 1), -1);
+    int idx = 6 + (rq->marg_has_imu ? 9 : 0);
+    for (int k = 0; k < rq->n_marg; k++) {
+        if (rq->lmk_marg[k] < 0 || rq->lmk_marg[k] >= d.n_lmk) { h->err = "marginalize: landmark index out of range"; return SADVIO_E_INVALID_ARG; }
+        lcol[rq->lmk_marg[k]] = idx; idx += 3;
+    }
+    int kf_keep_col = -1;
+    if (rq->kf_keep >= 0) { kf_keep_col = idx; idx += 15; }
+    for (int k = 0; k < rq->n_keep; k++) {
+        if (rq->lmk_keep[k] < 0 || rq->lmk_keep[k] >= d.n_lmk) { h->err = "marginalize: landmark index out of range"; return SADVIO_E_INVALID_ARG; }
+        lcol[rq->lmk_keep[k]] = idx; idx += 3;
+    }
+    if (res) { res->m = m; res->n = n; res->n_full = 0; res->kf_col = kf_keep_col >= 0 ? kf_keep_col - m : -1; res->sweeps_mm = res->sweeps_k = 0; }
+    if (lmk_col_out) for (int k = 0; k < rq->n_keep; k++) lmk_col_out[k] = lcol[rq->lmk_keep[k]] - m;
+    if (n < 4) { h->err = "marginalize: fewer than 4 kept columns, refused (marginalization.cpp:215-216)"; return SADVIO_E_REFUSED; }
+
+    SolveOpts so{};
+    DevPtrs P = make_ptrs(h, so, 2);
+    DevBuf<double> dA, db, G, V, ev, Vs, Ainv, T, Ak, bk, dJ, dr0, dlastJ, dlastr;
+    DevBuf<int> ditems, dflag, dsel, dlastcol;
+    DevBuf<MargSmall> dsmall;
+    HIP_TRY(dA.alloc((size_t)N * N)); HIP_TRY(db.alloc(N)); HIP_TRY(dflag.alloc(1));
+    HIP_TRY(hipMemsetAsync(dA.p, 0, sizeof(double) * (size_t)N * N, h->stream));
+    HIP_TRY(hipMemsetAsync(db.p, 0, sizeof(double) * N, h->stream));
+    // reprojection factors of kept then marginalised landmarks seen from frame0
+    {
+        std::vector<int> it2, itl;
+        for (int pass = 0; pass < 2; pass++) {
+            const int cnt = pass == 0 ? rq->n_keep : rq->n_marg;
+            const int32_t* list = pass == 0 ? rq->lmk_keep : rq->lmk_marg;
+            for (int k = 0; k < cnt; k++) {
+                const int gl = d.lmk_base + list[k];
+                for (int o = h->h_lmk_ob[gl]; o < h->h_lmk_oe[gl]; o++)
+                    if (h->h_obs_kf[o] == d.kf_base + rq->kf_marg) { it2.push_back(o); it2.push_back(lcol[list[k]]); itl.push_back(gl); }
+            }
+        }
+        const int n_items = (int)itl.size();
+        if (n_items > 0) {
+            it2.insert(it2.end(), itl.begin(), itl.end());
+            HIP_TRY(ditems.alloc(it2.size()));
+            HIP_TRY(hipMemcpyAsync(ditems.p, it2.data(), it2.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            auto ko = h->factor_type == SADVIO_FACTOR_PIXEL ? k_marg_obs<0> : k_marg_obs<1>;
+            hipLaunchKernelGGL(ko, dim3((n_items + 127) / 128), dim3(128), 0, h->stream, P, ditems.p, n_items, dA.p, db.p, N);
+            HIP_TRY(hipStreamSynchronize(h->stream));  // it2 goes out of scope
+        }
+    }
+    // IMU factor + bias factor, pose priors
+    {
+        MargSmall S{};
+        if (rq->imu && rq->kf_keep >= 0 && rq->marg_has_imu) {
+            sadvio_imu_factor f = *rq->imu;
+            f.kf_i = rq->kf_marg; f.kf_j = rq->kf_keep;
+            if (!make_imu_dev(f, d.kf_base, S.imu)) { h->err = "marginalize: IMU covariance is not positive definite"; return SADVIO_E_INVALID_ARG; }
+            S.has_imu = 1; S.kf_i = d.kf_base + rq->kf_marg; S.kf_j = d.kf_base + rq->kf_keep; S.kf_keep_col = kf_keep_col;
+        }
+        for (int k = 0; k < rq->n_prior; k++) {
+            const sadvio_pose_prior& pr = rq->priors[k];
+            const int base = pr.kf == rq->kf_marg ? 0 : (pr.kf == rq->kf_keep ? kf_keep_col : -1);
+            if (base < 0) continue;
+            const int q = S.n_prior++;
+            S.prior_kf[q] = d.kf_base + pr.kf; S.prior_base[q] = base;
+            memcpy(S.prior_T[q], pr.T_prior, sizeof(S.prior_T[q])); memcpy(S.prior_inf[q], pr.inf_diag, sizeof(S.prior_inf[q]));
+        }
+        if (S.has_imu || S.n_prior) {
+            HIP_TRY(dsmall.alloc(1));
+            HIP_TRY(hipMemcpyAsync(dsmall.p, &S, sizeof(S), hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_marg_small, dim3(1), dim3(64), 0, h->stream, P, dsmall.p, dA.p, db.p, N);
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
+    }
+    // previous prior at zero deltas
+    if (rq->last_n_full > 0) {
+        const int nl = rq->last_n, nf = rq->last_n_full;
+        if (!rq->last_J || !rq->last_r0 || nl <= 0) { h->err = "marginalize: previous prior arrays missing"; return SADVIO_E_INVALID_ARG; }
+        std::vector<int> col(nl, -1);
+        if (rq->last_kf >= 0) {
+            const int base = (rq->last_kf == rq->kf_marg) ? 0 : ((rq->last_kf == rq->kf_keep) ? kf_keep_col : -1);
+            const int width = (rq->last_kf == rq->kf_marg) ? (rq->marg_has_imu ? 15 : 6) : 15;
+            if (base >= 0) for (int a = 0; a < width && rq->last_kf_col + a < nl; a++) col[rq->last_kf_col + a] = base + a;
+        }
+        for (int k = 0; k < rq->last_n_keep; k++) {
+            if (rq->last_lmk_col[k] < 0) continue;
+            const int li = rq->last_lmk_index[k];
+            if (li < 0 || li >= d.n_lmk) continue;
+            const int lc = lcol[li];
+            if (lc < 0) continue;
+            for (int a = 0; a < 3; a++) col[rq->last_lmk_col[k] + a] = lc + a;
+        }
+        HIP_TRY(dlastJ.alloc((size_t)nf * nl)); HIP_TRY(dlastr.alloc(nf)); HIP_TRY(dlastcol.alloc(nl));
+        HIP_TRY(hipMemcpyAsync(dlastJ.p, rq->last_J, sizeof(double) * (size_t)nf * nl, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(dlastr.p, rq->last_r0, sizeof(double) * nf, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(dlastcol.p, col.data(), sizeof(int) * nl, hipMemcpyHostToDevice, h->stream));
+        const long long items = (long long)nl * nl;
+        hipLaunchKernelGGL(k_marg_last_prior, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, dlastJ.p, dlastr.p, dlastcol.p, nf, nl, dA.p, db.p, N);
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    // Schur complement with the eigen pseudo-inverse of Amm (marginalization.cpp:234-248)
+    const int big = std::max(m, n);
+    HIP_TRY(G.alloc((size_t)big * big)); HIP_TRY(V.alloc((size_t)big * big)); HIP_TRY(ev.alloc(big)); HIP_TRY(Vs.alloc((size_t)big * big));
+    HIP_TRY(Ainv.alloc((size_t)m * m)); HIP_TRY(T.alloc((size_t)n * m)); HIP_TRY(Ak.alloc((size_t)n * n)); HIP_TRY(bk.alloc(n));
+    int sw = run_jacobi(h, dA.p, N, m, 0, G.p, V.p, ev.p, dflag.p);
+    if (sw < 0) { h->err = "marginalize: HIP error in the eigen-solver"; return SADVIO_E_HIP; }
+    if (res) res->sweeps_mm = sw;
+    std::vector<double> hev(m);
+    HIP_TRY(hipMemcpyAsync(hev.data(), ev.p, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    {
+        const double cut = marg_cut(hev);
+        std::vector<double> sel(m);
+        for (int i = 0; i < m; i++) sel[i] = hev[i] > cut ? 1.0 / sqrt(hev[i]) : 0.0;
+        HIP_TRY(hipMemcpyAsync(ev.p, sel.data(), sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+        const long long mm = (long long)m * m;
+        hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, h->stream, V.p, ev.p, m, Vs.p);
+        // Ainv = Vs^T Vs ; T = Arm Ainv ; Ak = Arr - T Arm^T ; bk = brr - T bmm
+        hipLaunchKernelGGL(k_gemm, dim3((m + 15) / 16, (m + 15) / 16), dim3(256), 0, h->stream, Ainv.p, (long long)m, Vs.p, 1LL, (long long)m, Vs.p,
+                           (long long)m, 1LL, m, m, m, 1.0, 0.0);
+        hipLaunchKernelGGL(k_gemm, dim3((m + 15) / 16, (n + 15) / 16), dim3(256), 0, h->stream, T.p, (long long)m, dA.p + (size_t)m * N, (long long)N, 1LL,
+                           Ainv.p, (long long)m, 1LL, n, m, m, 1.0, 0.0);
+        HIP_TRY(hipMemcpy2DAsync(Ak.p, sizeof(double) * n, dA.p + (size_t)m * N + m, sizeof(double) * N, sizeof(double) * n, n, hipMemcpyDeviceToDevice, h->stream));
+        hipLaunchKernelGGL(k_gemm, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, h->stream, Ak.p, (long long)n, T.p, (long long)m, 1LL,
+                           dA.p + (size_t)m * N, 1LL, (long long)N, n, n, m, -1.0, 1.0);
+        hipLaunchKernelGGL(k_marg_bk, dim3((n + 127) / 128), dim3(128), 0, h->stream, T.p, db.p, n, m, bk.p);
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    // rank-revealing decomposition of Ak (lower triangle, as Eigen reads it), marginalization.cpp:318-342
+    sw = run_jacobi(h, Ak.p, n, n, 1, G.p, V.p, ev.p, dflag.p);
+    if (sw < 0) { h->err = "marginalize: HIP error in the eigen-solver"; return SADVIO_E_HIP; }
+    if (res) res->sweeps_k = sw;
+    std::vector<double> hev2(n);
+    HIP_TRY(hipMemcpyAsync(hev2.data(), ev.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<int> sel_rows;
+    {
+        const double cut = marg_cut(hev2);
+        // ascending eigenvalue order, like Eigen::SelfAdjointEigenSolver (row order of J only)
+        std::vector<int> order(n);
+        for (int i = 0; i < n; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return hev2[a] < hev2[b]; });
+        for (int i : order) if (hev2[i] > cut) sel_rows.push_back(i);
+    }
+    const int nf = (int)sel_rows.size();
+    if (res) res->n_full = nf;
+    if (nf > 0) {
+        HIP_TRY(dsel.alloc(nf)); HIP_TRY(dJ.alloc((size_t)nf * n)); HIP_TRY(dr0.alloc(nf));
+        HIP_TRY(hipMemcpyAsync(dsel.p, sel_rows.data(), sizeof(int) * nf, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_marg_prior, dim3(nf), dim3(JAC_THREADS), 0, h->stream, V.p, ev.p, dsel.p, nf, n, bk.p, dJ.p, dr0.p);
+        if (J_out) HIP_TRY(hipMemcpyAsync(J_out, dJ.p, sizeof(double) * (size_t)nf * n, hipMemcpyDeviceToHost, h->stream));
+        if (r0_out) HIP_TRY(hipMemcpyAsync(r0_out, dr0.p, sizeof(double) * nf, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipGetLastError());
+    dA.release(); db.release(); G.release(); V.release(); ev.release(); Vs.release(); Ainv.release(); T.release(); Ak.release(); bk.release();
+    dJ.release(); dr0.release(); dlastJ.release(); dlastr.release(); ditems.release(); dflag.release(); dsel.release(); dlastcol.release(); dsmall.release();
+    return SADVIO_OK;
 }
 
 int sadvio_ba_set_collective(sadvio_ba_handle* h, int32_t rank, int32_t world, sadvio_allreduce_fn fn, void* ctx) {

@@ -1,0 +1,249 @@
+// marg_kernels.h — K8: the dense marginalisation prior on the device (BundleAdjustmentCERESAnalytic::marginalize,
+// …Analytic.cpp:431-663 -> Marginalization::{computeInformationAndGradient, computeSchurComplement,
+// rankReveallingDecomposition, computeJacobiansAndResiduals}, marginalization.cpp:145-265,318-342,516-530).
+//
+//   A = sum J^T J, b = + sum J^T r over the blocks touching frame0, evaluated at zero deltas   (k_marg_*)
+//   Amm^+ by eigen-decomposition (lambda > cut), Ak = Arr - Arm Amm^+ Arm^T, bk likewise        (k_jacobi_*, k_gemm)
+//   Ak = U Lambda U^T, J = Lambda^1/2 U^T, r0 = -Lambda^-1/2 U^T bk                             (k_jacobi_*, k_marg_prior)
+//
+// Eigen-solver: one-sided (Hestenes) Jacobi on the rows of G = A (symmetric, so rows = columns) with the
+// round-robin ordering: n/2 independent row pairs per launch, one workgroup per pair (3 dot products + the
+// rotation of two rows of G and of V, all unit-stride); n - 1 launches per sweep. For a symmetric PSD matrix the
+// rows of V converge to the eigenvectors and lambda_i = v_i . g_i. The prior (J^T J, J^T r0) is invariant to the
+// eigenvector sign / order conventions, which is what the parity tests compare.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace sadvio {
+
+constexpr int JAC_THREADS = 256;
+
+__device__ __forceinline__ double block_sum_256(double v, double* sh /*[4]*/) {
+    v = wave_sum(v);
+    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (ln == 0) sh[wv] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// pair k of round-robin step s over npad (even) players
+__device__ __forceinline__ void rr_pair(int npad, int s, int k, int& p, int& q) {
+    const int r = npad - 1;
+    if (k == 0) { p = r; q = s % r; }
+    else { p = (s + k) % r; q = (s - k + r) % r; }
+    if (p > q) { const int t = p; p = q; q = t; }
+}
+
+__global__ __launch_bounds__(JAC_THREADS) void k_jacobi_step(double* __restrict__ G, double* __restrict__ V, int n, int npad,
+                                                             int s, double tol, int* rotated) {
+    int p, q;
+    rr_pair(npad, s, blockIdx.x, p, q);
+    if (q >= n) return;  // dummy player of an odd n
+    __shared__ double sh[4];
+    double* gp = G + (size_t)p * n;
+    double* gq = G + (size_t)q * n;
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < n; i += JAC_THREADS) { const double x = gp[i], y = gq[i]; a += x * x; b += y * y; c += x * y; }
+    a = block_sum_256(a, sh); b = block_sum_256(b, sh); c = block_sum_256(c, sh);
+    if (a == 0.0 || b == 0.0 || c * c <= tol * tol * a * b) return;
+    if (threadIdx.x == 0) *rotated = 1;
+    const double zeta = (b - a) / (2.0 * c);
+    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+    double* vp = V + (size_t)p * n;
+    double* vq = V + (size_t)q * n;
+    for (int i = threadIdx.x; i < n; i += JAC_THREADS) {
+        const double x = gp[i], y = gq[i];
+        gp[i] = cs * x - sn * y; gq[i] = sn * x + cs * y;
+        const double u = vp[i], w = vq[i];
+        vp[i] = cs * u - sn * w; vq[i] = sn * u + cs * w;
+    }
+}
+
+// G = sym(A block), V = I
+__global__ void k_jacobi_init(const double* __restrict__ A, long long lda, int n, double* G, double* V, int lower_only) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * n) return;
+    const int i = (int)(idx / n), j = (int)(idx - (long long)i * n);
+    const double aij = A[(size_t)i * lda + j], aji = A[(size_t)j * lda + i];
+    G[idx] = lower_only ? (i >= j ? aij : aji) : 0.5 * (aij + aji);
+    V[idx] = i == j ? 1.0 : 0.0;
+}
+
+// lambda_i = v_i . g_i (one workgroup per row)
+__global__ __launch_bounds__(JAC_THREADS) void k_jacobi_eigenvalues(const double* G, const double* V, int n, double* ev) {
+    __shared__ double sh[4];
+    const int i = blockIdx.x;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < n; k += JAC_THREADS) s += G[(size_t)i * n + k] * V[(size_t)i * n + k];
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) ev[i] = s;
+}
+
+// C[i][j] = beta C[i][j] + alpha sum_k A(i,k) B(k,j) with arbitrary strides (covers every transpose); 16x16 tiles.
+__global__ __launch_bounds__(256) void k_gemm(double* C, long long ldc, const double* A, long long sai, long long sak,
+                                              const double* B, long long sbk, long long sbj, int M, int N, int K, double alpha,
+                                              double beta) {
+    __shared__ double As[16][17], Bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const int ka = k0 + tx, kb = k0 + ty;
+        As[ty][tx] = (i < M && ka < K) ? A[(size_t)i * sai + (size_t)ka * sak] : 0.0;
+        Bs[ty][tx] = (kb < K && j < N) ? B[(size_t)kb * sbk + (size_t)j * sbj] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc += As[ty][k] * Bs[k][tx];
+        __syncthreads();
+    }
+    if (i < M && j < N) C[(size_t)i * ldc + j] = (beta == 0.0 ? 0.0 : beta * C[(size_t)i * ldc + j]) + alpha * acc;
+}
+
+// rows of V (eigenvectors) scaled by sel[i] (0 = dropped): Vs[i][:] = sel[i] * V[i][:]
+__global__ void k_scale_rows(const double* V, const double* sel, int n, double* Vs) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * n) return;
+    Vs[idx] = sel[idx / n] * V[idx];
+}
+
+// ---- assembly of A, b ---------------------------------------------------------------------------------------
+// Generic block: J (rows x ncols, row-major), r (rows), col map -> A (N x N, both triangles) and b.
+__device__ __forceinline__ void marg_accumulate(double* A, double* b, int N, const double* J, const double* r, int rows, int ncols,
+                                                const int* col) {
+    for (int a = 0; a < ncols; a++) {
+        if (col[a] < 0) continue;
+        double g = 0.0;
+        for (int q = 0; q < rows; q++) g += J[q * ncols + a] * r[q];
+        atomic_add_f64(&b[col[a]], g);
+        for (int c2 = 0; c2 < ncols; c2++) {
+            if (col[c2] < 0) continue;
+            double h = 0.0;
+            for (int q = 0; q < rows; q++) h += J[q * ncols + a] * J[q * ncols + c2];
+            atomic_add_f64(&A[(size_t)col[a] * N + col[c2]], h);
+        }
+    }
+}
+
+// reprojection factors of the kept / marginalised landmarks seen from frame0 at zero deltas (…Analytic.cpp:510-572)
+template <int FACTOR>
+__global__ void k_marg_obs(DevPtrs P, const int* items /*[n][2]: device obs index, first column of the landmark*/, int n_items,
+                           double* A, double* b, int N) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_items) return;
+    const int o = items[2 * e], lc = items[2 * e + 1];
+    const int kf = P.obs_kf[o], cam = P.obs_cam[o];
+    double d6[6] = {0, 0, 0, 0, 0, 0}, tab[POSE_TAB];
+    pose_table_entry(P.kf_T0 + 12 * (long long)kf, d6, tab);
+    // landmark index from the item list is implicit in the column; position comes with the item's third slot
+    const int gl = items[2 * n_items + e];
+    const double pw[3] = {P.lmk_p[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1], P.lmk_p[3 * (long long)gl + 2]};
+    double r[2], Jp[12], Jl[6], J[18];
+    if (FACTOR == 0) {
+        const double* m = P.obs_meas + 2 * (long long)o;
+        pixel_factor<true>(tab, P.cam_K + 4 * (long long)cam, P.cam_T + 12 * (long long)cam, pw, m[0], m[1], P.cam_isig[cam], r, Jp, Jl);
+    } else {
+        const double* m = P.obs_meas + 3 * (long long)o;
+        double bb[3] = {m[0], m[1], m[2]};
+        angular_factor<true>(tab, P.cam_T + 12 * (long long)cam, pw, bb, P.cam_isig[cam], r, Jp, Jl);
+    }
+    int col[9];
+    for (int q = 0; q < 2; q++) {
+        for (int a = 0; a < 6; a++) J[q * 9 + a] = Jp[q * 6 + a];
+        for (int a = 0; a < 3; a++) J[q * 9 + 6 + a] = Jl[q * 3 + a];
+    }
+    for (int a = 0; a < 6; a++) col[a] = a;
+    for (int a = 0; a < 3; a++) col[6 + a] = lc + a;
+    marg_accumulate(A, b, N, J, r, 2, 9, col);
+}
+
+// IMUFactor + IMUBiasFactor (frame0, frame1) and the PosePriordx blocks: a handful of blocks, one thread each.
+struct MargSmall {
+    int has_imu, kf_i, kf_j, kf_keep_col;  // global key-frame indices
+    ImuDev imu;
+    int n_prior;
+    int prior_kf[4], prior_base[4];
+    double prior_T[4][12], prior_inf[4][6];
+};
+
+__global__ void k_marg_small(DevPtrs P, const MargSmall* Sp, double* A, double* b, int N) {
+    const MargSmall& S = *Sp;
+    const int t = threadIdx.x;
+    const double z[6] = {0, 0, 0, 0, 0, 0};
+    if (t == 0 && S.has_imu) {
+        double r[9], J[9 * 24];
+        imu_factor(S.imu, P.kf_T0 + 12 * (long long)S.kf_i, P.kf_T0 + 12 * (long long)S.kf_j, P.kf_vel + 3 * (long long)S.kf_i,
+                   P.kf_vel + 3 * (long long)S.kf_j, z, z, z, z, z, z, r, J);
+        int col[24];
+        for (int a = 0; a < 6; a++) { col[a] = a; col[6 + a] = S.kf_keep_col + a; }
+        for (int a = 0; a < 3; a++) { col[12 + a] = 6 + a; col[15 + a] = S.kf_keep_col + 6 + a; col[18 + a] = 9 + a; col[21 + a] = 12 + a; }
+        marg_accumulate(A, b, N, J, r, 9, 24, col);
+    }
+    if (t == 1 && S.has_imu) {
+        double rb[6], Jb[72];
+        int colb[12];
+        for (int i = 0; i < 72; i++) Jb[i] = 0.0;
+        for (int a = 0; a < 3; a++) {
+            rb[a] = S.imu.sa * (P.kf_ba[3 * (long long)S.kf_j + a] - P.kf_ba[3 * (long long)S.kf_i + a]);
+            rb[3 + a] = S.imu.sg * (P.kf_bg[3 * (long long)S.kf_j + a] - P.kf_bg[3 * (long long)S.kf_i + a]);
+            Jb[a * 12 + a] = -S.imu.sa; Jb[(3 + a) * 12 + 3 + a] = -S.imu.sg; Jb[a * 12 + 6 + a] = S.imu.sa; Jb[(3 + a) * 12 + 9 + a] = S.imu.sg;
+            colb[a] = 9 + a; colb[3 + a] = 12 + a; colb[6 + a] = S.kf_keep_col + 9 + a; colb[9 + a] = S.kf_keep_col + 12 + a;
+        }
+        marg_accumulate(A, b, N, Jb, rb, 6, 12, colb);
+    }
+    if (t >= 2 && t - 2 < S.n_prior) {
+        const int k = t - 2;
+        double r[6], J[36];
+        int col[6];
+        pose_prior_factor(P.kf_T0 + 12 * (long long)S.prior_kf[k], S.prior_T[k], S.prior_inf[k], z, r, J);
+        for (int a = 0; a < 6; a++) col[a] = S.prior_base[k] + a;
+        marg_accumulate(A, b, N, J, r, 6, 6, col);
+    }
+}
+
+// previous dense prior at zero deltas: A[col a][col c] += sum_q J[q][a] J[q][c], b[col a] += sum_q J[q][a] r0[q]
+__global__ void k_marg_last_prior(const double* J, const double* r0, const int* col, int nf, int nl, double* A, double* b, int N) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)nl * nl) return;
+    const int a = (int)(idx / nl), c = (int)(idx - (long long)a * nl);
+    if (col[a] < 0 || col[c] < 0) return;
+    double h = 0.0;
+    for (int q = 0; q < nf; q++) h += J[(size_t)q * nl + a] * J[(size_t)q * nl + c];
+    atomic_add_f64(&A[(size_t)col[a] * N + col[c]], h);
+    if (c == a) {
+        double g = 0.0;
+        for (int q = 0; q < nf; q++) g += J[(size_t)q * nl + a] * r0[q];
+        atomic_add_f64(&b[col[a]], g);
+    }
+}
+
+// bk = brr - T bmm (one thread per row of T: n x m)
+__global__ void k_marg_bk(const double* T, const double* b, int n, int m, double* bk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = b[m + i];
+    for (int k = 0; k < m; k++) s -= T[(size_t)i * m + k] * b[k];
+    bk[i] = s;
+}
+
+// prior rows from the selected eigenpairs of Ak: J[c][:] = sqrt(lam_c) v_c, r0[c] = -(v_c . bk) / sqrt(lam_c)
+__global__ __launch_bounds__(JAC_THREADS) void k_marg_prior(const double* V, const double* ev, const int* sel_rows, int n_full, int n,
+                                                            const double* bk, double* J, double* r0) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x;
+    const int k = sel_rows[c];
+    const double lam = ev[k], sq = sqrt(lam);
+    double dot = 0.0;
+    for (int i = threadIdx.x; i < n; i += JAC_THREADS) {
+        const double v = V[(size_t)k * n + i];
+        J[(size_t)c * n + i] = sq * v;
+        dot += v * bk[i];
+    }
+    dot = block_sum_256(dot, sh);
+    if (threadIdx.x == 0) r0[c] = -sqrt(1.0 / lam) * dot;
+}
+
+}  // namespace sadvio

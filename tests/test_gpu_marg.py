@@ -1,0 +1,104 @@
+"""GPU parity of the marginalisation of the oldest key-frame into a dense prior (K8, sadvio_ba_marginalize) against
+the oracle (oracle/marg.c, pinned on the reference's marginalization_test.cpp fixture). The prior is compared
+through its invariants J^T J (= Ak on its range) and J^T r0: eigenvector signs / order are conventions."""
+import numpy as np
+import pytest
+
+from marg_helpers import with_lonely_landmarks
+from sadvio_amd import capi, synthetic
+from test_oracle_marg import pre_marginalize, toy_window
+from vio_helpers import make_vio_window
+
+pytestmark = pytest.mark.gpu
+
+
+def check_prior(g, o, rtol=1e-8):
+    assert g is not None and o is not None
+    assert (g["m"], g["n"], g["n_full"], g["kf_col"]) == (o["m"], o["n"], o["n_full"], o["kf_col"])
+    assert np.array_equal(g["lmk_col"], o["lmk_col"])
+    Hg, Ho = g["J"].T @ g["J"], o["J"].T @ o["J"]
+    scale = np.abs(Ho).max()
+    assert np.abs(Hg - Ho).max() <= rtol * scale
+    gg, go = g["J"].T @ g["r0"], o["J"].T @ o["r0"]
+    assert np.abs(gg - go).max() <= rtol * max(np.abs(go).max(), np.sqrt(scale))
+    assert np.abs(g["J"] @ g["J"].T - np.diag(np.diag(g["J"] @ g["J"].T))).max() <= 1e-8 * scale  # rows orthogonal
+
+
+def test_reference_toy_graph(backend_cls, oracle_lib):
+    """marginalization_test.cpp fixture: n = 6, m = 9."""
+    w = toy_window()
+    w.obs_meas = w.obs_meas + np.random.default_rng(0).standard_normal(w.obs_meas.shape)
+    keep, marg = pre_marginalize(w, 0)
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    g = be.marginalize(0, 0, marg, keep)
+    assert be.marginalize(0, 0, [], []) is None   # margFailTest: n < 4 refused
+    be.close()
+    assert (g["m"], g["n"]) == (9, 6)
+    check_prior(g, oracle_lib.marginalize(w, 0, marg, keep))
+
+
+@pytest.mark.parametrize("factor", [capi.FACTOR_PIXEL, capi.FACTOR_ANGULAR])
+def test_vo_window_oldest_keyframe(backend_cls, oracle_lib, factor):
+    w = synthetic.make_window(n_kf=6, n_lmk=400, seed=71, factor=factor)
+    kf0 = w.n_kf - 1
+    w = with_lonely_landmarks(w, kf0, 12)
+    keep, marg = pre_marginalize(w, kf0)
+    assert len(keep) > 10 and len(marg) > 3
+    args = dict(kf_marg=kf0, lmk_marg=marg, lmk_keep=keep, priors=w.pose_priors)
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    g = be.marginalize(0, **args)
+    be.close()
+    check_prior(g, oracle_lib.marginalize(w, **args))
+
+
+def test_vio_window_with_imu_and_previous_prior(backend_cls, oracle_lib):
+    w = make_vio_window(n_kf=6, n_lmk=400, seed=72)
+    kf0, kf1 = w.n_kf - 1, w.n_kf - 2
+    w = with_lonely_landmarks(w, kf0, 10)
+    keep, marg = pre_marginalize(w, kf0)
+    imu = [f for f in w.imu_factors if f["kf_i"] == kf0 and f["kf_j"] == kf1][0]
+    # a previous prior on frame0's 15 states and some of the landmarks kept now (built like the reference's J, r0)
+    rng = np.random.default_rng(7)
+    prev_l = np.array(keep[:6] + marg[:2], dtype=np.int32)
+    nl = 15 + 3 * len(prev_l)
+    last = {"J": rng.standard_normal((nl - 3, nl)), "r0": 0.3 * rng.standard_normal(nl - 3), "kf_keep": kf0, "kf_col": 0,
+            "lmk_index": prev_l, "lmk_col": (15 + 3 * np.arange(len(prev_l))).astype(np.int32)}
+    args = dict(kf_marg=kf0, lmk_marg=marg, lmk_keep=keep, kf_keep=kf1, marg_has_imu=True, imu=imu, priors=w.pose_priors, last=last)
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    g = be.marginalize(0, **args)
+    be.close()
+    o = oracle_lib.marginalize(w, **args)
+    assert g["kf_col"] == 0 and g["n"] == 15 + 3 * len(keep)
+    check_prior(g, o)
+
+
+def test_device_prior_feeds_the_next_solve(backend_cls, oracle_lib):
+    """marginalize -> set_dense_prior -> solve of the window without frame0, all on the device, against the same
+    pipeline on the oracle."""
+    w = with_lonely_landmarks(make_vio_window(n_kf=6, n_lmk=400, seed=73), 5, 10)
+    kf0, kf1 = w.n_kf - 1, w.n_kf - 2
+    keep, marg = pre_marginalize(w, kf0)
+    imu = [f for f in w.imu_factors if f["kf_i"] == kf0 and f["kf_j"] == kf1][0]
+    args = dict(kf_marg=kf0, lmk_marg=marg, lmk_keep=keep, kf_keep=kf1, marg_has_imu=True, imu=imu, priors=w.pose_priors)
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    g = be.marginalize(0, **args)
+    o = oracle_lib.marginalize(w, **args)
+    # next window: same arrays, frame0 constant and without factors of its own (its information now lives in the prior)
+    w2 = with_lonely_landmarks(make_vio_window(n_kf=6, n_lmk=400, seed=73), 5, 10)
+    w2.pose_priors = []
+    w2.kf_const = np.zeros(w2.n_kf, dtype=np.uint8); w2.kf_const[kf0] = 1
+    w2.imu_factors = [f for f in w2.imu_factors if f["kf_i"] != kf0]
+    opts = capi.reference_options()
+    w2.dense_prior = {k: g[k] for k in ("J", "r0", "kf_keep", "kf_col", "lmk_index", "lmk_col")}
+    be.set_windows([w2])
+    s = be.solve(opts)[0]
+    d = be.get_deltas(0)
+    be.close()
+    ref = oracle_lib.solve(w2, opts, dense_prior={k: o[k] for k in ("J", "r0", "kf_keep", "kf_col", "lmk_index", "lmk_col")})
+    assert np.isclose(s.final_cost, ref["summary"].final_cost, rtol=1e-8)
+    assert s.iterations == ref["summary"].iterations
+    assert np.abs(d["pose"] - ref["pose"]).max() <= 1e-6 and np.abs(d["lmk"] - ref["lmk"]).max() <= 1e-5
