@@ -256,6 +256,16 @@ typedef struct sadvio_marg_result {
 int sadvio_ba_marginalize(sadvio_ba_handle *h, int32_t w, const sadvio_marg_request *rq, sadvio_marg_result *res,
                           int32_t *lmk_col, double *J, double *r0);
 
+/* NFR sparsification of a dense prior (Marginalization::sparsifyVIO / sparsifyVO, marginalization.cpp:362-514) into
+ * the factor list of the sparse branch of addMarginalizationResiduals (…Analytic.cpp:363-426): vio != 0 -> one
+ * IMUPriordx on kf_keep + one PoseToLandmarkFactor per kept landmark; vio == 0 -> greedy landmark chain ordered by
+ * |tr Lambda_ij|, a Landmark3DPrior on the minimum-entropy landmark + LandmarkToLandmarkFactor links. The prior is
+ * the (J, column map) pair produced by sadvio_ba_marginalize / passed to sadvio_ba_set_dense_prior; linearisation
+ * values (T_f_w, v, ba, bg, landmark positions) are those of window `w`. `out` has room for n_keep + 1 factors. */
+int sadvio_ba_sparsify(sadvio_ba_handle *h, int32_t w, int32_t vio, int32_t n_full, int32_t n, const double *J,
+                       int32_t kf_keep, int32_t kf_col, int32_t n_keep, const int32_t *lmk_index, const int32_t *lmk_col,
+                       int32_t *n_out, sadvio_sparse_prior *out);
+
 /* ---- one window spanning several GPUs (no reference counterpart: the reference is one process) ----
  * The landmarks of a window (with all their observations) are partitioned over `world` processes, one GPU each;
  * key-frames, cameras, pose priors and IMU factors are replicated (a dense prior is not supported on a

@@ -294,3 +294,187 @@ int oracle_marginalize(const oracle_marg_request *rq, oracle_marg_result *res, i
     free(Aks); free(ev2); free(V2);
     return SADVIO_OK;
 }
+
+/* ---- NFR sparsification (Marginalization::sparsifyVIO :362-408, sparsifyVO :410-514) -------------------------
+ * Input: the dense prior J = Lambda^1/2 U^T (n_full x n) of oracle_marginalize; U and Sigma = Lambda^-1 are
+ * recovered from it (lambda_c = |J_c|^2, U[:,c] = J_c / sqrt(lambda_c)), then the reference's formulas are applied
+ * as coded: J~ = J_f U, cov = J~ Sigma J~^T, symmetric square root of the information through a 3x3 / 15x15
+ * eigen-decomposition with the eigenvalue cut 1e-12. Output: the factor list the sparse branch of
+ * addMarginalizationResiduals builds (…Analytic.cpp:363-426). */
+static void small_inverse(const double *A, int n, double *Ai) {
+    double M[15 * 30];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) { M[i * 2 * n + j] = A[i * n + j]; M[i * 2 * n + n + j] = (i == j); }
+    for (int c = 0; c < n; c++) {
+        int p = c;
+        for (int r = c + 1; r < n; r++) if (fabs(M[r * 2 * n + c]) > fabs(M[p * 2 * n + c])) p = r;
+        if (p != c) for (int j = 0; j < 2 * n; j++) { double t = M[c * 2 * n + j]; M[c * 2 * n + j] = M[p * 2 * n + j]; M[p * 2 * n + j] = t; }
+        double d = 1.0 / M[c * 2 * n + c];
+        for (int j = 0; j < 2 * n; j++) M[c * 2 * n + j] *= d;
+        for (int r = 0; r < n; r++) {
+            if (r == c) continue;
+            double f = M[r * 2 * n + c];
+            if (f != 0.0) for (int j = 0; j < 2 * n; j++) M[r * 2 * n + j] -= f * M[c * 2 * n + j];
+        }
+    }
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) Ai[i * n + j] = M[i * 2 * n + n + j];
+}
+
+/* sqrt-information of a factor: S = cov (rows x rows). invert_first: VIO path (inf = cov^-1, keep eig > eps, sqrt);
+ * else VO path (eig of cov, 1/eig for eig > eps, sqrt). W row-major rows x rows. */
+static void nfr_sqrt_info(const double *S, int rows, int invert_first, double *W) {
+    double M[225], ev[15], V[225];
+    if (invert_first) small_inverse(S, rows, M); else memcpy(M, S, sizeof(double) * (size_t)rows * rows);
+    for (int i = 0; i < rows; i++) for (int j = 0; j < i; j++) { double s = 0.5 * (M[i * rows + j] + M[j * rows + i]); M[i * rows + j] = M[j * rows + i] = s; }
+    oracle_sym_eig(M, rows, ev, V);
+    for (int i = 0; i < rows; i++)
+        for (int j = 0; j < rows; j++) {
+            double s = 0;
+            for (int k = 0; k < rows; k++) {
+                double e = ev[k] > MARG_EPS ? (invert_first ? ev[k] : 1.0 / ev[k]) : 0.0;
+                s += V[i * rows + k] * sqrt(e) * V[j * rows + k];
+            }
+            W[i * rows + j] = s;
+        }
+}
+
+/* cov = (Jsel U[cidx,:]) Sigma (Jsel U[cidx,:])^T */
+static void nfr_cov(const double *J, int nf, int n, const double *lam, const double *Jsel, int rows, int cols, const int *cidx,
+                    double *S) {
+    memset(S, 0, sizeof(double) * (size_t)rows * rows);
+    for (int c = 0; c < nf; c++) {
+        double jt[15];
+        for (int a = 0; a < rows; a++) {
+            double s = 0;
+            for (int k = 0; k < cols; k++) s += Jsel[a * cols + k] * (J[(size_t)c * n + cidx[k]] / sqrt(lam[c]));  /* J_f U */
+            jt[a] = s;
+        }
+        for (int a = 0; a < rows; a++) for (int b = 0; b < rows; b++) S[a * rows + b] += jt[a] * (1.0 / lam[c]) * jt[b];
+    }
+}
+
+int oracle_sparsify(const sadvio_flat_window *w, int32_t vio, int32_t nf, int32_t n, const double *J, int32_t kf_keep,
+                    int32_t kf_col, int32_t n_keep, const int32_t *lmk_index, const int32_t *lmk_col, int32_t *n_out,
+                    sadvio_sparse_prior *out) {
+    *n_out = 0;
+    if (n == 0 || nf == 0) return SADVIO_E_REFUSED;
+    double *lam = (double *)malloc(sizeof(double) * (size_t)nf);
+    for (int c = 0; c < nf; c++) { double s = 0; for (int i = 0; i < n; i++) s += J[(size_t)c * n + i] * J[(size_t)c * n + i]; lam[c] = s; }
+    int cnt = 0;
+    if (vio) {
+        if (kf_keep < 0) { free(lam); return SADVIO_E_INVALID_ARG; }
+        const double *T = w->kf_T_f_w + 12 * kf_keep; /* R row-major 9, t 3 */
+        double tsk[9], Rt[9];
+        so3_skew(T + 9, tsk);
+        m3_mul(T, tsk, Rt);
+        /* absolute factor of the kept frame first (…Analytic.cpp:373-386 adds it first) */
+        {
+            double Jsel[225], S[225];
+            int cidx[15];
+            memset(Jsel, 0, sizeof(Jsel));
+            for (int a = 0; a < 15; a++) { Jsel[a * 15 + a] = 1.0; cidx[a] = kf_col + a; }
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    Jsel[i * 15 + j] = T[3 * i + j];            /* block(0, f, 3, 3) = R */
+                    Jsel[i * 15 + 3 + j] = T[3 * i + j];        /* block(0, f+3, 3, 3) = R */
+                    Jsel[(3 + i) * 15 + 3 + j] = T[3 * i + j];  /* block(3, f+3, 3, 3) = R */
+                }
+            nfr_cov(J, nf, n, lam, Jsel, 15, 15, cidx, S);
+            sadvio_sparse_prior *o = out + cnt++;
+            memset(o, 0, sizeof(*o));
+            o->type = SADVIO_SPARSE_IMU_PRIOR; o->kf = kf_keep; o->lmk0 = o->lmk1 = -1;
+            memcpy(o->T_prior, T, 96);
+            for (int a = 0; a < 3; a++) {
+                o->v_prior[a] = w->kf_vel ? w->kf_vel[3 * kf_keep + a] : 0.0;
+                o->ba_prior[a] = w->kf_ba ? w->kf_ba[3 * kf_keep + a] : 0.0;
+                o->bg_prior[a] = w->kf_bg ? w->kf_bg[3 * kf_keep + a] : 0.0;
+            }
+            nfr_sqrt_info(S, 15, 1, o->sqrt_inf);
+        }
+        for (int k = 0; k < n_keep; k++) {
+            if (lmk_col[k] < 0) continue;
+            double Jsel[27], S[9];
+            int cidx[9];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    Jsel[i * 9 + j] = T[3 * i + j];          /* landmark block: R */
+                    Jsel[i * 9 + 3 + j] = -Rt[3 * i + j];    /* frame rotation block: -R [t]x */
+                    Jsel[i * 9 + 6 + j] = T[3 * i + j];      /* frame translation block: R */
+                }
+            for (int a = 0; a < 3; a++) { cidx[a] = lmk_col[k] + a; cidx[3 + a] = kf_col + a; cidx[6 + a] = kf_col + 3 + a; }
+            nfr_cov(J, nf, n, lam, Jsel, 3, 9, cidx, S);
+            sadvio_sparse_prior *o = out + cnt++;
+            memset(o, 0, sizeof(*o));
+            o->type = SADVIO_SPARSE_POSE_TO_LMK; o->kf = kf_keep; o->lmk0 = lmk_index[k]; o->lmk1 = -1;
+            se3_apply(T, w->lmk_p + 3 * lmk_index[k], o->delta);
+            nfr_sqrt_info(S, 3, 1, o->sqrt_inf);
+        }
+    } else {
+        /* greedy chain ordering on |trace(Ak_ij)|, Ak = J^T J (:417-456) */
+        int K = 0;
+        int *idx = (int *)malloc(sizeof(int) * (size_t)(n_keep > 0 ? n_keep : 1));
+        for (int k = 0; k < n_keep; k++) if (lmk_col[k] >= 0) idx[K++] = k;
+        if (K < 2) { free(idx); free(lam); return SADVIO_E_REFUSED; }
+        double *mi = (double *)calloc((size_t)K * K, sizeof(double));
+        for (int a = 0; a < K; a++)
+            for (int b = a + 1; b < K; b++) {
+                double tr = 0;
+                for (int c = 0; c < nf; c++)
+                    for (int q = 0; q < 3; q++) tr += J[(size_t)c * n + lmk_col[idx[a]] + q] * J[(size_t)c * n + lmk_col[idx[b]] + q];
+                mi[a * K + b] = mi[b * K + a] = fabs(tr);
+            }
+        int *order = (int *)malloc(sizeof(int) * (size_t)K), no = 0;
+        int mr = 0, mc = 0;
+        double best = -1;
+        for (int j = 0; j < K; j++) for (int i = 0; i < K; i++) if (mi[i * K + j] > best) { best = mi[i * K + j]; mr = i; mc = j; } /* column-major visit */
+        order[no++] = mr; order[no++] = mc;
+        for (int i = 0; i < K; i++) { mi[i * K + mr] = 0; mi[mr * K + i] = 0; mi[i * K + mc] = 0; }
+        int cur = mc;
+        for (;;) {
+            int bc = 0; double bv = mi[cur * K];
+            for (int j = 1; j < K; j++) if (mi[cur * K + j] > bv) { bv = mi[cur * K + j]; bc = j; }
+            if (bv == 0) break;
+            order[no++] = bc;
+            for (int j = 0; j < K; j++) mi[cur * K + j] = 0;
+            for (int i = 0; i < K; i++) mi[i * K + bc] = 0;
+            cur = bc;
+        }
+        /* landmark with the prior: minimum entropy = minimum det of its 3x3 covariance block (:458-466) */
+        const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        int root = 0; double best_det = 0;
+        for (int k = 0; k < no; k++) {
+            int cidx[3] = {lmk_col[idx[order[k]]], lmk_col[idx[order[k]]] + 1, lmk_col[idx[order[k]]] + 2};
+            double S[9];
+            nfr_cov(J, nf, n, lam, I3, 3, 3, cidx, S);
+            double det = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+            if (k == 0 || det < best_det) { best_det = det; root = k; }
+        }
+        {
+            int l = idx[order[root]];
+            int cidx[3] = {lmk_col[l], lmk_col[l] + 1, lmk_col[l] + 2};
+            double S[9];
+            nfr_cov(J, nf, n, lam, I3, 3, 3, cidx, S);
+            sadvio_sparse_prior *o = out + cnt++;
+            memset(o, 0, sizeof(*o));
+            o->type = SADVIO_SPARSE_LMK_PRIOR; o->kf = -1; o->lmk0 = lmk_index[l]; o->lmk1 = -1;
+            memcpy(o->delta, w->lmk_p + 3 * lmk_index[l], 24);
+            nfr_sqrt_info(S, 3, 0, o->sqrt_inf);
+        }
+        for (int k = 0; k + 1 < no; k++) {
+            int la = idx[order[k]], lb = idx[order[k + 1]];
+            double Jsel[18] = {1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1}, S[9];
+            int cidx[6];
+            for (int a = 0; a < 3; a++) { cidx[a] = lmk_col[la] + a; cidx[3 + a] = lmk_col[lb] + a; }
+            nfr_cov(J, nf, n, lam, Jsel, 3, 6, cidx, S);
+            sadvio_sparse_prior *o = out + cnt++;
+            memset(o, 0, sizeof(*o));
+            o->type = SADVIO_SPARSE_LMK_TO_LMK; o->kf = -1; o->lmk0 = lmk_index[la]; o->lmk1 = lmk_index[lb];
+            for (int a = 0; a < 3; a++) o->delta[a] = w->lmk_p[3 * lmk_index[la] + a] - w->lmk_p[3 * lmk_index[lb] + a];
+            nfr_sqrt_info(S, 3, 0, o->sqrt_inf);
+        }
+        free(idx); free(mi); free(order);
+    }
+    free(lam);
+    *n_out = cnt;
+    return SADVIO_OK;
+}

@@ -203,6 +203,23 @@ def marginalize(w: FlatWindow, kf_marg, lmk_marg, lmk_keep, kf_keep=-1, marg_has
             "lmk_index": kp.copy(), "lmk_col": lmk_col[: len(kp)].copy(), "m": res.m, "n": res.n, "n_full": nf, "Ak": Ak, "bk": bk}
 
 
+def sparsify(w: FlatWindow, prior: dict, vio: bool):
+    """oracle_sparsify: dense prior dict -> list of sparse prior dicts (None when refused)."""
+    from sadvio_amd.capi import sparse_prior_to_dict
+    wc = w.to_c()
+    J = np.ascontiguousarray(prior["J"], dtype=np.float64)
+    li = np.ascontiguousarray(prior.get("lmk_index", []), dtype=np.int32); lc = np.ascontiguousarray(prior.get("lmk_col", []), dtype=np.int32)
+    out = (SparsePriorC * (len(li) + 1))()
+    n_out = C.c_int32(0)
+    f = lib().oracle_sparsify
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_int32, _ip, _ip, _ip, C.c_void_p]
+    rc = f(C.byref(wc), int(bool(vio)), J.shape[0], J.shape[1], _p(J), int(prior.get("kf_keep", -1)), int(prior.get("kf_col", 0)), len(li),
+           li.ctypes.data_as(_ip), lc.ctypes.data_as(_ip), C.byref(n_out), out)
+    if rc != 0:
+        return None
+    return [sparse_prior_to_dict(out[i]) for i in range(n_out.value)]
+
+
 # ---- factor probes ----
 def factor_pixel(T0, K, Tsf, p0, uv, sigma, dpose, dl):
     r = np.zeros(2); Jp = np.zeros((2, 6)); Jl = np.zeros((2, 3)); v = C.c_int32(0)

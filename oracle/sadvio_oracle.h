@@ -133,6 +133,12 @@ typedef struct oracle_marg_result {
 int oracle_marginalize(const oracle_marg_request *rq, oracle_marg_result *res, int32_t *lmk_col, double *A_full,
                        double *b_full, double *Ak, double *bk, double *U, double *Lambda, double *J, double *r0);
 
+/* NFR sparsification of a dense prior into the sparse-branch factor list (sparsifyVIO / sparsifyVO,
+ * marginalization.cpp:362-514). out has room for n_keep + 1 factors. */
+int oracle_sparsify(const sadvio_flat_window *w, int32_t vio, int32_t n_full, int32_t n, const double *J, int32_t kf_keep,
+                    int32_t kf_col, int32_t n_keep, const int32_t *lmk_index, const int32_t *lmk_col, int32_t *n_out,
+                    sadvio_sparse_prior *out);
+
 /* Symmetric eigen-decomposition (cyclic Jacobi), eigenvalues ascending, V column-eigenvectors row-major. */
 void oracle_sym_eig(const double *A, int32_t n, double *evals, double *V);
 

@@ -250,6 +250,14 @@ class FlatWindow:
         return arr, len(self.imu_factors)
 
 
+def sparse_prior_to_dict(s: SparsePriorC) -> dict:
+    n = 15 if s.type == SPARSE_IMU_PRIOR else 3
+    return {"type": int(s.type), "kf": int(s.kf), "lmk0": int(s.lmk0), "lmk1": int(s.lmk1),
+            "T_prior": np.array(s.T_prior[:]), "v_prior": np.array(s.v_prior[:]), "ba_prior": np.array(s.ba_prior[:]),
+            "bg_prior": np.array(s.bg_prior[:]), "delta": np.array(s.delta[:]),
+            "sqrt_inf": np.array(s.sqrt_inf[: n * n]).reshape(n, n)}
+
+
 def fill_imu_factor(dst: ImuFactorC, f: dict) -> None:
     dst.kf_i, dst.kf_j, dst.dt = int(f["kf_i"]), int(f["kf_j"]), float(f["dt"])
     for k in ("delta_R", "delta_v", "delta_p", "J_dR_bg", "J_dv_ba", "J_dv_bg", "J_dp_ba", "J_dp_bg", "cov"):
@@ -286,6 +294,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                                               C.c_int32, C.c_int32, _ip, _ip]
     lib.sadvio_ba_set_sparse_priors.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(SparsePriorC)]
     lib.sadvio_ba_marginalize.argtypes = [C.c_void_p, C.c_int32, C.POINTER(MargRequestC), C.POINTER(MargResultC), _ip, _dp, _dp]
+    lib.sadvio_ba_sparsify.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_int32,
+                                        _ip, _ip, _ip, C.POINTER(SparsePriorC)]
     lib.sadvio_ba_set_collective.argtypes = [C.c_void_p, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p]
     lib.sadvio_ba_rccl_unique_id.argtypes = [C.c_void_p]
     lib.sadvio_ba_comm_init_rccl.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
@@ -408,6 +418,20 @@ class Backend:
         return {"J": Jo[: nf * n].reshape(nf, n).copy(), "r0": r0o[:nf].copy(), "kf_keep": kf_keep, "kf_col": res.kf_col,
                 "lmk_index": kp.copy(), "lmk_col": lmk_col[: len(kp)].copy(), "m": res.m, "n": res.n, "n_full": nf,
                 "sweeps": (res.sweeps_mm, res.sweeps_k)}
+
+    def sparsify(self, w: int, prior: dict, vio: bool):
+        """NFR sparsification of a dense prior dict (as returned by marginalize) into sparse_priors dicts."""
+        J = np.ascontiguousarray(prior["J"], dtype=np.float64)
+        li = np.ascontiguousarray(prior.get("lmk_index", []), dtype=np.int32); lc = np.ascontiguousarray(prior.get("lmk_col", []), dtype=np.int32)
+        out = (SparsePriorC * (len(li) + 1))()
+        n_out = C.c_int32(0)
+        rc = self.lib.sadvio_ba_sparsify(self.h, w, int(bool(vio)), J.shape[0], J.shape[1], _ptr(J), int(prior.get("kf_keep", -1)),
+                                         int(prior.get("kf_col", 0)), len(li), li.ctypes.data_as(_ip), lc.ctypes.data_as(_ip),
+                                         C.byref(n_out), out)
+        if rc == E_REFUSED:
+            return None
+        self._check(rc, "sparsify")
+        return [sparse_prior_to_dict(out[i]) for i in range(n_out.value)]
 
     def solve(self, opts: Optional[SolveOptions] = None) -> List[SolveSummary]:
         opts = opts or reference_options()

@@ -1080,6 +1080,215 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     return SADVIO_OK;
 }
 
+namespace {
+// host-side post-processing of the tiny (3x3 / 15x15) NFR covariances
+void host_sym_eig(const double* Ain, int n, double* ev, double* V) {
+    double A[225];
+    memcpy(A, Ain, sizeof(double) * n * n);
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 100; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; i++) { diag += A[i * n + i] * A[i * n + i]; for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j]; }
+        if (off <= 1e-60 || off <= 1e-32 * diag) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; k++) { const double a = A[k * n + p], b = A[k * n + q]; A[k * n + p] = c * a - s * b; A[k * n + q] = s * a + c * b; }
+                for (int k = 0; k < n; k++) { const double a = A[p * n + k], b = A[q * n + k]; A[p * n + k] = c * a - s * b; A[q * n + k] = s * a + c * b; }
+                for (int k = 0; k < n; k++) { const double a = V[k * n + p], b = V[k * n + q]; V[k * n + p] = c * a - s * b; V[k * n + q] = s * a + c * b; }
+            }
+    }
+    for (int i = 0; i < n; i++) ev[i] = A[i * n + i];
+}
+
+bool host_inverse(const double* A, int n, double* Ai) {
+    std::vector<double> M((size_t)n * 2 * n);
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) { M[i * 2 * n + j] = A[i * n + j]; M[i * 2 * n + n + j] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < n; c++) {
+        int p = c;
+        for (int r = c + 1; r < n; r++) if (std::fabs(M[r * 2 * n + c]) > std::fabs(M[p * 2 * n + c])) p = r;
+        if (M[p * 2 * n + c] == 0.0) return false;
+        if (p != c) for (int j = 0; j < 2 * n; j++) std::swap(M[c * 2 * n + j], M[p * 2 * n + j]);
+        const double d = 1.0 / M[c * 2 * n + c];
+        for (int j = 0; j < 2 * n; j++) M[c * 2 * n + j] *= d;
+        for (int r = 0; r < n; r++) {
+            if (r == c) continue;
+            const double f = M[r * 2 * n + c];
+            if (f != 0.0) for (int j = 0; j < 2 * n; j++) M[r * 2 * n + j] -= f * M[c * 2 * n + j];
+        }
+    }
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) Ai[i * n + j] = M[i * 2 * n + n + j];
+    return true;
+}
+
+// symmetric square root of the information of an NFR factor from its covariance (marginalization.cpp:379-385 /
+// :482-487): VIO inverts first and keeps eigenvalues > 1e-12, VO inverts the eigenvalues > 1e-12
+bool nfr_sqrt_info(const double* S, int rows, bool invert_first, double* W) {
+    double M[225], ev[15], V[225];
+    if (invert_first) { if (!host_inverse(S, rows, M)) return false; }
+    else memcpy(M, S, sizeof(double) * rows * rows);
+    for (int i = 0; i < rows; i++) for (int j = 0; j < i; j++) { const double s = 0.5 * (M[i * rows + j] + M[j * rows + i]); M[i * rows + j] = M[j * rows + i] = s; }
+    host_sym_eig(M, rows, ev, V);
+    for (int i = 0; i < rows; i++)
+        for (int j = 0; j < rows; j++) {
+            double s = 0;
+            for (int k = 0; k < rows; k++) {
+                const double e = ev[k] > 1e-12 ? (invert_first ? ev[k] : 1.0 / ev[k]) : 0.0;
+                s += V[i * rows + k] * std::sqrt(e) * V[j * rows + k];
+            }
+            W[i * rows + j] = s;
+        }
+    return true;
+}
+}  // namespace
+
+int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, int32_t n, const double* J, int32_t kf_keep,
+                       int32_t kf_col, int32_t n_keep, const int32_t* lmk_index, const int32_t* lmk_col, int32_t* n_out,
+                       sadvio_sparse_prior* out) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (n_out) *n_out = 0;
+    if (!h->uploaded) { h->err = "sparsify before set_windows"; return SADVIO_E_STATE; }
+    if (w < 0 || w >= (int)h->wins.size() || !J || !n_out || !out || n_keep < 0 || (n_keep > 0 && (!lmk_index || !lmk_col))) { h->err = "sparsify: bad argument"; return SADVIO_E_INVALID_ARG; }
+    if (n <= 0 || nf <= 0) { h->err = "sparsify: empty prior"; return SADVIO_E_REFUSED; }
+    const HostWin& HW = h->wins[w];
+    const WinDev& d = HW.d;
+    if (vio && (kf_keep < 0 || kf_keep >= d.n_kf || kf_col < 0 || kf_col + 15 > n)) { h->err = "sparsify: kept key-frame out of range"; return SADVIO_E_INVALID_ARG; }
+    for (int k = 0; k < n_keep; k++)
+        if (lmk_col[k] >= 0 && (lmk_index[k] < 0 || lmk_index[k] >= d.n_lmk || lmk_col[k] + 3 > n)) { h->err = "sparsify: kept landmark out of range"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    // linearisation values of the window (host read-back of the few entries needed)
+    double T[12], v3[3], ba3[3], bg3[3];
+    if (vio) {
+        const long long g = d.kf_base + kf_keep;
+        HIP_TRY(hipMemcpy(T, h->d_kf_T0.p + 12 * g, sizeof(T), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(v3, h->d_kf_vel.p + 3 * g, 24, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ba3, h->d_kf_ba.p + 3 * g, 24, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(bg3, h->d_kf_bg.p + 3 * g, 24, hipMemcpyDeviceToHost));
+    }
+    std::vector<double> lp(3 * (size_t)std::max(d.n_lmk, 1));
+    if (d.n_lmk) HIP_TRY(hipMemcpy(lp.data(), h->d_lmk_p.p + 3 * (size_t)d.lmk_base, sizeof(double) * 3 * d.n_lmk, hipMemcpyDeviceToHost));
+    DevBuf<double> dJ, dlam, dS, dmi;
+    DevBuf<NfrSpec> dspec;
+    DevBuf<int> dlc;
+    HIP_TRY(dJ.alloc((size_t)nf * n)); HIP_TRY(dlam.alloc(nf));
+    HIP_TRY(hipMemcpyAsync(dJ.p, J, sizeof(double) * (size_t)nf * n, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_row_norm2, dim3(nf), dim3(JAC_THREADS), 0, h->stream, dJ.p, nf, n, dlam.p);
+    std::vector<NfrSpec> specs;
+    std::vector<int> kept;  // positions k with lmk_col >= 0
+    for (int k = 0; k < n_keep; k++) if (lmk_col[k] >= 0) kept.push_back(k);
+    std::vector<int> order;  // VO: chain order (indices into kept)
+    if (vio) {
+        double tsk[9] = {0, -T[11], T[10], T[11], 0, -T[9], -T[10], T[9], 0}, Rt[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += T[3 * i + k] * tsk[3 * k + j]; Rt[3 * i + j] = s; }
+        NfrSpec f{};
+        f.rows = 15; f.cols = 15;
+        for (int a = 0; a < 15; a++) { f.Jsel[a * 15 + a] = 1.0; f.cidx[a] = kf_col + a; }
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { f.Jsel[i * 15 + j] = T[3 * i + j]; f.Jsel[i * 15 + 3 + j] = T[3 * i + j]; f.Jsel[(3 + i) * 15 + 3 + j] = T[3 * i + j]; }
+        specs.push_back(f);
+        for (int k : kept) {
+            NfrSpec s{};
+            s.rows = 3; s.cols = 9;
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { s.Jsel[i * 9 + j] = T[3 * i + j]; s.Jsel[i * 9 + 3 + j] = -Rt[3 * i + j]; s.Jsel[i * 9 + 6 + j] = T[3 * i + j]; }
+            for (int a = 0; a < 3; a++) { s.cidx[a] = lmk_col[k] + a; s.cidx[3 + a] = kf_col + a; s.cidx[6 + a] = kf_col + 3 + a; }
+            specs.push_back(s);
+        }
+    } else {
+        const int K = (int)kept.size();
+        if (K < 2) { h->err = "sparsify: fewer than two kept landmarks"; return SADVIO_E_REFUSED; }
+        std::vector<int> lc(K);
+        for (int a = 0; a < K; a++) lc[a] = lmk_col[kept[a]];
+        HIP_TRY(dlc.alloc(K)); HIP_TRY(dmi.alloc((size_t)K * K));
+        HIP_TRY(hipMemcpyAsync(dlc.p, lc.data(), sizeof(int) * K, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(dmi.p, 0, sizeof(double) * (size_t)K * K, h->stream));
+        hipLaunchKernelGGL(k_nfr_trace, dim3((K * K + 255) / 256), dim3(256), 0, h->stream, dJ.p, nf, n, dlc.p, K, dmi.p);
+        std::vector<double> mi((size_t)K * K);
+        HIP_TRY(hipMemcpyAsync(mi.data(), dmi.p, sizeof(double) * (size_t)K * K, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        // greedy chain (marginalization.cpp:432-456); Eigen's maxCoeff visits a column-major matrix column by column
+        int mr = 0, mc = 0; double best = -1;
+        for (int j = 0; j < K; j++) for (int i = 0; i < K; i++) if (mi[(size_t)i * K + j] > best) { best = mi[(size_t)i * K + j]; mr = i; mc = j; }
+        order.push_back(mr); order.push_back(mc);
+        for (int i = 0; i < K; i++) { mi[(size_t)i * K + mr] = 0; mi[(size_t)mr * K + i] = 0; mi[(size_t)i * K + mc] = 0; }
+        int cur = mc;
+        for (;;) {
+            int bc = 0; double bv = mi[(size_t)cur * K];
+            for (int j = 1; j < K; j++) if (mi[(size_t)cur * K + j] > bv) { bv = mi[(size_t)cur * K + j]; bc = j; }
+            if (bv == 0) break;
+            order.push_back(bc);
+            for (int j = 0; j < K; j++) mi[(size_t)cur * K + j] = 0;
+            for (int i = 0; i < K; i++) mi[(size_t)i * K + bc] = 0;
+            cur = bc;
+        }
+        // covariance of every ordered landmark (entropy root, unary factor) then of every chain link
+        for (int a : order) {
+            NfrSpec s{};
+            s.rows = 3; s.cols = 3;
+            for (int q = 0; q < 3; q++) { s.Jsel[q * 3 + q] = 1.0; s.cidx[q] = lmk_col[kept[a]] + q; }
+            specs.push_back(s);
+        }
+        for (size_t k = 0; k + 1 < order.size(); k++) {
+            NfrSpec s{};
+            s.rows = 3; s.cols = 6;
+            for (int q = 0; q < 3; q++) { s.Jsel[q * 6 + q] = 1.0; s.Jsel[q * 6 + 3 + q] = -1.0; s.cidx[q] = lmk_col[kept[order[k]]] + q; s.cidx[3 + q] = lmk_col[kept[order[k + 1]]] + q; }
+            specs.push_back(s);
+        }
+    }
+    const int ns = (int)specs.size();
+    HIP_TRY(dspec.alloc(ns)); HIP_TRY(dS.alloc((size_t)ns * 225));
+    HIP_TRY(hipMemcpyAsync(dspec.p, specs.data(), sizeof(NfrSpec) * ns, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_nfr_cov, dim3(ns), dim3(JAC_THREADS), 0, h->stream, dJ.p, nf, n, dlam.p, dspec.p, dS.p);
+    std::vector<double> S((size_t)ns * 225);
+    HIP_TRY(hipMemcpyAsync(S.data(), dS.p, sizeof(double) * (size_t)ns * 225, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipGetLastError());
+    int cnt = 0;
+    auto fail = [&]() { h->err = "sparsify: singular factor covariance"; return SADVIO_E_NOT_USABLE; };
+    if (vio) {
+        sadvio_sparse_prior* o = out + cnt++;
+        memset(o, 0, sizeof(*o));
+        o->type = SADVIO_SPARSE_IMU_PRIOR; o->kf = kf_keep; o->lmk0 = o->lmk1 = -1;
+        memcpy(o->T_prior, T, sizeof(T)); memcpy(o->v_prior, v3, 24); memcpy(o->ba_prior, ba3, 24); memcpy(o->bg_prior, bg3, 24);
+        if (!nfr_sqrt_info(&S[0], 15, true, o->sqrt_inf)) return fail();
+        for (size_t i = 0; i < kept.size(); i++) {
+            const int k = kept[i];
+            o = out + cnt++;
+            memset(o, 0, sizeof(*o));
+            o->type = SADVIO_SPARSE_POSE_TO_LMK; o->kf = kf_keep; o->lmk0 = lmk_index[k]; o->lmk1 = -1;
+            const double* p = &lp[3 * (size_t)lmk_index[k]];
+            for (int a = 0; a < 3; a++) o->delta[a] = T[3 * a] * p[0] + T[3 * a + 1] * p[1] + T[3 * a + 2] * p[2] + T[9 + a];
+            if (!nfr_sqrt_info(&S[(i + 1) * 225], 3, true, o->sqrt_inf)) return fail();
+        }
+    } else {
+        const int no = (int)order.size();
+        int root = 0; double best_det = 0;
+        for (int k = 0; k < no; k++) {
+            const double* s = &S[(size_t)k * 225];
+            const double det = s[0] * (s[4] * s[8] - s[5] * s[7]) - s[1] * (s[3] * s[8] - s[5] * s[6]) + s[2] * (s[3] * s[7] - s[4] * s[6]);
+            if (k == 0 || det < best_det) { best_det = det; root = k; }
+        }
+        sadvio_sparse_prior* o = out + cnt++;
+        memset(o, 0, sizeof(*o));
+        const int lr = lmk_index[kept[order[root]]];
+        o->type = SADVIO_SPARSE_LMK_PRIOR; o->kf = -1; o->lmk0 = lr; o->lmk1 = -1;
+        memcpy(o->delta, &lp[3 * (size_t)lr], 24);
+        if (!nfr_sqrt_info(&S[(size_t)root * 225], 3, false, o->sqrt_inf)) return fail();
+        for (int k = 0; k + 1 < no; k++) {
+            const int la = lmk_index[kept[order[k]]], lb = lmk_index[kept[order[k + 1]]];
+            o = out + cnt++;
+            memset(o, 0, sizeof(*o));
+            o->type = SADVIO_SPARSE_LMK_TO_LMK; o->kf = -1; o->lmk0 = la; o->lmk1 = lb;
+            for (int a = 0; a < 3; a++) o->delta[a] = lp[3 * (size_t)la + a] - lp[3 * (size_t)lb + a];
+            if (!nfr_sqrt_info(&S[(size_t)(no + k) * 225], 3, false, o->sqrt_inf)) return fail();
+        }
+    }
+    *n_out = cnt;
+    return SADVIO_OK;
+}
+
 int sadvio_ba_set_collective(sadvio_ba_handle* h, int32_t rank, int32_t world, sadvio_allreduce_fn fn, void* ctx) {
     if (!h) return SADVIO_E_INVALID_ARG;
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) { h->err = "set_collective: bad rank / world / callback"; return SADVIO_E_INVALID_ARG; }

@@ -246,4 +246,63 @@ __global__ __launch_bounds__(JAC_THREADS) void k_marg_prior(const double* V, con
     if (threadIdx.x == 0) r0[c] = -sqrt(1.0 / lam) * dot;
 }
 
+
+// ---- NFR sparsification (Marginalization::sparsifyVIO / sparsifyVO, marginalization.cpp:362-514) ------------------
+// Everything is computed from the dense prior J = Lambda^1/2 U^T: lambda_c = |J_c|^2, U[:,c] = J_c / sqrt(lambda_c),
+// Sigma = Lambda^-1, so the covariance of an NFR factor with (sparse) Jacobian J_f is
+//   cov = (J_f U) Sigma (J_f U)^T = sum_c w_c w_c^T,  w_c = Jsel J_c[cidx] / lambda_c.
+struct NfrSpec {
+    int rows, cols;
+    int cidx[15];
+    double Jsel[225];  // rows x cols row-major
+};
+
+__global__ __launch_bounds__(JAC_THREADS) void k_row_norm2(const double* J, int nf, int n, double* lam) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += JAC_THREADS) { const double v = J[(size_t)c * n + i]; s += v * v; }
+    s = block_sum_256(s, sh);
+    if (threadIdx.x == 0) lam[c] = s;
+}
+
+// one workgroup per factor: S[f] (15 x 15 slot, rows x rows used) = sum_c w_c w_c^T
+__global__ __launch_bounds__(JAC_THREADS) void k_nfr_cov(const double* J, int nf, int n, const double* lam, const NfrSpec* specs, double* S) {
+    __shared__ double acc[225];
+    const NfrSpec& sp = specs[blockIdx.x];
+    const int rows = sp.rows, cols = sp.cols;
+    for (int i = threadIdx.x; i < 225; i += JAC_THREADS) acc[i] = 0.0;
+    __syncthreads();
+    for (int c = threadIdx.x; c < nf; c += JAC_THREADS) {
+        const double il = 1.0 / lam[c];
+        double u[15], w[15];
+        for (int k = 0; k < cols; k++) u[k] = J[(size_t)c * n + sp.cidx[k]];
+        for (int a = 0; a < rows; a++) {
+            double s = 0.0;
+            for (int k = 0; k < cols; k++) s += sp.Jsel[a * cols + k] * u[k];
+            w[a] = s * il;
+        }
+        for (int a = 0; a < rows; a++)
+            for (int b = 0; b <= a; b++) atomic_add_f64(&acc[a * 15 + b], w[a] * w[b]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * rows; i += JAC_THREADS) {
+        const int a = i / rows, b = i - a * rows;
+        S[(size_t)blockIdx.x * 225 + i] = a >= b ? acc[a * 15 + b] : acc[b * 15 + a];
+    }
+}
+
+// |trace of the 3x3 block (a, b) of J^T J| for every pair of kept landmarks (computeOffDiag, :304-316)
+__global__ void k_nfr_trace(const double* J, int nf, int n, const int* lcols, int K, double* mi) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= K * K) return;
+    const int a = idx / K, b = idx - a * K;
+    if (a >= b) return;
+    double tr = 0.0;
+    for (int c = 0; c < nf; c++)
+        for (int q = 0; q < 3; q++) tr += J[(size_t)c * n + lcols[a] + q] * J[(size_t)c * n + lcols[b] + q];
+    mi[a * K + b] = fabs(tr);
+    mi[b * K + a] = fabs(tr);
+}
+
 }  // namespace sadvio
