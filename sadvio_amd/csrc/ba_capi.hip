@@ -1408,7 +1408,15 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     auto kbk = h->factor_type == SADVIO_FACTOR_PIXEL ? k_build_kept<0> : k_build_kept<1>;
     HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
     HIP_TRY(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back));
-    HIP_TRY(hipFuncSetAttribute((const void*)k_solve<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
+    bool extras = false;  // any pose-only factor family beyond PosePriordx in the batch?
+    for (int w = 0; w < n_win; w++) {
+        const WinDev& d = h->wins[w].d;
+        if (d.imu_end > d.imu_begin || d.sp_end > d.sp_begin || d.dp_n_full > 0) extras = true;
+    }
+    auto ks0 = extras ? k_solve<0, true> : k_solve<0, false>;
+    auto ks1 = extras ? k_solve<1, true> : k_solve<1, false>;
+    auto ks2 = extras ? k_solve<2, true> : k_solve<2, false>;
+    HIP_TRY(hipFuncSetAttribute((const void*)ks0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_solve));
     const int reset_blocks = (int)std::min<long long>(1024, std::max<long long>(1, (P.n_xl + P.n_xp + 255) / 256));
     // rows below a block column of S that can be non-zero: (block half-bandwidth + 1) * dpf from the co-visibility
     // structure and the IMU pairs; a dense prior fills the kept-landmark block, so those windows are dense
@@ -1447,9 +1455,9 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 ScopedTimer t(h, "allreduce_reduced_system");
                 if (h->coll_fn(h->coll_ctx, h->d_S.p, (int64_t)h->red_total, (void*)h->stream) != 0) coll_failed = true;
             }
-            if (h->n_big < n_win) { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(k_solve<0>, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
+            if (h->n_big < n_win) { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(ks0, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
             if (h->n_big) {
-                { ScopedTimer t(h, "k_solve_front"); hipLaunchKernelGGL(k_solve<1>, dim3(n_win), dim3(SOLVE_THREADS), 64, h->stream, P, s); }
+                { ScopedTimer t(h, "k_solve_front"); hipLaunchKernelGGL(ks1, dim3(n_win), dim3(SOLVE_THREADS), 64, h->stream, P, s); }
                 {
                     // blocked Cholesky + solve of S, gred in place (dense_chol.h): two launches per 32 columns
                     ScopedTimer t(h, "k_chol_panel+update+backsolve");
@@ -1475,7 +1483,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                         hipLaunchKernelGGL(k_chol_backsolve, dim3(1), dim3(CH_THREADS), 0, h->stream, Sw, (long long)d.ld, yw, N, bw, info, skip);
                     }
                 }
-                { ScopedTimer t(h, "k_solve_back"); hipLaunchKernelGGL(k_solve<2>, dim3(n_win), dim3(SOLVE_THREADS), 64, h->stream, P, s); }
+                { ScopedTimer t(h, "k_solve_back"); hipLaunchKernelGGL(ks2, dim3(n_win), dim3(SOLVE_THREADS), 64, h->stream, P, s); }
                 for (int w = 0; w < n_win; w++) {
                     const WinDev& d = h->wins[w].d;
                     if (d.ld) (void)hipMemsetAsync(h->d_S.p + d.S_off, 0, sizeof(double) * (size_t)d.Np * d.Np, h->stream);
@@ -1499,7 +1507,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         unsigned char* kp = key.data();
         memcpy(kp + sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t), lay.data(), lay.size() * sizeof(int));
         memcpy(kp, &P, sizeof(DevPtrs)); kp += sizeof(DevPtrs);
-        const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type};
+        const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type + 2 * (int)extras};
         memcpy(kp, ints, sizeof(ints)); kp += sizeof(ints);
         const size_t szs[3] = {lds_build, lds_back, lds_solve};
         memcpy(kp, szs, sizeof(szs));

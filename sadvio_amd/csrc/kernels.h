@@ -789,6 +789,50 @@ __device__ __forceinline__ void pivot_gather_factor(const double* P, const doubl
     }
 }
 
+// TIL 16x16 tiles (pair indices pp, pp + stride, ...) of the trailing update C -= Lp_i Lp_j^T on the FP64 matrix
+// cores; every LDS load is unconditional (clamped address), masking happens on the loaded values.
+template <int NB, int TIL>
+__device__ __forceinline__ void trail_tiles(double* P, const double* LpT, int ldp, int s, int m, int pp0, int stride, int lr, int lk) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    d4 c[TIL];
+    double a0[TIL], b0[TIL], a1[TIL], b1[TIL];
+    int addr[TIL][4];
+    bool okr[TIL][4];
+#pragma unroll
+    for (int u = 0; u < TIL; u++) {
+        int ta = 0, rem = pp0 + u * stride;
+        while (rem >= ta + 1) { rem -= ta + 1; ta++; }
+        const int i0 = ta << 4, j0 = rem << 4;
+        const int ai = i0 + lr, bj = j0 + lr;
+        const int aic = ai < m ? ai : m - 1, bjc = bj < m ? bj : m - 1;
+        const int k1 = lk + 4 < NB ? lk + 4 : 0;
+        a0[u] = LpT[lk * ldp + aic]; b0[u] = LpT[lk * ldp + bjc];
+        a1[u] = LpT[k1 * ldp + aic]; b1[u] = LpT[k1 * ldp + bjc];
+        const int col = j0 + lr;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int row = i0 + lk + 4 * rg;
+            okr[u][rg] = row < m && row >= NB && col <= row && col < m - 1;
+            const int rowc = row < m ? row : m - 1;
+            const int colc = col <= rowc ? col : rowc;
+            addr[u][rg] = tri(s + rowc, s + colc);
+            c[u][rg] = P[addr[u][rg]];
+        }
+        a0[u] = (ai < m && lk < NB) ? -a0[u] : 0.0; b0[u] = (bj < m && lk < NB) ? b0[u] : 0.0;
+        a1[u] = (ai < m && lk + 4 < NB) ? -a1[u] : 0.0; b1[u] = (bj < m && lk + 4 < NB) ? b1[u] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < TIL; u++) {
+        c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], c[u], 0, 0, 0);
+        c[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], c[u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < TIL; u++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+            if (okr[u][rg]) P[addr[u][rg]] = c[u][rg];
+}
+
 template <int NB>
 __device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, double* xs, double* LpT,
                                                   double* linvTab, long long* ts) {
@@ -851,38 +895,12 @@ __device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, d
             const int nt16 = (m + 15) >> 4;
             const int npair = nt16 * (nt16 + 1) / 2;
             const int lr = ln & 15, lk = ln >> 4;
-            for (int pp = bw; pp < npair; pp += nbw) {
-                int ta = 0, rem = pp;
-                while (rem >= ta + 1) { rem -= ta + 1; ta++; }
-                const int i0 = ta << 4, j0 = rem << 4;
-                // every LDS load is unconditional (clamped address) so that they issue back to back; the
-                // masking happens on the loaded values
-                const int ai = i0 + lr, bj = j0 + lr;
-                const int aic = ai < m ? ai : m - 1, bjc = bj < m ? bj : m - 1;
-                const int k1 = lk + 4 < NB ? lk + 4 : 0;
-                double a0 = LpT[lk * ldp + aic], b0 = LpT[lk * ldp + bjc];
-                double a1 = LpT[k1 * ldp + aic], b1 = LpT[k1 * ldp + bjc];
-                const int col = j0 + lr;
-                int addr[4];
-                bool okr[4];
-                d4 c;
-#pragma unroll
-                for (int rg = 0; rg < 4; rg++) {
-                    const int row = i0 + lk + 4 * rg;
-                    okr[rg] = row < m && row >= NB && col <= row && col < m - 1;
-                    const int rowc = row < m ? row : m - 1;
-                    const int colc = col <= rowc ? col : rowc;
-                    addr[rg] = tri(s + rowc, s + colc);
-                    c[rg] = P[addr[rg]];
-                }
-                a0 = (ai < m && lk < NB) ? -a0 : 0.0; b0 = (bj < m && lk < NB) ? b0 : 0.0;
-                a1 = (ai < m && lk + 4 < NB) ? -a1 : 0.0; b1 = (bj < m && lk + 4 < NB) ? b1 : 0.0;
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
-#pragma unroll
-                for (int rg = 0; rg < 4; rg++)
-                    if (okr[rg]) P[addr[rg]] = c[rg];
-            }
+            // full groups of 4 tiles per wave are processed together (all LDS loads first, independent and back to
+            // back, then the MFMAs, then the stores: the tiles of one step are disjoint and the strip is read-only
+            // here); the remainder one tile at a time
+            int pp = bw;
+            for (; pp + 3 * nbw < npair; pp += 4 * nbw) trail_tiles<NB, 4>(P, LpT, ldp, s, m, pp, nbw, lr, lk);
+            for (; pp < npair; pp += nbw) trail_tiles<NB, 1>(P, LpT, ldp, s, m, pp, nbw, lr, lk);
             if (ts && k == 2 && tid == 64) ts[12] = wall_clock64();
         }
         __syncthreads();
@@ -989,7 +1007,9 @@ __device__ __noinline__ bool sparse_eval(const DevPtrs& P, const WinDev& W, cons
 // MODE 0: the whole step in LDS (Np <= MAX_LDS_NP): gather S, pose-only factors, damping, Cholesky, candidate.
 // Windows whose reduced system does not fit LDS (W.ld != 0, S kept as a full row-major lower triangle in HBM)
 // run the same front (MODE 1) and back (MODE 2) halves around a library factorisation of S in place.
-template <int MODE>
+// EXTRAS = false compiles the IMU / sparse-prior / dense-prior sections out: the plain visual window (config 2)
+// then runs a kernel without their register and scratch footprint.
+template <int MODE, bool EXTRAS>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool BIG = MODE != 0;
@@ -1085,7 +1105,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     }
     // IMUFactor + IMUBiasFactor (K3): one thread per factor evaluates r and the whitened 9x24 Jacobian into an
     // HBM scratch row; the J^T J accumulation is then spread over all threads (LDS atomics into A).
-    if (n_imu > 0) {
+    if (EXTRAS && n_imu > 0) {
         const double* xv = P.xv + (long long)cur * P.xv_stride;
         const double* xba = P.xba + (long long)cur * P.xv_stride;
         const double* xbg = P.xbg + (long long)cur * P.xv_stride;
@@ -1151,7 +1171,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     // sparse (NFR) prior factors: one thread per factor evaluates r, J into an HBM scratch row, then the J^T J
     // accumulation is spread over all threads (same scheme as the IMU factors)
     const int n_sp = W.sp_end - W.sp_begin;
-    if (n_sp > 0) {
+    if (EXTRAS && n_sp > 0) {
         const double* xv = P.xv + (long long)cur * P.xv_stride;
         const double* xba = P.xba + (long long)cur * P.xv_stride;
         const double* xbg = P.xbg + (long long)cur * P.xv_stride;
@@ -1194,7 +1214,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     }
     // dense marginalisation prior (K4 / a9): r = r0 + J dx, J constant. H = J^T J and J^T were formed once
     // at upload; per step two wave-per-row GEMVs (r, J^T r) and the scatter of H through the column map.
-    if (W.dp_n_full > 0) {
+    if (EXTRAS && W.dp_n_full > 0) {
         __syncthreads();
         const int n = W.dp_n, nf = W.dp_n_full;
         double* D = P.dp_data + W.dp_off;
@@ -1371,7 +1391,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         pose_prior_factor(P.kf_T0 + 12 * (long long)pr.kf, pr.T_prior, pr.inf, d6, rc, nullptr);
         for (int q = 0; q < 6; q++) cc += rc[q] * rc[q];
     }
-    if (n_imu > 0) {
+    if (EXTRAS && n_imu > 0) {
         const double* xv = P.xv + (long long)cur * P.xv_stride;
         const double* xba = P.xba + (long long)cur * P.xv_stride;
         const double* xbg = P.xbg + (long long)cur * P.xv_stride;
@@ -1424,7 +1444,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
         }
     }
-    if (W.sp_end > W.sp_begin) {
+    if (EXTRAS && W.sp_end > W.sp_begin) {
         const int n_sp = W.sp_end - W.sp_begin;
         const double* xv = P.xv + (long long)cur * P.xv_stride;
         const double* xba = P.xba + (long long)cur * P.xv_stride;
@@ -1456,7 +1476,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             for (int q = 0; q < rows; q++) cc += r[q] * r[q];
         }
     }
-    if (W.dp_n_full > 0) {
+    if (EXTRAS && W.dp_n_full > 0) {
         // model cost change and candidate cost of the dense prior: m = J delta, r_cand = r + m
         const int n = W.dp_n, nf = W.dp_n_full;
         double* D = P.dp_data + W.dp_off;

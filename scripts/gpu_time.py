@@ -23,6 +23,10 @@ t=time.perf_counter()
 for _ in range(20): s = be.solve(opts)
 dt=(time.perf_counter()-t)/20
 print(f"   unprofiled wall/solve {dt*1e3:.3f} ms -> {nw*10/dt:.0f} it/s")
+t=time.perf_counter()
+for _ in range(5):
+    be.set_windows(ws)
+print(f"   set_windows wall {1e3*(time.perf_counter()-t)/5:.3f} ms (flatten done; pageable host -> device upload + tiling), {sum(w.n_obs for w in ws)} obs")
 be.close()
 be = capi.Backend(device=0, use_graph=True)
 be.set_windows(ws)
