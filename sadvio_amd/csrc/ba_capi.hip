@@ -1383,6 +1383,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     }
     DevPtrs P = make_ptrs(h, o, stride);
     const int n_tiles = (int)h->tiles.size();
+    // with many tiles, re-summing all partials in every k_build workgroup costs more than one tiny launch per slot
+    P.decide_kernel = n_tiles >= 1024 ? 1 : 0;
     const int mtk = h->max_tile_kf;
     const size_t nt = 6 * (size_t)h->max_tile_free;
     int Rp = 16 * ((6 * h->max_gemm_free + 15) / 16);                          // padded rows of the Y / E strips
@@ -1403,8 +1405,11 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     const size_t lds_back = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)mtk * 18) + 16;
     const size_t lds_solve = sizeof(double) * ((size_t)(h->max_np + 2) * 6 + (size_t)(h->max_np + 1) * (h->max_np + 2) / 2 +
                                                4 * (size_t)h->max_np + (size_t)(h->max_np / 5 + 1) * 36) + 64;
-    auto kb = h->factor_type == SADVIO_FACTOR_PIXEL ? k_build<0> : k_build<1>;
-    auto kk = h->factor_type == SADVIO_FACTOR_PIXEL ? k_backsub<0> : k_backsub<1>;
+    // robust loss or prior-kept landmarks in the batch: the kernels carrying those (rare) paths
+    const bool rare = o.huber_a > 0.0 || h->n_kept > 0;
+    const bool pix = h->factor_type == SADVIO_FACTOR_PIXEL;
+    auto kb = pix ? (rare ? k_build<0, true> : k_build<0, false>) : (rare ? k_build<1, true> : k_build<1, false>);
+    auto kk = pix ? (rare ? k_backsub<0, true> : k_backsub<0, false>) : (rare ? k_backsub<1, true> : k_backsub<1, false>);
     auto kbk = h->factor_type == SADVIO_FACTOR_PIXEL ? k_build_kept<0> : k_build_kept<1>;
     HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
     HIP_TRY(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back));
@@ -1495,8 +1500,9 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 ScopedTimer t(h, "allreduce_step_partials");
                 if (h->coll_fn(h->coll_ctx, h->d_rank_s.p, (int64_t)n_win * h->world * 4, (void*)h->stream) != 0) coll_failed = true;
             }
+            if (P.decide_kernel) { ScopedTimer t(h, "k_decide"); hipLaunchKernelGGL(k_decide, dim3(n_win), dim3(64), 0, h->stream, P, s, 0); }
         }
-        { ScopedTimer t(h, "k_final"); hipLaunchKernelGGL(k_final, dim3(n_win), dim3(64), 0, h->stream, P, slots); }
+        { ScopedTimer t(h, "k_final"); hipLaunchKernelGGL(k_decide, dim3(n_win), dim3(64), 0, h->stream, P, slots - 1, 1); }
     };
     if (h->cfg.use_graph && !h->cfg.profile_kernels && !h->coll_fn) {
         // the whole <= 20-iteration solve is one graph launch; the key covers every kernel argument
@@ -1507,7 +1513,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         unsigned char* kp = key.data();
         memcpy(kp + sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t), lay.data(), lay.size() * sizeof(int));
         memcpy(kp, &P, sizeof(DevPtrs)); kp += sizeof(DevPtrs);
-        const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type + 2 * (int)extras};
+        const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type + 2 * (int)extras + 4 * (int)rare};  // P (incl. decide_kernel) is part of the key
         memcpy(kp, ints, sizeof(ints)); kp += sizeof(ints);
         const size_t szs[3] = {lds_build, lds_back, lds_solve};
         memcpy(kp, szs, sizeof(szs));

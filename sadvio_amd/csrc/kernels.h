@@ -47,6 +47,7 @@ struct DevPtrs {
     int* big_info;        // [n_win] potrf info of the windows solved out of LDS
     // a window sharded over `world` GPUs (landmark partition): per-rank partial sums, exchanged with the reduced
     // system by one all-reduce per phase; rank r writes slot r and zeroes the others (sum == gather)
+    int decide_kernel;    // 1: the LM decision of a slot is taken by k_decide (many tiles); 0: by every k_build workgroup
     int world, rank;
     double* rank_b;       // [n_win][world][4] lin_cost, fixed_cost, gmax, -      (after k_build)
     double* rank_s;       // [n_win][world][4] cand_cost, mcc, step_norm2, cand_norm2 (after k_backsub)
@@ -224,7 +225,8 @@ struct ObsLin {
 };
 
 // Lane-local linearisation of observation `o` of landmark `gl` from LDS tables.
-template <int FACTOR>
+// RARE = false compiles the robust loss out (plain window BA: huber_a = 0, no prior-kept landmarks).
+template <int FACTOR, bool RARE>
 __device__ __forceinline__ void lane_linearize(const DevPtrs& P, const double* poseTab, const double* camTab,
                                                const int* rowTab, int cam_base, int o, const double* pw, bool keep_jl,
                                                bool lcounted, ObsLin& L) {
@@ -242,9 +244,10 @@ __device__ __forceinline__ void lane_linearize(const DevPtrs& P, const double* p
         double b[3] = {m[0], m[1], m[2]};
         angular_factor<true>(tab, ct + 4, pw, b, ct[16], L.r, L.Jp, L.Jl);
     }
-    {
+    L.rho = L.r[0] * L.r[0] + L.r[1] * L.r[1];
+    if (RARE) {
         double sc;
-        L.rho = huber_rho(P.o.huber_a, L.r[0] * L.r[0] + L.r[1] * L.r[1], sc);
+        L.rho = huber_rho(P.o.huber_a, L.rho, sc);
         if (sc != 1.0) {
             L.r[0] *= sc; L.r[1] *= sc;
 #pragma unroll
@@ -341,7 +344,7 @@ __host__ __device__ inline size_t tile_tables_bytes(int n_kf) {
 }
 
 // ---- K5: build the reduced system ----------------------------------------------------------------
-template <int FACTOR>
+template <int FACTOR, bool RARE>
 __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot, int max_tile_kf, int strip_doubles, int Rp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Tile T = P.tiles[blockIdx.x];
@@ -349,8 +352,11 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
     SADVIO_TS(3, 32);
     __shared__ double s_part[BUILD_WAVES * 4];
     LmState st;
-    if (slot == 0) st = P.states[(long long)T.w * P.state_stride];
-    else {
+    if (slot == 0 || P.decide_kernel) {
+        // many tiles: the accept / reject decision of the previous slot was taken once per window by k_decide
+        st = P.states[(long long)T.w * P.state_stride + slot];
+    } else {
+        // few tiles: every workgroup recomputes it (cheaper than one more launch on the critical path):
         // totals of the previous slot = window part (k_solve) + the tiles' k_backsub partials
         if (wv == 0) wave_sum_backsub_partials(P, (slot - 1) & 1, T.w, T.win_tile0, T.win_ntiles, ln, s_part);
         __syncthreads();
@@ -358,8 +364,8 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
         a.cand_cost += s_part[0]; a.mcc += s_part[1]; a.step_norm2 += s_part[2]; a.cand_norm2 += s_part[3];
         st = lm_decide(P.states[(long long)T.w * P.state_stride + slot - 1], a, P.o);
         __syncthreads();  // s_part is reused below
+        if (T.first_of_window && tid == 0) P.states[(long long)T.w * P.state_stride + slot] = st;
     }
-    if (slot > 0 && T.first_of_window && tid == 0) P.states[(long long)T.w * P.state_stride + slot] = st;
     if (st.done) return;
     SADVIO_TS(3, 33);
     // LDS carve
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
         if (L.valid) {
             const double pw[3] = {P.lmk_p[3 * (long long)gl] + xl[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1] + xl[3 * (long long)gl + 1],
                                   P.lmk_p[3 * (long long)gl + 2] + xl[3 * (long long)gl + 2]};
-            lane_linearize<FACTOR>(P, poseTab, camTab, rowTab, T.cam_base, ob + q, pw, lfree, lcode != 1, L);
+            lane_linearize<FACTOR, RARE>(P, poseTab, camTab, rowTab, T.cam_base, ob + q, pw, lfree, lcode != 1, L);
             const double c = L.rho;
             if (L.counted) cost_part += c;
             else { fixed_part += c; L.r[0] = 0.0; L.r[1] = 0.0; }
@@ -1509,7 +1515,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
 }
 
 // ---- K7: back-substitution + candidate cost -------------------------------------------------------
-template <int FACTOR>
+template <int FACTOR, bool RARE>
 __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, int max_tile_kf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Tile T = P.tiles[blockIdx.x];
@@ -1565,7 +1571,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
         L.row = -1; L.slot = 0; L.counted = false;
         if (L.valid) {
             const double pw[3] = {p0[0] + x0[0], p0[1] + x0[1], p0[2] + x0[2]};
-            lane_linearize<FACTOR>(P, poseTab, camTab, rowTab, T.cam_base, ob + q, pw, lcode != 1, lcode != 1, L);
+            lane_linearize<FACTOR, RARE>(P, poseTab, camTab, rowTab, T.cam_base, ob + q, pw, lcode != 1, lcode != 1, L);
             if (!L.counted) { L.r[0] = 0.0; L.r[1] = 0.0; }
         } else {
             L.r[0] = L.r[1] = 0.0;
@@ -1591,7 +1597,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
         double d0 = -(Mi[0] * t0 + Mi[1] * t1 + Mi[2] * t2);
         double d1 = -(Mi[1] * t0 + Mi[3] * t1 + Mi[4] * t2);
         double d2 = -(Mi[2] * t0 + Mi[4] * t1 + Mi[5] * t2);
-        if (lcode == 2) {  // kept landmark: its step is part of the reduced solution (|step|^2 is counted there)
+        if (RARE && lcode == 2) {  // kept landmark: its step is part of the reduced solution (|step|^2 is counted there)
             const double* dr = P.delta + T.red_off + P.lmk_red[gl];
             d0 = dr[0]; d1 = dr[1]; d2 = dr[2];
         }
@@ -1601,7 +1607,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
             if (active) {
                 sn += d0 * d0 + d1 * d1 + d2 * d2;
                 cn += c0 * c0 + c1 * c1 + c2 * c2;
-            } else if (lcode == 2) cn += c0 * c0 + c1 * c1 + c2 * c2;
+            } else if (RARE && lcode == 2) cn += c0 * c0 + c1 * c1 + c2 * c2;
         }
         if (L.valid && L.counted) {
             // model cost change of this residual block: -(J d)^T (r + J d / 2)
@@ -1624,7 +1630,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
                 angular_factor<false>(ctab, ct + 4, pw, bb, ct[16], r, nullptr, nullptr);
             }
             double sc_unused;
-            cc += huber_rho(P.o.huber_a, r[0] * r[0] + r[1] * r[1], sc_unused);
+            cc += RARE ? huber_rho(P.o.huber_a, r[0] * r[0] + r[1] * r[1], sc_unused) : r[0] * r[0] + r[1] * r[1];
         }
     }
     sn = wave_sum(sn); cn = wave_sum(cn); mcc = wave_sum(mcc); cc = wave_sum(cc);
@@ -1737,22 +1743,33 @@ __global__ void k_init_tables(DevPtrs P, int n_kf_tot) {
     for (int i = 0; i < POSE_TAB; i++) P.ptab[(long long)g * POSE_TAB + i] = tab[i];
 }
 
-// Last decision of the solve: state[slots] = decide(state[slots-1], totals[slots-1]); one wave per window.
-__global__ void k_final(DevPtrs P, int slots) {
+// Decision of slot `slot` (one wave per window): state[slot + 1] = decide(state[slot], totals[slot]). Launched after
+// every k_backsub when the batch has many tiles (P.decide_kernel), and always once at the end of the solve
+// (final = 1), where it also writes the read-back record.
+__global__ void k_decide(DevPtrs P, int slot, int final) {
     const int w = blockIdx.x, ln = threadIdx.x;
     __shared__ double s4[4];
     const WinDev W = P.win[w];
-    wave_sum_backsub_partials(P, (slots - 1) & 1, w, W.tile_begin, W.tile_end - W.tile_begin, ln, s4);
-    __syncthreads();
+    LmState f;
+    const bool already = final && P.decide_kernel;  // the per-slot launch of the last slot did it
+    if (!already) {
+        wave_sum_backsub_partials(P, slot & 1, w, W.tile_begin, W.tile_end - W.tile_begin, ln, s4);
+        __syncthreads();
+    }
     if (ln == 0) {
-        IterAcc a = P.acc[(long long)w * P.state_stride + slots - 1];
-        a.cand_cost += s4[0]; a.mcc += s4[1]; a.step_norm2 += s4[2]; a.cand_norm2 += s4[3];
-        const LmState f = lm_decide(P.states[(long long)w * P.state_stride + slots - 1], a, P.o);
-        P.states[(long long)w * P.state_stride + slots] = f;
-        FinalRec rec;
-        rec.s = f;
-        rec.fixed_cost = P.acc[(long long)w * P.state_stride].fixed_cost;
-        P.final_out[w] = rec;
+        if (already) f = P.states[(long long)w * P.state_stride + slot + 1];
+        else {
+            IterAcc a = P.acc[(long long)w * P.state_stride + slot];
+            a.cand_cost += s4[0]; a.mcc += s4[1]; a.step_norm2 += s4[2]; a.cand_norm2 += s4[3];
+            f = lm_decide(P.states[(long long)w * P.state_stride + slot], a, P.o);
+            P.states[(long long)w * P.state_stride + slot + 1] = f;
+        }
+        if (final) {
+            FinalRec rec;
+            rec.s = f;
+            rec.fixed_cost = P.acc[(long long)w * P.state_stride].fixed_cost;
+            P.final_out[w] = rec;
+        }
     }
 }
 
