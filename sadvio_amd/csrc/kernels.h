@@ -63,7 +63,7 @@ struct DevPtrs {
     int state_stride;
     int n_win;
     long long* dbg_ts;  // [64] phase timestamps (wall_clock64, 100 MHz) of workgroup 0 when debug & 4096
-    int debug;  // timing experiments only (SADVIO_DEBUG env): bit0 skip S blocks, bit1 skip flush, bit2 skip gradient
+    int debug;  // SADVIO_DEBUG env: bit 12 (4096) = in-kernel phase timestamps of workgroup 0 into dbg_ts (results unaffected)
     SolveOpts o;
 };
 
@@ -339,7 +339,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 __host__ __device__ inline size_t tile_tables_bytes(int n_kf) {
-    size_t b = sizeof(double) * ((size_t)n_kf * POSE_TAB + MAX_WIN_CAM * 17) + sizeof(int) * (size_t)MAX_TILE_KF;
+    // pose tables + camera tables + row table; a global-atomics tile may list up to 64 key-frames (> MAX_TILE_KF)
+    size_t b = sizeof(double) * ((size_t)n_kf * POSE_TAB + MAX_WIN_CAM * 17) + sizeof(int) * (size_t)(n_kf > MAX_TILE_KF ? n_kf : MAX_TILE_KF);
     return (b + 15) & ~(size_t)15;
 }
 
@@ -594,7 +595,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
         }
         // S blocks: lane a adds rows of Jp_a^T W_ab Jp_b for every partner b of its landmark whose block is
         // on or below the diagonal; W_ab = delta_ab I - N_a Jl_b^T
-        if (!(P.debug & 1)) {
+        {
             for (int b = 0; b < T.kmax; b++) {  // wave-uniform bound: the shuffle below is convergent
                 const int lb = grp * G + b;  // partner lane
                 const int pb = __shfl(L.row, lb, 64);
@@ -666,7 +667,6 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
         __syncthreads();
     }
     if (lds_mode) {
-        if (P.debug & 2) return;
         // flush non-zeros; in lds_mode rowTab rows are 6*rank with the list sorted by global index, so the
         // local lower triangle maps onto the global lower triangle. One wave per row, lanes along the row.
         int* growTab = (int*)stage;  // local row -> global row (stage strip is free now)
@@ -1294,7 +1294,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     }
     __syncthreads();
     if (st.done) return;
-    if (P.debug & 128) return;
     SADVIO_TS(3, 2);
     // Jacobi scaling (iteration 0) and LM diagonal; right-hand side into row Np of the packed matrix
     double* sp = P.s_pose + W.red_off;
@@ -1331,7 +1330,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             return;
         }
     }
-    if (P.debug & 256) return;
     SADVIO_TS(3, 4);
     // delta = -y ; candidate poses ; norms ; pose-only model cost
     double* dl = P.delta + W.red_off;
@@ -1359,7 +1357,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             if (fi >= 0) cn += v * v;
         }
         // pose table of the candidate buffer (k_backsub reads it now, k_build reads it if the step is accepted)
-        if (P.debug & 512) { for (int i = 0; i < POSE_TAB; i++) tab[i] = d6[i % 6]; } else
         pose_table_entry(P.kf_T0 + 12 * (long long)g, d6, tab);
         {
             double* dst = P.ptab + (long long)(1 - cur) * P.ptab_stride + (long long)g * POSE_TAB;

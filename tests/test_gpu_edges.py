@@ -1,0 +1,102 @@
+"""Edge cases of the window layout through the C ABI: maximum track lengths (every tile mode of k_build), windows
+without landmarks, mixed batches on the kernels that carry the rare paths, capacity errors."""
+import numpy as np
+import pytest
+
+from sadvio_amd import capi, synthetic
+from sparse_helpers import vio_sparse_priors
+from test_gpu_prior import random_prior
+from vio_helpers import make_vio_window
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-6
+LMK_TOL = 1e-5
+
+
+def agree(be, k, w, ref, s, vio=False):
+    d = be.get_deltas(k)
+    rs = ref["summary"]
+    assert (s.iterations, s.termination) == (rs.iterations, rs.termination)
+    assert np.isclose(s.final_cost, rs.final_cost, rtol=1e-9)
+    assert np.abs(d["pose"] - ref["pose"]).max() <= POSE_TOL
+    assert d["lmk"].size == 0 or np.abs(d["lmk"] - ref["lmk"]).max() <= LMK_TOL
+    if vio:
+        for q in ("dv", "dba", "dbg"):
+            assert np.abs(d[q] - ref[q]).max() <= POSE_TOL
+
+
+@pytest.mark.parametrize("obs_per_lmk", [12, 40, 64])
+def test_long_tracks_use_every_tile_mode(backend_cls, oracle_lib, obs_per_lmk):
+    """12 views: LDS tiles with ds_add_f64; 40 / 64 views (= MAX_LMK_OBS, one wave per landmark): more than 20 free
+    key-frames per tile -> global-atomics tiles."""
+    w = synthetic.make_window(n_kf=34, n_lmk=120, obs_per_lmk=obs_per_lmk, seed=91, length=6.0)
+    assert np.diff(w.lmk_obs_ptr).max() == obs_per_lmk
+    opts = capi.reference_options()
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    s = be.solve(opts)[0]
+    agree(be, 0, w, oracle_lib.solve(w, opts), s)
+    be.close()
+
+
+def test_capacity_errors(backend_cls):
+    w = synthetic.make_window(n_kf=34, n_lmk=50, obs_per_lmk=64, seed=92, length=6.0)
+    # a 65th observation of landmark 0
+    w.obs_kf = np.insert(w.obs_kf, 0, w.obs_kf[0]); w.obs_cam = np.insert(w.obs_cam, 0, w.obs_cam[0])
+    w.obs_meas = np.insert(w.obs_meas, 0, w.obs_meas[0], axis=0)
+    w.lmk_obs_ptr = w.lmk_obs_ptr.copy(); w.lmk_obs_ptr[1:] += 1
+    be = backend_cls(device=0)
+    with pytest.raises(capi.SadvioError, match="64 observations"):
+        be.set_windows([w])
+    w = synthetic.make_window(n_kf=3, n_lmk=20, seed=1)
+    w.cam_K = np.tile(w.cam_K, (5, 1)); w.cam_T_s_f = np.tile(w.cam_T_s_f, (5, 1)); w.cam_sigma = np.tile(w.cam_sigma, 5)
+    with pytest.raises(capi.SadvioError, match="8 cameras"):
+        be.set_windows([w])
+    be.close()
+
+
+def test_window_without_landmarks_inertial_only(backend_cls, oracle_lib):
+    """No visual factor at all: pose priors + IMU chain (the reduced system is only built by the solve kernel)."""
+    w = make_vio_window(n_kf=5, n_lmk=40, seed=93)
+    w.lmk_p = np.zeros((0, 3)); w.lmk_obs_ptr = np.zeros(1, dtype=np.int32); w.lmk_id = np.zeros(0, dtype=np.int64)
+    w.obs_kf = np.zeros(0, dtype=np.int32); w.obs_cam = np.zeros(0, dtype=np.int32); w.obs_meas = np.zeros((0, 2))
+    w._keep = []
+    for k in range(w.n_kf - 1):  # anchor every frame weakly, else the problem is rank deficient
+        w.pose_priors.append((k, w.kf_T_f_w[k].copy(), 3.0 * np.ones(6)))
+    opts = capi.reference_options()
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    s = be.solve(opts)[0]
+    agree(be, 0, w, oracle_lib.solve(w, opts), s, vio=True)
+    be.close()
+
+
+def test_mixed_vio_batch_on_the_extras_kernels(backend_cls, oracle_lib):
+    """One submission: a plain VIO window, one with a dense prior, one with sparse prior factors."""
+    wa = make_vio_window(n_kf=5, n_lmk=200, seed=94)
+    wb = make_vio_window(n_kf=6, n_lmk=250, seed=95)
+    wb.dense_prior = random_prior(wb, 15, wb.n_kf - 2, np.random.default_rng(6))
+    wc = make_vio_window(n_kf=5, n_lmk=200, seed=96)
+    wc.sparse_priors = vio_sparse_priors(wc, wc.n_kf - 2, list(range(0, 30, 2)), np.random.default_rng(7), noise=0.05)
+    opts = capi.reference_options()
+    be = backend_cls(device=0)
+    be.set_windows([wa, wb, wc])
+    sums = be.solve(opts)
+    agree(be, 0, wa, oracle_lib.solve(wa, opts), sums[0], vio=True)
+    agree(be, 1, wb, oracle_lib.solve(wb, opts, dense_prior=wb.dense_prior), sums[1], vio=True)
+    agree(be, 2, wc, oracle_lib.solve(wc, opts), sums[2], vio=True)
+    be.close()
+
+
+def test_huber_loss_with_kept_landmarks(backend_cls, oracle_lib):
+    """Robust loss and prior-kept landmarks together (k_build_kept applies the same corrector)."""
+    from frontend_helpers import with_outliers
+    w = with_outliers(synthetic.make_window(n_kf=6, n_lmk=300, seed=97), frac=0.08, seed=5)
+    w.dense_prior = random_prior(w, 15, -1, np.random.default_rng(8))
+    opts = capi.reference_options(); opts.huber_a = 1.345 ** 0.5
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    s = be.solve(opts)[0]
+    agree(be, 0, w, oracle_lib.solve(w, opts, dense_prior=w.dense_prior), s)
+    be.close()
