@@ -107,6 +107,7 @@ struct sadvio_ba_handle {
     int factor_type = 0;
     int max_n_kf = 0, max_npose = 0, max_np = 0, n_big = 0;
     DevBuf<int> d_big_info;
+    DevBuf<double> d_big_linv;  // inverse pivot blocks of the banded solver, N * NB doubles per out-of-LDS window
     bool uploaded = false, solved = false;
     // window sharded over several GPUs: collective hook (user callback or the built-in RCCL one)
     int world = 1, rank = 0;
@@ -1447,6 +1448,12 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         for (int w = 0; w < n_win; w++)
             for (int r = 0; r < h->world; r++) big_bw[w] = std::max(big_bw[w], (int)slots[((size_t)w * h->world + r) * 4]);
     }
+    std::vector<long long> big_linv_off(n_win, 0);
+    {
+        long long tot = 0;
+        for (int w = 0; w < n_win; w++) if (h->wins[w].d.ld) { big_linv_off[w] = tot; tot += 6LL * h->wins[w].d.Np; }
+        HIP_TRY(h->d_big_linv.alloc((size_t)std::max<long long>(tot, 1)));
+    }
     bool coll_failed = false;
     auto enqueue = [&]() {
         { ScopedTimer t(h, "k_reset"); hipLaunchKernelGGL(k_reset, dim3(reset_blocks), dim3(256), 0, h->stream, P); }
@@ -1464,8 +1471,9 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             if (h->n_big) {
                 { ScopedTimer t(h, "k_solve_front"); hipLaunchKernelGGL(ks1, dim3(n_win), dim3(SOLVE_THREADS), 64, h->stream, P, s); }
                 {
-                    // blocked Cholesky + solve of S, gred in place (dense_chol.h): two launches per 32 columns
-                    ScopedTimer t(h, "k_chol_panel+update+backsolve");
+                    // Cholesky + solve of S, gred in place (dense_chol.h): banded systems by one sliding-window launch,
+                    // dense ones (a dense prior fills the kept-landmark block) by two launches per 32 columns
+                    ScopedTimer t(h, "reduced_cholesky_solve");
                     for (int w = 0; w < n_win; w++) {
                         const WinDev& d = h->wins[w].d;
                         if (!d.ld) continue;
@@ -1474,6 +1482,19 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                         int* info = h->d_big_info.p + w;
                         const int* skip = (const int*)((const char*)(h->d_states.p + (size_t)w * stride + s) + offsetof(LmState, done));
                         const int N = d.Np, bw = big_bw[w];
+                        const int nb = d.dpf == 6 ? 6 : 5;
+                        if (bw < N && bw + nb <= MAX_LDS_NP) {
+                            // block-banded system: one workgroup slides an LDS window down the band (dense_chol.h)
+                            const int C = std::max(nb, std::min(bw, MAX_LDS_NP - bw) / nb * nb);  // measured: C = bw beats the largest window that fits
+                            const int Rmax = bw + C;
+                            const size_t lds = sizeof(double) * ((size_t)(Rmax + 2) * 6 + (size_t)(Rmax + 1) * (Rmax + 2) / 2 + 2 * (size_t)Rmax +
+                                                                 (size_t)(Rmax / nb + 1) * nb * nb) + 64;
+                            auto kbs = d.dpf == 6 ? k_band_solve<6> : k_band_solve<5>;
+                            (void)hipFuncSetAttribute((const void*)kbs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                            hipLaunchKernelGGL(kbs, dim3(1), dim3(SOLVE_THREADS), lds, h->stream, Sw, (long long)d.ld, yw, h->d_big_linv.p + big_linv_off[w],
+                                               N, bw, C, info, skip);
+                            continue;
+                        }
                         for (int k0 = 0; k0 < N; k0 += CH_NB) {
                             const int nb = std::min(CH_NB, N - k0), s0 = k0 + nb;
                             const int rows_end = std::min(N, s0 + bw), m = rows_end - s0;

@@ -249,4 +249,172 @@ __global__ __launch_bounds__(CH_THREADS) void k_chol_backsolve(const double* __r
     }
 }
 
+
+// ---- block-banded systems: sliding LDS window over the tuned in-LDS factorisation ----------------------------------
+// A long trajectory gives a block-banded S (half bandwidth bw scalars, known on the host). A window of R = bw + C
+// rows is held packed in LDS; chol_solve_packed<NB, PARTIAL> eliminates its first C columns (their L entries only
+// reach bw rows further down, so they are final) and leaves the updated bw x bw Schur complement, which is carried
+// to the top-left corner of the next window while the new rows are loaded from HBM. L (off-diagonal blocks) is
+// written in place, the inverse pivot blocks to `linv_g`, the right-hand side rides along as the extra row. The
+// backward pass walks the windows in reverse. ONE launch per solve instead of 2 N / 32: the whole factorisation is a
+// single workgroup -- the dependency chain of a banded Cholesky is sequential anyway.
+// packed lower-triangle index g -> (row i, column j <= i)
+__device__ __forceinline__ void tri_decode(int g, int& i, int& j) {
+    i = (int)((sqrt(8.0 * (double)g + 1.0) - 1.0) * 0.5);
+    while (tri(i + 1, 0) <= g) i++;
+    while (tri(i, 0) > g) i--;
+    j = g - tri(i, 0);
+}
+
+template <int NB>
+__global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(double* __restrict__ A, long long ld, double* __restrict__ y,
+                                                              double* __restrict__ linv_g, int N, int bw, int C, int* info,
+                                                              const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    if (*info != 0) return;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int Rmax = bw + C;
+    double* LpT = (double*)smem;                              // [NBP][Rmax + 2]
+    double* Pk = LpT + (size_t)(Rmax + 2) * NBP;              // packed window incl. rhs row
+    double* xv = Pk + (size_t)(Rmax + 1) * (Rmax + 2) / 2;   // [Rmax] work vector of the backward pass
+    double* xs = xv + Rmax;                                   // [Rmax]
+    double* linvTab = xs + Rmax;                              // [Rmax / NB][NB * NB]
+    __shared__ int s_fail;
+    if (tid == 0) s_fail = 0;
+    int carried = 0, Rprev = 0, Cprev = 0;
+    for (int c0 = 0; c0 < N; c0 += C) {
+        const int Cw = min(C, N - c0);
+        const int R = min(bw + Cw, N - c0);
+        // (1) carry: old (i + Cprev, j + Cprev) -> new (i, j) for i, j < carried, rhs row likewise; through registers
+        {
+            constexpr int MAXC = (MAX_LDS_NP * (MAX_LDS_NP + 1) / 2 + MAX_LDS_NP + SOLVE_THREADS - 1) / SOLVE_THREADS;
+            double v[MAXC];
+            const int ntri = carried * (carried + 1) / 2;
+            const int nc = ntri + carried;  // + the rhs entries
+#pragma unroll
+            for (int q = 0; q < MAXC; q++) {
+                const int e = tid + q * SOLVE_THREADS;
+                if (e < nc) {
+                    int i, j;
+                    if (e < ntri) { tri_decode(e, i, j); v[q] = Pk[tri(i + Cprev, j + Cprev)]; }
+                    else v[q] = Pk[tri(Rprev, e - ntri + Cprev)];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < MAXC; q++) {
+                const int e = tid + q * SOLVE_THREADS;
+                if (e < nc) Pk[e < ntri ? e : tri(R, e - ntri)] = v[q];
+            }
+        }
+        // (2) fresh rows [carried, R) from HBM (zero outside the band by construction of A); the packed index runs
+        //     linearly, four independent loads in flight per thread
+        {
+            const int g0 = tri(carried, 0), g1 = tri(R, 0);
+            for (int gb = g0 + tid; gb < g1; gb += 4 * nt) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int g = gb + u * nt;
+                    if (g < g1) { int i, j; tri_decode(g, i, j); v[u] = A[(long long)(c0 + i) * ld + c0 + j]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int g = gb + u * nt;
+                    if (g < g1) Pk[g] = v[u];
+                }
+            }
+        }
+        for (int j = carried + tid; j < R; j += nt) Pk[tri(R, j)] = y[c0 + j];
+        if (tid == 0) Pk[tri(R, R)] = 0.0;
+        __syncthreads();
+        // (3) eliminate the first Cw columns
+        const int nsteps = Cw / NB;
+        const bool ok = chol_solve_packed<NB, true>(Pk, R, xv, xs, LpT, linvTab, nullptr, nsteps);
+        __syncthreads();
+        if (!ok) { if (tid == 0) *info = c0 + 1; return; }
+        // (4) file L (rows below each pivot block), the inverse pivot blocks and the substituted rhs
+        for (int g = tid; g < tri(R, 0); g += nt) {
+            int i, j;
+            tri_decode(g, i, j);
+            if (j < min(Cw, (i / NB) * NB)) A[(long long)(c0 + i) * ld + c0 + j] = Pk[g];  // left of row i's own pivot block
+        }
+        for (int e = tid; e < nsteps * NB * NB; e += nt) linv_g[(long long)(c0 / NB) * NB * NB + e] = linvTab[e];
+        for (int j = tid; j < Cw; j += nt) y[c0 + j] = Pk[tri(R, j)];
+        carried = R - Cw; Rprev = R; Cprev = Cw;
+        __syncthreads();
+    }
+    // backward pass: x = L^-T z, windows in reverse. The L entries were stored over addresses this CU has read before:
+    // drop possibly stale L1 lines first.
+    __threadfence();
+    __syncthreads();
+    const int nwin = (N + C - 1) / C;
+    for (int wi = nwin - 1; wi >= 0; wi--) {
+        const int c0 = wi * C;
+        const int Cw = min(C, N - c0);
+        const int R = min(bw + Cw, N - c0);
+        const int nsteps = Cw / NB;
+        {
+            const int g1 = tri(R, 0);
+            for (int gb = tid; gb < g1; gb += 4 * nt) {
+                double v[4];
+                bool use[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int g = gb + u * nt;
+                    use[u] = false;
+                    if (g < g1) {
+                        int i, j;
+                        tri_decode(g, i, j);
+                        use[u] = j < min(Cw, (i / NB) * NB);
+                        if (use[u]) v[u] = A[(long long)(c0 + i) * ld + c0 + j];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (use[u]) Pk[gb + u * nt] = v[u];
+            }
+        }
+        for (int e = tid; e < nsteps * NB * NB; e += nt) linvTab[e] = linv_g[(long long)(c0 / NB) * NB * NB + e];
+        for (int i = tid; i < R; i += nt) xv[i] = y[c0 + i];  // i < Cw: z, i >= Cw: x already solved
+        __syncthreads();
+        // rows below the window's columns: x[j] -= sum_{i >= Cw} L[i][j] x_i
+        for (int j = tid; j < Cw; j += nt) {
+            double t = xv[j];
+            for (int i = Cw; i < R; i++) t -= Pk[tri(i, j)] * xv[i];
+            xs[j] = t;
+        }
+        __syncthreads();
+        for (int j = tid; j < Cw; j += nt) xv[j] = xs[j];
+        __syncthreads();
+        for (int k = nsteps - 1; k >= 0; k--) {
+            const int b0 = k * NB;
+            double xk[NB];
+#pragma unroll
+            for (int cc = 0; cc < NB; cc++) {
+                double t = 0.0;
+#pragma unroll
+                for (int q = cc; q < NB; q++) t += linvTab[k * NB * NB + q * NB + cc] * xv[b0 + q];
+                xk[cc] = t;
+            }
+            if (tid < NB) {
+                double v = xk[0];
+#pragma unroll
+                for (int cc = 1; cc < NB; cc++) if (tid == cc) v = xk[cc];
+                xs[b0 + tid] = v;
+            }
+            for (int j = tid; j < b0; j += nt) {
+                double t = xv[j];
+#pragma unroll
+                for (int cc = 0; cc < NB; cc++) t -= Pk[tri(b0 + cc, j)] * xk[cc];
+                xv[j] = t;
+            }
+            __syncthreads();
+        }
+        for (int j = tid; j < Cw; j += nt) y[c0 + j] = xs[j];
+        __syncthreads();
+    }
+}
+
 }  // namespace sadvio

@@ -798,7 +798,7 @@ __device__ __forceinline__ void pivot_gather_factor(const double* P, const doubl
 // TIL 16x16 tiles (pair indices pp, pp + stride, ...) of the trailing update C -= Lp_i Lp_j^T on the FP64 matrix
 // cores; every LDS load is unconditional (clamped address), masking happens on the loaded values.
 template <int NB, int TIL>
-__device__ __forceinline__ void trail_tiles(double* P, const double* LpT, int ldp, int s, int m, int pp0, int stride, int lr, int lk) {
+__device__ __forceinline__ void trail_tiles(double* P, const double* LpT, int ldp, int s, int m, int pp0, int stride, int lr, int lk, int rmin) {
     typedef double d4 __attribute__((ext_vector_type(4)));
     d4 c[TIL];
     double a0[TIL], b0[TIL], a1[TIL], b1[TIL];
@@ -818,7 +818,7 @@ __device__ __forceinline__ void trail_tiles(double* P, const double* LpT, int ld
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
             const int row = i0 + lk + 4 * rg;
-            okr[u][rg] = row < m && row >= NB && col <= row && col < m - 1;
+            okr[u][rg] = row < m && row >= rmin && col <= row && col < m - 1;
             const int rowc = row < m ? row : m - 1;
             const int colc = col <= rowc ? col : rowc;
             addr[u][rg] = tri(s + rowc, s + colc);
@@ -839,11 +839,13 @@ __device__ __forceinline__ void trail_tiles(double* P, const double* LpT, int ld
             if (okr[u][rg]) P[addr[u][rg]] = c[u][rg];
 }
 
-template <int NB>
+// PARTIAL: only the first `nsteps` block columns are eliminated (the rest of the matrix is left as the updated
+// Schur complement, pivot blocks included) and no back-substitution is done: one window of the block-banded solver.
+template <int NB, bool PARTIAL = false>
 __device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, double* xs, double* LpT,
-                                                  double* linvTab, long long* ts) {
+                                                  double* linvTab, long long* ts, int nsteps = 0) {
     const int tid = threadIdx.x, nt = blockDim.x, ln = tid & 63;
-    const int nblk = N / NB;
+    const int nblk = PARTIAL ? nsteps : N / NB;
     const int ldp = N + 2;
     __shared__ int s_bad;
     if (tid == 0) s_bad = 0;
@@ -904,9 +906,12 @@ __device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, d
             // full groups of 4 tiles per wave are processed together (all LDS loads first, independent and back to
             // back, then the MFMAs, then the stores: the tiles of one step are disjoint and the strip is read-only
             // here); the remainder one tile at a time
+            // the next pivot block is updated by the pivot wave (look-ahead); the last step of a partial
+            // factorisation has no look-ahead, so the bulk waves update those rows as well
+            const int rmin = (PARTIAL && k + 1 == nblk) ? 0 : NB;
             int pp = bw;
-            for (; pp + 3 * nbw < npair; pp += 4 * nbw) trail_tiles<NB, 4>(P, LpT, ldp, s, m, pp, nbw, lr, lk);
-            for (; pp < npair; pp += nbw) trail_tiles<NB, 1>(P, LpT, ldp, s, m, pp, nbw, lr, lk);
+            for (; pp + 3 * nbw < npair; pp += 4 * nbw) trail_tiles<NB, 4>(P, LpT, ldp, s, m, pp, nbw, lr, lk, rmin);
+            for (; pp < npair; pp += nbw) trail_tiles<NB, 1>(P, LpT, ldp, s, m, pp, nbw, lr, lk, rmin);
             if (ts && k == 2 && tid == 64) ts[12] = wall_clock64();
         }
         __syncthreads();
@@ -914,6 +919,7 @@ __device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, d
     }
     if (ts && tid == 0) ts[14] = wall_clock64();
     if (s_bad) return false;
+    if (PARTIAL) return true;
     // --- block back-substitution: xs = L^-T y, y = row N of P; one barrier per block ---
     for (int i = tid; i < N; i += nt) x[i] = P[tri(N, i)];
     __syncthreads();
