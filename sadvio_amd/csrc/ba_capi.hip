@@ -311,7 +311,7 @@ int layout_reduced(sadvio_ba_handle* h) {
             dp_data.insert(dp_data.end(), D.J.begin(), D.J.end());
             dp_data.resize(dp_data.size() + (size_t)n * nf + (size_t)n * n, 0.0);  // Jt, H: filled on the device
             dp_data.insert(dp_data.end(), D.r0.begin(), D.r0.end());
-            dp_data.resize(dp_data.size() + (size_t)n + nf, 0.0);                 // dx, r scratch
+            dp_data.resize(dp_data.size() + (size_t)n + nf + 1, 0.0);             // dx, r scratch, cost slot
             if (dp_data.size() & 1) dp_data.push_back(0.0);
         }
         // landmarks touched by sparse prior factors stay in the reduced system as well
@@ -1454,6 +1454,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         for (int w = 0; w < n_win; w++) if (h->wins[w].d.ld) { big_linv_off[w] = tot; tot += 6LL * h->wins[w].d.Np; }
         HIP_TRY(h->d_big_linv.alloc((size_t)std::max<long long>(tot, 1)));
     }
+    int dp_max_nf = 0, dp_max_n = 0;
+    for (int w = 0; w < n_win; w++) { dp_max_nf = std::max(dp_max_nf, h->wins[w].d.dp_n_full); dp_max_n = std::max(dp_max_n, h->wins[w].d.dp_n); }
     bool coll_failed = false;
     auto enqueue = [&]() {
         { ScopedTimer t(h, "k_reset"); hipLaunchKernelGGL(k_reset, dim3(reset_blocks), dim3(256), 0, h->stream, P); }
@@ -1461,6 +1463,12 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         for (int s = 0; s < slots; s++) {
             { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
             if (h->n_kept) { ScopedTimer t(h, "k_build_kept"); hipLaunchKernelGGL(kbk, dim3((h->n_kept + 127) / 128), dim3(128), 0, h->stream, P, s); }
+            if (dp_max_nf > 0) {
+                ScopedTimer t(h, "k_prior_r+gh");
+                const int colb = (dp_max_n + 3) / 4;
+                hipLaunchKernelGGL(k_prior_r, dim3((dp_max_nf + 3) / 4, n_win), dim3(256), 0, h->stream, P, s);
+                hipLaunchKernelGGL(k_prior_gh, dim3(colb + (unsigned)(((long long)dp_max_n * dp_max_n + 255) / 256), n_win), dim3(256), 0, h->stream, P, s, colb);
+            }
             if (h->coll_fn) {
                 // the window spans devices: gather the per-rank partial sums and all-reduce the reduced system
                 { ScopedTimer t(h, "k_rank_partials"); hipLaunchKernelGGL(k_rank_partials, dim3(n_win), dim3(64), 0, h->stream, P, s, 0); }
@@ -1515,6 +1523,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                     if (d.ld) (void)hipMemsetAsync(h->d_S.p + d.S_off, 0, sizeof(double) * (size_t)d.Np * d.Np, h->stream);
                 }
             }
+            if (dp_max_nf > 0) { ScopedTimer t(h, "k_prior_m"); hipLaunchKernelGGL(k_prior_m, dim3((dp_max_nf + 3) / 4, n_win), dim3(256), 0, h->stream, P, s); }
             { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
             if (h->coll_fn) {
                 { ScopedTimer t(h, "k_rank_partials"); hipLaunchKernelGGL(k_rank_partials, dim3(n_win), dim3(64), 0, h->stream, P, s, 1); }
@@ -1529,7 +1538,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         // the whole <= 20-iteration solve is one graph launch; the key covers every kernel argument
         std::vector<int> lay;  // layout-dependent launch parameters of the out-of-LDS windows
         for (int w = 0; w < n_win; w++) { lay.push_back(h->wins[w].d.Np); lay.push_back(h->wins[w].d.ld); lay.push_back(big_bw[w]); }
-        lay.push_back(h->n_kept); lay.push_back(h->n_big);
+        lay.push_back(h->n_kept); lay.push_back(h->n_big); lay.push_back(dp_max_nf); lay.push_back(dp_max_n);
         std::vector<unsigned char> key(sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t) + lay.size() * sizeof(int));
         unsigned char* kp = key.data();
         memcpy(kp + sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t), lay.data(), lay.size() * sizeof(int));

@@ -1224,48 +1224,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
         }
     }
-    // dense marginalisation prior (K4 / a9): r = r0 + J dx, J constant. H = J^T J and J^T were formed once
-    // at upload; per step two wave-per-row GEMVs (r, J^T r) and the scatter of H through the column map.
-    if (EXTRAS && W.dp_n_full > 0) {
-        __syncthreads();
-        const int n = W.dp_n, nf = W.dp_n_full;
-        double* D = P.dp_data + W.dp_off;
-        const double* Jm = D;
-        const double* Jt = Jm + (size_t)nf * n;
-        const double* Hm = Jt + (size_t)n * nf;
-        const double* r0 = Hm + (size_t)n * n;
-        double* dxv = D + 2 * (size_t)nf * n + (size_t)n * n + nf;
-        double* rv = dxv + n;
-        const int* kind = P.dp_ints + W.dp_int_off;
-        const int* index = kind + n;
-        const int* col = index + n;
-        const double* srcs[5] = {xp, P.xv + (long long)cur * P.xv_stride, P.xba + (long long)cur * P.xv_stride,
-                                 P.xbg + (long long)cur * P.xv_stride, P.xl + (long long)cur * P.xl_stride};
-        for (int a = tid; a < n; a += blockDim.x) dxv[a] = kind[a] < 0 ? 0.0 : srcs[kind[a]][index[a]];
-        __syncthreads();
-        for (int i = wv; i < nf; i += nwv) {
-            double s = 0.0;
-            for (int a = ln; a < n; a += 64) s += Jm[(size_t)i * n + a] * dxv[a];
-            s = wave_sum(s);
-            if (ln == 0) { s += r0[i]; rv[i] = s; cost_part += s * s; }
-        }
-        __syncthreads();
-        for (int a = wv; a < n; a += nwv) {
-            const int ca = col[a];
-            if (ca < 0) continue;
-            double g = 0.0;
-            for (int i = ln; i < nf; i += 64) g += Jt[(size_t)a * nf + i] * rv[i];
-            g = wave_sum(g);
-            if (ln == 0) { y[ca] += g; gf[ca] += g; hd[ca] += Hm[(size_t)a * n + a]; }
-        }
-        for (long long idx = tid; idx < (long long)n * n; idx += blockDim.x) {
-            const int a = (int)(idx / n), b = (int)(idx - (long long)a * n);
-            if (b > a) continue;
-            const int ca = col[a], cb = col[b];
-            if (ca < 0 || cb < 0) continue;
-            A[ca >= cb ? aidx(ca, cb) : aidx(cb, ca)] += Hm[idx];
-        }
-        __syncthreads();
+    // dense marginalisation prior (K4 / a9): its gradient, diagonal and J^T J were added to gred / gfull / hdiag / S
+    // by the wide kernels k_prior_r / k_prior_gh before this kernel; only its cost is picked up here
+    if (EXTRAS && W.dp_n_full > 0 && tid == 0) {
+        double* pc = P.dp_data + W.dp_off + 2 * (size_t)W.dp_n_full * W.dp_n + (size_t)W.dp_n * W.dp_n + W.dp_n_full + W.dp_n + W.dp_n_full;
+        cost_part += pc[0];
+        pc[0] = 0.0;
     }
     // window totals of the linearisation: tiles' k_build partials + the pose-only factors evaluated here
     double gm = 0.0;
@@ -1485,23 +1449,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             for (int q = 0; q < rows; q++) cc += r[q] * r[q];
         }
     }
-    if (EXTRAS && W.dp_n_full > 0) {
-        // model cost change and candidate cost of the dense prior: m = J delta, r_cand = r + m
-        const int n = W.dp_n, nf = W.dp_n_full;
-        double* D = P.dp_data + W.dp_off;
-        const double* Jm = D;
-        double* dxv = D + 2 * (size_t)nf * n + (size_t)n * n + nf;
-        const double* rv = dxv + n;
-        const int* col = P.dp_ints + W.dp_int_off + 2 * n;
-        for (int a = tid; a < n; a += blockDim.x) dxv[a] = col[a] >= 0 ? y[col[a]] : 0.0;
-        __syncthreads();
-        for (int i = wv; i < nf; i += nwv) {
-            double m = 0.0;
-            for (int a = ln; a < n; a += 64) m += Jm[(size_t)i * n + a] * dxv[a];
-            m = wave_sum(m);
-            if (ln == 0) { mcc += -m * (rv[i] + 0.5 * m); cc += (rv[i] + m) * (rv[i] + m); }
-        }
-    }
     SADVIO_TS(3, 7);
     sn = wave_sum(sn); cn = wave_sum(cn); mcc = wave_sum(mcc); cc = wave_sum(cc);
     if (bad) acc->chol_fail = 1;
@@ -1645,6 +1592,121 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
         for (int k = 0; k < BUILD_WAVES; k++) { a0 += s_part[k * 4]; a1 += s_part[k * 4 + 1]; a2 += s_part[k * 4 + 2]; a3 += s_part[k * 4 + 3]; }
         TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + blockIdx.x;
         ta->cand_cost = a0; ta->mcc = a1; ta->step_norm2 = a2; ta->cand_norm2 = a3;
+    }
+}
+
+// ---- dense marginalisation prior (MarginalizationFactor, marginalization.hpp:113-215) on many workgroups ----------
+// J (n_full x n, several MB) is streamed by the whole chip instead of one workgroup: per LM step
+//   k_prior_r   r = r0 + J dx (one wave per row), cost = sum r^2                      -> dp scratch, dp cost slot
+//   k_prior_gh  g = J^T r into gred / gfull, diag(J^T J) into hdiag (one wave per column); J^T J into S (one thread
+//               per element, plain read-modify-write: nothing else touches S between k_build and k_solve)
+//   k_prior_m   after the step: m = J delta (one wave per row) -> model cost change / candidate cost of the slot
+// dp_data layout per window: J | J^T | J^T J | r0 | dx | r | cost(1).
+__device__ __forceinline__ double* dp_ptr(const DevPtrs& P, const WinDev& W, int which) {
+    const size_t nf = W.dp_n_full, n = W.dp_n;
+    double* D = P.dp_data + W.dp_off;
+    switch (which) {
+        case 0: return D;                                  // J
+        case 1: return D + nf * n;                         // J^T
+        case 2: return D + 2 * nf * n;                     // H
+        case 3: return D + 2 * nf * n + n * n;             // r0
+        case 4: return D + 2 * nf * n + n * n + nf;        // dx
+        case 5: return D + 2 * nf * n + n * n + nf + n;    // r
+        default: return D + 2 * nf * n + n * n + 2 * nf + n;  // cost
+    }
+}
+
+__global__ __launch_bounds__(256) void k_prior_r(DevPtrs P, int slot) {
+    const int w = blockIdx.y;
+    const WinDev W = P.win[w];
+    if (W.dp_n_full == 0) return;
+    const LmState st = P.states[(long long)w * P.state_stride + slot];
+    if (st.done) return;
+    const int n = W.dp_n, nf = W.dp_n_full, ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wv;
+    __shared__ double s_c[4];
+    double c = 0.0;
+    if (i < nf) {
+        const double* J = dp_ptr(P, W, 0);
+        const int* kind = P.dp_ints + W.dp_int_off;
+        const int* index = kind + n;
+        const int cur = st.cur;
+        const double* srcs[5] = {P.xp + (long long)cur * P.xp_stride, P.xv + (long long)cur * P.xv_stride, P.xba + (long long)cur * P.xv_stride,
+                                 P.xbg + (long long)cur * P.xv_stride, P.xl + (long long)cur * P.xl_stride};
+        double s = 0.0;
+        for (int a = ln; a < n; a += 64) {
+            const int k = kind[a];
+            const double dx = k < 0 ? 0.0 : srcs[k][index[a]];
+            s += J[(size_t)i * n + a] * dx;
+        }
+        s = wave_sum(s);
+        if (ln == 0) { s += dp_ptr(P, W, 3)[i]; dp_ptr(P, W, 5)[i] = s; c = s * s; }
+    }
+    if (ln == 0) s_c[wv] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_add_f64(dp_ptr(P, W, 6), s_c[0] + s_c[1] + s_c[2] + s_c[3]);
+}
+
+__global__ __launch_bounds__(256) void k_prior_gh(DevPtrs P, int slot, int col_blocks) {
+    const int w = blockIdx.y;
+    const WinDev W = P.win[w];
+    if (W.dp_n_full == 0) return;
+    if (P.states[(long long)w * P.state_stride + slot].done) return;
+    const int n = W.dp_n, nf = W.dp_n_full;
+    const int* col = P.dp_ints + W.dp_int_off + 2 * n;
+    const double* H = dp_ptr(P, W, 2);
+    if ((int)blockIdx.x < col_blocks) {
+        const int ln = threadIdx.x & 63, a = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (a >= n) return;
+        const int ca = col[a];
+        if (ca < 0) return;
+        const double* Jt = dp_ptr(P, W, 1);
+        const double* r = dp_ptr(P, W, 5);
+        double g = 0.0;
+        for (int i = ln; i < nf; i += 64) g += Jt[(size_t)a * nf + i] * r[i];
+        g = wave_sum(g);
+        if (ln == 0) {
+            P.gred[W.red_off + ca] += g; P.gfull[W.red_off + ca] += g; P.hdiag[W.red_off + ca] += H[(size_t)a * n + a];
+        }
+        return;
+    }
+    const long long idx = (long long)(blockIdx.x - col_blocks) * 256 + threadIdx.x;
+    if (idx >= (long long)n * n) return;
+    const int a = (int)(idx / n), b = (int)(idx - (long long)a * n);
+    if (b > a) return;
+    const int ca = col[a], cb = col[b];
+    if (ca < 0 || cb < 0) return;
+    double* Sg = P.S + W.S_off;
+    Sg[ca >= cb ? s_index(W.ld, ca, cb) : s_index(W.ld, cb, ca)] += H[idx];
+}
+
+__global__ __launch_bounds__(256) void k_prior_m(DevPtrs P, int slot) {
+    const int w = blockIdx.y;
+    const WinDev W = P.win[w];
+    if (W.dp_n_full == 0) return;
+    IterAcc* acc = P.acc + (long long)w * P.state_stride + slot;
+    if (P.states[(long long)w * P.state_stride + slot].done || acc->chol_fail) return;
+    const int n = W.dp_n, nf = W.dp_n_full, ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wv;
+    __shared__ double s_m[4], s_c[4];
+    double mc = 0.0, cc = 0.0;
+    if (i < nf) {
+        const double* J = dp_ptr(P, W, 0);
+        const int* col = P.dp_ints + W.dp_int_off + 2 * n;
+        const double* dl = P.delta + W.red_off;
+        double m = 0.0;
+        for (int a = ln; a < n; a += 64) {
+            const int ca = col[a];
+            if (ca >= 0) m += J[(size_t)i * n + a] * dl[ca];
+        }
+        m = wave_sum(m);
+        if (ln == 0) { const double r = dp_ptr(P, W, 5)[i]; mc = -m * (r + 0.5 * m); cc = (r + m) * (r + m); }
+    }
+    if (ln == 0) { s_m[wv] = mc; s_c[wv] = cc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomic_add_f64(&acc->mcc, s_m[0] + s_m[1] + s_m[2] + s_m[3]);
+        atomic_add_f64(&acc->cand_cost, s_c[0] + s_c[1] + s_c[2] + s_c[3]);
     }
 }
 
