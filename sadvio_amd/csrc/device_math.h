@@ -415,7 +415,9 @@ __device__ __forceinline__ void pose_to_landmark_factor(const double* T0, const 
 // J (optional) is the whitened 9x24 Jacobian, row-major. Quirks kept as coded: the pose_i translation block
 // uses the UNperturbed R_i0 (:185), [6:9,0:3] of pose_i uses p_j instead of p_j - p_i (:181-184), pose_j's
 // translation block uses exp(w_j)^T (:198).
-template <typename ImuT>
+// WHITEN = false leaves the UN-whitened 9x24 Jacobian in J (the caller multiplies by W with many threads); r is
+// whitened in both cases.
+template <typename ImuT, bool WHITEN = true>
 __device__ __noinline__ void imu_factor(const ImuT& f, const double* Ti0, const double* Tj0, const double* vi0,
                                         const double* vj0, const double* dpi, const double* dpj, const double* dvi,
                                         const double* dvj, const double* dba, const double* dbg, double* r, double* J) {
@@ -461,7 +463,8 @@ __device__ __noinline__ void imu_factor(const ImuT& f, const double* Ti0, const 
         r[q] = s;
     }
     if (!J) return;
-    double U[9 * 24];  // un-whitened Jacobian
+    double Uloc[WHITEN ? 9 * 24 : 1];  // un-whitened Jacobian
+    double* U = WHITEN ? Uloc : J;
     for (int i = 0; i < 9 * 24; i++) U[i] = 0.0;
     double Jr_r[9], Jr_ri[9], Jrwi[9], Jrwj[9], A[9], B[9], S[9], RS[9];
     so3_right_jacobian(r_dr, Jr_r);
@@ -500,12 +503,13 @@ __device__ __noinline__ void imu_factor(const ImuT& f, const double* Ti0, const 
     m3_mul_t(Jr_ri, dR, A);  // Jr^-1 dR^T
     m3_mul(A, Jrb, D1); m3_mul(D1, f.J_dR_bg, D2);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[i * 24 + 21 + j] = -D2[3 * i + j];
-    for (int q = 0; q < 9; q++)
-        for (int c = 0; c < 24; c++) {
-            double s = 0;
-            for (int k = 0; k < 9; k++) s += f.W[9 * q + k] * U[k * 24 + c];
-            J[q * 24 + c] = s;
-        }
+    if (WHITEN)
+        for (int q = 0; q < 9; q++)
+            for (int c = 0; c < 24; c++) {
+                double s = 0;
+                for (int k = 0; k < 9; k++) s += f.W[9 * q + k] * U[k * 24 + c];
+                J[q * 24 + c] = s;
+            }
 }
 
 }  // namespace sadvio

@@ -1128,9 +1128,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             const bool all_const = P.kf_fidx[i] < 0 && P.kf_fidx[j] < 0;
             double dpi[6], dpj[6], r[9];
             for (int q = 0; q < 6; q++) { dpi[q] = xp[6 * (long long)i + q]; dpj[q] = xp[6 * (long long)j + q]; }
-            imu_factor(f, P.kf_T0 + 12 * (long long)i, P.kf_T0 + 12 * (long long)j, P.kf_vel + 3 * (long long)i,
-                       P.kf_vel + 3 * (long long)j, dpi, dpj, xv + 3 * (long long)i, xv + 3 * (long long)j,
-                       xba + 3 * (long long)i, xbg + 3 * (long long)i, r, all_const ? nullptr : sc);
+            imu_factor<ImuDev, false>(f, P.kf_T0 + 12 * (long long)i, P.kf_T0 + 12 * (long long)j, P.kf_vel + 3 * (long long)i,
+                                      P.kf_vel + 3 * (long long)j, dpi, dpj, xv + 3 * (long long)i, xv + 3 * (long long)j,
+                                      xba + 3 * (long long)i, xbg + 3 * (long long)i, r, all_const ? nullptr : sc);  // un-whitened J
             double c = 0.0;
             for (int q = 0; q < 9; q++) { sc[9 * 24 + q] = r[q]; c += r[q] * r[q]; }
             for (int q = 0; q < 3; q++) {
@@ -1140,6 +1140,27 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
                 c += rb_a * rb_a + rb_g * rb_g;
             }
             if (all_const) fixed_part += c; else cost_part += c;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // whitening J <- W J spread over the threads: item = (factor, column), in place per column
+        for (int it = tid; it < n_imu * 24; it += blockDim.x) {
+            const int k = it / 24, cc = it - 24 * k;
+            const ImuDev& f = P.imus[W.imu_begin + k];
+            if (P.kf_fidx[f.kf_i] < 0 && P.kf_fidx[f.kf_j] < 0) continue;
+            double* sc = P.imu_scratch + (long long)(W.imu_begin + k) * (IMU_J + 6);
+            double u[9], o[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) u[q] = sc[q * 24 + cc];
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                double s = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < 9; kk++) s += f.W[9 * q + kk] * u[kk];
+                o[q] = s;
+            }
+#pragma unroll
+            for (int q = 0; q < 9; q++) sc[q * 24 + cc] = o[q];
         }
         __threadfence_block();
         __syncthreads();
