@@ -83,6 +83,20 @@ struct RcclLib {
     const char* (*err_string)(int) = nullptr;
 };
 
+// Deep copy of a caller's window (set_windows) + the observation arrays actually tiled: pose-to-landmark NFR factors
+// whose landmark can be eliminated are appended to the landmark's observation list as two pseudo-observations
+// (rows 0-1 and row 2 of the 3-row factor), so that they ride the ordinary Schur elimination.
+struct SrcWin {
+    sadvio_flat_window v{};   // view into the vectors below
+    std::vector<int64_t> kf_id, lmk_id;
+    std::vector<double> kf_T, kf_vel, kf_ba, kf_bg, cam_K, cam_T, cam_sigma, lmk_p, obs_meas;
+    std::vector<uint8_t> kf_const, lmk_const;
+    std::vector<int32_t> lmk_obs_ptr, obs_kf, obs_cam;
+    // augmented observation list (what build_layout tiles) and its map to the caller's observation index (-1 = pseudo)
+    std::vector<int32_t> a_ptr, a_kf, a_cam, a_src;
+    std::vector<double> a_meas;
+};
+
 struct DensePriorHost {
     int n_full = 0, n = 0, kf_keep = -1, kf_col = 0;
     std::vector<double> J, r0;
@@ -118,6 +132,9 @@ struct sadvio_ba_handle {
     DevBuf<double> d_rank_b, d_rank_s;
     // dense marginalisation priors (host copies, one per window) and the layout they induce
     std::vector<DensePriorHost> dprior_per_win;
+    std::vector<SrcWin> src;                       // caller windows (deep copies)
+    std::vector<std::vector<char>> sp_elim;        // per window, per sparse factor: handled as pseudo-observations
+    std::vector<int> n_obs_user;                   // caller's observation count per window
     std::vector<std::vector<sadvio_sparse_prior>> sparse_per_win;
     DevBuf<SparseDev> d_sparse;
     DevBuf<double> d_sp_scratch;
@@ -316,9 +333,18 @@ int layout_reduced(sadvio_ba_handle* h) {
         }
         // landmarks touched by sparse prior factors stay in the reduced system as well
         d.sp_begin = (int)sparse.size();
-        for (const sadvio_sparse_prior& s : h->sparse_per_win[w]) {
+        for (size_t sk = 0; sk < h->sparse_per_win[w].size(); sk++) {
+            const sadvio_sparse_prior& s = h->sparse_per_win[w][sk];
             SparseDev o{};
             o.type = s.type;
+            const bool elim = w < (int)h->sp_elim.size() && sk < h->sp_elim[w].size() && h->sp_elim[w][sk];
+            if (elim) {
+                // rides the Schur elimination as two pseudo-observations of its landmark: only its constants are needed
+                o.type = 4; o.kf = d.kf_base + s.kf; o.lmk0 = d.lmk_base + s.lmk0; o.lmk1 = -1;
+                memcpy(o.delta, s.delta, 24); memcpy(o.W, s.sqrt_inf, sizeof(o.W));
+                sparse.push_back(o);
+                continue;
+            }
             o.kf = s.kf >= 0 ? d.kf_base + s.kf : -1;
             const int ls[2] = {s.type == SADVIO_SPARSE_IMU_PRIOR ? -1 : s.lmk0, s.type == SADVIO_SPARSE_LMK_TO_LMK ? s.lmk1 : -1};
             int gls[2] = {-1, -1};
@@ -485,17 +511,68 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     delete h;
 }
 
-int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_flat_window* wins) {
-    if (!h) return SADVIO_E_INVALID_ARG;
-    if (n_windows <= 0 || !wins) { h->err = "set_windows: no windows"; return SADVIO_E_INVALID_ARG; }
+// (Re)build the device layout from the stored caller windows + the current factor lists: concatenation, the
+// per-landmark observation order, pseudo-observations of eliminable pose-to-landmark factors, tiles, reduced layout.
+static int build_layout(sadvio_ba_handle* h) {
+    const int n_windows = (int)h->src.size();
     HIP_TRY(hipSetDevice(h->device));
-    h->uploaded = false; h->solved = false;
+    h->solved = false;
     h->wins.assign(n_windows, HostWin());
-    h->priors_per_win.assign(n_windows, {});
-    h->imus_per_win.assign(n_windows, {});
-    h->dprior_per_win.assign(n_windows, {});
-    h->sparse_per_win.assign(n_windows, {});
     h->tiles.clear();
+    h->sp_elim.assign(n_windows, {});
+    h->n_obs_user.assign(n_windows, 0);
+    // which sparse factors ride the Schur elimination as pseudo-observations: PoseToLandmark factors whose landmark is
+    // free and not held in the reduced system for another reason (dense prior, landmark prior / landmark chain factor)
+    std::vector<sadvio_flat_window> views(n_windows);
+    int sp_global = 0;
+    for (int w = 0; w < n_windows; w++) {
+        SrcWin& S = h->src[w];
+        const auto& sp = h->sparse_per_win[w];
+        h->sp_elim[w].assign(sp.size(), 0);
+        h->n_obs_user[w] = S.v.n_obs;
+        views[w] = S.v;
+        std::vector<char> held(std::max(S.v.n_lmk, 1), 0);
+        const DensePriorHost& D = h->dprior_per_win[w];
+        for (size_t i = 0; i < D.lmk_index.size(); i++) if (D.n_full > 0 && D.lmk_col[i] >= 0) held[D.lmk_index[i]] = 1;
+        for (const auto& s : sp) {
+            if (s.type == SADVIO_SPARSE_LMK_PRIOR) held[s.lmk0] = 1;
+            if (s.type == SADVIO_SPARSE_LMK_TO_LMK) { held[s.lmk0] = 1; held[s.lmk1] = 1; }
+        }
+        std::vector<std::vector<int>> extra(S.v.n_lmk);  // per landmark: global sparse-factor indices to append
+        bool any = false;
+        for (size_t k = 0; k < sp.size(); k++) {
+            const auto& s = sp[k];
+            if (s.type != SADVIO_SPARSE_POSE_TO_LMK || held[s.lmk0]) continue;
+            if (!S.lmk_const.empty() && S.lmk_const[s.lmk0]) continue;
+            h->sp_elim[w][k] = 1;
+            extra[s.lmk0].push_back(sp_global + (int)k);
+            any = true;
+        }
+        sp_global += (int)sp.size();
+        if (any) {
+            const int ms = S.v.factor_type == SADVIO_FACTOR_PIXEL ? 2 : 3;
+            S.a_ptr.assign(1, 0); S.a_kf.clear(); S.a_cam.clear(); S.a_src.clear(); S.a_meas.clear();
+            for (int l = 0; l < S.v.n_lmk; l++) {
+                for (int o = S.lmk_obs_ptr[l]; o < S.lmk_obs_ptr[l + 1]; o++) {
+                    S.a_kf.push_back(S.obs_kf[o]); S.a_cam.push_back(S.obs_cam[o]); S.a_src.push_back(o);
+                    for (int q = 0; q < ms; q++) S.a_meas.push_back(S.obs_meas[(size_t)ms * o + q]);
+                }
+                for (int gfi : extra[l])
+                    for (int half = 0; half < 2; half++) {
+                        const auto& s = sp[gfi - (sp_global - (int)sp.size())];
+                        S.a_kf.push_back(s.kf); S.a_cam.push_back(-1 - (2 * gfi + half)); S.a_src.push_back(-1);
+                        for (int q = 0; q < ms; q++) S.a_meas.push_back(0.0);
+                    }
+                S.a_ptr.push_back((int32_t)S.a_kf.size());
+            }
+            views[w].n_obs = (int32_t)S.a_kf.size();
+            views[w].lmk_obs_ptr = S.a_ptr.data(); views[w].obs_kf = S.a_kf.data(); views[w].obs_cam = S.a_cam.data();
+            views[w].obs_meas = S.a_meas.data();
+        } else {
+            S.a_src.clear();
+        }
+    }
+    const sadvio_flat_window* wins = views.data();
     h->factor_type = wins[0].factor_type;
     int kf_b = 0, cam_b = 0, lmk_b = 0, obs_b = 0;
     h->max_n_kf = h->max_npose = h->max_np = 0; h->n_big = 0;
@@ -515,11 +592,6 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
             h->err = "set_windows: lmk_obs_ptr is not a CSR over n_obs";
             return SADVIO_E_INVALID_ARG;
         }
-        for (int o = 0; o < F.n_obs; o++)
-            if (F.obs_kf[o] < 0 || F.obs_kf[o] >= F.n_kf || F.obs_cam[o] < 0 || F.obs_cam[o] >= F.n_cam) {
-                h->err = "set_windows: observation index out of range";
-                return SADVIO_E_INVALID_ARG;
-            }
         if (F.lmk_const) h->has_lmk_const = true;
         HostWin& H = h->wins[w];
         WinDev& d = H.d;
@@ -589,9 +661,9 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
             for (int k = 0; k < o1 - o0; k++) {
                 const int src = idx[k], dst = o0 + k;
                 pkf[dst] = F.obs_kf[src]; pcam[dst] = F.obs_cam[src];
-                h->obs_perm[d.obs_base + dst] = src;
+                h->obs_perm[d.obs_base + dst] = h->src[w].a_src.empty() ? src : h->src[w].a_src[src];  // -1: pseudo-observation
                 obs_kf[d.obs_base + dst] = d.kf_base + F.obs_kf[src];
-                obs_cam[d.obs_base + dst] = d.cam_base + F.obs_cam[src];
+                obs_cam[d.obs_base + dst] = F.obs_cam[src] < 0 ? F.obs_cam[src] : d.cam_base + F.obs_cam[src];
                 memcpy(&obs_meas[(size_t)ms * (d.obs_base + dst)], F.obs_meas + (size_t)ms * src, sizeof(double) * ms);
                 run = (k > 0 && pkf[dst] == pkf[dst - 1]) ? run + 1 : 1;
                 run_max[l] = std::max(run_max[l], run);
@@ -726,6 +798,67 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
     return SADVIO_OK;
 }
 
+int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_flat_window* wins) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (n_windows <= 0 || !wins) { h->err = "set_windows: no windows"; return SADVIO_E_INVALID_ARG; }
+    h->uploaded = false; h->solved = false;
+    for (int w = 0; w < n_windows; w++) {
+        const sadvio_flat_window& F = wins[w];
+        if (F.n_kf <= 0 || F.n_cam <= 0 || F.n_lmk < 0 || F.n_obs < 0 || !F.kf_T_f_w || !F.cam_K || !F.cam_T_s_f ||
+            (F.n_lmk > 0 && (!F.lmk_p || !F.lmk_obs_ptr)) || (F.n_obs > 0 && (!F.obs_kf || !F.obs_cam || !F.obs_meas))) {
+            h->err = "set_windows: missing array in window " + std::to_string(w);
+            return SADVIO_E_INVALID_ARG;
+        }
+        if (F.n_lmk > 0 && (F.lmk_obs_ptr[0] != 0 || F.lmk_obs_ptr[F.n_lmk] != F.n_obs)) {
+            h->err = "set_windows: lmk_obs_ptr is not a CSR over n_obs";
+            return SADVIO_E_INVALID_ARG;
+        }
+        for (int l = 0; l < F.n_lmk; l++)
+            if (F.lmk_obs_ptr[l + 1] < F.lmk_obs_ptr[l]) { h->err = "set_windows: CSR not monotone"; return SADVIO_E_INVALID_ARG; }
+        for (int o = 0; o < F.n_obs; o++)
+            if (F.obs_kf[o] < 0 || F.obs_kf[o] >= F.n_kf || F.obs_cam[o] < 0 || F.obs_cam[o] >= F.n_cam) {
+                h->err = "set_windows: observation index out of range";
+                return SADVIO_E_INVALID_ARG;
+            }
+    }
+    // deep copies: later set_* calls rebuild the layout without the caller's buffers
+    h->src.assign(n_windows, SrcWin());
+    for (int w = 0; w < n_windows; w++) {
+        const sadvio_flat_window& F = wins[w];
+        SrcWin& S = h->src[w];
+        const int ms = F.factor_type == SADVIO_FACTOR_PIXEL ? 2 : 3;
+        S.kf_T.assign(F.kf_T_f_w, F.kf_T_f_w + 12 * (size_t)F.n_kf);
+        S.cam_K.assign(F.cam_K, F.cam_K + 4 * (size_t)F.n_cam); S.cam_T.assign(F.cam_T_s_f, F.cam_T_s_f + 12 * (size_t)F.n_cam);
+        if (F.cam_sigma) S.cam_sigma.assign(F.cam_sigma, F.cam_sigma + F.n_cam);
+        if (F.kf_id) S.kf_id.assign(F.kf_id, F.kf_id + F.n_kf);
+        if (F.kf_const) S.kf_const.assign(F.kf_const, F.kf_const + F.n_kf);
+        if (F.kf_vel) S.kf_vel.assign(F.kf_vel, F.kf_vel + 3 * (size_t)F.n_kf);
+        if (F.kf_ba) S.kf_ba.assign(F.kf_ba, F.kf_ba + 3 * (size_t)F.n_kf);
+        if (F.kf_bg) S.kf_bg.assign(F.kf_bg, F.kf_bg + 3 * (size_t)F.n_kf);
+        if (F.n_lmk) { S.lmk_p.assign(F.lmk_p, F.lmk_p + 3 * (size_t)F.n_lmk); S.lmk_obs_ptr.assign(F.lmk_obs_ptr, F.lmk_obs_ptr + F.n_lmk + 1); }
+        else S.lmk_obs_ptr.assign(1, 0);
+        if (F.lmk_id) S.lmk_id.assign(F.lmk_id, F.lmk_id + F.n_lmk);
+        if (F.lmk_const) S.lmk_const.assign(F.lmk_const, F.lmk_const + F.n_lmk);
+        if (F.n_obs) {
+            S.obs_kf.assign(F.obs_kf, F.obs_kf + F.n_obs); S.obs_cam.assign(F.obs_cam, F.obs_cam + F.n_obs);
+            S.obs_meas.assign(F.obs_meas, F.obs_meas + (size_t)ms * F.n_obs);
+        }
+        S.v = F;
+        S.v.kf_T_f_w = S.kf_T.data(); S.v.cam_K = S.cam_K.data(); S.v.cam_T_s_f = S.cam_T.data();
+        S.v.cam_sigma = F.cam_sigma ? S.cam_sigma.data() : nullptr;
+        S.v.kf_id = F.kf_id ? S.kf_id.data() : nullptr; S.v.kf_const = F.kf_const ? S.kf_const.data() : nullptr;
+        S.v.kf_vel = F.kf_vel ? S.kf_vel.data() : nullptr; S.v.kf_ba = F.kf_ba ? S.kf_ba.data() : nullptr; S.v.kf_bg = F.kf_bg ? S.kf_bg.data() : nullptr;
+        S.v.lmk_p = S.lmk_p.data(); S.v.lmk_obs_ptr = S.lmk_obs_ptr.data();
+        S.v.lmk_id = F.lmk_id ? S.lmk_id.data() : nullptr; S.v.lmk_const = F.lmk_const ? S.lmk_const.data() : nullptr;
+        S.v.obs_kf = S.obs_kf.data(); S.v.obs_cam = S.obs_cam.data(); S.v.obs_meas = S.obs_meas.data();
+    }
+    h->priors_per_win.assign(n_windows, {});
+    h->imus_per_win.assign(n_windows, {});
+    h->dprior_per_win.assign(n_windows, {});
+    h->sparse_per_win.assign(n_windows, {});
+    return build_layout(h);
+}
+
 int sadvio_ba_set_pose_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const sadvio_pose_prior* pr) {
     if (!h) return SADVIO_E_INVALID_ARG;
     if (!h->uploaded) { h->err = "set_pose_priors before set_windows"; return SADVIO_E_STATE; }
@@ -841,6 +974,7 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t w, int32_t n_full, in
         D.lmk_index.assign(lmk_index, lmk_index + n_keep); D.lmk_col.assign(lmk_col, lmk_col + n_keep);
     }
     h->dprior_per_win[w] = std::move(D);
+    if (!h->sparse_per_win[w].empty()) return build_layout(h);  // which sparse factors are eliminable may change
     int rc = layout_reduced(h);
     if (rc != SADVIO_OK) return rc;
     return upload_priors(h);
@@ -864,9 +998,7 @@ int sadvio_ba_set_sparse_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const
         }
     }
     h->sparse_per_win[w].assign(f, f + n);
-    int rc = layout_reduced(h);
-    if (rc != SADVIO_OK) return rc;
-    return upload_priors(h);
+    return build_layout(h);  // eliminable pose-to-landmark factors become pseudo-observations: the tiles change
 }
 
 namespace {
@@ -958,7 +1090,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
             for (int k = 0; k < cnt; k++) {
                 const int gl = d.lmk_base + list[k];
                 for (int o = h->h_lmk_ob[gl]; o < h->h_lmk_oe[gl]; o++)
-                    if (h->h_obs_kf[o] == d.kf_base + rq->kf_marg) { it2.push_back(o); it2.push_back(lcol[list[k]]); itl.push_back(gl); }
+                    if (h->h_obs_kf[o] == d.kf_base + rq->kf_marg && h->obs_perm[o] >= 0) { it2.push_back(o); it2.push_back(lcol[list[k]]); itl.push_back(gl); }  // pseudo-observations excluded
             }
         }
         const int n_items = (int)itl.size();
@@ -1407,7 +1539,9 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     const size_t lds_solve = sizeof(double) * ((size_t)(h->max_np + 2) * 6 + (size_t)(h->max_np + 1) * (h->max_np + 2) / 2 +
                                                4 * (size_t)h->max_np + (size_t)(h->max_np / 5 + 1) * 36) + 64;
     // robust loss or prior-kept landmarks in the batch: the kernels carrying those (rare) paths
-    const bool rare = o.huber_a > 0.0 || h->n_kept > 0;
+    bool any_pseudo = false;
+    for (const auto& v : h->sp_elim) for (char e : v) any_pseudo |= e != 0;
+    const bool rare = o.huber_a > 0.0 || h->n_kept > 0 || any_pseudo;
     const bool pix = h->factor_type == SADVIO_FACTOR_PIXEL;
     auto kb = pix ? (rare ? k_build<0, true> : k_build<0, false>) : (rare ? k_build<1, true> : k_build<1, false>);
     auto kk = pix ? (rare ? k_backsub<0, true> : k_backsub<0, false>) : (rare ? k_backsub<1, true> : k_backsub<1, false>);
@@ -1646,6 +1780,7 @@ int sadvio_ba_linearize(sadvio_ba_handle* h, int32_t w, const double* pose_delta
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int a = 0; a < d.n_obs; a++) {
         const int src = h->obs_perm[d.obs_base + a];  // caller's index of the observation stored at position a
+        if (src < 0) continue;                          // pseudo-observation
         if (r2) memcpy(r2 + 2 * (size_t)src, &hb[2 * (size_t)a], 16);
         if (Jp12) memcpy(Jp12 + 12 * (size_t)src, &hb[2 * (size_t)d.n_obs + 12 * (size_t)a], 96);
         if (Jl6) memcpy(Jl6 + 6 * (size_t)src, &hb[14 * (size_t)d.n_obs + 6 * (size_t)a], 48);

@@ -188,6 +188,34 @@ __device__ __forceinline__ void pose_table_entry(const double* T0, const double*
     tab[39] = d6[3]; tab[40] = d6[4]; tab[41] = d6[5];
 }
 
+// PoseToLandmarkFactor (residuals.hpp:570-595) as a pseudo-observation evaluated from a pose table: two of its three
+// rows (half 0: rows 0, 1; half 1: row 2 and a zero row) in the 2-row layout of the visual factors. WANT_J = false
+// only needs R | t (the first 12 table entries).
+template <bool WANT_J>
+__device__ __forceinline__ void p2l_pseudo_obs(const double* tab, const double* q, const double* delta, const double* W, int half,
+                                               double* r, double* Jp, double* Jl) {
+    double Rq[3], e[3];
+    m3_vec(tab, q, Rq);
+    for (int a = 0; a < 3; a++) e[a] = Rq[a] + tab[9 + a] - delta[a];
+    const int r0 = half ? 2 : 0;
+    r[0] = W[3 * r0] * e[0] + W[3 * r0 + 1] * e[1] + W[3 * r0 + 2] * e[2];
+    r[1] = half ? 0.0 : W[3] * e[0] + W[4] * e[1] + W[5] * e[2];
+    if (WANT_J) {
+        double Sq[9], A[9], B[9], C[9], WR0[9], WR[9];
+        so3_skew(q, Sq);
+        m3_mul(tab + 30, Sq, A);      // dR [q]x
+        m3_mul(A, tab + 12, B);       // dR [q]x Jr(w)
+        m3_mul(W, tab + 21, WR0);     // W R0
+        m3_mul(WR0, B, C);
+        m3_mul(W, tab, WR);           // W R
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            Jp[j] = -C[3 * r0 + j]; Jp[3 + j] = WR0[3 * r0 + j]; Jl[j] = WR[3 * r0 + j];
+            Jp[6 + j] = half ? 0.0 : -C[3 + j]; Jp[9 + j] = half ? 0.0 : WR0[3 + j]; Jl[3 + j] = half ? 0.0 : WR[3 + j];
+        }
+    }
+}
+
 // Pixel reprojection residual (+ Jacobians). cam = K[4] | Tsf[12]. Returns validity
 // (Camera.cpp:128-136); invalid => r = 0, Jacobians kept (…Analytic.h:63-65).
 template <bool WANT_J>

@@ -231,11 +231,29 @@ __device__ __forceinline__ void lane_linearize(const DevPtrs& P, const double* p
                                                const int* rowTab, int cam_base, int o, const double* pw, bool keep_jl,
                                                bool lcounted, ObsLin& L) {
     const int slot = P.obs_slot[o];
-    const int cam = P.obs_cam[o] - cam_base;
+    const int craw = P.obs_cam[o];
+    const int cam = craw < 0 ? 0 : craw - cam_base;
     const double* tab = poseTab + slot * POSE_TAB;
     const double* ct = camTab + cam * 17;  // K[4] Tsf[12] isig
     L.slot = slot;
     L.row = rowTab[slot];
+    if (RARE && craw < 0) {
+        // pseudo-observation: one half of a PoseToLandmarkFactor of the sparsified prior (no loss function on it)
+        const int code = -1 - craw;
+        const SparseDev& f = P.sparse[code >> 1];
+        p2l_pseudo_obs<true>(tab, pw, f.delta, f.W, code & 1, L.r, L.Jp, L.Jl);
+        L.rho = L.r[0] * L.r[0] + L.r[1] * L.r[1];
+        if (L.row < 0) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) L.Jp[i] = 0.0;
+        }
+        if (!keep_jl) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) L.Jl[i] = 0.0;
+        }
+        L.counted = (L.row >= 0) || lcounted;
+        return;
+    }
     if (FACTOR == 0) {
         const double* m = P.obs_meas + 2 * (long long)o;
         pixel_factor<true>(tab, ct, ct + 4, pw, m[0], m[1], ct[16], L.r, L.Jp, L.Jl);
@@ -963,6 +981,7 @@ __device__ __forceinline__ int imu_col(int a, int fi, int fj) {
 // ---- sparse prior factors inside the reduced solve --------------------------------------------------------
 // reduced-vector column of Jacobian column a (0..14) of sparse factor f; -1 = constant / unused
 __device__ __forceinline__ int sparse_col(const SparseDev& f, int a, int fi, int dpf, int lr0, int lr1) {
+    if (f.type == 4) return -1;  // rides the Schur elimination as pseudo-observations (k_build / k_backsub)
     if (f.type == 0) return (fi >= 0 && a < dpf) ? fi * dpf + a : -1;
     if (f.type == 1) return a < 6 ? (fi < 0 ? -1 : fi * dpf + a) : (a < 9 ? (lr0 < 0 ? -1 : lr0 + a - 6) : -1);
     if (f.type == 2) return (a < 3 && lr0 >= 0) ? lr0 + a : -1;
@@ -1212,6 +1231,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         __syncthreads();
         for (int k = tid; k < n_sp; k += blockDim.x) {
             const SparseDev& f = P.sparse[W.sp_begin + k];
+            if (f.type == 4) continue;
             double* sc = P.sp_scratch + (long long)(W.sp_begin + k) * SPARSE_J;
             double r[15];
             const bool in_program = sparse_eval(P, W, f, xp, xv, xba, xbg, xl, nullptr, r, sc);
@@ -1448,7 +1468,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         for (int it = tid; it < n_sp * 15; it += blockDim.x) {
             const int k = it / 15, q = it - 15 * k;
             const SparseDev& f = P.sparse[W.sp_begin + k];
-            if (q >= sparse_rows(f)) continue;
+            if (f.type == 4 || q >= sparse_rows(f)) continue;
             const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
             const int lr0 = (f.lmk0 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk0] : -1;
             const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
@@ -1465,7 +1485,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         for (int k = tid; k < n_sp; k += blockDim.x) {
             double r[15];
             const SparseDev& f = P.sparse[W.sp_begin + k];
-            if (!sparse_eval(P, W, f, xp, xv, xba, xbg, xl, y, r, nullptr)) continue;
+            if (f.type == 4 || !sparse_eval(P, W, f, xp, xv, xba, xbg, xl, y, r, nullptr)) continue;
             const int rows = sparse_rows(f);
             for (int q = 0; q < rows; q++) cc += r[q] * r[q];
         }
@@ -1587,11 +1607,18 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
             mcc += -m0 * (L.r[0] + 0.5 * m0) - m1 * (L.r[1] + 0.5 * m1);
             // residual at the candidate point
             const int o = ob + q;
-            const int cam = P.obs_cam[o] - T.cam_base;
+            const int craw = P.obs_cam[o];
+            const int cam = craw < 0 ? 0 : craw - T.cam_base;
             const double* ct = camTab + cam * 17;
             const double pw[3] = {p0[0] + c0, p0[1] + c1, p0[2] + c2};
             const double* ctab = candTab + L.slot * 12;
             double r[2];
+            if (RARE && craw < 0) {
+                const int code = -1 - craw;
+                const SparseDev& f = P.sparse[code >> 1];
+                p2l_pseudo_obs<false>(ctab, pw, f.delta, f.W, code & 1, r, nullptr, nullptr);
+                cc += r[0] * r[0] + r[1] * r[1];
+            } else {
             if (FACTOR == 0) {
                 const double* m = P.obs_meas + 2 * (long long)o;
                 pixel_factor<false>(ctab, ct, ct + 4, pw, m[0], m[1], ct[16], r, nullptr, nullptr);
@@ -1602,6 +1629,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
             }
             double sc_unused;
             cc += RARE ? huber_rho(P.o.huber_a, r[0] * r[0] + r[1] * r[1], sc_unused) : r[0] * r[0] + r[1] * r[1];
+            }
         }
     }
     sn = wave_sum(sn); cn = wave_sum(cn); mcc = wave_sum(mcc); cc = wave_sum(cc);
@@ -1876,6 +1904,7 @@ __global__ void k_linearize_probe(DevPtrs P, int w, double* r2, double* Jp12, do
     while (!(P.lmk_ob[lo] <= o && o < P.lmk_oe[lo]) && lo > W.lmk_base) lo--;
     int gl = lo;
     int kf = P.obs_kf[o], cam = P.obs_cam[o];
+    if (cam < 0) return;  // pseudo-observation of a sparse prior factor: not part of the caller's observation list
     double d6[6], tab[POSE_TAB];
     for (int i = 0; i < 6; i++) d6[i] = P.xp[6 * (long long)kf + i];
     pose_table_entry(P.kf_T0 + 12 * (long long)kf, d6, tab);
