@@ -121,6 +121,7 @@ struct sadvio_ba_handle {
     int factor_type = 0;
     int max_n_kf = 0, max_npose = 0, max_np = 0, n_big = 0;
     DevBuf<int> d_big_info;
+    DevBuf<double> d_big_M;     // inverse diagonal blocks of the wide-panel dense solver, 96 x 96 per 96 columns
     DevBuf<double> d_big_linv;  // inverse pivot blocks of the banded solver, N * NB doubles per out-of-LDS window
     bool uploaded = false, solved = false;
     // window sharded over several GPUs: collective hook (user callback or the built-in RCCL one)
@@ -1582,8 +1583,11 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         for (int w = 0; w < n_win; w++)
             for (int r = 0; r < h->world; r++) big_bw[w] = std::max(big_bw[w], (int)slots[((size_t)w * h->world + r) * 4]);
     }
-    std::vector<long long> big_linv_off(n_win, 0);
+    std::vector<long long> big_linv_off(n_win, 0), big_M_off(n_win, 0);
     {
+        long long totM = 0;
+        for (int w = 0; w < n_win; w++) if (h->wins[w].d.ld) { big_M_off[w] = totM; totM += (long long)((h->wins[w].d.Np + WD - 1) / WD) * WD * WD; }
+        HIP_TRY(h->d_big_M.alloc((size_t)std::max<long long>(totM, 1)));
         long long tot = 0;
         for (int w = 0; w < n_win; w++) if (h->wins[w].d.ld) { big_linv_off[w] = tot; tot += 6LL * h->wins[w].d.Np; }
         HIP_TRY(h->d_big_linv.alloc((size_t)std::max<long long>(tot, 1)));
@@ -1635,6 +1639,29 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                             (void)hipFuncSetAttribute((const void*)kbs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                             hipLaunchKernelGGL(kbs, dim3(1), dim3(SOLVE_THREADS), lds, h->stream, Sw, (long long)d.ld, yw, h->d_big_linv.p + big_linv_off[w],
                                                N, bw, C, info, skip);
+                            continue;
+                        }
+                        if (N >= 2 * WD) {
+                            // dense system: 96-column panels through the LDS solver + MFMA panel / update kernels
+                            double* Mw = h->d_big_M.p + big_M_off[w];
+                            const size_t lds_d = sizeof(double) * ((size_t)(WD + 2) * 6 + (size_t)(WD + 1) * (WD + 2) / 2 + 2 * WD + 2 * WD_NBK * 36 + (size_t)WD * (WD + 1)) + 64;
+                            const size_t lds_t = sizeof(double) * (size_t)(CH_TS + WD) * WDS;
+                            const size_t lds_s = sizeof(double) * 2 * (size_t)CH_TS * WDS;
+                            (void)hipFuncSetAttribute((const void*)k_wchol_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
+                            (void)hipFuncSetAttribute((const void*)k_wchol_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+                            (void)hipFuncSetAttribute((const void*)k_wchol_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+                            (void)hipFuncSetAttribute((const void*)k_wchol_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * WD * WDS));
+                            int st = 0;
+                            for (int c0 = 0; c0 < N; c0 += WD, st++) {
+                                hipLaunchKernelGGL(k_wchol_diag, dim3(1), dim3(SOLVE_THREADS), lds_d, h->stream, Sw, (long long)d.ld, yw, Mw + (size_t)st * WD * WD, N, c0, info, skip);
+                                const int m = N - (c0 + WD);
+                                if (m > 0) {
+                                    const int nt = (m + CH_TS - 1) / CH_TS;
+                                    hipLaunchKernelGGL(k_wchol_trsm, dim3(nt), dim3(CH_THREADS), lds_t, h->stream, Sw, (long long)d.ld, Mw + (size_t)st * WD * WD, N, c0, info, skip);
+                                    hipLaunchKernelGGL(k_wchol_syrk, dim3(nt * (nt + 1) / 2 + (m + CH_THREADS - 1) / CH_THREADS), dim3(CH_THREADS), lds_s, h->stream, Sw, (long long)d.ld, yw, N, c0, info, skip);
+                                }
+                            }
+                            hipLaunchKernelGGL(k_wchol_backsolve, dim3(1), dim3(SOLVE_THREADS), sizeof(double) * WD * WDS, h->stream, Sw, (long long)d.ld, yw, Mw, N, info, skip);
                             continue;
                         }
                         for (int k0 = 0; k0 < N; k0 += CH_NB) {

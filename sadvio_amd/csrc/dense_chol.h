@@ -417,4 +417,252 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(double* __restrict
     }
 }
 
+// ---- dense systems: wide panels built on the in-LDS factorisation -------------------------------------------------
+// A dense reduced system (a dense prior couples the kept landmarks; N_p ~ 1 000) is factorised 96 columns at a time:
+//   k_wchol_diag   one workgroup: the 96 x 96 diagonal block (+ its rhs entries) goes through the tuned LDS solver
+//                  (chol_solve_packed<6, PARTIAL>, identity padding beyond N), then M = L_dd^-1 is formed from the
+//                  inverse pivot blocks by block anti-diagonals and stored; z = L_dd^-1 y_d
+//   k_wchol_trsm   X = A_panel M^T: one (rows x 96) x (96 x 96) product per 64-row tile on the FP64 matrix cores
+//   k_wchol_syrk   A_trailing -= X X^T on 64 x 64 tiles with K = 96 (FP64 MFMA), rhs row y -= X z
+//   k_wchol_backsolve   x_d = M^T (z_d - X_p^T x_p), super-steps in reverse, one workgroup
+// 3 launches per 96 columns instead of 2 per 32, and the panel / update work runs on MFMA instead of per-thread
+// substitution chains.
+constexpr int WD = 96;
+constexpr int WD_NBK = WD / 6;
+constexpr int WDS = WD + 4;  // LDS row stride: (lane & 15) * 100 + (lane >> 4) hits every bank pair exactly twice
+
+// stage `rows` x WD doubles from global (row stride ld) into an LDS slab [..][WDS]; rows beyond `valid` are zero.
+// Eight independent loads are in flight per thread before the first LDS store.
+__device__ __forceinline__ void stage_slab(double (*dst)[WDS], const double* __restrict__ src, long long ld, int rows, int valid) {
+    const int total = rows * WD;
+    for (int eb = threadIdx.x; eb < total; eb += 8 * blockDim.x) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = eb + u * blockDim.x;
+            const int r = e / WD, cc = e - r * WD;
+            v[u] = (e < total && r < valid) ? src[(long long)r * ld + cc] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = eb + u * blockDim.x;
+            if (e < total) dst[e / WD][e - (e / WD) * WD] = v[u];
+        }
+    }
+}
+
+__global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_diag(double* __restrict__ A, long long ld, double* __restrict__ y,
+                                                              double* __restrict__ Mg, int N, int c0, int* info, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    if (*info != 0) return;
+    constexpr int NB = 6;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double* LpT = (double*)smem;                         // [NBP][WD + 2]
+    double* Pk = LpT + (size_t)(WD + 2) * NBP;           // packed window incl. rhs row
+    double* xv = Pk + (size_t)(WD + 1) * (WD + 2) / 2;
+    double* xs = xv + WD;
+    double* linvTab = xs + WD;                           // [WD_NBK][36]
+    double* Ml = linvTab + WD_NBK * 36;                  // [WD][WD + 1] inverse of the block factor
+    double* Tt = Ml + (size_t)WD * (WD + 1);             // [WD_NBK][36] temporaries of one anti-diagonal
+    // load (identity padding beyond N)
+    for (int gb = tid; gb < tri(WD, 0); gb += 5 * nt) {   // five independent loads in flight per thread
+        double v[5];
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int g = gb + u * nt;
+            if (g < tri(WD, 0)) {
+                int i, j;
+                tri_decode(g, i, j);
+                v[u] = (c0 + i < N) ? A[(long long)(c0 + i) * ld + c0 + j] : (i == j ? 1.0 : 0.0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int g = gb + u * nt;
+            if (g < tri(WD, 0)) Pk[g] = v[u];
+        }
+    }
+    for (int j = tid; j < WD; j += nt) Pk[tri(WD, j)] = (c0 + j < N) ? y[c0 + j] : 0.0;
+    if (tid == 0) Pk[tri(WD, WD)] = 0.0;
+    __syncthreads();
+    const bool ok = chol_solve_packed<NB, true>(Pk, WD, xv, xs, LpT, linvTab, nullptr, WD_NBK);
+    __syncthreads();
+    if (!ok) { if (tid == 0) *info = c0 + 1; return; }
+    for (int j = tid; j < WD && c0 + j < N; j += nt) y[c0 + j] = Pk[tri(WD, j)];
+    // M = L^-1 by block anti-diagonals: M_kk = Linv_k; M_kj = -Linv_k sum_{i=j}^{k-1} L_ki M_ij
+    for (int e = tid; e < WD * (WD + 1); e += nt) Ml[e] = 0.0;
+    __syncthreads();
+    for (int e = tid; e < WD_NBK * 36; e += nt) {
+        const int k = e / 36, a = (e % 36) / 6, b = e % 6;
+        Ml[(6 * k + a) * (WD + 1) + 6 * k + b] = linvTab[k * 36 + a * 6 + b];
+    }
+    __syncthreads();
+    for (int d = 1; d < WD_NBK; d++) {
+        const int nblk = WD_NBK - d;
+        for (int e = tid; e < nblk * 36; e += nt) {
+            const int j = e / 36, a = (e % 36) / 6, b = e % 6, k = j + d;
+            // row 6k+a of L left of its pivot block is contiguous in the packed layout: columns 6j .. 6k-1
+            const double* lrow = Pk + tri(6 * k + a, 6 * j);
+            const double* mcol = Ml + (size_t)(6 * j) * (WD + 1) + 6 * j + b;
+            double t0 = 0.0, t1 = 0.0;
+            const int len = 6 * d;
+#pragma unroll 6
+            for (int q = 0; q < len; q += 2) {
+                t0 += lrow[q] * mcol[(size_t)q * (WD + 1)];
+                t1 += lrow[q + 1] * mcol[(size_t)(q + 1) * (WD + 1)];
+            }
+            Tt[e] = t0 + t1;
+        }
+        __syncthreads();
+        for (int e = tid; e < nblk * 36; e += nt) {
+            const int j = e / 36, a = (e % 36) / 6, b = e % 6, k = j + d;
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 6; q++) t += linvTab[k * 36 + a * 6 + q] * Tt[j * 36 + q * 6 + b];
+            Ml[(6 * k + a) * (WD + 1) + 6 * j + b] = -t;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < WD * WD; e += nt) Mg[e] = Ml[(e / WD) * (WD + 1) + (e % WD)];
+}
+
+// X = A[s .. N, c0 .. c0 + WD) * M^T, 64 rows per workgroup
+__global__ __launch_bounds__(CH_THREADS) void k_wchol_trsm(double* __restrict__ A, long long ld, const double* __restrict__ Mg,
+                                                           int N, int c0, const int* info, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    if (*info != 0) return;
+    const int s = c0 + WD;
+    const int r0 = s + blockIdx.x * CH_TS;
+    if (r0 >= N) return;
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    double (*Xa)[WDS] = (double (*)[WDS])smem;
+    double (*Ms)[WDS] = (double (*)[WDS])(smem + sizeof(double) * CH_TS * WDS);
+    stage_slab(Xa, A + (long long)r0 * ld + c0, ld, CH_TS, N - r0);
+    stage_slab(Ms, Mg, WD, WD, WD);
+    __syncthreads();
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int lr = ln & 15, lk = ln >> 4;
+    d4 acc[WD / 16];
+#pragma unroll
+    for (int cb = 0; cb < WD / 16; cb++) {
+        d4 c4 = {0.0, 0.0, 0.0, 0.0};
+        for (int kk = 0; kk < 16 * (cb + 1); kk += 16) {   // M is lower triangular: k <= column; 4 k-steps per batch of loads
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { av[u] = Xa[16 * wv + lr][kk + 4 * u + lk]; bv[u] = Ms[16 * cb + lr][kk + 4 * u + lk]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], c4, 0, 0, 0);
+        }
+        acc[cb] = c4;
+    }
+#pragma unroll
+    for (int cb = 0; cb < WD / 16; cb++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int row = r0 + 16 * wv + lk + 4 * rg;
+            if (row < N) A[(long long)row * ld + c0 + 16 * cb + lr] = acc[cb][rg];
+        }
+}
+
+// trailing update by the WD-wide panel X and rhs row; K = WD
+__global__ __launch_bounds__(CH_THREADS) void k_wchol_syrk(double* __restrict__ A, long long ld, double* __restrict__ y, int N, int c0,
+                                                           const int* info, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    if (*info != 0) return;
+    const int s = c0 + WD;
+    const int m = N - s;
+    if (m <= 0) return;
+    const int nt = (m + CH_TS - 1) / CH_TS;
+    const int npair = nt * (nt + 1) / 2;
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    if ((int)blockIdx.x >= npair) {
+        const int j = (blockIdx.x - npair) * CH_THREADS + tid;
+        if (j < m) {
+            const double* xrow = A + (long long)(s + j) * ld + c0;
+            double acc = 0.0;
+#pragma unroll 8
+            for (int cc = 0; cc < WD; cc++) acc += y[c0 + cc] * xrow[cc];
+            y[s + j] -= acc;
+        }
+        return;
+    }
+    double (*Pi)[WDS] = (double (*)[WDS])smem;
+    double (*Pj)[WDS] = (double (*)[WDS])(smem + sizeof(double) * CH_TS * WDS);
+    int ti = 0, rem = blockIdx.x;
+    while (rem >= ti + 1) { rem -= ti + 1; ti++; }
+    const int tj = rem;
+    const int i0 = ti * CH_TS, j0 = tj * CH_TS;
+    stage_slab(Pi, A + (long long)(s + i0) * ld + c0, ld, CH_TS, m - i0);
+    stage_slab(Pj, A + (long long)(s + j0) * ld + c0, ld, CH_TS, m - j0);
+    __syncthreads();
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int lr = ln & 15, lk = ln >> 4;
+    const int ib = wv;
+    for (int jb = 0; jb < 4; jb++) {
+        if (ti == tj && jb > ib) continue;
+        const int rbase = i0 + 16 * ib, cbase = j0 + 16 * jb;
+        if (rbase >= m || cbase >= m) continue;
+        d4 c;
+        long long addr[4];
+        bool ok[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int row = rbase + lk + 4 * rg, col = cbase + lr;
+            ok[rg] = row < m && col < m && col <= row;
+            addr[rg] = (long long)(s + (row < m ? row : m - 1)) * ld + s + (col < m ? col : m - 1);
+            c[rg] = ok[rg] ? A[addr[rg]] : 0.0;
+        }
+        for (int kk = 0; kk < WD; kk += 24) {   // 6 k-steps per batch of LDS loads
+            double a[6], b[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++) { a[u] = -Pi[16 * ib + lr][kk + 4 * u + lk]; b[u] = Pj[16 * jb + lr][kk + 4 * u + lk]; }
+#pragma unroll
+            for (int u = 0; u < 6; u++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+            if (ok[rg]) A[addr[rg]] = c[rg];
+    }
+}
+
+// x = L^-T z in place: super-steps in reverse, one workgroup. Right-looking: once the 96 unknowns x_d of a step are
+// known (x_d = M^T t_d), every earlier right-hand-side entry is updated, y[c] -= sum_r X[d rows r][c] x_d[r] -- row
+// reads of X, unit stride across the threads.
+__global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_backsolve(const double* __restrict__ A, long long ld, double* __restrict__ y,
+                                                                   const double* __restrict__ Mg_all, int N, const int* info,
+                                                                   const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    if (*info != 0) return;
+    double (*Ms)[WDS] = (double (*)[WDS])smem;
+    __shared__ double tv[WD], xd[WD];
+    const int tid = threadIdx.x;
+    const int nsteps = (N + WD - 1) / WD;
+    for (int st = nsteps - 1; st >= 0; st--) {
+        const int c0 = st * WD;
+        const int nr = min(WD, N - c0);
+        const double* Mg = Mg_all + (size_t)st * WD * WD;
+        for (int e = tid; e < WD * WD; e += SOLVE_THREADS) Ms[e / WD][e % WD] = Mg[e];
+        if (tid < WD) tv[tid] = tid < nr ? y[c0 + tid] : 0.0;
+        __syncthreads();
+        if (tid < WD) {
+            double x = 0.0;
+            for (int k = tid; k < WD; k++) x += Ms[k][tid] * tv[k];  // (M^T t)_c = sum_{k >= c} M[k][c] t_k
+            xd[tid] = x;
+            if (tid < nr) y[c0 + tid] = x;
+        }
+        __syncthreads();
+        for (int cc = tid; cc < c0; cc += SOLVE_THREADS) {
+            double acc = 0.0;
+#pragma unroll 8
+            for (int r = 0; r < nr; r++) acc += A[(long long)(c0 + r) * ld + cc] * xd[r];
+            y[cc] -= acc;
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace sadvio
