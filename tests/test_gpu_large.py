@@ -65,3 +65,25 @@ def test_mixed_batch_small_and_large(backend_cls, oracle_lib):
         assert sums[k].iterations == ref["summary"].iterations
         assert np.abs(d["pose"] - ref["pose"]).max() <= POSE_TOL
     be.close()
+
+
+@pytest.mark.parametrize("band", [3, None])
+def test_vio_window_out_of_lds(backend_cls, oracle_lib, band):
+    """30-key-frame VIO window (15 states per key-frame, N_p = 435): banded (k_band_solve with 5-column pivots) when
+    the co-visibility band is narrow, dense 96-column panels otherwise."""
+    from vio_helpers import make_vio_window
+    kw = dict(length=15.0, band=band) if band else {}
+    w = make_vio_window(n_kf=30, n_lmk=1500, seed=17, **kw)
+    opts = capi.reference_options()
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    s = be.solve(opts)[0]
+    d = be.get_deltas(0)
+    be.close()
+    ref = oracle_lib.solve(w, opts)
+    rs = ref["summary"]
+    assert (s.iterations, s.termination) == (rs.iterations, rs.termination)
+    assert np.isclose(s.final_cost, rs.final_cost, rtol=1e-9)
+    assert np.abs(d["pose"] - ref["pose"]).max() <= POSE_TOL and np.abs(d["lmk"] - ref["lmk"]).max() <= LMK_TOL
+    for q in ("dv", "dba", "dbg"):
+        assert np.abs(d[q] - ref[q]).max() <= POSE_TOL

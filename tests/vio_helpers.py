@@ -14,12 +14,12 @@ def log_so3(R):
     return oracle.so3_log(R)
 
 
-def make_vio_window(n_kf=6, n_lmk=300, seed=3, dt=0.25, factor=capi.FACTOR_PIXEL, fixed=1, noise=True, obs_per_lmk=5):
+def make_vio_window(n_kf=6, n_lmk=300, seed=3, dt=0.25, factor=capi.FACTOR_PIXEL, fixed=1, noise=True, obs_per_lmk=5, **window_kw):
     """VO window of `synthetic.make_window` + per-key-frame (v, ba, bg) + IMUFactor/IMUBiasFactor between
     consecutive key-frames (AOptimizer.cpp:55-92). Pre-integrated deltas are made consistent with the ground
     truth trajectory (plus noise of the propagated covariance); covariance and bias Jacobians come from the
     restated processIMU run on constant measurements over the same interval at 200 Hz."""
-    w = synthetic.make_window(n_kf=n_kf, n_lmk=n_lmk, seed=seed, factor=factor, fixed=fixed, obs_per_lmk=obs_per_lmk)
+    w = synthetic.make_window(n_kf=n_kf, n_lmk=n_lmk, seed=seed, factor=factor, fixed=fixed, obs_per_lmk=obs_per_lmk, **window_kw)
     rng = np.random.default_rng(seed + 77)
     Tt = [T12_to_4(t) for t in w.truth["T_f_w"]]            # newest first
     pos = [inv4(T)[:3, 3] for T in Tt]
