@@ -95,6 +95,10 @@ struct SrcWin {
     // augmented observation list (what build_layout tiles) and its map to the caller's observation index (-1 = pseudo)
     std::vector<int32_t> a_ptr, a_kf, a_cam, a_src;
     std::vector<double> a_meas;
+    // cameras with identical (K, T_s_f, sigma) are stored once: SaDVIO has one ImageSensor object per (frame, camera),
+    // i.e. 2 x N_kf table entries that are all copies of the rig's two cameras
+    std::vector<double> u_cam_K, u_cam_T, u_cam_sigma;
+    std::vector<int32_t> u_obs_cam;
 };
 
 struct DensePriorHost {
@@ -532,6 +536,27 @@ static int build_layout(sadvio_ba_handle* h) {
         h->sp_elim[w].assign(sp.size(), 0);
         h->n_obs_user[w] = S.v.n_obs;
         views[w] = S.v;
+        {
+            std::vector<int> cmap(S.v.n_cam, -1);
+            S.u_cam_K.clear(); S.u_cam_T.clear(); S.u_cam_sigma.clear();
+            for (int c = 0; c < S.v.n_cam; c++) {
+                const double sg = S.cam_sigma.empty() ? 1.0 : S.cam_sigma[c];
+                const int nu = (int)S.u_cam_sigma.size();
+                for (int u = 0; u < nu && cmap[c] < 0; u++)
+                    if (!memcmp(&S.u_cam_K[4 * u], &S.cam_K[4 * c], 32) && !memcmp(&S.u_cam_T[12 * u], &S.cam_T[12 * c], 96) && S.u_cam_sigma[u] == sg) cmap[c] = u;
+                if (cmap[c] < 0) {
+                    cmap[c] = nu;
+                    S.u_cam_K.insert(S.u_cam_K.end(), &S.cam_K[4 * c], &S.cam_K[4 * c] + 4);
+                    S.u_cam_T.insert(S.u_cam_T.end(), &S.cam_T[12 * c], &S.cam_T[12 * c] + 12);
+                    S.u_cam_sigma.push_back(sg);
+                }
+            }
+            S.u_obs_cam.resize(S.obs_cam.size());
+            for (size_t o = 0; o < S.obs_cam.size(); o++) S.u_obs_cam[o] = cmap[S.obs_cam[o]];
+            views[w].n_cam = (int32_t)S.u_cam_sigma.size();
+            views[w].cam_K = S.u_cam_K.data(); views[w].cam_T_s_f = S.u_cam_T.data(); views[w].cam_sigma = S.u_cam_sigma.data();
+            views[w].obs_cam = S.u_obs_cam.data();
+        }
         std::vector<char> held(std::max(S.v.n_lmk, 1), 0);
         const DensePriorHost& D = h->dprior_per_win[w];
         for (size_t i = 0; i < D.lmk_index.size(); i++) if (D.n_full > 0 && D.lmk_col[i] >= 0) held[D.lmk_index[i]] = 1;
@@ -555,7 +580,7 @@ static int build_layout(sadvio_ba_handle* h) {
             S.a_ptr.assign(1, 0); S.a_kf.clear(); S.a_cam.clear(); S.a_src.clear(); S.a_meas.clear();
             for (int l = 0; l < S.v.n_lmk; l++) {
                 for (int o = S.lmk_obs_ptr[l]; o < S.lmk_obs_ptr[l + 1]; o++) {
-                    S.a_kf.push_back(S.obs_kf[o]); S.a_cam.push_back(S.obs_cam[o]); S.a_src.push_back(o);
+                    S.a_kf.push_back(S.obs_kf[o]); S.a_cam.push_back(S.u_obs_cam[o]); S.a_src.push_back(o);
                     for (int q = 0; q < ms; q++) S.a_meas.push_back(S.obs_meas[(size_t)ms * o + q]);
                 }
                 for (int gfi : extra[l])
@@ -685,7 +710,7 @@ static int build_layout(sadvio_ba_handle* h) {
         // tiles: runs of consecutive landmarks. Every landmark gets a group of G lanes (G = pow2 >= the
         // tile's largest observation count); a workgroup of BUILD_WAVES waves holds BUILD_WAVES * 64 / G
         // landmarks per round. A tile is cut when its key-frame list would exceed the LDS tile capacity.
-        if (F.n_cam > MAX_WIN_CAM) { h->err = "set_windows: more than 8 cameras per window"; return SADVIO_E_INVALID_ARG; }
+        if (F.n_cam > MAX_WIN_CAM) { h->err = "set_windows: more than 8 distinct cameras per window"; return SADVIO_E_INVALID_ARG; }
         d.tile_begin = (int)h->tiles.size();
         {
             int l = 0;

@@ -51,7 +51,9 @@ def test_capacity_errors(backend_cls):
         be.set_windows([w])
     w = synthetic.make_window(n_kf=3, n_lmk=20, seed=1)
     w.cam_K = np.tile(w.cam_K, (5, 1)); w.cam_T_s_f = np.tile(w.cam_T_s_f, (5, 1)); w.cam_sigma = np.tile(w.cam_sigma, 5)
-    with pytest.raises(capi.SadvioError, match="8 cameras"):
+    be.set_windows([w])                      # ten table entries, two distinct cameras: stored once each
+    w.cam_K = w.cam_K + 1e-3 * np.arange(10)[:, None]
+    with pytest.raises(capi.SadvioError, match="8 distinct cameras"):
         be.set_windows([w])
     be.close()
 
@@ -99,4 +101,22 @@ def test_huber_loss_with_kept_landmarks(backend_cls, oracle_lib):
     be.set_windows([w])
     s = be.solve(opts)[0]
     agree(be, 0, w, oracle_lib.solve(w, opts, dense_prior=w.dense_prior), s)
+    be.close()
+
+
+def test_one_camera_entry_per_keyframe_like_the_reference(backend_cls, oracle_lib):
+    """SaDVIO has one ImageSensor per (frame, camera): 2 N_kf table entries, all copies of the rig's two cameras."""
+    w = synthetic.make_window(n_kf=6, n_lmk=300, seed=98)
+    n_kf = w.n_kf
+    cam_of = w.obs_cam.copy()
+    w.obs_cam = (2 * w.obs_kf + cam_of).astype(np.int32)          # entry index = 2 * key-frame + camera
+    w.cam_K = np.tile(w.cam_K, (n_kf, 1)); w.cam_T_s_f = np.tile(w.cam_T_s_f, (n_kf, 1)); w.cam_sigma = np.tile(w.cam_sigma, n_kf)
+    opts = capi.reference_options()
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    s = be.solve(opts)[0]
+    agree(be, 0, w, oracle_lib.solve(w, opts), s)
+    r, Jp, Jl = be.linearize(0)
+    ro, Jpo, Jlo, _ = oracle_lib.linearize(w)
+    assert np.abs(r - ro).max() <= 1e-10 * max(1.0, np.abs(ro).max())
     be.close()
