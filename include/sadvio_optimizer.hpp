@@ -8,6 +8,7 @@
 // (BundleAdjustmentCERESAnalytic.cpp:197-314), the solver options of each entry point and the write-back
 // (AOptimizer.cpp:329-340, 391-434).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -78,6 +79,8 @@ struct LandmarkState {
     int64_t id = 0;
     double p[3] = {0, 0, 0};  // T_w_l translation
     bool initialized = true, outlier = false;
+    bool in_map = true;       // ALandmark::isInMap
+    bool has_prior = false;   // ALandmark::hasPrior / setPrior (set by marginalize, marginalization.cpp:83)
     std::vector<Feature> features;
 };
 
@@ -135,80 +138,228 @@ class HipOptimizer {
         return solve(map, 0, true, o, false, true);
     }
 
+    // BundleAdjustmentCERESAnalytic::marginalize (…Analytic.cpp:431-663) with Marginalization::preMarginalize
+    // (marginalization.cpp:23-143) restated on the snapshot: frame0 (index into map.frames) is marginalised into a prior
+    // on frame1's states (VIO) and on the landmarks frame0 shares with the rest of the window. Returns false when the
+    // Schur complement is refused (fewer than 4 kept columns, marginalization.cpp:215-216): the prior is then cleared,
+    // as the reference does (…Analytic.cpp:620-625). The prior is held by this object (like _marginalization_last)
+    // and added to the next localMapBA / localMapVIOptimization whose snapshot still contains its variables (by id).
+    bool marginalize(LocalMapSnapshot& map, int frame0, int frame1, bool enable_sparsif) {
+        const int nkf = (int)map.frames.size();
+        if (frame0 < 0 || frame0 >= nkf || frame1 < 0 || frame1 >= nkf || frame0 == frame1) { _err = "marginalize: bad frame index"; return false; }
+        Flat F;
+        flatten(map, 0, map.frames[frame0].has_imu || map.frames[frame1].has_imu, false, false, F);
+        // landmark selection (marginalization.cpp:50-88)
+        std::vector<int32_t> keep, marg;
+        std::vector<int> flat_of(map.landmarks.size(), -1);
+        for (size_t k = 0; k < F.lmk_src.size(); k++) flat_of[F.lmk_src[k]] = (int)k;
+        for (size_t l = 0; l < map.landmarks.size(); l++) {
+            LandmarkState& L = map.landmarks[l];
+            if (L.outlier || !L.in_map || !L.initialized) continue;
+            bool in_frame0 = false, lonely = true;
+            int num_cam = 0;
+            for (const Feature& ft : L.features) {
+                if (ft.frame != frame0) lonely = false; else { num_cam++; in_frame0 = true; }
+            }
+            if (!in_frame0) continue;                       // only the landmarks of frame0 are visited (:51)
+            if (num_cam != 2 && !L.has_prior) continue;     // no full 3D information and no prior: ignored (:72-75)
+            if (!lonely) { L.has_prior = true; keep.push_back(flat_of[l]); }
+            else marg.push_back(flat_of[l]);
+        }
+        // resurrected landmarks of the previous prior (:116-139)
+        bool discard_prior = false;
+        if (_prior.valid)
+            for (size_t q = 0; q < _prior.lmk_id.size() && !discard_prior; q++) {
+                int idx = -1;
+                for (size_t l = 0; l < map.landmarks.size(); l++) if (map.landmarks[l].id == _prior.lmk_id[q]) idx = (int)l;
+                if (idx < 0 || flat_of[idx] < 0) { if (idx >= 0 && map.landmarks[idx].outlier) discard_prior = true; continue; }
+                bool known = false;
+                for (int32_t k : keep) known |= k == flat_of[idx];
+                for (int32_t k : marg) known |= k == flat_of[idx];
+                if (!known) keep.push_back(flat_of[idx]);
+            }
+        if (discard_prior) _prior = Prior();
+        sadvio_marg_request rq{};
+        rq.kf_marg = frame0;
+        rq.marg_has_imu = map.frames[frame0].has_imu ? 1 : 0;
+        rq.kf_keep = map.frames[frame1].has_imu ? frame1 : -1;                          // marginalization.cpp:99-104
+        rq.n_marg = (int)marg.size(); rq.lmk_marg = marg.data();
+        rq.n_keep = (int)keep.size(); rq.lmk_keep = keep.data();
+        sadvio_imu_factor imu{};
+        for (const ImuPair& p : map.imu_pairs)
+            if (p.frame_i == frame0 && p.frame_j == frame1) { imu = p.f; rq.imu = &imu; }
+        std::vector<sadvio_pose_prior> pri;
+        for (const sadvio_pose_prior& p : F.priors) if (p.kf == frame0 || p.kf == frame1) pri.push_back(p);   // …Analytic.cpp:605-617
+        rq.n_prior = (int)pri.size(); rq.priors = pri.data();
+        std::vector<int32_t> last_idx, last_col;
+        if (_prior.valid && _prior.kf_id == map.frames[frame0].id) {                    // the previous prior sits on frame0 (:574-603)
+            rq.last_n_full = _prior.n_full; rq.last_n = _prior.n; rq.last_J = _prior.J.data(); rq.last_r0 = _prior.r0.data();
+            rq.last_kf = _prior.kf_col >= 0 ? frame0 : -1; rq.last_kf_col = std::max(_prior.kf_col, 0);
+            for (size_t q = 0; q < _prior.lmk_id.size(); q++) {
+                int fi = -1;
+                for (size_t k = 0; k < F.lmk_id.size(); k++) if (F.lmk_id[k] == _prior.lmk_id[q]) fi = (int)k;
+                last_idx.push_back(fi < 0 ? 0 : fi); last_col.push_back(fi < 0 ? -1 : _prior.lmk_col[q]);
+            }
+            rq.last_n_keep = (int)last_idx.size(); rq.last_lmk_index = last_idx.data(); rq.last_lmk_col = last_col.data();
+        }
+        const int n = (rq.kf_keep >= 0 ? 15 : 0) + 3 * rq.n_keep;
+        std::vector<int32_t> lcol(std::max<size_t>(keep.size(), 1));
+        std::vector<double> J((size_t)std::max(n * n, 1)), r0((size_t)std::max(n, 1));
+        sadvio_marg_result res{};
+        int rc = upload(F);
+        if (rc == SADVIO_OK) rc = sadvio_ba_marginalize(_h, 0, &rq, &res, lcol.data(), J.data(), r0.data());
+        _prior = Prior(); _sparse.clear(); _sparse_lmk_id.clear();
+        if (rc != SADVIO_OK) { if (rc != SADVIO_E_REFUSED) _err = sadvio_ba_last_error(_h); return false; }
+        _prior.valid = true; _prior.n_full = res.n_full; _prior.n = res.n;
+        _prior.J.assign(J.begin(), J.begin() + (size_t)res.n_full * res.n); _prior.r0.assign(r0.begin(), r0.begin() + res.n_full);
+        _prior.kf_id = rq.kf_keep >= 0 ? map.frames[frame1].id : -1; _prior.kf_col = res.kf_col;
+        for (size_t k = 0; k < keep.size(); k++) { _prior.lmk_id.push_back(F.lmk_id[keep[k]]); _prior.lmk_col.push_back(lcol[k]); }
+        if (enable_sparsif && keep.size() > 1) {
+            std::vector<sadvio_sparse_prior> out(keep.size() + 1);
+            int32_t n_out = 0;
+            rc = sadvio_ba_sparsify(_h, 0, rq.kf_keep >= 0, res.n_full, res.n, _prior.J.data(), rq.kf_keep, std::max(res.kf_col, 0),
+                                    (int)keep.size(), keep.data(), lcol.data(), &n_out, out.data());
+            if (rc == SADVIO_OK) {
+                _sparse.assign(out.begin(), out.begin() + n_out);
+                _sparse_kf_id = rq.kf_keep >= 0 ? map.frames[frame1].id : -1;
+                for (const sadvio_sparse_prior& s : _sparse) { _sparse_lmk_id.push_back(s.lmk0 >= 0 ? F.lmk_id[s.lmk0] : -1); _sparse_lmk_id.push_back(s.lmk1 >= 0 ? F.lmk_id[s.lmk1] : -1); }
+            }
+        }
+        return true;
+    }
+    bool has_prior() const { return _prior.valid; }
+    int prior_rows() const { return _prior.n_full; }
+    size_t sparse_factor_count() const { return _sparse.size(); }
+
     const sadvio_solve_summary& summary() const { return _sum; }
     const std::string& last_error() const { return _err; }
 
   private:
-    bool solve(LocalMapSnapshot& map, size_t fixed, bool vio, const sadvio_solve_options& opt, bool all_const, bool lmk_const) {
-        const int nkf = (int)map.frames.size();
-        std::vector<int64_t> kf_id(nkf), lmk_id;
-        std::vector<double> kf_T(12 * (size_t)nkf), kf_v(3 * (size_t)nkf), kf_ba(3 * (size_t)nkf), kf_bg(3 * (size_t)nkf);
-        std::vector<uint8_t> kf_const(nkf), lc;
-        std::vector<double> cam_K, cam_T, cam_sigma;
-        std::vector<int> cam_base(nkf);
+    struct Flat {   // the flattened window + the vectors it points into
+        sadvio_flat_window w{};
+        std::vector<int64_t> kf_id, lmk_id;
+        std::vector<double> kf_T, kf_v, kf_ba, kf_bg, cam_K, cam_T, cam_sigma, lmk_p, meas;
+        std::vector<uint8_t> kf_const, lc;
+        std::vector<int> cam_base, lmk_src;
+        std::vector<int32_t> ptr, obs_kf, obs_cam;
         std::vector<sadvio_pose_prior> priors;
+        std::vector<sadvio_imu_factor> imus;
+    };
+    struct Prior {  // the dense prior kept between marginalize() and the next window solves, variables named by id
+        bool valid = false;
+        int n_full = 0, n = 0, kf_col = -1;
+        int64_t kf_id = -1;
+        std::vector<double> J, r0;
+        std::vector<int64_t> lmk_id;
+        std::vector<int32_t> lmk_col;
+    };
+
+    // inclusion rules of addResidualsLocalMap (BundleAdjustmentCERESAnalytic.cpp:197-314)
+    void flatten(const LocalMapSnapshot& map, size_t fixed, bool vio, bool all_const, bool lmk_const, Flat& F) const {
+        const int nkf = (int)map.frames.size();
+        F.kf_id.resize(nkf); F.kf_T.resize(12 * (size_t)nkf); F.kf_v.resize(3 * (size_t)nkf); F.kf_ba.resize(3 * (size_t)nkf);
+        F.kf_bg.resize(3 * (size_t)nkf); F.kf_const.resize(nkf); F.cam_base.resize(nkf); F.ptr.assign(1, 0);
         for (int i = 0; i < nkf; i++) {
             const FrameState& f = map.frames[i];
-            kf_id[i] = f.id;
-            std::memcpy(&kf_T[12 * (size_t)i], f.T_f_w.R, 72); std::memcpy(&kf_T[12 * (size_t)i + 9], f.T_f_w.t, 24);
-            std::memcpy(&kf_v[3 * (size_t)i], f.v, 24); std::memcpy(&kf_ba[3 * (size_t)i], f.ba, 24); std::memcpy(&kf_bg[3 * (size_t)i], f.bg, 24);
-            kf_const[i] = all_const || (i > nkf - (int)fixed - 1);                       // …Analytic.cpp:219
+            F.kf_id[i] = f.id;
+            std::memcpy(&F.kf_T[12 * (size_t)i], f.T_f_w.R, 72); std::memcpy(&F.kf_T[12 * (size_t)i + 9], f.T_f_w.t, 24);
+            std::memcpy(&F.kf_v[3 * (size_t)i], f.v, 24); std::memcpy(&F.kf_ba[3 * (size_t)i], f.ba, 24); std::memcpy(&F.kf_bg[3 * (size_t)i], f.bg, 24);
+            F.kf_const[i] = all_const || (i > nkf - (int)fixed - 1);                     // …Analytic.cpp:219
             if (f.has_prior) {                                                           // :224-228
                 sadvio_pose_prior p{};
                 p.kf = i; std::memcpy(p.T_prior, f.T_prior.R, 72); std::memcpy(p.T_prior + 9, f.T_prior.t, 24);
                 std::memcpy(p.inf_diag, f.inf_prior, 48);
-                priors.push_back(p);
+                F.priors.push_back(p);
             }
-            cam_base[i] = (int)cam_sigma.size();
+            F.cam_base[i] = (int)F.cam_sigma.size();
             for (const CameraModel& c : f.cameras) {
                 const double K[4] = {c.fx, c.fy, c.cx, c.cy};
-                cam_K.insert(cam_K.end(), K, K + 4);
-                cam_T.insert(cam_T.end(), c.T_s_f.R, c.T_s_f.R + 9); cam_T.insert(cam_T.end(), c.T_s_f.t, c.T_s_f.t + 3);
-                cam_sigma.push_back(_angular ? 1.5 / (0.5 * (c.fx + c.fy)) : 1.0);      // …Analytic.h:46 / Angular….cpp:283
+                F.cam_K.insert(F.cam_K.end(), K, K + 4);
+                F.cam_T.insert(F.cam_T.end(), c.T_s_f.R, c.T_s_f.R + 9); F.cam_T.insert(F.cam_T.end(), c.T_s_f.t, c.T_s_f.t + 3);
+                F.cam_sigma.push_back(_angular ? 1.5 / (0.5 * (c.fx + c.fy)) : 1.0);    // …Analytic.h:46 / Angular….cpp:283
             }
         }
-        std::vector<int> lmk_src;
-        std::vector<double> lmk_p, meas;
-        std::vector<int32_t> ptr{0}, obs_kf, obs_cam;
         for (int l = 0; l < (int)map.landmarks.size(); l++) {
             const LandmarkState& L = map.landmarks[l];
             if (!L.initialized || L.outlier) continue;                                   // :239
-            lmk_src.push_back(l); lmk_id.push_back(L.id); lc.push_back(lmk_const ? 1 : 0);
-            lmk_p.insert(lmk_p.end(), L.p, L.p + 3);
+            F.lmk_src.push_back(l); F.lmk_id.push_back(L.id); F.lc.push_back(lmk_const ? 1 : 0);
+            F.lmk_p.insert(F.lmk_p.end(), L.p, L.p + 3);
             for (const Feature& ft : L.features) {
                 if (ft.frame < 0 || ft.frame >= nkf) continue;                           // :256-258 (frame not in the window)
                 const CameraModel& c = map.frames[ft.frame].cameras[ft.camera];
-                obs_kf.push_back(ft.frame); obs_cam.push_back(cam_base[ft.frame] + ft.camera);
+                F.obs_kf.push_back(ft.frame); F.obs_cam.push_back(F.cam_base[ft.frame] + ft.camera);
                 if (_angular) {                                                          // Camera.cpp:15-25: K^-1 [u v 1] normalised
-                    double b[3] = {(ft.u - c.cx) / c.fx, (ft.v - c.cy) / c.fy, 1.0};
-                    const double n = std::sqrt(b[0] * b[0] + b[1] * b[1] + 1.0);
-                    meas.insert(meas.end(), {b[0] / n, b[1] / n, b[2] / n});
-                } else meas.insert(meas.end(), {ft.u, ft.v});
+                    const double b[3] = {(ft.u - c.cx) / c.fx, (ft.v - c.cy) / c.fy, 1.0};
+                    const double nn = std::sqrt(b[0] * b[0] + b[1] * b[1] + 1.0);
+                    F.meas.insert(F.meas.end(), {b[0] / nn, b[1] / nn, b[2] / nn});
+                } else F.meas.insert(F.meas.end(), {ft.u, ft.v});
             }
-            ptr.push_back((int32_t)obs_kf.size());
+            F.ptr.push_back((int32_t)F.obs_kf.size());
         }
-        sadvio_flat_window w{};
-        w.n_kf = nkf; w.n_cam = (int)cam_sigma.size(); w.n_lmk = (int)lmk_src.size(); w.n_obs = (int)obs_kf.size();
-        w.factor_type = _angular ? SADVIO_FACTOR_ANGULAR : SADVIO_FACTOR_PIXEL; w.has_imu = vio ? 1 : 0;
-        w.kf_id = kf_id.data(); w.kf_T_f_w = kf_T.data(); w.kf_const = kf_const.data();
-        w.kf_vel = kf_v.data(); w.kf_ba = kf_ba.data(); w.kf_bg = kf_bg.data();
-        w.cam_K = cam_K.data(); w.cam_T_s_f = cam_T.data(); w.cam_sigma = cam_sigma.data();
-        w.lmk_id = lmk_id.data(); w.lmk_p = lmk_p.data(); w.lmk_const = lc.data(); w.lmk_obs_ptr = ptr.data();
-        w.obs_kf = obs_kf.data(); w.obs_cam = obs_cam.data(); w.obs_meas = meas.data();
-        std::vector<sadvio_imu_factor> imus;
         if (vio)
             for (const ImuPair& p : map.imu_pairs) {                                     // AOptimizer.cpp:69-72
                 if (p.frame_i == p.frame_j || p.f.dt > 1.0) continue;
                 sadvio_imu_factor f = p.f; f.kf_i = p.frame_i; f.kf_j = p.frame_j;
-                imus.push_back(f);
+                F.imus.push_back(f);
             }
-        int rc = sadvio_ba_set_windows(_h, 1, &w);
-        if (rc == SADVIO_OK) rc = sadvio_ba_set_pose_priors(_h, 0, (int)priors.size(), priors.data());
-        if (rc == SADVIO_OK && !imus.empty()) rc = sadvio_ba_set_imu_factors(_h, 0, (int)imus.size(), imus.data());
+        sadvio_flat_window& w = F.w;
+        w.n_kf = nkf; w.n_cam = (int)F.cam_sigma.size(); w.n_lmk = (int)F.lmk_src.size(); w.n_obs = (int)F.obs_kf.size();
+        w.factor_type = _angular ? SADVIO_FACTOR_ANGULAR : SADVIO_FACTOR_PIXEL; w.has_imu = vio ? 1 : 0;
+        w.kf_id = F.kf_id.data(); w.kf_T_f_w = F.kf_T.data(); w.kf_const = F.kf_const.data();
+        w.kf_vel = F.kf_v.data(); w.kf_ba = F.kf_ba.data(); w.kf_bg = F.kf_bg.data();
+        w.cam_K = F.cam_K.data(); w.cam_T_s_f = F.cam_T.data(); w.cam_sigma = F.cam_sigma.data();
+        w.lmk_id = F.lmk_id.data(); w.lmk_p = F.lmk_p.data(); w.lmk_const = F.lc.data(); w.lmk_obs_ptr = F.ptr.data();
+        w.obs_kf = F.obs_kf.data(); w.obs_cam = F.obs_cam.data(); w.obs_meas = F.meas.data();
+    }
+
+    int upload(const Flat& F) {
+        int rc = sadvio_ba_set_windows(_h, 1, &F.w);
+        if (rc == SADVIO_OK) rc = sadvio_ba_set_pose_priors(_h, 0, (int)F.priors.size(), F.priors.data());
+        if (rc == SADVIO_OK && !F.imus.empty()) rc = sadvio_ba_set_imu_factors(_h, 0, (int)F.imus.size(), F.imus.data());
+        return rc;
+    }
+
+    // addMarginalizationResiduals (…Analytic.cpp:316-426): the stored prior on the variables still in the window
+    int add_marginalization_prior(const Flat& F) {
+        if (!_sparse.empty()) {
+            std::vector<sadvio_sparse_prior> fs;
+            for (size_t k = 0; k < _sparse.size(); k++) {
+                sadvio_sparse_prior s = _sparse[k];
+                auto find_l = [&](int64_t id) { for (size_t q = 0; q < F.lmk_id.size(); q++) if (F.lmk_id[q] == id) return (int)q; return -1; };
+                auto find_k = [&](int64_t id) { for (size_t q = 0; q < F.kf_id.size(); q++) if (F.kf_id[q] == id) return (int)q; return -1; };
+                if (s.kf >= 0) { s.kf = find_k(_sparse_kf_id); if (s.kf < 0) continue; }
+                if (s.lmk0 >= 0) { s.lmk0 = find_l(_sparse_lmk_id[2 * k]); if (s.lmk0 < 0) continue; }
+                if (s.lmk1 >= 0) { s.lmk1 = find_l(_sparse_lmk_id[2 * k + 1]); if (s.lmk1 < 0) continue; }
+                fs.push_back(s);
+            }
+            return fs.empty() ? SADVIO_OK : sadvio_ba_set_sparse_priors(_h, 0, (int)fs.size(), fs.data());
+        }
+        if (!_prior.valid) return SADVIO_OK;
+        int kf = -1;
+        if (_prior.kf_col >= 0) {
+            for (size_t q = 0; q < F.kf_id.size(); q++) if (F.kf_id[q] == _prior.kf_id) kf = (int)q;
+            if (kf < 0) return SADVIO_OK;   // the kept frame left the window: nothing to attach the prior to
+        }
+        std::vector<int32_t> idx, col;
+        for (size_t q = 0; q < _prior.lmk_id.size(); q++) {
+            int fi = -1;
+            for (size_t k = 0; k < F.lmk_id.size(); k++) if (F.lmk_id[k] == _prior.lmk_id[q]) fi = (int)k;
+            idx.push_back(fi < 0 ? 0 : fi); col.push_back(fi < 0 ? -1 : _prior.lmk_col[q]);   // absent landmark: zero delta
+        }
+        return sadvio_ba_set_dense_prior(_h, 0, _prior.n_full, _prior.n, _prior.J.data(), _prior.r0.data(), kf, std::max(_prior.kf_col, 0),
+                                         (int)idx.size(), idx.data(), col.data());
+    }
+
+    bool solve(LocalMapSnapshot& map, size_t fixed, bool vio, const sadvio_solve_options& opt, bool all_const, bool lmk_const) {
+        const int nkf = (int)map.frames.size();
+        Flat F;
+        flatten(map, fixed, vio, all_const, lmk_const, F);
+        int rc = upload(F);
+        if (rc == SADVIO_OK && !all_const && !lmk_const) rc = add_marginalization_prior(F);   // window solves only
         if (rc == SADVIO_OK) rc = sadvio_ba_solve(_h, &opt, &_sum);
         if (rc != SADVIO_OK && rc != SADVIO_E_NOT_USABLE) { _err = sadvio_ba_last_error(_h); return false; }   // state untouched
         if (rc == SADVIO_E_NOT_USABLE) return false;
-        std::vector<double> dpose(6 * (size_t)nkf), dl(3 * (size_t)std::max(w.n_lmk, 1)), dv(3 * (size_t)nkf), dba(3 * (size_t)nkf), dbg(3 * (size_t)nkf);
+        std::vector<double> dpose(6 * (size_t)nkf), dl(3 * (size_t)std::max(F.w.n_lmk, 1)), dv(3 * (size_t)nkf), dba(3 * (size_t)nkf), dbg(3 * (size_t)nkf);
         if (sadvio_ba_get_deltas(_h, 0, dpose.data(), dl.data(), dv.data(), dba.data(), dbg.data()) != SADVIO_OK) { _err = sadvio_ba_last_error(_h); return false; }
         for (int i = 0; i < nkf; i++) {                                                  // AOptimizer.cpp:329-332
             apply_pose_delta(map.frames[i].T_f_w, &dpose[6 * (size_t)i]);
@@ -217,8 +368,8 @@ class HipOptimizer {
                     map.frames[i].v[a] += dv[3 * (size_t)i + a]; map.frames[i].ba[a] += dba[3 * (size_t)i + a]; map.frames[i].bg[a] += dbg[3 * (size_t)i + a];
                 }
         }
-        for (size_t k = 0; k < lmk_src.size(); k++)                                      // :334-340
-            for (int a = 0; a < 3; a++) map.landmarks[lmk_src[k]].p[a] += dl[3 * k + a];
+        for (size_t k = 0; k < F.lmk_src.size(); k++)                                    // :334-340
+            for (int a = 0; a < 3; a++) map.landmarks[F.lmk_src[k]].p[a] += dl[3 * k + a];
         return true;
     }
 
@@ -226,6 +377,10 @@ class HipOptimizer {
     sadvio_solve_summary _sum{};
     std::string _err;
     bool _angular;
+    Prior _prior;
+    std::vector<sadvio_sparse_prior> _sparse;   // the sparsified prior (indices of the window it was built on)
+    std::vector<int64_t> _sparse_lmk_id;        // [2 k], [2 k + 1]: ids of lmk0 / lmk1 of factor k
+    int64_t _sparse_kf_id = -1;
 };
 
 }  // namespace sadvio

@@ -104,3 +104,10 @@ def test_clearing_the_prior_restores_the_plain_solve(backend_cls, oracle_lib):
     again = be.solve(capi.reference_options())[0].final_cost
     be.close()
     assert abs(with_prior - base) > 1e-3 and np.isclose(again, base, rtol=1e-12)
+
+
+def test_vo_prior_hbm_path(backend_cls, oracle_lib):
+    """Pure VO (6 states per key-frame) with 250 kept landmarks: N_p = 774, dense 96-column panels."""
+    w = synthetic.make_window(n_kf=5, n_lmk=600, seed=35)
+    w.dense_prior = random_prior(w, 250, -1, np.random.default_rng(9), rank_deficit=0)
+    compare(backend_cls, oracle_lib, w, capi.reference_options())
