@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -101,6 +102,66 @@ struct SrcWin {
     std::vector<int32_t> u_obs_cam;
 };
 
+// Host -> device uploads of one layout build are packed into ONE pinned staging buffer, copied with one
+// hipMemcpyAsync and scattered to their destinations by one kernel: ~25 small pageable copies cost ~15 us each.
+struct UploadItem { unsigned long long dst; unsigned long long off; unsigned long long bytes; };
+__global__ void k_scatter_uploads(const char* stage, const UploadItem* items, int n_items) {
+    for (int it = blockIdx.y; it < n_items; it += gridDim.y) {
+        const UploadItem u = items[it];
+        char* dst = (char*)u.dst;
+        const char* src = stage + u.off;
+        const unsigned long long words = u.bytes >> 3;  // staging offsets and device allocations are 8-byte aligned
+        for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (unsigned long long)gridDim.x * blockDim.x)
+            ((unsigned long long*)dst)[i] = ((const unsigned long long*)src)[i];
+        if (blockIdx.x == 0 && threadIdx.x < (u.bytes & 7)) dst[(words << 3) + threadIdx.x] = src[(words << 3) + threadIdx.x];
+    }
+}
+struct UploadBatch {
+    std::vector<UploadItem> items;
+    char* pinned = nullptr; size_t pinned_cap = 0, used = 0;   // sources are packed straight into pinned memory
+    char* dev = nullptr; size_t dev_cap = 0;
+    bool failed = false;
+    void reserve(size_t bytes) {
+        if (bytes <= pinned_cap) return;
+        char* np = nullptr;
+        const size_t cap = bytes + bytes / 2 + 4096;
+        if (hipHostMalloc((void**)&np, cap, hipHostMallocDefault) != hipSuccess) { failed = true; return; }
+        if (pinned) { memcpy(np, pinned, used); (void)hipHostFree(pinned); }
+        pinned = np; pinned_cap = cap;
+    }
+    void add(void* dst, const void* src, size_t bytes) {
+        if (!bytes) return;
+        const size_t off = (used + 7) & ~(size_t)7;
+        reserve(off + bytes);
+        if (failed) return;
+        memcpy(pinned + off, src, bytes);
+        used = off + bytes;
+        items.push_back({(unsigned long long)dst, (unsigned long long)off, (unsigned long long)bytes});
+    }
+    hipError_t flush(hipStream_t stream) {
+        if (failed) { failed = false; items.clear(); used = 0; return hipErrorOutOfMemory; }
+        if (items.empty()) return hipSuccess;
+        const size_t data_bytes = (used + 7) & ~(size_t)7;
+        const size_t total = data_bytes + items.size() * sizeof(UploadItem);
+        reserve(total);
+        if (failed) { failed = false; items.clear(); used = 0; return hipErrorOutOfMemory; }
+        hipError_t e = hipSuccess;
+        if (dev_cap < total) {
+            if (dev) (void)hipFree(dev);
+            dev = nullptr; dev_cap = 0;
+            if ((e = hipMalloc((void**)&dev, total + total / 2)) != hipSuccess) return e;
+            dev_cap = total + total / 2;
+        }
+        memcpy(pinned + data_bytes, items.data(), items.size() * sizeof(UploadItem));
+        if ((e = hipMemcpyAsync(dev, pinned, total, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_scatter_uploads, dim3(64, (unsigned)std::min<size_t>(items.size(), 64)), dim3(256), 0, stream, dev, (const UploadItem*)(dev + data_bytes), (int)items.size());
+        e = hipStreamSynchronize(stream);  // the pinned buffer is reused by the next batch
+        items.clear(); used = 0;
+        return e;
+    }
+    ~UploadBatch() { if (pinned) (void)hipHostFree(pinned); if (dev) (void)hipFree(dev); }
+};
+
 struct DensePriorHost {
     int n_full = 0, n = 0, kf_keep = -1, kf_col = 0;
     std::vector<double> J, r0;
@@ -128,6 +189,7 @@ struct sadvio_ba_handle {
     DevBuf<double> d_big_M;     // inverse diagonal blocks of the wide-panel dense solver, 96 x 96 per 96 columns
     DevBuf<double> d_big_linv;  // inverse pivot blocks of the banded solver, N * NB doubles per out-of-LDS window
     bool uploaded = false, solved = false;
+    UploadBatch up;   // pending host -> device uploads of the current layout build
     // window sharded over several GPUs: collective hook (user callback or the built-in RCCL one)
     int world = 1, rank = 0;
     sadvio_allreduce_fn coll_fn = nullptr;
@@ -396,16 +458,17 @@ int layout_reduced(sadvio_ba_handle* h) {
     HIP_TRY(hipMemsetAsync(h->d_S.p, 0, sizeof(double) * (size_t)std::max<long long>(h->red_total, 1), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_rank_s.p, 0, sizeof(double) * (size_t)nrb, h->stream));
     HIP_TRY(h->d_sparse.alloc(std::max<size_t>(sparse.size(), 1))); HIP_TRY(h->d_sp_scratch.alloc(std::max<size_t>(sparse.size(), 1) * SPARSE_J));
-    if (!sparse.empty()) HIP_TRY(hipMemcpyAsync(h->d_sparse.p, sparse.data(), sparse.size() * sizeof(SparseDev), hipMemcpyHostToDevice, h->stream));
+    h->up.add(h->d_sparse.p, sparse.data(), sparse.size() * sizeof(SparseDev));
     if (kept.empty()) kept.assign(3, 0);
     if (dp_ints.empty()) dp_ints.push_back(0);
     if (dp_data.empty()) dp_data.push_back(0.0);
     HIP_TRY(h->d_tiles.alloc(h->tiles.size())); HIP_TRY(h->d_lmk_red.alloc(lmk_red.size())); HIP_TRY(h->d_lmk_const.alloc(lmk_const.size()));
     HIP_TRY(h->d_kept_obs.alloc(kept.size())); HIP_TRY(h->d_dp_ints.alloc(dp_ints.size())); HIP_TRY(h->d_dp_data.alloc(dp_data.size()));
-#define UP(dst, src) HIP_TRY(hipMemcpyAsync((dst).p, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, h->stream))
+#define UP(dst, src) h->up.add((dst).p, (src).data(), (src).size() * sizeof((src)[0]))
     UP(h->d_tiles, h->tiles); UP(h->d_lmk_red, lmk_red); UP(h->d_lmk_const, lmk_const); UP(h->d_kept_obs, kept);
     UP(h->d_dp_ints, dp_ints); UP(h->d_dp_data, dp_data);
 #undef UP
+    if (!preps.empty()) HIP_TRY(h->up.flush(h->stream));  // the prepare kernels read J on the device
     for (const Prep& pr : preps) {
         double* J = h->d_dp_data.p + pr.off;
         double* Jt = J + (size_t)pr.nf * pr.n;
@@ -413,7 +476,6 @@ int layout_reduced(sadvio_ba_handle* h) {
         const long long items = std::max((long long)pr.nf * pr.n, (long long)pr.n * pr.n);
         hipLaunchKernelGGL(k_dense_prior_prepare, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, J, Jt, H, pr.nf, pr.n);
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));  // host vectors go out of scope
     return SADVIO_OK;
 }
 
@@ -426,7 +488,7 @@ int upload_priors(sadvio_ba_handle* h) {
     }
     HIP_TRY(h->d_priors.alloc(h->priors.size()));
     if (!h->priors.empty())
-        HIP_TRY(hipMemcpyAsync(h->d_priors.p, h->priors.data(), h->priors.size() * sizeof(PriorDev), hipMemcpyHostToDevice, h->stream));
+        h->up.add(h->d_priors.p, h->priors.data(), h->priors.size() * sizeof(PriorDev));
     h->imus.clear();
     for (size_t w = 0; w < h->wins.size(); w++) {
         h->wins[w].d.imu_begin = (int)h->imus.size();
@@ -436,11 +498,11 @@ int upload_priors(sadvio_ba_handle* h) {
     HIP_TRY(h->d_imus.alloc(h->imus.size()));
     HIP_TRY(h->d_imu_scratch.alloc(h->imus.size() * (size_t)(IMU_J + 6)));
     if (!h->imus.empty())
-        HIP_TRY(hipMemcpyAsync(h->d_imus.p, h->imus.data(), h->imus.size() * sizeof(ImuDev), hipMemcpyHostToDevice, h->stream));
+        h->up.add(h->d_imus.p, h->imus.data(), h->imus.size() * sizeof(ImuDev));
     std::vector<WinDev> wd(h->wins.size());
     for (size_t w = 0; w < h->wins.size(); w++) wd[w] = h->wins[w].d;
-    HIP_TRY(hipMemcpyAsync(h->d_win.p, wd.data(), wd.size() * sizeof(WinDev), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->up.add(h->d_win.p, wd.data(), wd.size() * sizeof(WinDev));
+    HIP_TRY(h->up.flush(h->stream));  // one staged copy + scatter for everything queued since the layout build began
     return SADVIO_OK;
 }
 
@@ -519,6 +581,9 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
 // (Re)build the device layout from the stored caller windows + the current factor lists: concatenation, the
 // per-landmark observation order, pseudo-observations of eliminable pose-to-landmark factors, tiles, reduced layout.
 static int build_layout(sadvio_ba_handle* h) {
+    const bool dbg_t = getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 8192);
+    auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (dbg_t) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[sadvio dbg] build_layout %-14s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_start).count()); t_start = t; } };
     const int n_windows = (int)h->src.size();
     HIP_TRY(hipSetDevice(h->device));
     h->solved = false;
@@ -598,6 +663,7 @@ static int build_layout(sadvio_ba_handle* h) {
             S.a_src.clear();
         }
     }
+    lap("views");
     const sadvio_flat_window* wins = views.data();
     h->factor_type = wins[0].factor_type;
     int kf_b = 0, cam_b = 0, lmk_b = 0, obs_b = 0;
@@ -678,11 +744,18 @@ static int build_layout(sadvio_ba_handle* h) {
         // obs_perm maps device position -> caller position for the per-observation probe.
         std::vector<int> pkf(F.n_obs), pcam(F.n_obs);
         std::vector<int> run_max(F.n_lmk, 0);
+        std::vector<int> idx;  // reused across landmarks
         for (int l = 0; l < F.n_lmk; l++) {
             const int o0 = F.lmk_obs_ptr[l], o1 = F.lmk_obs_ptr[l + 1];
-            std::vector<int> idx(o1 - o0);
+            idx.resize(o1 - o0);
             for (int k = 0; k < o1 - o0; k++) idx[k] = o0 + k;
-            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return F.obs_kf[a] < F.obs_kf[b]; });
+            // tracks are short: insertion sort (stable) by key-frame
+            for (int a = 1; a < o1 - o0; a++) {
+                const int v = idx[a], kv = F.obs_kf[v];
+                int b = a - 1;
+                while (b >= 0 && F.obs_kf[idx[b]] > kv) { idx[b + 1] = idx[b]; b--; }
+                idx[b + 1] = v;
+            }
             int run = 0;
             for (int k = 0; k < o1 - o0; k++) {
                 const int src = idx[k], dst = o0 + k;
@@ -714,14 +787,14 @@ static int build_layout(sadvio_ba_handle* h) {
         d.tile_begin = (int)h->tiles.size();
         {
             int l = 0;
-            std::vector<int> mark(F.n_kf, -1);
+            std::vector<int> mark(F.n_kf, -1), add, kfs, slot_of(F.n_kf, -1);
             while (l < F.n_lmk || (int)h->tiles.size() == d.tile_begin) {
                 Tile t{};
                 t.w = w; t.lmk0 = d.lmk_base + l; t.kmax = 1; t.G = 8;
                 t.dpf = d.dpf;  // Np, red_off, S_off, ld: layout_reduced
                 t.cam_base = d.cam_base; t.n_cam = F.n_cam;
                 t.first_of_window = ((int)h->tiles.size() == d.tile_begin) ? 1 : 0;
-                std::vector<int> kfs;
+                kfs.clear();
                 int nfree = 0, tile_run_max = 0;
                 const int l_begin = l;
                 while (l < F.n_lmk) {
@@ -732,7 +805,7 @@ static int build_layout(sadvio_ba_handle* h) {
                     const int cap = BUILD_WAVES * (64 / G);  // landmarks per tile (one round per wave)
                     if (l - l_begin + 1 > cap && l > l_begin) break;
                     // key-frames this landmark would add
-                    std::vector<int> add;
+                    add.clear();
                     int add_free = 0;
                     for (int o = F.lmk_obs_ptr[l]; o < F.lmk_obs_ptr[l + 1]; o++) {
                         const int kf = pkf[o];
@@ -763,7 +836,6 @@ static int build_layout(sadvio_ba_handle* h) {
                 if (t.lds_mode == 2) h->max_gemm_free = std::max(h->max_gemm_free, nfree);
                 if ((int)kfs.size() > 64) { h->err = "set_windows: a landmark is observed from more than 64 key-frames"; return SADVIO_E_INVALID_ARG; }
                 t.kf_off = (int)tile_kf.size(); t.n_kf = (int)kfs.size(); t.n_free = t.lds_mode ? nfree : 0;
-                std::vector<int> slot_of(F.n_kf, -1);
                 int rank = 0;
                 for (size_t i = 0; i < kfs.size(); i++) {
                     const int kf = kfs[i];
@@ -786,6 +858,7 @@ static int build_layout(sadvio_ba_handle* h) {
         d.tile_end = (int)h->tiles.size();
         for (int ti = d.tile_begin; ti < d.tile_end; ti++) { h->tiles[ti].win_tile0 = d.tile_begin; h->tiles[ti].win_ntiles = d.tile_end - d.tile_begin; }
     }
+    lap("concat+tiles");
     if (getenv("SADVIO_DEBUG")) {
         int hist[32] = {0}, modes[3] = {0};
         for (auto& t : h->tiles) { hist[std::min(t.n_free, 31)]++; modes[t.lds_mode]++; }
@@ -806,7 +879,7 @@ static int build_layout(sadvio_ba_handle* h) {
     HIP_TRY(h->d_s_lmk.alloc(3 * (size_t)std::max(lmk_b, 1)));
     HIP_TRY(h->d_lmk_ob.alloc(lmk_ob.size())); HIP_TRY(h->d_lmk_oe.alloc(lmk_oe.size()));
     HIP_TRY(h->d_obs_kf.alloc(obs_kf.size())); HIP_TRY(h->d_obs_cam.alloc(obs_cam.size())); HIP_TRY(h->d_obs_meas.alloc(obs_meas.size()));
-#define UP(dst, src) HIP_TRY(hipMemcpyAsync((dst).p, (src).data(), (src).size() * sizeof((src)[0]), hipMemcpyHostToDevice, h->stream))
+#define UP(dst, src) h->up.add((dst).p, (src).data(), (src).size() * sizeof((src)[0]))
     UP(h->d_kf_T0, kf_T0); UP(h->d_kf_fidx, kf_fidx); UP(h->d_kf_vel, kf_vel);
     UP(h->d_kf_ba, kf_ba); UP(h->d_kf_bg, kf_bg); UP(h->d_cam_K, cam_K); UP(h->d_cam_T, cam_T); UP(h->d_cam_isig, cam_isig);
     if (lmk_b) { UP(h->d_lmk_p, lmk_p); }
@@ -815,10 +888,13 @@ static int build_layout(sadvio_ba_handle* h) {
 #undef UP
     h->h_lmk_const_user = lmk_const; h->user_lmk_const = h->has_lmk_const;
     h->h_lmk_ob = lmk_ob; h->h_lmk_oe = lmk_oe; h->h_kf_fidx = kf_fidx; h->h_obs_kf = obs_kf;
+    lap("alloc+queue");
     int rc = layout_reduced(h);
     if (rc != SADVIO_OK) return rc;
+    lap("layout_reduced");
     rc = upload_priors(h);  // also uploads the window descriptors and synchronises (host vectors go out of scope)
     if (rc != SADVIO_OK) return rc;
+    lap("flush");
     h->uploaded = true;
     for (auto& k : h->kclasses) { k.total_ms = 0; k.launches = 0; }
     return SADVIO_OK;
