@@ -306,6 +306,21 @@ int sadvio_ba_get_ids(sadvio_ba_handle *h, int32_t w, int64_t *kf_id, int64_t *l
 int sadvio_ba_linearize(sadvio_ba_handle *h, int32_t w, const double *pose_delta6, const double *lmk_delta3,
                         double *r2, double *J_pose12, double *J_lmk6);
 
+/* ALandmark::sanityCheck / avgChi2err / chi2err (ALandmark.cpp:98-146) for every landmark of window `w`, the gate
+ * AOptimizer::landmarkOptimization applies before it writes a landmark back (AOptimizer.cpp:124-141):
+ *   avg_chi2[l] = mean over the landmark's observations of |proj - meas|^2 / sigma^2, where an observation whose
+ *                 projection fails the tests of Camera::project (depth < 0.1, pixel outside [0,width]x[0,height],
+ *                 non-finite; Camera.cpp:26-52) counts 1000;
+ *   inlier[l]   = (n_obs >= 2 && avg_chi2 <= 2)   (95 % chi2 test on a 2-D detection).
+ * `image_wh` = n_cam x (width, height) of the caller's cameras (NULL: (2 cx, 2 cy), the bound the factors use).
+ * Evaluated at the deltas given (NULL = zeros = the linearisation origin; the reference tests the landmark's pose
+ * BEFORE the solved delta is applied). sigma is the FEATURE's pixel sigma (AFeature::getSigma, 1.0 everywhere in the
+ * reference, AFeature2D.h:18): `pixel_sigma` > 0 sets it; <= 0 selects the window's cam_sigma for pixel windows and
+ * 1.0 for angular windows (whose cam_sigma is an angle). Angular windows: the measured pixel is recovered from the
+ * stored bearing through K. Either output may be NULL. */
+int sadvio_ba_landmark_chi2(sadvio_ba_handle *h, int32_t w, const double *pose_delta6, const double *lmk_delta3,
+                            const double *image_wh, double pixel_sigma, double *avg_chi2, int32_t *inlier);
+
 /* Average device time in microseconds per kernel class since the last set_windows, measured
  * with hipEvents on the handle's stream (cfg.profile_kernels = 1). `names` receives pointers
  * to static strings. Returns the number of classes written (<= cap). */

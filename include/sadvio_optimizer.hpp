@@ -55,11 +55,13 @@ inline void apply_pose_delta(Pose& T, const double* d6) {
 struct CameraModel {          // one ImageSensor of a key-frame: pinhole K + frame -> sensor transform
     double fx, fy, cx, cy;
     Pose T_s_f;
+    double width = 0, height = 0;   // image size used by ALandmark::sanityCheck (Camera.cpp:45); 0 = (2 cx, 2 cy)
 };
 
 struct FrameState {           // what the optimizer reads / writes of an isae::Frame (+ its IMU)
     int64_t id = 0;
     Pose T_f_w;
+    bool is_keyframe = true;  // Frame::isKeyFrame: window / landmark solves only use features of key-frames (…Analytic.cpp:131,256)
     std::vector<CameraModel> cameras;
     bool has_prior = false;   // Frame::hasPrior / getPrior / getInfPrior (…Analytic.cpp:224-228)
     Pose T_prior;
@@ -117,11 +119,13 @@ class HipOptimizer {
         solve(map, fixed_frame_number, true, o, false, false);
         return true;
     }
-    // AOptimizer::landmarkOptimization (:98-150): poses constant, Huber(sqrt(1.345)), 10 iterations
+    // AOptimizer::landmarkOptimization (:98-150): poses constant, Huber(sqrt(1.345)), 10 iterations; a landmark is
+    // written back only if it passes ALandmark::sanityCheck — evaluated, as in the reference, at the pose it had BEFORE
+    // the solve (:124-141) — and is flagged outlier / inlier by that check
     bool landmarkOptimization(LocalMapSnapshot& map) {
         sadvio_solve_options o; sadvio_ba_default_options(&o);
         o.max_num_iterations = 10; o.huber_a = std::sqrt(1.345);
-        solve(map, 0, false, o, true, false);
+        solve(map, 0, false, o, true, false, true);
         return true;
     }
     // AOptimizer::singleFrameOptimization (:152-217): frame 0 free, landmarks constant, 5 iterations, no loss
@@ -241,6 +245,8 @@ class HipOptimizer {
         std::vector<double> kf_T, kf_v, kf_ba, kf_bg, cam_K, cam_T, cam_sigma, lmk_p, meas;
         std::vector<uint8_t> kf_const, lc;
         std::vector<int> cam_base, lmk_src;
+        std::vector<double> cam_wh;       // image size per flat camera (sanityCheck)
+        int n_non_kf_obs = 0;             // features skipped because their frame is not a key-frame
         std::vector<int32_t> ptr, obs_kf, obs_cam;
         std::vector<sadvio_pose_prior> priors;
         std::vector<sadvio_imu_factor> imus;
@@ -255,7 +261,7 @@ class HipOptimizer {
     };
 
     // inclusion rules of addResidualsLocalMap (BundleAdjustmentCERESAnalytic.cpp:197-314)
-    void flatten(const LocalMapSnapshot& map, size_t fixed, bool vio, bool all_const, bool lmk_const, Flat& F) const {
+    void flatten(const LocalMapSnapshot& map, size_t fixed, bool vio, bool all_const, bool lmk_const, Flat& F, bool kf_only = true) const {
         const int nkf = (int)map.frames.size();
         F.kf_id.resize(nkf); F.kf_T.resize(12 * (size_t)nkf); F.kf_v.resize(3 * (size_t)nkf); F.kf_ba.resize(3 * (size_t)nkf);
         F.kf_bg.resize(3 * (size_t)nkf); F.kf_const.resize(nkf); F.cam_base.resize(nkf); F.ptr.assign(1, 0);
@@ -277,6 +283,7 @@ class HipOptimizer {
                 F.cam_K.insert(F.cam_K.end(), K, K + 4);
                 F.cam_T.insert(F.cam_T.end(), c.T_s_f.R, c.T_s_f.R + 9); F.cam_T.insert(F.cam_T.end(), c.T_s_f.t, c.T_s_f.t + 3);
                 F.cam_sigma.push_back(_angular ? 1.5 / (0.5 * (c.fx + c.fy)) : 1.0);    // …Analytic.h:46 / Angular….cpp:283
+                F.cam_wh.push_back(c.width > 0 ? c.width : 2.0 * c.cx); F.cam_wh.push_back(c.height > 0 ? c.height : 2.0 * c.cy);
             }
         }
         for (int l = 0; l < (int)map.landmarks.size(); l++) {
@@ -286,6 +293,7 @@ class HipOptimizer {
             F.lmk_p.insert(F.lmk_p.end(), L.p, L.p + 3);
             for (const Feature& ft : L.features) {
                 if (ft.frame < 0 || ft.frame >= nkf) continue;                           // :256-258 (frame not in the window)
+                if (kf_only && !map.frames[ft.frame].is_keyframe) { F.n_non_kf_obs++; continue; }   // :131, :256
                 const CameraModel& c = map.frames[ft.frame].cameras[ft.camera];
                 F.obs_kf.push_back(ft.frame); F.obs_cam.push_back(F.cam_base[ft.frame] + ft.camera);
                 if (_angular) {                                                          // Camera.cpp:15-25: K^-1 [u v 1] normalised
@@ -350,10 +358,11 @@ class HipOptimizer {
                                          (int)idx.size(), idx.data(), col.data());
     }
 
-    bool solve(LocalMapSnapshot& map, size_t fixed, bool vio, const sadvio_solve_options& opt, bool all_const, bool lmk_const) {
+    bool solve(LocalMapSnapshot& map, size_t fixed, bool vio, const sadvio_solve_options& opt, bool all_const, bool lmk_const,
+               bool chi2_gate = false) {
         const int nkf = (int)map.frames.size();
         Flat F;
-        flatten(map, fixed, vio, all_const, lmk_const, F);
+        flatten(map, fixed, vio, all_const, lmk_const, F, !lmk_const);   // addSingleFrameResiduals has no key-frame test (:5-50)
         int rc = upload(F);
         if (rc == SADVIO_OK && !all_const && !lmk_const) rc = add_marginalization_prior(F);   // window solves only
         if (rc == SADVIO_OK) rc = sadvio_ba_solve(_h, &opt, &_sum);
@@ -368,8 +377,24 @@ class HipOptimizer {
                     map.frames[i].v[a] += dv[3 * (size_t)i + a]; map.frames[i].ba[a] += dba[3 * (size_t)i + a]; map.frames[i].bg[a] += dbg[3 * (size_t)i + a];
                 }
         }
-        for (size_t k = 0; k < F.lmk_src.size(); k++)                                    // :334-340
-            for (int a = 0; a < 3; a++) map.landmarks[F.lmk_src[k]].p[a] += dl[3 * k + a];
+        std::vector<int32_t> inlier(F.lmk_src.size(), 1);
+        if (chi2_gate && !F.lmk_src.empty()) {                                           // ALandmark.cpp:130-146
+            const Flat* G = &F;
+            Flat Fall;
+            if (F.n_non_kf_obs) {   // sanityCheck walks ALL the features of the landmark, key-frame or not
+                flatten(map, fixed, vio, all_const, lmk_const, Fall, false);
+                if (sadvio_ba_set_windows(_h, 1, &Fall.w) != SADVIO_OK) { _err = sadvio_ba_last_error(_h); return false; }
+                G = &Fall;
+            }
+            if (sadvio_ba_landmark_chi2(_h, 0, nullptr, nullptr, G->cam_wh.data(), 1.0, nullptr, inlier.data()) != SADVIO_OK) {
+                _err = sadvio_ba_last_error(_h); return false;
+            }
+        }
+        for (size_t k = 0; k < F.lmk_src.size(); k++) {                                  // :334-340
+            LandmarkState& L = map.landmarks[F.lmk_src[k]];
+            if (chi2_gate) L.outlier = !inlier[k];                                       // setOutlier / setInlier
+            if (inlier[k]) for (int a = 0; a < 3; a++) L.p[a] += dl[3 * k + a];
+        }
         return true;
     }
 

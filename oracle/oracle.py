@@ -67,6 +67,7 @@ def lib():
         _lib.oracle_solve.argtypes = [C.POINTER(OracleProblem), C.POINTER(SolveOptions), C.POINTER(SolveSummary),
                                       _dp, _dp, _dp, _dp, _dp, _dp, C.c_int32]
         _lib.oracle_linearize.argtypes = [C.POINTER(FlatWindowC), _dp, _dp, _dp, _dp, _dp, _ip]
+        _lib.oracle_landmark_chi2.argtypes = [C.POINTER(FlatWindowC), _dp, _dp, _dp, C.c_double, _dp, _ip]
         _lib.oracle_first_step.argtypes = [C.POINTER(OracleProblem), C.POINTER(SolveOptions), _dp, _dp, _dp, _dp,
                                            C.c_int32]
         _lib.oracle_imu_process.argtypes = [C.POINTER(ImuState), C.POINTER(ImuState), _dp, _dp, C.c_double,
@@ -137,6 +138,18 @@ def linearize(w: FlatWindow, pose_delta=None, lmk_delta=None):
     ld = None if lmk_delta is None else _arr(lmk_delta, 3 * w.n_lmk)
     lib().oracle_linearize(C.byref(wc), _p(pd), _p(ld), _p(r), _p(Jp), _p(Jl), valid.ctypes.data_as(_ip))
     return r, Jp, Jl, valid
+
+
+def landmark_chi2(w: FlatWindow, pose_delta=None, lmk_delta=None, image_wh=None, pixel_sigma=0.0):
+    """(avg_chi2[n_lmk], inlier[n_lmk]) — ALandmark::sanityCheck at the given deltas."""
+    wc = w.to_c()
+    avg = np.zeros(w.n_lmk); inl = np.zeros(w.n_lmk, dtype=np.int32)
+    pd = None if pose_delta is None else _arr(pose_delta, 6 * w.n_kf)
+    ld = None if lmk_delta is None else _arr(lmk_delta, 3 * w.n_lmk)
+    wh = None if image_wh is None else _arr(image_wh, 2 * w.n_cam)
+    rc = lib().oracle_landmark_chi2(C.byref(wc), _p(pd), _p(ld), _p(wh), pixel_sigma, _p(avg), inl.ctypes.data_as(_ip))
+    assert rc == 0, rc
+    return avg, inl
 
 
 def first_step(w: FlatWindow, opts: SolveOptions = None):

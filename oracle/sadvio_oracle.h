@@ -53,6 +53,11 @@ int oracle_solve(const oracle_problem *prob, const sadvio_solve_options *opts, s
                  double *pose_delta6, double *lmk_delta3, double *dv3, double *dba3, double *dbg3,
                  double *iter_log, int32_t iter_log_cap);
 
+/* ALandmark::sanityCheck per landmark (ALandmark.cpp:98-146): mean chi2 of the landmark's observations (failed
+ * projection = 1000) and the 95 % gate (n_obs >= 2 && mean <= 2). Either output may be NULL. */
+int oracle_landmark_chi2(const sadvio_flat_window *win, const double *pose_delta6, const double *lmk_delta3,
+                         const double *image_wh, double pixel_sigma, double *avg_chi2, int32_t *inlier);
+
 /* One LM step computed two ways on the SAME linearisation (zero deltas): via the Schur
  * complement, and returns H (dense, full un-reduced) for an independent check in the tests. */
 int oracle_first_step(const oracle_problem *prob, const sadvio_solve_options *opts, double *delta_pose6,

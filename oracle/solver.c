@@ -961,6 +961,48 @@ int oracle_linearize(const sadvio_flat_window *w, const double *pose_delta6, con
     return 0;
 }
 
+/* ALandmark::chi2err / avgChi2err / sanityCheck (ALandmark.cpp:98-146) with the projection tests of
+ * Camera::project(T_w_lmk, model, scale, p2ds) (Camera.cpp:26-52): depth < 0.1, outside [0,cols]x[0,rows] or
+ * non-finite => the feature counts 1000. image_wh NULL: (2 cx, 2 cy). Angular windows: pixel recovered through K
+ * from the stored bearing (the reference reads the feature's pixel, AFeature2D.h:21). */
+int oracle_landmark_chi2(const sadvio_flat_window *w, const double *pose_delta6, const double *lmk_delta3,
+                         const double *image_wh, double pixel_sigma, double *avg_chi2, int32_t *inlier) {
+    static const double z6[6] = {0, 0, 0, 0, 0, 0};
+    for (int l = 0; l < w->n_lmk; l++) {
+        const double *dl = lmk_delta3 ? lmk_delta3 + 3 * l : z6;
+        double pw[3] = {w->lmk_p[3 * l] + dl[0], w->lmk_p[3 * l + 1] + dl[1], w->lmk_p[3 * l + 2] + dl[2]};
+        double sum = 0.0;
+        int n = 0;
+        for (int o = w->lmk_obs_ptr[l]; o < w->lmk_obs_ptr[l + 1]; o++, n++) {
+            int kf = w->obs_kf[o], cam = w->obs_cam[o];
+            const double *K = w->cam_K + 4 * cam;
+            double dT[12], Tfw[12], Tsw[12], tc[3];
+            se3_from_delta6(pose_delta6 ? pose_delta6 + 6 * kf : z6, dT);
+            se3_mul(w->kf_T_f_w + 12 * kf, dT, Tfw);
+            se3_mul(w->cam_T_s_f + 12 * cam, Tfw, Tsw); /* getWorld2SensorTransform() */
+            se3_apply(Tsw, pw, tc);
+            double pt[3] = {K[0] * tc[0] + K[2] * tc[2], K[1] * tc[1] + K[3] * tc[2], tc[2]};
+            double u = pt[0] / pt[2], v = pt[1] / pt[2];
+            double cols = image_wh ? image_wh[2 * cam] : 2.0 * K[2], rows = image_wh ? image_wh[2 * cam + 1] : 2.0 * K[3];
+            double mu, mv;
+            if (w->factor_type == SADVIO_FACTOR_PIXEL) { mu = w->obs_meas[2 * o]; mv = w->obs_meas[2 * o + 1]; }
+            else {
+                const double *b = w->obs_meas + 3 * o;
+                mu = K[0] * b[0] / b[2] + K[2]; mv = K[1] * b[1] / b[2] + K[3];
+            }
+            if (tc[2] < 0.1 || u < 0 || v < 0 || u > cols || v > rows || !isfinite(u) || !isfinite(v)) { sum += 1000.0; continue; }
+            /* f->getSigma(): the feature's PIXEL sigma, 1.0 in the reference (AFeature2D.h:18) */
+            double sg = pixel_sigma > 0 ? pixel_sigma : (w->factor_type == SADVIO_FACTOR_PIXEL && w->cam_sigma ? w->cam_sigma[cam] : 1.0);
+            double e0 = (u - mu) / sg, e1 = (v - mv) / sg;
+            sum += e0 * e0 + e1 * e1; /* one point per feature: the mean over getPoints() is the value itself */
+        }
+        double avg = n ? sum / n : 0.0;
+        if (avg_chi2) avg_chi2[l] = avg;
+        if (inlier) inlier[l] = (n >= 2 && !(avg > 2.0)) ? 1 : 0;
+    }
+    return 0;
+}
+
 /* ---- factor / geometry probes ---- */
 void oracle_factor_pixel(const double *T0, const double *K, const double *Tsf, const double *p0, const double *uv,
                          double sigma, const double *dpose, const double *dl, double *r, double *Jp, double *Jl,

@@ -303,6 +303,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.sadvio_ba_get_deltas.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
     lib.sadvio_ba_get_ids.argtypes = [C.c_void_p, C.c_int32, _lp, _lp]
     lib.sadvio_ba_linearize.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
+    lib.sadvio_ba_landmark_chi2.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, C.c_double, _dp, _ip]
     lib.sadvio_ba_get_kernel_times.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), _dp, _lp]
     lib.sadvio_ba_last_error.argtypes = [C.c_void_p]
     lib.sadvio_ba_last_error.restype = C.c_char_p
@@ -463,6 +464,17 @@ class Backend:
         self._check(self.lib.sadvio_ba_linearize(self.h, w, _ptr(pd), _ptr(ld), _ptr(r), _ptr(Jp), _ptr(Jl)),
                     "linearize")
         return r, Jp, Jl
+
+    def landmark_chi2(self, w: int = 0, pose_delta=None, lmk_delta=None, image_wh=None, pixel_sigma=0.0):
+        """(avg_chi2[n_lmk], inlier[n_lmk]) — ALandmark::sanityCheck (ALandmark.cpp:98-146) at the given deltas."""
+        win = self.windows[w]
+        avg = np.zeros(win.n_lmk); inl = np.zeros(win.n_lmk, dtype=np.int32)
+        pd = None if pose_delta is None else np.ascontiguousarray(pose_delta, dtype=np.float64)
+        ld = None if lmk_delta is None else np.ascontiguousarray(lmk_delta, dtype=np.float64)
+        wh = None if image_wh is None else np.ascontiguousarray(image_wh, dtype=np.float64)
+        self._check(self.lib.sadvio_ba_landmark_chi2(self.h, w, _ptr(pd), _ptr(ld), _ptr(wh), pixel_sigma, _ptr(avg),
+                                                     inl.ctypes.data_as(_ip)), "landmark_chi2")
+        return avg, inl
 
     def kernel_times(self):
         cap = 32

@@ -100,6 +100,7 @@ struct SrcWin {
     // i.e. 2 x N_kf table entries that are all copies of the rig's two cameras
     std::vector<double> u_cam_K, u_cam_T, u_cam_sigma;
     std::vector<int32_t> u_obs_cam;
+    std::vector<int> cam_map;   // caller's camera index -> stored camera index
 };
 
 // Host -> device uploads of one layout build are packed into ONE pinned staging buffer, copied with one
@@ -618,6 +619,7 @@ static int build_layout(sadvio_ba_handle* h) {
             }
             S.u_obs_cam.resize(S.obs_cam.size());
             for (size_t o = 0; o < S.obs_cam.size(); o++) S.u_obs_cam[o] = cmap[S.obs_cam[o]];
+            S.cam_map = cmap;
             views[w].n_cam = (int32_t)S.u_cam_sigma.size();
             views[w].cam_K = S.u_cam_K.data(); views[w].cam_T_s_f = S.u_cam_T.data(); views[w].cam_sigma = S.u_cam_sigma.data();
             views[w].obs_cam = S.u_obs_cam.data();
@@ -1914,6 +1916,49 @@ int sadvio_ba_linearize(sadvio_ba_handle* h, int32_t w, const double* pose_delta
         if (Jl6) memcpy(Jl6 + 6 * (size_t)src, &hb[14 * (size_t)d.n_obs + 6 * (size_t)a], 48);
     }
     h->solved = false;
+    return SADVIO_OK;
+}
+
+int sadvio_ba_landmark_chi2(sadvio_ba_handle* h, int32_t w, const double* pose_delta6, const double* lmk_delta3, const double* image_wh,
+                            double pixel_sigma, double* avg_chi2, int32_t* inlier) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (!h->uploaded) { h->err = "landmark_chi2 before set_windows"; return SADVIO_E_STATE; }
+    if (w < 0 || w >= (int)h->wins.size()) { h->err = "landmark_chi2: window out of range"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    const WinDev& d = h->wins[w].d;
+    if (d.n_lmk == 0) return SADVIO_OK;
+    const SrcWin& S = h->src[w];
+    // image bounds per stored camera (identical cameras are stored once; they must agree on the image size)
+    std::vector<double> wh(2 * (size_t)d.n_cam, -1.0);
+    for (int c = 0; c < S.v.n_cam; c++) {
+        const int u = S.cam_map[c];
+        const double bw = image_wh ? image_wh[2 * c] : 2.0 * S.cam_K[4 * (size_t)c + 2], bh = image_wh ? image_wh[2 * c + 1] : 2.0 * S.cam_K[4 * (size_t)c + 3];
+        if (wh[2 * u] >= 0.0 && (wh[2 * u] != bw || wh[2 * u + 1] != bh)) { h->err = "landmark_chi2: cameras with identical (K, T_s_f, sigma) differ in image size"; return SADVIO_E_INVALID_ARG; }
+        wh[2 * u] = bw; wh[2 * u + 1] = bh;
+    }
+    // deltas live in scratch (the solved state of the handle stays readable): [wh | out | xp | xl]
+    const size_t n_wh = 2 * (size_t)(d.cam_base + d.n_cam), n_xp = 6 * (size_t)d.n_kf, n_xl = 3 * (size_t)d.n_lmk;
+    HIP_TRY(h->d_probe.alloc(n_wh + 2 * (size_t)d.n_lmk + n_xp + n_xl));
+    double* d_wh = h->d_probe.p; double* d_out = d_wh + n_wh; double* d_sxp = d_out + 2 * (size_t)d.n_lmk; double* d_sxl = d_sxp + n_xp;
+    HIP_TRY(hipMemsetAsync(d_sxp, 0, sizeof(double) * (n_xp + n_xl), h->stream));
+    if (pose_delta6) HIP_TRY(hipMemcpyAsync(d_sxp, pose_delta6, sizeof(double) * n_xp, hipMemcpyHostToDevice, h->stream));
+    if (lmk_delta3) HIP_TRY(hipMemcpyAsync(d_sxl, lmk_delta3, sizeof(double) * n_xl, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_wh + 2 * (size_t)d.cam_base, wh.data(), sizeof(double) * wh.size(), hipMemcpyHostToDevice, h->stream));
+    SolveOpts o{};
+    DevPtrs P = make_ptrs(h, o, 1);
+    P.xp = d_sxp - 6 * (ptrdiff_t)d.kf_base; P.xl = d_sxl - 3 * (ptrdiff_t)d.lmk_base;  // the kernel indexes globally
+    const int blocks = (d.n_lmk + 63) / 64;
+    const double isig = pixel_sigma > 0.0 ? 1.0 / pixel_sigma : (h->factor_type == SADVIO_FACTOR_PIXEL ? 0.0 : 1.0);  // 0: cam_isig
+    if (h->factor_type == SADVIO_FACTOR_PIXEL) hipLaunchKernelGGL(k_lmk_chi2<0>, dim3(blocks), dim3(64), 0, h->stream, P, w, d_wh, isig, d_out);
+    else hipLaunchKernelGGL(k_lmk_chi2<1>, dim3(blocks), dim3(64), 0, h->stream, P, w, d_wh, isig, d_out);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> hb(2 * (size_t)d.n_lmk);
+    HIP_TRY(hipMemcpyAsync(hb.data(), d_out, sizeof(double) * hb.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int l = 0; l < d.n_lmk; l++) {
+        if (avg_chi2) avg_chi2[l] = hb[2 * (size_t)l];
+        if (inlier) inlier[l] = (hb[2 * (size_t)l + 1] >= 2.0 && !(hb[2 * (size_t)l] > 2.0)) ? 1 : 0;
+    }
     return SADVIO_OK;
 }
 

@@ -1924,4 +1924,48 @@ __global__ void k_linearize_probe(DevPtrs P, int w, double* r2, double* Jp12, do
     for (int i = 0; i < 6; i++) Jl6[6 * (long long)a + i] = Jl[i];
 }
 
+// ALandmark::avgChi2err (ALandmark.cpp:98-128) per landmark, at the deltas held in buffer 0: one lane per landmark
+// (front-end windows hold a few hundred landmarks with short tracks). out[2 l] = mean chi2, out[2 l + 1] = n_obs.
+template <int FACTOR>
+__global__ void k_lmk_chi2(DevPtrs P, int w, const double* wh, double inv_sigma_px, double* out) {
+    const WinDev W = P.win[w];
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= W.n_lmk) return;
+    const long long gl = W.lmk_base + l;
+    const double pw[3] = {P.lmk_p[3 * gl] + P.xl[3 * gl], P.lmk_p[3 * gl + 1] + P.xl[3 * gl + 1], P.lmk_p[3 * gl + 2] + P.xl[3 * gl + 2]};
+    double sum = 0.0;
+    int n = 0;
+    for (int o = P.lmk_ob[gl]; o < P.lmk_oe[gl]; o++) {
+        const int kf = P.obs_kf[o], cam = P.obs_cam[o];
+        if (cam < 0) continue;  // pseudo-observation of a sparse prior factor
+        double d6[6], dR[9], R[9], pf[3], pc[3];
+        for (int i = 0; i < 6; i++) d6[i] = P.xp[6 * (long long)kf + i];
+        const double* T0 = P.kf_T0 + 12 * (long long)kf;
+        so3_exp(d6, dR);
+        m3_mul(T0, dR, R);
+        double t[3];
+        m3_vec(T0, d6 + 3, t);
+        m3_vec(R, pw, pf);
+        for (int a = 0; a < 3; a++) pf[a] += t[a] + T0[9 + a];
+        const double* Ts = P.cam_T + 12 * (long long)cam;
+        m3_vec(Ts, pf, pc);
+        for (int a = 0; a < 3; a++) pc[a] += Ts[9 + a];
+        const double* K = P.cam_K + 4 * (long long)cam;
+        const double u = (K[0] * pc[0] + K[2] * pc[2]) / pc[2], v = (K[1] * pc[1] + K[3] * pc[2]) / pc[2];
+        double mu, mv;
+        if (FACTOR == 0) { mu = P.obs_meas[2 * (long long)o]; mv = P.obs_meas[2 * (long long)o + 1]; }
+        else {
+            const double* b = P.obs_meas + 3 * (long long)o;
+            mu = K[0] * b[0] / b[2] + K[2]; mv = K[1] * b[1] / b[2] + K[3];
+        }
+        const bool ok = !(pc[2] < 0.1) && !(u < 0.0 || v < 0.0 || u > wh[2 * cam] || v > wh[2 * cam + 1]) && isfinite(u) && isfinite(v);
+        const double is = inv_sigma_px > 0.0 ? inv_sigma_px : P.cam_isig[cam];
+        const double e0 = (u - mu) * is, e1 = (v - mv) * is;
+        sum += ok ? e0 * e0 + e1 * e1 : 1000.0;
+        n++;
+    }
+    out[2 * l] = n ? sum / (double)n : 0.0;
+    out[2 * l + 1] = (double)n;
+}
+
 }  // namespace sadvio

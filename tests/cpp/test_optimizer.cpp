@@ -88,16 +88,26 @@ int main() {
         check(m.landmarks[3].p[0] == p3, "localMapBA: outlier landmark untouched");
         check(pose_err(m.frames.back().T_f_w, truth.frames.back().T_f_w) == 0.0, "localMapBA: fixed oldest frame untouched");
     }
-    // --- landmarkOptimization: poses constant, landmarks move back ---
+    // --- landmarkOptimization: poses constant; landmarks that pass the chi2 gate at their OLD pose move back, the
+    //     others are flagged outlier and left where they were (AOptimizer.cpp:124-141, ALandmark.cpp:130-146) ---
     {
         LocalMapSnapshot truth = make_map(rng, 4, 200), m = truth;
-        for (auto& L : m.landmarks) for (double& x : L.p) x += 0.004 * G(rng);   // ~1 px: inside the Huber inlier region
+        for (auto& L : m.landmarks) for (double& x : L.p) x += 0.002 * G(rng);   // ~0.5 px: inside the Huber inlier region
+        m.landmarks[5].p[0] += 0.2;                                               // ~20 px off: fails the 95 % chi2 test
+        m.frames[0].is_keyframe = false;                                          // its features leave the residuals, not the gate
+        const LocalMapSnapshot before = m;
         check(opt.landmarkOptimization(m), "landmarkOptimization returns true");
-        double wl = 0, wp = 0;
-        for (size_t l = 0; l < m.landmarks.size(); l++) for (int a = 0; a < 3; a++) wl = std::fmax(wl, std::fabs(m.landmarks[l].p[a] - truth.landmarks[l].p[a]));
+        double wl = 0, wp = 0, moved_out = 0;
+        int n_in = 0, n_out = 0;
+        for (size_t l = 0; l < m.landmarks.size(); l++) {
+            if (m.landmarks[l].outlier) { n_out++; for (int a = 0; a < 3; a++) moved_out = std::fmax(moved_out, std::fabs(m.landmarks[l].p[a] - before.landmarks[l].p[a])); }
+            else { n_in++; for (int a = 0; a < 3; a++) wl = std::fmax(wl, std::fabs(m.landmarks[l].p[a] - truth.landmarks[l].p[a])); }
+        }
         for (size_t i = 0; i < m.frames.size(); i++) wp = std::fmax(wp, pose_err(m.frames[i].T_f_w, truth.frames[i].T_f_w));
-        std::printf("   lmk err %.3e pose err %.3e it %d cost %.3e -> %.3e\n", wl, wp, opt.summary().iterations, opt.summary().initial_cost, opt.summary().final_cost);
-        check(wl < 1e-3 && wp == 0.0, "landmarkOptimization: landmarks recovered, frames untouched");
+        std::printf("   inliers %d outliers %d lmk err %.3e pose err %.3e it %d cost %.3e -> %.3e\n", n_in, n_out, wl, wp, opt.summary().iterations, opt.summary().initial_cost, opt.summary().final_cost);
+        check(wl < 1e-3 && wp == 0.0, "landmarkOptimization: inlier landmarks recovered, frames untouched");
+        check(m.landmarks[5].outlier && moved_out == 0.0, "landmarkOptimization: chi2-rejected landmarks flagged and untouched");
+        check(n_in > 4 * n_out, "landmarkOptimization: most landmarks pass the gate");
     }
     // --- singleFrameOptimization: one frame against constant landmarks ---
     {

@@ -59,3 +59,35 @@ def test_window_ba_with_huber_loss(backend_cls, oracle_lib):
     w = with_outliers(synthetic.make_window(n_kf=8, n_lmk=800, seed=56), frac=0.08, seed=4)
     o = capi.reference_options(); o.huber_a = 1.345 ** 0.5
     compare(backend_cls, oracle_lib, w, o)
+
+
+@pytest.mark.parametrize("factor", [capi.FACTOR_PIXEL, capi.FACTOR_ANGULAR])
+def test_landmark_chi2_gate(backend_cls, oracle_lib, factor):
+    """ALandmark::sanityCheck (ALandmark.cpp:98-146), the gate of landmarkOptimization's write-back
+    (AOptimizer.cpp:124-141): per-landmark mean chi2 and inlier flag, at the origin and at the solved state."""
+    w = landmark_optimization_window(factor=factor, seed=57 + factor)
+    if factor == capi.FACTOR_ANGULAR:
+        w.obs_meas /= np.linalg.norm(w.obs_meas, axis=1, keepdims=True)
+    w.lmk_p = w.lmk_p.copy()
+    w.lmk_p[3] += np.array([0.0, 0.0, -60.0])      # behind the cameras: every feature counts 1000
+    w.lmk_p[7] += np.array([40.0, 0.0, 0.0])       # outside the image
+    wh = np.tile([700.0, 460.0], (w.n_cam, 1))
+    be = backend_cls(device=0)
+    try:
+        be.set_windows([w])
+        be.solve(capi.landmark_optimization_options())
+        d = be.get_deltas(0)
+        a0, i0 = be.landmark_chi2(0)
+        a1, i1 = be.landmark_chi2(0, lmk_delta=d["lmk"])
+        a2, i2 = be.landmark_chi2(0, lmk_delta=d["lmk"], image_wh=wh)
+        d_again = be.get_deltas(0)                 # the probe leaves the solved state readable
+    finally:
+        be.close()
+    for (a, i), kw in (((a0, i0), {}), ((a1, i1), {"lmk_delta": d["lmk"]}), ((a2, i2), {"lmk_delta": d["lmk"], "image_wh": wh})):
+        ar, ir = oracle_lib.landmark_chi2(w, **kw)
+        assert np.allclose(a, ar, rtol=1e-9, atol=1e-9)
+        sure = np.abs(ar - 2.0) > 1e-6             # away from the threshold the flags are identical
+        assert (i[sure] == ir[sure]).all()
+    assert a0[3] == 1000.0 and i0[3] == 0 and i0[7] == 0
+    assert i1.sum() > i0.sum() and i2.sum() <= i1.sum()
+    assert np.array_equal(d_again["lmk"], d["lmk"])

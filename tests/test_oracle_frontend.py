@@ -71,3 +71,61 @@ def test_single_frame_optimization_recovers_the_pose(oracle_lib):
     ang, dist = synthetic.pose_distance(synthetic.apply_pose_delta(w.kf_T_f_w[0], res["pose"][0]), w.truth["T_f_w"][0])
     ang0, dist0 = synthetic.pose_distance(w.kf_T_f_w[0], w.truth["T_f_w"][0])
     assert ang < 0.1 * ang0 and dist < 0.2 * dist0 and res["summary"].iterations <= 5
+
+
+def _chi2_numpy(w, lmk_delta=None, image_wh=None):
+    """Independent restatement of ALandmark::avgChi2err with homogeneous 4x4 matrices."""
+    def T4(t12):
+        M = np.eye(4); M[:3, :3] = np.asarray(t12[:9]).reshape(3, 3); M[:3, 3] = t12[9:]
+        return M
+    avg = np.zeros(w.n_lmk); inl = np.zeros(w.n_lmk, dtype=np.int32)
+    for l in range(w.n_lmk):
+        p = np.append(w.lmk_p[l] + (0 if lmk_delta is None else lmk_delta[l]), 1.0)
+        vals = []
+        for o in range(w.lmk_obs_ptr[l], w.lmk_obs_ptr[l + 1]):
+            k, c = int(w.obs_kf[o]), int(w.obs_cam[o])
+            fx, fy, cx, cy = w.cam_K[c]
+            tc = (T4(w.cam_T_s_f[c]) @ T4(w.kf_T_f_w[k]) @ p)[:3]
+            u, v = fx * tc[0] / tc[2] + cx, fy * tc[1] / tc[2] + cy
+            cols, rows = (2 * cx, 2 * cy) if image_wh is None else image_wh[c]
+            if tc[2] < 0.1 or u < 0 or v < 0 or u > cols or v > rows or not np.isfinite([u, v]).all():
+                vals.append(1000.0)
+            else:
+                vals.append((((np.array([u, v]) - w.obs_meas[o]) / w.cam_sigma[c]) ** 2).sum())
+        avg[l] = np.mean(vals) if vals else 0.0
+        inl[l] = int(len(vals) >= 2 and avg[l] <= 2.0)
+    return avg, inl
+
+
+def test_landmark_chi2_matches_independent_restatement(oracle_lib):
+    """ALandmark::sanityCheck (ALandmark.cpp:98-146): mean chi2 per landmark, 1000 for failed projections, gate at 2."""
+    w = landmark_optimization_window(n_lmk=200)
+    # a landmark behind the cameras, one far outside the image, one with a single observation
+    w.lmk_p = w.lmk_p.copy()
+    w.lmk_p[3] = w.lmk_p[3] + np.array([0.0, 0.0, -60.0])
+    w.lmk_p[7] = w.lmk_p[7] + np.array([40.0, 0.0, 0.0])
+    avg, inl = oracle_lib.landmark_chi2(w)
+    avg_n, inl_n = _chi2_numpy(w)
+    assert np.allclose(avg, avg_n, rtol=1e-10, atol=1e-12) and (inl == inl_n).all()
+    assert avg[3] == 1000.0 and inl[3] == 0 and inl[7] == 0
+    # explicit image size: a tighter image rejects more
+    wh = np.tile([600.0, 400.0], (w.n_cam, 1))
+    avg2, inl2 = oracle_lib.landmark_chi2(w, image_wh=wh)
+    avg2_n, inl2_n = _chi2_numpy(w, image_wh=wh)
+    assert np.allclose(avg2, avg2_n, rtol=1e-10, atol=1e-12) and (inl2 == inl2_n).all() and inl2.sum() < inl.sum()
+    # at the solved landmark positions the inlier tracks improve
+    res = oracle_lib.solve(w, capi.landmark_optimization_options())
+    avg3, inl3 = oracle_lib.landmark_chi2(w, lmk_delta=res["lmk"])
+    avg3_n, inl3_n = _chi2_numpy(w, lmk_delta=res["lmk"])
+    assert np.allclose(avg3, avg3_n, rtol=1e-9, atol=1e-10) and (inl3 == inl3_n).all()
+    # the 5 cm initial landmark error fails the test at the origin; the solved positions of clean tracks pass it
+    clean = np.ones(w.n_lmk, dtype=bool)
+    clean[np.searchsorted(w.lmk_obs_ptr, w.truth["outliers"], side="right") - 1] = False
+    clean[[3, 7]] = False
+    assert inl.mean() < 0.3 and inl3[clean].mean() > 0.8 and inl3[~clean].mean() < inl3[clean].mean()
+
+
+def test_landmark_chi2_single_observation_is_outlier(oracle_lib):
+    w = synthetic.make_window(n_kf=1, n_lmk=20, obs_per_lmk=1, seed=60, fixed=0)
+    avg, inl = oracle_lib.landmark_chi2(w)
+    assert (inl == 0).all() and (avg < 1000).any()
