@@ -321,6 +321,39 @@ int sadvio_ba_linearize(sadvio_ba_handle *h, int32_t w, const double *pose_delta
 int sadvio_ba_landmark_chi2(sadvio_ba_handle *h, int32_t w, const double *pose_delta6, const double *lmk_delta3,
                             const double *image_wh, double pixel_sigma, double *avg_chi2, int32_t *inlier);
 
+/* ---- visual-inertial initialisation: AOptimizer::VIInit (AOptimizer.cpp:448-581) ----
+ * Unknowns: the gravity direction r_wi (2 parameters, R_w_i = exp_so3((r0, r1, 0)), :464-466, :537), one velocity
+ * delta per frame that an IMUFactorInit touches (:459-463), the log-scale lambda (:478-481; constant unless
+ * optim_scale) and the bias deltas dba, dbg (constant in VIInit, :469-476; `optim_bias` frees them, which is how the
+ * reference's own factor test drives IMUFactorInit, imu_test.cpp:505-545). Residuals: IMUFactorInit
+ * (residuals.hpp:302-410) per pair, + the two bias priors Landmark3DPrior(0, 0, I / sigma) (:503-516) when the biases
+ * are free. Solved with the same Ceres-2.2 LM rules as the window solves (the reference: 50 iterations, f_tol 1e-3). */
+typedef struct sadvio_viinit_problem {
+    int32_t n_frames;
+    int32_t n_factors;
+    const double *T_f_w;              /* [n_frames][12] */
+    const double *vel;                /* [n_frames][3] IMU::getVelocity of each frame */
+    const sadvio_imu_factor *factors; /* IMUFactorInit(imu_i, imu_j): kf_i / kf_j index the frames (pairing rule :485-500:
+                                         i = imu_j->getLastKF(), i != j); dt, delta_*, J_*, cov are read */
+    int32_t optim_scale;
+    int32_t optim_bias;
+    double sigma_dba, sigma_dbg;      /* sqrt(dt_window) * b{acc,gyr}_noise (:504-512); read only when optim_bias */
+} sadvio_viinit_problem;
+
+typedef struct sadvio_viinit_result {
+    double r_wi[2];
+    double lambda;
+    double dba[3], dbg[3];
+    double R_w_i[9]; /* exp_so3((r_wi, 0)) row-major: what VIInit hands back through its R_w_i argument */
+    double scale;    /* exp(lambda): VIInit's return value (:575) */
+} sadvio_viinit_result;
+
+/* dv3: [n_frames][3] velocity deltas (zero for frames no factor touches). The adapter applies the result as
+ * AOptimizer.cpp:526-562 (velocities, T_f_w.translation() *= scale, T_f_w = T_f_w * T_w_i, landmarks, priors).
+ * At most 48 frames (the whole solve runs inside one workgroup). */
+int sadvio_ba_vi_init(sadvio_ba_handle *h, const sadvio_viinit_problem *prob, const sadvio_solve_options *opts,
+                      sadvio_solve_summary *summary, sadvio_viinit_result *res, double *dv3);
+
 /* Average device time in microseconds per kernel class since the last set_windows, measured
  * with hipEvents on the handle's stream (cfg.profile_kernels = 1). `names` receives pointers
  * to static strings. Returns the number of classes written (<= cap). */

@@ -142,6 +142,57 @@ class HipOptimizer {
         return solve(map, 0, true, o, false, true);
     }
 
+    // AOptimizer::VIInit (:448-581): gravity direction, velocities and (optim_scale) the metric scale of a visual-only
+    // map from the pre-integrated IMU factors between its key-frames; returns exp(lambda) and applies the result as
+    // :526-562 — velocities += dv, T_f_w <- (R_f_w, s t_f_w) * (R_w_i, 0), priors re-anchored at 100, landmarks
+    // p <- s R_w_i^T p. (The reference adds dba to Ba twice and never updates Bg, :529-530; both deltas are constant
+    // zero in this problem, :472-476, so nothing is written.) R_w_i is row-major 3x3. On a backend error nothing is
+    // written and 1.0 is returned.
+    double VIInit(LocalMapSnapshot& map, double* R_w_i, bool optim_scale = false) {
+        const int n = (int)map.frames.size();
+        std::vector<double> T(12 * (size_t)n), vel(3 * (size_t)n), dv(3 * (size_t)n, 0.0);
+        for (int i = 0; i < n; i++) {
+            std::memcpy(&T[12 * (size_t)i], map.frames[i].T_f_w.R, 72); std::memcpy(&T[12 * (size_t)i + 9], map.frames[i].T_f_w.t, 24);
+            std::memcpy(&vel[3 * (size_t)i], map.frames[i].v, 24);
+        }
+        std::vector<sadvio_imu_factor> fs;
+        for (const ImuPair& p : map.imu_pairs) {                                          // :485-500
+            if (p.frame_i == p.frame_j || p.frame_i < 0 || p.frame_j < 0 || p.frame_i >= n || p.frame_j >= n) continue;
+            if (!map.frames[p.frame_i].has_imu || !map.frames[p.frame_j].has_imu) continue;
+            sadvio_imu_factor f = p.f; f.kf_i = p.frame_i; f.kf_j = p.frame_j;
+            fs.push_back(f);
+        }
+        sadvio_viinit_problem pb{};
+        pb.n_frames = n; pb.n_factors = (int)fs.size(); pb.T_f_w = T.data(); pb.vel = vel.data(); pb.factors = fs.data();
+        pb.optim_scale = optim_scale ? 1 : 0; pb.optim_bias = 0; pb.sigma_dba = pb.sigma_dbg = 1.0;
+        sadvio_solve_options o; sadvio_ba_default_options(&o);
+        o.max_num_iterations = 50;                                                        // :519-527
+        sadvio_viinit_result r{};
+        const int rc = sadvio_ba_vi_init(_h, &pb, &o, &_sum, &r, dv.data());
+        const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (R_w_i) std::memcpy(R_w_i, I3, sizeof(I3));
+        if (rc != SADVIO_OK) { _err = sadvio_ba_last_error(_h); return 1.0; }
+        if (R_w_i) std::memcpy(R_w_i, r.R_w_i, sizeof(r.R_w_i));
+        const double s = r.scale;
+        for (int i = 0; i < n; i++) {
+            FrameState& f = map.frames[i];
+            if (f.has_imu) for (int a = 0; a < 3; a++) f.v[a] += dv[3 * (size_t)i + a];   // :526-531
+            double Rn[9];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) Rn[3 * a + b] = f.T_f_w.R[3 * a] * r.R_w_i[b] + f.T_f_w.R[3 * a + 1] * r.R_w_i[3 + b] + f.T_f_w.R[3 * a + 2] * r.R_w_i[6 + b];
+            std::memcpy(f.T_f_w.R, Rn, sizeof(Rn));
+            for (int a = 0; a < 3; a++) f.T_f_w.t[a] *= s;                                 // :541-548
+            if (f.has_prior) { f.T_prior = f.T_f_w; for (double& x : f.inf_prior) x = 100.0; }   // :550-552
+        }
+        for (LandmarkState& L : map.landmarks) {                                          // :555-562
+            if (L.outlier) continue;
+            double q[3];
+            for (int a = 0; a < 3; a++) q[a] = s * (r.R_w_i[a] * L.p[0] + r.R_w_i[3 + a] * L.p[1] + r.R_w_i[6 + a] * L.p[2]);
+            std::memcpy(L.p, q, sizeof(q));
+        }
+        return s;
+    }
+
     // BundleAdjustmentCERESAnalytic::marginalize (…Analytic.cpp:431-663) with Marginalization::preMarginalize
     // (marginalization.cpp:23-143) restated on the snapshot: frame0 (index into map.frames) is marginalised into a prior
     // on frame1's states (VIO) and on the landmarks frame0 shares with the rest of the window. Returns false when the

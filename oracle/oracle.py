@@ -11,6 +11,7 @@ import subprocess
 
 import numpy as np
 
+from sadvio_amd import capi
 from sadvio_amd.capi import (FlatWindow, FlatWindowC, ImuFactorC, PosePriorC, SolveOptions, SolveSummary, SparsePriorC,
                              fill_imu_factor, reference_options)
 
@@ -67,6 +68,9 @@ def lib():
         _lib.oracle_solve.argtypes = [C.POINTER(OracleProblem), C.POINTER(SolveOptions), C.POINTER(SolveSummary),
                                       _dp, _dp, _dp, _dp, _dp, _dp, C.c_int32]
         _lib.oracle_linearize.argtypes = [C.POINTER(FlatWindowC), _dp, _dp, _dp, _dp, _dp, _ip]
+        _lib.oracle_viinit.argtypes = [C.POINTER(capi.ViInitProblemC), C.POINTER(SolveOptions), C.POINTER(SolveSummary),
+                                       C.POINTER(capi.ViInitResultC), _dp]
+        _lib.oracle_factor_imu_init.argtypes = [C.POINTER(ImuFactorC)] + [_dp] * 7
         _lib.oracle_landmark_chi2.argtypes = [C.POINTER(FlatWindowC), _dp, _dp, _dp, C.c_double, _dp, _ip]
         _lib.oracle_first_step.argtypes = [C.POINTER(OracleProblem), C.POINTER(SolveOptions), _dp, _dp, _dp, _dp,
                                            C.c_int32]
@@ -268,6 +272,25 @@ def factor_imu(fdict, Ti0, Tj0, vi0, vj0, params24):
                                  _p(_arr(vj0, 3)), _p(_arr(params24, 24)), _p(r), _p(J))
     assert rc == 0, rc
     return r, J
+
+
+def factor_imu_init(fdict, Ti, Tj, vi, vj, params15):
+    """IMUFactorInit (residuals.hpp:302-410): (r[9], J[9,15]) with columns r_wi(2) dv_i(3) dv_j(3) dba(3) dbg(3) lambda."""
+    fc = ImuFactorC()
+    fill_imu_factor(fc, fdict)
+    r = np.zeros(9); J = np.zeros((9, 15))
+    rc = lib().oracle_factor_imu_init(C.byref(fc), _p(_arr(Ti, 12)), _p(_arr(Tj, 12)), _p(_arr(vi, 3)), _p(_arr(vj, 3)),
+                                      _p(_arr(params15, 15)), _p(r), _p(J))
+    assert rc == 0, rc
+    return r, J
+
+
+def viinit(T_f_w, vel, factors, opts=None, **kw):
+    """AOptimizer::VIInit (AOptimizer.cpp:448-581) restated; arguments as capi.make_viinit_problem."""
+    P, keep = capi.make_viinit_problem(T_f_w, vel, factors, **kw)
+    s = SolveSummary(); r = capi.ViInitResultC(); dv = np.zeros((P.n_frames, 3))
+    rc = lib().oracle_viinit(C.byref(P), C.byref(opts or capi.viinit_options()), C.byref(s), C.byref(r), _p(dv))
+    return capi.viinit_result_to_dict(rc, s, r, dv)
 
 
 def factor_imu_bias(fdict, bai, bgi, baj, bgj, params12):

@@ -144,6 +144,13 @@ int oracle_sparsify(const sadvio_flat_window *w, int32_t vio, int32_t n_full, in
                     int32_t kf_col, int32_t n_keep, const int32_t *lmk_index, const int32_t *lmk_col, int32_t *n_out,
                     sadvio_sparse_prior *out);
 
+/* ---- VI initialisation (AOptimizer::VIInit, AOptimizer.cpp:448-581; IMUFactorInit, residuals.hpp:302-410) ---- */
+/* params15 = r_wi[2] dv_i[3] dv_j[3] dba[3] dbg[3] lambda[1]; J = 9 x 15 row-major (whitened, blocks side by side). */
+int oracle_factor_imu_init(const sadvio_imu_factor *f, const double *Ti, const double *Tj, const double *vi, const double *vj,
+                           const double *params15, double *r9, double *J);
+int oracle_viinit(const sadvio_viinit_problem *prob, const sadvio_solve_options *opts, sadvio_solve_summary *summary,
+                  sadvio_viinit_result *res, double *dv3);
+
 /* Symmetric eigen-decomposition (cyclic Jacobi), eigenvalues ascending, V column-eigenvectors row-major. */
 void oracle_sym_eig(const double *A, int32_t n, double *evals, double *V);
 

@@ -60,6 +60,17 @@ class ImuFactorC(C.Structure):
     ]
 
 
+class ViInitProblemC(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("n_factors", C.c_int32), ("T_f_w", C.POINTER(C.c_double)),
+                ("vel", C.POINTER(C.c_double)), ("factors", C.POINTER(ImuFactorC)), ("optim_scale", C.c_int32),
+                ("optim_bias", C.c_int32), ("sigma_dba", C.c_double), ("sigma_dbg", C.c_double)]
+
+
+class ViInitResultC(C.Structure):
+    _fields_ = [("r_wi", C.c_double * 2), ("lambda_", C.c_double), ("dba", C.c_double * 3), ("dbg", C.c_double * 3),
+                ("R_w_i", C.c_double * 9), ("scale", C.c_double)]
+
+
 class PosePriorC(C.Structure):
     _fields_ = [("kf", C.c_int32), ("pad", C.c_int32), ("T_prior", C.c_double * 12), ("inf_diag", C.c_double * 6)]
 
@@ -143,6 +154,31 @@ def single_frame_options(vi: bool = False) -> SolveOptions:
     o.max_num_iterations = 5
     o.huber_a = 1.345 ** 0.5 if vi else 0.0
     return o
+
+
+def viinit_options() -> SolveOptions:
+    """AOptimizer::VIInit (AOptimizer.cpp:518-528): LM, 50 iterations, function_tolerance 1e-3, no loss."""
+    o = reference_options()
+    o.max_num_iterations = 50
+    return o
+
+
+def make_viinit_problem(T_f_w, vel, factors, optim_scale=False, optim_bias=False, sigma_dba=1.0, sigma_dbg=1.0):
+    """(ViInitProblemC, keep-alive tuple) from arrays + a list of IMU factor dicts (kf_i / kf_j index the frames)."""
+    T = np.ascontiguousarray(T_f_w, dtype=np.float64).reshape(-1, 12)
+    v = np.ascontiguousarray(vel, dtype=np.float64).reshape(-1, 3)
+    assert T.shape[0] == v.shape[0]
+    arr = (ImuFactorC * max(1, len(factors)))()
+    for i, f in enumerate(factors):
+        fill_imu_factor(arr[i], f)
+    P = ViInitProblemC(T.shape[0], len(factors), T.ctypes.data_as(_dp), v.ctypes.data_as(_dp), arr, int(optim_scale),
+                       int(optim_bias), float(sigma_dba), float(sigma_dbg))
+    return P, (T, v, arr)
+
+
+def viinit_result_to_dict(rc, s, r: ViInitResultC, dv) -> dict:
+    return {"rc": rc, "summary": s, "r_wi": np.array(r.r_wi[:]), "lambda": float(r.lambda_), "dba": np.array(r.dba[:]),
+            "dbg": np.array(r.dbg[:]), "R_w_i": np.array(r.R_w_i[:]).reshape(3, 3), "scale": float(r.scale), "dv": dv}
 
 
 def gn_options(iters: int = 10) -> SolveOptions:
@@ -303,6 +339,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.sadvio_ba_get_deltas.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
     lib.sadvio_ba_get_ids.argtypes = [C.c_void_p, C.c_int32, _lp, _lp]
     lib.sadvio_ba_linearize.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
+    lib.sadvio_ba_vi_init.argtypes = [C.c_void_p, C.POINTER(ViInitProblemC), C.POINTER(SolveOptions), C.POINTER(SolveSummary),
+                                      C.POINTER(ViInitResultC), _dp]
     lib.sadvio_ba_landmark_chi2.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, C.c_double, _dp, _ip]
     lib.sadvio_ba_get_kernel_times.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), _dp, _lp]
     lib.sadvio_ba_last_error.argtypes = [C.c_void_p]
@@ -475,6 +513,15 @@ class Backend:
         self._check(self.lib.sadvio_ba_landmark_chi2(self.h, w, _ptr(pd), _ptr(ld), _ptr(wh), pixel_sigma, _ptr(avg),
                                                      inl.ctypes.data_as(_ip)), "landmark_chi2")
         return avg, inl
+
+    def vi_init(self, T_f_w, vel, factors, opts: SolveOptions = None, **kw):
+        """AOptimizer::VIInit (AOptimizer.cpp:448-581) on the device; see make_viinit_problem for the arguments."""
+        P, keep = make_viinit_problem(T_f_w, vel, factors, **kw)
+        s = SolveSummary(); r = ViInitResultC(); dv = np.zeros((P.n_frames, 3))
+        rc = self.lib.sadvio_ba_vi_init(self.h, C.byref(P), C.byref(opts or viinit_options()), C.byref(s), C.byref(r), _ptr(dv))
+        if rc not in (0, E_NOT_USABLE):
+            self._check(rc, "vi_init")
+        return viinit_result_to_dict(rc, s, r, dv)
 
     def kernel_times(self):
         cap = 32

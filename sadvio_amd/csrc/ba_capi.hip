@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "dense_chol.h"
 #include "marg_kernels.h"
+#include "viinit_kernels.h"
 
 using namespace sadvio;
 
@@ -1134,6 +1135,17 @@ double marg_cut(const std::vector<double>& ev) {
     return std::max(1e-12, (double)ev.size() * 2.220446049250313e-16 * mx);
 }
 
+// exp_so3((a, b, 0)) row-major (geometry.h:131-147: first order below 1e-9)
+void host_exp_so3(double a, double b, double* R) {
+    const double th = std::sqrt(a * a + b * b);
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (th < 1e-9) { const double S[9] = {0, 0, b, 0, 0, -a, -b, a, 0}; for (int i = 0; i < 9; i++) R[i] = I[i] + S[i]; return; }
+    const double x = a / th, y = b / th;
+    const double S[9] = {0, 0, y, 0, 0, -x, -y, x, 0};
+    double S2[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) S2[3 * i + j] = S[3 * i] * S[j] + S[3 * i + 1] * S[3 + j] + S[3 * i + 2] * S[6 + j];
+    for (int i = 0; i < 9; i++) R[i] = I[i] + (1.0 - std::cos(th)) * S2[i] + std::sin(th) * S[i];
+}
 bool make_imu_dev(const sadvio_imu_factor& f, int kf_base, ImuDev& o) {
     o.kf_i = kf_base + f.kf_i; o.kf_j = kf_base + f.kf_j; o.dt = f.dt;
     memcpy(o.dR, f.delta_R, sizeof(o.dR)); memcpy(o.dv, f.delta_v, sizeof(o.dv)); memcpy(o.dp, f.delta_p, sizeof(o.dp));
@@ -1535,7 +1547,7 @@ int sadvio_ba_set_collective(sadvio_ba_handle* h, int32_t rank, int32_t world, s
 }
 
 namespace {
-std::string load_rccl(RcclLib& R) {
+static std::string load_rccl(RcclLib& R) {
     if (R.lib) return "";
     R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!R.lib) R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
@@ -1917,6 +1929,84 @@ int sadvio_ba_linearize(sadvio_ba_handle* h, int32_t w, const double* pose_delta
     }
     h->solved = false;
     return SADVIO_OK;
+}
+
+int sadvio_ba_vi_init(sadvio_ba_handle* h, const sadvio_viinit_problem* pb, const sadvio_solve_options* opts, sadvio_solve_summary* sum,
+                      sadvio_viinit_result* res, double* dv3) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (!pb || !opts || pb->n_frames < 0 || pb->n_factors < 0 || (pb->n_frames > 0 && (!pb->T_f_w || !pb->vel)) || (pb->n_factors > 0 && !pb->factors)) {
+        h->err = "vi_init: bad argument"; return SADVIO_E_INVALID_ARG;
+    }
+    if (pb->n_frames > VIINIT_MAX_FRAMES) { h->err = "vi_init: more than 48 frames"; return SADVIO_E_INVALID_ARG; }
+    if (pb->optim_bias && !(pb->sigma_dba > 0.0 && pb->sigma_dbg > 0.0)) { h->err = "vi_init: bias prior sigmas must be positive"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    const int n = pb->n_frames, nf = pb->n_factors;
+    // program layout: r_wi | velocity deltas of the frames a factor touches (frame order) | dba dbg | lambda
+    std::vector<int> vcol(std::max(n, 1), -1);
+    std::vector<ImuDev> fd(std::max(nf, 1));
+    for (int k = 0; k < nf; k++) {
+        const sadvio_imu_factor& f = pb->factors[k];
+        if (f.kf_i < 0 || f.kf_i >= n || f.kf_j < 0 || f.kf_j >= n || f.kf_i == f.kf_j) { h->err = "vi_init: factor frame index out of range"; return SADVIO_E_INVALID_ARG; }
+        if (!make_imu_dev(f, 0, fd[k])) { h->err = "vi_init: IMU covariance is not positive definite"; return SADVIO_E_INVALID_ARG; }
+        vcol[f.kf_i] = vcol[f.kf_j] = 0;
+    }
+    int D = 2;
+    for (int i = 0; i < n; i++) if (vcol[i] == 0) { vcol[i] = D; D += 3; }
+    ViInitDev P{};
+    P.n_frames = n; P.n_factors = nf; P.optim_bias = pb->optim_bias ? 1 : 0;
+    P.c_ba = P.c_bg = P.c_l = -1;
+    if (pb->optim_bias) { P.c_ba = D; P.c_bg = D + 3; D += 6; P.isig_ba = 1.0 / pb->sigma_dba; P.isig_bg = 1.0 / pb->sigma_dbg; }
+    if (pb->optim_scale) { P.c_l = D; D += 1; }
+    P.D = D;
+    std::vector<double> out((size_t)D + 8, 0.0);
+    sadvio_solve_summary S{};
+    if (nf == 0) S.termination = SADVIO_TERM_GRADIENT_TOL;   // empty program: Ceres returns at once
+    else {
+        P.o.max_num_iterations = opts->max_num_iterations; P.o.jacobi_scaling = opts->jacobi_scaling;
+        P.o.max_num_consecutive_invalid_steps = opts->max_num_consecutive_invalid_steps;
+        P.o.function_tolerance = opts->function_tolerance; P.o.gradient_tolerance = opts->gradient_tolerance;
+        P.o.parameter_tolerance = opts->parameter_tolerance; P.o.initial_radius = opts->initial_trust_region_radius;
+        P.o.max_radius = opts->max_trust_region_radius; P.o.min_radius = opts->min_trust_region_radius;
+        P.o.min_lm_diagonal = opts->min_lm_diagonal; P.o.max_lm_diagonal = opts->max_lm_diagonal; P.o.min_relative_decrease = opts->min_relative_decrease;
+        // one allocation: header | T | vel | out | scratch | factors | vcol
+        const size_t n_d = 12 * (size_t)n + 3 * (size_t)n + out.size() + 2 * (size_t)nf * VIINIT_FJ;
+        const size_t bytes = sizeof(ViInitDev) + 8 * n_d + sizeof(ImuDev) * (size_t)nf + sizeof(int) * (size_t)n + 64;
+        DevBuf<char> buf;
+        HIP_TRY(buf.alloc(bytes));
+        char* base = buf.p;
+        double* dT = (double*)(base + ((sizeof(ViInitDev) + 15) & ~(size_t)15));
+        double* dvel = dT + 12 * (size_t)n; double* dout = dvel + 3 * (size_t)n; double* dscr = dout + out.size();
+        ImuDev* df = (ImuDev*)(dscr + 2 * (size_t)nf * VIINIT_FJ);
+        int* dvc = (int*)(df + nf);
+        P.T = dT; P.vel = dvel; P.out = dout; P.scratch = dscr; P.f = df; P.vcol = dvc;
+        HIP_TRY(hipMemcpyAsync(base, &P, sizeof(P), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(dT, pb->T_f_w, 96 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(dvel, pb->vel, 24 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(df, fd.data(), sizeof(ImuDev) * (size_t)nf, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(dvc, vcol.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+        const size_t lds = 8 * ((size_t)(D + 1) * (D + 2) / 2 + 6 * (size_t)D);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_viinit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_viinit, dim3(1), dim3(VIINIT_THREADS), lds, h->stream, (const ViInitDev*)base);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out.data(), dout, 8 * out.size(), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        const double* s = out.data() + D;
+        S.initial_cost = s[0]; S.final_cost = s[1]; S.final_radius = s[2]; S.iterations = (int)s[3]; S.termination = (int)s[4];
+        S.num_successful_steps = (int)s[5]; S.num_unsuccessful_steps = (int)s[6];
+    }
+    if (sum) *sum = S;
+    if (res) {
+        memset(res, 0, sizeof(*res));
+        res->r_wi[0] = out[0]; res->r_wi[1] = out[1];
+        res->lambda = P.c_l >= 0 ? out[P.c_l] : 0.0;
+        for (int a = 0; a < 3; a++) { res->dba[a] = P.c_ba >= 0 ? out[P.c_ba + a] : 0.0; res->dbg[a] = P.c_bg >= 0 ? out[P.c_bg + a] : 0.0; }
+        host_exp_so3(res->r_wi[0], res->r_wi[1], res->R_w_i);
+        res->scale = std::exp(res->lambda);
+    }
+    if (dv3)
+        for (int i = 0; i < n; i++)
+            for (int a = 0; a < 3; a++) dv3[3 * i + a] = vcol[i] >= 0 ? out[vcol[i] + a] : 0.0;
+    return S.termination == SADVIO_TERM_FAILURE ? SADVIO_E_NOT_USABLE : SADVIO_OK;
 }
 
 int sadvio_ba_landmark_chi2(sadvio_ba_handle* h, int32_t w, const double* pose_delta6, const double* lmk_delta3, const double* image_wh,

@@ -2,6 +2,7 @@
 // style (imu_test.cpp:464-487: perturb, optimise, compare with the ground truth): a small stereo local map is built
 // in plain structs, perturbed, solved through HipOptimizer::localMapBA / landmarkOptimization / singleFrameOptimization,
 // and the recovered state is compared with the ground truth. Exit code 0 = pass. Needs a gfx950 device.
+#include <array>
 #include <cstdio>
 #include <random>
 
@@ -162,6 +163,70 @@ int main() {
         LocalMapSnapshot lonely = make_map(rng, 2, 3);
         lonely.landmarks.clear();
         check(!opt.marginalize(lonely, 1, 0, false) && !opt.has_prior(), "marginalize of a frame without landmarks is refused, prior cleared");
+    }
+    // --- VIInit: scale, gravity direction and velocities of a visual-only map from pre-integrated IMU factors ---
+    // Non-rotating body: Delta_R = I, Delta_v = v_j - v_i - g dt, Delta_p = p_j - p_i - v_i dt - g dt^2 / 2 exactly
+    // (IMU.cpp:5-91 with constant orientation), so any (p_k, v_k) sequence gives a consistent factor set.
+    {
+        const int n = 8;
+        const double dt = 0.4, gw[3] = {0, 0, -9.81}, scale_in = 0.5, tilt[3] = {0.04, -0.07, 0.0};
+        double Rwi[9];
+        exp_so3(tilt, Rwi);
+        std::vector<std::array<double, 3>> P(n), V(n);
+        for (int k = 0; k < n; k++) {   // k = 0 oldest
+            const double t = dt * k;
+            P[k] = {1.5 * std::sin(0.7 * t), std::cos(0.5 * t), 0.4 * std::sin(0.9 * t)};
+            V[k] = {1.05 * std::cos(0.7 * t), -0.5 * std::sin(0.5 * t), 0.36 * std::cos(0.9 * t)};
+        }
+        LocalMapSnapshot m;
+        for (int i = 0; i < n; i++) {   // newest first
+            const int k = n - 1 - i;
+            FrameState f;
+            f.id = 300 + i; f.has_imu = true;
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) f.T_f_w.R[3 * a + b] = Rwi[3 * b + a];   // R_in = R_true R_w_i^T, R_true = I
+            for (int a = 0; a < 3; a++) {
+                f.T_f_w.t[a] = 0;
+                for (int b = 0; b < 3; b++) f.T_f_w.t[a] -= f.T_f_w.R[3 * a + b] * P[k][b] * scale_in;
+                f.v[a] = V[k][a] * scale_in + 0.01 * G(rng);
+            }
+            if (i == n - 1) { f.has_prior = true; f.T_prior = f.T_f_w; }
+            m.frames.push_back(f);
+        }
+        for (int k = 1; k < n; k++) {
+            ImuPair pr{};
+            pr.frame_i = n - k; pr.frame_j = n - 1 - k;   // older -> newer
+            sadvio_imu_factor& f = pr.f;
+            f.dt = dt;
+            const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            std::memcpy(f.delta_R, I3, sizeof(I3));
+            for (int a = 0; a < 3; a++) {
+                f.delta_v[a] = V[k][a] - V[k - 1][a] - gw[a] * dt;
+                f.delta_p[a] = P[k][a] - P[k - 1][a] - V[k - 1][a] * dt - 0.5 * gw[a] * dt * dt;
+            }
+            for (int q = 0; q < 9; q++) f.cov[10 * q] = q < 3 ? 1e-6 : (q < 6 ? 1e-4 : 1e-5);
+            f.bacc_noise = 3e-3; f.bgyr_noise = 2e-5;
+            m.imu_pairs.push_back(pr);
+        }
+        LandmarkState L; L.p[0] = 1.0; L.p[1] = -2.0; L.p[2] = 3.0;
+        m.landmarks.push_back(L);
+        double R[9];
+        const double s = opt.VIInit(m, R, true);
+        double re = 0, ve = 0, fe = 0;
+        for (int q = 0; q < 9; q++) re = std::fmax(re, std::fabs(R[q] - Rwi[q]));
+        for (int i = 0; i < n; i++)
+            for (int a = 0; a < 3; a++) {
+                ve = std::fmax(ve, std::fabs(m.frames[i].v[a] - V[n - 1 - i][a]));
+                for (int b = 0; b < 3; b++) fe = std::fmax(fe, std::fabs(m.frames[i].T_f_w.R[3 * a + b] - (a == b ? 1.0 : 0.0)));
+            }
+        std::printf("   scale %.6f (truth 2) R_w_i err %.2e velocity err %.2e frame rotation err %.2e it %d cost %.3e -> %.3e\n", s, re, ve, fe,
+                    opt.summary().iterations, opt.summary().initial_cost, opt.summary().final_cost);
+        check(std::fabs(s - 2.0) < 1e-2 && re < 2e-3, "VIInit: scale and gravity direction recovered");
+        check(ve < 2e-2 && fe < 2e-3, "VIInit: velocities and frame rotations written back");
+        double lp[3] = {0, 0, 0};
+        for (int a = 0; a < 3; a++) lp[a] = s * (R[a] * 1.0 + R[3 + a] * -2.0 + R[6 + a] * 3.0);
+        check(std::fabs(m.landmarks[0].p[0] - lp[0]) + std::fabs(m.landmarks[0].p[1] - lp[1]) + std::fabs(m.landmarks[0].p[2] - lp[2]) < 1e-12 &&
+                  m.frames.back().inf_prior[0] == 100.0 && pose_err(m.frames.back().T_prior, m.frames.back().T_f_w) == 0.0,
+              "VIInit: landmarks rescaled, prior re-anchored");
     }
     std::printf("%s (%d failure%s)\n", fails ? "FAILED" : "PASSED", fails, fails == 1 ? "" : "s");
     return fails ? 1 : 0;
