@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "sadvio_ba.h"
+#include "sadvio_io.hpp"
 
 namespace sadvio {
 
@@ -288,6 +289,8 @@ class HipOptimizer {
 
     const sadvio_solve_summary& summary() const { return _sum; }
     const std::string& last_error() const { return _err; }
+    // every window handed to the backend is also written to <dir>/window_NNNNNN.sadvio (include/sadvio_io.hpp)
+    void set_dump_dir(const std::string& dir) { _dump_dir = dir; _dump_count = 0; }
 
   private:
     struct Flat {   // the flattened window + the vectors it points into
@@ -414,6 +417,12 @@ class HipOptimizer {
         const int nkf = (int)map.frames.size();
         Flat F;
         flatten(map, fixed, vio, all_const, lmk_const, F, !lmk_const);   // addSingleFrameResiduals has no key-frame test (:5-50)
+        if (!_dump_dir.empty()) {   // replayable record of exactly what the backend is given (scripts/replay.py)
+            char name[64];
+            std::snprintf(name, sizeof(name), "/window_%06d.sadvio", _dump_count++);
+            const std::string e = write_window(_dump_dir + name, F.w, (int)F.priors.size(), F.priors.data(), (int)F.imus.size(), F.imus.data());
+            if (!e.empty()) _err = e;
+        }
         int rc = upload(F);
         if (rc == SADVIO_OK && !all_const && !lmk_const) rc = add_marginalization_prior(F);   // window solves only
         if (rc == SADVIO_OK) rc = sadvio_ba_solve(_h, &opt, &_sum);
@@ -449,6 +458,8 @@ class HipOptimizer {
         return true;
     }
 
+    std::string _dump_dir;
+    int _dump_count = 0;
     sadvio_ba_handle* _h = nullptr;
     sadvio_solve_summary _sum{};
     std::string _err;

@@ -57,7 +57,7 @@ static double pose_err(const Pose& a, const Pose& b) {
     return e;
 }
 
-int main() {
+int main(int argc, char** argv) {
     std::mt19937 rng(20250404);
     std::normal_distribution<double> G(0.0, 1.0);
     int fails = 0;
@@ -75,7 +75,9 @@ int main() {
         m.landmarks[3].outlier = true;                          // excluded from the problem, must stay untouched (…Analytic.cpp:239)
         const double p3 = m.landmarks[3].p[0];
         sadvio_solve_options unused; (void)unused;
+        if (argc > 1) opt.set_dump_dir(argv[1]);
         for (int rep = 0; rep < 3; rep++) check(opt.localMapBA(m, 1), "localMapBA returns true");
+        opt.set_dump_dir("");
         double worst = 0;
         for (size_t i = 0; i < m.frames.size(); i++) worst = std::fmax(worst, pose_err(m.frames[i].T_f_w, truth.frames[i].T_f_w));
         std::printf("   last_error: '%s'\n", opt.last_error().c_str());
