@@ -190,6 +190,7 @@ struct sadvio_ba_handle {
     DevBuf<int> d_big_info;
     DevBuf<double> d_big_M;     // inverse diagonal blocks of the wide-panel dense solver, 96 x 96 per 96 columns
     DevBuf<double> d_big_linv;  // inverse pivot blocks of the banded solver, N * NB doubles per out-of-LDS window
+    DevBuf<double> d_big_mid;   // the two Schur complements on the middle block of the twisted banded factorisation
     bool uploaded = false, solved = false;
     UploadBatch up;   // pending host -> device uploads of the current layout build
     // window sharded over several GPUs: collective hook (user callback or the built-in RCCL one)
@@ -1698,8 +1699,12 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         for (int w = 0; w < n_win; w++)
             for (int r = 0; r < h->world; r++) big_bw[w] = std::max(big_bw[w], (int)slots[((size_t)w * h->world + r) * 4]);
     }
-    std::vector<long long> big_linv_off(n_win, 0), big_M_off(n_win, 0);
+    std::vector<long long> big_linv_off(n_win, 0), big_M_off(n_win, 0), big_mid_off(n_win, 0);
     {
+        long long totm = 0;
+        for (int w = 0; w < n_win; w++)
+            if (h->wins[w].d.ld) { const long long b = std::min(big_bw[w], MAX_LDS_NP); big_mid_off[w] = totm; totm += 2 * (b * (b + 1) / 2 + b); }
+        HIP_TRY(h->d_big_mid.alloc((size_t)std::max<long long>(totm, 1)));
         long long totM = 0;
         for (int w = 0; w < n_win; w++) if (h->wins[w].d.ld) { big_M_off[w] = totM; totM += (long long)((h->wins[w].d.Np + WD - 1) / WD) * WD * WD; }
         HIP_TRY(h->d_big_M.alloc((size_t)std::max<long long>(totM, 1)));
@@ -1752,8 +1757,22 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                                                                  (size_t)(Rmax / nb + 1) * nb * nb) + 64;
                             auto kbs = d.dpf == 6 ? k_band_solve<6> : k_band_solve<5>;
                             (void)hipFuncSetAttribute((const void*)kbs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                            hipLaunchKernelGGL(kbs, dim3(1), dim3(SOLVE_THREADS), lds, h->stream, Sw, (long long)d.ld, yw, h->d_big_linv.p + big_linv_off[w],
-                                               N, bw, C, info, skip);
+                            long long* dbg = (P.debug & 4096) && s == 3 ? h->d_dbg.p + 44 : nullptr;
+                            double* lv = h->d_big_linv.p + big_linv_off[w];
+                            if (N - bw >= 4 * C) {
+                                // long band: twisted factorisation, both ends at once (dense_chol.h)
+                                const int M = (N - bw) / 2 / nb * nb;
+                                double* md = h->d_big_mid.p + big_mid_off[w];
+                                auto kbm = d.dpf == 6 ? k_band_mid<6> : k_band_mid<5>;
+                                const size_t lds_m = sizeof(double) * ((size_t)(bw + 2) * 6 + (size_t)(bw + 1) * (bw + 2) / 2 + 2 * (size_t)bw + (size_t)(bw / nb + 1) * nb * nb) + 64;
+                                (void)hipFuncSetAttribute((const void*)kbm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);
+                                if (dbg) fprintf(stderr, "[sadvio dbg] twisted band solve N %d bw %d C %d M %d\n", N, bw, C, M);
+                                hipLaunchKernelGGL(kbs, dim3(2), dim3(SOLVE_THREADS), lds, h->stream, Sw, (long long)d.ld, yw, lv, N, bw, C, info, skip, dbg, M, 0, md);
+                                hipLaunchKernelGGL(kbm, dim3(1), dim3(SOLVE_THREADS), lds_m, h->stream, Sw, (long long)d.ld, yw, N, bw, M, md, info, skip);
+                                hipLaunchKernelGGL(kbs, dim3(2), dim3(SOLVE_THREADS), lds, h->stream, Sw, (long long)d.ld, yw, lv, N, bw, C, info, skip, dbg, M, 1, md);
+                            } else {
+                                hipLaunchKernelGGL(kbs, dim3(1), dim3(SOLVE_THREADS), lds, h->stream, Sw, (long long)d.ld, yw, lv, N, bw, C, info, skip, dbg, -1, 0, (double*)nullptr);
+                            }
                             continue;
                         }
                         if (N >= 2 * WD) {
@@ -1849,8 +1868,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             for (int i = 1; i < 16; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[0]) * 0.01);
             fprintf(stderr, "  shader clock %.3f GHz\n[sadvio dbg] k_build:", (double)(ts[21] - ts[20]) / ((ts[15] - ts[0]) * 10.0));
             for (int i = 33; i < 43; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[32]) * 0.01);
-            fprintf(stderr, "\n[sadvio dbg] k_chol_panel:");
-            for (int i = 45; i < 51; i++) fprintf(stderr, " %d:%.2f", i - 44, (ts[i] - ts[44]) * 0.01);
+            fprintf(stderr, "\n[sadvio dbg] k_chol_panel / k_band_solve (fwd window 2: carry fresh chol store | fwd end | bwd window 2: load below steps | bwd end):");
+            for (int i = 45; i < 55; i++) fprintf(stderr, " %d:%.2f", i - 44, (ts[i] - ts[44]) * 0.01);
             fprintf(stderr, "\n");
         }
     }

@@ -266,26 +266,50 @@ __device__ __forceinline__ void tri_decode(int g, int& i, int& j) {
     j = g - tri(i, 0);
 }
 
+// Twisted factorisation (twist_M >= 0): the band is eliminated from BOTH ends at once by two workgroups — half 0 runs
+// columns [0, M) top-down, half 1 runs columns [M + bw, N) bottom-up (the same code on the index-reversed matrix; the
+// symmetric element is read from the stored lower triangle) — each leaving its bw x bw Schur complement on the middle
+// block [M, M + bw) in `mid`. k_band_mid adds the two, solves the middle block, and the backward passes of both halves
+// (phase 1) start from it. The sequential pivot chain, which is all this solver's time (3 us per 6 columns), is halved.
+// twist_M < 0: one workgroup does the whole band, forward and backward (short systems).
+struct BandMap {
+    int rev, N;
+    __device__ __forceinline__ long long a(long long ld, int li, int lj) const {  // local li >= lj -> element of the stored lower triangle
+        return rev ? (long long)(N - 1 - lj) * ld + (N - 1 - li) : (long long)li * ld + lj;
+    }
+    __device__ __forceinline__ int v(int li) const { return rev ? N - 1 - li : li; }
+    __device__ __forceinline__ long long blk(int lb, int nblk_tot) const { return rev ? nblk_tot - 1 - lb : lb; }
+};
+
 template <int NB>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(double* __restrict__ A, long long ld, double* __restrict__ y,
                                                               double* __restrict__ linv_g, int N, int bw, int C, int* info,
-                                                              const int* skip) {
+                                                              const int* skip, long long* dbg, int twist_M, int phase, double* __restrict__ mid) {
+#define BAND_TS(win_, idx_) do { if (dbg && tid == 0 && blockIdx.x == 0 && (win_)) dbg[idx_] = wall_clock64(); } while (0)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
     if (*info != 0) return;
     const int tid = threadIdx.x, nt = blockDim.x;
+    const bool twisted = twist_M >= 0;
+    BandMap mp;
+    mp.rev = twisted && blockIdx.x == 1; mp.N = N;
+    // columns this workgroup eliminates / rows of its (local) system
+    const int Ne = !twisted ? N : (mp.rev ? N - twist_M - bw : twist_M);
+    const int Nh = !twisted ? N : Ne + bw;
+    const int nblk_tot = N / NB;
     const int Rmax = bw + C;
     double* LpT = (double*)smem;                              // [NBP][Rmax + 2]
     double* Pk = LpT + (size_t)(Rmax + 2) * NBP;              // packed window incl. rhs row
     double* xv = Pk + (size_t)(Rmax + 1) * (Rmax + 2) / 2;   // [Rmax] work vector of the backward pass
     double* xs = xv + Rmax;                                   // [Rmax]
     double* linvTab = xs + Rmax;                              // [Rmax / NB][NB * NB]
-    __shared__ int s_fail;
-    if (tid == 0) s_fail = 0;
+    if (!twisted || phase == 0) {
     int carried = 0, Rprev = 0, Cprev = 0;
-    for (int c0 = 0; c0 < N; c0 += C) {
-        const int Cw = min(C, N - c0);
-        const int R = min(bw + Cw, N - c0);
+    for (int c0 = 0; c0 < Ne; c0 += C) {
+        const int Cw = min(C, Ne - c0);
+        const int R = min(bw + Cw, Nh - c0);
+        const bool tsw = c0 == 2 * C;
+        BAND_TS(tsw, 0);
         // (1) carry: old (i + Cprev, j + Cprev) -> new (i, j) for i, j < carried, rhs row likewise; through registers
         {
             constexpr int MAXC = (MAX_LDS_NP * (MAX_LDS_NP + 1) / 2 + MAX_LDS_NP + SOLVE_THREADS - 1) / SOLVE_THREADS;
@@ -308,6 +332,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(double* __restrict
                 if (e < nc) Pk[e < ntri ? e : tri(R, e - ntri)] = v[q];
             }
         }
+        BAND_TS(tsw, 1);
         // (2) fresh rows [carried, R) from HBM (zero outside the band by construction of A); the packed index runs
         //     linearly, four independent loads in flight per thread
         {
@@ -317,7 +342,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(double* __restrict
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int g = gb + u * nt;
-                    if (g < g1) { int i, j; tri_decode(g, i, j); v[u] = A[(long long)(c0 + i) * ld + c0 + j]; }
+                    if (g < g1) { int i, j; tri_decode(g, i, j); v[u] = A[mp.a(ld, c0 + i, c0 + j)]; }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -326,35 +351,57 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(double* __restrict
                 }
             }
         }
-        for (int j = carried + tid; j < R; j += nt) Pk[tri(R, j)] = y[c0 + j];
+        for (int j = carried + tid; j < R; j += nt) Pk[tri(R, j)] = y[mp.v(c0 + j)];
         if (tid == 0) Pk[tri(R, R)] = 0.0;
         __syncthreads();
+        BAND_TS(tsw, 2);
         // (3) eliminate the first Cw columns
         const int nsteps = Cw / NB;
         const bool ok = chol_solve_packed<NB, true>(Pk, R, xv, xs, LpT, linvTab, nullptr, nsteps);
         __syncthreads();
+        BAND_TS(tsw, 3);
         if (!ok) { if (tid == 0) *info = c0 + 1; return; }
         // (4) file L (rows below each pivot block), the inverse pivot blocks and the substituted rhs
         for (int g = tid; g < tri(R, 0); g += nt) {
             int i, j;
             tri_decode(g, i, j);
-            if (j < min(Cw, (i / NB) * NB)) A[(long long)(c0 + i) * ld + c0 + j] = Pk[g];  // left of row i's own pivot block
+            if (j < min(Cw, (i / NB) * NB)) A[mp.a(ld, c0 + i, c0 + j)] = Pk[g];  // left of row i's own pivot block
         }
-        for (int e = tid; e < nsteps * NB * NB; e += nt) linv_g[(long long)(c0 / NB) * NB * NB + e] = linvTab[e];
-        for (int j = tid; j < Cw; j += nt) y[c0 + j] = Pk[tri(R, j)];
+        for (int e = tid; e < nsteps * NB * NB; e += nt) {
+            const int lb = e / (NB * NB);
+            linv_g[mp.blk(c0 / NB + lb, nblk_tot) * NB * NB + (e - lb * NB * NB)] = linvTab[e];
+        }
+        for (int j = tid; j < Cw; j += nt) y[mp.v(c0 + j)] = Pk[tri(R, j)];
         carried = R - Cw; Rprev = R; Cprev = Cw;
         __syncthreads();
+        BAND_TS(tsw, 4);
+        BAND_TS(c0 + C >= Ne, 5);
+    }
+    if (twisted) {
+        // the Schur complement this half leaves on the middle block (bw x bw + rhs), in the middle block's own order
+        double* mo = mid + (size_t)blockIdx.x * (tri(bw, 0) + bw);
+        for (int g = tid; g < tri(bw, 0); g += nt) {
+            int i, j;
+            tri_decode(g, i, j);
+            const double v = Pk[tri(i + Cprev, j + Cprev)];
+            if (mp.rev) mo[tri(bw - 1 - j, bw - 1 - i)] = v; else mo[g] = v;
+        }
+        for (int i = tid; i < bw; i += nt) mo[tri(bw, 0) + (mp.rev ? bw - 1 - i : i)] = Pk[tri(Rprev, i + Cprev)];
+        return;
     }
     // backward pass: x = L^-T z, windows in reverse. The L entries were stored over addresses this CU has read before:
     // drop possibly stale L1 lines first.
     __threadfence();
     __syncthreads();
-    const int nwin = (N + C - 1) / C;
+    }
+    const int nwin = (Ne + C - 1) / C;
     for (int wi = nwin - 1; wi >= 0; wi--) {
         const int c0 = wi * C;
-        const int Cw = min(C, N - c0);
-        const int R = min(bw + Cw, N - c0);
+        const int Cw = min(C, Ne - c0);
+        const int R = min(bw + Cw, Nh - c0);
         const int nsteps = Cw / NB;
+        const bool tsw = wi == 2;
+        BAND_TS(tsw, 6);
         {
             const int g1 = tri(R, 0);
             for (int gb = tid; gb < g1; gb += 4 * nt) {
@@ -368,7 +415,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(double* __restrict
                         int i, j;
                         tri_decode(g, i, j);
                         use[u] = j < min(Cw, (i / NB) * NB);
-                        if (use[u]) v[u] = A[(long long)(c0 + i) * ld + c0 + j];
+                        if (use[u]) v[u] = A[mp.a(ld, c0 + i, c0 + j)];
                     }
                 }
 #pragma unroll
@@ -376,9 +423,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(double* __restrict
                     if (use[u]) Pk[gb + u * nt] = v[u];
             }
         }
-        for (int e = tid; e < nsteps * NB * NB; e += nt) linvTab[e] = linv_g[(long long)(c0 / NB) * NB * NB + e];
-        for (int i = tid; i < R; i += nt) xv[i] = y[c0 + i];  // i < Cw: z, i >= Cw: x already solved
+        for (int e = tid; e < nsteps * NB * NB; e += nt) {
+            const int lb = e / (NB * NB);
+            linvTab[e] = linv_g[mp.blk(c0 / NB + lb, nblk_tot) * NB * NB + (e - lb * NB * NB)];
+        }
+        for (int i = tid; i < R; i += nt) xv[i] = y[mp.v(c0 + i)];  // i < Cw: z, i >= Cw: x already solved
         __syncthreads();
+        BAND_TS(tsw, 7);
         // rows below the window's columns: x[j] -= sum_{i >= Cw} L[i][j] x_i
         for (int j = tid; j < Cw; j += nt) {
             double t = xv[j];
@@ -388,6 +439,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(double* __restrict
         __syncthreads();
         for (int j = tid; j < Cw; j += nt) xv[j] = xs[j];
         __syncthreads();
+        BAND_TS(tsw, 8);
         for (int k = nsteps - 1; k >= 0; k--) {
             const int b0 = k * NB;
             double xk[NB];
@@ -412,9 +464,41 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(double* __restrict
             }
             __syncthreads();
         }
-        for (int j = tid; j < Cw; j += nt) y[c0 + j] = xs[j];
+        for (int j = tid; j < Cw; j += nt) y[mp.v(c0 + j)] = xs[j];
         __syncthreads();
+        BAND_TS(tsw, 9);
+        BAND_TS(wi == 0, 10);
     }
+#undef BAND_TS
+}
+
+// Middle block of the twisted factorisation: S_mid = (A_mid + fwd updates) + (A_mid + bwd updates) - A_mid, likewise
+// the right-hand side; solved in LDS; x_mid goes to y[M .. M + bw), where both backward passes pick it up.
+template <int NB>
+__global__ __launch_bounds__(SOLVE_THREADS) void k_band_mid(const double* __restrict__ A, long long ld, double* __restrict__ y, int N, int bw, int M,
+                                                            const double* __restrict__ mid, int* info, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    if (*info != 0) return;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double* LpT = (double*)smem;
+    double* Pk = LpT + (size_t)(bw + 2) * NBP;
+    double* xv = Pk + (size_t)(bw + 1) * (bw + 2) / 2;
+    double* xs = xv + bw;
+    double* linvTab = xs + bw;
+    const int ntri = tri(bw, 0), half = ntri + bw;
+    for (int g = tid; g < ntri; g += nt) {
+        int i, j;
+        tri_decode(g, i, j);
+        Pk[g] = mid[g] + mid[half + g] - A[(long long)(M + i) * ld + M + j];
+    }
+    for (int i = tid; i < bw; i += nt) Pk[tri(bw, i)] = mid[ntri + i] + mid[half + ntri + i] - y[M + i];
+    if (tid == 0) Pk[tri(bw, bw)] = 0.0;
+    __syncthreads();
+    const bool ok = chol_solve_packed<NB, false>(Pk, bw, xv, xs, LpT, linvTab, nullptr);
+    __syncthreads();
+    if (!ok) { if (tid == 0) *info = M + 1; return; }
+    for (int i = tid; i < bw; i += nt) y[M + i] = xs[i];
 }
 
 // ---- dense systems: wide panels built on the in-LDS factorisation -------------------------------------------------
