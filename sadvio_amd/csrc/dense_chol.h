@@ -357,7 +357,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_solve(double* __restrict
         BAND_TS(tsw, 2);
         // (3) eliminate the first Cw columns
         const int nsteps = Cw / NB;
-        const bool ok = chol_solve_packed<NB, true>(Pk, R, xv, xs, LpT, linvTab, nullptr, nsteps);
+        const bool ok = chol_solve_packed<NB, true, true>(Pk, R, xv, xs, LpT, linvTab, nullptr, nsteps, bw);
         __syncthreads();
         BAND_TS(tsw, 3);
         if (!ok) { if (tid == 0) *info = c0 + 1; return; }

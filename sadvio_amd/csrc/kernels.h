@@ -815,8 +815,8 @@ __device__ __forceinline__ void pivot_gather_factor(const double* P, const doubl
 
 // TIL 16x16 tiles (pair indices pp, pp + stride, ...) of the trailing update C -= Lp_i Lp_j^T on the FP64 matrix
 // cores; every LDS load is unconditional (clamped address), masking happens on the loaded values.
-template <int NB, int TIL>
-__device__ __forceinline__ void trail_tiles(double* P, const double* LpT, int ldp, int s, int m, int pp0, int stride, int lr, int lk, int rmin) {
+template <int NB, int TIL, bool BAND = false>
+__device__ __forceinline__ void trail_tiles(double* P, const double* LpT, int ldp, int s, int m, int pp0, int stride, int lr, int lk, int rmin, int rhs_row) {
     typedef double d4 __attribute__((ext_vector_type(4)));
     d4 c[TIL];
     double a0[TIL], b0[TIL], a1[TIL], b1[TIL];
@@ -839,7 +839,7 @@ __device__ __forceinline__ void trail_tiles(double* P, const double* LpT, int ld
             okr[u][rg] = row < m && row >= rmin && col <= row && col < m - 1;
             const int rowc = row < m ? row : m - 1;
             const int colc = col <= rowc ? col : rowc;
-            addr[u][rg] = tri(s + rowc, s + colc);
+            addr[u][rg] = tri((BAND && rowc == m - 1) ? rhs_row : s + rowc, s + colc);  // local row m - 1 is the rhs row (banded windows skip the zero rows between)
             c[u][rg] = P[addr[u][rg]];
         }
         a0[u] = (ai < m && lk < NB) ? -a0[u] : 0.0; b0[u] = (bj < m && lk < NB) ? b0[u] : 0.0;
@@ -859,9 +859,11 @@ __device__ __forceinline__ void trail_tiles(double* P, const double* LpT, int ld
 
 // PARTIAL: only the first `nsteps` block columns are eliminated (the rest of the matrix is left as the updated
 // Schur complement, pivot blocks included) and no back-substitution is done: one window of the block-banded solver.
-template <int NB, bool PARTIAL = false>
+// `band` > 0 (banded window): the rows of a pivot block's panel beyond band - NB below it are structurally zero, so the
+// panel and the trailing update cover only those rows plus the rhs row.
+template <int NB, bool PARTIAL = false, bool BAND = false>
 __device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, double* xs, double* LpT,
-                                                  double* linvTab, long long* ts, int nsteps = 0) {
+                                                  double* linvTab, long long* ts, int nsteps = 0, int band = 0) {
     const int tid = threadIdx.x, nt = blockDim.x, ln = tid & 63;
     const int nblk = PARTIAL ? nsteps : N / NB;
     const int ldp = N + 2;
@@ -878,7 +880,9 @@ __device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, d
     for (int k = 0; k < nblk; k++) {
         const int c0 = k * NB;
         const int s = c0 + NB;
-        const int m = N + 1 - s;  // trailing rows s .. N (row N = rhs)
+        const int mfull = N + 1 - s;  // trailing rows s .. N (row N = rhs)
+        const int mb = BAND ? min(mfull - 1, band - NB) : mfull - 1;  // matrix rows with a non-zero panel
+        const int m = mb + 1;         // + the rhs row, local index mb
         if (ts && k == 2 && tid == 0) ts[9] = wall_clock64();
         // --- panel: L_rk = A_rk Linv^T for the rows below the pivot, also into the transposed strip;
         //     one thread per output element (row r, column c): short chains, all loads unconditional ---
@@ -886,7 +890,7 @@ __device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, d
             const double* lt = linvTab + k * NB * NB;
             for (int e = tid; e < m * NB; e += nt) {
                 const int r = e / NB, c = e - r * NB;
-                const double* row = P + tri(s + r, c0);
+                const double* row = P + tri((!BAND || r < mb) ? s + r : N, c0);
                 double a[NB], lc[NB];
 #pragma unroll
                 for (int q = 0; q < NB; q++) { a[q] = row[q]; lc[q] = lt[c * NB + q]; }  // lt is zero above the diagonal
@@ -913,7 +917,7 @@ __device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, d
             // (nobody touches these columns during the trailing update)
             for (int e = tid - 64; e < m * NB; e += nt - 64) {
                 const int r = e / NB, c = e - r * NB;
-                P[tri(s + r, c0 + c)] = LpT[c * ldp + r];
+                P[tri((!BAND || r < mb) ? s + r : N, c0 + c)] = LpT[c * ldp + r];
             }
             typedef double d4 __attribute__((ext_vector_type(4)));
             const int nbw = (nt >> 6) - 1;                              // bulk waves
@@ -928,8 +932,8 @@ __device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, d
             // factorisation has no look-ahead, so the bulk waves update those rows as well
             const int rmin = (PARTIAL && k + 1 == nblk) ? 0 : NB;
             int pp = bw;
-            for (; pp + 3 * nbw < npair; pp += 4 * nbw) trail_tiles<NB, 4>(P, LpT, ldp, s, m, pp, nbw, lr, lk, rmin);
-            for (; pp < npair; pp += nbw) trail_tiles<NB, 1>(P, LpT, ldp, s, m, pp, nbw, lr, lk, rmin);
+            for (; pp + 3 * nbw < npair; pp += 4 * nbw) trail_tiles<NB, 4, BAND>(P, LpT, ldp, s, m, pp, nbw, lr, lk, rmin, N);
+            for (; pp < npair; pp += nbw) trail_tiles<NB, 1, BAND>(P, LpT, ldp, s, m, pp, nbw, lr, lk, rmin, N);
             if (ts && k == 2 && tid == 64) ts[12] = wall_clock64();
         }
         __syncthreads();
