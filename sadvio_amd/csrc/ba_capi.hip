@@ -190,6 +190,7 @@ struct sadvio_ba_handle {
     DevBuf<int> d_big_info;
     DevBuf<double> d_big_M;     // inverse diagonal blocks of the wide-panel dense solver, 96 x 96 per 96 columns
     DevBuf<double> d_big_linv;  // inverse pivot blocks of the banded solver, N * NB doubles per out-of-LDS window
+    DevBuf<double> d_coll_band; // band-packed copy of the reduced system for the sharded all-reduce
     DevBuf<double> d_big_mid;   // the two Schur complements on the middle block of the twisted banded factorisation
     bool uploaded = false, solved = false;
     UploadBatch up;   // pending host -> device uploads of the current layout build
@@ -1731,7 +1732,18 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 // the window spans devices: gather the per-rank partial sums and all-reduce the reduced system
                 { ScopedTimer t(h, "k_rank_partials"); hipLaunchKernelGGL(k_rank_partials, dim3(n_win), dim3(64), 0, h->stream, P, s, 0); }
                 ScopedTimer t(h, "allreduce_reduced_system");
-                if (h->coll_fn(h->coll_ctx, h->d_S.p, (int64_t)h->red_total, (void*)h->stream) != 0) coll_failed = true;
+                const WinDev& d0 = h->wins[0].d;
+                if (n_win == 1 && d0.ld && big_bw[0] < d0.Np && d0.S_off == 0) {
+                    // one banded window spanning the devices: only the band of S travels (dense_chol.h: k_band_pack)
+                    const long long nbd = (long long)d0.Np * big_bw[0], tail = h->red_total - (long long)d0.Np * d0.ld;
+                    if (h->d_coll_band.alloc((size_t)(nbd + tail)) != hipSuccess) coll_failed = true;
+                    else {
+                        const int pb = (int)std::min<long long>((nbd + tail + 255) / 256, 2048);
+                        hipLaunchKernelGGL(k_band_pack, dim3(pb), dim3(256), 0, h->stream, h->d_S.p, (long long)d0.ld, d0.Np, big_bw[0], tail, h->d_coll_band.p, 0);
+                        if (h->coll_fn(h->coll_ctx, h->d_coll_band.p, (int64_t)(nbd + tail), (void*)h->stream) != 0) coll_failed = true;
+                        hipLaunchKernelGGL(k_band_pack, dim3(pb), dim3(256), 0, h->stream, h->d_S.p, (long long)d0.ld, d0.Np, big_bw[0], tail, h->d_coll_band.p, 1);
+                    }
+                } else if (h->coll_fn(h->coll_ctx, h->d_S.p, (int64_t)h->red_total, (void*)h->stream) != 0) coll_failed = true;
             }
             if (h->n_big < n_win) { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(ks0, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
             if (h->n_big) {
@@ -1751,7 +1763,10 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                         const int nb = d.dpf == 6 ? 6 : 5;
                         if (bw < N && bw + nb <= MAX_LDS_NP) {
                             // block-banded system: one workgroup slides an LDS window down the band (dense_chol.h)
-                            const int C = std::max(nb, std::min(bw, MAX_LDS_NP - bw) / nb * nb);  // measured: C = bw beats the largest window that fits
+                            // with the update trimmed to the band a step costs the same in any window: the largest window that fits
+                            // amortises the per-window carry / load / store best (SADVIO_BAND_C overrides, for measurements)
+                            int C = std::max(nb, (MAX_LDS_NP - bw) / nb * nb);
+                            if (const char* e = getenv("SADVIO_BAND_C")) C = std::max(nb, std::min(C, atoi(e) / nb * nb));
                             const int Rmax = bw + C;
                             const size_t lds = sizeof(double) * ((size_t)(Rmax + 2) * 6 + (size_t)(Rmax + 1) * (Rmax + 2) / 2 + 2 * (size_t)Rmax +
                                                                  (size_t)(Rmax / nb + 1) * nb * nb) + 64;

@@ -266,6 +266,25 @@ __device__ __forceinline__ void tri_decode(int g, int& i, int& j) {
     j = g - tri(i, 0);
 }
 
+// A window sharded over several GPUs all-reduces its reduced system every step; for a banded S only the band
+// (N x bw entries instead of N x N: 45x fewer bytes at config 5) travels: pack -> all-reduce -> unpack.
+// buf = [band: row i holds S[i][i - bw + 1 .. i] | tail: the `tail` doubles that follow S (gradients, diagonal, partials)].
+__global__ void k_band_pack(const double* __restrict__ S, long long ld, int N, int bw, long long tail, double* __restrict__ buf, int unpack) {
+    const long long nb = (long long)N * bw, total = nb + tail;
+    double* Sm = const_cast<double*>(S);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        if (e < nb) {
+            const int i = (int)(e / bw), t = (int)(e - (long long)i * bw);
+            const int j = i - (bw - 1) + t;
+            if (j < 0) { if (!unpack) buf[e] = 0.0; continue; }
+            if (unpack) Sm[(long long)i * ld + j] = buf[e]; else buf[e] = S[(long long)i * ld + j];
+        } else {
+            const long long q = (long long)N * ld + (e - nb);   // the tail follows the full N x ld matrix
+            if (unpack) Sm[q] = buf[e]; else buf[e] = S[q];
+        }
+    }
+}
+
 // Twisted factorisation (twist_M >= 0): the band is eliminated from BOTH ends at once by two workgroups — half 0 runs
 // columns [0, M) top-down, half 1 runs columns [M + bw, N) bottom-up (the same code on the index-reversed matrix; the
 // symmetric element is read from the stored lower triangle) — each leaving its bw x bw Schur complement on the middle
