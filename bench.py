@@ -147,7 +147,7 @@ def main():
                     "iteration_achieved_GBps": round(sum(ab.values()) / (iter_us * 1e-6) / 1e9, 2)}
         # --- batched throughput (independent windows in one submission) ---
         batched = None
-        if args.batch > 0:
+        if args.batch > 0 and world == 1:
             bw = [synthetic.make_window(seed=base_seed + 100 + i) for i in range(min(args.batch, 8))]
             bw = [bw[i % len(bw)] for i in range(args.batch)]
             bb = capi.Backend(device=local_rank, use_graph=True)
@@ -170,7 +170,7 @@ def main():
                        "frac_of_hbm_peak": round(biters * per_iter_bytes / bdt / 1e9 / HBM_PEAK_GBS, 4)}
         # --- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores ---
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (the other ranks would idle on the barrier)
             from oracle import oracle
             oracle.build()
             ncores = os.cpu_count() or 1
