@@ -249,6 +249,8 @@ struct sadvio_ba_handle {
     bool has_lmk_const = false;
     // profiling
     std::vector<KernelClass> kclasses;
+    hipStream_t side = nullptr;            // IMU factor evaluation runs here, concurrently with k_build / k_backsub
+    hipEvent_t ev_fork = nullptr, ev_lin = nullptr, ev_solved = nullptr, ev_cost = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<std::pair<int, int>> ev_used;  // (class, pool index)
     size_t ev_next = 0;
@@ -496,11 +498,11 @@ int upload_priors(sadvio_ba_handle* h) {
     h->imus.clear();
     for (size_t w = 0; w < h->wins.size(); w++) {
         h->wins[w].d.imu_begin = (int)h->imus.size();
-        for (auto& f : h->imus_per_win[w]) h->imus.push_back(f);
+        for (auto& f : h->imus_per_win[w]) { h->imus.push_back(f); h->imus.back().win = (int)w; }
         h->wins[w].d.imu_end = (int)h->imus.size();
     }
     HIP_TRY(h->d_imus.alloc(h->imus.size()));
-    HIP_TRY(h->d_imu_scratch.alloc(h->imus.size() * (size_t)(IMU_J + 6)));
+    HIP_TRY(h->d_imu_scratch.alloc(h->imus.size() * (size_t)IMU_ROW));
     if (!h->imus.empty())
         h->up.add(h->d_imus.p, h->imus.data(), h->imus.size() * sizeof(ImuDev));
     std::vector<WinDev> wd(h->wins.size());
@@ -558,6 +560,9 @@ int sadvio_ba_create(const sadvio_ba_config* cfg, sadvio_ba_handle** out) {
     if (cfg) h->cfg = *cfg;
     h->device = dev;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return SADVIO_E_HIP; }
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) h->side = nullptr;   // optional: without it everything is serial
+    for (hipEvent_t* e : {&h->ev_fork, &h->ev_lin, &h->ev_solved, &h->ev_cost})
+        if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { *e = nullptr; if (h->side) { (void)hipStreamDestroy(h->side); h->side = nullptr; } }
     *out = h;
     return SADVIO_OK;
 }
@@ -569,6 +574,8 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->rccl.comm) (void)h->rccl.destroy(h->rccl.comm);
     if (h->h_final) (void)hipHostFree(h->h_final);
+    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    for (hipEvent_t e : {h->ev_fork, h->ev_lin, h->ev_solved, h->ev_cost}) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     h->d_win.release(); h->d_tiles.release(); h->d_kf_T0.release(); h->d_xp.release(); h->d_xv.release();
@@ -1156,6 +1163,7 @@ bool make_imu_dev(const sadvio_imu_factor& f, int kf_base, ImuDev& o) {
     if (!imu_sqrt_information(f.cov, o.W)) return false;
     o.sa = 1.0 / sqrt(f.dt * f.bacc_noise * f.bacc_noise);
     o.sg = 1.0 / sqrt(f.dt * f.bgyr_noise * f.bgyr_noise);
+    o.win = 0; o.pad = 0;
     return true;
 }
 }  // namespace
@@ -1654,8 +1662,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     }
     if (getenv("SADVIO_DEBUG")) fprintf(stderr, "[sadvio dbg] lds_build %zu B, Rp %d, strip_doubles %d, max_tile_kf %d, max_tile_free %d, tiles %d\n", lds_build, Rp, strip_doubles, mtk, h->max_tile_free, n_tiles);
     const size_t lds_back = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)mtk * 18) + 16;
-    const size_t lds_solve = sizeof(double) * ((size_t)(h->max_np + 2) * 6 + (size_t)(h->max_np + 1) * (h->max_np + 2) / 2 +
-                                               4 * (size_t)h->max_np + (size_t)(h->max_np / 5 + 1) * 36) + 64;
+    const size_t npq = (size_t)h->max_np + 5;   // VIO windows are padded to a multiple of 6 inside k_solve
+    const size_t lds_solve = sizeof(double) * ((npq + 2) * 6 + (npq + 1) * (npq + 2) / 2 + 4 * npq + (npq / 5 + 1) * 36) + 64;
     // robust loss or prior-kept landmarks in the batch: the kernels carrying those (rare) paths
     bool any_pseudo = false;
     for (const auto& v : h->sp_elim) for (char e : v) any_pseudo |= e != 0;
@@ -1719,7 +1727,17 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     auto enqueue = [&]() {
         { ScopedTimer t(h, "k_reset"); hipLaunchKernelGGL(k_reset, dim3(reset_blocks), dim3(256), 0, h->stream, P); }
         { ScopedTimer t(h, "k_init_tables"); hipLaunchKernelGGL(k_init_tables, dim3((h->n_kf_tot + 63) / 64), dim3(64), 0, h->stream, P, h->n_kf_tot); }
+        const int n_imu_all = (int)h->imus.size();
+        // IMU factors are evaluated on a side stream: the linearisation next to k_build, the candidate cost next to
+        // k_backsub (fork / join with events; inside the captured graph these become parallel branches)
+        const bool fork = n_imu_all > 0 && h->side && !h->cfg.profile_kernels && !h->coll_fn;
         for (int s = 0; s < slots; s++) {
+            if (fork) {
+                (void)hipEventRecord(h->ev_fork, h->stream);
+                (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
+                hipLaunchKernelGGL(k_imu_eval<true>, dim3(n_imu_all), dim3(64), 0, h->side, P, s, 1);
+                (void)hipEventRecord(h->ev_lin, h->side);
+            }
             { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
             if (h->n_kept) { ScopedTimer t(h, "k_build_kept"); hipLaunchKernelGGL(kbk, dim3((h->n_kept + 127) / 128), dim3(128), 0, h->stream, P, s); }
             if (dp_max_nf > 0) {
@@ -1745,6 +1763,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                     }
                 } else if (h->coll_fn(h->coll_ctx, h->d_S.p, (int64_t)h->red_total, (void*)h->stream) != 0) coll_failed = true;
             }
+            if (fork) (void)hipStreamWaitEvent(h->stream, h->ev_lin, 0);
+            else if (n_imu_all) { ScopedTimer t(h, "k_imu_lin"); hipLaunchKernelGGL(k_imu_eval<true>, dim3(n_imu_all), dim3(64), 0, h->stream, P, s, 0); }
             if (h->n_big < n_win) { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(ks0, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
             if (h->n_big) {
                 { ScopedTimer t(h, "k_solve_front"); hipLaunchKernelGGL(ks1, dim3(n_win), dim3(SOLVE_THREADS), 64, h->stream, P, s); }
@@ -1833,8 +1853,15 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                     if (d.ld) (void)hipMemsetAsync(h->d_S.p + d.S_off, 0, sizeof(double) * (size_t)d.Np * d.Np, h->stream);
                 }
             }
+            if (fork) {
+                (void)hipEventRecord(h->ev_solved, h->stream);
+                (void)hipStreamWaitEvent(h->side, h->ev_solved, 0);
+                hipLaunchKernelGGL(k_imu_eval<false>, dim3(n_imu_all), dim3(64), 0, h->side, P, s, 0);
+                (void)hipEventRecord(h->ev_cost, h->side);
+            } else if (n_imu_all) { ScopedTimer t(h, "k_imu_cost"); hipLaunchKernelGGL(k_imu_eval<false>, dim3(n_imu_all), dim3(64), 0, h->stream, P, s, 0); }
             if (dp_max_nf > 0) { ScopedTimer t(h, "k_prior_m"); hipLaunchKernelGGL(k_prior_m, dim3((dp_max_nf + 3) / 4, n_win), dim3(256), 0, h->stream, P, s); }
             { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
+            if (fork) (void)hipStreamWaitEvent(h->stream, h->ev_cost, 0);
             if (h->coll_fn) {
                 { ScopedTimer t(h, "k_rank_partials"); hipLaunchKernelGGL(k_rank_partials, dim3(n_win), dim3(64), 0, h->stream, P, s, 1); }
                 ScopedTimer t(h, "allreduce_step_partials");
@@ -1881,6 +1908,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         if (hipMemcpy(ts, h->d_dbg.p, sizeof(ts), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[sadvio dbg] phase dt (us):");
             for (int i = 1; i < 16; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[0]) * 0.01);
+            fprintf(stderr, "  pose-only phases (priors | imu cost | JtJ | bias | sparse,dense | totals):");
+            for (int i = 22; i < 27; i++) fprintf(stderr, " %.2f", (ts[i] - ts[0]) * 0.01);
             fprintf(stderr, "  shader clock %.3f GHz\n[sadvio dbg] k_build:", (double)(ts[21] - ts[20]) / ((ts[15] - ts[0]) * 10.0));
             for (int i = 33; i < 43; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[32]) * 0.01);
             fprintf(stderr, "\n[sadvio dbg] k_chol_panel / k_band_solve (fwd window 2: carry fresh chol store | fwd end | bwd window 2: load below steps | bwd end):");

@@ -86,6 +86,7 @@ struct ImuDev {
     double J_dR_bg[9], J_dv_ba[9], J_dv_bg[9], J_dp_ba[9], J_dp_bg[9];
     double W[81];
     double sa, sg;   // 1 / sqrt(dt * bacc_noise^2), 1 / sqrt(dt * bgyr_noise^2)
+    int win, pad;    // window of the factor (filled when the per-window lists are concatenated)
 };
 // One factor of the sparsified marginalisation prior (sadvio_sparse_prior with global indices).
 struct SparseDev {
@@ -95,6 +96,11 @@ struct SparseDev {
 };
 constexpr int SPARSE_J = 15 * 15 + 15;  // J (rows x 15) + r kept in HBM scratch between phases
 constexpr int IMU_J = 9 * 24 + 9;  // whitened Jacobian + residual kept in HBM scratch between phases
+// scratch row of one IMU factor: J 216 | r 9 | bias residuals 6 | H = J^T J (lower, 300) | g = J^T r (24) | target of each H / g
+// entry in the window's reduced system ((row << 16) | col, or -1) as doubles (324), all written by k_imu_eval<true>
+constexpr int IMU_H = IMU_J + 6;
+constexpr int IMU_IX = IMU_H + 324;
+constexpr int IMU_ROW = IMU_IX + 324;
 
 // Levenberg-Marquardt control state at the beginning of a slot (one step attempt).
 struct LmState {

@@ -446,9 +446,9 @@ __device__ __forceinline__ void pose_to_landmark_factor(const double* T0, const 
 // WHITEN = false leaves the UN-whitened 9x24 Jacobian in J (the caller multiplies by W with many threads); r is
 // whitened in both cases.
 template <typename ImuT, bool WHITEN = true>
-__device__ __noinline__ void imu_factor(const ImuT& f, const double* Ti0, const double* Tj0, const double* vi0,
-                                        const double* vj0, const double* dpi, const double* dpj, const double* dvi,
-                                        const double* dvj, const double* dba, const double* dbg, double* r, double* J) {
+__device__ __forceinline__ void imu_factor_body(const ImuT& f, const double* Ti0, const double* Tj0, const double* vi0,
+                                                const double* vj0, const double* dpi, const double* dpj, const double* dvi,
+                                                const double* dvj, const double* dba, const double* dbg, double* r, double* J) {
     const double G[3] = {0.0, 0.0, -9.81};  // IMU.h:8
     double dRi[9], dRj[9], Ri[9], Rj[9], ti[3], tj[3];
     so3_exp(dpi, dRi); so3_exp(dpj, dRj);
@@ -538,6 +538,15 @@ __device__ __noinline__ void imu_factor(const ImuT& f, const double* Ti0, const 
                 for (int k = 0; k < 9; k++) s += f.W[9 * q + k] * U[k * 24 + c];
                 J[q * 24 + c] = s;
             }
+}
+
+// Out-of-line copy for the big kernels (k_solve, k_marg_small: inlining it there costs more registers than the call);
+// k_imu_eval inlines the body into a 64-lane kernel where everything stays in registers.
+template <typename ImuT, bool WHITEN = true>
+__device__ __noinline__ void imu_factor(const ImuT& f, const double* Ti0, const double* Tj0, const double* vi0,
+                                        const double* vj0, const double* dpi, const double* dpj, const double* dvi,
+                                        const double* dvj, const double* dba, const double* dbg, double* r, double* J) {
+    imu_factor_body<ImuT, WHITEN>(f, Ti0, Tj0, vi0, vj0, dpi, dpj, dvi, dvj, dba, dbg, r, J);
 }
 
 }  // namespace sadvio

@@ -38,7 +38,7 @@ struct DevPtrs {
     long long ptab_stride;
     const PriorDev* priors;
     const ImuDev* imus;
-    double* imu_scratch;  // [n_imu_tot][IMU_J + 6] whitened J (9x24), r (9), bias residual (6)
+    double* imu_scratch;  // [n_imu_tot][IMU_ROW], see ba_types.h
     double* S; double* gred; double* gfull; double* hdiag; double* delta; double* s_pose;
     LmState* states;  // [n_win][slots+2]
     IterAcc* acc;     // [n_win][slots+1] window totals (written by single workgroups only)
@@ -1069,14 +1069,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     double* gredg = P.gred + W.red_off;
     double* gfullg = P.gfull + W.red_off;
     double* hdg = P.hdiag + W.red_off;
-    const int tri_n = (Np + 1) * (Np + 2) / 2;  // packed lower triangle incl. the right-hand-side row Np
-    double* LpT = (double*)smem;                // [NBP][Np+2] transposed panel strip
-    double* A = BIG ? Sg : LpT + (size_t)(Np + 2) * NBP;   // packed lower (LDS) | full row-major lower (HBM)
+    // VIO windows (15 columns per key-frame) are padded with identity rows to a multiple of 6: the 6-wide pivot blocks
+    // need 28 steps for 11 key-frames where 5-wide ones need 33, and K = 6 fills the two MFMA k-steps better than K = 5
+    const int Nq = (!BIG && W.dpf == 15 && W.n_red == 0) ? (Np + 5) / 6 * 6 : Np;
+    const int tri_n = (Nq + 1) * (Nq + 2) / 2;  // packed lower triangle incl. the right-hand-side row Nq
+    double* LpT = (double*)smem;                // [NBP][Nq+2] transposed panel strip
+    double* A = BIG ? Sg : LpT + (size_t)(Nq + 2) * NBP;   // packed lower (LDS) | full row-major lower (HBM)
     double* y = BIG ? gredg : A + tri_n;        // rhs -> work vector of the back-substitution
-    double* gf = BIG ? gfullg : y + Np;         // full gradient
-    double* hd = BIG ? hdg : gf + Np;           // diag(H)
-    double* xs = BIG ? gredg : hd + Np;         // solution (BIG: potrs overwrites the right-hand side)
-    double* linvTab = xs + Np;                  // [Np/NB][NB*NB] inverse pivot blocks
+    double* gf = BIG ? gfullg : y + Nq;         // full gradient
+    double* hd = BIG ? hdg : gf + Nq;           // diag(H)
+    double* xs = BIG ? gredg : hd + Nq;         // solution (BIG: potrs overwrites the right-hand side)
+    double* linvTab = xs + Nq;                  // [Nq/NB][NB*NB] inverse pivot blocks
     auto aidx = [&](int i, int j) -> long long { return BIG ? (long long)i * ld + j : (long long)tri(i, j); };  // i >= j
     const int cur = st.cur;
     const double* xp = P.xp + (long long)cur * P.xp_stride;
@@ -1138,85 +1141,43 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
         }
     }
-    // IMUFactor + IMUBiasFactor (K3): one thread per factor evaluates r and the whitened 9x24 Jacobian into an
-    // HBM scratch row; the J^T J accumulation is then spread over all threads (LDS atomics into A).
+    SADVIO_TS(3, 22);
+    // IMUFactor + IMUBiasFactor (K3): k_imu_eval<true> (one 64-lane workgroup per factor, launched between k_build and
+    // this kernel) left r, the whitened 9x24 Jacobian and the bias residuals in the HBM scratch row; here the costs are
+    // summed and the J^T J accumulation is spread over all threads (LDS atomics into A).
     if (EXTRAS && n_imu > 0) {
-        const double* xv = P.xv + (long long)cur * P.xv_stride;
-        const double* xba = P.xba + (long long)cur * P.xv_stride;
-        const double* xbg = P.xbg + (long long)cur * P.xv_stride;
         for (int k = tid; k < n_imu; k += blockDim.x) {
             const ImuDev& f = P.imus[W.imu_begin + k];
-            double* sc = P.imu_scratch + (long long)(W.imu_begin + k) * (IMU_J + 6);
-            const int i = f.kf_i, j = f.kf_j;
-            const bool all_const = P.kf_fidx[i] < 0 && P.kf_fidx[j] < 0;
-            double dpi[6], dpj[6], r[9];
-            for (int q = 0; q < 6; q++) { dpi[q] = xp[6 * (long long)i + q]; dpj[q] = xp[6 * (long long)j + q]; }
-            imu_factor<ImuDev, false>(f, P.kf_T0 + 12 * (long long)i, P.kf_T0 + 12 * (long long)j, P.kf_vel + 3 * (long long)i,
-                                      P.kf_vel + 3 * (long long)j, dpi, dpj, xv + 3 * (long long)i, xv + 3 * (long long)j,
-                                      xba + 3 * (long long)i, xbg + 3 * (long long)i, r, all_const ? nullptr : sc);  // un-whitened J
+            const double* sc = P.imu_scratch + (long long)(W.imu_begin + k) * IMU_ROW;
             double c = 0.0;
-            for (int q = 0; q < 9; q++) { sc[9 * 24 + q] = r[q]; c += r[q] * r[q]; }
-            for (int q = 0; q < 3; q++) {
-                const double rb_a = f.sa * (P.kf_ba[3 * (long long)j + q] + xba[3 * (long long)j + q] - P.kf_ba[3 * (long long)i + q] - xba[3 * (long long)i + q]);
-                const double rb_g = f.sg * (P.kf_bg[3 * (long long)j + q] + xbg[3 * (long long)j + q] - P.kf_bg[3 * (long long)i + q] - xbg[3 * (long long)i + q]);
-                sc[IMU_J + q] = rb_a; sc[IMU_J + 3 + q] = rb_g;
-                c += rb_a * rb_a + rb_g * rb_g;
-            }
-            if (all_const) fixed_part += c; else cost_part += c;
+            for (int q = 0; q < 9; q++) c += sc[9 * 24 + q] * sc[9 * 24 + q];
+            for (int q = 0; q < 6; q++) c += sc[IMU_J + q] * sc[IMU_J + q];
+            if (P.kf_fidx[f.kf_i] < 0 && P.kf_fidx[f.kf_j] < 0) fixed_part += c; else cost_part += c;
         }
-        __threadfence_block();
-        __syncthreads();
-        // whitening J <- W J spread over the threads: item = (factor, column), in place per column
-        for (int it = tid; it < n_imu * 24; it += blockDim.x) {
-            const int k = it / 24, cc = it - 24 * k;
-            const ImuDev& f = P.imus[W.imu_begin + k];
-            if (P.kf_fidx[f.kf_i] < 0 && P.kf_fidx[f.kf_j] < 0) continue;
-            double* sc = P.imu_scratch + (long long)(W.imu_begin + k) * (IMU_J + 6);
-            double u[9], o[9];
-#pragma unroll
-            for (int q = 0; q < 9; q++) u[q] = sc[q * 24 + cc];
-#pragma unroll
-            for (int q = 0; q < 9; q++) {
-                double s = 0.0;
-#pragma unroll
-                for (int kk = 0; kk < 9; kk++) s += f.W[9 * q + kk] * u[kk];
-                o[q] = s;
-            }
-#pragma unroll
-            for (int q = 0; q < 9; q++) sc[q * 24 + cc] = o[q];
+        SADVIO_TS(3, 23);
+        // J^T J and J^T r of the IMU factors were formed by k_imu_eval<true> together with the position of every entry in
+        // this window's reduced system: one coalesced read + one LDS atomic per entry here (the products themselves,
+        // with their dependent global loads, cost 16 us inside this kernel)
+        for (int it = tid; it < n_imu * 324; it += blockDim.x) {
+            const int k = it / 324, e = it - 324 * k;
+            const double* row = P.imu_scratch + (long long)(W.imu_begin + k) * IMU_ROW;
+            const int ix = (int)row[IMU_IX + e];
+            if (ix < 0) continue;
+            const double v = row[IMU_H + e];
+            const int ca = ix >> 16, cb = ix & 0xffff;
+            if (e < 300) {
+                atomic_add_f64(&A[aidx(ca, cb)], v);
+                if (ca == cb) atomic_add_f64(&hd[ca], v);
+            } else { atomic_add_f64(&y[ca], v); atomic_add_f64(&gf[ca], v); }
         }
-        __threadfence_block();
-        __syncthreads();
-        // J^T J of the IMU factors: item = (factor, a, b <= a)
-        for (int it = tid; it < n_imu * 300; it += blockDim.x) {
-            const int k = it / 300;
-            int e = it - 300 * k, a = 0;
-            while (e >= a + 1) { e -= a + 1; a++; }
-            const int b = e;
-            const ImuDev& f = P.imus[W.imu_begin + k];
-            const int fi = P.kf_fidx[f.kf_i], fj = P.kf_fidx[f.kf_j];
-            if (fi < 0 && fj < 0) continue;
-            const int ca = imu_col(a, fi, fj), cb = imu_col(b, fi, fj);
-            if (ca < 0 || cb < 0) continue;
-            const double* sc = P.imu_scratch + (long long)(W.imu_begin + k) * (IMU_J + 6);
-            double h = 0.0;
-#pragma unroll
-            for (int q = 0; q < 9; q++) h += sc[q * 24 + a] * sc[q * 24 + b];
-            atomic_add_f64(&A[ca >= cb ? aidx(ca, cb) : aidx(cb, ca)], h);
-            if (a == b) {
-                double g = 0.0;
-#pragma unroll
-                for (int q = 0; q < 9; q++) g += sc[q * 24 + a] * sc[9 * 24 + q];
-                atomic_add_f64(&y[ca], g); atomic_add_f64(&gf[ca], g); atomic_add_f64(&hd[ca], h);
-            }
-        }
+        SADVIO_TS(3, 24);
         // bias random walk: item = (factor, axis, ba|bg): Jacobians are -/+ s I
         for (int it = tid; it < n_imu * 6; it += blockDim.x) {
             const int k = it / 6, e = it - 6 * k, ax = e % 3, gy = e / 3;
             const ImuDev& f = P.imus[W.imu_begin + k];
             const int fi = P.kf_fidx[f.kf_i], fj = P.kf_fidx[f.kf_j];
             const double sgm = gy ? f.sg : f.sa;
-            const double rb = P.imu_scratch[(long long)(W.imu_begin + k) * (IMU_J + 6) + IMU_J + 3 * gy + ax];
+            const double rb = P.imu_scratch[(long long)(W.imu_begin + k) * IMU_ROW + IMU_J + 3 * gy + ax];
             const int ci = fi < 0 ? -1 : fi * 15 + 9 + 3 * gy + ax, cj = fj < 0 ? -1 : fj * 15 + 9 + 3 * gy + ax;
             const double s2 = sgm * sgm;
             if (ci >= 0) { atomic_add_f64(&A[aidx(ci, ci)], s2); atomic_add_f64(&hd[ci], s2); atomic_add_f64(&y[ci], -sgm * rb); atomic_add_f64(&gf[ci], -sgm * rb); }
@@ -1224,6 +1185,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             if (ci >= 0 && cj >= 0) atomic_add_f64(&A[ci >= cj ? aidx(ci, cj) : aidx(cj, ci)], -s2);
         }
     }
+    SADVIO_TS(3, 25);
     // sparse (NFR) prior factors: one thread per factor evaluates r, J into an HBM scratch row, then the J^T J
     // accumulation is spread over all threads (same scheme as the IMU factors)
     const int n_sp = W.sp_end - W.sp_begin;
@@ -1276,6 +1238,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         cost_part += pc[0];
         pc[0] = 0.0;
     }
+    SADVIO_TS(3, 26);
     // window totals of the linearisation: tiles' k_build partials + the pose-only factors evaluated here
     double gm = 0.0;
     if (P.world > 1) {
@@ -1318,9 +1281,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         else s = sp[i];
         double s2 = s * s;
         A[aidx(i, i)] += fmin(fmax(s2 * hd[i], P.o.min_lm_diagonal), P.o.max_lm_diagonal) / st.radius / s2;
-        if (!BIG) A[tri(Np, i)] = y[i];
+        if (!BIG) A[tri(Nq, i)] = y[i];
     }
-    if (!BIG && tid == 0) A[tri(Np, Np)] = 0.0;
+    if (!BIG) {
+        for (int e = tid; e < tri(Nq, 0) - tri(Np, 0); e += blockDim.x) {   // identity padding rows Np .. Nq - 1
+            const int g = tri(Np, 0) + e;
+            int i = Np;
+            while (tri(i + 1, 0) <= g) i++;
+            A[g] = (g - tri(i, 0) == i) ? 1.0 : 0.0;
+        }
+        for (int i = Np + tid; i <= Nq; i += blockDim.x) A[tri(Nq, i)] = 0.0;   // rhs of the padding rows + the corner
+    }
     __syncthreads();
     SADVIO_TS(3, 3);
     if (MODE == 1) return;  // the host enqueues potrf / potrs on S, gred next
@@ -1330,8 +1301,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         bool ok = true;  // Np == 0 (every key-frame constant, landmarkOptimization): nothing to factor
         if (Np == 0) {}
         else if (W.n_red > 0) ok = chol_solve_packed<3>(A, Np, y, xs, LpT, linvTab, ts);  // Np = dpf n_free + 3 n_red
-        else if (W.dpf == 6) ok = chol_solve_packed<6>(A, Np, y, xs, LpT, linvTab, ts);
-        else ok = chol_solve_packed<5>(A, Np, y, xs, LpT, linvTab, ts);
+        else ok = chol_solve_packed<6>(A, Nq, y, xs, LpT, linvTab, ts);   // dpf 6, or dpf 15 padded to a multiple of 6
         if (!ok) {
             if (tid == 0) acc->chol_fail = 1;
             return;
@@ -1419,7 +1389,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             const ImuDev& f = P.imus[W.imu_begin + k];
             const int fi = P.kf_fidx[f.kf_i], fj = P.kf_fidx[f.kf_j];
             if (fi < 0 && fj < 0) continue;
-            const double* sc = P.imu_scratch + (long long)(W.imu_begin + k) * (IMU_J + 6);
+            const double* sc = P.imu_scratch + (long long)(W.imu_begin + k) * IMU_ROW;
             double m = 0.0, r;
             if (q < 9) {
                 for (int a = 0; a < 24; a++) { const int ca = imu_col(a, fi, fj); if (ca >= 0) m += sc[q * 24 + a] * y[ca]; }
@@ -1433,34 +1403,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
             mcc += -m * (r + 0.5 * m);
         }
-        // candidate cost: one thread per factor at x + delta
-        for (int k = tid; k < n_imu; k += blockDim.x) {
-            const ImuDev& f = P.imus[W.imu_begin + k];
-            const int i = f.kf_i, j = f.kf_j;
-            const int fi = P.kf_fidx[i], fj = P.kf_fidx[j];
-            if (fi < 0 && fj < 0) continue;
-            double dpi[6], dpj[6], dvi[3], dvj[3], dbai[3], dbgi[3], dbaj[3], dbgj[3], r[9];
-            for (int q = 0; q < 6; q++) {
-                dpi[q] = xp[6 * (long long)i + q] + (fi < 0 ? 0.0 : y[fi * 15 + q]);
-                dpj[q] = xp[6 * (long long)j + q] + (fj < 0 ? 0.0 : y[fj * 15 + q]);
-            }
-            for (int q = 0; q < 3; q++) {
-                dvi[q] = xv[3 * (long long)i + q] + (fi < 0 ? 0.0 : y[fi * 15 + 6 + q]);
-                dvj[q] = xv[3 * (long long)j + q] + (fj < 0 ? 0.0 : y[fj * 15 + 6 + q]);
-                dbai[q] = xba[3 * (long long)i + q] + (fi < 0 ? 0.0 : y[fi * 15 + 9 + q]);
-                dbgi[q] = xbg[3 * (long long)i + q] + (fi < 0 ? 0.0 : y[fi * 15 + 12 + q]);
-                dbaj[q] = xba[3 * (long long)j + q] + (fj < 0 ? 0.0 : y[fj * 15 + 9 + q]);
-                dbgj[q] = xbg[3 * (long long)j + q] + (fj < 0 ? 0.0 : y[fj * 15 + 12 + q]);
-            }
-            imu_factor(f, P.kf_T0 + 12 * (long long)i, P.kf_T0 + 12 * (long long)j, P.kf_vel + 3 * (long long)i,
-                       P.kf_vel + 3 * (long long)j, dpi, dpj, dvi, dvj, dbai, dbgi, r, nullptr);
-            for (int q = 0; q < 9; q++) cc += r[q] * r[q];
-            for (int q = 0; q < 3; q++) {
-                const double ra = f.sa * (P.kf_ba[3 * (long long)j + q] + dbaj[q] - P.kf_ba[3 * (long long)i + q] - dbai[q]);
-                const double rg = f.sg * (P.kf_bg[3 * (long long)j + q] + dbgj[q] - P.kf_bg[3 * (long long)i + q] - dbgi[q]);
-                cc += ra * ra + rg * rg;
-            }
-        }
+        // candidate cost of the IMU factors: k_imu_eval<false>, launched after this kernel, adds it to acc->cand_cost
     }
     if (EXTRAS && W.sp_end > W.sp_begin) {
         const int n_sp = W.sp_end - W.sp_begin;
@@ -1887,6 +1830,97 @@ __global__ void k_decide(DevPtrs P, int slot, int final) {
             rec.s = f;
             rec.fixed_cost = P.acc[(long long)w * P.state_stride].fixed_cost;
             P.final_out[w] = rec;
+        }
+    }
+}
+
+// IMUFactor + IMUBiasFactor of one key-frame pair (residuals.hpp:133-300), one 64-lane workgroup per factor: inside
+// k_solve (512 threads, 128 VGPRs) this code lived in scratch memory and cost 49 us + 21 us per LM step on a 12-KF
+// window; here the body is inlined and stays in registers.
+//   LIN = true  (between k_build and k_solve): r, bias residuals and the whitened 9x24 Jacobian at x into the scratch row
+//   LIN = false (after k_solve): residuals at the candidate x + delta, their squared sum added to the slot's cand_cost
+// own_decide: the kernel runs on a side stream concurrently with k_build, so (like every k_build workgroup) it takes the
+// accept / reject decision of the previous slot itself instead of reading the state k_build publishes.
+template <bool LIN>
+__global__ __launch_bounds__(64) void k_imu_eval(DevPtrs P, int slot, int own_decide) {
+    const int k = blockIdx.x, ln = threadIdx.x;
+    const ImuDev& f = P.imus[k];
+    const long long so = (long long)f.win * P.state_stride + slot;
+    LmState st;
+    if (LIN && own_decide && slot > 0 && !P.decide_kernel) {
+        __shared__ double s4[4];
+        const WinDev& W = P.win[f.win];
+        wave_sum_backsub_partials(P, (slot - 1) & 1, f.win, W.tile_begin, W.tile_end - W.tile_begin, ln, s4);
+        __syncthreads();
+        IterAcc a = P.acc[so - 1];
+        a.cand_cost += s4[0]; a.mcc += s4[1]; a.step_norm2 += s4[2]; a.cand_norm2 += s4[3];
+        st = lm_decide(P.states[so - 1], a, P.o);
+    } else st = P.states[so];
+    if (st.done) return;
+    const int i = f.kf_i, j = f.kf_j;
+    const bool all_const = P.kf_fidx[i] < 0 && P.kf_fidx[j] < 0;
+    if (!LIN && all_const) return;
+    const int buf = LIN ? st.cur : 1 - st.cur;
+    const double* xp = P.xp + (long long)buf * P.xp_stride;
+    const double* xv = P.xv + (long long)buf * P.xv_stride;
+    const double* xba = P.xba + (long long)buf * P.xv_stride;
+    const double* xbg = P.xbg + (long long)buf * P.xv_stride;
+    __shared__ double U[9 * 24];
+    __shared__ double rs[9];
+    double* sc = P.imu_scratch + (long long)k * IMU_ROW;
+    if (ln == 0) {
+        double dpi[6], dpj[6], r[9];
+        for (int q = 0; q < 6; q++) { dpi[q] = xp[6 * (long long)i + q]; dpj[q] = xp[6 * (long long)j + q]; }
+        imu_factor_body<ImuDev, false>(f, P.kf_T0 + 12 * (long long)i, P.kf_T0 + 12 * (long long)j, P.kf_vel + 3 * (long long)i,
+                                       P.kf_vel + 3 * (long long)j, dpi, dpj, xv + 3 * (long long)i, xv + 3 * (long long)j,
+                                       xba + 3 * (long long)i, xbg + 3 * (long long)i, r, (LIN && !all_const) ? U : nullptr);
+        double c = 0.0;
+        for (int q = 0; q < 9; q++) { if (LIN) { sc[9 * 24 + q] = r[q]; rs[q] = r[q]; } c += r[q] * r[q]; }
+        for (int q = 0; q < 3; q++) {
+            const double rb_a = f.sa * (P.kf_ba[3 * (long long)j + q] + xba[3 * (long long)j + q] - P.kf_ba[3 * (long long)i + q] - xba[3 * (long long)i + q]);
+            const double rb_g = f.sg * (P.kf_bg[3 * (long long)j + q] + xbg[3 * (long long)j + q] - P.kf_bg[3 * (long long)i + q] - xbg[3 * (long long)i + q]);
+            if (LIN) { sc[IMU_J + q] = rb_a; sc[IMU_J + 3 + q] = rb_g; }
+            c += rb_a * rb_a + rb_g * rb_g;
+        }
+        if (!LIN) atomic_add_f64(&P.acc[so].cand_cost, c);
+    }
+    if (LIN && !all_const) {
+        __syncthreads();
+        if (ln < 24) {   // J <- W J, one column per lane (kept in LDS for the products below)
+            double u[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) u[q] = U[q * 24 + ln];
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                double s = 0.0;
+#pragma unroll
+                for (int kk = q; kk < 9; kk++) s += f.W[9 * q + kk] * u[kk];   // W is upper triangular (L^T)
+                sc[q * 24 + ln] = s;
+                U[q * 24 + ln] = s;
+            }
+        }
+        __syncthreads();
+        // H = J^T J (lower triangle, 300), g = J^T r (24) and where each entry goes in the reduced system
+        const int fi = P.kf_fidx[i], fj = P.kf_fidx[j];
+        for (int e = ln; e < 324; e += 64) {
+            double v = 0.0;
+            int ix = -1;
+            if (e < 300) {
+                int a = 0, b = e;
+                while (b >= a + 1) { b -= a + 1; a++; }
+#pragma unroll
+                for (int q = 0; q < 9; q++) v += U[q * 24 + a] * U[q * 24 + b];
+                const int ca = imu_col(a, fi, fj), cb = imu_col(b, fi, fj);
+                if (ca >= 0 && cb >= 0) ix = ca >= cb ? (ca << 16) | cb : (cb << 16) | ca;
+            } else {
+                const int a = e - 300;
+#pragma unroll
+                for (int q = 0; q < 9; q++) v += U[q * 24 + a] * rs[q];
+                const int ca = imu_col(a, fi, fj);
+                if (ca >= 0) ix = ca << 16;
+            }
+            sc[IMU_H + e] = v;
+            sc[IMU_IX + e] = (double)ix;
         }
     }
 }

@@ -25,3 +25,12 @@ for name, (dp, sp) in cases.items():
     for _ in range(3): s = be.solve(opts)
     print(name, {k: round(v["avg_us"], 1) for k, v in be.kernel_times().items()}, "cost", s[0].initial_cost, "->", s[0].final_cost, flush=True)
     be.close()
+    for ug in (False, True):
+        be = capi.Backend(device=0, use_graph=ug)
+        be.set_windows([w])
+        for _ in range(3): be.solve(opts)
+        t = time.perf_counter()
+        for _ in range(10): s = be.solve(opts)
+        dt = (time.perf_counter() - t) / 10
+        print(f"   {name}: graph={ug} wall/solve {dt*1e3:.3f} ms -> {10/dt:.0f} it/s  final cost {s[0].final_cost}", flush=True)
+        be.close()
