@@ -208,6 +208,8 @@ struct sadvio_ba_handle {
     std::vector<int> n_obs_user;                   // caller's observation count per window
     std::vector<std::vector<sadvio_sparse_prior>> sparse_per_win;
     DevBuf<SparseDev> d_sparse;
+    DevBuf<int> d_sp_list;
+    int n_sp_list = 0;   // sparse prior factors evaluated by k_sparse_eval (all windows)
     DevBuf<double> d_sp_scratch;
     std::vector<unsigned char> h_lmk_const_user;  // as given by the caller
     std::vector<int> h_lmk_ob, h_lmk_oe, h_kf_fidx, h_obs_kf;
@@ -322,7 +324,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.world = h->world; P.rank = h->rank; P.rank_b = h->d_rank_b.p; P.rank_s = h->d_rank_s.p;
     P.lmk_red = h->d_lmk_red.p; P.kept_obs = h->d_kept_obs.p; P.n_kept = h->n_kept;
     P.dp_data = h->d_dp_data.p; P.dp_ints = h->d_dp_ints.p;
-    P.sparse = h->d_sparse.p; P.sp_scratch = h->d_sp_scratch.p;
+    P.sparse = h->d_sparse.p; P.sp_scratch = h->d_sp_scratch.p; P.sp_list = h->d_sp_list.p;
     P.n_xp = (long long)h->d_xp.n; P.n_xv = (long long)h->d_xv.n; P.n_xl = (long long)h->d_xl.n;
     P.n_win = (int)h->wins.size();
     { const char* e = getenv("SADVIO_DEBUG"); P.debug = e ? atoi(e) : 0; }
@@ -355,6 +357,7 @@ int layout_reduced(sadvio_ba_handle* h) {
     std::vector<unsigned char> lmk_const = h->h_lmk_const_user;
     std::vector<int> kept, dp_ints;
     std::vector<SparseDev> sparse;
+    std::vector<int> sp_list;
     std::vector<double> dp_data;
     bool any_red = false;
     struct Prep { long long off; int nf, n; };
@@ -406,10 +409,11 @@ int layout_reduced(sadvio_ba_handle* h) {
         }
         // landmarks touched by sparse prior factors stay in the reduced system as well
         d.sp_begin = (int)sparse.size();
+        d.spl_begin = (int)sp_list.size();
         for (size_t sk = 0; sk < h->sparse_per_win[w].size(); sk++) {
             const sadvio_sparse_prior& s = h->sparse_per_win[w][sk];
             SparseDev o{};
-            o.type = s.type;
+            o.type = s.type; o.win = w;
             const bool elim = w < (int)h->sp_elim.size() && sk < h->sp_elim[w].size() && h->sp_elim[w][sk];
             if (elim) {
                 // rides the Schur elimination as two pseudo-observations of its landmark: only its constants are needed
@@ -433,9 +437,11 @@ int layout_reduced(sadvio_ba_handle* h) {
             o.lmk0 = gls[0]; o.lmk1 = gls[1];
             memcpy(o.T_prior, s.T_prior, sizeof(o.T_prior)); memcpy(o.v_prior, s.v_prior, 24); memcpy(o.ba_prior, s.ba_prior, 24);
             memcpy(o.bg_prior, s.bg_prior, 24); memcpy(o.delta, s.delta, 24); memcpy(o.W, s.sqrt_inf, sizeof(o.W));
+            sp_list.push_back((int)sparse.size());
             sparse.push_back(o);
         }
         d.sp_end = (int)sparse.size();
+        d.spl_end = (int)sp_list.size();
         d.kept_end = (int)kept.size() / 3;
         d.n_red = n_red;
         d.Np = d.n_free_kf * d.dpf + 3 * n_red;
@@ -465,6 +471,9 @@ int layout_reduced(sadvio_ba_handle* h) {
     HIP_TRY(hipMemsetAsync(h->d_rank_s.p, 0, sizeof(double) * (size_t)nrb, h->stream));
     HIP_TRY(h->d_sparse.alloc(std::max<size_t>(sparse.size(), 1))); HIP_TRY(h->d_sp_scratch.alloc(std::max<size_t>(sparse.size(), 1) * SPARSE_J));
     h->up.add(h->d_sparse.p, sparse.data(), sparse.size() * sizeof(SparseDev));
+    HIP_TRY(h->d_sp_list.alloc(std::max<size_t>(sp_list.size(), 1)));
+    h->n_sp_list = (int)sp_list.size();
+    h->up.add(h->d_sp_list.p, sp_list.data(), sp_list.size() * sizeof(int));
     if (kept.empty()) kept.assign(3, 0);
     if (dp_ints.empty()) dp_ints.push_back(0);
     if (dp_data.empty()) dp_data.push_back(0.0);
@@ -1730,12 +1739,14 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         const int n_imu_all = (int)h->imus.size();
         // IMU factors are evaluated on a side stream: the linearisation next to k_build, the candidate cost next to
         // k_backsub (fork / join with events; inside the captured graph these become parallel branches)
-        const bool fork = n_imu_all > 0 && h->side && !h->cfg.profile_kernels && !h->coll_fn;
+        const int n_spl = h->n_sp_list;
+        const bool fork = (n_imu_all > 0 || n_spl > 0) && h->side && !h->cfg.profile_kernels && !h->coll_fn;
         for (int s = 0; s < slots; s++) {
             if (fork) {
                 (void)hipEventRecord(h->ev_fork, h->stream);
                 (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
-                hipLaunchKernelGGL(k_imu_eval<true>, dim3(n_imu_all), dim3(64), 0, h->side, P, s, 1);
+                if (n_imu_all) hipLaunchKernelGGL(k_imu_eval<true>, dim3(n_imu_all), dim3(64), 0, h->side, P, s, 1);
+                if (n_spl) hipLaunchKernelGGL(k_sparse_eval<true>, dim3(n_spl), dim3(64), 0, h->side, P, s, 1);
                 (void)hipEventRecord(h->ev_lin, h->side);
             }
             { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
@@ -1764,7 +1775,10 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 } else if (h->coll_fn(h->coll_ctx, h->d_S.p, (int64_t)h->red_total, (void*)h->stream) != 0) coll_failed = true;
             }
             if (fork) (void)hipStreamWaitEvent(h->stream, h->ev_lin, 0);
-            else if (n_imu_all) { ScopedTimer t(h, "k_imu_lin"); hipLaunchKernelGGL(k_imu_eval<true>, dim3(n_imu_all), dim3(64), 0, h->stream, P, s, 0); }
+            else {
+                if (n_imu_all) { ScopedTimer t(h, "k_imu_lin"); hipLaunchKernelGGL(k_imu_eval<true>, dim3(n_imu_all), dim3(64), 0, h->stream, P, s, 0); }
+                if (n_spl) { ScopedTimer t(h, "k_sparse_lin"); hipLaunchKernelGGL(k_sparse_eval<true>, dim3(n_spl), dim3(64), 0, h->stream, P, s, 0); }
+            }
             if (h->n_big < n_win) { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(ks0, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
             if (h->n_big) {
                 { ScopedTimer t(h, "k_solve_front"); hipLaunchKernelGGL(ks1, dim3(n_win), dim3(SOLVE_THREADS), 64, h->stream, P, s); }
@@ -1856,9 +1870,13 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             if (fork) {
                 (void)hipEventRecord(h->ev_solved, h->stream);
                 (void)hipStreamWaitEvent(h->side, h->ev_solved, 0);
-                hipLaunchKernelGGL(k_imu_eval<false>, dim3(n_imu_all), dim3(64), 0, h->side, P, s, 0);
+                if (n_imu_all) hipLaunchKernelGGL(k_imu_eval<false>, dim3(n_imu_all), dim3(64), 0, h->side, P, s, 0);
+                if (n_spl) hipLaunchKernelGGL(k_sparse_eval<false>, dim3(n_spl), dim3(64), 0, h->side, P, s, 0);
                 (void)hipEventRecord(h->ev_cost, h->side);
-            } else if (n_imu_all) { ScopedTimer t(h, "k_imu_cost"); hipLaunchKernelGGL(k_imu_eval<false>, dim3(n_imu_all), dim3(64), 0, h->stream, P, s, 0); }
+            } else {
+                if (n_imu_all) { ScopedTimer t(h, "k_imu_cost"); hipLaunchKernelGGL(k_imu_eval<false>, dim3(n_imu_all), dim3(64), 0, h->stream, P, s, 0); }
+                if (n_spl) { ScopedTimer t(h, "k_sparse_cost"); hipLaunchKernelGGL(k_sparse_eval<false>, dim3(n_spl), dim3(64), 0, h->stream, P, s, 0); }
+            }
             if (dp_max_nf > 0) { ScopedTimer t(h, "k_prior_m"); hipLaunchKernelGGL(k_prior_m, dim3((dp_max_nf + 3) / 4, n_win), dim3(256), 0, h->stream, P, s); }
             { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
             if (fork) (void)hipStreamWaitEvent(h->stream, h->ev_cost, 0);

@@ -45,6 +45,7 @@ struct WinDev {
     long long dp_off; // into dp_data: J[nf*n] Jt[n*nf] H[n*n] r0[nf] dx[n] r[nf]
     int kept_begin, kept_end;  // slice of kept_obs (observations of the reduced landmarks)
     int sp_begin, sp_end;      // slice of the sparse prior factors
+    int spl_begin, spl_end;    // slice of sp_list: the factors evaluated inside the solve (not riding the Schur elimination)
 };
 
 // One workgroup of k_build / k_backsub: a run of consecutive landmarks of one window. Each landmark is
@@ -91,10 +92,11 @@ struct ImuDev {
 // One factor of the sparsified marginalisation prior (sadvio_sparse_prior with global indices).
 struct SparseDev {
     int type, kf, lmk0, lmk1;
+    int win, pad;   // window of the factor
     double T_prior[12], v_prior[3], ba_prior[3], bg_prior[3], delta[3];
     double W[225];
 };
-constexpr int SPARSE_J = 15 * 15 + 15;  // J (rows x 15) + r kept in HBM scratch between phases
+constexpr int SPARSE_J = 15 * 15 + 15 + 2;  // J (rows x 15) + r + in-program flag kept in HBM scratch between phases
 constexpr int IMU_J = 9 * 24 + 9;  // whitened Jacobian + residual kept in HBM scratch between phases
 // scratch row of one IMU factor: J 216 | r 9 | bias residuals 6 | H = J^T J (lower, 300) | g = J^T r (24) | target of each H / g
 // entry in the window's reduced system ((row << 16) | col, or -1) as doubles (324), all written by k_imu_eval<true>

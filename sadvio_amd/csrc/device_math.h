@@ -383,9 +383,9 @@ __device__ __forceinline__ void pose_prior_factor(const double* T0, const double
 
 // IMUPriordx (residuals.hpp:649-695): params pose6 | dv3 | dba3 | dbg3; r = W e. The pose block of the Jacobian is
 // W [J6; 0]; the v / ba / bg blocks are plain identities at rows 6 / 9 / 12, NOT whitened (as coded, :679-693).
-__device__ __noinline__ void imu_prior_factor(const double* T0, const double* v0, const double* ba0, const double* bg0,
-                                              const double* Tp, const double* vp, const double* bap, const double* bgp,
-                                              const double* W, const double* prm, double* r, double* J) {
+__device__ __forceinline__ void imu_prior_factor_body(const double* T0, const double* v0, const double* ba0, const double* bg0,
+                                                      const double* Tp, const double* vp, const double* bap, const double* bgp,
+                                                      const double* W, const double* prm, double* r, double* J) {
     const double ones[6] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
     double e[15], J6[36];
     pose_prior_factor(T0, Tp, ones, prm, e, J ? J6 : nullptr);
@@ -409,6 +409,12 @@ __device__ __noinline__ void imu_prior_factor(const double* T0, const double* v0
             for (int a = 6; a < 15; a++) J[i * 15 + a] = (i == a) ? 1.0 : 0.0;
         }
     }
+}
+
+__device__ __noinline__ void imu_prior_factor(const double* T0, const double* v0, const double* ba0, const double* bg0,
+                                              const double* Tp, const double* vp, const double* bap, const double* bgp,
+                                              const double* W, const double* prm, double* r, double* J) {
+    imu_prior_factor_body(T0, v0, ba0, bg0, Tp, vp, bap, bgp, W, prm, r, J);
 }
 
 // PoseToLandmarkFactor (residuals.hpp:570-595): r = W (T_f_w (exp w, t) (p + dl) - delta); columns pose6 | lmk3.

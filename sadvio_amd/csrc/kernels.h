@@ -56,6 +56,7 @@ struct DevPtrs {
     int n_kept;
     double* dp_data;      // dense priors, see WinDev::dp_off
     const SparseDev* sparse;  // sparse prior factors
+    const int* sp_list;       // indices (into sparse) of the factors the solve evaluates itself, per window slice
     double* sp_scratch;       // [n_sparse][SPARSE_J]
     const int* dp_ints;
     long long n_xp, n_xv, n_xl;  // doubles in the (double-buffered) delta arrays, zeroed by k_reset
@@ -995,9 +996,10 @@ __device__ __forceinline__ int sparse_rows(const SparseDev& f) { return f.type =
 
 // Evaluate sparse factor f at the state (xp, xv, xba, xbg, xl) + optional step `y` (reduced vector, may be null).
 // J (rows x 15) may be null. Returns false if every parameter block is constant.
-__device__ __noinline__ bool sparse_eval(const DevPtrs& P, const WinDev& W, const SparseDev& f, const double* xp, const double* xv,
-                                        const double* xba, const double* xbg, const double* xl, const double* y,
-                                        double* r, double* J) {
+template <bool INL>
+__device__ __forceinline__ bool sparse_eval_t(const DevPtrs& P, const WinDev& W, const SparseDev& f, const double* xp, const double* xv,
+                                              const double* xba, const double* xbg, const double* xl, const double* y,
+                                              double* r, double* J) {
     const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
     const int lr0 = (f.lmk0 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk0] : -1;
     const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
@@ -1013,8 +1015,10 @@ __device__ __noinline__ bool sparse_eval(const DevPtrs& P, const WinDev& W, cons
             prm[9 + q] = xba[3 * k + q] + (st ? y[fi * 15 + 9 + q] : 0.0);
             prm[12 + q] = xbg[3 * k + q] + (st ? y[fi * 15 + 12 + q] : 0.0);
         }
-        imu_prior_factor(P.kf_T0 + 12 * k, P.kf_vel + 3 * k, P.kf_ba + 3 * k, P.kf_bg + 3 * k, f.T_prior, f.v_prior,
-                         f.ba_prior, f.bg_prior, f.W, prm, r, J);
+        if (INL) imu_prior_factor_body(P.kf_T0 + 12 * k, P.kf_vel + 3 * k, P.kf_ba + 3 * k, P.kf_bg + 3 * k, f.T_prior, f.v_prior,
+                                       f.ba_prior, f.bg_prior, f.W, prm, r, J);
+        else imu_prior_factor(P.kf_T0 + 12 * k, P.kf_vel + 3 * k, P.kf_ba + 3 * k, P.kf_bg + 3 * k, f.T_prior, f.v_prior,
+                              f.ba_prior, f.bg_prior, f.W, prm, r, J);
         return true;
     }
     double q0[3], q1[3] = {0.0, 0.0, 0.0};
@@ -1036,6 +1040,12 @@ __device__ __noinline__ bool sparse_eval(const DevPtrs& P, const WinDev& W, cons
             for (int j = 0; j < 3; j++) { J[i * 15 + j] = f.W[3 * i + j]; J[i * 15 + 3 + j] = -f.W[3 * i + j]; }
     }
     return true;
+}
+
+__device__ __noinline__ bool sparse_eval(const DevPtrs& P, const WinDev& W, const SparseDev& f, const double* xp, const double* xv,
+                                        const double* xba, const double* xbg, const double* xl, const double* y,
+                                        double* r, double* J) {
+    return sparse_eval_t<false>(P, W, f, xp, xv, xba, xbg, xl, y, r, J);
 }
 
 // ---- K6: reduced solve, one workgroup per window -------------------------------------------------
@@ -1194,23 +1204,21 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         const double* xba = P.xba + (long long)cur * P.xv_stride;
         const double* xbg = P.xbg + (long long)cur * P.xv_stride;
         const double* xl = P.xl + (long long)cur * P.xl_stride;
-        __syncthreads();
-        for (int k = tid; k < n_sp; k += blockDim.x) {
-            const SparseDev& f = P.sparse[W.sp_begin + k];
-            if (f.type == 4) continue;
-            double* sc = P.sp_scratch + (long long)(W.sp_begin + k) * SPARSE_J;
-            double r[15];
-            const bool in_program = sparse_eval(P, W, f, xp, xv, xba, xbg, xl, nullptr, r, sc);
-            const int rows = sparse_rows(f);
+        // r, J of the factors were written to the scratch rows by k_sparse_eval<true> (64-lane workgroup per factor)
+        for (int kl = tid; kl < W.spl_end - W.spl_begin; kl += blockDim.x) {
+            const int k = P.sp_list[W.spl_begin + kl];
+            const double* sc = P.sp_scratch + (long long)k * SPARSE_J;
+            const int rows = sparse_rows(P.sparse[k]);
             double c = 0.0;
-            for (int q = 0; q < rows; q++) { sc[225 + q] = r[q]; c += r[q] * r[q]; }
-            if (in_program) cost_part += c; else fixed_part += c;
+            for (int q = 0; q < rows; q++) c += sc[225 + q] * sc[225 + q];
+            if (sc[240] != 0.0) cost_part += c; else fixed_part += c;
         }
-        __threadfence_block();
-        __syncthreads();
-        for (int it = tid; it < n_sp * 120; it += blockDim.x) {
-            const int k = it / 120;
-            int e = it - 120 * k, a = 0;
+        // items over the factors evaluated here only: a sparsified VIO prior is one IMUPriordx + hundreds of
+        // pose-to-landmark factors that ride the Schur elimination (type 4) and would each cost dependent global loads
+        for (int it = tid; it < (W.spl_end - W.spl_begin) * 120; it += blockDim.x) {
+            const int kl = it / 120;
+            const int k = P.sp_list[W.spl_begin + kl] - W.sp_begin;
+            int e = it - 120 * kl, a = 0;
             while (e >= a + 1) { e -= a + 1; a++; }
             const int b = e;
             const SparseDev& f = P.sparse[W.sp_begin + k];
@@ -1412,8 +1420,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         const double* xbg = P.xbg + (long long)cur * P.xv_stride;
         const double* xl = P.xl + (long long)cur * P.xl_stride;
         // model cost change, item = (factor, residual row)
-        for (int it = tid; it < n_sp * 15; it += blockDim.x) {
-            const int k = it / 15, q = it - 15 * k;
+        for (int it = tid; it < (W.spl_end - W.spl_begin) * 15; it += blockDim.x) {
+            const int kl = it / 15, q = it - 15 * kl;
+            const int k = P.sp_list[W.spl_begin + kl] - W.sp_begin;
             const SparseDev& f = P.sparse[W.sp_begin + k];
             if (f.type == 4 || q >= sparse_rows(f)) continue;
             const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
@@ -1428,14 +1437,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
             mcc += -m * (sc[225 + q] + 0.5 * m);
         }
-        // candidate cost: one thread per factor at x + delta
-        for (int k = tid; k < n_sp; k += blockDim.x) {
-            double r[15];
-            const SparseDev& f = P.sparse[W.sp_begin + k];
-            if (f.type == 4 || !sparse_eval(P, W, f, xp, xv, xba, xbg, xl, y, r, nullptr)) continue;
-            const int rows = sparse_rows(f);
-            for (int q = 0; q < rows; q++) cc += r[q] * r[q];
-        }
+        // candidate cost of these factors: k_sparse_eval<false>, after this kernel, adds it to acc->cand_cost
     }
     SADVIO_TS(3, 7);
     sn = wave_sum(sn); cn = wave_sum(cn); mcc = wave_sum(mcc); cc = wave_sum(cc);
@@ -1922,6 +1924,56 @@ __global__ __launch_bounds__(64) void k_imu_eval(DevPtrs P, int slot, int own_de
             sc[IMU_H + e] = v;
             sc[IMU_IX + e] = (double)ix;
         }
+    }
+}
+
+// Sparse prior factors that the solve evaluates itself (IMUPriordx, landmark priors / chains), one 64-lane workgroup per
+// listed factor, same split as k_imu_eval: LIN -> r, J into the scratch row at x; !LIN -> cost at the candidate
+// x + delta (delta = the reduced step k_solve left in P.delta).
+template <bool LIN>
+__global__ __launch_bounds__(64) void k_sparse_eval(DevPtrs P, int slot, int own_decide) {
+    const int k = P.sp_list[blockIdx.x], ln = threadIdx.x;
+    const SparseDev& f = P.sparse[k];
+    const WinDev& W = P.win[f.win];
+    const long long so = (long long)f.win * P.state_stride + slot;
+    LmState st;
+    if (LIN && own_decide && slot > 0 && !P.decide_kernel) {
+        __shared__ double s4[4];
+        wave_sum_backsub_partials(P, (slot - 1) & 1, f.win, W.tile_begin, W.tile_end - W.tile_begin, ln, s4);
+        __syncthreads();
+        IterAcc a = P.acc[so - 1];
+        a.cand_cost += s4[0]; a.mcc += s4[1]; a.step_norm2 += s4[2]; a.cand_norm2 += s4[3];
+        st = lm_decide(P.states[so - 1], a, P.o);
+    } else st = P.states[so];
+    if (st.done) return;
+    const int cur = st.cur;
+    const double* xp = P.xp + (long long)cur * P.xp_stride;
+    const double* xv = P.xv + (long long)cur * P.xv_stride;
+    const double* xba = P.xba + (long long)cur * P.xv_stride;
+    const double* xbg = P.xbg + (long long)cur * P.xv_stride;
+    const double* xl = P.xl + (long long)cur * P.xl_stride;
+    __shared__ double Js[225];
+    __shared__ double rs[16];
+    __shared__ int s_in;
+    double* sc = P.sp_scratch + (long long)k * SPARSE_J;
+    const int rows = sparse_rows(f);
+    if (ln == 0) {
+        double r[15];
+        for (int q = 0; q < 15; q++) r[q] = 0.0;
+        const bool in_program = sparse_eval_t<true>(P, W, f, xp, xv, xba, xbg, xl, LIN ? nullptr : P.delta + W.red_off, r, LIN ? Js : nullptr);
+        s_in = in_program ? 1 : 0;
+        if (LIN) { for (int q = 0; q < 15; q++) rs[q] = r[q]; }
+        else if (in_program) {
+            double c = 0.0;
+            for (int q = 0; q < rows; q++) c += r[q] * r[q];
+            atomic_add_f64(&P.acc[so].cand_cost, c);
+        }
+    }
+    if (LIN) {
+        __syncthreads();
+        if (s_in) for (int e = ln; e < rows * 15; e += 64) sc[e] = Js[e];
+        if (ln < 15) sc[225 + ln] = rs[ln];
+        if (ln == 0) sc[240] = (double)s_in;
     }
 }
 
