@@ -1886,6 +1886,9 @@ __global__ __launch_bounds__(64) void k_imu_eval(DevPtrs P, int slot, int own_de
         }
         if (!LIN) atomic_add_f64(&P.acc[so].cand_cost, c);
     }
+    if (LIN && all_const) {   // nothing of this factor enters the reduced system (its cost is part of the fixed cost)
+        for (int e = ln; e < 324; e += 64) sc[IMU_IX + e] = -1.0;
+    }
     if (LIN && !all_const) {
         __syncthreads();
         if (ln < 24) {   // J <- W J, one column per lane (kept in LDS for the products below)

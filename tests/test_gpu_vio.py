@@ -91,3 +91,20 @@ def test_vio_constant_frames(backend_cls, oracle_lib):
     ref = oracle_lib.solve(w, opts)
     assert_match(s, d, ref)
     assert np.abs(d["dv"][w.kf_const == 1]).max() == 0 and np.abs(d["dba"][w.kf_const == 1]).max() == 0
+
+
+def test_all_constant_imu_factor_on_a_reused_handle(backend_cls, oracle_lib):
+    """An IMU factor between two constant key-frames contributes nothing to the reduced system. Its scratch row may hold
+    the entries of a factor of the PREVIOUS window on the same handle (found by scripts/gpu_fuzz.py): they must not leak."""
+    opts = capi.reference_options()
+    w1 = make_vio_window(n_kf=6, n_lmk=250, seed=21, fixed=0)
+    w2 = make_vio_window(n_kf=6, n_lmk=250, seed=22, fixed=2)
+    be = backend_cls(device=0)
+    try:
+        be.set_windows([w1]); be.solve(opts)
+        be.set_windows([w2])
+        s = be.solve(opts)[0]
+        d = be.get_deltas(0)
+    finally:
+        be.close()
+    assert_match(s, d, oracle_lib.solve(w2, opts))
