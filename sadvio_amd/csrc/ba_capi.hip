@@ -191,6 +191,7 @@ struct sadvio_ba_handle {
     DevBuf<double> d_big_M;     // inverse diagonal blocks of the wide-panel dense solver, 96 x 96 per 96 columns
     DevBuf<double> d_big_linv;  // inverse pivot blocks of the banded solver, N * NB doubles per out-of-LDS window
     DevBuf<double> d_coll_band; // band-packed copy of the reduced system for the sharded all-reduce
+    DevBuf<double> d_bcr;       // block-cyclic-reduction workspace of the long banded systems
     DevBuf<double> d_big_mid;   // the two Schur complements on the middle block of the twisted banded factorisation
     bool uploaded = false, solved = false;
     UploadBatch up;   // pending host -> device uploads of the current layout build
@@ -1808,7 +1809,45 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                             (void)hipFuncSetAttribute((const void*)kbs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                             long long* dbg = (P.debug & 4096) && s == 3 ? h->d_dbg.p + 44 : nullptr;
                             double* lv = h->d_big_linv.p + big_linv_off[w];
-                            if (N - bw >= 4 * C) {
+                            const int Kb = (N + bw - 1) / bw;
+                            if (nb == 6 && Kb >= 16 && 2 * bw <= MAX_LDS_NP - 1 && n_win == 1 && !getenv("SADVIO_NO_BCR")) {
+                                // very long band: block cyclic reduction over the bw x bw blocks, log2(K) levels (dense_chol.h)
+                                const size_t b = (size_t)bw, bb = b * b, K = (size_t)Kb;
+                                const size_t per = 8 * bb + b * (b + 1) / 2 + (b / 6) * 36 + 5 * b;
+                                if (h->d_bcr.alloc(K * per) != hipSuccess) { coll_failed = true; continue; }
+                                BcrPtrs B{};
+                                double* q = h->d_bcr.p;
+                                B.D = q; q += K * bb; B.E = q; q += K * bb; B.Wp = q; q += K * bb; B.Wn = q; q += K * bb;
+                                B.Ul = q; q += K * bb; B.Ur = q; q += K * bb;
+                                B.Lp = q; q += K * (b * (b + 1) / 2); B.linv = q; q += K * (b / 6) * 36;
+                                B.g = q; q += K * b; B.yv = q; q += K * b; B.gl = q; q += K * b; B.gr = q; q += K * b; B.X = q; q += K * b;
+                                B.K = Kb; B.b = bw; B.N = N;
+                                const int R2 = 2 * bw;
+                                const size_t lds_e = sizeof(double) * ((size_t)(R2 + 2) * 6 + (size_t)(R2 + 1) * (R2 + 2) / 2 + 2 * (size_t)R2 + (size_t)(bw / 6 + 1) * 36) + 64;
+                                const size_t lds_c = sizeof(double) * 2 * b * (b + 1);
+                                const size_t lds_r = lds_e + sizeof(double) * (size_t)(bw / 6 + 1) * 36;   // up to two blocks, all 2 b / 6 pivot blocks kept
+                                const size_t lds_b = sizeof(double) * (b * (b + 1) / 2 + 4 * b + (b / 6) * 36);
+                                (void)hipFuncSetAttribute((const void*)k_bcr_elim<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e);
+                                (void)hipFuncSetAttribute((const void*)k_bcr_combine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+                                (void)hipFuncSetAttribute((const void*)k_bcr_root<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+                                (void)hipFuncSetAttribute((const void*)k_bcr_back<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+                                hipLaunchKernelGGL(k_bcr_extract, dim3(Kb), dim3(256), 0, h->stream, Sw, (long long)d.ld, yw, B, skip, info);
+                                int smax = 0, s_root = 0;
+                                for (int sst = 1; sst < Kb; sst *= 2) {
+                                    const int na = (Kb + sst - 1) / sst;
+                                    if (na == 2) { s_root = sst; break; }   // two blocks left: solved together by k_bcr_root
+                                    hipLaunchKernelGGL(k_bcr_elim<6>, dim3(na / 2, 2), dim3(SOLVE_THREADS), lds_e, h->stream, B, sst, info, skip);
+                                    hipLaunchKernelGGL(k_bcr_combine, dim3(na), dim3(512), lds_c, h->stream, B, sst, info, skip);
+                                    smax = sst;
+                                }
+                                hipLaunchKernelGGL(k_bcr_root<6>, dim3(1), dim3(SOLVE_THREADS), lds_r, h->stream, B, s_root, info, skip);
+                                for (int sst = smax; sst >= 1; sst /= 2) {
+                                    const int na = (Kb + sst - 1) / sst;
+                                    hipLaunchKernelGGL(k_bcr_back<6>, dim3(na / 2), dim3(256), lds_b, h->stream, B, sst, info, skip);
+                                }
+                                hipLaunchKernelGGL(k_bcr_writeback, dim3((N + 255) / 256), dim3(256), 0, h->stream, B, yw, info, skip);
+                                if (dbg) fprintf(stderr, "[sadvio dbg] block cyclic reduction N %d bw %d K %d\n", N, bw, Kb);
+                            } else if (N - bw >= 4 * C) {
                                 // long band: twisted factorisation, both ends at once (dense_chol.h)
                                 const int M = (N - bw) / 2 / nb * nb;
                                 double* md = h->d_big_mid.p + big_mid_off[w];

@@ -520,6 +520,223 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_band_mid(const double* __rest
     for (int i = tid; i < bw; i += nt) y[M + i] = xs[i];
 }
 
+// ---- long bands: block cyclic reduction ------------------------------------------------------------------------------
+// With blocks of b = bw columns the banded S is block tridiagonal (K = N / b diagonal blocks D_k, couplings E_k = rows of
+// block k+1 x columns of block k). Cyclic reduction eliminates every other block of the active set at once: log2(K)
+// levels instead of N / 6 sequential pivot steps. Eliminating block i with active neighbours p < i < n:
+//     D_i = L L^T,  W_X = A_Xi L^-T (X = p, n),  y_i = L^-1 g_i
+//     D_X -= W_X W_X^T,  g_X -= W_X y_i,  new coupling A'_np = -W_n W_p^T
+// One workgroup per (i, X) runs the tuned LDS solver on the window [D_i ; A_Xi | 0 ; g_i | 0] (partial factorisation of
+// the first b columns: the panel rows ARE W_X, the trailing block IS -W_X W_X^T, the rhs row holds y_i and -W_X y_i);
+// k_bcr_combine adds the two updates an even block receives and forms the fill blocks; the last block is solved
+// directly; the backward levels compute x_i = L^-T (y_i - W_p^T x_p - W_n^T x_n). Storage per block: b x b row-major.
+struct BcrPtrs {
+    double *D, *E, *g;          // active block-tridiagonal system (E_k: rows of the NEXT ACTIVE block x columns of k)
+    double *Lp, *linv, *yv;     // per eliminated block: packed factor rows, inverse pivot blocks, y = L^-1 g
+    double *Wp, *Wn;            // per eliminated block: W_p (rows p x cols i), W_n
+    double *Ul, *Ur, *gl, *gr;  // per surviving block: update from the elimination of its right / left neighbour
+    double *X;                  // solution blocks
+    int K, b, N;
+};
+
+__global__ void k_bcr_extract(const double* __restrict__ S, long long ld, const double* __restrict__ y, BcrPtrs B, const int* skip, const int* info) {
+    if ((skip && *skip) || *info != 0) return;
+    const int k = blockIdx.x, b = B.b;
+    const int r0 = k * b;
+    double* D = B.D + (size_t)k * b * b;
+    double* E = B.E + (size_t)k * b * b;
+    for (int e = threadIdx.x; e < b * b; e += blockDim.x) {
+        const int r = e / b, c = e - r * b;
+        const int gr = r0 + r, gc = r0 + c;
+        double v;
+        if (gr < B.N && gc < B.N) v = (c <= r) ? S[(long long)gr * ld + gc] : S[(long long)gc * ld + gr];
+        else v = (r == c) ? 1.0 : 0.0;   // identity padding of the last block
+        D[e] = v;
+        const int er = r0 + b + r;       // row of block k+1; columns of block k; outside the band the matrix is zero
+        E[e] = (k + 1 < B.K && er < B.N && er - gc < b) ? S[(long long)er * ld + gc] : 0.0;
+    }
+    for (int r = threadIdx.x; r < b; r += blockDim.x) B.g[(size_t)k * b + r] = (r0 + r < B.N) ? y[r0 + r] : 0.0;
+}
+
+template <int NB>
+__global__ __launch_bounds__(SOLVE_THREADS) void k_bcr_elim(BcrPtrs B, int s, int* info, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((skip && *skip) || *info != 0) return;
+    const int tid = threadIdx.x, nt = blockDim.x, b = B.b;
+    const int i = (2 * blockIdx.x + 1) * s, X = blockIdx.y;   // X = 0: previous active block p, 1: next active block n
+    const int p = i - s, n = i + s;
+    if (i >= B.K) return;
+    if (X == 1 && n >= B.K) return;
+    const int R = 2 * b;
+    double* LpT = (double*)smem;
+    double* Pk = LpT + (size_t)(R + 2) * NBP;
+    double* xv = Pk + (size_t)(R + 1) * (R + 2) / 2;
+    double* xs = xv + R;
+    double* linvTab = xs + R;
+    const size_t bb = (size_t)b * b;
+    const double* D = B.D + (size_t)i * bb;
+    // rows 0 .. b-1: D_i (lower); rows b .. 2b-1: [A_Xi | 0]; row 2b: [g_i | 0]
+    for (int g = tid; g < tri(R + 1, 0); g += nt) {
+        int r, c;
+        tri_decode(g, r, c);
+        double v = 0.0;
+        if (r < b) v = D[(size_t)r * b + c];
+        else if (r < R) {
+            if (c < b) v = X ? B.E[(size_t)i * bb + (size_t)(r - b) * b + c]      // A_ni = E_i (rows n, cols i)
+                             : B.E[(size_t)p * bb + (size_t)c * b + (r - b)];     // A_pi = E_p^T (E_p: rows i, cols p)
+        } else if (c < b) v = B.g[(size_t)i * b + c];
+        Pk[g] = v;
+    }
+    __syncthreads();
+    const bool ok = chol_solve_packed<NB, true>(Pk, R, xv, xs, LpT, linvTab, nullptr, b / NB);
+    __syncthreads();
+    if (!ok) { if (tid == 0) *info = i * b + 1; return; }
+    double* W = (X ? B.Wn : B.Wp) + (size_t)i * bb;
+    const int e_blk = X ? n : p;
+    double* U = (X ? B.Ur : B.Ul) + (size_t)e_blk * bb;    // X = n: the update comes from n's LEFT neighbour -> Ur[n]; X = p: Ul[p]
+    double* gu = (X ? B.gr : B.gl) + (size_t)e_blk * b;
+    for (int e = tid; e < b * b; e += nt) {
+        const int r = e / b, c = e - r * b;
+        W[e] = Pk[tri(b + r, c)];
+        U[e] = (c <= r) ? Pk[tri(b + r, b + c)] : Pk[tri(b + c, b + r)];
+    }
+    for (int r = tid; r < b; r += nt) gu[r] = Pk[tri(R, b + r)];
+    if (X == 0) {   // p always exists for an eliminated block: this workgroup files the factor
+        double* Lp = B.Lp + (size_t)i * (b * (b + 1) / 2);
+        for (int g = tid; g < b * (b + 1) / 2; g += nt) Lp[g] = Pk[g];
+        for (int e = tid; e < (b / NB) * NB * NB; e += nt) B.linv[(size_t)i * (b / NB) * NB * NB + e] = linvTab[e];
+        for (int r = tid; r < b; r += nt) B.yv[(size_t)i * b + r] = Pk[tri(R, r)];
+    }
+}
+
+// Survivors of a level absorb their updates; eliminated blocks with two neighbours leave the fill block A'_np = -W_n W_p^T.
+__global__ __launch_bounds__(512) void k_bcr_combine(BcrPtrs B, int s, const int* info, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((skip && *skip) || *info != 0) return;
+    const int j = blockIdx.x, blk = j * s, b = B.b, tid = threadIdx.x, nt = blockDim.x;
+    if (blk >= B.K) return;
+    const size_t bb = (size_t)b * b;
+    if ((j & 1) == 0) {
+        double* D = B.D + (size_t)blk * bb;
+        double* g = B.g + (size_t)blk * b;
+        const bool hl = blk + s < B.K, hr = blk - s >= 0;
+        for (int e = tid; e < b * b; e += nt) {
+            double v = D[e];
+            if (hl) v += B.Ul[(size_t)blk * bb + e];
+            if (hr) v += B.Ur[(size_t)blk * bb + e];
+            D[e] = v;
+        }
+        for (int r = tid; r < b; r += nt) {
+            double v = g[r];
+            if (hl) v += B.gl[(size_t)blk * b + r];
+            if (hr) v += B.gr[(size_t)blk * b + r];
+            g[r] = v;
+        }
+        return;
+    }
+    const int p = blk - s, n = blk + s;
+    if (n >= B.K) return;
+    double* Wn = (double*)smem;          // [b][b + 1] padded rows: conflict-free column walks
+    double* Wp = Wn + (size_t)b * (b + 1);
+    for (int e = tid; e < b * b; e += nt) {
+        const int r = e / b, c = e - r * b;
+        Wn[r * (b + 1) + c] = B.Wn[(size_t)blk * bb + e];
+        Wp[r * (b + 1) + c] = B.Wp[(size_t)blk * bb + e];
+    }
+    __syncthreads();
+    double* E = B.E + (size_t)p * bb;    // new coupling of the pair (p, n): rows n, columns p
+    // E = -W_n W_p^T on the FP64 matrix cores: one 16 x 16 output tile per wave and round, K = b in steps of 4
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int ls = b + 1, nt16 = (b + 15) >> 4;
+    const int wv = tid >> 6, ln = tid & 63, lr = ln & 15, lk = ln >> 4, nw = nt >> 6;
+    for (int tile = wv; tile < nt16 * nt16; tile += nw) {
+        const int ti = tile / nt16, tj = tile - ti * nt16;
+        const int ar = 16 * ti + lr, br = 16 * tj + lr;
+        const double* pa = Wn + min(ar, b - 1) * ls;
+        const double* pb = Wp + min(br, b - 1) * ls;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < b; k0 += 4) {
+            const int k = k0 + lk;
+            const double av = pa[min(k, b - 1)], bv = pb[min(k, b - 1)];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ar < b && k < b) ? av : 0.0, (br < b && k < b) ? bv : 0.0, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int row = 16 * ti + lk + 4 * rg, col = 16 * tj + lr;
+            if (row < b && col < b) E[(size_t)row * b + col] = -acc[rg];
+        }
+    }
+}
+
+// The last one or two active blocks (0 and s2 > 0) are solved together in LDS: [D_0 ; E_0 D_s2] is a dense system of
+// at most 2 b <= 173 columns, cheaper than one more reduction level.
+template <int NB>
+__global__ __launch_bounds__(SOLVE_THREADS) void k_bcr_root(BcrPtrs B, int s2, int* info, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((skip && *skip) || *info != 0) return;
+    const int tid = threadIdx.x, nt = blockDim.x, b = B.b;
+    const int n = s2 > 0 ? 2 * b : b;
+    double* LpT = (double*)smem;
+    double* Pk = LpT + (size_t)(n + 2) * NBP;
+    double* xv = Pk + (size_t)(n + 1) * (n + 2) / 2;
+    double* xs = xv + n;
+    double* linvTab = xs + n;
+    const size_t bb = (size_t)b * b;
+    for (int g = tid; g < tri(n + 1, 0); g += nt) {
+        int r, c;
+        tri_decode(g, r, c);
+        double v = 0.0;
+        if (r < b) v = B.D[(size_t)r * b + c];
+        else if (r < n) v = c < b ? B.E[(size_t)(r - b) * b + c] : B.D[(size_t)s2 * bb + (size_t)(r - b) * b + (c - b)];
+        else if (c < n) v = c < b ? B.g[c] : B.g[(size_t)s2 * b + (c - b)];
+        Pk[g] = v;
+    }
+    __syncthreads();
+    const bool ok = chol_solve_packed<NB, false>(Pk, n, xv, xs, LpT, linvTab, nullptr);
+    __syncthreads();
+    if (!ok) { if (tid == 0) *info = 1; return; }
+    for (int r = tid; r < n; r += nt) B.X[r < b ? (size_t)r : (size_t)s2 * b + (r - b)] = xs[r];
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_bcr_back(BcrPtrs B, int s, const int* info, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((skip && *skip) || *info != 0) return;
+    const int tid = threadIdx.x, nt = blockDim.x, b = B.b;
+    const int i = (2 * blockIdx.x + 1) * s, p = i - s, n = i + s;
+    if (i >= B.K) return;
+    const size_t bb = (size_t)b * b;
+    double* Pk = (double*)smem;                       // packed factor rows of block i
+    double* x = Pk + b * (b + 1) / 2;
+    double* xs = x + b;
+    double* linvTab = xs + b;
+    double* xp = linvTab + (b / NB) * NB * NB;
+    double* xn = xp + b;
+    for (int g = tid; g < b * (b + 1) / 2; g += nt) Pk[g] = B.Lp[(size_t)i * (b * (b + 1) / 2) + g];
+    for (int e = tid; e < (b / NB) * NB * NB; e += nt) linvTab[e] = B.linv[(size_t)i * (b / NB) * NB * NB + e];
+    for (int r = tid; r < b; r += nt) { xp[r] = B.X[(size_t)p * b + r]; xn[r] = n < B.K ? B.X[(size_t)n * b + r] : 0.0; }
+    __syncthreads();
+    for (int c = tid; c < b; c += nt) {   // t = y_i - W_p^T x_p - W_n^T x_n
+        double t = B.yv[(size_t)i * b + c];
+        const double* Wp = B.Wp + (size_t)i * bb;
+        for (int r = 0; r < b; r++) t -= Wp[(size_t)r * b + c] * xp[r];
+        if (n < B.K) {
+            const double* Wn = B.Wn + (size_t)i * bb;
+            for (int r = 0; r < b; r++) t -= Wn[(size_t)r * b + c] * xn[r];
+        }
+        x[c] = t;
+    }
+    __syncthreads();
+    block_backsub<NB>(Pk, b / NB, x, xs, linvTab);
+    for (int r = tid; r < b; r += nt) B.X[(size_t)i * b + r] = xs[r];
+}
+
+__global__ void k_bcr_writeback(BcrPtrs B, double* __restrict__ y, const int* info, const int* skip) {
+    if ((skip && *skip) || *info != 0) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < B.N) y[e] = B.X[e];   // X blocks are contiguous b-vectors: block k, row r sits at k * b + r
+}
+
 // ---- dense systems: wide panels built on the in-LDS factorisation -------------------------------------------------
 // A dense reduced system (a dense prior couples the kept landmarks; N_p ~ 1 000) is factorised 96 columns at a time:
 //   k_wchol_diag   one workgroup: the 96 x 96 diagonal block (+ its rhs entries) goes through the tuned LDS solver

@@ -858,6 +858,37 @@ __device__ __forceinline__ void trail_tiles(double* P, const double* LpT, int ld
             if (okr[u][rg]) P[addr[u][rg]] = c[u][rg];
 }
 
+// xs = L^-T x for the packed factor P (off-diagonal blocks) + inverse pivot blocks linvTab; x is destroyed. One barrier
+// per block column; every thread of the workgroup must call it.
+template <int NB>
+__device__ __forceinline__ void block_backsub(const double* P, int nblk, double* x, double* xs, const double* linvTab) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int k = nblk - 1; k >= 0; k--) {
+        const int c0 = k * NB;
+        double xk[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = c; q < NB; q++) t += linvTab[k * NB * NB + q * NB + c] * x[c0 + q];
+            xk[c] = t;
+        }
+        if (tid < NB) {
+            double v = xk[0];
+#pragma unroll
+            for (int c = 1; c < NB; c++) if (tid == c) v = xk[c];
+            xs[c0 + tid] = v;
+        }
+        for (int j = tid; j < c0; j += nt) {
+            double t = x[j];
+#pragma unroll
+            for (int c = 0; c < NB; c++) t -= P[tri(c0 + c, j)] * xk[c];
+            x[j] = t;
+        }
+        __syncthreads();
+    }
+}
+
 // PARTIAL: only the first `nsteps` block columns are eliminated (the rest of the matrix is left as the updated
 // Schur complement, pivot blocks included) and no back-substitution is done: one window of the block-banded solver.
 // `band` > 0 (banded window): the rows of a pivot block's panel beyond band - NB below it are structurally zero, so the
@@ -946,30 +977,7 @@ __device__ __forceinline__ bool chol_solve_packed(double* P, int N, double* x, d
     // --- block back-substitution: xs = L^-T y, y = row N of P; one barrier per block ---
     for (int i = tid; i < N; i += nt) x[i] = P[tri(N, i)];
     __syncthreads();
-    for (int k = nblk - 1; k >= 0; k--) {
-        const int c0 = k * NB;
-        double xk[NB];
-#pragma unroll
-        for (int c = 0; c < NB; c++) {
-            double t = 0.0;
-#pragma unroll
-            for (int q = c; q < NB; q++) t += linvTab[k * NB * NB + q * NB + c] * x[c0 + q];
-            xk[c] = t;
-        }
-        if (tid < NB) {
-            double v = xk[0];
-#pragma unroll
-            for (int c = 1; c < NB; c++) if (tid == c) v = xk[c];
-            xs[c0 + tid] = v;
-        }
-        for (int j = tid; j < c0; j += nt) {
-            double t = x[j];
-#pragma unroll
-            for (int c = 0; c < NB; c++) t -= P[tri(c0 + c, j)] * xk[c];
-            x[j] = t;
-        }
-        __syncthreads();
-    }
+    block_backsub<NB>(P, nblk, x, xs, linvTab);
     return true;
 }
 

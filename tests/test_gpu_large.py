@@ -87,3 +87,29 @@ def test_vio_window_out_of_lds(backend_cls, oracle_lib, band):
     assert np.abs(d["pose"] - ref["pose"]).max() <= POSE_TOL and np.abs(d["lmk"] - ref["lmk"]).max() <= LMK_TOL
     for q in ("dv", "dba", "dbg"):
         assert np.abs(d[q] - ref[q]).max() <= POSE_TOL
+
+
+def test_very_long_band_block_cyclic_reduction(backend_cls, oracle_lib, monkeypatch):
+    """200 key-frames (N_p = 1194, bw = 66 -> 19 diagonal blocks): the reduced system goes through the block cyclic
+    reduction (dense_chol.h); same answer as the twisted band solver and as the oracle's dense Cholesky."""
+    w = synthetic.make_window(n_kf=200, n_lmk=12000, length=100.0, band=6, seed=44)
+    opts = capi.gn_options(3)
+
+    def run():
+        be = backend_cls(device=0)
+        try:
+            be.set_windows([w])
+            s = be.solve(opts)[0]
+            return s, be.get_deltas(0)
+        finally:
+            be.close()
+
+    s_bcr, d_bcr = run()
+    monkeypatch.setenv("SADVIO_NO_BCR", "1")
+    s_tw, d_tw = run()
+    monkeypatch.delenv("SADVIO_NO_BCR")
+    ref = oracle_lib.solve(w, opts, n_threads=2)
+    for s, d in ((s_bcr, d_bcr), (s_tw, d_tw)):
+        assert np.isclose(s.final_cost, ref["summary"].final_cost, rtol=1e-8)
+        assert np.abs(d["pose"] - ref["pose"]).max() <= 1e-6 and np.abs(d["lmk"] - ref["lmk"]).max() <= 1e-5
+    assert np.abs(d_bcr["pose"] - d_tw["pose"]).max() <= 1e-8
