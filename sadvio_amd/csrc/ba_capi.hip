@@ -1724,6 +1724,12 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         for (int w = 0; w < n_win; w++)
             if (h->wins[w].d.ld) { const long long b = std::min(big_bw[w], MAX_LDS_NP); big_mid_off[w] = totm; totm += 2 * (b * (b + 1) / 2 + b); }
         HIP_TRY(h->d_big_mid.alloc((size_t)std::max<long long>(totm, 1)));
+        // workspace of the block cyclic reduction (one banded window with >= 22 diagonal blocks): allocated here, never
+        // inside the (possibly captured) launch sequence
+        if (n_win == 1 && h->wins[0].d.ld && h->wins[0].d.dpf == 6) {
+            const size_t b = (size_t)big_bw[0], K = ((size_t)h->wins[0].d.Np + b - 1) / std::max<size_t>(b, 1);
+            if (b > 0 && K >= 22 && 2 * b <= (size_t)MAX_LDS_NP - 1) HIP_TRY(h->d_bcr.alloc(K * (8 * b * b + b * (b + 1) / 2 + (b / 6) * 36 + 5 * b)));
+        }
         long long totM = 0;
         for (int w = 0; w < n_win; w++) if (h->wins[w].d.ld) { big_M_off[w] = totM; totM += (long long)((h->wins[w].d.Np + WD - 1) / WD) * WD * WD; }
         HIP_TRY(h->d_big_M.alloc((size_t)std::max<long long>(totM, 1)));
@@ -1810,11 +1816,10 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                             long long* dbg = (P.debug & 4096) && s == 3 ? h->d_dbg.p + 44 : nullptr;
                             double* lv = h->d_big_linv.p + big_linv_off[w];
                             const int Kb = (N + bw - 1) / bw;
-                            if (nb == 6 && Kb >= 16 && 2 * bw <= MAX_LDS_NP - 1 && n_win == 1 && !getenv("SADVIO_NO_BCR")) {
+                            if (nb == 6 && Kb >= 22 && 2 * bw <= MAX_LDS_NP - 1 && n_win == 1 && !getenv("SADVIO_NO_BCR")) {   // below ~22 blocks the twisted solver wins (measured)
                                 // very long band: block cyclic reduction over the bw x bw blocks, log2(K) levels (dense_chol.h)
                                 const size_t b = (size_t)bw, bb = b * b, K = (size_t)Kb;
                                 const size_t per = 8 * bb + b * (b + 1) / 2 + (b / 6) * 36 + 5 * b;
-                                if (h->d_bcr.alloc(K * per) != hipSuccess) { coll_failed = true; continue; }
                                 BcrPtrs B{};
                                 double* q = h->d_bcr.p;
                                 B.D = q; q += K * bb; B.E = q; q += K * bb; B.Wp = q; q += K * bb; B.Wn = q; q += K * bb;

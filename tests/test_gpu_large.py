@@ -90,9 +90,9 @@ def test_vio_window_out_of_lds(backend_cls, oracle_lib, band):
 
 
 def test_very_long_band_block_cyclic_reduction(backend_cls, oracle_lib, monkeypatch):
-    """200 key-frames (N_p = 1194, bw = 66 -> 19 diagonal blocks): the reduced system goes through the block cyclic
+    """270 key-frames (N_p = 1614, bw = 66 -> 25 diagonal blocks): the reduced system goes through the block cyclic
     reduction (dense_chol.h); same answer as the twisted band solver and as the oracle's dense Cholesky."""
-    w = synthetic.make_window(n_kf=200, n_lmk=12000, length=100.0, band=6, seed=44)
+    w = synthetic.make_window(n_kf=270, n_lmk=14000, length=135.0, band=6, seed=44)
     opts = capi.gn_options(3)
 
     def run():
