@@ -1687,7 +1687,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     bool extras = false;  // any pose-only factor family beyond PosePriordx in the batch?
     for (int w = 0; w < n_win; w++) {
         const WinDev& d = h->wins[w].d;
-        if (d.imu_end > d.imu_begin || d.sp_end > d.sp_begin || d.dp_n_full > 0) extras = true;
+        if (d.imu_end > d.imu_begin || d.sp_end > d.sp_begin || d.dp_n_full > 0 || d.dpf == 15) extras = true;   // dpf 15: padded pivots live in the EXTRAS kernel
     }
     auto ks0 = extras ? k_solve<0, true> : k_solve<0, false>;
     auto ks1 = extras ? k_solve<1, true> : k_solve<1, false>;
@@ -1970,8 +1970,6 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         if (hipMemcpy(ts, h->d_dbg.p, sizeof(ts), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[sadvio dbg] phase dt (us):");
             for (int i = 1; i < 16; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[0]) * 0.01);
-            fprintf(stderr, "  pose-only phases (priors | imu cost | JtJ | bias | sparse,dense | totals):");
-            for (int i = 22; i < 27; i++) fprintf(stderr, " %.2f", (ts[i] - ts[0]) * 0.01);
             fprintf(stderr, "  shader clock %.3f GHz\n[sadvio dbg] k_build:", (double)(ts[21] - ts[20]) / ((ts[15] - ts[0]) * 10.0));
             for (int i = 33; i < 43; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[32]) * 0.01);
             fprintf(stderr, "\n[sadvio dbg] k_chol_panel / k_band_solve (fwd window 2: carry fresh chol store | fwd end | bwd window 2: load below steps | bwd end):");
