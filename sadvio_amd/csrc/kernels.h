@@ -68,7 +68,15 @@ struct DevPtrs {
     SolveOpts o;
 };
 
+// In-kernel phase timestamps (SADVIO_DEBUG & 4096) exist only in a build with -DSADVIO_KERNEL_TS: even as not-taken
+// branches they cost the latency-bound kernels ~1-2 us per launch (measured A/B on k_solve).
+#ifdef SADVIO_KERNEL_TS
 #define SADVIO_TS(slot_, idx_) do { if ((P.debug & 4096) && blockIdx.x == 0 && threadIdx.x == 0 && slot == (slot_)) P.dbg_ts[idx_] = wall_clock64(); } while (0)
+#define SADVIO_TS_PTR(cond_) ((cond_) ? P.dbg_ts : nullptr)
+#else
+#define SADVIO_TS(slot_, idx_) do { } while (0)
+#define SADVIO_TS_PTR(cond_) nullptr
+#endif
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
 // element (i >= j) of a window's reduced matrix in HBM: packed lower triangle (ld == 0) or full row-major
@@ -1099,7 +1107,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     __shared__ LmState st;
     __shared__ double s_red[SOLVE_THREADS / 64 * 4];
     SADVIO_TS(3, 0);
+#ifdef SADVIO_KERNEL_TS
     if ((P.debug & 4096) && blockIdx.x == 0 && tid == 0 && slot == 3) P.dbg_ts[20] = clock64();
+#endif
     if (tid == 0) st = *stp;
     __syncthreads();
     if (MODE == 1 && tid == 0) P.big_info[w] = 0;
@@ -1332,7 +1342,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     SADVIO_TS(3, 3);
     if (MODE == 1) return;  // the host enqueues potrf / potrs on S, gred next
     }  // MODE != 2
-    long long* ts = ((P.debug & 4096) && blockIdx.x == 0 && slot == 3) ? P.dbg_ts : nullptr;
+    long long* ts = SADVIO_TS_PTR((P.debug & 4096) && blockIdx.x == 0 && slot == 3);
     if (MODE == 0) {
         bool ok = true;  // Np == 0 (every key-frame constant, landmarkOptimization): nothing to factor
         if (Np == 0) {}
