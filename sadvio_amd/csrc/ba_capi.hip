@@ -1132,11 +1132,19 @@ int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int l
     const long long nn = (long long)n * n;
     hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, A, lda, n, G, V, lower_only);
     const int npad = n + (n & 1);
+    // noise floor of the column norms (see k_jacobi_floor); flag[2..3] = max norm bits, flag[4..5] = the floor
+    unsigned long long* amax = (unsigned long long*)(flag + 2);
+    double* floor2 = (double*)(flag + 4);
+    if (hipMemsetAsync(flag, 0, 8 * sizeof(int), h->stream) != hipSuccess) return -1;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_jacobi_floor, dim3(n), dim3(JAC_THREADS), 0, h->stream, G, n, amax, floor2, 0);
+        hipLaunchKernelGGL(k_jacobi_floor, dim3(1), dim3(JAC_THREADS), 0, h->stream, G, n, amax, floor2, 1);
+    }
     int sweeps = 0;
     for (; sweeps < 40 && npad >= 2; sweeps++) {
         if (hipMemsetAsync(flag, 0, sizeof(int), h->stream) != hipSuccess) return -1;
         for (int s = 0; s < npad - 1; s++)
-            hipLaunchKernelGGL(k_jacobi_step, dim3(npad / 2), dim3(JAC_THREADS), 0, h->stream, G, V, n, npad, s, 1e-14, flag);
+            hipLaunchKernelGGL(k_jacobi_step, dim3(npad / 2), dim3(JAC_THREADS), 0, h->stream, G, V, n, npad, s, 1e-14, flag, floor2);
         int f = 0;
         if (hipMemcpyAsync(&f, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
         if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
@@ -1214,7 +1222,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     DevBuf<double> dA, db, G, V, ev, Vs, Ainv, T, Ak, bk, dJ, dr0, dlastJ, dlastr;
     DevBuf<int> ditems, dflag, dsel, dlastcol;
     DevBuf<MargSmall> dsmall;
-    HIP_TRY(dA.alloc((size_t)N * N)); HIP_TRY(db.alloc(N)); HIP_TRY(dflag.alloc(1));
+    HIP_TRY(dA.alloc((size_t)N * N)); HIP_TRY(db.alloc(N)); HIP_TRY(dflag.alloc(8));
     HIP_TRY(hipMemsetAsync(dA.p, 0, sizeof(double) * (size_t)N * N, h->stream));
     HIP_TRY(hipMemsetAsync(db.p, 0, sizeof(double) * N, h->stream));
     // reprojection factors of kept then marginalised landmarks seen from frame0

@@ -37,8 +37,25 @@ __device__ __forceinline__ void rr_pair(int npad, int s, int k, int& p, int& q) 
     if (p > q) { const int t = p; p = q; q = t; }
 }
 
+// floor2 (device scalar, written by k_jacobi_floor): squared column norm below which a column belongs to the numerical null
+// space, (n eps)^2 max_p |g_p|^2. A pair of two such columns is noise against noise: the relative test can never settle
+// and only keeps the sweeps going, while both eigenvalues sit at or below the cut of the pseudo-inverse / rank-revealing
+// decomposition (marg_cut) and are dropped either way — such pairs are skipped.
+__global__ __launch_bounds__(JAC_THREADS) void k_jacobi_floor(const double* __restrict__ G, int n, unsigned long long* amax_bits, double* floor2, int finish) {
+    __shared__ double sh[4];
+    if (finish) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) { const double e = (double)n * 2.220446049250313e-16; *floor2 = e * e * __longlong_as_double((long long)*amax_bits); }
+        return;
+    }
+    const double* g = G + (size_t)blockIdx.x * n;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += JAC_THREADS) a += g[i] * g[i];
+    a = block_sum_256(a, sh);
+    if (threadIdx.x == 0) atomicMax(amax_bits, (unsigned long long)__double_as_longlong(a));   // non-negative doubles order like u64
+}
+
 __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_step(double* __restrict__ G, double* __restrict__ V, int n, int npad,
-                                                             int s, double tol, int* rotated) {
+                                                             int s, double tol, int* rotated, const double* floor2) {
     int p, q;
     rr_pair(npad, s, blockIdx.x, p, q);
     if (q >= n) return;  // dummy player of an odd n
@@ -49,6 +66,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_step(double* __restrict_
     for (int i = threadIdx.x; i < n; i += JAC_THREADS) { const double x = gp[i], y = gq[i]; a += x * x; b += y * y; c += x * y; }
     a = block_sum_256(a, sh); b = block_sum_256(b, sh); c = block_sum_256(c, sh);
     if (a == 0.0 || b == 0.0 || c * c <= tol * tol * a * b) return;
+    if (a < *floor2 && b < *floor2) return;
     if (threadIdx.x == 0) *rotated = 1;
     const double zeta = (b - a) / (2.0 * c);
     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
