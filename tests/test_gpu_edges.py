@@ -120,3 +120,29 @@ def test_one_camera_entry_per_keyframe_like_the_reference(backend_cls, oracle_li
     ro, Jpo, Jlo, _ = oracle_lib.linearize(w)
     assert np.abs(r - ro).max() <= 1e-10 * max(1.0, np.abs(ro).max())
     be.close()
+
+
+@pytest.mark.parametrize("what", ["nan_measurement", "inf_landmark"])
+def test_non_finite_input_fails_cleanly(backend_cls, oracle_lib, what):
+    """A NaN measurement / an infinite landmark: every step is invalid, the solve ends as Ceres' FAILURE after
+    max_num_consecutive_invalid_steps (SADVIO_E_NOT_USABLE, AOptimizer.cpp:259 semantics), deltas stay zero, nothing hangs,
+    and the handle solves a clean window right afterwards."""
+    w = synthetic.make_window(n_kf=4, n_lmk=100, seed=3)
+    if what == "nan_measurement":
+        w.obs_meas = w.obs_meas.copy(); w.obs_meas[17, 0] = np.nan
+    else:
+        w.lmk_p = w.lmk_p.copy(); w.lmk_p[5] = np.inf
+    ref = oracle_lib.solve(w, capi.reference_options())
+    be = backend_cls(device=0)
+    try:
+        be.set_windows([w])
+        s = be.solve(capi.reference_options())[0]
+        d = be.get_deltas(0)
+        assert (s.termination, s.iterations) == (ref["summary"].termination, ref["summary"].iterations) == (5, 5)
+        assert np.abs(d["pose"]).max() == 0.0 and np.abs(d["lmk"]).max() == 0.0
+        good = synthetic.make_window(n_kf=4, n_lmk=100, seed=3)
+        be.set_windows([good])
+        s2 = be.solve(capi.reference_options())[0]
+        assert s2.termination != 5 and np.isfinite(s2.final_cost) and s2.final_cost < s2.initial_cost
+    finally:
+        be.close()
