@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "sadvio_ba.h"
+#include "sadvio_cameras.hpp"
 #include "sadvio_io.hpp"
 
 namespace sadvio {
@@ -53,10 +54,23 @@ inline void apply_pose_delta(Pose& T, const double* d6) {
     std::memcpy(T.R, R, sizeof(R)); std::memcpy(T.t, t, sizeof(t));
 }
 
-struct CameraModel {          // one ImageSensor of a key-frame: pinhole K + frame -> sensor transform
+struct CameraModel {          // one ImageSensor of a key-frame: K + frame -> sensor transform (+ the model's parameters)
     double fx, fy, cx, cy;
     Pose T_s_f;
     double width = 0, height = 0;   // image size used by ALandmark::sanityCheck (Camera.cpp:45); 0 = (2 cx, 2 cy)
+    // non-pinhole models (sadvio_cameras.hpp) only work with the ANGULAR backend, as in the reference: the bearing comes
+    // from the model's getRayCamera, the factor itself is model-free
+    CameraKind kind = CameraKind::Pinhole;
+    double rmax = 1, xi = 0, alpha = 0;
+    bool distortion = false;
+    double D[4] = {0, 0, 0, 0};
+    CameraIntrinsics intrinsics() const {
+        CameraIntrinsics k;
+        k.kind = kind; k.fx = fx; k.fy = fy; k.cx = cx; k.cy = cy; k.rmax = rmax; k.xi = xi; k.alpha = alpha; k.distortion = distortion;
+        for (int i = 0; i < 4; i++) k.D[i] = D[i];
+        k.width = width > 0 ? width : 2.0 * cx; k.height = height > 0 ? height : 2.0 * cy;
+        return k;
+    }
 };
 
 struct FrameState {           // what the optimizer reads / writes of an isae::Frame (+ its IMU)
@@ -262,6 +276,10 @@ class HipOptimizer {
         std::vector<int32_t> lcol(std::max<size_t>(keep.size(), 1));
         std::vector<double> J((size_t)std::max(n * n, 1)), r0((size_t)std::max(n, 1));
         sadvio_marg_result res{};
+        if (F.non_pinhole_pixel) {   // the reference's own pixel factor has no Jacobian for these models (fisheye.cpp:352-405)
+            _err = "pixel factor with a non-pinhole camera: use the angular backend (HipOptimizer(device, true))";
+            return false;
+        }
         int rc = upload(F);
         if (rc == SADVIO_OK) rc = sadvio_ba_marginalize(_h, 0, &rq, &res, lcol.data(), J.data(), r0.data());
         _prior = Prior(); _sparse.clear(); _sparse_lmk_id.clear();
@@ -301,6 +319,7 @@ class HipOptimizer {
         std::vector<int> cam_base, lmk_src;
         std::vector<double> cam_wh;       // image size per flat camera (sanityCheck)
         int n_non_kf_obs = 0;             // features skipped because their frame is not a key-frame
+        bool any_non_pinhole = false, non_pinhole_pixel = false;
         std::vector<int32_t> ptr, obs_kf, obs_cam;
         std::vector<sadvio_pose_prior> priors;
         std::vector<sadvio_imu_factor> imus;
@@ -350,11 +369,15 @@ class HipOptimizer {
                 if (kf_only && !map.frames[ft.frame].is_keyframe) { F.n_non_kf_obs++; continue; }   // :131, :256
                 const CameraModel& c = map.frames[ft.frame].cameras[ft.camera];
                 F.obs_kf.push_back(ft.frame); F.obs_cam.push_back(F.cam_base[ft.frame] + ft.camera);
-                if (_angular) {                                                          // Camera.cpp:15-25: K^-1 [u v 1] normalised
-                    const double b[3] = {(ft.u - c.cx) / c.fx, (ft.v - c.cy) / c.fy, 1.0};
-                    const double nn = std::sqrt(b[0] * b[0] + b[1] * b[1] + 1.0);
-                    F.meas.insert(F.meas.end(), {b[0] / nn, b[1] / nn, b[2] / nn});
-                } else F.meas.insert(F.meas.end(), {ft.u, ft.v});
+                if (_angular) {                                                          // getRayCamera of the feature's camera model
+                    double b[3] = {0.0, 0.0, 1.0};
+                    ray_camera(c.intrinsics(), ft.u, ft.v, b);
+                    F.meas.insert(F.meas.end(), {b[0], b[1], b[2]});
+                } else {
+                    if (c.kind != CameraKind::Pinhole) F.non_pinhole_pixel = true;           // no analytic pixel factor exists for it
+                    F.meas.insert(F.meas.end(), {ft.u, ft.v});
+                }
+                if (c.kind != CameraKind::Pinhole) F.any_non_pinhole = true;
             }
             F.ptr.push_back((int32_t)F.obs_kf.size());
         }
@@ -412,6 +435,28 @@ class HipOptimizer {
                                          (int)idx.size(), idx.data(), col.data());
     }
 
+    // ALandmark::sanityCheck on the host for maps with non-pinhole cameras: every feature of the landmark (key-frame or
+    // not) is projected with its own camera model (sadvio_cameras.hpp) at the landmark's CURRENT position
+    void host_chi2_gate(const LocalMapSnapshot& map, const Flat& F, std::vector<int32_t>& inlier) const {
+        for (size_t k = 0; k < F.lmk_src.size(); k++) {
+            const LandmarkState& L = map.landmarks[F.lmk_src[k]];
+            double sum = 0.0;
+            int n = 0;
+            for (const Feature& ft : L.features) {
+                if (ft.frame < 0 || ft.frame >= (int)map.frames.size()) continue;
+                const FrameState& fr = map.frames[ft.frame];
+                const CameraModel& c = fr.cameras[ft.camera];
+                double pf[3], pc[3], u, v;
+                for (int a = 0; a < 3; a++) pf[a] = fr.T_f_w.R[3 * a] * L.p[0] + fr.T_f_w.R[3 * a + 1] * L.p[1] + fr.T_f_w.R[3 * a + 2] * L.p[2] + fr.T_f_w.t[a];
+                for (int a = 0; a < 3; a++) pc[a] = c.T_s_f.R[3 * a] * pf[0] + c.T_s_f.R[3 * a + 1] * pf[1] + c.T_s_f.R[3 * a + 2] * pf[2] + c.T_s_f.t[a];
+                const bool ok = project_camera(c.intrinsics(), pc, u, v);
+                sum += ok ? (u - ft.u) * (u - ft.u) + (v - ft.v) * (v - ft.v) : 1000.0;   // feature sigma = 1 px (AFeature2D.h:18)
+                n++;
+            }
+            inlier[k] = (n >= 2 && !(sum / n > 2.0)) ? 1 : 0;
+        }
+    }
+
     bool solve(LocalMapSnapshot& map, size_t fixed, bool vio, const sadvio_solve_options& opt, bool all_const, bool lmk_const,
                bool chi2_gate = false) {
         const int nkf = (int)map.frames.size();
@@ -422,6 +467,10 @@ class HipOptimizer {
             std::snprintf(name, sizeof(name), "/window_%06d.sadvio", _dump_count++);
             const std::string e = write_window(_dump_dir + name, F.w, (int)F.priors.size(), F.priors.data(), (int)F.imus.size(), F.imus.data());
             if (!e.empty()) _err = e;
+        }
+        if (F.non_pinhole_pixel) {   // the reference's own pixel factor has no Jacobian for these models (fisheye.cpp:352-405)
+            _err = "pixel factor with a non-pinhole camera: use the angular backend (HipOptimizer(device, true))";
+            return false;
         }
         int rc = upload(F);
         if (rc == SADVIO_OK && !all_const && !lmk_const) rc = add_marginalization_prior(F);   // window solves only
@@ -446,7 +495,8 @@ class HipOptimizer {
                 if (sadvio_ba_set_windows(_h, 1, &Fall.w) != SADVIO_OK) { _err = sadvio_ba_last_error(_h); return false; }
                 G = &Fall;
             }
-            if (sadvio_ba_landmark_chi2(_h, 0, nullptr, nullptr, G->cam_wh.data(), 1.0, nullptr, inlier.data()) != SADVIO_OK) {
+            if (F.any_non_pinhole) host_chi2_gate(map, F, inlier);   // the device gate projects with K only
+            else if (sadvio_ba_landmark_chi2(_h, 0, nullptr, nullptr, G->cam_wh.data(), 1.0, nullptr, inlier.data()) != SADVIO_OK) {
                 _err = sadvio_ba_last_error(_h); return false;
             }
         }

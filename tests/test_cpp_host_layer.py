@@ -32,3 +32,13 @@ def test_cpp_host_layer_recovers_perturbed_maps():
     r = subprocess.run([build()], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PASSED" in r.stdout
+
+
+def test_camera_models_round_trip(tmp_path):
+    """include/sadvio_cameras.hpp (getRayCamera / project of Camera, Fisheye x3, Omni, DoubleSphere): pure host code."""
+    exe = str(tmp_path / "test_cameras")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "test_cameras.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "PASSED" in r.stdout, r.stdout + r.stderr
