@@ -3,7 +3,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sadvio_amd import capi, synthetic
 nw = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-ws = [synthetic.make_window(seed=20250404 + i) for i in range(min(nw, 4))]
+factor = capi.FACTOR_ANGULAR if os.environ.get("SADVIO_ANGULAR") else capi.FACTOR_PIXEL   # the reference's shipped config uses the angular backend
+ws = [synthetic.make_window(seed=20250404 + i, factor=factor) for i in range(min(nw, 4))]
 ws = [ws[i % len(ws)] for i in range(nw)]
 opts = capi.gn_options(10); opts.max_num_consecutive_invalid_steps = 1000
 be = capi.Backend(device=0, profile_kernels=True)
