@@ -58,7 +58,8 @@ def main():
     import torch
 
     import __graft_entry__ as ge
-    ge.build_hip()
+    if local_rank == 0:
+        ge.build_hip()   # no-op when the in-tree .so is newer than its sources; never from several ranks at once
     from sadvio_amd import capi, synthetic
 
     if not torch.cuda.is_available():
@@ -69,6 +70,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()   # rank 0 of the node has finished (or skipped) the build
 
     def barrier():
         if dist is not None:
