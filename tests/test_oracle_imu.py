@@ -220,3 +220,47 @@ def test_predictionWithRotation2(oracle_lib):  # :654-703
     pos = Tinv[:3, :3] @ frame_to_world(cur)[:3, 3] + Tinv[:3, 3]
     assert np.linalg.norm(pos - np.array([-0.82143062, 0.80412303, 0.15357111])) < 1e-2
     assert np.linalg.norm(Tinv[:3, :3] @ arr(cur.v) - np.array([-1.97810799, 2.38035184, 0.5780088])) < 1e-2
+
+
+def test_accelerating_covariance_matches_monte_carlo(oracle_lib):  # :195-327
+    """3 s of constant acceleration at 100 Hz: the propagated 9x9 covariance of the pre-integration agrees with the sample
+    covariance of 100 noisy integrations (the reference's assertion: |trace(Sigma_MC - cov)| < 1e-3; its random_device
+    seed is replaced by a fixed one)."""
+    a, v = 0.2, 50.0
+    T_w_f = np.eye(4); T_w_f[:3, 3] = [10, 20, 0]
+    acc, gyr = np.array([a, 0.0, 9.81]), np.zeros(3)
+    dt = 0.01
+    cfg = dict(CFG); cfg["rate_hz"] = 100
+
+    def integrate(noise_rng=None):
+        def meas():
+            if noise_rng is None:
+                return acc, gyr
+            return (acc + noise_rng.normal(0, cfg["acc_noise"] / np.sqrt(dt), 3),
+                    gyr + noise_rng.normal(0, cfg["gyr_noise"] / np.sqrt(dt), 3))
+        a0, g0 = meas()
+        ch = Chain(a0, g0, 1e9, T_f_w=T_to_12(inv4(T_w_f)), v=(v, 0, 0), cfg=cfg)
+        cur = None
+        for i in range(1, 301):
+            ai, gi = meas()
+            cur = ch.step(ai, gi, 1e9 + (dt * i) * 1e9)
+        return cur
+
+    pred = integrate()
+    cov = arr(pred.cov).reshape(9, 9)
+    pr = oracle_lib.so3_log(arr(pred.delta_R).reshape(3, 3))
+    pv, pp = arr(pred.delta_v), arr(pred.delta_p)
+    rng = np.random.default_rng(20250404)
+    N = 100
+    Sigma = np.zeros((9, 9))
+    for _ in range(N):
+        s = integrate(rng)
+        xi = np.concatenate([oracle_lib.so3_log(arr(s.delta_R).reshape(3, 3)) - pr, arr(s.delta_v) - pv, arr(s.delta_p) - pp])
+        Sigma += np.outer(xi, xi)
+    Sigma /= N - 1
+    assert abs((Sigma - cov).trace()) < 1e-3
+    # beyond the reference's criterion: the rotation and velocity blocks agree entry by entry within sampling error (chi2 with
+    # 99 dof: +-35 % is 2.5 sigma). The POSITION block as the reference propagates it (IMU.cpp:56-74, pinned by the GTSAM
+    # literal of checkCov above) is 6 - 15 times the sample covariance; the loose trace criterion hides it. Restated as is.
+    ratio = np.diag(Sigma) / np.diag(cov)
+    assert np.all(np.abs(ratio[:6] - 1.0) < 0.45) and np.all(ratio[6:] < 0.5)
