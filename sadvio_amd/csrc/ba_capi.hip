@@ -1937,7 +1937,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 ScopedTimer t(h, "allreduce_step_partials");
                 if (h->coll_fn(h->coll_ctx, h->d_rank_s.p, (int64_t)n_win * h->world * 4, (void*)h->stream) != 0) coll_failed = true;
             }
-            if (P.decide_kernel) { ScopedTimer t(h, "k_decide"); hipLaunchKernelGGL(k_decide, dim3(n_win), dim3(64), 0, h->stream, P, s, 0); }
+            if (P.decide_kernel) { ScopedTimer t(h, "k_decide"); hipLaunchKernelGGL(k_decide, dim3(n_win), dim3(n_tiles / n_win >= 1024 ? 1024 : 64), 0, h->stream, P, s, 0); }
         }
         { ScopedTimer t(h, "k_final"); hipLaunchKernelGGL(k_decide, dim3(n_win), dim3(64), 0, h->stream, P, slots - 1, 1); }
     };

@@ -1854,7 +1854,21 @@ __global__ void k_decide(DevPtrs P, int slot, int final) {
     LmState f;
     const bool already = final && P.decide_kernel;  // the per-slot launch of the last slot did it
     if (!already) {
-        wave_sum_backsub_partials(P, slot & 1, w, W.tile_begin, W.tile_end - W.tile_begin, ln, s4);
+        if (blockDim.x == 64) wave_sum_backsub_partials(P, slot & 1, w, W.tile_begin, W.tile_end - W.tile_begin, ln, s4);
+        else {
+            // thousands of tiles (configs 4 / 5, large batches): every wave of the workgroup sums a slice of the partials
+            __shared__ double sw[16 * 4];
+            const int wv = ln >> 6, nw = blockDim.x >> 6, nt_w = W.tile_end - W.tile_begin;
+            const int per = (nt_w + nw - 1) / nw, t0 = min(wv * per, nt_w), t1 = min(t0 + per, nt_w);
+            if (P.world > 1) { if (wv == 0) wave_sum_backsub_partials(P, slot & 1, w, W.tile_begin, nt_w, ln & 63, sw); }
+            else wave_sum_backsub_partials(P, slot & 1, w, W.tile_begin + t0, t1 - t0, ln & 63, sw + 4 * wv);
+            __syncthreads();
+            if (ln < 4) {
+                double v = 0.0;
+                for (int q = 0; q < (P.world > 1 ? 1 : nw); q++) v += sw[4 * q + ln];
+                s4[ln] = v;
+            }
+        }
         __syncthreads();
     }
     if (ln == 0) {
