@@ -235,7 +235,10 @@ def bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_sol
             "config": {"workload": "synthetic 100 KF x 50000 landmarks x 250000 reprojection factors, GN 10 iters, "
                                    "landmark-sharded, RCCL all-reduce of the reduced system per LM step",
                        "parallelism": f"window sharded x{world}", "reduced_dim": n_p,
-                       "allreduce_bytes_per_step": 8 * (n_p * n_p + 3 * n_p + 4 * world) + 32 * world},
+                       # only the band of the reduced system travels (k_band_pack): N_p x bw with bw = 60 for this
+                       # window's 10-key-frame co-visibility, + gradient / diagonal vectors + the per-rank partials
+                       "allreduce_bytes_per_step": 8 * (n_p * 60 + 3 * n_p + 4 * world) + 32 * world,
+                       "allreduce_bytes_per_step_full_matrix": 8 * (n_p * n_p + 3 * n_p + 4 * world) + 32 * world},
             "final_cost": s.final_cost}))
     if dist is not None:
         dist.barrier()
