@@ -200,6 +200,8 @@ void sadvio_ba_destroy(sadvio_ba_handle *h);
  * concurrently; n_windows = 1 is the reference's case). Replaces addResidualsLocalMap
  * (…Analytic.cpp:197-314). Clears any factors set by earlier set_* calls. */
 int sadvio_ba_set_windows(sadvio_ba_handle *h, int32_t n_windows, const sadvio_flat_window *windows);
+/* The single-window call the adapter of one optimizer instance uses: set_windows(h, 1, window). */
+int sadvio_ba_set_window(sadvio_ba_handle *h, const sadvio_flat_window *window);
 
 /* PosePriordx blocks of window `w` (…Analytic.cpp:224-228). */
 int sadvio_ba_set_pose_priors(sadvio_ba_handle *h, int32_t w, int32_t n, const sadvio_pose_prior *priors);

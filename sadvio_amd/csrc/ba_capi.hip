@@ -2140,6 +2140,8 @@ int sadvio_ba_vi_init(sadvio_ba_handle* h, const sadvio_viinit_problem* pb, cons
     return S.termination == SADVIO_TERM_FAILURE ? SADVIO_E_NOT_USABLE : SADVIO_OK;
 }
 
+int sadvio_ba_set_window(sadvio_ba_handle* h, const sadvio_flat_window* window) { return sadvio_ba_set_windows(h, 1, window); }
+
 int sadvio_ba_landmark_chi2(sadvio_ba_handle* h, int32_t w, const double* pose_delta6, const double* lmk_delta3, const double* image_wh,
                             double pixel_sigma, double* avg_chi2, int32_t* inlier) {
     if (!h) return SADVIO_E_INVALID_ARG;
