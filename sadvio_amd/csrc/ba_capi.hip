@@ -1916,7 +1916,11 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 { ScopedTimer t(h, "k_solve_back"); hipLaunchKernelGGL(ks2, dim3(n_win), dim3(SOLVE_THREADS), 64, h->stream, P, s); }
                 for (int w = 0; w < n_win; w++) {
                     const WinDev& d = h->wins[w].d;
-                    if (d.ld) (void)hipMemsetAsync(h->d_S.p + d.S_off, 0, sizeof(double) * (size_t)d.Np * d.Np, h->stream);
+                    if (!d.ld) continue;
+                    if (big_bw[w] < d.Np && big_bw[w] + (d.dpf == 6 ? 6 : 5) <= MAX_LDS_NP)   // banded: only the band was written
+                        hipLaunchKernelGGL(k_band_zero, dim3((unsigned)std::min<long long>(((long long)d.Np * big_bw[w] + 255) / 256, 4096)), dim3(256), 0, h->stream,
+                                           h->d_S.p + d.S_off, (long long)d.ld, d.Np, big_bw[w]);
+                    else (void)hipMemsetAsync(h->d_S.p + d.S_off, 0, sizeof(double) * (size_t)d.Np * d.Np, h->stream);
                 }
             }
             if (fork) {
