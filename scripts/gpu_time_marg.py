@@ -10,7 +10,7 @@ from marg_helpers import with_lonely_landmarks
 from test_oracle_marg import pre_marginalize
 w = with_lonely_landmarks(make_vio_window(n_kf=12, n_lmk=7200, seed=6), 11, 40)
 keep, marg = pre_marginalize(w, 11)
-keep = keep[:300]
+keep = keep[:int(sys.argv[1]) if len(sys.argv) > 1 else 300]
 imu = [f for f in w.imu_factors if f["kf_i"] == 11 and f["kf_j"] == 10][0]
 rng = np.random.default_rng(1)
 last = {"J": 20.0 * (np.eye(15) + 0.1 * rng.standard_normal((15, 15))), "r0": 0.1 * rng.standard_normal(15), "kf_keep": 11, "kf_col": 0,
