@@ -54,6 +54,24 @@ inline void apply_pose_delta(Pose& T, const double* d6) {
     std::memcpy(T.R, R, sizeof(R)); std::memcpy(T.t, t, sizeof(t));
 }
 
+// IMU::biasDeltaCorrection (IMU.cpp:104-108): first-order update of a pre-integration for a bias change of its older frame
+inline void bias_delta_correction(sadvio_imu_factor& f, const double* d_ba, const double* d_bg) {
+    double w[3], E[9], R[9];
+    for (int i = 0; i < 3; i++) {
+        double dp = 0, dv = 0; w[i] = 0;
+        for (int j = 0; j < 3; j++) {
+            dp += f.J_dp_ba[3 * i + j] * d_ba[j] + f.J_dp_bg[3 * i + j] * d_bg[j];
+            dv += f.J_dv_ba[3 * i + j] * d_ba[j] + f.J_dv_bg[3 * i + j] * d_bg[j];
+            w[i] += f.J_dR_bg[3 * i + j] * d_bg[j];
+        }
+        f.delta_p[i] += dp; f.delta_v[i] += dv;
+    }
+    exp_so3(w, E);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) R[3 * i + j] = f.delta_R[3 * i] * E[j] + f.delta_R[3 * i + 1] * E[3 + j] + f.delta_R[3 * i + 2] * E[6 + j];
+    std::memcpy(f.delta_R, R, sizeof(R));
+}
+
 struct CameraModel {          // one ImageSensor of a key-frame: K + frame -> sensor transform (+ the model's parameters)
     double fx, fy, cx, cy;
     Pose T_s_f;
@@ -173,7 +191,7 @@ class HipOptimizer {
         std::vector<sadvio_imu_factor> fs;
         for (const ImuPair& p : map.imu_pairs) {                                          // :485-500
             if (p.frame_i == p.frame_j || p.frame_i < 0 || p.frame_j < 0 || p.frame_i >= n || p.frame_j >= n) continue;
-            if (!map.frames[p.frame_i].has_imu || !map.frames[p.frame_j].has_imu) continue;
+            if (!map.frames[p.frame_i].has_imu || !map.frames[p.frame_j].has_imu || !map.frames[p.frame_i].has_imu) continue;
             sadvio_imu_factor f = p.f; f.kf_i = p.frame_i; f.kf_j = p.frame_j;
             fs.push_back(f);
         }
@@ -256,13 +274,17 @@ class HipOptimizer {
         rq.n_marg = (int)marg.size(); rq.lmk_marg = marg.data();
         rq.n_keep = (int)keep.size(); rq.lmk_keep = keep.data();
         sadvio_imu_factor imu{};
-        for (const ImuPair& p : map.imu_pairs)
-            if (p.frame_i == frame0 && p.frame_j == frame1) { imu = p.f; rq.imu = &imu; }
+        if (map.frames[frame0].has_imu && map.frames[frame1].has_imu)                  // …Analytic.cpp:449
+            for (const ImuPair& p : map.imu_pairs)
+                if (p.frame_i == frame0 && p.frame_j == frame1) { imu = p.f; rq.imu = &imu; }
         std::vector<sadvio_pose_prior> pri;
-        for (const sadvio_pose_prior& p : F.priors) if (p.kf == frame0 || p.kf == frame1) pri.push_back(p);   // …Analytic.cpp:605-617
+        // frame0's PosePriordx (…Analytic.cpp:605-617); the angular backend also folds in frame1's (Angular….cpp:682)
+        for (const sadvio_pose_prior& p : F.priors) if (p.kf == frame0 || (_angular && p.kf == frame1)) pri.push_back(p);
         rq.n_prior = (int)pri.size(); rq.priors = pri.data();
         std::vector<int32_t> last_idx, last_col;
-        if (_prior.valid && _prior.kf_id == map.frames[frame0].id) {                    // the previous prior sits on frame0 (:574-603)
+        // the previous prior is folded in whenever it kept landmarks (:573); its kept frame — VIO only — is frame0 now.
+        // A VO prior (kf_col < 0) has no frame to match
+        if (_prior.valid && !_prior.lmk_id.empty() && (_prior.kf_col < 0 || _prior.kf_id == map.frames[frame0].id)) {
             rq.last_n_full = _prior.n_full; rq.last_n = _prior.n; rq.last_J = _prior.J.data(); rq.last_r0 = _prior.r0.data();
             rq.last_kf = _prior.kf_col >= 0 ? frame0 : -1; rq.last_kf_col = std::max(_prior.kf_col, 0);
             for (size_t q = 0; q < _prior.lmk_id.size(); q++) {
@@ -303,6 +325,10 @@ class HipOptimizer {
     }
     bool has_prior() const { return _prior.valid; }
     int prior_rows() const { return _prior.n_full; }
+    int prior_cols() const { return _prior.n; }
+    const std::vector<double>& prior_J() const { return _prior.J; }               // n_full x n row-major
+    const std::vector<int64_t>& prior_landmark_ids() const { return _prior.lmk_id; }
+    const std::vector<int32_t>& prior_landmark_cols() const { return _prior.lmk_col; }
     size_t sparse_factor_count() const { return _sparse.size(); }
 
     const sadvio_solve_summary& summary() const { return _sum; }
@@ -397,9 +423,11 @@ class HipOptimizer {
         w.obs_kf = F.obs_kf.data(); w.obs_cam = F.obs_cam.data(); w.obs_meas = F.meas.data();
     }
 
-    int upload(const Flat& F) {
+    // with_pose_priors: PosePriordx blocks are only added by addResidualsLocalMap (…Analytic.cpp:224-228) and marginalize
+    // (:605-617); addSingleFrameResiduals / addLandmarkResiduals (:5-50, 102-150) add none
+    int upload(const Flat& F, bool with_pose_priors = true) {
         int rc = sadvio_ba_set_windows(_h, 1, &F.w);
-        if (rc == SADVIO_OK) rc = sadvio_ba_set_pose_priors(_h, 0, (int)F.priors.size(), F.priors.data());
+        if (rc == SADVIO_OK && with_pose_priors) rc = sadvio_ba_set_pose_priors(_h, 0, (int)F.priors.size(), F.priors.data());
         if (rc == SADVIO_OK && !F.imus.empty()) rc = sadvio_ba_set_imu_factors(_h, 0, (int)F.imus.size(), F.imus.data());
         return rc;
     }
@@ -465,15 +493,16 @@ class HipOptimizer {
         if (!_dump_dir.empty()) {   // replayable record of exactly what the backend is given (scripts/replay.py)
             char name[64];
             std::snprintf(name, sizeof(name), "/window_%06d.sadvio", _dump_count++);
-            const std::string e = write_window(_dump_dir + name, F.w, (int)F.priors.size(), F.priors.data(), (int)F.imus.size(), F.imus.data());
+            const std::string e = write_window(_dump_dir + name, F.w, (!all_const && !lmk_const) ? (int)F.priors.size() : 0, F.priors.data(), (int)F.imus.size(), F.imus.data());
             if (!e.empty()) _err = e;
         }
         if (F.non_pinhole_pixel) {   // the reference's own pixel factor has no Jacobian for these models (fisheye.cpp:352-405)
             _err = "pixel factor with a non-pinhole camera: use the angular backend (HipOptimizer(device, true))";
             return false;
         }
-        int rc = upload(F);
-        if (rc == SADVIO_OK && !all_const && !lmk_const) rc = add_marginalization_prior(F);   // window solves only
+        const bool window_solve = !all_const && !lmk_const;
+        int rc = upload(F, window_solve);
+        if (rc == SADVIO_OK && window_solve) rc = add_marginalization_prior(F);
         if (rc == SADVIO_OK) rc = sadvio_ba_solve(_h, &opt, &_sum);
         if (rc != SADVIO_OK && rc != SADVIO_E_NOT_USABLE) { _err = sadvio_ba_last_error(_h); return false; }   // state untouched
         if (rc == SADVIO_E_NOT_USABLE) return false;
@@ -486,6 +515,13 @@ class HipOptimizer {
                     map.frames[i].v[a] += dv[3 * (size_t)i + a]; map.frames[i].ba[a] += dba[3 * (size_t)i + a]; map.frames[i].bg[a] += dbg[3 * (size_t)i + a];
                 }
         }
+        // IMU::biasDeltaCorrection (IMU.cpp:104-108) of every pre-integration whose older frame got a bias update
+        // (AOptimizer.cpp:421-434): localMapVIOptimization only — singleFrameVIOptimization does not do it (:262-296)
+        if (vio && window_solve)
+            for (ImuPair& p : map.imu_pairs) {
+                if (p.frame_i < 0 || p.frame_i >= nkf || p.frame_j < 0 || p.frame_j >= nkf || !map.frames[p.frame_j].has_imu || !map.frames[p.frame_i].has_imu) continue;
+                bias_delta_correction(p.f, &dba[3 * (size_t)p.frame_i], &dbg[3 * (size_t)p.frame_i]);
+            }
         std::vector<int32_t> inlier(F.lmk_src.size(), 1);
         if (chi2_gate && !F.lmk_src.empty()) {                                           // ALandmark.cpp:130-146
             const Flat* G = &F;

@@ -1275,6 +1275,8 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     if (rq->last_n_full > 0) {
         const int nl = rq->last_n, nf = rq->last_n_full;
         if (!rq->last_J || !rq->last_r0 || nl <= 0) { h->err = "marginalize: previous prior arrays missing"; return SADVIO_E_INVALID_ARG; }
+        if (rq->last_n_keep > 0 && (!rq->last_lmk_index || !rq->last_lmk_col)) { h->err = "marginalize: previous prior landmark lists missing"; return SADVIO_E_INVALID_ARG; }
+        if (rq->last_kf >= 0 && rq->last_kf_col < 0) { h->err = "marginalize: last_kf_col < 0"; return SADVIO_E_INVALID_ARG; }
         std::vector<int> col(nl, -1);
         if (rq->last_kf >= 0) {
             const int base = (rq->last_kf == rq->kf_marg) ? 0 : ((rq->last_kf == rq->kf_keep) ? kf_keep_col : -1);
@@ -1283,6 +1285,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         }
         for (int k = 0; k < rq->last_n_keep; k++) {
             if (rq->last_lmk_col[k] < 0) continue;
+            if (rq->last_lmk_col[k] + 3 > nl) { h->err = "marginalize: last_lmk_col exceeds the previous prior's columns"; return SADVIO_E_INVALID_ARG; }
             const int li = rq->last_lmk_index[k];
             if (li < 0 || li >= d.n_lmk) continue;
             const int lc = lcol[li];

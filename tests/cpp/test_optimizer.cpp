@@ -126,6 +126,115 @@ int main(int argc, char** argv) {
         for (size_t l = 0; l < m.landmarks.size(); l++) for (int a = 0; a < 3; a++) wl = std::fmax(wl, std::fabs(m.landmarks[l].p[a] - truth.landmarks[l].p[a]));
         check(wl == 0.0, "singleFrameOptimization: landmarks untouched");
     }
+    // --- singleFrameOptimization ignores Frame::hasPrior: addSingleFrameResiduals adds no PosePriordx (…Analytic.cpp:5-50),
+    //     although slamMono.cpp:18 puts a prior on every frame ---
+    {
+        LocalMapSnapshot truth = make_map(rng, 1, 300), m = truth;
+        double d[6] = {0.02, -0.01, 0.015, 0.05, -0.04, 0.03};
+        apply_pose_delta(m.frames[0].T_f_w, d);
+        m.frames[0].has_prior = true; m.frames[0].T_prior = m.frames[0].T_f_w;   // a strong prior at the WRONG pose
+        for (double& x : m.frames[0].inf_prior) x = 1e4;
+        opt.singleFrameOptimization(m); opt.singleFrameOptimization(m);
+        check(pose_err(m.frames[0].T_f_w, truth.frames[0].T_f_w) < 1e-5, "singleFrameOptimization: pose prior of the frame is not part of the problem");
+    }
+    // --- two marginalisations in a row in VO mode: the second prior folds the first one in (…Analytic.cpp:573-603; the
+    //     previous prior has no kept frame in VO) ---
+    {
+        LocalMapSnapshot base = make_map(rng, 6, 300);
+        auto drop_last = [](LocalMapSnapshot& s) {
+            const int gone = (int)s.frames.size() - 1;
+            s.frames.pop_back();
+            for (auto& L : s.landmarks) {
+                std::vector<Feature> kept;
+                for (const Feature& ft : L.features) if (ft.frame != gone) kept.push_back(ft);
+                L.features = kept;
+            }
+        };
+        auto info_of = [](const HipOptimizer& o, int64_t id) {   // trace of the 3x3 information block J^T J of a kept landmark
+            const auto& ids = o.prior_landmark_ids(); const auto& cols = o.prior_landmark_cols(); const auto& J = o.prior_J();
+            const int n = o.prior_cols(), nf = o.prior_rows();
+            for (size_t q = 0; q < ids.size(); q++)
+                if (ids[q] == id && cols[q] >= 0) {
+                    double tr = 0;
+                    for (int r = 0; r < nf; r++) for (int a = 0; a < 3; a++) tr += J[(size_t)r * n + cols[q] + a] * J[(size_t)r * n + cols[q] + a];
+                    return tr;
+                }
+            return -1.0;
+        };
+        LocalMapSnapshot chained = base;
+        HipOptimizer oc(0), of(0);
+        const bool ok1 = oc.marginalize(chained, 5, 4, false);
+        const size_t kept1 = oc.prior_landmark_ids().size();
+        const std::vector<int64_t> ids1 = oc.prior_landmark_ids();
+        drop_last(chained);
+        LocalMapSnapshot fresh = chained;
+        for (auto& L : fresh.landmarks) L.has_prior = false;      // what a run that lost the first prior would see
+        const bool ok2 = oc.marginalize(chained, 4, 3, false);
+        const bool ok3 = of.marginalize(fresh, 4, 3, false);
+        check(ok1 && ok2 && ok3 && kept1 > 10, "VO: two marginalisations in a row succeed");
+        int n_more = 0, n_cmp = 0;
+        for (int64_t id : ids1) {
+            const double a = info_of(oc, id), b = info_of(of, id);
+            if (a < 0 || b < 0) continue;
+            n_cmp++; if (a > b * (1.0 + 1e-9)) n_more++;
+        }
+        std::printf("   landmarks kept by both priors %d, with more information in the chained prior %d (chained kept %zu, fresh kept %zu)\n",
+                    n_cmp, n_more, oc.prior_landmark_ids().size(), of.prior_landmark_ids().size());
+        check(n_cmp > 5 && n_more == n_cmp, "VO: the second prior carries the first one's information on the landmarks they share");
+        check(oc.prior_landmark_ids().size() >= of.prior_landmark_ids().size(), "VO: landmarks of the first prior are resurrected into the second");
+    }
+    // --- localMapVIOptimization applies IMU::biasDeltaCorrection to the pre-integrations (AOptimizer.cpp:421-434,
+    //     IMU.cpp:104-108); singleFrameVIOptimization does not ---
+    {
+        const int n = 4;
+        const double dt = 0.2, gw[3] = {0, 0, -9.81};
+        LocalMapSnapshot m = make_map(rng, n, 250);
+        std::vector<std::array<double, 3>> P(n), V(n);
+        for (int i = 0; i < n; i++) {    // T_f_w = (I, -c): position c
+            P[i] = {-m.frames[i].T_f_w.t[0], -m.frames[i].T_f_w.t[1], -m.frames[i].T_f_w.t[2]};
+            V[i] = {0.3 / dt, 0, 0};
+            m.frames[i].has_imu = true;
+            for (int a = 0; a < 3; a++) { m.frames[i].v[a] = V[i][a]; m.frames[i].ba[a] = 0.02 * G(rng); m.frames[i].bg[a] = 0.002 * G(rng); }
+        }
+        for (int i = n - 1; i > 0; i--) {   // older (i) -> newer (i - 1)
+            ImuPair pr{};
+            pr.frame_i = i; pr.frame_j = i - 1;
+            sadvio_imu_factor& f = pr.f;
+            f.dt = dt;
+            const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            std::memcpy(f.delta_R, I3, sizeof(I3));
+            for (int a = 0; a < 3; a++) {
+                f.delta_v[a] = V[i - 1][a] - V[i][a] - gw[a] * dt + 0.01 * G(rng);      // a little inconsistent: the biases have to move
+                f.delta_p[a] = P[i - 1][a] - P[i][a] - V[i][a] * dt - 0.5 * gw[a] * dt * dt + 0.002 * G(rng);
+                f.J_dv_ba[4 * a] = -dt; f.J_dp_ba[4 * a] = -0.5 * dt * dt; f.J_dR_bg[4 * a] = -dt;
+                f.J_dv_bg[3 * a + (a + 1) % 3] = 0.3 * dt; f.J_dp_bg[3 * a + (a + 2) % 3] = 0.1 * dt * dt;
+            }
+            for (int q = 0; q < 9; q++) f.cov[10 * q] = q < 3 ? 1e-6 : (q < 6 ? 1e-4 : 1e-5);
+            f.bacc_noise = 3e-3; f.bgyr_noise = 2e-5;
+            m.imu_pairs.push_back(pr);
+        }
+        const LocalMapSnapshot before = m;
+        check(opt.localMapVIOptimization(m, 1), "localMapVIOptimization returns true");
+        double worst = 0, moved = 0;
+        for (size_t k = 0; k < m.imu_pairs.size(); k++) {
+            const ImuPair& a = before.imu_pairs[k];
+            const ImuPair& b = m.imu_pairs[k];
+            double dba[3], dbg[3];
+            for (int q = 0; q < 3; q++) { dba[q] = m.frames[a.frame_i].ba[q] - before.frames[a.frame_i].ba[q]; dbg[q] = m.frames[a.frame_i].bg[q] - before.frames[a.frame_i].bg[q]; moved = std::fmax(moved, std::fabs(dba[q]) + std::fabs(dbg[q])); }
+            sadvio_imu_factor want = a.f;
+            bias_delta_correction(want, dba, dbg);
+            for (int q = 0; q < 3; q++) worst = std::fmax(worst, std::fmax(std::fabs(want.delta_p[q] - b.f.delta_p[q]), std::fabs(want.delta_v[q] - b.f.delta_v[q])));
+            for (int q = 0; q < 9; q++) worst = std::fmax(worst, std::fabs(want.delta_R[q] - b.f.delta_R[q]));
+        }
+        std::printf("   bias change %.3e, pre-integration mismatch after correction %.3e (it %d)\n", moved, worst, opt.summary().iterations);
+        check(moved > 1e-6 && worst < 1e-12, "localMapVIOptimization: pre-integrations corrected for the solved bias deltas");
+        LocalMapSnapshot s = before;
+        const std::vector<ImuPair> pairs0 = s.imu_pairs;
+        opt.singleFrameVIOptimization(s);
+        bool same = true;
+        for (size_t k = 0; k < pairs0.size(); k++) same &= std::memcmp(&pairs0[k].f, &s.imu_pairs[k].f, sizeof(sadvio_imu_factor)) == 0;
+        check(same, "singleFrameVIOptimization leaves the pre-integrations alone");
+    }
     // --- marginalize: the oldest frame goes into a prior that then holds the gauge of the remaining window ---
     // The dense prior is r0 + J dx with dx = the deltas of the NEXT solve: it says "stay where marginalize() found you"
     // (plus r0, whose sign follows the reference as coded: b = +sum J^T r, r0 = -Lambda^-1/2 U^T bk, SURVEY.md quirk B.7,

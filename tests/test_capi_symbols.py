@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "sadvio_ba.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(sadvio_ba_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(sadvio_ba_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_declares_the_boundary():

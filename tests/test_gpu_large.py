@@ -1,6 +1,6 @@
 """GPU parity for windows whose reduced system does not fit LDS (N_p > 174): S is built into a full
-row-major matrix in HBM, factorised in place (rocSOLVER potrf / potrs), with the same device-side
-LM control as the small path. BASELINE.json configs 4 (100 KF x 50 k landmarks) and a scaled config 5."""
+row-major matrix in HBM, factorised in place by the library's own kernels (band / cyclic-reduction / panel Cholesky,
+dense_chol.h), with the same device-side LM control as the small path. BASELINE.json configs 4 (100 KF x 50 k landmarks) and a scaled config 5."""
 import numpy as np
 import pytest
 
