@@ -11,9 +11,14 @@ import subprocess
 
 import numpy as np
 
-from sadvio_amd import capi
-from sadvio_amd.capi import (FlatWindow, FlatWindowC, ImuFactorC, PosePriorC, SolveOptions, SolveSummary, SparsePriorC,
-                             fill_imu_factor, reference_options)
+from . import structs as S
+from .structs import reference_options
+
+# the oracle's own mirrors of the C header (oracle/structs.py) — nothing is imported from the product package
+FlatWindowC, ImuFactorC, PosePriorC, SparsePriorC = S.flat_window, S.imu_factor, S.pose_prior, S.sparse_prior
+SolveOptions, SolveSummary = S.solve_options, S.solve_summary
+fill_imu_factor = S.fill_imu
+FlatWindow = object   # any object with the header's field names as attributes (duck-typed)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(_HERE, "_build", "libsadvio_oracle.so")
@@ -68,8 +73,8 @@ def lib():
         _lib.oracle_solve.argtypes = [C.POINTER(OracleProblem), C.POINTER(SolveOptions), C.POINTER(SolveSummary),
                                       _dp, _dp, _dp, _dp, _dp, _dp, C.c_int32]
         _lib.oracle_linearize.argtypes = [C.POINTER(FlatWindowC), _dp, _dp, _dp, _dp, _dp, _ip]
-        _lib.oracle_viinit.argtypes = [C.POINTER(capi.ViInitProblemC), C.POINTER(SolveOptions), C.POINTER(SolveSummary),
-                                       C.POINTER(capi.ViInitResultC), _dp]
+        _lib.oracle_viinit.argtypes = [C.POINTER(S.viinit_problem), C.POINTER(SolveOptions), C.POINTER(SolveSummary),
+                                       C.POINTER(S.viinit_result), _dp]
         _lib.oracle_factor_imu_init.argtypes = [C.POINTER(ImuFactorC)] + [_dp] * 7
         _lib.oracle_landmark_chi2.argtypes = [C.POINTER(FlatWindowC), _dp, _dp, _dp, C.c_double, _dp, _ip]
         _lib.oracle_first_step.argtypes = [C.POINTER(OracleProblem), C.POINTER(SolveOptions), _dp, _dp, _dp, _dp,
@@ -96,17 +101,17 @@ def _arr(x, n=None):
 
 
 def make_problem(w: FlatWindow, dense_prior=None, n_threads=1):
-    wc = w.to_c()
-    pa, npri = w.priors_c()
-    ia, nimu = w.imus_c()
+    wc, wkeep = S.window_to_c(w)
+    pa, npri = S.priors_to_c(getattr(w, "pose_priors", []))
+    ia, nimu = S.imus_to_c(getattr(w, "imu_factors", []))
     P = OracleProblem()
     P.win = C.pointer(wc)
     P.n_prior, P.priors = npri, pa
     P.n_imu, P.imus = nimu, ia
     P.n_threads = n_threads
-    sa, nsp = w.sparse_c()
+    sa, nsp = S.sparse_to_c(getattr(w, "sparse_priors", []))
     P.n_sparse, P.sparse = nsp, sa
-    keep = [wc, pa, ia, sa]
+    keep = [wc, wkeep, pa, ia, sa]
     if dense_prior is not None:
         J = np.ascontiguousarray(dense_prior["J"], dtype=np.float64)
         r0 = np.ascontiguousarray(dense_prior["r0"], dtype=np.float64)
@@ -122,7 +127,7 @@ def make_problem(w: FlatWindow, dense_prior=None, n_threads=1):
 
 
 def solve(w: FlatWindow, opts: SolveOptions = None, dense_prior=None, n_threads=1, log_cap=64):
-    opts = opts or reference_options()
+    opts = S.options_from(opts)
     P, keep = make_problem(w, dense_prior, n_threads)
     pose = np.zeros((w.n_kf, 6)); lmk = np.zeros((w.n_lmk, 3))
     dv = np.zeros((w.n_kf, 3)); dba = np.zeros((w.n_kf, 3)); dbg = np.zeros((w.n_kf, 3))
@@ -135,7 +140,7 @@ def solve(w: FlatWindow, opts: SolveOptions = None, dense_prior=None, n_threads=
 
 
 def linearize(w: FlatWindow, pose_delta=None, lmk_delta=None):
-    wc = w.to_c()
+    wc, wkeep = S.window_to_c(w)
     r = np.zeros((w.n_obs, 2)); Jp = np.zeros((w.n_obs, 2, 6)); Jl = np.zeros((w.n_obs, 2, 3))
     valid = np.zeros(w.n_obs, dtype=np.int32)
     pd = None if pose_delta is None else _arr(pose_delta, 6 * w.n_kf)
@@ -146,7 +151,7 @@ def linearize(w: FlatWindow, pose_delta=None, lmk_delta=None):
 
 def landmark_chi2(w: FlatWindow, pose_delta=None, lmk_delta=None, image_wh=None, pixel_sigma=0.0):
     """(avg_chi2[n_lmk], inlier[n_lmk]) — ALandmark::sanityCheck at the given deltas."""
-    wc = w.to_c()
+    wc, wkeep = S.window_to_c(w)
     avg = np.zeros(w.n_lmk); inl = np.zeros(w.n_lmk, dtype=np.int32)
     pd = None if pose_delta is None else _arr(pose_delta, 6 * w.n_kf)
     ld = None if lmk_delta is None else _arr(lmk_delta, 3 * w.n_lmk)
@@ -158,7 +163,7 @@ def landmark_chi2(w: FlatWindow, pose_delta=None, lmk_delta=None, image_wh=None,
 
 def first_step(w: FlatWindow, opts: SolveOptions = None):
     """(delta_pose, delta_lmk, H_full, g_full) of the first LM step at zero deltas."""
-    opts = opts or reference_options()
+    opts = S.options_from(opts)
     P, keep = make_problem(w)
     dp = np.zeros((w.n_kf, 6)); dl = np.zeros((w.n_lmk, 3))
     N = lib().oracle_first_step(C.byref(P), C.byref(opts), _dp(), _dp(), _p(np.zeros(1)), _p(np.zeros(1)), -1)
@@ -170,8 +175,8 @@ def first_step(w: FlatWindow, opts: SolveOptions = None):
 
 def sparse_factor(w: FlatWindow, k: int, xp=None, xv=None, xba=None, xbg=None, xl=None):
     """(r[rows], J[rows,15]) of sparse prior factor k of the window at the given deltas."""
-    wc = w.to_c()
-    sa, _ = w.sparse_c()
+    wc, wkeep = S.window_to_c(w)
+    sa, _ = S.sparse_to_c(w.sparse_priors)
     r = np.zeros(15); J = np.zeros((15, 15))
     arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (xp, xv, xba, xbg, xl)]
     f = lib().oracle_sparse_factor
@@ -182,14 +187,14 @@ def sparse_factor(w: FlatWindow, k: int, xp=None, xv=None, xba=None, xbg=None, x
 
 def marginalize(w: FlatWindow, kf_marg, lmk_marg, lmk_keep, kf_keep=-1, marg_has_imu=False, imu=None, priors=(), last=None):
     """oracle_marginalize with the same calling convention as capi.Backend.marginalize. Returns None when refused."""
-    wc = w.to_c()
+    wc, wkeep = S.window_to_c(w)
     rq = MargRequest()
     rq.win = C.pointer(wc)
     mk = np.ascontiguousarray(lmk_marg, dtype=np.int32); kp = np.ascontiguousarray(lmk_keep, dtype=np.int32)
     rq.kf_marg, rq.kf_keep, rq.marg_has_imu = kf_marg, kf_keep, int(bool(marg_has_imu))
     rq.n_marg, rq.lmk_marg = len(mk), mk.ctypes.data_as(_ip)
     rq.n_keep, rq.lmk_keep = len(kp), kp.ctypes.data_as(_ip)
-    keep = [wc, mk, kp]
+    keep = [wc, wkeep, mk, kp]
     if imu is not None:
         ia = (ImuFactorC * 1)()
         fill_imu_factor(ia[0], imu)
@@ -222,8 +227,7 @@ def marginalize(w: FlatWindow, kf_marg, lmk_marg, lmk_keep, kf_keep=-1, marg_has
 
 def sparsify(w: FlatWindow, prior: dict, vio: bool):
     """oracle_sparsify: dense prior dict -> list of sparse prior dicts (None when refused)."""
-    from sadvio_amd.capi import sparse_prior_to_dict
-    wc = w.to_c()
+    wc, wkeep = S.window_to_c(w)
     J = np.ascontiguousarray(prior["J"], dtype=np.float64)
     li = np.ascontiguousarray(prior.get("lmk_index", []), dtype=np.int32); lc = np.ascontiguousarray(prior.get("lmk_col", []), dtype=np.int32)
     out = (SparsePriorC * (len(li) + 1))()
@@ -234,7 +238,15 @@ def sparsify(w: FlatWindow, prior: dict, vio: bool):
            li.ctypes.data_as(_ip), lc.ctypes.data_as(_ip), C.byref(n_out), out)
     if rc != 0:
         return None
-    return [sparse_prior_to_dict(out[i]) for i in range(n_out.value)]
+    return [_sparse_to_dict(out[i]) for i in range(n_out.value)]
+
+
+def _sparse_to_dict(s):
+    n = 15 if s.type == 0 else 3
+    return {"type": int(s.type), "kf": int(s.kf), "lmk0": int(s.lmk0), "lmk1": int(s.lmk1),
+            "T_prior": np.array(s.T_prior[:]), "v_prior": np.array(s.v_prior[:]), "ba_prior": np.array(s.ba_prior[:]),
+            "bg_prior": np.array(s.bg_prior[:]), "delta": np.array(s.delta[:]),
+            "sqrt_inf": np.array(s.sqrt_inf[: n * n]).reshape(n, n)}
 
 
 # ---- factor probes ----
@@ -287,10 +299,18 @@ def factor_imu_init(fdict, Ti, Tj, vi, vj, params15):
 
 def viinit(T_f_w, vel, factors, opts=None, **kw):
     """AOptimizer::VIInit (AOptimizer.cpp:448-581) restated; arguments as capi.make_viinit_problem."""
-    P, keep = capi.make_viinit_problem(T_f_w, vel, factors, **kw)
-    s = SolveSummary(); r = capi.ViInitResultC(); dv = np.zeros((P.n_frames, 3))
-    rc = lib().oracle_viinit(C.byref(P), C.byref(opts or capi.viinit_options()), C.byref(s), C.byref(r), _p(dv))
-    return capi.viinit_result_to_dict(rc, s, r, dv)
+    T = np.ascontiguousarray(T_f_w, dtype=np.float64).reshape(-1, 12)
+    v = np.ascontiguousarray(vel, dtype=np.float64).reshape(-1, 3)
+    arr, nf = S.imus_to_c(factors)
+    P = S.viinit_problem(T.shape[0], nf, T.ctypes.data_as(_dp), v.ctypes.data_as(_dp), arr, int(kw.get("optim_scale", False)),
+                         int(kw.get("optim_bias", False)), float(kw.get("sigma_dba", 1.0)), float(kw.get("sigma_dbg", 1.0)))
+    o = S.options_from(opts)
+    if opts is None:
+        o.max_num_iterations = 50   # AOptimizer.cpp:518-528
+    s = SolveSummary(); r = S.viinit_result(); dv = np.zeros((P.n_frames, 3))
+    rc = lib().oracle_viinit(C.byref(P), C.byref(o), C.byref(s), C.byref(r), _p(dv))
+    return {"rc": rc, "summary": s, "r_wi": np.array(r.r_wi[:]), "lambda": float(r.lambda_), "dba": np.array(r.dba[:]),
+            "dbg": np.array(r.dbg[:]), "R_w_i": np.array(r.R_w_i[:]).reshape(3, 3), "scale": float(r.scale), "dv": dv}
 
 
 def factor_imu_bias(fdict, bai, bgi, baj, bgj, params12):

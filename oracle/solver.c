@@ -229,10 +229,10 @@ static double eval_cost(ctx_t *c, const state_t *x) {
             if (P->dp_lmk_col[q] < 0) continue;
             for (int a = 0; a < 3; a++) dx[P->dp_lmk_col[q] + a] = x->xl[3 * P->dp_lmk_index[q] + a];
         }
-        for (int i = 0; i < nf; i++) {
+        for (int i = 0; i < nf; i++) {   /* cost only: c->dp_res (the residual at the linearisation point, used by
+                                            model_cost_change of the following attempts) must survive a rejected candidate */
             double s = P->dp_r0[i];
             for (int j = 0; j < n; j++) s += P->dp_J[(size_t)i * n + j] * dx[j];
-            c->dp_res[i] = s;
             cost += s * s;
         }
         free(dx);

@@ -1,0 +1,576 @@
+"""oracle/twin.py — an INDEPENDENT second restatement of the visual-BA arithmetic (TEST INFRASTRUCTURE ONLY).
+
+Written from the reference's source lines and from Ceres Solver 2.2.0's published trust-region algorithm, WITHOUT going
+through oracle/*.c: plain NumPy, generic in the scalar type — float64, numpy.longdouble (x87 80-bit) or mpmath `mpf`
+(50+ digits, arrays of dtype=object). It pins the C oracle (and through it the HIP path) on the headline `localMapBA`
+path, for which the reference holds no golden vector:
+
+  * factor arithmetic:   ReprojectionErrCeres_pointxd_dx::Evaluate  cpp/include/isaeslam/optimizers/BundleAdjustmentCERESAnalytic.h:52-90
+                         Camera::project                            cpp/src/data/sensors/Camera.cpp:84-139
+                         AngularErrCeres_pointxd_dx::Evaluate       cpp/include/isaeslam/optimizers/AngularAdjustmentCERESAnalytic.h:55-111
+                         PosePriordx::Evaluate                      cpp/include/isaeslam/optimizers/residuals.hpp:607-628
+                         SO(3) helpers                              cpp/include/utilities/geometry.h:17-37,131-166
+  * the problem of addResidualsLocalMap (BundleAdjustmentCERESAnalytic.cpp:197-314) on a flat window;
+  * Ceres 2.2.0 TrustRegionMinimizer + LevenbergMarquardtStrategy (trust_region_minimizer.cc, levenberg_marquardt_strategy.cc,
+    corrector.cc, as published; solver options AOptimizer.cpp:315-323) on the UN-REDUCED normal equations
+    (J^T J + D^2) y = J^T r — the reference's SPARSE_NORMAL_CHOLESKY solve — by a dense factorisation, no Schur complement.
+
+tests/golden/make_golden.py generates the committed golden vectors from THIS module (float64, cross-checked against the
+50-digit evaluation); tests/test_twin.py compares the C oracle with it. Nothing under sadvio_amd/ may import it.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+try:
+    import mpmath
+except Exception:  # pragma: no cover
+    mpmath = None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# scalar back ends
+# ---------------------------------------------------------------------------------------------------------------
+class Backend:
+    """Scalar type + the handful of transcendental functions the factors need."""
+
+    def __init__(self, kind="f64", digits=50):
+        self.kind = kind
+        if kind == "f64":
+            self.dtype = np.float64
+        elif kind == "ld":
+            self.dtype = np.longdouble
+        elif kind == "mp":
+            if mpmath is None:
+                raise RuntimeError("mpmath is not importable")
+            mpmath.mp.dps = digits
+            self.dtype = object
+        else:
+            raise ValueError(kind)
+
+    def s(self, x):
+        """scalar"""
+        if self.kind == "mp":
+            return x if isinstance(x, mpmath.mpf) else mpmath.mpf(float(x)) if not isinstance(x, (int, str)) else mpmath.mpf(x)
+        return self.dtype(x)
+
+    def a(self, x):
+        """array"""
+        x = np.asarray(x)
+        if self.kind == "mp":
+            out = np.empty(x.shape, dtype=object)
+            for idx in np.ndindex(x.shape):
+                out[idx] = self.s(x[idx])
+            return out
+        return x.astype(self.dtype)
+
+    def zeros(self, shape):
+        if self.kind == "mp":
+            out = np.empty(shape, dtype=object)
+            out.fill(mpmath.mpf(0))
+            return out
+        return np.zeros(shape, dtype=self.dtype)
+
+    def eye(self, n):
+        m = self.zeros((n, n))
+        for i in range(n):
+            m[i, i] = self.s(1)
+        return m
+
+    def _f(self, name, x):
+        if self.kind == "mp":
+            return getattr(mpmath, name)(x)
+        return getattr(np, {"acos": "arccos"}.get(name, name))(x)
+
+    def sqrt(self, x): return self._f("sqrt", x)
+    def sin(self, x): return self._f("sin", x)
+    def cos(self, x): return self._f("cos", x)
+    def acos(self, x): return self._f("acos", x)
+
+    def isfinite(self, x):
+        if self.kind == "mp":
+            return mpmath.isfinite(x)
+        return bool(np.isfinite(x))
+
+    def f(self, x):
+        """to float64 (scalar or array)"""
+        if isinstance(x, np.ndarray):
+            return np.array([float(v) for v in x.ravel()], dtype=np.float64).reshape(x.shape)
+        return float(x)
+
+
+def norm(B, v):
+    return B.sqrt(sum(x * x for x in v))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# geometry.h
+# ---------------------------------------------------------------------------------------------------------------
+def skew(B, w):                                                  # geometry.h:17-23
+    z = B.s(0)
+    return np.array([[z, -w[2], w[1]], [w[2], z, -w[0]], [-w[1], w[0], z]], dtype=B.dtype)
+
+
+def vee(B, S):                                                   # FromskewMatrix, geometry.h:25-28
+    return np.array([S[2, 1], S[0, 2], S[1, 0]], dtype=B.dtype)
+
+
+def so3_right_jacobian(B, w):                                    # geometry.h:30-37
+    n = norm(B, w)
+    if n < 1e-5:
+        return B.eye(3)
+    S = skew(B, w)
+    return B.eye(3) - ((1 - B.cos(n)) / (n * n)) * S + ((n - B.sin(n)) / (n * n * n)) * (S @ S)
+
+
+def exp_so3(B, v):                                               # geometry.h:131-147
+    angle = norm(B, v)
+    if angle < 1e-9:
+        return B.eye(3) + skew(B, v)
+    S = skew(B, v / angle)
+    return B.eye(3) + (1 - B.cos(angle)) * (S @ S) + B.sin(angle) * S
+
+
+def log_so3(B, M):                                               # geometry.h:149-166
+    c = (M[0, 0] + M[1, 1] + M[2, 2]) / 2 - B.s(1) / 2
+    c = min(max(c, B.s(-1)), B.s(1))
+    angle = B.acos(c)
+    d = vee(B, M - M.T)
+    if abs(B.sin(angle)) < 1e-9 or angle < 1e-9:
+        return d / 2
+    return (angle / (2 * B.sin(angle))) * d
+
+
+def inv3(B, A):
+    """3x3 inverse by the adjugate (what Eigen's fixed-size .inverse() computes)."""
+    c = B.zeros((3, 3))
+    c[0, 0] = A[1, 1] * A[2, 2] - A[1, 2] * A[2, 1]
+    c[0, 1] = A[0, 2] * A[2, 1] - A[0, 1] * A[2, 2]
+    c[0, 2] = A[0, 1] * A[1, 2] - A[0, 2] * A[1, 1]
+    c[1, 0] = A[1, 2] * A[2, 0] - A[1, 0] * A[2, 2]
+    c[1, 1] = A[0, 0] * A[2, 2] - A[0, 2] * A[2, 0]
+    c[1, 2] = A[0, 2] * A[1, 0] - A[0, 0] * A[1, 2]
+    c[2, 0] = A[1, 0] * A[2, 1] - A[1, 1] * A[2, 0]
+    c[2, 1] = A[0, 1] * A[2, 0] - A[0, 0] * A[2, 1]
+    c[2, 2] = A[0, 0] * A[1, 1] - A[0, 1] * A[1, 0]
+    det = A[0, 0] * c[0, 0] + A[0, 1] * c[1, 0] + A[0, 2] * c[2, 0]
+    return c / det
+
+
+def split_T(B, T12):
+    T = B.a(np.asarray(T12).reshape(12))
+    return T[:9].reshape(3, 3), T[9:12].copy()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# factors
+# ---------------------------------------------------------------------------------------------------------------
+def pixel_factor(B, T_f_w0, K, T_s_f, p0, uv, sigma, dpose, dl):
+    """ReprojectionErrCeres_pointxd_dx::Evaluate + Camera::project. Returns r[2], J_pose[2,6], J_lmk[2,3], valid."""
+    R0, t0 = split_T(B, T_f_w0)
+    Rs, ts = split_T(B, T_s_f)
+    K = B.a(K); p0 = B.a(p0); uv = B.a(uv); dpose = B.a(dpose); dl = B.a(dl)
+    w = 1 / B.s(sigma)                                           # info_sqrt_ = (1 / sigma) I   (…Analytic.h:46)
+    dR = exp_so3(B, dpose[:3])
+    R = R0 @ dR                                                  # T_f_w = T_f_w0 * (exp(w), t)  (…Analytic.h:54-55)
+    t = R0 @ dpose[3:6] + t0
+    pw = p0 + dl                                                 # T_w_lmk * (I, dl), point landmark (…Analytic.h:58)
+    tc = Rs @ (R @ pw + t) + ts                                  # Camera.cpp:92-93
+    fx, fy, cx, cy = K
+    Kc = np.array([[fx, B.s(0), cx], [B.s(0), fy, cy], [B.s(0), B.s(0), B.s(1)]], dtype=B.dtype)
+    pt = Kc @ tc                                                 # :96
+    z = pt[2]
+    Jh = np.array([[1 / z, B.s(0), -pt[0] / (z * z)], [B.s(0), 1 / z, -pt[1] / (z * z)]], dtype=B.dtype)   # :97-99
+    p2d = np.array([pt[0] / z, pt[1] / z], dtype=B.dtype)        # :101-102
+    Jint = B.zeros((3, 6))                                       # :104-110
+    Jint[:, :3] = -(R @ skew(B, pw) @ so3_right_jacobian(B, log_so3(B, R)))
+    Jint[:, 3:] = B.eye(3)
+    Jframe = w * (Jh @ Kc @ Rs @ Jint)                           # :112-115
+    Jlmk = w * (Jh @ Kc @ (Rs @ R))                              # :118-125
+    valid = True                                                 # :127-137
+    if tc[2] < 0.1:
+        valid = False
+    if p2d[0] < 0 or p2d[1] < 0 or p2d[0] > 2 * cx or p2d[1] > 2 * cy:
+        valid = False
+    if not (B.isfinite(p2d[0]) and B.isfinite(p2d[1])):
+        valid = False
+    r = w * (p2d - uv) if valid else B.zeros(2)                  # …Analytic.h:62-67
+    Jl = B.zeros((6, 6))                                         # :70-77
+    Jl[:3, :3] = inv3(B, so3_right_jacobian(B, log_so3(B, R))) @ so3_right_jacobian(B, dpose[:3])
+    Jl[3:, 3:] = R0
+    return r, Jframe @ Jl, Jlmk, valid
+
+
+def angular_factor(B, T_f_w0, T_s_f, p0, bearing, sigma, dpose, dl):
+    """AngularErrCeres_pointxd_dx::Evaluate. Returns r[2], J_pose[2,6], J_lmk[2,3]."""
+    R0, t0 = split_T(B, T_f_w0)
+    Rs, ts = split_T(B, T_s_f)
+    p0 = B.a(p0); b = B.a(bearing); dpose = B.a(dpose); dl = B.a(dl)
+    w = 1 / B.s(sigma)                                           # :60
+    dR = exp_so3(B, dpose[:3])
+    q = p0 + dl
+    pf = R0 @ (dR @ q + dpose[3:6]) + t0                         # _T_f_w * dT * (_t_w_lmk + dt)   (:63)
+    tsl = Rs @ pf + ts
+    nrm = norm(B, tsl)
+    bs = tsl / nrm                                               # :64-65
+    ex = np.array([B.s(1), B.s(0), B.s(0)], dtype=B.dtype)
+    ez = np.array([B.s(0), B.s(0), B.s(1)], dtype=B.dtype)
+    cross = lambda u, v: np.array([u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]], dtype=B.dtype)
+    b1 = cross(b, ex) if norm(B, b - ex) > 1e-5 else cross(b, ez)   # :68-75
+    b1 = b1 / norm(B, b1)
+    b2 = cross(b1, b)
+    b2 = b2 / norm(B, b2)                                        # :77-78
+    Pt = np.stack([b1, b2])                                      # :80-83
+    r = w * (Pt @ (bs - b))                                      # :86
+    Jel = Pt @ (B.eye(3) - np.outer(bs, bs)) @ Rs @ R0 / nrm     # :90-92
+    Jbf = B.zeros((3, 6))                                        # :95-99
+    Jbf[:, :3] = -(dR @ skew(B, q) @ so3_right_jacobian(B, log_so3(B, dR)))
+    Jbf[:, 3:] = B.eye(3)
+    return r, w * (Jel @ Jbf), w * (Jel @ dR)                    # :102, :107
+
+
+def pose_prior_factor(B, T_f_w0, T_prior, inf_diag, dpose):
+    """PosePriordx::Evaluate, sqrt_inf = diag(inf_diag) (BundleAdjustmentCERESAnalytic.cpp:226). Returns r[6], J[6,6]."""
+    R0, t0 = split_T(B, T_f_w0)
+    Rp, tp = split_T(B, T_prior)
+    dpose = B.a(dpose); W = B.a(inf_diag)
+    dR = exp_so3(B, dpose[:3])
+    R = R0 @ dR                                                  # T = _T * dT   (:609)
+    t = R0 @ dpose[3:6] + t0
+    Rpi = Rp.T                                                   # _T_prior.inverse()
+    tpi = -(Rpi @ tp)
+    Re = R @ Rpi                                                 # T * T_prior^-1
+    te = R @ tpi + t
+    err = np.concatenate([log_so3(B, Re), te])                   # se3_RTtoVec6d   (:610)
+    J = B.eye(6)                                                 # :613-623
+    wv = log_so3(B, R @ Rp.T)
+    J[:3, :3] = inv3(B, so3_right_jacobian(B, wv)) @ Rp @ so3_right_jacobian(B, dpose[:3])
+    J[3:, :3] = R @ skew(B, Rp.T @ tp) @ so3_right_jacobian(B, dpose[:3])
+    J[3:, 3:] = R0
+    return W * err, W[:, None] * J
+
+
+def huber(B, s, a):
+    """ceres::HuberLoss(a)::Evaluate -> (rho, rho'), loss_function.cc; s = |r|^2."""
+    b = B.s(a) * B.s(a)
+    if s > b:
+        r = B.sqrt(s)
+        return 2 * B.s(a) * r - b, max(B.s(a) / r, B.s(0) + np.finfo(np.float64).tiny)
+    return s, B.s(1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the problem of addResidualsLocalMap on a flat window (duck-typed: attribute names of sadvio_flat_window)
+# ---------------------------------------------------------------------------------------------------------------
+class Problem:
+    """Parameter blocks: free key-frames (6 each, window order) then free landmarks (3 each, window order). A residual
+    block all of whose parameters are constant contributes to fixed_cost only (Ceres' reduced program)."""
+
+    def __init__(self, B, w, huber_a=0.0):
+        self.B, self.w, self.huber_a = B, w, huber_a
+        self.n_kf = int(np.asarray(w.kf_T_f_w).reshape(-1, 12).shape[0])
+        self.n_lmk = int(np.asarray(w.lmk_p).reshape(-1, 3).shape[0])
+        kc = np.asarray(w.kf_const).astype(bool)
+        lc = np.zeros(self.n_lmk, bool) if getattr(w, "lmk_const", None) is None else np.asarray(w.lmk_const).astype(bool)
+        ptr = np.asarray(w.lmk_obs_ptr)
+        self.ptr = ptr
+        # a landmark is a parameter block only if some residual block uses it
+        has_obs = (ptr[1:] - ptr[:-1]) > 0
+        self.kf_col = np.full(self.n_kf, -1)
+        self.lmk_col = np.full(self.n_lmk, -1)
+        n = 0
+        for k in range(self.n_kf):
+            if not kc[k]:
+                self.kf_col[k] = n
+                n += 6
+        self.n_pose = n
+        for l in range(self.n_lmk):
+            if not lc[l] and has_obs[l]:
+                self.lmk_col[l] = n
+                n += 3
+        self.n = n
+        self.T = np.asarray(w.kf_T_f_w, dtype=np.float64).reshape(-1, 12)
+        self.K = np.asarray(w.cam_K, dtype=np.float64).reshape(-1, 4)
+        self.Ts = np.asarray(w.cam_T_s_f, dtype=np.float64).reshape(-1, 12)
+        self.sig = np.asarray(w.cam_sigma, dtype=np.float64)
+        self.P = np.asarray(w.lmk_p, dtype=np.float64).reshape(-1, 3)
+        self.meas = np.asarray(w.obs_meas, dtype=np.float64)
+        self.okf, self.ocam = np.asarray(w.obs_kf), np.asarray(w.obs_cam)
+        self.priors = list(getattr(w, "pose_priors", []))
+        self.dense = getattr(w, "dense_prior", None)
+
+    def split(self, x):
+        """x (length n, scalar type of B) -> per key-frame 6-vectors, per landmark 3-vectors (zeros when constant)."""
+        B = self.B
+        xp = B.zeros((self.n_kf, 6)); xl = B.zeros((self.n_lmk, 3))
+        for k in range(self.n_kf):
+            if self.kf_col[k] >= 0:
+                xp[k] = x[self.kf_col[k]: self.kf_col[k] + 6]
+        for l in range(self.n_lmk):
+            if self.lmk_col[l] >= 0:
+                xl[l] = x[self.lmk_col[l]: self.lmk_col[l] + 3]
+        return xp, xl
+
+    def blocks(self, x, want_j=True):
+        """Yield (r, [(col, J)], in_program) for every residual block at x, loss function already applied (Corrector)."""
+        B = self.B
+        xp, xl = self.split(x)
+        pixel = int(self.w.factor_type) == 0
+        for l in range(self.n_lmk):
+            for o in range(self.ptr[l], self.ptr[l + 1]):
+                k, c = int(self.okf[o]), int(self.ocam[o])
+                if pixel:
+                    r, Jp, Jl, _ = pixel_factor(B, self.T[k], self.K[c], self.Ts[c], self.P[l], self.meas[o][:2], self.sig[c], xp[k], xl[l])
+                else:
+                    r, Jp, Jl = angular_factor(B, self.T[k], self.Ts[c], self.P[l], self.meas[o][:3], self.sig[c], xp[k], xl[l])
+                s = r[0] * r[0] + r[1] * r[1]
+                rho = s
+                if self.huber_a > 0:                              # corrector.cc: rho'' <= 0 -> scale r and J by sqrt(rho')
+                    rho, d1 = huber(B, s, self.huber_a)
+                    sc = B.sqrt(d1)
+                    r, Jp, Jl = sc * r, sc * Jp, sc * Jl
+                cols = []
+                if self.kf_col[k] >= 0:
+                    cols.append((self.kf_col[k], Jp))
+                if self.lmk_col[l] >= 0:
+                    cols.append((self.lmk_col[l], Jl))
+                yield r, cols, bool(cols), rho
+        for (k, Tp, inf) in self.priors:                          # PosePriordx blocks (…Analytic.cpp:224-228)
+            k = int(k)
+            r, J = pose_prior_factor(B, self.T[k], Tp, inf, xp[k])
+            cols = [(self.kf_col[k], J)] if self.kf_col[k] >= 0 else []
+            yield r, cols, bool(cols), sum(v * v for v in r)
+        if self.dense is not None:                                # MarginalizationFactor: r = r0 + J dx (marginalization.hpp:113-215), VO layout
+            d = self.dense
+            J = B.a(np.asarray(d["J"], dtype=np.float64)); r0 = B.a(np.asarray(d["r0"], dtype=np.float64))
+            if int(d.get("kf_keep", -1)) >= 0:
+                raise NotImplementedError("twin: dense prior with a kept frame (VIO) is not restated")
+            dx = B.zeros(J.shape[1]); cols = []
+            for li, lc in zip(d["lmk_index"], d["lmk_col"]):
+                if lc < 0:
+                    continue
+                dx[lc: lc + 3] = xl[int(li)]
+                if self.lmk_col[int(li)] >= 0:
+                    cols.append((self.lmk_col[int(li)], J[:, lc: lc + 3]))
+            r = r0 + J @ dx
+            yield r, cols, bool(cols), sum(v * v for v in r)
+
+    def evaluate(self, x, want_j=True):
+        """cost (reduced program), fixed cost, residual vector, dense Jacobian [m, n] (None unless want_j)."""
+        B = self.B
+        rs, rows, cost, fixed = [], [], B.s(0), B.s(0)
+        for r, cols, inprog, rho in self.blocks(x, want_j):
+            if not inprog:
+                fixed = fixed + rho / 2
+                continue
+            cost = cost + rho / 2
+            rs.append(r)
+            rows.append(cols)
+        m = sum(len(r) for r in rs)
+        res = np.concatenate(rs) if rs else B.zeros(0)
+        if not want_j:
+            return cost, fixed, res, None
+        J = B.zeros((m, self.n))
+        i = 0
+        for r, cols in zip(rs, rows):
+            for (c, Jb) in cols:
+                J[i: i + len(r), c: c + Jb.shape[1]] = Jb
+            i += len(r)
+        return cost, fixed, res, J
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dense SPD solve, generic scalar type
+# ---------------------------------------------------------------------------------------------------------------
+def cholesky_solve(B, A, b):
+    """x = A^-1 b for SPD A by an (unblocked, row-vectorised) Cholesky factorisation; returns None if not PD."""
+    if B.kind == "f64":
+        try:
+            L = np.linalg.cholesky(A)
+        except np.linalg.LinAlgError:
+            return None
+        y = np.linalg.solve(L, b)          # LAPACK, independent of the oracle's hand-written Schur + Cholesky
+        return np.linalg.solve(L.T, y)
+    n = A.shape[0]
+    L = A.copy()
+    for j in range(n):
+        d = L[j, j] - (L[j, :j] * L[j, :j]).sum() if j else L[j, j]
+        if not d > 0:
+            return None
+        d = B.sqrt(d)
+        L[j, j] = d
+        if j + 1 < n:
+            L[j + 1:, j] = (L[j + 1:, j] - (L[j + 1:, :j] @ L[j, :j] if j else 0)) / d
+    y = b.copy()
+    for i in range(n):
+        y[i] = (y[i] - (L[i, :i] * y[:i]).sum() if i else y[i]) / L[i, i]
+    x = y.copy()
+    for i in range(n - 1, -1, -1):
+        x[i] = (x[i] - (L[i + 1:, i] * x[i + 1:]).sum() if i + 1 < n else x[i]) / L[i, i]
+    return x
+
+
+def schur_solve(B, P, H, g, D2):
+    """(H + diag(D2)) y = g by eliminating the landmark blocks — only used for the long-double arbitration runs on windows
+    whose un-reduced system is too large for a long-double dense factorisation. Exact-arithmetic equivalent of cholesky_solve."""
+    npz = P.n_pose
+    A = H + np.diag(D2)
+    S = A[:npz, :npz].copy()
+    gp = g[:npz].copy()
+    Minv = {}
+    for l in range(P.n_lmk):
+        c = P.lmk_col[l]
+        if c < 0:
+            continue
+        Mi = inv3(B, A[c: c + 3, c: c + 3])
+        Minv[l] = Mi
+        E = A[:npz, c: c + 3]
+        Y = E @ Mi
+        S -= Y @ E.T
+        gp -= Y @ g[c: c + 3]
+    yp = cholesky_solve(B, S, gp)
+    if yp is None:
+        return None
+    y = B.zeros(P.n)
+    y[:npz] = yp
+    for l, Mi in Minv.items():
+        c = P.lmk_col[l]
+        y[c: c + 3] = Mi @ (g[c: c + 3] - A[:npz, c: c + 3].T @ yp)
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Ceres 2.2.0 trust-region loop (Levenberg-Marquardt strategy), as published
+# ---------------------------------------------------------------------------------------------------------------
+DEFAULTS = dict(max_num_iterations=20, jacobi_scaling=1, max_num_consecutive_invalid_steps=5, function_tolerance=1e-3,
+                gradient_tolerance=1e-10, parameter_tolerance=1e-8, initial_trust_region_radius=1e4,
+                max_trust_region_radius=1e16, min_trust_region_radius=1e-32, min_lm_diagonal=1e-6, max_lm_diagonal=1e32,
+                min_relative_decrease=1e-3, huber_a=0.0)
+TERM = {"NO_CONVERGENCE": 0, "FUNCTION_TOL": 1, "PARAMETER_TOL": 2, "GRADIENT_TOL": 3, "MIN_RADIUS": 4, "FAILURE": 5}
+
+
+def options_dict(opts=None):
+    o = dict(DEFAULTS)
+    if opts is not None:
+        for k in o:
+            o[k] = getattr(opts, k) if not isinstance(opts, dict) else opts.get(k, o[k])
+    return o
+
+
+def lm_solve(w, opts=None, kind="f64", digits=50, use_schur=False, max_iterations=None):
+    """Minimise the window's cost with Ceres' trust-region / LM schedule. Returns a dict: pose[n_kf,6], lmk[n_lmk,3]
+    (float64), summary fields and `log` (one row per iteration: cost, cost_change, radius, step_norm, relative_decrease,
+    successful, gradient_max, model_cost_change — the layout of the C oracle's log)."""
+    o = options_dict(opts)
+    if max_iterations is not None:
+        o["max_num_iterations"] = max_iterations
+    B = Backend(kind, digits)
+    P = Problem(B, w, huber_a=o["huber_a"])
+    n = P.n
+    x = B.zeros(n)
+    x_norm = B.s(0)
+    cost, fixed, r, J = P.evaluate(x)
+    g = J.T @ r                                                   # gradient of the UNSCALED problem
+    scale = B.zeros(n)
+    for i in range(n):                                            # jacobian_scaling = 1 / (1 + ||col||), iteration 0 only
+        scale[i] = 1 / (1 + B.sqrt((J[:, i] * J[:, i]).sum())) if o["jacobi_scaling"] else B.s(1)
+    J = J * scale[None, :]
+    gmax = max([abs(v) for v in g]) if n else B.s(0)
+    radius = B.s(o["initial_trust_region_radius"])
+    decrease_factor = B.s(2)
+    reuse_diagonal = False
+    diagonal = None
+    log = [[B.f(cost), 0.0, B.f(radius), 0.0, 0.0, 1.0, B.f(gmax), 0.0]]
+    out = dict(initial_cost=B.f(cost), fixed_cost=B.f(fixed), n_success=0, n_unsuccess=0, termination=TERM["NO_CONVERGENCE"])
+    it = 0
+    n_invalid = 0
+    step_successful = True
+    if gmax <= o["gradient_tolerance"]:
+        out["termination"] = TERM["GRADIENT_TOL"]
+    else:
+        while True:
+            # FinalizeIterationAndCheckIfMinimizerCanContinue
+            if it >= o["max_num_iterations"]:
+                out["termination"] = TERM["NO_CONVERGENCE"]
+                break
+            if step_successful and gmax <= o["gradient_tolerance"]:
+                out["termination"] = TERM["GRADIENT_TOL"]
+                break
+            if radius < o["min_trust_region_radius"]:
+                out["termination"] = TERM["MIN_RADIUS"]
+                break
+            it += 1
+            # LevenbergMarquardtStrategy::ComputeStep
+            if not reuse_diagonal:
+                diagonal = B.zeros(n)
+                for i in range(n):
+                    d = (J[:, i] * J[:, i]).sum()
+                    diagonal[i] = min(max(d, B.s(o["min_lm_diagonal"])), B.s(o["max_lm_diagonal"]))
+            D2 = diagonal / radius                                # lm_diagonal = sqrt(diagonal / radius); D^2 enters the normal equations
+            H = J.T @ J
+            rhs = J.T @ r
+            y = schur_solve(B, P, H, rhs, D2) if use_schur else cholesky_solve(B, H + np.diag(D2), rhs)
+            valid = y is not None and all(B.isfinite(v) for v in y)
+            mcc = B.s(0)
+            if valid:
+                step = -y
+                Jd = J @ step
+                mcc = -(Jd * (r + Jd / 2)).sum()                  # model_cost_change
+                valid = mcc > 0
+            if not valid:                                         # HandleInvalidStep
+                n_invalid += 1
+                step_successful = False
+                log.append([B.f(cost), 0.0, B.f(radius), 0.0, 0.0, 0.0, B.f(gmax), B.f(mcc)])
+                if n_invalid >= o["max_num_consecutive_invalid_steps"]:
+                    out["termination"] = TERM["FAILURE"]
+                    break
+                radius = radius / 2                               # StepIsInvalid
+                reuse_diagonal = True
+                continue
+            n_invalid = 0
+            delta = step * scale
+            cand = x + delta
+            cand_cost, _, _, _ = P.evaluate(cand, want_j=False)
+            step_norm = B.sqrt((delta * delta).sum())
+            if step_norm <= o["parameter_tolerance"] * (x_norm + o["parameter_tolerance"]):
+                out["termination"] = TERM["PARAMETER_TOL"]
+                log.append([B.f(cand_cost), B.f(cost - cand_cost), B.f(radius), B.f(step_norm), 0.0, 0.0, B.f(gmax), B.f(mcc)])
+                break
+            cost_change = cost - cand_cost
+            if abs(cost_change) <= o["function_tolerance"] * cost:
+                out["termination"] = TERM["FUNCTION_TOL"]
+                log.append([B.f(cand_cost), B.f(cost_change), B.f(radius), B.f(step_norm), B.f(cost_change / mcc), 0.0, B.f(gmax), B.f(mcc)])
+                break
+            rho = cost_change / mcc
+            if rho > o["min_relative_decrease"]:                  # HandleSuccessfulStep
+                x = cand
+                x_norm = B.sqrt((x * x).sum())
+                cost, _, r, J = P.evaluate(x)
+                g = J.T @ r
+                J = J * scale[None, :]
+                gmax = max(abs(v) for v in g)
+                radius = radius / max(B.s(1) / 3, 1 - (2 * rho - 1) ** 3)   # StepAccepted
+                radius = min(B.s(o["max_trust_region_radius"]), radius)
+                decrease_factor = B.s(2)
+                reuse_diagonal = False
+                step_successful = True
+                out["n_success"] += 1
+                log.append([B.f(cost), B.f(cost_change), B.f(radius), B.f(step_norm), B.f(rho), 1.0, B.f(gmax), B.f(mcc)])
+            else:                                                 # HandleUnsuccessfulStep / StepRejected
+                radius = radius / decrease_factor
+                decrease_factor = decrease_factor * 2
+                reuse_diagonal = True
+                step_successful = False
+                out["n_unsuccess"] += 1
+                log.append([B.f(cost), B.f(cost_change), B.f(radius), B.f(step_norm), B.f(rho), 0.0, B.f(gmax), B.f(mcc)])
+    xp, xl = P.split(x)
+    out.update(pose=B.f(xp), lmk=B.f(xl), iterations=it, final_cost=B.f(cost), final_radius=B.f(radius), log=np.array(log),
+               x_scalar=x, backend=B, problem=P)
+    return out
+
+
+def first_iteration(w, opts=None, kind="f64", digits=50):
+    """ONE full LM iteration at x = 0 on the un-reduced normal equations: the step (pose / landmark parts, float64), the
+    model cost change, the candidate cost and the step quality."""
+    res = lm_solve(w, opts, kind=kind, digits=digits, max_iterations=1)
+    return res

@@ -1,12 +1,20 @@
-"""Generates tests/golden/*.npz: seeded inputs + expected outputs of the BA hot path.
+"""Generates tests/golden/window_*_5kf.npz: seeded inputs + expected outputs of the BA hot path.
 
-The reference (C++/Eigen/Ceres/OpenCV) cannot be built or imported in this environment, and it stores no
-numeric goldens for its visual factors. These vectors are produced by the repo's CPU oracle
-AFTER it has been pinned against the reference tests' known answers (tests/test_oracle_*.py); they freeze
-those answers so that (a) the oracle cannot drift silently and (b) the HIP path is checked on the GPU box
-against committed numbers as well as against the live oracle.
+The reference (C++/Eigen/Ceres/OpenCV) cannot be built or imported in this environment and stores no numeric goldens for
+its visual factors. These vectors therefore come from oracle/twin.py — the INDEPENDENT NumPy / mpmath
+restatement written from the reference's source lines and Ceres 2.2.0's published trust-region algorithm — and NOT from
+the C oracle they are used to check:
 
-Run from the repo root:  python tests/golden/make_golden.py
+  lin0_* / lin1_*   per-observation residuals and Jacobians, evaluated with 50-digit mpmath arithmetic and rounded to
+                    float64 (the exact value of what ReprojectionErrCeres_pointxd_dx / AngularErrCeres_pointxd_dx::Evaluate
+                    compute, at zero deltas and at a random delta);
+  ref_* / gn5_*     the full LM solve (reference options AOptimizer.cpp:315-323, and 5 forced Gauss-Newton-like steps) on the
+                    UN-REDUCED normal equations in long-double arithmetic: solution, summary, per-iteration log
+                    [cost, cost_change, radius, step_norm, relative_decrease, successful, gradient_max, model_cost_change].
+
+tests/test_golden_cpu.py holds the C oracle to them, tests/test_gpu_parity.py the HIP path (incl. the per-iteration costs
+of the device-side trace). Run from the repo root (build container only; takes about a minute):
+    python tests/golden/make_golden.py
 """
 import os
 import sys
@@ -15,8 +23,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle import oracle  # noqa: E402
-from sadvio_amd import capi, synthetic  # noqa: E402
+from oracle import twin  # noqa: E402
+from sadvio_amd import capi, synthetic  # noqa: E402  (window generator + option presets only)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -30,28 +38,44 @@ def window_arrays(w):
                 prior_inf=np.array([p[2] for p in w.pose_priors]).reshape(-1, 6))
 
 
+def linearize_mp(w, pd, ld):
+    """Every observation's (r, J_pose, J_lmk) in 50-digit arithmetic, rounded to float64."""
+    B = twin.Backend("mp", 50)
+    r = np.zeros((w.n_obs, 2)); Jp = np.zeros((w.n_obs, 2, 6)); Jl = np.zeros((w.n_obs, 2, 3))
+    for l in range(w.n_lmk):
+        for o in range(w.lmk_obs_ptr[l], w.lmk_obs_ptr[l + 1]):
+            k, c = int(w.obs_kf[o]), int(w.obs_cam[o])
+            if w.factor_type == capi.FACTOR_PIXEL:
+                a, b, d, _ = twin.pixel_factor(B, w.kf_T_f_w[k], w.cam_K[c], w.cam_T_s_f[c], w.lmk_p[l], w.obs_meas[o][:2], w.cam_sigma[c], pd[k], ld[l])
+            else:
+                a, b, d = twin.angular_factor(B, w.kf_T_f_w[k], w.cam_T_s_f[c], w.lmk_p[l], w.obs_meas[o][:3], w.cam_sigma[c], pd[k], ld[l])
+            r[o], Jp[o], Jl[o] = B.f(a), B.f(b), B.f(d)
+    return r, Jp, Jl
+
+
 def make(name, factor, seed):
     w = synthetic.make_window(n_kf=5, n_lmk=120, seed=seed, factor=factor)
-    w.to_c()
+    w.kf_id = np.arange(w.n_kf, dtype=np.int64); w.lmk_id = np.arange(w.n_lmk, dtype=np.int64)
     # a prior on a free key-frame as well (first frames of a SLAM run carry one, slamBiMono.cpp:17)
     w.pose_priors.append((0, w.kf_T_f_w[0].copy(), 100.0 * np.ones(6)))
     rng = np.random.default_rng(seed + 1)
     pd = 0.01 * rng.standard_normal((w.n_kf, 6)); ld = 0.03 * rng.standard_normal((w.n_lmk, 3))
-    r0, Jp0, Jl0, v0 = oracle.linearize(w)
-    r1, Jp1, Jl1, v1 = oracle.linearize(w, pd, ld)
+    r0, Jp0, Jl0 = linearize_mp(w, np.zeros((w.n_kf, 6)), np.zeros((w.n_lmk, 3)))
+    r1, Jp1, Jl1 = linearize_mp(w, pd, ld)
     out = window_arrays(w)
-    out.update(lin0_r=r0, lin0_Jp=Jp0, lin0_Jl=Jl0, lin_pose_delta=pd, lin_lmk_delta=ld, lin1_r=r1, lin1_Jp=Jp1,
-               lin1_Jl=Jl1)
+    out.update(lin0_r=r0, lin0_Jp=Jp0, lin0_Jl=Jl0, lin_pose_delta=pd, lin_lmk_delta=ld, lin1_r=r1, lin1_Jp=Jp1, lin1_Jl=Jl1)
     for tag, opts in (("ref", capi.reference_options()), ("gn5", capi.gn_options(5))):
-        res = oracle.solve(w, opts)
-        s = res["summary"]
+        res = twin.lm_solve(w, opts, kind="ld")
+        f64 = twin.lm_solve(w, opts, kind="f64")      # same algorithm, LAPACK dense solve: spread = rounding sensitivity
+        assert (res["iterations"], res["termination"]) == (f64["iterations"], f64["termination"])
         out.update({f"{tag}_pose": res["pose"], f"{tag}_lmk": res["lmk"],
-                    f"{tag}_summary": np.array([s.iterations, s.num_successful_steps, s.num_unsuccessful_steps,
-                                                s.termination, s.initial_cost, s.final_cost, s.fixed_cost,
-                                                s.final_radius]),
-                    f"{tag}_log": res["log"]})
+                    f"{tag}_summary": np.array([res["iterations"], res["n_success"], res["n_unsuccess"], res["termination"],
+                                                res["initial_cost"], res["final_cost"], res["fixed_cost"], res["final_radius"]]),
+                    f"{tag}_log": res["log"],
+                    f"{tag}_f64_spread": np.array([np.abs(res["pose"] - f64["pose"]).max(), np.abs(res["lmk"] - f64["lmk"]).max()])})
+        print(name, tag, "iterations", res["iterations"], "term", res["termination"], "cost", res["initial_cost"], "->", res["final_cost"],
+              "f64-vs-long-double spread pose %.1e lmk %.1e" % tuple(out[f"{tag}_f64_spread"]))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
-    print(name, "iterations", int(out["ref_summary"][0]), "cost", out["ref_summary"][4], "->", out["ref_summary"][5])
 
 
 if __name__ == "__main__":

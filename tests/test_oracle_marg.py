@@ -53,7 +53,7 @@ def pre_marginalize(w, kf0):
 
 
 def run_marg(oracle_lib, w, kf_marg, keep, marg, kf_keep=-1):
-    wc = w.to_c()
+    wc, _keep = oracle_lib.S.window_to_c(w)
     rq = oracle_lib.MargRequest()
     rq.win = C.pointer(wc)
     rq.kf_marg, rq.kf_keep, rq.marg_has_imu = kf_marg, kf_keep, 0
