@@ -299,6 +299,14 @@ int sadvio_ba_solve(sadvio_ba_handle *h, const sadvio_solve_options *opts, sadvi
 int sadvio_ba_get_deltas(sadvio_ba_handle *h, int32_t w, double *pose_delta6, double *lmk_delta3,
                          double *dv3, double *dba3, double *dbg3);
 
+/* Per-iteration log of the last solve of window `w`: what ceres::Solver::Summary::iterations holds for the reference
+ * (AOptimizer.cpp:325-327 keeps the summary; FullReport prints it). Row i (8 doubles) = the state after i step attempts:
+ *   [0] cost  [1] cost_change  [2] trust_region_radius  [3] step_norm  [4] relative_decrease  [5] step_is_successful
+ *   [6] gradient_max_norm at that state (-1 for the state after the last attempt, which is not linearised again)
+ *   [7] model_cost_change of the attempt.
+ * Row 0 is the starting point. `n_rows` receives iterations + 1; at most `cap_rows` rows are written. */
+int sadvio_ba_get_trace(sadvio_ba_handle *h, int32_t w, int32_t cap_rows, double *rows8, int32_t *n_rows);
+
 /* Echo of the opaque ids of window `w` in output order (bit-exact identity check). */
 int sadvio_ba_get_ids(sadvio_ba_handle *h, int32_t w, int64_t *kf_id, int64_t *lmk_id);
 

@@ -338,6 +338,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.sadvio_ba_solve.argtypes = [C.c_void_p, C.POINTER(SolveOptions), C.POINTER(SolveSummary)]
     lib.sadvio_ba_get_deltas.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
     lib.sadvio_ba_get_ids.argtypes = [C.c_void_p, C.c_int32, _lp, _lp]
+    lib.sadvio_ba_get_trace.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _ip]
     lib.sadvio_ba_linearize.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
     lib.sadvio_ba_vi_init.argtypes = [C.c_void_p, C.POINTER(ViInitProblemC), C.POINTER(SolveOptions), C.POINTER(SolveSummary),
                                       C.POINTER(ViInitResultC), _dp]
@@ -487,6 +488,14 @@ class Backend:
         self._check(self.lib.sadvio_ba_get_deltas(self.h, w, _ptr(pose), _ptr(lmk), _ptr(dv), _ptr(dba), _ptr(dbg)),
                     "get_deltas")
         return {"pose": pose, "lmk": lmk, "dv": dv, "dba": dba, "dbg": dbg}
+
+    def get_trace(self, w: int = 0) -> np.ndarray:
+        """Per-iteration log [iterations + 1, 8] of the last solve (sadvio_ba_get_trace)."""
+        n = C.c_int32(0)
+        self._check(self.lib.sadvio_ba_get_trace(self.h, w, 0, _dp(), C.byref(n)), "get_trace")
+        rows = np.zeros((n.value, 8))
+        self._check(self.lib.sadvio_ba_get_trace(self.h, w, n.value, _ptr(rows), C.byref(n)), "get_trace")
+        return rows
 
     def get_ids(self, w: int = 0):
         win = self.windows[w]

@@ -238,6 +238,7 @@ struct sadvio_ba_handle {
     DevBuf<double> d_imu_scratch;
     DevBuf<double> d_S, d_gred, d_gfull, d_hdiag, d_delta, d_s_pose;
     DevBuf<LmState> d_states;
+    DevBuf<double> d_trace;
     DevBuf<IterAcc> d_acc;
     DevBuf<FinalRec> d_final;
     FinalRec* h_final = nullptr;  // pinned
@@ -318,6 +319,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.S = h->d_S.p; P.gred = h->d_gred.p; P.gfull = h->d_gfull.p; P.hdiag = h->d_hdiag.p;
     P.delta = h->d_delta.p; P.s_pose = h->d_s_pose.p;
     P.dbg_ts = h->d_dbg.p;
+    P.trace = h->d_trace.p;
     P.states = h->d_states.p; P.acc = h->d_acc.p; P.tacc = h->d_tacc.p; P.n_tiles = (int)h->tiles.size();
     P.state_stride = state_stride;
     P.final_out = h->d_final.p;
@@ -594,7 +596,7 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     h->d_lmk_p.release(); h->d_xl.release(); h->d_s_lmk.release(); h->d_lmk_const.release();
     h->d_lmk_ob.release(); h->d_lmk_oe.release(); h->d_obs_kf.release(); h->d_obs_cam.release();
     h->d_obs_meas.release(); h->d_priors.release(); h->d_S.release(); h->d_rank_s.release(); h->d_gred.release(); h->d_gfull.release();
-    h->d_hdiag.release(); h->d_delta.release(); h->d_s_pose.release(); h->d_states.release(); h->d_acc.release();
+    h->d_hdiag.release(); h->d_delta.release(); h->d_s_pose.release(); h->d_states.release(); h->d_trace.release(); h->d_acc.release();
     h->d_probe.release(); h->d_tile_kf.release(); h->d_tile_row.release(); h->d_obs_slot.release(); h->d_ptab.release(); h->d_tacc.release(); h->d_dbg.release(); h->d_imus.release(); h->d_imu_scratch.release();
     delete h;
 }
@@ -1652,6 +1654,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     const int stride = slots + 2;
     HIP_TRY(h->d_dbg.alloc(64));
     HIP_TRY(h->d_states.alloc((size_t)n_win * stride));
+    HIP_TRY(h->d_trace.alloc((size_t)n_win * stride * 8));
     HIP_TRY(h->d_acc.alloc((size_t)n_win * stride));
     HIP_TRY(h->d_final.alloc((size_t)n_win));
     HIP_TRY(h->d_big_info.alloc((size_t)n_win));
@@ -2024,6 +2027,19 @@ int sadvio_ba_get_deltas(sadvio_ba_handle* h, int32_t w, double* pose, double* l
     double* srcs[3] = {h->d_xv.p, h->d_xba.p, h->d_xbg.p};
     for (int q = 0; q < 3; q++)
         if (outs[q]) HIP_TRY(hipMemcpy(outs[q], srcs[q] + (size_t)cur * 3 * h->n_kf_tot + 3 * (size_t)d.kf_base, sizeof(double) * 3 * d.n_kf, hipMemcpyDeviceToHost));
+    return SADVIO_OK;
+}
+
+int sadvio_ba_get_trace(sadvio_ba_handle* h, int32_t w, int32_t cap_rows, double* rows8, int32_t* n_rows) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (!h->solved) { h->err = "get_trace before solve"; return SADVIO_E_STATE; }
+    if (w < 0 || w >= (int)h->wins.size() || cap_rows < 0 || (cap_rows > 0 && !rows8)) { h->err = "get_trace: bad argument"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    const int stride = h->last_slots + 2;
+    const int n = std::min(h->fin[w].s.iter + 1, stride);
+    if (n_rows) *n_rows = n;
+    const int m = std::min(n, cap_rows);
+    if (m > 0) HIP_TRY(hipMemcpy(rows8, h->d_trace.p + (size_t)w * stride * 8, sizeof(double) * 8 * (size_t)m, hipMemcpyDeviceToHost));
     return SADVIO_OK;
 }
 

@@ -63,6 +63,7 @@ struct DevPtrs {
     int n_tiles;
     int state_stride;
     int n_win;
+    double* trace;      // [n_win][state_stride][8] per-iteration log (sadvio_ba_get_trace), written by the slot's single decider
     long long* dbg_ts;  // [64] phase timestamps (wall_clock64, 100 MHz) of workgroup 0 when debug & 4096
     int debug;  // SADVIO_DEBUG env: bit 12 (4096) = in-kernel phase timestamps of workgroup 0 into dbg_ts (results unaffected)
     SolveOpts o;
@@ -128,6 +129,23 @@ __device__ __forceinline__ LmState lm_decide(LmState s, const IterAcc& a, const 
     if (s.iter >= o.max_num_iterations) { s.done = 1; s.termination = 0; }
     else if (s.radius <= o.min_radius) { s.done = 1; s.termination = 4; }
     return s;
+}
+
+// Iteration log of a window (the IterationSummary fields Ceres reports, in the layout of the oracle's log): row i = the
+// state after i step attempts: [cost, cost_change, radius, step_norm, relative_decrease, successful, max |gradient| at
+// that state (-1 where it was not linearised: after the last attempt), model_cost_change]. Called by the one thread that
+// publishes the decision of `slot` (prev = state before the attempt, a = its totals, next = the decision).
+__device__ __forceinline__ void trace_write(const DevPtrs& P, int w, int slot, const LmState& prev, const IterAcc& a, const LmState& next) {
+    if (!P.trace || prev.done) return;
+    double* R = P.trace + ((long long)w * P.state_stride + slot) * 8;
+    if (slot == 0) { R[0] = 0.5 * a.lin_cost; R[1] = 0.0; R[2] = prev.radius; R[3] = 0.0; R[4] = 0.0; R[5] = 1.0; R[7] = 0.0; }
+    R[6] = __longlong_as_double((long long)a.gmax_bits);
+    double* N = R + 8;
+    const bool valid = a.chol_fail == 0 && a.mcc > 0.0;
+    const double cc = valid ? 0.5 * (a.lin_cost - a.cand_cost) : 0.0;
+    const bool judged = valid && !(next.done && (next.termination == 1 || next.termination == 2));
+    N[0] = next.x_cost; N[1] = cc; N[2] = next.radius; N[3] = valid ? sqrt(a.step_norm2) : 0.0;
+    N[4] = judged ? cc / a.mcc : 0.0; N[5] = next.n_success > prev.n_success ? 1.0 : 0.0; N[6] = -1.0; N[7] = a.mcc;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -390,9 +408,10 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
         __syncthreads();
         IterAcc a = P.acc[(long long)T.w * P.state_stride + slot - 1];
         a.cand_cost += s_part[0]; a.mcc += s_part[1]; a.step_norm2 += s_part[2]; a.cand_norm2 += s_part[3];
-        st = lm_decide(P.states[(long long)T.w * P.state_stride + slot - 1], a, P.o);
+        const LmState prev = P.states[(long long)T.w * P.state_stride + slot - 1];
+        st = lm_decide(prev, a, P.o);
         __syncthreads();  // s_part is reused below
-        if (T.first_of_window && tid == 0) P.states[(long long)T.w * P.state_stride + slot] = st;
+        if (T.first_of_window && tid == 0) { P.states[(long long)T.w * P.state_stride + slot] = st; trace_write(P, T.w, slot - 1, prev, a, st); }
     }
     if (st.done) return;
     SADVIO_TS(3, 33);
@@ -1827,6 +1846,7 @@ __global__ void k_reset(DevPtrs P) {
     const long long nta = 2LL * P.n_tiles * (long long)(sizeof(TileAcc) / 8);
     for (long long i = t; i < nta; i += nt) ta[i] = 0ull;
     const long long ns = (long long)P.n_win * P.state_stride;
+    if (P.trace) for (long long i = t; i < ns * 8; i += nt) P.trace[i] = 0.0;
     for (long long i = t; i < ns; i += nt) {
         LmState z{};
         if (i % P.state_stride == 0) { z.radius = P.o.initial_radius; z.decrease_factor = 2.0; }
@@ -1876,8 +1896,10 @@ __global__ void k_decide(DevPtrs P, int slot, int final) {
         else {
             IterAcc a = P.acc[(long long)w * P.state_stride + slot];
             a.cand_cost += s4[0]; a.mcc += s4[1]; a.step_norm2 += s4[2]; a.cand_norm2 += s4[3];
-            f = lm_decide(P.states[(long long)w * P.state_stride + slot], a, P.o);
+            const LmState prev = P.states[(long long)w * P.state_stride + slot];
+            f = lm_decide(prev, a, P.o);
             P.states[(long long)w * P.state_stride + slot + 1] = f;
+            trace_write(P, w, slot, prev, a, f);
         }
         if (final) {
             FinalRec rec;

@@ -57,3 +57,23 @@ def cached_oracle_solve(name, oracle_lib, w, opts, dense_prior=None, n_threads=8
                             final_cost=s.final_cost, pose=ref["pose"], lmk=ref["lmk"], dv=ref["dv"], dba=ref["dba"],
                             dbg=ref["dbg"])
     return ref
+
+
+def assert_trace_matches(trace, log, termination, cost_rtol=1e-9):
+    """Device iteration log (Backend.get_trace) against a reference log of the same layout (oracle / twin): SURVEY.md
+    §8(d) — the cost after each iteration equal to 1e-9 — plus radius, step norm, step quality, accept / reject, gradient
+    max and model cost change. The attempt that ends a solve through the function / parameter tolerance is not applied, and
+    the sources log its cost / radius / quality columns differently: those are compared up to the row before it."""
+    trace, log = np.asarray(trace), np.asarray(log)
+    assert trace.shape == log.shape, (trace.shape, log.shape)
+    n = len(log) - (1 if termination in (1, 2) else 0)
+    c0 = max(abs(log[0, 0]), 1e-300)
+    assert np.allclose(trace[:n, 0], log[:n, 0], rtol=cost_rtol, atol=0), np.abs(trace[:n, 0] / log[:n, 0] - 1).max()
+    assert np.allclose(trace[:, 1], log[:, 1], rtol=1e-6, atol=1e-9 * c0)
+    assert np.allclose(trace[:n, 2], log[:n, 2], rtol=1e-6)
+    assert np.allclose(trace[:, 3], log[:, 3], rtol=1e-7, atol=1e-12)
+    assert np.allclose(trace[:n, 4], log[:n, 4], rtol=1e-5, atol=1e-9)
+    assert np.array_equal(trace[:n, 5], log[:n, 5])
+    m = min(n, len(log) - 1)      # the state after the last attempt is not linearised on the device (-1)
+    assert np.allclose(trace[:m, 6], log[:m, 6], rtol=1e-7)
+    assert np.allclose(trace[:, 7], log[:, 7], rtol=1e-7, atol=1e-12 * c0)

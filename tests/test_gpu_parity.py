@@ -8,7 +8,7 @@ against the committed golden vectors. Tolerances (FP64 everywhere):
 import numpy as np
 import pytest
 
-from golden_util import load_window
+from golden_util import assert_trace_matches, load_window
 from sadvio_amd import capi, synthetic
 
 pytestmark = pytest.mark.gpu
@@ -80,6 +80,8 @@ def test_golden_vectors(backend_cls, name):
         assert np.isclose(s.initial_cost, gs[4], rtol=1e-10) and np.isclose(s.final_cost, gs[5], rtol=1e-9)
         assert np.abs(d["pose"] - g[f"{tag}_pose"]).max() <= POSE_TOL
         assert np.abs(d["lmk"] - g[f"{tag}_lmk"]).max() <= LMK_TOL
+        # per-iteration parity against the long-double twin's log (cost after each iteration to 1e-9)
+        assert_trace_matches(be.get_trace(0), g[f"{tag}_log"], int(gs[3]))
     kf_id, lmk_id = be.get_ids(0)
     assert np.array_equal(kf_id, g["kf_id"]) and np.array_equal(lmk_id, g["lmk_id"])
     be.close()
@@ -205,3 +207,23 @@ def test_error_paths(backend_cls):
     with pytest.raises(capi.SadvioError):
         be.set_windows([w])             # observation index out of range
     be.close()
+
+
+@pytest.mark.parametrize("factor", [capi.FACTOR_PIXEL, capi.FACTOR_ANGULAR])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_iteration_trace_matches_oracle(backend_cls, oracle_lib, factor, use_graph):
+    """The device-side LM loop iterate by iterate (sadvio_ba_get_trace) on solves with accepted AND rejected steps: a
+    small initial trust region that has to grow, a tight function tolerance, a strongly perturbed start."""
+    w = synthetic.make_window(n_kf=8, n_lmk=600, obs_per_lmk=5, seed=31, factor=factor, lmk_perturb=0.3, rot_perturb_deg=2.0)
+    for radius, ftol in ((1e4, 1e-3), (1e-2, 1e-6), (1e-4, 1e-9)):
+        opts = capi.reference_options()
+        opts.initial_trust_region_radius = radius; opts.function_tolerance = ftol
+        be = backend_cls(device=0, use_graph=use_graph)
+        be.set_windows([w, w])          # a batch: both windows must carry their own log
+        sums = be.solve(opts)
+        ref = oracle_lib.solve(w, opts)
+        rs = ref["summary"]
+        for k in range(2):
+            assert (sums[k].iterations, sums[k].termination, sums[k].num_unsuccessful_steps) == (rs.iterations, rs.termination, rs.num_unsuccessful_steps)
+            assert_trace_matches(be.get_trace(k), ref["log"], rs.termination)
+        be.close()

@@ -4,7 +4,7 @@ Checked against the CPU oracle on the same inputs, on the LDS-resident path (N_p
 import numpy as np
 import pytest
 
-from golden_util import cached_oracle_solve
+from golden_util import assert_trace_matches, cached_oracle_solve
 from sadvio_amd import capi, synthetic
 from vio_helpers import make_vio_window
 
@@ -42,6 +42,7 @@ def compare(backend_cls, oracle_lib, w, opts, vio=False, golden=None):
         be.set_windows([w])
         s = be.solve(opts)[0]
         d = be.get_deltas(0)
+        trace = be.get_trace(0)
     finally:
         be.close()
     ref = (cached_oracle_solve(golden, oracle_lib, w, opts, dense_prior=w.dense_prior) if golden
@@ -52,6 +53,8 @@ def compare(backend_cls, oracle_lib, w, opts, vio=False, golden=None):
     assert (s.iterations, s.termination, s.num_successful_steps) == (rs.iterations, rs.termination, rs.num_successful_steps)
     assert np.abs(d["pose"] - ref["pose"]).max() <= POSE_TOL
     assert np.abs(d["lmk"] - ref["lmk"]).max() <= LMK_TOL
+    if "log" in ref:   # live oracle solve: iterate-by-iterate parity, incl. the attempts that follow a rejected step
+        assert_trace_matches(trace, ref["log"], rs.termination, cost_rtol=1e-8)
     if vio:
         for k in ("dv", "dba", "dbg"):
             assert np.abs(d[k] - ref[k]).max() <= POSE_TOL

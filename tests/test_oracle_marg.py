@@ -139,3 +139,63 @@ def test_sym_eig_against_numpy(oracle_lib):
         ev, V = oracle_lib.sym_eig(A)
         assert np.allclose(ev, np.linalg.eigvalsh(A), rtol=1e-10, atol=1e-10 * max(1, ev.max()))
         assert np.allclose(V @ np.diag(ev) @ V.T, A, rtol=1e-9, atol=1e-9 * np.abs(A).max())
+
+
+def test_eigen_cut_deviation_reproduces_the_reference_formula_in_exact_arithmetic(oracle_lib):
+    """oracle/marg.c and the HIP path cut eigenvalues at max(1e-12, n eps lambda_max) instead of the reference's absolute
+    1e-12 (marginalization.cpp:237,322). Demonstrated on the reference's own fixture (marginalization_test.cpp:26-168):
+      (1) evaluated with 50-digit arithmetic (oracle/twin.py Jacobians, mpmath eigen-decomposition) the reference's formula
+          WITH ITS OWN absolute cut drops an exactly-null eigenvalue of Amm (|lambda_0| < 1e-40) and yields Ak_exact;
+      (2) the restatement's Ak equals Ak_exact to 1e-8 (the reference's tolerance on Ak, :313);
+      (3) in float64 that eigenvalue computes to +-1e-11: which side of the absolute 1e-12 it lands on flips under
+          rounding-level input perturbations, and when it lands above, 1 / 1e-11 times the (1e-6) rounding error of the
+          eigenvector changes Ak by O(1) — the float64 result of the reference's line is a coin flip between Ak_exact and
+          garbage on its own fixture. The noise-floor cut always returns Ak_exact; that is the deviation, and why."""
+    mpmath = pytest.importorskip("mpmath")
+    from oracle import twin
+    w = toy_window()
+    keep, marg = pre_marginalize(w, 0)
+    out = run_marg(oracle_lib, w, 0, keep, marg)
+    m, n = out["m"], out["n"]
+    # A = sum J^T J over frame0's reprojection factors of the marginalised + kept landmarks (computeInformationAndGradient,
+    # marginalization.cpp:145-211) in 50-digit arithmetic; column layout [frame0 6 | marg landmarks | kept landmarks]
+    B = twin.Backend("mp", 50)
+    col = {}
+    for q, l in enumerate(marg):
+        col[l] = 6 + 3 * q
+    for q, l in enumerate(keep):
+        col[l] = m + 3 * q
+    A = B.zeros((m + n, m + n))
+    z6, z3 = np.zeros(6), np.zeros(3)
+    for l in list(marg) + list(keep):
+        for o in range(w.lmk_obs_ptr[l], w.lmk_obs_ptr[l + 1]):
+            if w.obs_kf[o] != 0:
+                continue
+            c = int(w.obs_cam[o])
+            _, Jp, Jl, _ = twin.pixel_factor(B, w.kf_T_f_w[0], w.cam_K[c], w.cam_T_s_f[c], w.lmk_p[l], w.obs_meas[o], w.cam_sigma[c], z6, z3)
+            J = B.zeros((2, m + n))
+            J[:, 0:6] = Jp
+            J[:, col[l]: col[l] + 3] = Jl
+            A = A + J.T @ J
+    assert np.abs(B.f(A) - out["A"]).max() <= 1e-9 * np.abs(out["A"]).max()
+    Amm = mpmath.matrix((0.5 * (A[:m, :m] + A[:m, :m].T)).tolist())
+    E, Q = mpmath.eigsy(Amm)
+    ev = [E[i] for i in range(m)]
+    assert min(abs(e) for e in ev) < mpmath.mpf(10) ** -40 and sorted(ev)[1] > 1       # one exactly-null direction
+    inv = Q * mpmath.diag([1 / e if e > mpmath.mpf("1e-12") else 0 for e in ev]) * Q.T   # the reference's line, its own cut
+    Arm = mpmath.matrix(A[m:, :m].tolist())
+    Ak_exact = mpmath.matrix(A[m:, m:].tolist()) - Arm * inv * Arm.T
+    Ak_exact = np.array([[float(Ak_exact[i, j]) for j in range(n)] for i in range(n)])
+    assert np.abs(out["Ak"] - Ak_exact).max() <= 1e-8 * np.abs(Ak_exact).max()
+    # (3) the float64 evaluation of the same line
+    A64 = out["A"]
+    Amm64 = 0.5 * (A64[:m, :m] + A64[:m, :m].T)
+    ev64, V = np.linalg.eigh(Amm64)
+    assert abs(ev64[0]) < 1e-9 and abs(ev64[0]) > 1e-13      # the "zero" computes to ~1e-11, ten times the absolute cut
+    rng = np.random.default_rng(0)
+    hits = sum(np.linalg.eigvalsh(0.5 * (P + P.T))[0] > 1e-12 for P in (Amm64 * (1 + 1e-16 * rng.standard_normal(Amm64.shape)) for _ in range(100)))
+    assert 10 < hits < 90                                    # a coin flip
+    kept = ev64.copy(); kept[0] = abs(ev64[0])               # the flip that lets 1 / 1e-11 in
+    inv64 = V @ np.diag(1.0 / kept) @ V.T
+    Ak_bad = A64[m:, m:] - A64[m:, :m] @ inv64 @ A64[m:, :m].T
+    assert np.abs(Ak_bad - Ak_exact).max() > 1e-3
