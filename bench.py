@@ -5,9 +5,12 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N)
 
-A "step" is one complete solve (10 LM step attempts, every early exit disabled) of the windows resident on this
-GPU; the windows are uploaded to HBM before the timed region. N > 1 shards independent windows (one set per
-GPU, weak scaling, no data-path collective — BASELINE.json north_star: "independent sub-windows / keyframe
+A "step" is --solves-per-step (default 100) back-to-back complete solves (each: 10 LM step attempts, every early exit
+disabled, one hipGraph launch) of the windows resident on this GPU, so that the driver's 20-step run times ~1 s of GPU
+work instead of 17 ms; `value` (BA iterations/s) does not depend on that grouping, `ms_per_step` is per step and
+`ms_per_solve` per solve. The windows are uploaded to HBM before the timed region (`upload_inclusive` reports the rate with
+set_windows + get_deltas inside, the way the reference's own timer brackets problem construction, slamBiMono.cpp:273-275).
+N > 1 shards independent windows (one set per GPU, weak scaling, no data-path collective — BASELINE.json north_star: "independent sub-windows / keyframe
 batches shard across the 8 GPUs"); torch.distributed (backend "nccl" = RCCL) is used only for the barriers and
 the max-over-ranks of the elapsed time.
 
@@ -17,6 +20,8 @@ One JSON line is printed by rank 0. Besides the contract's fields it carries
   cpu_baseline  the CPU oracle (a port of the reference's algorithm, the reference itself cannot be built
                 here) timed on this box's host cores on the same window
   batched       the same metric with 64 independent windows per launch (the bandwidth-bound regime)
+  marginalize   sadvio_ba_marginalize on a config-3 shaped window (12-KF VIO, 300 kept landmarks) with the oracle's CPU time beside it
+  sharded_window (N > 1 only) ONE config-4 window landmark-sharded over the ranks: RCCL all-reduce of the reduced system per LM step
 """
 import argparse
 import json
@@ -41,14 +46,17 @@ def algorithmic_bytes(n_obs, n_lmk, n_p):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--solves-per-step", type=int, default=100, help="complete GN-10 solves per timed step")
     ap.add_argument("--windows", type=int, default=1, help="independent config-2 windows per GPU in the timed run")
     ap.add_argument("--batch", type=int, default=64, help="windows per GPU of the extra batched measurement (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard-window", action="store_true",
-                    help="instead of independent windows: ONE config-4 window (100 KF x 50k landmarks) landmark-sharded "
-                         "over the ranks, reduced system all-reduced over RCCL per LM step (strong scaling)")
+                    help="ONLY the sharded measurement: ONE config-4 window (100 KF x 50k landmarks) landmark-sharded "
+                         "over the ranks, reduced system all-reduced over RCCL per LM step (strong scaling). With N > 1 the "
+                         "default run reports it as the `sharded_window` object next to the independent-window line")
+    ap.add_argument("--no-marginalize", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -77,12 +85,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_solves(be, opts, steps, warmup):
-        for _ in range(warmup):
+    def timed_solves(be, opts, steps, warmup, per_step=1):
+        for _ in range(warmup * per_step):
             be.solve(opts)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(steps * per_step):
             be.solve(opts)
         torch.cuda.synchronize()
         barrier()
@@ -94,7 +102,13 @@ def main():
         return dt
 
     if args.shard_window:
-        return bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves)
+        rec = bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves)
+        if rank == 0:
+            print(json.dumps(rec))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     opts = capi.gn_options(GN_ITERS)
     # every rank owns its own windows (different seeds): weak scaling over independent sub-windows
@@ -102,13 +116,26 @@ def main():
     wins = [synthetic.make_window(seed=base_seed + i) for i in range(args.windows)]
     be = capi.Backend(device=local_rank, use_graph=True)  # one hipGraph launch per solve
     be.set_windows(wins)
-    dt = timed_solves(be, opts, args.steps, args.warmup)
+    sps = max(1, args.solves_per_step)
+    dt = timed_solves(be, opts, args.steps, args.warmup, sps)
     sums = be.solve(opts)
+    # upload-inclusive rate: set_windows (validation, tiling, one pinned staging copy) + solve + read-back per solve
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_up = 50
+    for _ in range(n_up):
+        be.set_windows(wins)
+        be.solve(opts)
+        be.get_deltas(0)
+    dt_up = (time.perf_counter() - t0) / n_up
     be.close()
-    iters_per_step = sum(s.iterations for s in sums)
-    total_iters = iters_per_step * args.steps * world
+    iters_per_solve = sum(s.iterations for s in sums)
+    total_iters = iters_per_solve * args.steps * sps * world
     value = total_iters / dt
     ms_per_step = 1e3 * dt / args.steps
+    ms_per_solve = ms_per_step / sps
+    # N > 1: the collective path as well (same processes, same communicator): config 4 sharded over the ranks
+    sharded = bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves) if world > 1 else None
 
     out = None
     if rank == 0:
@@ -176,31 +203,48 @@ def main():
             from oracle import oracle
             oracle.build()
             ncores = os.cpu_count() or 1
+            usable = len(os.sched_getaffinity(0))      # the cores this process may actually run on
             res = {}
-            for thr in (1, 4):  # 4 = the reference's Ceres num_threads (AOptimizer.cpp:323)
+            counts = sorted({1, 4, min(usable, 16), min(usable, 64)})   # 4 = the reference's Ceres num_threads (AOptimizer.cpp:323)
+            for thr in counts:
                 oracle.solve(w0, opts, n_threads=thr)
                 t0 = time.perf_counter()
                 n = 0
-                while time.perf_counter() - t0 < 6.0:
+                while time.perf_counter() - t0 < 4.0:
                     r = oracle.solve(w0, opts, n_threads=thr)
                     n += r["summary"].iterations
                 res[thr] = n / (time.perf_counter() - t0)
             best = max(res, key=res.get)
             cpu = {"value": round(res[best], 2), "unit": "BA iterations/s", "cores": best, "kind": "port",
-                   "sample": f"config-2 window, GN-{GN_ITERS} solves repeated for ~6 s per thread count "
-                             f"(1 thread: {res[1]:.1f} it/s, 4 threads: {res[4]:.1f} it/s); host has {ncores} cores",
-                   "note": "reference (Ceres/Eigen) cannot be built here; oracle = C restatement, explicit Schur"}
+                   "sample": f"config-2 window, GN-{GN_ITERS} solves repeated for ~4 s per thread count",
+                   "threads_it_per_s": {str(k): round(v, 1) for k, v in res.items()},
+                   "host_cores": ncores, "usable_cores": usable,
+                   "ceres_on_box": ceres_probe(),
+                   "sparse_normal_cholesky_emulation": sparse_normal_baseline(oracle, w0, opts),
+                   "note": "the reference (Ceres 2.2 / Eigen / SuiteSparse) cannot be built here or on the GPU box; "
+                           "`value` = the C oracle (explicit Schur complement + dense Cholesky, OpenMP over landmarks); "
+                           "sparse_normal_cholesky_emulation = the reference's own linear-solver choice (un-reduced J^T J + D, "
+                           "sparse direct factorisation) with SciPy's SuperLU standing in for CHOLMOD"}
+        marg = None
+        if not args.no_marginalize and world == 1:
+            marg = marginalize_leg(local_rank, cpu is not None)
         out = {
-            "metric": "BA iterations/sec (ms/solve in ms_per_step), 20-KF/8k-landmark window",
+            "metric": "BA iterations/sec (ms/solve in ms_per_solve), 20-KF/8k-landmark window",
             "value": round(value, 1), "unit": "BA iterations/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "ms_per_solve": round(ms_per_solve, 5),
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "synthetic 20 KF x 8000 landmarks x 40000 reprojection factors (pixel), "
                                    f"GN {GN_ITERS} iters (LM step attempts, early exits disabled)",
-                       "windows_per_gpu": args.windows, "iterations_per_solve": iters_per_step // max(1, args.windows),
+                       "solves_per_step": sps,
+                       "windows_per_gpu": args.windows, "iterations_per_solve": iters_per_solve // max(1, args.windows),
                        "parallelism": f"independent windows x{world}" if world > 1 else "single window",
                        "n_kf": w0.n_kf, "n_lmk": w0.n_lmk, "n_obs": w0.n_obs, "reduced_dim": n_p},
             "roofline": roofline, "cpu_baseline": cpu, "batched": batched,
+            "upload_inclusive": {"value": round(iters_per_solve / dt_up, 1), "unit": "BA iterations/s",
+                                 "ms_per_solve": round(1e3 * dt_up, 4),
+                                 "what": "set_windows (host flatten -> HBM) + solve + get_deltas per solve, rank 0"},
+            "marginalize": marg, "sharded_window": sharded,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
@@ -211,8 +255,8 @@ def main():
 
 
 def bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves):
-    """BASELINE.json config 4: one 100-KF / 50k-landmark window spanning the GPUs of the node."""
-    import torch
+    """BASELINE.json config 4: one 100-KF / 50k-landmark window spanning the GPUs of the node. Returns the
+    record (rank 0) — printed as its own line by --shard-window, nested as `sharded_window` otherwise."""
     from sadvio_amd import capi, sharding, synthetic
     opts = capi.gn_options(GN_ITERS)
     w = synthetic.make_window(n_kf=100, n_lmk=50000, length=50.0, band=6, seed=4)  # same seed on every rank
@@ -222,27 +266,118 @@ def bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_sol
         dist.broadcast_object_list(uid, src=0)
     be.comm_init_rccl(rank, world, uid[0])
     be.set_windows([sharding.shard_window(w, rank, world)])
-    dt = timed_solves(be, opts, args.steps, args.warmup)
+    steps = max(5, args.steps)
+    dt = timed_solves(be, opts, steps, 2)
     s = be.solve(opts)[0]
     be.close()
-    if rank == 0:
-        n_p = 6 * int((w.kf_const == 0).sum())
-        print(json.dumps({
-            "metric": "BA iterations/sec, ONE 100-KF/50k-landmark window sharded over the GPUs",
-            "value": round(s.iterations * args.steps / dt, 1), "unit": "BA iterations/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic 100 KF x 50000 landmarks x 250000 reprojection factors, GN 10 iters, "
-                                   "landmark-sharded, RCCL all-reduce of the reduced system per LM step",
-                       "parallelism": f"window sharded x{world}", "reduced_dim": n_p,
-                       # only the band of the reduced system travels (k_band_pack): N_p x bw with bw = 60 for this
-                       # window's 10-key-frame co-visibility, + gradient / diagonal vectors + the per-rank partials
-                       "allreduce_bytes_per_step": 8 * (n_p * 60 + 3 * n_p + 4 * world) + 32 * world,
-                       "allreduce_bytes_per_step_full_matrix": 8 * (n_p * n_p + 3 * n_p + 4 * world) + 32 * world},
-            "final_cost": s.final_cost}))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    n_p = 6 * int((w.kf_const == 0).sum())
+    return {
+        "metric": "BA iterations/sec, ONE 100-KF/50k-landmark window sharded over the GPUs",
+        "value": round(s.iterations * steps / dt, 1), "unit": "BA iterations/s", "n_gpus": world,
+        "steps": steps, "warmup": 2, "ms_per_step": round(1e3 * dt / steps, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "synthetic 100 KF x 50000 landmarks x 250000 reprojection factors, GN 10 iters, "
+                               "landmark-sharded, RCCL all-reduce of the reduced system per LM step",
+                   "parallelism": f"window sharded x{world}", "reduced_dim": n_p, "rccl_ranks": world,
+                   "collectives_per_lm_step": 2,
+                   # only the band of the reduced system travels (k_band_pack): N_p x bw with bw = 60 for this
+                   # window's 10-key-frame co-visibility, + gradient / diagonal vectors + the per-rank partials
+                   "allreduce_bytes_per_step": 8 * (n_p * 60 + 3 * n_p + 4 * world) + 32 * world,
+                   "allreduce_bytes_per_step_full_matrix": 8 * (n_p * n_p + 3 * n_p + 4 * world) + 32 * world},
+        "final_cost": s.final_cost}
+
+
+def ceres_probe():
+    """Is a Ceres / Eigen installation present on this box (the B1 'Ceres CPU' line of BASELINE.md §3 needs one)?"""
+    import ctypes.util
+    import glob
+    libs = {n: ctypes.util.find_library(n) for n in ("ceres", "cholmod")}
+    eigen = bool(glob.glob("/usr/include/eigen3/Eigen/Core") or glob.glob("/usr/local/include/eigen3/Eigen/Core"))
+    return {"libceres": libs["ceres"], "libcholmod": libs["cholmod"], "eigen_headers": eigen,
+            "available": bool(libs["ceres"] and eigen)}
+
+
+def sparse_normal_baseline(oracle, w, opts, budget_s=5.0):
+    """LM iterations/s of the reference's linear-solver CHOICE on the CPU: Jacobians from the oracle's C evaluation, then the
+    UN-REDUCED normal equations (J^T J + D) y = J^T r factorised by a sparse direct solver — what
+    ceres::SPARSE_NORMAL_CHOLESKY does with CHOLMOD (AOptimizer.cpp:316) — here SciPy's SuperLU in symmetric mode with the
+    fill-free elimination order CHOLMOD's AMD finds on bundle-adjustment systems (landmark blocks first, poses last).
+    One thread; the split shows where the time goes."""
+    try:
+        import numpy as np
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spl
+    except Exception as e:  # pragma: no cover
+        return {"error": str(e)}
+    kc = np.asarray(w.kf_const).astype(bool)
+    n_pose = 6 * int((~kc).sum())
+    n = n_pose + 3 * w.n_lmk
+    kf_col = np.cumsum(~kc) * 6 - 6 + 3 * w.n_lmk      # poses last
+    kf_col[kc] = -1
+    lmk_of = np.repeat(np.arange(w.n_lmk), np.diff(w.lmk_obs_ptr))
+    free = kf_col[w.obs_kf] >= 0
+    rows = np.arange(2 * w.n_obs).reshape(-1, 2)
+    ri = np.concatenate([np.repeat(rows[free], 6, axis=1).ravel(), np.repeat(rows, 3, axis=1).ravel()])
+    ci = np.concatenate([(kf_col[w.obs_kf][free, None, None] + np.arange(6)[None, None, :] + np.zeros((1, 2, 1), int)).ravel(),
+                         (3 * lmk_of[:, None, None] + np.arange(3)[None, None, :] + np.zeros((1, 2, 1), int)).ravel()])
+    t_all, n_it, split = time.perf_counter(), 0, np.zeros(3)
+    while time.perf_counter() - t_all < budget_s:
+        t0 = time.perf_counter()
+        r, Jp, Jl, _ = oracle.linearize(w)
+        t1 = time.perf_counter()
+        J = sp.csr_matrix((np.concatenate([Jp[free].ravel(), Jl.ravel()]), (ri, ci)), shape=(2 * w.n_obs, n))
+        H = (J.T @ J).tocsc()
+        H = H + sp.diags(np.clip(H.diagonal(), 1e-6, 1e32) / 1e4)
+        t2 = time.perf_counter()
+        y = spl.splu(H, permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True)).solve(J.T @ r.ravel())
+        t3 = time.perf_counter()
+        assert np.isfinite(y).all()
+        split += [t1 - t0, t2 - t1, t3 - t2]
+        n_it += 1
+    dt = time.perf_counter() - t_all
+    return {"value": round(n_it / dt, 2), "unit": "BA iterations/s", "cores": 1,
+            "ms_linearize_assemble_factorize": [round(float(1e3 * x / n_it), 1) for x in split],
+            "sample": f"{n_it} linearise + assemble + factorise + solve passes on the config-2 window, {n} unknowns"}
+
+
+def marginalize_leg(device, with_cpu):
+    """sadvio_ba_marginalize (K8) on a config-3 shaped window: 12-KF VIO, frame0's IMU + visual factors + previous prior,
+    m = 135 marginalised / n = 915 kept columns (300 kept landmarks); the oracle's CPU restatement of
+    Marginalization::computeSchurComplement etc. (marginalization.cpp:213-265,318-342) timed beside it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    from sadvio_amd import capi
+    from vio_helpers import make_vio_window
+    from marg_helpers import with_lonely_landmarks
+    from test_oracle_marg import pre_marginalize
+    w = with_lonely_landmarks(make_vio_window(n_kf=12, n_lmk=7200, seed=6), 11, 40)
+    keep, marg = pre_marginalize(w, 11)
+    keep = keep[:300]
+    imu = [f for f in w.imu_factors if f["kf_i"] == 11 and f["kf_j"] == 10][0]
+    be = capi.Backend(device=device)
+    be.set_windows([w])
+    times = []
+    for _ in range(4):
+        t = time.perf_counter()
+        g = be.marginalize(0, 11, marg, keep, kf_keep=10, marg_has_imu=True, imu=imu, priors=w.pose_priors)
+        times.append(time.perf_counter() - t)
+    be.close()
+    rec = {"gpu_ms": round(1e3 * min(times[1:]), 2), "m": int(g["m"]), "n": int(g["n"]), "n_full": int(g["n_full"]),
+           "jacobi_sweeps": list(g["sweeps"]), "workload": "config-3 shape: 12-KF VIO window, 300 kept landmarks, IMU + visual factors of frame0"}
+    if with_cpu:
+        from oracle import oracle
+        t = time.perf_counter()
+        ref = oracle.marginalize(w, 11, marg, keep, kf_keep=10, marg_has_imu=True, imu=imu, priors=w.pose_priors)
+        rec["cpu_oracle_ms"] = round(1e3 * (time.perf_counter() - t), 1)
+        rec["cpu_kind"] = "port (cyclic Jacobi eigen-solver, one thread; the reference uses Eigen::SelfAdjointEigenSolver)"
+        t = time.perf_counter()
+        A = np.asarray(ref["Ak"])
+        np.linalg.eigh(0.5 * (A + A.T))
+        rec["cpu_lapack_eigh_of_Ak_ms"] = round(1e3 * (time.perf_counter() - t), 1)
+        rec["information_rel_diff_vs_oracle"] = float(np.abs(g["J"].T @ g["J"] - ref["J"].T @ ref["J"]).max() / np.abs(ref["J"].T @ ref["J"]).max())
+    return rec
 
 
 if __name__ == "__main__":

@@ -48,7 +48,12 @@ def cached_oracle_solve(name, oracle_lib, w, opts, dense_prior=None, n_threads=8
             s = SimpleNamespace(iterations=int(z["iterations"]), termination=int(z["termination"]),
                                 num_successful_steps=int(z["num_successful_steps"]),
                                 initial_cost=float(z["initial_cost"]), final_cost=float(z["final_cost"]))
-            return {"summary": s, "pose": z["pose"], "lmk": z["lmk"], "dv": z["dv"], "dba": z["dba"], "dbg": z["dbg"]}
+            out = {"summary": s, "pose": z["pose"], "lmk": z["lmk"], "dv": z["dv"], "dba": z["dba"], "dbg": z["dbg"]}
+            if "lmk_stride" in z.files:     # config 5: every lmk_stride-th landmark + the norm of the full vector are stored
+                out.update(lmk_stride=int(z["lmk_stride"]), lmk_sq_norm=float(z["lmk_sq_norm"]))
+            if "log" in z.files:
+                out["log"] = z["log"]
+            return out
     ref = oracle_lib.solve(w, opts, dense_prior=dense_prior, n_threads=n_threads)
     if write:
         s = ref["summary"]
