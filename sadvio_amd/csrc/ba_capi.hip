@@ -452,7 +452,7 @@ int layout_reduced(sadvio_ba_handle* h) {
         // full row-major matrix (lower triangle used) that the library factorisation works on in place
         d.ld = d.Np > MAX_LDS_NP ? d.Np : 0;
         d.S_off = s_b; d.red_off = red_b;
-        red_b += d.Np; s_b += d.ld ? (((long long)d.Np * d.Np + 1) & ~1LL) : (((long long)d.Np * (d.Np + 1) / 2 + 1) & ~1LL);
+        red_b += d.Np; s_b += d.ld ? (((long long)d.Np * d.Np + 1) & ~1LL) : (long long)c16_size(d.Np);   // LDS-sized systems: the tile-packed image of chol16.h
         if (d.ld) h->n_big++; else h->max_np = std::max(h->max_np, d.Np);
         for (int ti = d.tile_begin; ti < d.tile_end; ti++) {
             Tile& t = h->tiles[ti];
@@ -1686,8 +1686,9 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     }
     if (getenv("SADVIO_DEBUG")) fprintf(stderr, "[sadvio dbg] lds_build %zu B, Rp %d, strip_doubles %d, max_tile_kf %d, max_tile_free %d, tiles %d\n", lds_build, Rp, strip_doubles, mtk, h->max_tile_free, n_tiles);
     const size_t lds_back = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)mtk * 18) + 16;
-    const size_t npq = (size_t)h->max_np + 5;   // VIO windows are padded to a multiple of 6 inside k_solve
-    const size_t lds_solve = sizeof(double) * ((npq + 2) * 6 + (npq + 1) * (npq + 2) / 2 + 4 * npq + (npq / 5 + 1) * 36) + 64;
+    // k_solve<0>: tile-packed image + y / gf / hd / xs + the chol16 exchange areas
+    const size_t npq = (size_t)h->max_np;
+    const size_t lds_solve = sizeof(double) * ((size_t)c16_size((int)npq) + 4 * npq + 1 + 2 * C16_PUB + 64 + 16 * (size_t)c16_blocks((int)npq + 1)) + 64;
     // robust loss or prior-kept landmarks in the batch: the kernels carrying those (rare) paths
     bool any_pseudo = false;
     for (const auto& v : h->sp_elim) for (char e : v) any_pseudo |= e != 0;

@@ -1,0 +1,340 @@
+// chol16.h — in-LDS Cholesky solve of the reduced pose system (N <= 174) on 16x16 tiles, one 512-thread workgroup.
+//
+// Layout ("tile-packed"): the lower block triangle of the (N + 1) x (N + 1) matrix [S ; rhs^T] in 16 x 16 tiles,
+// tile (I, J), I >= J, at ((I (I + 1) / 2 + J) * 256 doubles, COLUMN-major inside the tile (element (r, c) at c * 16 + r).
+// A wave holds a tile as 4 registers per lane: lane l = 16 k + i, register s <-> element (i, 4 s + k) ("X layout") — the
+// register s of a tile is 64 consecutive doubles (conflict-free ds_read_b64 / ds_write_b64), and it is at the same time
+//   * the A / B operand of v_mfma_f64_16x16x4_f64 for the 4 columns 4 s .. 4 s + 3 of the tile, and
+//   * the accumulator layout of the TRANSPOSED tile (D[row = k + 4 s][col = i], measured: scripts/probe/uarch_probe.hip),
+// so  X(C) += mfma(A = X(P)[s], B = X(Q)[s])  accumulates  C += Q P^T  with no data movement between products, and a
+// SYMMETRIC tile's register s is directly the operand of its own rank-4 update.
+//
+// Factorisation (right-looking, block columns of 16, 4-column steps inside a block):
+//   pivot wave (wave 0)  one diagonal tile D in registers. Per 4-column step: the 4 x 4 pivot block goes to SGPRs
+//                        (v_readlane), its Cholesky factor is computed uniformly (v_rsq_f64 + 2 Newton steps per column:
+//                        65 cycles, the dependency floor), every lane gets the 4 entries of its row with three
+//                        v_permlane{16,32}_swap pairs and forward-substitutes them (y = a L_ss^-T), D -= y y^T is ONE MFMA.
+//                        The step's y (= 4 columns of L_kk) and the 10 numbers of the 4 x 4 factor are published in LDS.
+//   all waves            "replay" the same 4 steps on the panel tiles below (A_Ik -> L_Ik = A_Ik L_kk^-T, one MFMA per step)
+//                        and on an identity tile (-> L_kk^-T, kept in the dead diagonal tile for the back-substitution);
+//   bulk waves           trailing update C_IJ -= L_Ik L_Jk^T, 4 MFMAs per tile, while the pivot wave updates and factors
+//                        the next diagonal tile (look-ahead).
+// Two workgroup barriers per block column (8 for N = 114 instead of 38 with 6-column blocks). The right-hand side is row N
+// of the matrix (forward substitution for free); columns >= N of the last tile are dummy pivots (inverse 0: no effect).
+// Back-substitution: thread c owns y_c; per block, x_J = L_JJ^-T v_J by 16 lanes, y_c -= L_Jc^T x_J by everyone.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sadvio {
+
+typedef double c16_d4 __attribute__((ext_vector_type(4)));
+
+constexpr int C16_STEP = 64 + 64;        // published per 4-column step: y (the step's 4 columns of L_kk) + the M = L_ss^-1 operand, one double per lane each
+constexpr int C16_PUB = 4 * C16_STEP;    // per block column; double-buffered by block parity
+
+__host__ __device__ constexpr int c16_tile(int I, int J) { return ((I * (I + 1)) >> 1) + J; }
+// element (i, j), i >= j, of the tile-packed lower triangle (diagonal tiles: the lower half; see c16_symmetrize)
+__host__ __device__ constexpr int c16_index(int i, int j) { return (c16_tile(i >> 4, j >> 4) << 8) + ((j & 15) << 4) + (i & 15); }
+__host__ __device__ constexpr int c16_blocks(int n_rows) { return (n_rows + 15) >> 4; }
+// doubles of the image of an N-column system (+ the right-hand-side row)
+__host__ __device__ constexpr int c16_size(int N) { return (c16_blocks(N + 1) * (c16_blocks(N + 1) + 1) / 2) << 8; }
+
+__device__ __forceinline__ double c16_readlane(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double c16_rsqrt(double d) {   // v_rsq_f64 (2^-24) + 2 Newton steps: 1.4e-16 (measured)
+    double y = __builtin_amdgcn_rsq(d);
+    double e = __builtin_fma(-d * y, y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    e = __builtin_fma(-d * y, y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    return y;
+}
+// (even-row member, odd-row member) of the lane pair {l, l ^ 16} in both lanes; likewise (lower, upper) of {l, l ^ 32}
+__device__ __forceinline__ void c16_pair16(double v, double& e, double& o) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    e = __hiloint2double(b[0], a[0]); o = __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ void c16_pair32(double v, double& l, double& u) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    l = __hiloint2double(b[0], a[0]); u = __hiloint2double(b[1], a[1]);
+}
+
+// value of the lane (i - 1) % 16 of the same 16-lane row: DPP row_ror:1 (a lane receives from the lane 1 below, cyclically),
+// i.e. after d applications lane i holds the value lane (i - d) % 16 started with. The back-substitution wants (i + d) % 16:
+// it applies row_ror:15 = one step the other way.
+__device__ __forceinline__ double c16_row_ror1(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x12F, 0xF, 0xF, true);   // row_ror:15
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x12F, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ c16_d4 c16_load(const double* t, int ln) {
+    c16_d4 v;
+    v[0] = t[ln]; v[1] = t[64 + ln]; v[2] = t[128 + ln]; v[3] = t[192 + ln];
+    return v;
+}
+__device__ __forceinline__ void c16_store(double* t, int ln, c16_d4 v) {
+    t[ln] = v[0]; t[64 + ln] = v[1]; t[128 + ln] = v[2]; t[192 + ln] = v[3];
+}
+
+// Mirror the lower halves of the diagonal tiles into their upper halves (the assembly only writes i >= j).
+__device__ __forceinline__ void c16_symmetrize(double* A, int nb) {
+    for (int e = threadIdx.x; e < nb * 120; e += blockDim.x) {
+        const int I = e / 120;
+        int q = e - I * 120, c = 1;
+        while (q >= c) { q -= c; c++; }          // (r, c), r < c <= 15
+        double* t = A + (c16_tile(I, I) << 8);
+        t[c * 16 + q] = t[q * 16 + c];
+    }
+}
+
+// ---- one 4-column step ------------------------------------------------------------------------------------------------
+// The 4 x 4 pivot block P = D[4S .. 4S+3][4S .. 4S+3] is made uniform (v_readlane or an LDS broadcast), its Cholesky factor
+// L_ss and M = L_ss^-1 are computed in every lane; M goes into an MFMA A operand "Mpad" (lane (r < 4, k): M[r][k]) so that
+//     y = (tile register of the step) L_ss^-T  =  first accumulator register of  mfma(A = Mpad, B = register)
+// for the diagonal tile AND for every panel tile: the replay is two MFMAs per step, no cross-lane VALU work.
+// No sign test on the pivots: a non-positive pivot turns into NaN / inf (v_rsq_f64) and reaches the solution, which the
+// caller tests; columns >= nreal are dummies (inverse 0: they neither change nor produce anything).
+struct C16Lane {          // per-lane constants
+    int e;                // Mpad select: index into the 10 entries of M (row-major lower: 00 10 11 20 21 22 30 31 32 33) or -1
+    double k0, k1, k2, k3;   // 1.0 where lane / 16 == q: the lane's own column of a step, selected by multiplication
+    long long* dbg;          // probe builds: timestamps inside the first pivot steps (null in the library)
+};
+__device__ __forceinline__ void c16_stamp(const C16Lane& lc, int slot, double& tie) {
+    if (lc.dbg) {
+        asm volatile("s_nop 0" : "+v"(tie) :: "memory");
+        long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        asm volatile("s_nop 0" : "+v"(tie) :: "memory");
+        if ((threadIdx.x & 63) == 0) lc.dbg[slot] = t;
+    }
+}
+__device__ __forceinline__ C16Lane c16_lane(int ln) {
+    const int r = ln & 15, k = ln >> 4;
+    C16Lane c;
+    c.e = (r < 4 && k <= r) ? (r * (r + 1) / 2 + k) : -1;
+    c.k0 = k == 0 ? 1.0 : 0.0; c.k1 = k == 1 ? 1.0 : 0.0; c.k2 = k == 2 ? 1.0 : 0.0; c.k3 = k == 3 ? 1.0 : 0.0;
+    c.dbg = nullptr;
+    return c;
+}
+
+template <int S, int GATHER>
+__device__ __forceinline__ void c16_gather(double u, double* gbuf, int ln, double (&a)[10]) {
+    if (GATHER == 0) {
+        // D[4S + r][4S + c] (r >= c) = D[4S + c][4S + r] sits in lane 16 r + 4 S + c
+        a[0] = c16_readlane(u, 4 * S);
+        a[1] = c16_readlane(u, 16 + 4 * S); a[2] = c16_readlane(u, 16 + 4 * S + 1);
+        a[3] = c16_readlane(u, 32 + 4 * S); a[4] = c16_readlane(u, 32 + 4 * S + 1); a[5] = c16_readlane(u, 32 + 4 * S + 2);
+        a[6] = c16_readlane(u, 48 + 4 * S); a[7] = c16_readlane(u, 48 + 4 * S + 1); a[8] = c16_readlane(u, 48 + 4 * S + 2);
+        a[9] = c16_readlane(u, 48 + 4 * S + 3);
+    } else {
+        gbuf[ln] = u;      // wave-private 64 doubles; same-wave LDS accesses complete in order
+        const double2 r1 = *(const double2*)(gbuf + 16 + 4 * S), r2 = *(const double2*)(gbuf + 32 + 4 * S);
+        const double2 r3 = *(const double2*)(gbuf + 48 + 4 * S), r3b = *(const double2*)(gbuf + 48 + 4 * S + 2);
+        a[0] = gbuf[4 * S]; a[1] = r1.x; a[2] = r1.y; a[3] = r2.x; a[4] = r2.y; a[5] = gbuf[32 + 4 * S + 2];
+        a[6] = r3.x; a[7] = r3.y; a[8] = r3b.x; a[9] = r3b.y;
+    }
+}
+
+template <int S, int GATHER>
+__device__ __forceinline__ void c16_pivot_step(c16_d4& D, int nreal, double* pub, double* gbuf, int ln, const C16Lane& lc) {
+    double u = D[S];
+    c16_stamp(lc, 8 * S + 0, u);
+    // the 4 entries of the lane's row (independent of the factor: issued in the shadow of the gather)
+    double ev, od, a0, a1, a2, a3;
+    c16_pair16(u, ev, od);
+    c16_pair32(ev, a0, a2);
+    c16_pair32(od, a1, a3);
+    c16_stamp(lc, 8 * S + 1, a3);
+    double a[10];
+    c16_gather<S, GATHER>(u, gbuf, ln, a);
+    c16_stamp(lc, 8 * S + 2, a[9]);
+    const double i0 = nreal > 0 ? c16_rsqrt(a[0]) : 0.0;
+    const double l10 = a[1] * i0, l20 = a[3] * i0, l30 = a[6] * i0;
+    const double i1 = nreal > 1 ? c16_rsqrt(__builtin_fma(-l10, l10, a[2])) : 0.0;
+    const double l21 = __builtin_fma(-l20, l10, a[4]) * i1, l31 = __builtin_fma(-l30, l10, a[7]) * i1;
+    const double i2 = nreal > 2 ? c16_rsqrt(__builtin_fma(-l21, l21, __builtin_fma(-l20, l20, a[5]))) : 0.0;
+    const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, a[8])) * i2;
+    double i3 = nreal > 3 ? c16_rsqrt(__builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, a[9])))) : 0.0;
+    c16_stamp(lc, 8 * S + 3, i3);
+    // y = (row's 4 entries) L_ss^-T by forward substitution; the lane keeps its own column
+    const double y0 = a0 * i0;
+    const double y1 = __builtin_fma(-l10, y0, a1) * i1;
+    const double y2 = __builtin_fma(-l21, y1, __builtin_fma(-l20, y0, a2)) * i2;
+    const double y3 = __builtin_fma(-l32, y2, __builtin_fma(-l31, y1, __builtin_fma(-l30, y0, a3))) * i3;
+    double y = __builtin_fma(lc.k3, y3, __builtin_fma(lc.k2, y2, __builtin_fma(lc.k1, y1, lc.k0 * y0)));
+    c16_stamp(lc, 8 * S + 4, y);
+    if (S < 3) D = __builtin_amdgcn_mfma_f64_16x16x4f64(-y, y, D, 0, 0, 0);
+    if (S < 3) { double t = D[S + 1]; c16_stamp(lc, 8 * S + 5, t); D[S + 1] = t; }
+    // for the other waves (in the shadow of the MFMA): M = L_ss^-1 as an MFMA A operand
+    const double m10 = -(l10 * i0) * i1;
+    const double m21 = -(l21 * i1) * i2;
+    const double m32 = -(l32 * i2) * i3;
+    const double m20 = -__builtin_fma(l21, m10, l20 * i0) * i2;
+    const double m31 = -__builtin_fma(l32, m21, l31 * i1) * i3;
+    const double m30 = -__builtin_fma(l32, m20, __builtin_fma(l31, m10, l30 * i0)) * i3;
+    const int e = lc.e;
+    double mp = 0.0;
+    mp = e == 0 ? i0 : mp; mp = e == 1 ? m10 : mp; mp = e == 2 ? i1 : mp; mp = e == 3 ? m20 : mp; mp = e == 4 ? m21 : mp;
+    mp = e == 5 ? i2 : mp; mp = e == 6 ? m30 : mp; mp = e == 7 ? m31 : mp; mp = e == 8 ? m32 : mp; mp = e == 9 ? i3 : mp;
+    c16_stamp(lc, 8 * S + 6, mp);
+    double* p = pub + S * C16_STEP;
+    p[ln] = y;
+    p[64 + ln] = mp;
+}
+
+template <int GATHER>
+__device__ __forceinline__ void c16_pivot_block(c16_d4 D, int nreal, double* pub, double* gbuf, int ln, const C16Lane& lc) {
+    c16_pivot_step<0, GATHER>(D, nreal, pub, gbuf, ln, lc);
+    c16_pivot_step<1, GATHER>(D, nreal - 4, pub, gbuf, ln, lc);
+    c16_pivot_step<2, GATHER>(D, nreal - 8, pub, gbuf, ln, lc);
+    c16_pivot_step<3, GATHER>(D, nreal - 12, pub, gbuf, ln, lc);
+}
+
+// Replay the published steps of a block on tile X (rows of some tile row, columns of the block): returns X L_kk^-T.
+__device__ __forceinline__ c16_d4 c16_replay(c16_d4 X, const double* pub, int ln) {
+    c16_d4 Y;
+    double lcv[4], mp[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) { lcv[s] = pub[s * C16_STEP + ln]; mp[s] = pub[s * C16_STEP + 64 + ln]; }
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        c16_d4 z = {0.0, 0.0, 0.0, 0.0};
+        z = __builtin_amdgcn_mfma_f64_16x16x4f64(mp[s], X[s], z, 0, 0, 0);
+        Y[s] = z[0];
+        if (s < 3) X = __builtin_amdgcn_mfma_f64_16x16x4f64(-lcv[s], z[0], X, 0, 0, 0);   // X -= y L_kk[:, step]^T
+    }
+    return Y;
+}
+
+// Solve [S] x = rhs for the tile-packed image A (N columns, rhs = row N; diagonal tiles already symmetric). On return
+// xs[0 .. N) = S^-1 rhs. Every thread of the 512-thread workgroup must call it. pub: 2 * C16_PUB + 64 doubles; yv: 16 * nb
+// doubles. Returns false if the solution is not finite (a non-positive pivot). ts (may be null): phase timestamps.
+template <int GATHER = 0>
+__device__ __forceinline__ bool c16_solve(double* A, int N, double* xs, double* pub, double* yv, long long* ts) {
+    const int tid = threadIdx.x, ln = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = blockDim.x >> 6;
+    const int nb = c16_blocks(N + 1);     // tile rows incl. the right-hand-side row
+    const int nbc = c16_blocks(N);        // block columns with real pivots
+    C16Lane lc = c16_lane(ln);
+    lc.dbg = ts ? ts + 32 : nullptr;
+    double* gbuf = pub + 2 * C16_PUB;     // the pivot wave's gather buffer
+    __shared__ int s_bad;
+    if (tid == 0) s_bad = 0;
+    if (wv == 0) c16_pivot_block<GATHER>(c16_load(A, ln), N < 16 ? N : 16, pub, gbuf, ln, lc);
+    __syncthreads();
+    if (ts && tid == 0) ts[0] = clock64();
+    for (int kb = 0; kb < nbc; kb++) {
+        const double* pb = pub + (kb & 1) * C16_PUB;
+        const int m = nb - kb - 1;        // tile rows below the diagonal tile
+        // ---- phase A: L_Ik = A_Ik L_kk^-T for the m panel tiles; task m: the identity -> L_kk^-T into tile (kb, kb) ----
+        for (int t = wv; t <= m; t += nwv) {
+            double* tp = A + (c16_tile(t < m ? kb + 1 + t : kb, kb) << 8);
+            c16_d4 X;
+            if (t < m) X = c16_load(tp, ln);
+            else {
+                const int i = ln & 15, k = ln >> 4;
+#pragma unroll
+                for (int s = 0; s < 4; s++) X[s] = (i == 4 * s + k) ? 1.0 : 0.0;
+            }
+            c16_store(tp, ln, c16_replay(X, pb, ln));
+        }
+        __syncthreads();
+        if (ts && tid == 0 && kb < 8) ts[1 + 2 * kb] = clock64();
+        // ---- phase B: look-ahead factorisation of the next diagonal tile | trailing update of everything else ----
+        if (wv == 0) {
+            if (kb + 1 < nbc) {
+                const c16_d4 Lp = c16_load(A + (c16_tile(kb + 1, kb) << 8), ln);
+                c16_d4 D = c16_load(A + (c16_tile(kb + 1, kb + 1) << 8), ln);
+                c16_d4 D2 = {0.0, 0.0, 0.0, 0.0};     // two accumulators: two dependent MFMAs instead of four
+                D = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[0], Lp[0], D, 0, 0, 0);
+                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[1], Lp[1], D2, 0, 0, 0);
+                D = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[2], Lp[2], D, 0, 0, 0);
+                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[3], Lp[3], D2, 0, 0, 0);
+                D += D2;
+                const int left = N - 16 * (kb + 1);
+                c16_pivot_block<GATHER>(D, left < 16 ? left : 16, pub + ((kb + 1) & 1) * C16_PUB, gbuf, ln, lc);
+            }
+        } else {
+            // tiles (I, J), kb < J <= I, J < nbc, minus the pivot wave's (kb + 1, kb + 1), dealt round-robin in row order:
+            // the wave walks the rows and steps `nwv - 1` tiles at a time
+            int I = kb + 1, J = kb + 1 + wv;            // task index wv - 1 counted after skipping the first tile
+            while (true) {
+                int jmax = I < nbc ? I : nbc - 1;
+                while (I < nb && J > jmax) { J -= jmax - kb; I++; jmax = I < nbc ? I : nbc - 1; }   // row I holds jmax - kb tiles
+                if (I >= nb) break;
+                double* ct = A + (c16_tile(I, J) << 8);
+                c16_d4 C = c16_load(ct, ln);
+                const c16_d4 LI = c16_load(A + (c16_tile(I, kb) << 8), ln);
+                const c16_d4 LJ = c16_load(A + (c16_tile(J, kb) << 8), ln);
+                c16_d4 C2 = {0.0, 0.0, 0.0, 0.0};
+                C = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[0], LI[0], C, 0, 0, 0);
+                C2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[1], LI[1], C2, 0, 0, 0);
+                C = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[2], LI[2], C, 0, 0, 0);
+                C2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[3], LI[3], C2, 0, 0, 0);
+                c16_store(ct, ln, C + C2);
+                J += nwv - 1;
+            }
+        }
+        __syncthreads();
+        if (ts && tid == 0 && kb < 8) ts[2 + 2 * kb] = clock64();
+    }
+    // ---- back-substitution x = L^-T y; y_c = L[N][c]: tile (IB, c / 16) row r, or (same diagonal tile) the published y ----
+    // thread c owns y_c in a register. Per block J (last first): the wave that owns the block's 16 threads forms
+    // x_J = L_JJ^-T v_J (tile (J, J) holds X(L_JJ^-T): element (i, c) at c * 16 + i, upper triangular) and publishes it;
+    // after the barrier every thread c < 16 J subtracts L[16 J .. 16 J + 15][c] . x_J (16 consecutive doubles of tile (J, c / 16)).
+    const int IB = N >> 4, r = N & 15;
+    double yreg = 0.0;
+    if (tid < 16 * nbc && tid < N) {
+        const int J = tid >> 4, cl = tid & 15;
+        if (J < IB) yreg = A[(c16_tile(IB, J) << 8) + cl * 16 + r];
+        else yreg = pub[(J & 1) * C16_PUB + (cl >> 2) * C16_STEP + 16 * (cl & 3) + r];   // lane (row r, k = cl & 3) of step cl / 4
+    }
+    bool bad = false;
+    for (int J = nbc - 1; J >= 0; J--) {
+        // the block's right-looking update reads L[16 J .. 16 J + 15][c]: issued before the barrier (independent of x_J)
+        double lcol[16];
+        if (tid < 16 * J) {
+            const double* lt = A + (c16_tile(J, tid >> 4) << 8) + (tid & 15) * 16;
+#pragma unroll
+            for (int i = 0; i < 16; i++) lcol[i] = lt[i];
+        }
+        if ((tid >> 4) == J) {              // 16 consecutive lanes of one wave = one DPP row
+            const int i = tid & 15;
+            const double* lt = A + (c16_tile(J, J) << 8) + i;
+            // x_i = sum_d L_JJ^-T[i][(i + d) % 16] v[(i + d) % 16]: v rotated through the row with DPP row_ror
+            double xi = lt[i * 16] * yreg;
+            double v = yreg;
+            int src = i;                      // rotated with the value: whose v the lane holds (direction-proof)
+#pragma unroll
+            for (int d = 1; d < 16; d++) {
+                v = c16_row_ror1(v);
+                src = __builtin_amdgcn_update_dpp(0, src, 0x12F, 0xF, 0xF, true);
+                xi = __builtin_fma(lt[src * 16], v, xi);
+            }
+            if (tid < N) { xs[tid] = xi; if (!(fabs(xi) < 1e300)) bad = true; }
+            yv[tid] = tid < N ? xi : 0.0;
+        }
+        __syncthreads();
+        if (tid < 16 * J) {
+            const double* xj = yv + 16 * J;
+#pragma unroll
+            for (int i = 0; i < 16; i++) yreg = __builtin_fma(-lcol[i], xj[i], yreg);
+        }
+    }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (ts && tid == 0) ts[20] = clock64();
+    return s_bad == 0;
+}
+
+}  // namespace sadvio

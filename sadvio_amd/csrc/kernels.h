@@ -15,6 +15,7 @@
 #pragma once
 #include "ba_types.h"
 #include "device_math.h"
+#include "chol16.h"
 
 namespace sadvio {
 
@@ -81,7 +82,8 @@ struct DevPtrs {
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
 // element (i >= j) of a window's reduced matrix in HBM: packed lower triangle (ld == 0) or full row-major
-__device__ __forceinline__ long long s_index(int ld, int i, int j) { return ld ? (long long)i * ld + j : (long long)tri(i, j); }
+// ld == 0: the 16 x 16 tile-packed lower triangle of chol16.h (= the LDS image of k_solve<0>, so that its gather is a linear copy)
+__device__ __forceinline__ long long s_index(int ld, int i, int j) { return ld ? (long long)i * ld + j : (long long)c16_index(i, j); }
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
@@ -725,12 +727,22 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
             }
         }
         __syncthreads();
-        for (int row = wv; row < Nt; row += BUILD_WAVES) {
-            const long long grow = s_index(T.ld, growTab[row], 0);
-            const double* srow = Stile + tri(row, 0);
-            for (int col = ln; col <= row; col += 64) {
-                const double v = srow[col];
-                if (v != 0.0) atomic_add_f64(&Sg[grow + growTab[col]], v);
+        if (T.ld) {   // full row-major S: one wave per row, lanes along the row (consecutive addresses)
+            for (int row = wv; row < Nt; row += BUILD_WAVES) {
+                const long long grow = (long long)growTab[row] * T.ld;
+                const double* srow = Stile + tri(row, 0);
+                for (int col = ln; col <= row; col += 64) {
+                    const double v = srow[col];
+                    if (v != 0.0) atomic_add_f64(&Sg[grow + growTab[col]], v);
+                }
+            }
+        } else {      // tile-packed S (column-major inside a tile): one wave per column, lanes down the column
+            for (int col = wv; col < Nt; col += BUILD_WAVES) {
+                const int gc = growTab[col];
+                for (int row = col + ln; row < Nt; row += 64) {
+                    const double v = Stile[tri(row, col)];
+                    if (v != 0.0) atomic_add_f64(&Sg[c16_index(growTab[row], gc)], v);
+                }
             }
         }
         for (int i = tid; i < Nt; i += blockDim.x) {
@@ -1139,20 +1151,18 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     double* gredg = P.gred + W.red_off;
     double* gfullg = P.gfull + W.red_off;
     double* hdg = P.hdiag + W.red_off;
-    // VIO windows (15 columns per key-frame) are padded with identity rows to a multiple of 6: the 6-wide pivot blocks
-    // need 28 steps for 11 key-frames where 5-wide ones need 33, and K = 6 fills the two MFMA k-steps better than K = 5
-    // (the host runs every window with 15 columns per key-frame through the EXTRAS kernels, so that the plain kernel
-    // keeps Nq == Np as a compile-time identity)
-    const int Nq = (EXTRAS && !BIG && W.dpf == 15 && W.n_red == 0) ? (Np + 5) / 6 * 6 : Np;
-    const int tri_n = (Nq + 1) * (Nq + 2) / 2;  // packed lower triangle incl. the right-hand-side row Nq
-    double* LpT = (double*)smem;                // [NBP][Nq+2] transposed panel strip
-    double* A = BIG ? Sg : LpT + (size_t)(Nq + 2) * NBP;   // packed lower (LDS) | full row-major lower (HBM)
-    double* y = BIG ? gredg : A + tri_n;        // rhs -> work vector of the back-substitution
-    double* gf = BIG ? gfullg : y + Nq;         // full gradient
-    double* hd = BIG ? hdg : gf + Nq;           // diag(H)
-    double* xs = BIG ? gredg : hd + Nq;         // solution (BIG: potrs overwrites the right-hand side)
-    double* linvTab = xs + Nq;                  // [Nq/NB][NB*NB] inverse pivot blocks
-    auto aidx = [&](int i, int j) -> long long { return BIG ? (long long)i * ld + j : (long long)tri(i, j); };  // i >= j
+    // N_p <= MAX_LDS_NP: the reduced system lives in LDS as the 16 x 16 tile-packed image of chol16.h (matrix + right-hand
+    // side row), which is also its layout in HBM: the hand-off is a linear copy
+    const int nbt = c16_blocks(Np + 1);         // tile rows incl. the right-hand-side row
+    const int img_n = c16_size(Np);
+    double* A = BIG ? Sg : (double*)smem;       // tile-packed lower (LDS) | full row-major lower (HBM)
+    double* y = BIG ? gredg : A + img_n;        // rhs -> work vector
+    double* gf = BIG ? gfullg : y + Np;         // full gradient
+    double* hd = BIG ? hdg : gf + Np;           // diag(H)
+    double* xs = BIG ? gredg : hd + Np;         // solution (BIG: the library factorisation overwrites the right-hand side)
+    double* pub = xs + Np + (Np & 1);           // chol16: published pivot steps (2 * C16_PUB + 64), 16-byte aligned
+    double* yv = pub + 2 * C16_PUB + 64;        // chol16: back-substitution exchange (16 * nbt)
+    auto aidx = [&](int i, int j) -> long long { return BIG ? (long long)i * ld + j : (long long)c16_index(i, j); };  // i >= j
     const int cur = st.cur;
     const double* xp = P.xp + (long long)cur * P.xp_stride;
     const int n_imu = W.imu_end - W.imu_begin;
@@ -1160,9 +1170,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     // load + clear the global accumulator: S is kept in HBM in the same packed lower-triangular layout as in
     // LDS, so this is a linear, fully coalesced 16-byte copy; all loads are issued before the first use.
     if (!BIG) {
-        const int n_s = Np * (Np + 1) / 2;
-        const int n2 = n_s >> 1;
-        constexpr int MAXV = (MAX_LDS_NP * (MAX_LDS_NP + 1) / 4 + SOLVE_THREADS - 1) / SOLVE_THREADS;
+        const int n2 = img_n >> 1;              // the image is a whole number of 256-double tiles
+        constexpr int MAXV = (c16_size(MAX_LDS_NP) / 2 + SOLVE_THREADS - 1) / SOLVE_THREADS;
         double2 v[MAXV];
         const double2* g2 = (const double2*)Sg;
 #pragma unroll
@@ -1176,7 +1185,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             const int i = tid + q * SOLVE_THREADS;
             if (q * SOLVE_THREADS < n2 && i < n2) { ((double2*)A)[i] = v[q]; ((double2*)Sg)[i] = z2; }
         }
-        if (tid == 0 && (n_s & 1)) { A[n_s - 1] = Sg[n_s - 1]; Sg[n_s - 1] = 0.0; }
     }
     if (!BIG)
     for (int i = tid; i < Np; i += blockDim.x) {
@@ -1346,16 +1354,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         else s = sp[i];
         double s2 = s * s;
         A[aidx(i, i)] += fmin(fmax(s2 * hd[i], P.o.min_lm_diagonal), P.o.max_lm_diagonal) / st.radius / s2;
-        if (!BIG) A[tri(Nq, i)] = y[i];
+        if (!BIG) A[c16_index(Np, i)] = y[i];   // right-hand side = row Np (the rest of that row and the padding rows are zero: S is)
     }
     if (!BIG) {
-        for (int e = tid; e < tri(Nq, 0) - tri(Np, 0); e += blockDim.x) {   // identity padding rows Np .. Nq - 1
-            const int g = tri(Np, 0) + e;
-            int i = Np;
-            while (tri(i + 1, 0) <= g) i++;
-            A[g] = (g - tri(i, 0) == i) ? 1.0 : 0.0;
-        }
-        for (int i = Np + tid; i <= Nq; i += blockDim.x) A[tri(Nq, i)] = 0.0;   // rhs of the padding rows + the corner
+        __syncthreads();
+        c16_symmetrize(A, nbt);                 // the assembly writes i >= j only; the diagonal tiles are used as full symmetric tiles
     }
     __syncthreads();
     SADVIO_TS(3, 3);
@@ -1364,9 +1367,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     long long* ts = SADVIO_TS_PTR((P.debug & 4096) && blockIdx.x == 0 && slot == 3);
     if (MODE == 0) {
         bool ok = true;  // Np == 0 (every key-frame constant, landmarkOptimization): nothing to factor
-        if (Np == 0) {}
-        else if (W.n_red > 0) ok = chol_solve_packed<3>(A, Np, y, xs, LpT, linvTab, ts);  // Np = dpf n_free + 3 n_red
-        else ok = chol_solve_packed<6>(A, Nq, y, xs, LpT, linvTab, ts);   // dpf 6, or dpf 15 padded to a multiple of 6
+        if (Np > 0) ok = c16_solve<0>(A, Np, xs, pub, yv, nullptr);
+        (void)ts;
         if (!ok) {
             if (tid == 0) acc->chol_fail = 1;
             return;

@@ -12,6 +12,14 @@
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ long long clk() { return __builtin_readcyclecounter(); }
+// s_memtime ordered after everything `x` depends on has ISSUED (the VALU pipe is in order) and before anything that uses x
+__device__ __forceinline__ long long clk_after(double& x) {
+    long long t;
+    asm volatile("s_nop 0" : "+v"(x) :: "memory");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    asm volatile("s_nop 0" : "+v"(x) :: "memory");
+    return t;
+}
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, lane);
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(512) void k_lat(double* out, long long* cyc, const 
     __syncthreads();
     // (0) dependent FP64 FMA chain, 256 deep
     if (wv == 0) {
-        t0 = clk(); x = chain_fma<256>(x, a, b); t1 = clk();
+        t0 = clk_after(x); x = chain_fma<256>(x, a, b); t1 = clk_after(x);
         if (ln == 0) cyc[0] = t1 - t0;
         out[ln] = x;
     }
@@ -87,10 +95,11 @@ __global__ __launch_bounds__(512) void k_lat(double* out, long long* cyc, const 
     // (1) 4 independent FMA chains interleaved, 64 deep each (issue rate)
     if (wv == 0) {
         double y0 = x, y1 = x + 1, y2 = x + 2, y3 = x + 3;
-        t0 = clk();
+        t0 = clk_after(y3);
 #pragma unroll
         for (int i = 0; i < 64; i++) { y0 = __builtin_fma(y0, a, b); y1 = __builtin_fma(y1, a, b); y2 = __builtin_fma(y2, a, b); y3 = __builtin_fma(y3, a, b); }
-        t1 = clk();
+        y3 += y0 + y1 + y2;
+        t1 = clk_after(y3);
         if (ln == 0) cyc[1] = t1 - t0;
         out[64 + ln] = y0 + y1 + y2 + y3;
     }
@@ -98,10 +107,10 @@ __global__ __launch_bounds__(512) void k_lat(double* out, long long* cyc, const 
     // (2) dependent rsq chain (rsq -> fma -> rsq ...), 64 deep: cost of rsq + 1 fma
     if (wv == 0) {
         double y = fabs(x) + 1.0;
-        t0 = clk();
+        t0 = clk_after(y);
 #pragma unroll
         for (int i = 0; i < 64; i++) { y = __builtin_amdgcn_rsq(y); y = __builtin_fma(y, a, 2.0); }
-        t1 = clk();
+        t1 = clk_after(y);
         if (ln == 0) cyc[2] = t1 - t0;
         out[128 + ln] = y;
     }
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(512) void k_lat(double* out, long long* cyc, const 
     // (3) full pivot step chain: rsq + 2 Newton + scale + dependent update, 32 deep
     if (wv == 0) {
         double d = fabs(x) + 2.0, l = 0.3;
-        t0 = clk();
+        t0 = clk_after(d);
 #pragma unroll
         for (int i = 0; i < 32; i++) {
             double y = __builtin_amdgcn_rsq(d);
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(512) void k_lat(double* out, long long* cyc, const 
             l = l * y;
             d = __builtin_fma(-l, l, 3.0);
         }
-        t1 = clk();
+        t1 = clk_after(d);
         if (ln == 0) cyc[3] = t1 - t0;
         out[192 + ln] = d;
     }
@@ -128,24 +137,24 @@ __global__ __launch_bounds__(512) void k_lat(double* out, long long* cyc, const 
     // (4) readlane -> VALU use -> readlane chain, 64 deep (value moves lane to lane)
     if (wv == 0) {
         double y = x;
-        t0 = clk();
+        t0 = clk_after(y);
 #pragma unroll
         for (int i = 0; i < 64; i++) { double s = readlane_f64(y, (i * 7 + 3) & 63); y = __builtin_fma(y, a, s); }
-        t1 = clk();
+        t1 = clk_after(y);
         if (ln == 0) cyc[4] = t1 - t0;
         out[256 + ln] = y;
     }
     __syncthreads();
     // (5) 20 independent readlanes (10 doubles) + one dependent fma each: issue cost
     if (wv == 0) {
-        double acc = 0.0;
-        t0 = clk();
+        double acc = x;
+        t0 = clk_after(acc);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
 #pragma unroll
             for (int i = 0; i < 10; i++) acc += readlane_f64(x, (i * 5 + r) & 63);
         }
-        t1 = clk();
+        t1 = clk_after(acc);
         if (ln == 0) cyc[5] = t1 - t0;
         out[320 + ln] = acc;
     }
@@ -153,10 +162,11 @@ __global__ __launch_bounds__(512) void k_lat(double* out, long long* cyc, const 
     // (6) dependent MFMA chain on one accumulator, 32 deep
     if (wv == 0) {
         d4 c = {x, x, x, x};
-        t0 = clk();
+        double c0s = c[0];
+        t0 = clk_after(c0s); c[0] = c0s;
 #pragma unroll
         for (int i = 0; i < 32; i++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-        t1 = clk();
+        c0s = c[0]; t1 = clk_after(c0s); c[0] = c0s;
         if (ln == 0) cyc[6] = t1 - t0;
         out[384 + ln] = c[0] + c[1] + c[2] + c[3];
     }
@@ -164,13 +174,14 @@ __global__ __launch_bounds__(512) void k_lat(double* out, long long* cyc, const 
     // (7) 4 independent accumulators x 8 (MFMA issue rate)
     if (wv == 0) {
         d4 c0 = {x, x, x, x}, c1 = c0, c2 = c0, c3 = c0;
-        t0 = clk();
+        double q0 = c3[0];
+        t0 = clk_after(q0); c3[0] = q0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
             c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
         }
-        t1 = clk();
+        q0 = c0[0] + c1[0] + c2[0] + c3[0]; t1 = clk_after(q0); c3[0] = q0;
         if (ln == 0) cyc[7] = t1 - t0;
         out[448 + ln] = c0[0] + c1[1] + c2[2] + c3[3];
     }
@@ -179,10 +190,10 @@ __global__ __launch_bounds__(512) void k_lat(double* out, long long* cyc, const 
     if (wv == 0) {
         d4 c = {x, x, x, x};
         double y = a;
-        t0 = clk();
+        t0 = clk_after(y);
 #pragma unroll
         for (int i = 0; i < 16; i++) { c = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, c, 0, 0, 0); y = c[i & 3] * b; }
-        t1 = clk();
+        t1 = clk_after(y);
         if (ln == 0) cyc[8] = t1 - t0;
         out[512 + ln] = y;
     }
@@ -190,10 +201,10 @@ __global__ __launch_bounds__(512) void k_lat(double* out, long long* cyc, const 
     // (9) xor16 + xor32 exchange chain (gather of the 4 lane-group values), 32 deep
     if (wv == 0) {
         double y = x;
-        t0 = clk();
+        t0 = clk_after(y);
 #pragma unroll
         for (int i = 0; i < 32; i++) { double p = xor16_other(y); double q = xor32_other(y + p); y = __builtin_fma(q, a, p); }
-        t1 = clk();
+        t1 = clk_after(y);
         if (ln == 0) cyc[9] = t1 - t0;
         out[576 + ln] = y;
     }
