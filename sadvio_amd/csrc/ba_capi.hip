@@ -1688,7 +1688,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     const size_t lds_back = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)mtk * 18) + 16;
     // k_solve<0>: tile-packed image + y / gf / hd / xs + the chol16 exchange areas
     const size_t npq = (size_t)h->max_np;
-    const size_t lds_solve = sizeof(double) * ((size_t)c16_size((int)npq) + 4 * npq + 1 + 2 * C16_PUB + 64 + 16 * (size_t)c16_blocks((int)npq + 1)) + 64;
+    const size_t lds_solve = sizeof(double) * ((size_t)c16_size((int)npq) + 4 * npq + 1 + C16_WORK + 16 * (size_t)c16_blocks((int)npq + 1)) + 64;
     // robust loss or prior-kept landmarks in the batch: the kernels carrying those (rare) paths
     bool any_pseudo = false;
     for (const auto& v : h->sp_elim) for (char e : v) any_pseudo |= e != 0;

@@ -29,8 +29,10 @@ namespace sadvio {
 
 typedef double c16_d4 __attribute__((ext_vector_type(4)));
 
-constexpr int C16_STEP = 64 + 64;        // published per 4-column step: y (the step's 4 columns of L_kk) + the M = L_ss^-1 operand, one double per lane each
+constexpr int C16_STEP = 64;             // published per 4-column step: y = the step's 4 columns of L_kk (the back-substitution reads the rhs row's)
 constexpr int C16_PUB = 4 * C16_STEP;    // per block column; double-buffered by block parity
+constexpr int C16_WT = 16 * 17;          // L_kk^-T of the current block, element (r, c) at c * 17 + r (read transposed without bank conflicts)
+constexpr int C16_WORK = 2 * C16_PUB + 64 + C16_WT;   // doubles of the exchange area (`pub`)
 
 __host__ __device__ constexpr int c16_tile(int I, int J) { return ((I * (I + 1)) >> 1) + J; }
 // element (i, j), i >= j, of the tile-packed lower triangle (diagonal tiles: the lower half; see c16_symmetrize)
@@ -47,10 +49,11 @@ __device__ __forceinline__ double c16_readlane(double v, int lane) {
 }
 __device__ __forceinline__ double c16_rsqrt(double d) {   // v_rsq_f64 (2^-24) + 2 Newton steps: 1.4e-16 (measured)
     double y = __builtin_amdgcn_rsq(d);
-    double e = __builtin_fma(-d * y, y, 1.0);
-    y = __builtin_fma(0.5 * y, e, y);
-    e = __builtin_fma(-d * y, y, 1.0);
-    y = __builtin_fma(0.5 * y, e, y);
+    const double h = 0.5 * d;                              // y <- y + y (1/2 - h y^2): three operations per step
+    double e = __builtin_fma(-(h * y), y, 0.5);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-(h * y), y, 0.5);
+    y = __builtin_fma(y, e, y);
     return y;
 }
 // (even-row member, odd-row member) of the lane pair {l, l ^ 16} in both lanes; likewise (lower, upper) of {l, l ^ 32}
@@ -107,6 +110,7 @@ __device__ __forceinline__ void c16_symmetrize(double* A, int nb) {
 struct C16Lane {          // per-lane constants
     int e;                // Mpad select: index into the 10 entries of M (row-major lower: 00 10 11 20 21 22 30 31 32 33) or -1
     double k0, k1, k2, k3;   // 1.0 where lane / 16 == q: the lane's own column of a step, selected by multiplication
+    double w[10];            // 1.0 for the lane's entry of M (Mpad), else 0
     long long* dbg;          // probe builds: timestamps inside the first pivot steps (null in the library)
 };
 __device__ __forceinline__ void c16_stamp(const C16Lane& lc, int slot, double& tie) {
@@ -123,6 +127,8 @@ __device__ __forceinline__ C16Lane c16_lane(int ln) {
     C16Lane c;
     c.e = (r < 4 && k <= r) ? (r * (r + 1) / 2 + k) : -1;
     c.k0 = k == 0 ? 1.0 : 0.0; c.k1 = k == 1 ? 1.0 : 0.0; c.k2 = k == 2 ? 1.0 : 0.0; c.k3 = k == 3 ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < 10; q++) c.w[q] = c.e == q ? 1.0 : 0.0;
     c.dbg = nullptr;
     return c;
 }
@@ -146,17 +152,30 @@ __device__ __forceinline__ void c16_gather(double u, double* gbuf, int ln, doubl
 }
 
 template <int S, int GATHER>
-__device__ __forceinline__ void c16_pivot_step(c16_d4& D, int nreal, double* pub, double* gbuf, int ln, const C16Lane& lc) {
+__device__ __forceinline__ void c16_pivot_step(c16_d4& D, c16_d4& E, c16_d4& W, double& mp_io, double& y_io, int nreal, double* pub, double* gbuf, int ln, const C16Lane& lc) {
     double u = D[S];
     c16_stamp(lc, 8 * S + 0, u);
-    // the 4 entries of the lane's row (independent of the factor: issued in the shadow of the gather)
-    double ev, od, a0, a1, a2, a3;
-    c16_pair16(u, ev, od);
-    c16_pair32(ev, a0, a2);
-    c16_pair32(od, a1, a3);
-    c16_stamp(lc, 8 * S + 1, a3);
+    double a0, a1, a2, a3;   // the 4 entries of the lane's row (independent of the factor)
     double a[10];
-    c16_gather<S, GATHER>(u, gbuf, ln, a);
+    c16_d4 zw = {0.0, 0.0, 0.0, 0.0};
+    if (GATHER == 0) {
+        double ev, od;
+        c16_pair16(u, ev, od);
+        c16_pair32(ev, a0, a2);
+        c16_pair32(od, a1, a3);
+        c16_stamp(lc, 8 * S + 1, a3);
+        c16_gather<S, 0>(u, gbuf, ln, a);
+    } else {
+        gbuf[ln] = u;          // wave-private; same-wave LDS accesses complete in order
+        const double* row = gbuf + (ln & 15);
+        if (S > 0) zw = __builtin_amdgcn_mfma_f64_16x16x4f64(mp_io, E[S - 1], zw, 0, 0, 0);   // the previous step on the identity tile, see below
+        a0 = row[0]; a1 = row[16]; a2 = row[32]; a3 = row[48];
+        const double2 r1 = *(const double2*)(gbuf + 16 + 4 * S), r2 = *(const double2*)(gbuf + 32 + 4 * S);
+        const double2 r3 = *(const double2*)(gbuf + 48 + 4 * S), r3b = *(const double2*)(gbuf + 48 + 4 * S + 2);
+        a[0] = gbuf[4 * S]; a[1] = r1.x; a[2] = r1.y; a[3] = r2.x; a[4] = r2.y; a[5] = gbuf[32 + 4 * S + 2];
+        a[6] = r3.x; a[7] = r3.y; a[8] = r3b.x; a[9] = r3b.y;
+        c16_stamp(lc, 8 * S + 1, a3);
+    }
     c16_stamp(lc, 8 * S + 2, a[9]);
     const double i0 = nreal > 0 ? c16_rsqrt(a[0]) : 0.0;
     const double l10 = a[1] * i0, l20 = a[3] * i0, l30 = a[6] * i0;
@@ -166,6 +185,10 @@ __device__ __forceinline__ void c16_pivot_step(c16_d4& D, int nreal, double* pub
     const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, a[8])) * i2;
     double i3 = nreal > 3 ? c16_rsqrt(__builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, a[9])))) : 0.0;
     c16_stamp(lc, 8 * S + 3, i3);
+    if (GATHER == 1 && S > 0) {   // the matrix pipe finished zw during the factor chain
+        W[S - 1] = zw[0];
+        E = __builtin_amdgcn_mfma_f64_16x16x4f64(-y_io, zw[0], E, 0, 0, 0);
+    }
     // y = (row's 4 entries) L_ss^-T by forward substitution; the lane keeps its own column
     const double y0 = a0 * i0;
     const double y1 = __builtin_fma(-l10, y0, a1) * i1;
@@ -182,153 +205,207 @@ __device__ __forceinline__ void c16_pivot_step(c16_d4& D, int nreal, double* pub
     const double m20 = -__builtin_fma(l21, m10, l20 * i0) * i2;
     const double m31 = -__builtin_fma(l32, m21, l31 * i1) * i3;
     const double m30 = -__builtin_fma(l32, m20, __builtin_fma(l31, m10, l30 * i0)) * i3;
-    const int e = lc.e;
-    double mp = 0.0;
-    mp = e == 0 ? i0 : mp; mp = e == 1 ? m10 : mp; mp = e == 2 ? i1 : mp; mp = e == 3 ? m20 : mp; mp = e == 4 ? m21 : mp;
-    mp = e == 5 ? i2 : mp; mp = e == 6 ? m30 : mp; mp = e == 7 ? m31 : mp; mp = e == 8 ? m32 : mp; mp = e == 9 ? i3 : mp;
+    double mp;   // the lane's entry of M by multiplication with 0 / 1 weights (half the instructions of a select chain)
+    mp = lc.w[0] * i0;
+    mp = __builtin_fma(lc.w[1], m10, mp); mp = __builtin_fma(lc.w[2], i1, mp); mp = __builtin_fma(lc.w[3], m20, mp);
+    mp = __builtin_fma(lc.w[4], m21, mp); mp = __builtin_fma(lc.w[5], i2, mp); mp = __builtin_fma(lc.w[6], m30, mp);
+    mp = __builtin_fma(lc.w[7], m31, mp); mp = __builtin_fma(lc.w[8], m32, mp); mp = __builtin_fma(lc.w[9], i3, mp);
     c16_stamp(lc, 8 * S + 6, mp);
-    double* p = pub + S * C16_STEP;
-    p[ln] = y;
-    p[64 + ln] = mp;
-}
-
-template <int GATHER>
-__device__ __forceinline__ void c16_pivot_block(c16_d4 D, int nreal, double* pub, double* gbuf, int ln, const C16Lane& lc) {
-    c16_pivot_step<0, GATHER>(D, nreal, pub, gbuf, ln, lc);
-    c16_pivot_step<1, GATHER>(D, nreal - 4, pub, gbuf, ln, lc);
-    c16_pivot_step<2, GATHER>(D, nreal - 8, pub, gbuf, ln, lc);
-    c16_pivot_step<3, GATHER>(D, nreal - 12, pub, gbuf, ln, lc);
-}
-
-// Replay the published steps of a block on tile X (rows of some tile row, columns of the block): returns X L_kk^-T.
-__device__ __forceinline__ c16_d4 c16_replay(c16_d4 X, const double* pub, int ln) {
-    c16_d4 Y;
-    double lcv[4], mp[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) { lcv[s] = pub[s * C16_STEP + ln]; mp[s] = pub[s * C16_STEP + 64 + ln]; }
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        c16_d4 z = {0.0, 0.0, 0.0, 0.0};
-        z = __builtin_amdgcn_mfma_f64_16x16x4f64(mp[s], X[s], z, 0, 0, 0);
-        Y[s] = z[0];
-        if (s < 3) X = __builtin_amdgcn_mfma_f64_16x16x4f64(-lcv[s], z[0], X, 0, 0, 0);   // X -= y L_kk[:, step]^T
+    pub[S * C16_STEP + ln] = y;
+    // The same step on the identity tile E (after the four steps W = I L_kk^-T) is two MFMAs, zw = M E[S] and E -= y zw^T.
+    // They are issued one step LATE, inside the next step (zw before its factor chain, the update after it), so that the
+    // matrix pipe works under VALU instructions the wave has to issue anyway instead of stalling it; the last step's is
+    // finished by c16_pivot_block.
+    if (GATHER == 0) {
+        c16_d4 zw = {0.0, 0.0, 0.0, 0.0};
+        zw = __builtin_amdgcn_mfma_f64_16x16x4f64(mp, E[S], zw, 0, 0, 0);
+        W[S] = zw[0];
+        if (S < 3) E = __builtin_amdgcn_mfma_f64_16x16x4f64(-y, zw[0], E, 0, 0, 0);
     }
-    return Y;
+    mp_io = mp; y_io = y;
+}
+
+// Factor the diagonal tile D (nreal real pivot columns): publishes the steps' y, returns X(L_kk^-T).
+template <int GATHER>
+__device__ __forceinline__ c16_d4 c16_pivot_block(c16_d4 D, int nreal, double* pub, double* gbuf, int ln, const C16Lane& lc) {
+    c16_d4 E, W;
+    const int i = ln & 15, k = ln >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; s++) E[s] = (i == 4 * s + k) ? 1.0 : 0.0;
+    double mp = 0.0, y = 0.0;
+    c16_pivot_step<0, GATHER>(D, E, W, mp, y, nreal, pub, gbuf, ln, lc);
+    c16_pivot_step<1, GATHER>(D, E, W, mp, y, nreal - 4, pub, gbuf, ln, lc);
+    c16_pivot_step<2, GATHER>(D, E, W, mp, y, nreal - 8, pub, gbuf, ln, lc);
+    c16_pivot_step<3, GATHER>(D, E, W, mp, y, nreal - 12, pub, gbuf, ln, lc);
+    if (GATHER == 1) {
+        c16_d4 zw = {0.0, 0.0, 0.0, 0.0};
+        zw = __builtin_amdgcn_mfma_f64_16x16x4f64(mp, E[3], zw, 0, 0, 0);
+        W[3] = zw[0];
+    }
+    return W;
+}
+
+// X(L_kk^-T) -> its tile (for the back-substitution, X layout) and the padded transposed buffer (for the panel products)
+__device__ __forceinline__ void c16_publish_w(double* tile, double* wt, int ln, c16_d4 W) {
+    c16_store(tile, ln, W);
+    const int i = ln & 15, k = ln >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; s++) wt[(4 * s + k) * 17 + i] = W[s];    // element (r = i, c = 4 s + k)
+}
+
+// L_Ik = A_Ik L_kk^-T: X(Q P^T) = sum_s mfma(A = X(P)[s], B = X(Q)[s]) with Q = A_Ik and P = L_kk^-1, whose X layout
+// (lane (i, k), register s: L_kk^-1[i][4 s + k] = L_kk^-T[4 s + k][i]) is the transposed read of the buffer
+__device__ __forceinline__ c16_d4 c16_panel(c16_d4 X, const double* wt, int ln) {
+    const int i = ln & 15, k = ln >> 4;
+    const double* w = wt + i * 17 + k;
+    c16_d4 Y = {0.0, 0.0, 0.0, 0.0}, Y2 = {0.0, 0.0, 0.0, 0.0};
+    Y = __builtin_amdgcn_mfma_f64_16x16x4f64(w[0], X[0], Y, 0, 0, 0);
+    Y2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[4], X[1], Y2, 0, 0, 0);
+    Y = __builtin_amdgcn_mfma_f64_16x16x4f64(w[8], X[2], Y, 0, 0, 0);
+    Y2 = __builtin_amdgcn_mfma_f64_16x16x4f64(w[12], X[3], Y2, 0, 0, 0);
+    return Y + Y2;
+}
+
+// H = L_IJ L_JJ^-1 in place of a panel tile (the diagonal tile holds X(L_JJ^-T)): with it the back-substitution is
+// x_J = z_J - sum_{I > J} H_IJ^T x_I with z = the right-hand-side row of H — no triangular solve per block.
+__device__ __forceinline__ void c16_to_h(double* A, int I, int J, int ln) {
+    double* t = A + (c16_tile(I, J) << 8);
+    const c16_d4 L = c16_load(t, ln);
+    const c16_d4 W = c16_load(A + (c16_tile(J, J) << 8), ln);
+    c16_d4 H = {0.0, 0.0, 0.0, 0.0}, H2 = {0.0, 0.0, 0.0, 0.0};
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(W[0], L[0], H, 0, 0, 0);
+    H2 = __builtin_amdgcn_mfma_f64_16x16x4f64(W[1], L[1], H2, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(W[2], L[2], H, 0, 0, 0);
+    H2 = __builtin_amdgcn_mfma_f64_16x16x4f64(W[3], L[3], H2, 0, 0, 0);
+    c16_store(t, ln, H + H2);
 }
 
 // Solve [S] x = rhs for the tile-packed image A (N columns, rhs = row N; diagonal tiles already symmetric). On return
-// xs[0 .. N) = S^-1 rhs. Every thread of the 512-thread workgroup must call it. pub: 2 * C16_PUB + 64 doubles; yv: 16 * nb
+// xs[0 .. N) = S^-1 rhs. Every thread of the 512-thread workgroup must call it. pub: C16_WORK doubles; yv: 16 * nb
 // doubles. Returns false if the solution is not finite (a non-positive pivot). ts (may be null): phase timestamps.
-template <int GATHER = 0>
-__device__ __forceinline__ bool c16_solve(double* A, int N, double* xs, double* pub, double* yv, long long* ts) {
+template <int GATHER = 1>
+__device__ __forceinline__ bool c16_solve(double* A, int N, double* xs, double* pub, double* yv, long long* ts, long long* dbg = nullptr) {
     const int tid = threadIdx.x, ln = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = blockDim.x >> 6;
     const int nb = c16_blocks(N + 1);     // tile rows incl. the right-hand-side row
     const int nbc = c16_blocks(N);        // block columns with real pivots
     C16Lane lc = c16_lane(ln);
-    lc.dbg = ts ? ts + 32 : nullptr;
+    lc.dbg = dbg;
     double* gbuf = pub + 2 * C16_PUB;     // the pivot wave's gather buffer
+    double* wt = gbuf + 64;               // L_kk^-T of the block just factored, transposed read
     __shared__ int s_bad;
     if (tid == 0) s_bad = 0;
-    if (wv == 0) c16_pivot_block<GATHER>(c16_load(A, ln), N < 16 ? N : 16, pub, gbuf, ln, lc);
+    c16_d4 D = {0.0, 0.0, 0.0, 0.0};      // pivot wave: the next diagonal tile
+    if (wv == 0) c16_publish_w(A, wt, ln, c16_pivot_block<GATHER>(c16_load(A, ln), N < 16 ? N : 16, pub, gbuf, ln, lc));
     __syncthreads();
     if (ts && tid == 0) ts[0] = clock64();
     for (int kb = 0; kb < nbc; kb++) {
-        const double* pb = pub + (kb & 1) * C16_PUB;
         const int m = nb - kb - 1;        // tile rows below the diagonal tile
-        // ---- phase A: L_Ik = A_Ik L_kk^-T for the m panel tiles; task m: the identity -> L_kk^-T into tile (kb, kb) ----
-        for (int t = wv; t <= m; t += nwv) {
-            double* tp = A + (c16_tile(t < m ? kb + 1 + t : kb, kb) << 8);
-            c16_d4 X;
-            if (t < m) X = c16_load(tp, ln);
-            else {
-                const int i = ln & 15, k = ln >> 4;
-#pragma unroll
-                for (int s = 0; s < 4; s++) X[s] = (i == 4 * s + k) ? 1.0 : 0.0;
+        // ---- phase A: L_Ik = A_Ik L_kk^-T, one product per panel tile. The pivot wave takes the tile it needs next,
+        //      (kb + 1, kb), and updates the next diagonal tile with it ----
+        if (wv == 0) {
+            if (m >= 1) {
+                double* tp = A + (c16_tile(kb + 1, kb) << 8);
+                const c16_d4 Y = c16_panel(c16_load(tp, ln), wt, ln);
+                c16_store(tp, ln, Y);
+                if (kb + 1 < nbc) {
+                    D = c16_load(A + (c16_tile(kb + 1, kb + 1) << 8), ln);
+                    c16_d4 D2 = {0.0, 0.0, 0.0, 0.0};     // two accumulators: two dependent MFMAs instead of four
+                    D = __builtin_amdgcn_mfma_f64_16x16x4f64(-Y[0], Y[0], D, 0, 0, 0);
+                    D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Y[1], Y[1], D2, 0, 0, 0);
+                    D = __builtin_amdgcn_mfma_f64_16x16x4f64(-Y[2], Y[2], D, 0, 0, 0);
+                    D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Y[3], Y[3], D2, 0, 0, 0);
+                    D += D2;
+                }
             }
-            c16_store(tp, ln, c16_replay(X, pb, ln));
+        } else {
+            for (int I = kb + 1 + wv; I < nb; I += nwv - 1) {
+                double* tp = A + (c16_tile(I, kb) << 8);
+                c16_store(tp, ln, c16_panel(c16_load(tp, ln), wt, ln));
+            }
         }
         __syncthreads();
         if (ts && tid == 0 && kb < 8) ts[1 + 2 * kb] = clock64();
-        // ---- phase B: look-ahead factorisation of the next diagonal tile | trailing update of everything else ----
+        // ---- phase B: factorisation of the next diagonal tile (look-ahead) | trailing update of everything else, and the
+        //      panel of the PREVIOUS block column (no longer needed as L) turned into H = L L_JJ^-1 ----
         if (wv == 0) {
             if (kb + 1 < nbc) {
-                const c16_d4 Lp = c16_load(A + (c16_tile(kb + 1, kb) << 8), ln);
-                c16_d4 D = c16_load(A + (c16_tile(kb + 1, kb + 1) << 8), ln);
-                c16_d4 D2 = {0.0, 0.0, 0.0, 0.0};     // two accumulators: two dependent MFMAs instead of four
-                D = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[0], Lp[0], D, 0, 0, 0);
-                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[1], Lp[1], D2, 0, 0, 0);
-                D = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[2], Lp[2], D, 0, 0, 0);
-                D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[3], Lp[3], D2, 0, 0, 0);
-                D += D2;
                 const int left = N - 16 * (kb + 1);
-                c16_pivot_block<GATHER>(D, left < 16 ? left : 16, pub + ((kb + 1) & 1) * C16_PUB, gbuf, ln, lc);
+                const c16_d4 W = c16_pivot_block<GATHER>(D, left < 16 ? left : 16, pub + ((kb + 1) & 1) * C16_PUB, gbuf, ln, lc);
+                c16_publish_w(A + (c16_tile(kb + 1, kb + 1) << 8), wt, ln, W);   // wt: every wave is past its phase-A reads (barrier)
             }
         } else {
-            // tiles (I, J), kb < J <= I, J < nbc, minus the pivot wave's (kb + 1, kb + 1), dealt round-robin in row order:
-            // the wave walks the rows and steps `nwv - 1` tiles at a time
-            int I = kb + 1, J = kb + 1 + wv;            // task index wv - 1 counted after skipping the first tile
-            while (true) {
-                int jmax = I < nbc ? I : nbc - 1;
-                while (I < nb && J > jmax) { J -= jmax - kb; I++; jmax = I < nbc ? I : nbc - 1; }   // row I holds jmax - kb tiles
-                if (I >= nb) break;
-                double* ct = A + (c16_tile(I, J) << 8);
-                c16_d4 C = c16_load(ct, ln);
-                const c16_d4 LI = c16_load(A + (c16_tile(I, kb) << 8), ln);
-                const c16_d4 LJ = c16_load(A + (c16_tile(J, kb) << 8), ln);
-                c16_d4 C2 = {0.0, 0.0, 0.0, 0.0};
-                C = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[0], LI[0], C, 0, 0, 0);
-                C2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[1], LI[1], C2, 0, 0, 0);
-                C = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[2], LI[2], C, 0, 0, 0);
-                C2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[3], LI[3], C2, 0, 0, 0);
-                c16_store(ct, ln, C + C2);
-                J += nwv - 1;
+            // tiles (I, J), kb < J <= I, J < nbc, minus the pivot wave's (kb + 1, kb + 1), dealt round-robin in row order.
+            // The wave that shares the pivot wave's SIMD (wave nwv / 2 with waves placed round-robin on the 4 SIMDs) stays
+            // out of it: whatever it issues is taken from the pivot chain (+40 % on a pivot step, measured)
+            // ... unless the trailing update is the longer side (many tile rows left: N > ~130)
+            const bool all = (nb - kb) * (nb - kb - 1) / 2 > 4 * (nwv - 2) + 2;
+            const int nbw = all ? nwv - 1 : nwv - 2;                   // bulk waves of this phase
+            const int bw = (all || wv < nwv / 2) ? wv - 1 : wv - 2;    // index among them
+            if (all || wv != nwv / 2) {
+                int I = kb + 1, J = kb + 2 + bw;
+                while (true) {
+                    int jmax = I < nbc ? I : nbc - 1;
+                    while (I < nb && J > jmax) { J -= jmax - kb; I++; jmax = I < nbc ? I : nbc - 1; }   // row I holds jmax - kb tiles
+                    if (I >= nb) break;
+                    double* ct = A + (c16_tile(I, J) << 8);
+                    c16_d4 C = c16_load(ct, ln);
+                    const c16_d4 LI = c16_load(A + (c16_tile(I, kb) << 8), ln);
+                    const c16_d4 LJ = c16_load(A + (c16_tile(J, kb) << 8), ln);
+                    c16_d4 C2 = {0.0, 0.0, 0.0, 0.0};
+                    C = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[0], LI[0], C, 0, 0, 0);
+                    C2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[1], LI[1], C2, 0, 0, 0);
+                    C = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[2], LI[2], C, 0, 0, 0);
+                    C2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-LJ[3], LI[3], C2, 0, 0, 0);
+                    c16_store(ct, ln, C + C2);
+                    J += nbw;
+                }
+                if (kb >= 1)
+                    for (int Ic = kb + (nbw - 1 - bw); Ic < nb; Ic += nbw) c16_to_h(A, Ic, kb - 1, ln);   // last waves first: they got fewer tiles above
             }
         }
         __syncthreads();
         if (ts && tid == 0 && kb < 8) ts[2 + 2 * kb] = clock64();
     }
-    // ---- back-substitution x = L^-T y; y_c = L[N][c]: tile (IB, c / 16) row r, or (same diagonal tile) the published y ----
-    // thread c owns y_c in a register. Per block J (last first): the wave that owns the block's 16 threads forms
-    // x_J = L_JJ^-T v_J (tile (J, J) holds X(L_JJ^-T): element (i, c) at c * 16 + i, upper triangular) and publishes it;
-    // after the barrier every thread c < 16 J subtracts L[16 J .. 16 J + 15][c] . x_J (16 consecutive doubles of tile (J, c / 16)).
+    // the last block column's panel (at most the tile row of the right-hand side when N is a multiple of 16)
+    for (int Ic = nbc + wv; Ic < nb; Ic += nwv) c16_to_h(A, Ic, nbc - 1, ln);
+    // ---- back-substitution. z_c = H[N][c] = (L_JJ^-T y_J)[c]; x_I = z_I once the blocks above are in; then every thread
+    //      c < 16 I subtracts H_I,J(c)^T x_I (16 consecutive doubles of tile (I, c / 16)). One barrier per block. ----
     const int IB = N >> 4, r = N & 15;
-    double yreg = 0.0;
-    if (tid < 16 * nbc && tid < N) {
+    __syncthreads();
+    double z = 0.0;
+    if (tid < N) {
         const int J = tid >> 4, cl = tid & 15;
-        if (J < IB) yreg = A[(c16_tile(IB, J) << 8) + cl * 16 + r];
-        else yreg = pub[(J & 1) * C16_PUB + (cl >> 2) * C16_STEP + 16 * (cl & 3) + r];   // lane (row r, k = cl & 3) of step cl / 4
+        if (J < IB) z = A[(c16_tile(IB, J) << 8) + cl * 16 + r];
+    }
+    if (r > 0 && (tid >> 4) == IB) {       // the block that shares its diagonal tile with the right-hand side: z = L_JJ^-T y_J
+        const int cl = tid & 15;
+        yv[tid] = tid < N ? pub[(IB & 1) * C16_PUB + (cl >> 2) * C16_STEP + 16 * (cl & 3) + r] : 0.0;   // lane (row r, k = cl & 3) of step cl / 4
+        const double* lt = A + (c16_tile(IB, IB) << 8) + cl;
+        const double* v = yv + 16 * IB;
+        double xi = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) xi = __builtin_fma(lt[c * 16], v[c], xi);
+        z = tid < N ? xi : 0.0;
     }
     bool bad = false;
-    for (int J = nbc - 1; J >= 0; J--) {
-        // the block's right-looking update reads L[16 J .. 16 J + 15][c]: issued before the barrier (independent of x_J)
-        double lcol[16];
-        if (tid < 16 * J) {
-            const double* lt = A + (c16_tile(J, tid >> 4) << 8) + (tid & 15) * 16;
+    for (int I = nbc - 1; I >= 0; I--) {
+        double hcol[16];
+        if (tid < 16 * I) {                // issued before the barrier: independent of x_I
+            const double* ht = A + (c16_tile(I, tid >> 4) << 8) + (tid & 15) * 16;
 #pragma unroll
-            for (int i = 0; i < 16; i++) lcol[i] = lt[i];
+            for (int i = 0; i < 16; i++) hcol[i] = ht[i];
         }
-        if ((tid >> 4) == J) {              // 16 consecutive lanes of one wave = one DPP row
-            const int i = tid & 15;
-            const double* lt = A + (c16_tile(J, J) << 8) + i;
-            // x_i = sum_d L_JJ^-T[i][(i + d) % 16] v[(i + d) % 16]: v rotated through the row with DPP row_ror
-            double xi = lt[i * 16] * yreg;
-            double v = yreg;
-            int src = i;                      // rotated with the value: whose v the lane holds (direction-proof)
-#pragma unroll
-            for (int d = 1; d < 16; d++) {
-                v = c16_row_ror1(v);
-                src = __builtin_amdgcn_update_dpp(0, src, 0x12F, 0xF, 0xF, true);
-                xi = __builtin_fma(lt[src * 16], v, xi);
-            }
-            if (tid < N) { xs[tid] = xi; if (!(fabs(xi) < 1e300)) bad = true; }
-            yv[tid] = tid < N ? xi : 0.0;
+        if ((tid >> 4) == I) {
+            yv[tid] = z;
+            if (tid < N) { xs[tid] = z; if (!(fabs(z) < 1e300)) bad = true; }
         }
+        if (I == 0) break;
         __syncthreads();
-        if (tid < 16 * J) {
-            const double* xj = yv + 16 * J;
+        if (tid < 16 * I) {
+            const double* xi = yv + 16 * I;
 #pragma unroll
-            for (int i = 0; i < 16; i++) yreg = __builtin_fma(-lcol[i], xj[i], yreg);
+            for (int i = 0; i < 16; i++) z = __builtin_fma(-hcol[i], xi[i], z);
         }
     }
     if (bad) s_bad = 1;

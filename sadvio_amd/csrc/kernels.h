@@ -1160,8 +1160,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     double* gf = BIG ? gfullg : y + Np;         // full gradient
     double* hd = BIG ? hdg : gf + Np;           // diag(H)
     double* xs = BIG ? gredg : hd + Np;         // solution (BIG: the library factorisation overwrites the right-hand side)
-    double* pub = xs + Np + (Np & 1);           // chol16: published pivot steps (2 * C16_PUB + 64), 16-byte aligned
-    double* yv = pub + 2 * C16_PUB + 64;        // chol16: back-substitution exchange (16 * nbt)
+    double* pub = xs + Np + (Np & 1);           // chol16: exchange area (C16_WORK doubles), 16-byte aligned
+    double* yv = pub + C16_WORK;                // chol16: back-substitution exchange (16 * nbt)
     auto aidx = [&](int i, int j) -> long long { return BIG ? (long long)i * ld + j : (long long)c16_index(i, j); };  // i >= j
     const int cur = st.cur;
     const double* xp = P.xp + (long long)cur * P.xp_stride;
@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     long long* ts = SADVIO_TS_PTR((P.debug & 4096) && blockIdx.x == 0 && slot == 3);
     if (MODE == 0) {
         bool ok = true;  // Np == 0 (every key-frame constant, landmarkOptimization): nothing to factor
-        if (Np > 0) ok = c16_solve<0>(A, Np, xs, pub, yv, nullptr);
+        if (Np > 0) ok = c16_solve<1>(A, Np, xs, pub, yv, nullptr);
         (void)ts;
         if (!ok) {
             if (tid == 0) acc->chol_fail = 1;
