@@ -141,14 +141,24 @@ typedef struct sadvio_pose_prior {
 #define SADVIO_SPARSE_POSE_TO_LMK 1
 #define SADVIO_SPARSE_LMK_PRIOR 2
 #define SADVIO_SPARSE_LMK_TO_LMK 3
+/*   SADVIO_SPARSE_RELATIVE_POSE  Relative6DPose           (residuals.hpp:70-131)   kf = a, kf_b = b; T_prior = T_a_b_prior,
+ *                                sqrt_inf 6x6. The factor a pose graph over sparsified windows is made of (SURVEY.md §8f
+ *                                rank 2; information from sadvio_ba_marginalize_relative). As coded it composes its deltas on
+ *                                the FRAME-TO-WORLD transforms, T_w_a (exp(w), t): in a window that carries such factors the
+ *                                kf_T_f_w slots of a and b are read as T_w_a / T_w_b (a pose-graph window passes frame-to-world
+ *                                poses; mixing with visual factors, which read the slot as world-to-frame, is the caller's
+ *                                business). */
+#define SADVIO_SPARSE_RELATIVE_POSE 4
 typedef struct sadvio_sparse_prior {
     int32_t type;
     int32_t kf;          /* key-frame index in the window, or -1 */
     int32_t lmk0, lmk1;  /* landmark indices in the window, or -1 */
-    double T_prior[12];  /* IMUPriordx */
+    double T_prior[12];  /* IMUPriordx; Relative6DPose: T_a_b_prior */
     double v_prior[3], ba_prior[3], bg_prior[3];
     double delta[3];
     double sqrt_inf[225];
+    int32_t kf_b;        /* Relative6DPose: the second key-frame */
+    int32_t pad;
 } sadvio_sparse_prior;
 
 /* Solver options. sadvio_ba_default_options() fills the reference's hard-coded values
@@ -267,6 +277,18 @@ int sadvio_ba_marginalize(sadvio_ba_handle *h, int32_t w, const sadvio_marg_requ
 int sadvio_ba_sparsify(sadvio_ba_handle *h, int32_t w, int32_t vio, int32_t n_full, int32_t n, const double *J,
                        int32_t kf_keep, int32_t kf_col, int32_t n_keep, const int32_t *lmk_index, const int32_t *lmk_col,
                        int32_t *n_out, sadvio_sparse_prior *out);
+
+/* ---- relative-pose information between two key-frames (NFR), SURVEY.md §8f rank 2 --------------------------------
+ * Replaces BundleAdjustmentCERESAnalytic::marginalizeRelative (…Analytic.cpp:665-809) with
+ * Marginalization::preMarginalizeRelative (marginalization.cpp:532-588) on window `w`: every landmark of kf_a that also
+ * has a feature in kf_b is marginalised (reprojection factors of its features in the two frames), the two poses are
+ * kept (n = 12), Ak -> Sigma_k = pseudo-inverse through the rank-revealing decomposition, and the information of a
+ * Relative6DPose(T_w_a, T_w_b, T_a_b = T_a_w T_w_b, sqrt_inf = I) factor is recovered: inf = (J Sigma_k J^T)^-1.
+ * As coded: a landmark enters the list once PER feature it has in kf_b, and its factors are added once per entry (stereo
+ * landmarks count twice). Frames with IMU states are refused (the reference indexes their velocity / bias columns
+ * outside of its own layout, :705-737). Returns SADVIO_E_REFUSED when no landmark is shared.
+ * inf36: 6x6 row-major (rotation 3 | translation 3); Ak144 (may be NULL): the 12x12 reduced information. */
+int sadvio_ba_marginalize_relative(sadvio_ba_handle *h, int32_t w, int32_t kf_a, int32_t kf_b, double *inf36, double *Ak144);
 
 /* ---- one window spanning several GPUs (no reference counterpart: the reference is one process) ----
  * The landmarks of a window (with all their observations) are partitioned over `world` processes, one GPU each;

@@ -215,6 +215,58 @@ static inline void factor_pose_prior(const double *T0, const double *Tprior, con
     }
 }
 
+/*
+ * Relative6DPose::Evaluate (residuals.hpp:70-131). Ta / Tb: the transforms the factor composes its deltas on (the reference
+ * passes frame-to-world poses T_w_a, T_w_b, …Analytic.cpp:787-790); Tab: T_a_b_prior; W: 6x6 sqrt information, row-major.
+ * r = W [log(R); t] of T = T_a_b_prior^-1 (Ta dTa)^-1 (Tb dTb). Ja, Jb 6x6 row-major (may be NULL).
+ */
+static inline void factor_relative_pose(const double *Ta, const double *Tb, const double *Tab, const double *W, const double *da,
+                                        const double *db, double *r /*6*/, double *Ja /*6x6*/, double *Jb /*6x6*/) {
+    double dTa[12], dTb[12], Tau[12], Tbu[12], Tba[12], Taui[12], M[12], T[12], e[6], w[3];
+    se3_from_delta6(da, dTa); se3_from_delta6(db, dTb);
+    se3_mul(Ta, dTa, Tau); se3_mul(Tb, dTb, Tbu);              /* :80-81 */
+    se3_inverse(Tab, Tba);                                     /* :82 */
+    se3_inverse(Tau, Taui);
+    se3_mul(Tba, Taui, M); se3_mul(M, Tbu, T);                 /* :83 */
+    so3_log(T, w);
+    e[0] = w[0]; e[1] = w[1]; e[2] = w[2]; e[3] = T[9]; e[4] = T[10]; e[5] = T[11];   /* se3_RTtoVec6d, :84 */
+    for (int i = 0; i < 6; i++) { double s = 0; for (int j = 0; j < 6; j++) s += W[6 * i + j] * e[j]; r[i] = s; }
+    if (!Ja && !Jb) return;
+    double Jrw[9], Jrwi[9];
+    so3_right_jacobian(w, Jrw);                                /* w = log_so3(T.rotation()), :90 */
+    m3_inverse(Jrw, Jrwi);
+    double J[36];
+    if (Ja) {
+        double Jrd[9], A[9], B[9], C[9], tba[3], S[9];
+        so3_right_jacobian(da, Jrd);
+        memset(J, 0, sizeof(J));
+        m3_tmul(Tbu, Tau, A);                                  /* R_b^T R_a */
+        m3_mul(Jrwi, A, B); m3_mul(B, Jrd, C);                 /* :98-99, negated below */
+        for (int i = 0; i < 3; i++) tba[i] = Tbu[9 + i] - Tau[9 + i];
+        so3_skew(tba, S);
+        double D1[9], D2[9], D3[9], D4[9];
+        m3_mul_t(Tba, Tau, D1);                                /* R_ba_prior R_a^T */
+        m3_mul(D1, S, D2); m3_mul(D2, Tau, D3); m3_mul(D3, Jrd, D4);   /* :102-104 */
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                J[i * 6 + j] = -C[3 * i + j];
+                J[(3 + i) * 6 + j] = D4[3 * i + j];
+                J[(3 + i) * 6 + 3 + j] = -Tba[3 * i + j];      /* :107 */
+            }
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { double s = 0; for (int k = 0; k < 6; k++) s += W[6 * i + k] * J[6 * k + j]; Ja[6 * i + j] = s; }
+    }
+    if (Jb) {
+        double Jrd[9], B[9], D1[9], D2[9];
+        so3_right_jacobian(db, Jrd);
+        memset(J, 0, sizeof(J));
+        m3_mul(Jrwi, Jrd, B);                                  /* :118 */
+        m3_mul_t(Tba, Tau, D1); m3_mul(D1, Tbu, D2);           /* :121 */
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) { J[i * 6 + j] = B[3 * i + j]; J[(3 + i) * 6 + 3 + j] = D2[3 * i + j]; }
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { double s = 0; for (int k = 0; k < 6; k++) s += W[6 * i + k] * J[6 * k + j]; Jb[6 * i + j] = s; }
+    }
+}
+
 /* IMUPriordx::Evaluate (residuals.hpp:649-695). params: pose6 | dv3 | dba3 | dbg3. r = W e (15), e = [log(R Rp^-1);
  * trans(T Tp^-1); v + dv - vp; ba + dba - bap; bg + dbg - bgp]. Jacobian 15x15 row-major [pose6|v3|ba3|bg3]: the pose
  * block is W * [J6; 0] (:676), the v / ba / bg blocks are plain identities at rows 6 / 9 / 12 -- NOT multiplied by

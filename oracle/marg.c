@@ -21,6 +21,7 @@
 #include "sadvio_oracle.h"
 
 #define MARG_EPS 1e-12 /* marginalization.hpp:56 */
+static void small_inverse(const double *A, int n, double *Ai);
 
 /* Eigenvalue cut of the pseudo-inverse / rank-revealing decomposition. The reference keeps
  * lambda > 1e-12 (absolute, marginalization.cpp:237,322). On its own test fixture
@@ -292,6 +293,132 @@ int oracle_marginalize(const oracle_marg_request *rq, oracle_marg_result *res, i
     }
     free(A); free(b); free(lcol); free(Amm); free(ev); free(V); free(Ainv); free(T); free(Ak); free(bk);
     free(Aks); free(ev2); free(V2);
+    return SADVIO_OK;
+}
+
+/* ---- relative-pose information (NFR) between two key-frames ----------------------------------------------------
+ * BundleAdjustmentCERESAnalytic::marginalizeRelative (…Analytic.cpp:665-809) + Marginalization::preMarginalizeRelative
+ * (marginalization.cpp:532-588), VO frames. As coded: the list of landmarks to marginalise gets one entry per feature a
+ * landmark of frame a has in frame b (:548-559: a stereo landmark is entered twice, its column index is the first
+ * entry's, the second entry's 3 columns stay empty) and the reprojection factors of a landmark (its features in a and
+ * b) are added once per entry (:741-770). Kept: pose a at m, pose b at m + 6. The pseudo-inverse of Amm goes through
+ * its eigen-decomposition in the reference; Amm is block diagonal here (3x3 per landmark, empty blocks for the repeated
+ * entries), so the decomposition is done block by block — the same eigenvalues, the same cut, the same pseudo-inverse.
+ * Then Sigma_k = U diag(1 / lambda) U^T (:255-262) and inf = (J Sigma_k J^T)^-1 with J = [Ja Jb] of
+ * Relative6DPose(T_w_a, T_w_b, T_a_b, I) at zero deltas (:784-807). */
+int oracle_marginalize_relative(const sadvio_flat_window *w, int32_t kf_a, int32_t kf_b, double *inf36, double *Ak_out /*144 or NULL*/,
+                                int32_t *m_out) {
+    static const double z[6] = {0, 0, 0, 0, 0, 0};
+    if (w->has_imu) return SADVIO_E_INVALID_ARG;
+    /* entries: (landmark, first index) in the order of preMarginalizeRelative */
+    int cap = 16, ne = 0;
+    int *el = (int *)malloc(sizeof(int) * cap), *ec = (int *)malloc(sizeof(int) * cap);
+    int *first = (int *)malloc(sizeof(int) * (size_t)(w->n_lmk > 0 ? w->n_lmk : 1));
+    for (int l = 0; l < w->n_lmk; l++) first[l] = -1;
+    int last = 0;
+    for (int l = 0; l < w->n_lmk; l++) {   /* frame a's landmarks, window order */
+        int in_a = 0;
+        for (int o = w->lmk_obs_ptr[l]; o < w->lmk_obs_ptr[l + 1]; o++) in_a |= w->obs_kf[o] == kf_a;
+        if (!in_a) continue;
+        for (int o = w->lmk_obs_ptr[l]; o < w->lmk_obs_ptr[l + 1]; o++) {
+            if (w->obs_kf[o] != kf_b) continue;
+            if (ne == cap) { cap *= 2; el = (int *)realloc(el, sizeof(int) * cap); ec = (int *)realloc(ec, sizeof(int) * cap); }
+            if (first[l] < 0) first[l] = last;
+            el[ne] = l; ec[ne] = first[l]; ne++;
+            last += 3;
+        }
+    }
+    const int m = last, n = 12, N = m + n;
+    if (m_out) *m_out = m;
+    if (ne == 0) { free(el); free(ec); free(first); return SADVIO_E_REFUSED; }
+    /* Amm blocks (3x3 per column index), Arm (12 x m), Arr (12 x 12); b is not needed for the information */
+    double *Amm = (double *)calloc((size_t)m * 3, sizeof(double));      /* block l0: rows l0..l0+2 x 3 */
+    double *Arm = (double *)calloc((size_t)n * m, sizeof(double));
+    double Arr[144];
+    memset(Arr, 0, sizeof(Arr));
+    for (int e = 0; e < ne; e++) {
+        const int l = el[e], lc = ec[e];
+        for (int o = w->lmk_obs_ptr[l]; o < w->lmk_obs_ptr[l + 1]; o++) {
+            const int kf = w->obs_kf[o];
+            if (kf != kf_a && kf != kf_b) continue;
+            const int cam = w->obs_cam[o], pc = kf == kf_a ? 0 : 6;
+            double r[2], Jp[12], Jl[6];
+            const double sigma = w->cam_sigma ? w->cam_sigma[cam] : 1.0;
+            if (w->factor_type == SADVIO_FACTOR_PIXEL)
+                factor_pixel(w->kf_T_f_w + 12 * kf, w->cam_K + 4 * cam, w->cam_T_s_f + 12 * cam, w->lmk_p + 3 * l, w->obs_meas + 2 * o,
+                             sigma, z, z, r, Jp, Jl);
+            else
+                factor_angular(w->kf_T_f_w + 12 * kf, w->cam_T_s_f + 12 * cam, w->lmk_p + 3 * l, w->obs_meas + 3 * o, sigma, z, z, r, Jp, Jl);
+            for (int q = 0; q < 2; q++) {
+                for (int a = 0; a < 3; a++) {
+                    for (int b2 = 0; b2 < 3; b2++) Amm[(size_t)(lc + a) * 3 + b2] += Jl[q * 3 + a] * Jl[q * 3 + b2];
+                    for (int p = 0; p < 6; p++) Arm[(size_t)(pc + p) * m + lc + a] += Jp[q * 6 + p] * Jl[q * 3 + a];
+                }
+                for (int p = 0; p < 6; p++) for (int p2 = 0; p2 < 6; p2++) Arr[(pc + p) * 12 + pc + p2] += Jp[q * 6 + p] * Jp[q * 6 + p2];
+            }
+        }
+    }
+    /* Ak = Arr - Arm Amm^+ Arm^T, Amm^+ block by block; the cut of the whole matrix (marg_cut over ALL eigenvalues) */
+    double *ev = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1)), *V = (double *)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1) * 3);
+    for (int c0 = 0; c0 < m; c0 += 3) {
+        double B[9], e3[3], V3[9];
+        for (int a = 0; a < 3; a++) for (int b2 = 0; b2 < 3; b2++) B[3 * a + b2] = 0.5 * (Amm[(size_t)(c0 + a) * 3 + b2] + Amm[(size_t)(c0 + b2) * 3 + a]);
+        oracle_sym_eig(B, 3, e3, V3);
+        for (int k = 0; k < 3; k++) { ev[c0 + k] = e3[k]; for (int a = 0; a < 3; a++) V[(size_t)(c0 + a) * 3 + k] = V3[3 * a + k]; }
+    }
+    const double cut = marg_cut(ev, m);
+    double Ak[144];
+    memcpy(Ak, Arr, sizeof(Ak));
+    for (int c0 = 0; c0 < m; c0 += 3) {
+        double Pi[9];
+        memset(Pi, 0, sizeof(Pi));
+        for (int k = 0; k < 3; k++) {
+            if (!(ev[c0 + k] > cut)) continue;
+            const double iv = 1.0 / ev[c0 + k];
+            for (int a = 0; a < 3; a++) for (int b2 = 0; b2 < 3; b2++) Pi[3 * a + b2] += V[(size_t)(c0 + a) * 3 + k] * iv * V[(size_t)(c0 + b2) * 3 + k];
+        }
+        for (int i = 0; i < 12; i++) {
+            double t[3];
+            for (int b2 = 0; b2 < 3; b2++) t[b2] = Arm[(size_t)i * m + c0] * Pi[b2] + Arm[(size_t)i * m + c0 + 1] * Pi[3 + b2] + Arm[(size_t)i * m + c0 + 2] * Pi[6 + b2];
+            for (int j = 0; j < 12; j++) Ak[i * 12 + j] -= t[0] * Arm[(size_t)j * m + c0] + t[1] * Arm[(size_t)j * m + c0 + 1] + t[2] * Arm[(size_t)j * m + c0 + 2];
+        }
+    }
+    if (Ak_out) memcpy(Ak_out, Ak, sizeof(Ak));
+    /* rank revealing decomposition (Eigen reads the lower triangle), Sigma_k = U diag(1 / lambda) U^T */
+    double Aks[144], ev2[12], V2[144], Sk[144];
+    for (int i = 0; i < 12; i++) for (int j = 0; j <= i; j++) Aks[i * 12 + j] = Aks[j * 12 + i] = Ak[i * 12 + j];
+    oracle_sym_eig(Aks, 12, ev2, V2);
+    /* Ak has an exact 6-dimensional null space (the gauge: only the relative pose is observed), whose eigenvalues
+     * compute to the rounding noise of the Schur complement — a sum over the marginalised landmarks of terms as large as
+     * lambda_max, i.e. ~ eps * lambda_max * (number of terms), 1e-7 .. 4e-6 on the test windows against 1e3 for the
+     * smallest real eigenvalue. The reference's absolute 1e-12 (marginalization.cpp:322) keeps whichever of them come out
+     * positive (1 / lambda ~ 1e6: its information matrix is then noise); the cut here is the noise floor of that sum, which
+     * returns the exact-arithmetic value of the reference's formula (cf. marg_cut). */
+    double cut_n = marg_cut(ev2, 12);
+    {
+        int n_l = 0;
+        for (int l = 0; l < w->n_lmk; l++) n_l += first[l] >= 0;
+        cut_n = fmax(cut_n, cut_n * (2.0 + n_l));
+    }
+    memset(Sk, 0, sizeof(Sk));
+    for (int k = 0; k < 12; k++) {
+        if (!(ev2[k] > cut_n)) continue;
+        const double iv = 1.0 / ev2[k];
+        for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) Sk[i * 12 + j] += V2[i * 12 + k] * iv * V2[j * 12 + k];
+    }
+    /* Relative6DPose(T_w_a, T_w_b, T_a_b = T_a_w T_w_b, I) at zero deltas */
+    double Twa[12], Twb[12], Tab[12], W[36], r6[6], Ja[36], Jb[36], J[72];
+    se3_inverse(w->kf_T_f_w + 12 * kf_a, Twa); se3_inverse(w->kf_T_f_w + 12 * kf_b, Twb);
+    se3_mul(w->kf_T_f_w + 12 * kf_a, Twb, Tab);
+    memset(W, 0, sizeof(W));
+    for (int i = 0; i < 6; i++) W[7 * i] = 1.0;
+    factor_relative_pose(Twa, Twb, Tab, W, z, z, r6, Ja, Jb);
+    for (int i = 0; i < 6; i++) for (int q = 0; q < 6; q++) { J[i * 12 + q] = Ja[i * 6 + q]; J[i * 12 + 6 + q] = Jb[i * 6 + q]; }
+    double JS[72], cov[36];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 12; j++) { double s2 = 0; for (int k = 0; k < 12; k++) s2 += J[i * 12 + k] * Sk[k * 12 + j]; JS[i * 12 + j] = s2; }
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { double s2 = 0; for (int k = 0; k < 12; k++) s2 += JS[i * 12 + k] * J[j * 12 + k]; cov[i * 6 + j] = s2; }
+    small_inverse(cov, 6, inf36);
+    free(el); free(ec); free(first); free(Amm); free(Arm); free(ev); free(V);
     return SADVIO_OK;
 }
 

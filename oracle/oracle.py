@@ -225,6 +225,18 @@ def marginalize(w: FlatWindow, kf_marg, lmk_marg, lmk_keep, kf_keep=-1, marg_has
             "lmk_index": kp.copy(), "lmk_col": lmk_col[: len(kp)].copy(), "m": res.m, "n": res.n, "n_full": nf, "Ak": Ak, "bk": bk}
 
 
+def marginalize_relative(w: FlatWindow, kf_a: int, kf_b: int):
+    """(inf[6,6], Ak[12,12], m) of oracle_marginalize_relative, or None when no landmark is shared."""
+    wc, wkeep = S.window_to_c(w)
+    inf = np.zeros((6, 6)); Ak = np.zeros((12, 12)); m = C.c_int32(0)
+    f = lib().oracle_marginalize_relative
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(C.c_int32)]
+    rc = f(C.byref(wc), kf_a, kf_b, _p(inf), _p(Ak), C.byref(m))
+    if rc != 0:
+        return None
+    return inf, Ak, m.value
+
+
 def sparsify(w: FlatWindow, prior: dict, vio: bool):
     """oracle_sparsify: dense prior dict -> list of sparse prior dicts (None when refused)."""
     wc, wkeep = S.window_to_c(w)
@@ -242,8 +254,8 @@ def sparsify(w: FlatWindow, prior: dict, vio: bool):
 
 
 def _sparse_to_dict(s):
-    n = 15 if s.type == 0 else 3
-    return {"type": int(s.type), "kf": int(s.kf), "lmk0": int(s.lmk0), "lmk1": int(s.lmk1),
+    n = 15 if s.type == 0 else (6 if s.type == 4 else 3)
+    return {"type": int(s.type), "kf": int(s.kf), "kf_b": int(s.kf_b), "lmk0": int(s.lmk0), "lmk1": int(s.lmk1),
             "T_prior": np.array(s.T_prior[:]), "v_prior": np.array(s.v_prior[:]), "ba_prior": np.array(s.ba_prior[:]),
             "bg_prior": np.array(s.bg_prior[:]), "delta": np.array(s.delta[:]),
             "sqrt_inf": np.array(s.sqrt_inf[: n * n]).reshape(n, n)}

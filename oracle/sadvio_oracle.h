@@ -53,6 +53,9 @@ int oracle_solve(const oracle_problem *prob, const sadvio_solve_options *opts, s
                  double *pose_delta6, double *lmk_delta3, double *dv3, double *dba3, double *dbg3,
                  double *iter_log, int32_t iter_log_cap);
 
+/* marginalizeRelative (…Analytic.cpp:665-809): 6x6 information of the relative pose of two VO key-frames. */
+int oracle_marginalize_relative(const sadvio_flat_window *win, int32_t kf_a, int32_t kf_b, double *inf36, double *Ak144, int32_t *m_out);
+
 /* ALandmark::sanityCheck per landmark (ALandmark.cpp:98-146): mean chi2 of the landmark's observations (failed
  * projection = 1000) and the 95 % gate (n_obs >= 2 && mean <= 2). Either output may be NULL. */
 int oracle_landmark_chi2(const sadvio_flat_window *win, const double *pose_delta6, const double *lmk_delta3,

@@ -116,6 +116,17 @@ static int sparse_small(const ctx_t *c, const state_t *x, const sadvio_sparse_pr
         if (want_J) for (int i = 0; i < 15; i++) for (int a = 0; a < 15; a++) f->J[i * 15 + a] = J[i * 15 + a];
         return 1;
     }
+    if (s->type == SADVIO_SPARSE_RELATIVE_POSE) {
+        int a = s->kf, b = s->kf_b, pa = c->kf_off[a], pb = c->kf_off[b];
+        if (pa < 0 && pb < 0) return 0;
+        double Ja[36], Jb[36];
+        factor_relative_pose(w->kf_T_f_w + 12 * a, w->kf_T_f_w + 12 * b, s->T_prior, s->sqrt_inf, x->xp + 6 * a, x->xp + 6 * b,
+                             f->r, want_J ? Ja : NULL, want_J ? Jb : NULL);
+        f->rows = 6; f->ncols = 12;
+        for (int q = 0; q < 6; q++) { f->col[q] = pa < 0 ? -1 : pa + q; f->col[6 + q] = pb < 0 ? -1 : pb + q; }
+        if (want_J) for (int i = 0; i < 6; i++) for (int q = 0; q < 6; q++) { f->J[i * 12 + q] = Ja[i * 6 + q]; f->J[i * 12 + 6 + q] = Jb[i * 6 + q]; }
+        return 1;
+    }
     f->rows = 3;
     if (s->type == SADVIO_SPARSE_POSE_TO_LMK) {
         int k = s->kf, l = s->lmk0, po = c->kf_off[k], lo = c->lmk_red[l];
@@ -614,7 +625,7 @@ static void ctx_init(ctx_t *c, const oracle_problem *P) {
     }
     for (int k = 0; k < P->n_sparse; k++) {
         const sadvio_sparse_prior *s = P->sparse + k;
-        int ls[2] = {s->type == SADVIO_SPARSE_IMU_PRIOR ? -1 : s->lmk0, s->type == SADVIO_SPARSE_LMK_TO_LMK ? s->lmk1 : -1};
+        int ls[2] = {(s->type == SADVIO_SPARSE_IMU_PRIOR || s->type == SADVIO_SPARSE_RELATIVE_POSE) ? -1 : s->lmk0, s->type == SADVIO_SPARSE_LMK_TO_LMK ? s->lmk1 : -1};
         for (int q = 0; q < 2; q++) {
             int l = ls[q];
             if (l < 0 || c->lmk_red[l] >= 0) continue;
@@ -1070,6 +1081,13 @@ int oracle_sparse_factor(const sadvio_flat_window *w, const sadvio_sparse_prior 
                          s->T_prior, s->v_prior, s->ba_prior, s->bg_prior, s->sqrt_inf, params, r, J ? Jf : NULL);
         if (J) memcpy(J, Jf, sizeof(Jf));
         return 15;
+    }
+    if (s->type == SADVIO_SPARSE_RELATIVE_POSE) {
+        double Ja[36], Jb[36];
+        factor_relative_pose(w->kf_T_f_w + 12 * s->kf, w->kf_T_f_w + 12 * s->kf_b, s->T_prior, s->sqrt_inf, xp ? xp + 6 * s->kf : z,
+                             xp ? xp + 6 * s->kf_b : z, r, J ? Ja : NULL, J ? Jb : NULL);
+        if (J) { memset(J, 0, sizeof(double) * 90); for (int i = 0; i < 6; i++) for (int q = 0; q < 6; q++) { J[i * 15 + q] = Ja[i * 6 + q]; J[i * 15 + 6 + q] = Jb[i * 6 + q]; } }
+        return 6;
     }
     const double *d0 = xl ? xl + 3 * s->lmk0 : z;
     if (J) memset(J, 0, sizeof(double) * 45);

@@ -32,7 +32,7 @@ class pose_prior(C.Structure):             # sadvio_pose_prior
 
 class sparse_prior(C.Structure):           # sadvio_sparse_prior
     _fields_ = [("type", i32), ("kf", i32), ("lmk0", i32), ("lmk1", i32), ("T_prior", f64 * 12), ("v_prior", f64 * 3),
-                ("ba_prior", f64 * 3), ("bg_prior", f64 * 3), ("delta", f64 * 3), ("sqrt_inf", f64 * 225)]
+                ("ba_prior", f64 * 3), ("bg_prior", f64 * 3), ("delta", f64 * 3), ("sqrt_inf", f64 * 225), ("kf_b", i32), ("pad", i32)]
 
 
 class solve_options(C.Structure):          # sadvio_solve_options
@@ -132,6 +132,7 @@ def sparse_to_c(factors):
     for i, f in enumerate(factors):
         a = arr[i]
         a.type, a.kf, a.lmk0, a.lmk1 = int(f["type"]), int(f.get("kf", -1)), int(f.get("lmk0", -1)), int(f.get("lmk1", -1))
+        a.kf_b = int(f.get("kf_b", -1))
         for k, n in (("T_prior", 12), ("v_prior", 3), ("ba_prior", 3), ("bg_prior", 3), ("delta", 3)):
             v = np.zeros(n) if f.get(k) is None else np.asarray(f[k], dtype=np.float64).ravel()
             getattr(a, k)[:] = list(v)

@@ -250,6 +250,30 @@ def pose_prior_factor(B, T_f_w0, T_prior, inf_diag, dpose):
     return W * err, W[:, None] * J
 
 
+def relative_pose_factor(B, Ta, Tb, Tab_prior, W, da, db):
+    """Relative6DPose::Evaluate (residuals.hpp:70-131): r[6], Ja[6,6], Jb[6,6]. Ta / Tb are the transforms the deltas are
+    composed on (T_w_a, T_w_b in the reference's only use, BundleAdjustmentCERESAnalytic.cpp:787-790)."""
+    Ra, ta = split_T(B, Ta); Rb, tb = split_T(B, Tb); Rp, tp = split_T(B, Tab_prior)
+    da = B.a(da); db = B.a(db); W = B.a(np.asarray(W).reshape(6, 6))
+    Rau = Ra @ exp_so3(B, da[:3]); tau = Ra @ da[3:6] + ta             # T_w_a_up  (:80)
+    Rbu = Rb @ exp_so3(B, db[:3]); tbu = Rb @ db[3:6] + tb             # T_w_b_up  (:81)
+    Rpi = Rp.T; tpi = -(Rpi @ tp)                                      # T_b_a_prior  (:82)
+    Rai = Rau.T; tai = -(Rai @ tau)
+    R1 = Rpi @ Rai; t1 = Rpi @ tai + tpi
+    R = R1 @ Rbu; t = R1 @ tbu + t1                                     # T  (:83)
+    w = log_so3(B, R)
+    err = W @ np.concatenate([w, t])                                    # :84
+    Jri = inv3(B, so3_right_jacobian(B, w))
+    Ja = B.eye(6)
+    Ja[:3, :3] = -(Jri @ Rbu.T @ Rau @ so3_right_jacobian(B, da[:3]))   # :98-99
+    Ja[3:, :3] = Rpi @ Rau.T @ skew(B, tbu - tau) @ Rau @ so3_right_jacobian(B, da[:3])   # :102-104
+    Ja[3:, 3:] = -Rpi                                                   # :107
+    Jb = B.eye(6)
+    Jb[:3, :3] = Jri @ so3_right_jacobian(B, db[:3])                    # :118
+    Jb[3:, 3:] = Rpi @ Rau.T @ Rbu                                      # :121
+    return err, W @ Ja, W @ Jb
+
+
 def huber(B, s, a):
     """ceres::HuberLoss(a)::Evaluate -> (rho, rho'), loss_function.cc; s = |r|^2."""
     b = B.s(a) * B.s(a)

@@ -78,10 +78,11 @@ class PosePriorC(C.Structure):
 class SparsePriorC(C.Structure):
     _fields_ = [("type", C.c_int32), ("kf", C.c_int32), ("lmk0", C.c_int32), ("lmk1", C.c_int32),
                 ("T_prior", C.c_double * 12), ("v_prior", C.c_double * 3), ("ba_prior", C.c_double * 3),
-                ("bg_prior", C.c_double * 3), ("delta", C.c_double * 3), ("sqrt_inf", C.c_double * 225)]
+                ("bg_prior", C.c_double * 3), ("delta", C.c_double * 3), ("sqrt_inf", C.c_double * 225),
+                ("kf_b", C.c_int32), ("pad", C.c_int32)]
 
 
-SPARSE_IMU_PRIOR, SPARSE_POSE_TO_LMK, SPARSE_LMK_PRIOR, SPARSE_LMK_TO_LMK = 0, 1, 2, 3
+SPARSE_IMU_PRIOR, SPARSE_POSE_TO_LMK, SPARSE_LMK_PRIOR, SPARSE_LMK_TO_LMK, SPARSE_RELATIVE_POSE = 0, 1, 2, 3, 4
 
 
 class MargRequestC(C.Structure):
@@ -263,6 +264,7 @@ class FlatWindow:
         for i, f in enumerate(self.sparse_priors):
             a = arr[i]
             a.type = int(f["type"]); a.kf = int(f.get("kf", -1)); a.lmk0 = int(f.get("lmk0", -1)); a.lmk1 = int(f.get("lmk1", -1))
+            a.kf_b = int(f.get("kf_b", -1))
             for k, n in (("T_prior", 12), ("v_prior", 3), ("ba_prior", 3), ("bg_prior", 3), ("delta", 3)):
                 v = np.zeros(n) if f.get(k) is None else np.asarray(f[k], dtype=np.float64).ravel()
                 getattr(a, k)[:] = list(v)
@@ -339,6 +341,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.sadvio_ba_get_deltas.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
     lib.sadvio_ba_get_ids.argtypes = [C.c_void_p, C.c_int32, _lp, _lp]
     lib.sadvio_ba_get_trace.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _ip]
+    lib.sadvio_ba_marginalize_relative.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]
     lib.sadvio_ba_linearize.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
     lib.sadvio_ba_vi_init.argtypes = [C.c_void_p, C.POINTER(ViInitProblemC), C.POINTER(SolveOptions), C.POINTER(SolveSummary),
                                       C.POINTER(ViInitResultC), _dp]
@@ -458,6 +461,15 @@ class Backend:
         return {"J": Jo[: nf * n].reshape(nf, n).copy(), "r0": r0o[:nf].copy(), "kf_keep": kf_keep, "kf_col": res.kf_col,
                 "lmk_index": kp.copy(), "lmk_col": lmk_col[: len(kp)].copy(), "m": res.m, "n": res.n, "n_full": nf,
                 "sweeps": (res.sweeps_mm, res.sweeps_k)}
+
+    def marginalize_relative(self, w: int, kf_a: int, kf_b: int):
+        """(inf[6,6], Ak[12,12]) of sadvio_ba_marginalize_relative, or None when refused (no shared landmark)."""
+        inf = np.zeros((6, 6)); Ak = np.zeros((12, 12))
+        rc = self.lib.sadvio_ba_marginalize_relative(self.h, w, kf_a, kf_b, _ptr(inf), _ptr(Ak))
+        if rc == E_REFUSED:
+            return None
+        self._check(rc, "marginalize_relative")
+        return inf, Ak
 
     def sparsify(self, w: int, prior: dict, vio: bool):
         """NFR sparsification of a dense prior dict (as returned by marginalize) into sparse_priors dicts."""

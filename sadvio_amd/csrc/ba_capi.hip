@@ -426,7 +426,9 @@ int layout_reduced(sadvio_ba_handle* h) {
                 continue;
             }
             o.kf = s.kf >= 0 ? d.kf_base + s.kf : -1;
-            const int ls[2] = {s.type == SADVIO_SPARSE_IMU_PRIOR ? -1 : s.lmk0, s.type == SADVIO_SPARSE_LMK_TO_LMK ? s.lmk1 : -1};
+            const bool rel = s.type == SADVIO_SPARSE_RELATIVE_POSE;
+            if (rel) { o.type = 5; o.kf2 = d.kf_base + s.kf_b; }   // internal type 4 is the pseudo-observation form above
+            const int ls[2] = {(s.type == SADVIO_SPARSE_IMU_PRIOR || rel) ? -1 : s.lmk0, s.type == SADVIO_SPARSE_LMK_TO_LMK ? s.lmk1 : -1};
             int gls[2] = {-1, -1};
             for (int q = 0; q < 2; q++) {
                 if (ls[q] < 0) continue;
@@ -695,7 +697,9 @@ static int build_layout(sadvio_ba_handle* h) {
     h->has_lmk_const = false;
     for (int w = 0; w < n_windows; w++) {
         const sadvio_flat_window& F = wins[w];
-        if (F.n_kf <= 0 || F.n_cam <= 0 || F.n_lmk < 0 || F.n_obs < 0 || !F.kf_T_f_w || !F.cam_K || !F.cam_T_s_f ||
+        // a pose-graph window (relative-pose factors only) has no cameras, landmarks or observations
+        if (F.n_kf <= 0 || F.n_cam < 0 || F.n_lmk < 0 || F.n_obs < 0 || !F.kf_T_f_w || (F.n_cam > 0 && (!F.cam_K || !F.cam_T_s_f)) ||
+            (F.n_obs > 0 && F.n_cam == 0) ||
             (F.n_lmk > 0 && (!F.lmk_p || !F.lmk_obs_ptr)) || (F.n_obs > 0 && (!F.obs_kf || !F.obs_cam || !F.obs_meas))) {
             h->err = "set_windows: missing array in window " + std::to_string(w);
             return SADVIO_E_INVALID_ARG;
@@ -930,7 +934,9 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
     h->uploaded = false; h->solved = false;
     for (int w = 0; w < n_windows; w++) {
         const sadvio_flat_window& F = wins[w];
-        if (F.n_kf <= 0 || F.n_cam <= 0 || F.n_lmk < 0 || F.n_obs < 0 || !F.kf_T_f_w || !F.cam_K || !F.cam_T_s_f ||
+        // a pose-graph window (relative-pose factors only) has no cameras, landmarks or observations
+        if (F.n_kf <= 0 || F.n_cam < 0 || F.n_lmk < 0 || F.n_obs < 0 || !F.kf_T_f_w || (F.n_cam > 0 && (!F.cam_K || !F.cam_T_s_f)) ||
+            (F.n_obs > 0 && F.n_cam == 0) ||
             (F.n_lmk > 0 && (!F.lmk_p || !F.lmk_obs_ptr)) || (F.n_obs > 0 && (!F.obs_kf || !F.obs_cam || !F.obs_meas))) {
             h->err = "set_windows: missing array in window " + std::to_string(w);
             return SADVIO_E_INVALID_ARG;
@@ -1115,9 +1121,14 @@ int sadvio_ba_set_sparse_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const
     const WinDev& d = h->wins[w].d;
     for (int i = 0; i < n; i++) {
         const sadvio_sparse_prior& s = f[i];
-        const bool need_kf = s.type == SADVIO_SPARSE_IMU_PRIOR || s.type == SADVIO_SPARSE_POSE_TO_LMK;
-        const bool need_l0 = s.type != SADVIO_SPARSE_IMU_PRIOR, need_l1 = s.type == SADVIO_SPARSE_LMK_TO_LMK;
-        if (s.type < 0 || s.type > 3 || (need_kf && (s.kf < 0 || s.kf >= d.n_kf)) || (need_l0 && (s.lmk0 < 0 || s.lmk0 >= d.n_lmk)) ||
+        const bool rel = s.type == SADVIO_SPARSE_RELATIVE_POSE;
+        if (rel && (s.kf_b < 0 || s.kf_b >= d.n_kf || s.kf_b == s.kf || d.dpf != 6)) {
+            h->err = "set_sparse_priors: relative-pose factor " + std::to_string(i) + " has a bad key-frame (or the window carries IMU states)";
+            return SADVIO_E_INVALID_ARG;
+        }
+        const bool need_kf = s.type == SADVIO_SPARSE_IMU_PRIOR || s.type == SADVIO_SPARSE_POSE_TO_LMK || rel;
+        const bool need_l0 = s.type != SADVIO_SPARSE_IMU_PRIOR && !rel, need_l1 = s.type == SADVIO_SPARSE_LMK_TO_LMK;
+        if (s.type < 0 || s.type > 4 || (need_kf && (s.kf < 0 || s.kf >= d.n_kf)) || (need_l0 && (s.lmk0 < 0 || s.lmk0 >= d.n_lmk)) ||
             (need_l1 && (s.lmk1 < 0 || s.lmk1 >= d.n_lmk || s.lmk1 == s.lmk0))) {
             h->err = "set_sparse_priors: factor " + std::to_string(i) + " has a bad type or index";
             return SADVIO_E_INVALID_ARG;
@@ -1428,6 +1439,67 @@ bool nfr_sqrt_info(const double* S, int rows, bool invert_first, double* W) {
 }
 }  // namespace
 
+int sadvio_ba_marginalize_relative(sadvio_ba_handle* h, int32_t w, int32_t kf_a, int32_t kf_b, double* inf36, double* Ak144) {
+    if (!h || !inf36) return SADVIO_E_INVALID_ARG;
+    if (!h->uploaded) { h->err = "marginalize_relative before set_windows"; return SADVIO_E_STATE; }
+    if (w < 0 || w >= (int)h->wins.size()) { h->err = "marginalize_relative: window out of range"; return SADVIO_E_INVALID_ARG; }
+    const WinDev& d = h->wins[w].d;
+    if (kf_a < 0 || kf_a >= d.n_kf || kf_b < 0 || kf_b >= d.n_kf || kf_a == kf_b) { h->err = "marginalize_relative: bad key-frame index"; return SADVIO_E_INVALID_ARG; }
+    if (d.has_imu) { h->err = "marginalize_relative: frames with IMU states are not supported (the reference's own column layout for them is inconsistent, BundleAdjustmentCERESAnalytic.cpp:705-737)"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    // preMarginalizeRelative (marginalization.cpp:532-588): a landmark of frame a is entered once per feature it has in frame b
+    const int ga = d.kf_base + kf_a, gb = d.kf_base + kf_b;
+    std::vector<int> items;
+    int m = 0;
+    for (int l = 0; l < d.n_lmk; l++) {
+        const int gl = d.lmk_base + l;
+        int ca = 0, cb = 0;
+        for (int o = h->h_lmk_ob[gl]; o < h->h_lmk_oe[gl]; o++) {
+            if (h->obs_perm[o] < 0) continue;      // pseudo-observation of a sparse prior factor
+            ca += h->h_obs_kf[o] == ga; cb += h->h_obs_kf[o] == gb;
+        }
+        if (ca > 0 && cb > 0) { items.push_back(gl); items.push_back(cb); m += 3 * cb; }
+    }
+    const int n_items = (int)items.size() / 2;
+    if (n_items == 0) { h->err = "marginalize_relative: the two key-frames share no landmark"; return SADVIO_E_REFUSED; }
+    DevBuf<int> ditems; DevBuf<double> dscr, dAk, dJ; DevBuf<unsigned long long> dmax;
+    HIP_TRY(ditems.alloc(items.size())); HIP_TRY(dscr.alloc((size_t)n_items * RELM_ROW)); HIP_TRY(dAk.alloc(144)); HIP_TRY(dJ.alloc(72)); HIP_TRY(dmax.alloc(1));
+    HIP_TRY(hipMemcpyAsync(ditems.p, items.data(), items.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(dAk.p, 0, 144 * sizeof(double), h->stream)); HIP_TRY(hipMemsetAsync(dmax.p, 0, 8, h->stream));
+    SolveOpts o{};
+    DevPtrs P = make_ptrs(h, o, 1);
+    auto kl = h->factor_type == SADVIO_FACTOR_PIXEL ? k_relmarg_lmk<0> : k_relmarg_lmk<1>;
+    hipLaunchKernelGGL(kl, dim3((n_items + 63) / 64), dim3(64), 0, h->stream, P, ditems.p, n_items, ga, gb, dscr.p, dAk.p, dmax.p);
+    hipLaunchKernelGGL(k_relmarg_apply, dim3((n_items + 63) / 64), dim3(64), 0, h->stream, dscr.p, n_items, m, dmax.p, dAk.p);
+    hipLaunchKernelGGL(k_relmarg_jac, dim3(1), dim3(64), 0, h->stream, P, ga, gb, dJ.p);
+    HIP_TRY(hipGetLastError());
+    double Ak[144], J[72];
+    HIP_TRY(hipMemcpyAsync(Ak, dAk.p, sizeof(Ak), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(J, dJ.p, sizeof(J), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (Ak144) memcpy(Ak144, Ak, sizeof(Ak));
+    // rankReveallingDecomposition (Eigen reads the lower triangle) -> Sigma_k = U diag(1 / lambda) U^T (marginalization.cpp:255-262)
+    double As[144], ev[12], V[144], Sk[144];
+    for (int i = 0; i < 12; i++) for (int j = 0; j <= i; j++) As[12 * i + j] = As[12 * j + i] = Ak[12 * i + j];
+    host_sym_eig(As, 12, ev, V);
+    double mx = 0.0;
+    for (int k = 0; k < 12; k++) mx = std::max(mx, std::fabs(ev[k]));
+    // noise floor of the Schur complement = a sum over the marginalised landmarks (see oracle/marg.c): the gauge null space
+    // of Ak computes to ~ eps * lambda_max * n_items
+    const double cut = std::max(1e-12, 12 * 2.220446049250313e-16 * mx * (2.0 + n_items));
+    memset(Sk, 0, sizeof(Sk));
+    for (int k = 0; k < 12; k++) {
+        if (!(ev[k] > cut)) continue;
+        const double iv = 1.0 / ev[k];
+        for (int i = 0; i < 12; i++) for (int j = 0; j < 12; j++) Sk[12 * i + j] += V[12 * i + k] * iv * V[12 * j + k];
+    }
+    double JS[72], cov[36];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 12; j++) { double s2 = 0; for (int k = 0; k < 12; k++) s2 += J[12 * i + k] * Sk[12 * k + j]; JS[12 * i + j] = s2; }
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { double s2 = 0; for (int k = 0; k < 12; k++) s2 += JS[12 * i + k] * J[12 * j + k]; cov[6 * i + j] = s2; }
+    if (!host_inverse(cov, 6, inf36)) { h->err = "marginalize_relative: singular covariance of the relative pose"; return SADVIO_E_REFUSED; }
+    return SADVIO_OK;
+}
+
 int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, int32_t n, const double* J, int32_t kf_keep,
                        int32_t kf_col, int32_t n_keep, const int32_t* lmk_index, const int32_t* lmk_col, int32_t* n_out,
                        sadvio_sparse_prior* out) {
@@ -1720,6 +1792,12 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             const int fi = h->h_kf_fidx[f.kf_i], fj = h->h_kf_fidx[f.kf_j];
             if (fi >= 0 && fj >= 0) hb = std::max(hb, std::abs(fi - fj));
         }
+        if (w < (int)h->sparse_per_win.size())
+            for (const sadvio_sparse_prior& sp : h->sparse_per_win[w])
+                if (sp.type == SADVIO_SPARSE_RELATIVE_POSE) {     // a relative-pose factor couples its two key-frames
+                    const int fi = h->h_kf_fidx[d.kf_base + sp.kf], fj = h->h_kf_fidx[d.kf_base + sp.kf_b];
+                    if (fi >= 0 && fj >= 0) hb = std::max(hb, std::abs(fi - fj));
+                }
         big_bw[w] = (d.n_red > 0 || d.dp_n_full > 0) ? d.Np : std::min(d.Np, (hb + 1) * d.dpf);
     }
     if (h->coll_fn && h->world > 1 && h->n_big) {

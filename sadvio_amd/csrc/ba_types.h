@@ -91,8 +91,8 @@ struct ImuDev {
 };
 // One factor of the sparsified marginalisation prior (sadvio_sparse_prior with global indices).
 struct SparseDev {
-    int type, kf, lmk0, lmk1;
-    int win, pad;   // window of the factor
+    int type, kf, lmk0, lmk1;   // type 4: pose-to-landmark factor riding the Schur elimination; 5: Relative6DPose (kf, kf2)
+    int win, kf2;   // window of the factor; second key-frame of a relative-pose factor
     double T_prior[12], v_prior[3], ba_prior[3], bg_prior[3], delta[3];
     double W[225];
 };

@@ -170,6 +170,56 @@ __device__ __forceinline__ void m3_inverse(const double* A, double* I) {
 // Per-key-frame quantities at the current deltas, staged once per workgroup.
 //   R = R0 exp(w), t = R0 td + t0   (T_f_w = T_f_w0 * (exp(w), td), geometry.h:198-203)
 //   Jr = so3_rightJacobian(w); dR = exp(w)
+// Relative6DPose::Evaluate (residuals.hpp:70-131): r = W [log R; t] of T = Tab^-1 (Ta dTa)^-1 (Tb dTb); J (6 x 15 row-major,
+// columns [a 6 | b 6 | -]) may be null. Ta / Tb are whatever the window's key-frame slots hold (frame-to-world poses in the
+// pose-graph use of the reference, …Analytic.cpp:787-790).
+__device__ __forceinline__ void relative_pose_factor(const double* Ta, const double* Tb, const double* Tab, const double* W,
+                                                     const double* da, const double* db, double* r, double* J) {
+    double Ea[9], Eb[9], Rau[9], Rbu[9], tau[3], tbu[3], v[3];
+    so3_exp(da, Ea); so3_exp(db, Eb);
+    m3_mul(Ta, Ea, Rau); m3_mul(Tb, Eb, Rbu);
+    m3_vec(Ta, da + 3, v); for (int i = 0; i < 3; i++) tau[i] = v[i] + Ta[9 + i];
+    m3_vec(Tb, db + 3, v); for (int i = 0; i < 3; i++) tbu[i] = v[i] + Tb[9 + i];
+    // R = Rp^T Rau^T Rbu ; t = Rp^T (Rau^T (tbu - tau) - tp)
+    double RaT_Rb[9], R[9], d[3], u[3], t[3], w[3];
+    m3_tmul(Rau, Rbu, RaT_Rb);
+    m3_tmul(Tab, RaT_Rb, R);
+    for (int i = 0; i < 3; i++) d[i] = tbu[i] - tau[i];
+    m3_tvec(Rau, d, u);
+    for (int i = 0; i < 3; i++) u[i] -= Tab[9 + i];
+    m3_tvec(Tab, u, t);
+    so3_log(R, w);
+    const double e[6] = {w[0], w[1], w[2], t[0], t[1], t[2]};
+    for (int i = 0; i < 6; i++) { double s = 0.0; for (int j = 0; j < 6; j++) s += W[6 * i + j] * e[j]; r[i] = s; }
+    if (!J) return;
+    double Jrw[9], Jrwi[9], Jra[9], Jrb[9], A[9], B[9], C[9], S[9], D1[9], D2[9], D3[9], D4[9], E2[9], F[9];
+    so3_right_jacobian(w, Jrw); m3_inverse(Jrw, Jrwi);
+    so3_right_jacobian(da, Jra); so3_right_jacobian(db, Jrb);
+    m3_tmul(Rbu, Rau, A); m3_mul(Jrwi, A, B); m3_mul(B, Jra, C);                      // :98-99 (negated below)
+    so3_skew(d, S);
+    // T_b_a_prior.rotation() * R_a^T = Rp^T Rau^T
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0.0; for (int k = 0; k < 3; k++) s += Tab[3 * k + i] * Rau[3 * j + k]; D1[3 * i + j] = s; }
+    m3_mul(D1, S, D2); m3_mul(D2, Rau, D3); m3_mul(D3, Jra, D4);                     // :102-104
+    m3_mul(Jrwi, Jrb, E2);                                                            // :118
+    m3_mul(D1, Rbu, F);                                                               // :121
+    double Jf[72];                                                                    // 6 x 12 before the weighting
+    for (int i = 0; i < 72; i++) Jf[i] = 0.0;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            Jf[i * 12 + j] = -C[3 * i + j];
+            Jf[(3 + i) * 12 + j] = D4[3 * i + j];
+            Jf[(3 + i) * 12 + 3 + j] = -Tab[3 * j + i];                               // -Rp^T  (:107)
+            Jf[i * 12 + 6 + j] = E2[3 * i + j];
+            Jf[(3 + i) * 12 + 9 + j] = F[3 * i + j];
+        }
+    for (int i = 0; i < 6; i++)
+        for (int c = 0; c < 15; c++) {
+            double s = 0.0;
+            if (c < 12) for (int k = 0; k < 6; k++) s += W[6 * i + k] * Jf[k * 12 + c];
+            J[i * 15 + c] = s;
+        }
+}
+
 constexpr int POSE_TAB = 42;  // R[9] t[3] Jr[9] R0[9] dR[9] td[3]
 __device__ __forceinline__ void pose_table_entry(const double* T0, const double* d6, double* tab) {
     double dR[9], Jr[9], R[9], t[3];

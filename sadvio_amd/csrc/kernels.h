@@ -1057,12 +1057,18 @@ __device__ __forceinline__ int imu_col(int a, int fi, int fj) {
 // reduced-vector column of Jacobian column a (0..14) of sparse factor f; -1 = constant / unused
 __device__ __forceinline__ int sparse_col(const SparseDev& f, int a, int fi, int dpf, int lr0, int lr1) {
     if (f.type == 4) return -1;  // rides the Schur elimination as pseudo-observations (k_build / k_backsub)
+    if (f.type == 5) return a < 6 ? (fi < 0 ? -1 : fi * dpf + a) : (a < 12 ? (lr0 < 0 ? -1 : lr0 + a - 6) : -1);  // lr0 = column of key-frame b
     if (f.type == 0) return (fi >= 0 && a < dpf) ? fi * dpf + a : -1;
     if (f.type == 1) return a < 6 ? (fi < 0 ? -1 : fi * dpf + a) : (a < 9 ? (lr0 < 0 ? -1 : lr0 + a - 6) : -1);
     if (f.type == 2) return (a < 3 && lr0 >= 0) ? lr0 + a : -1;
     return a < 3 ? (lr0 < 0 ? -1 : lr0 + a) : (a < 6 ? (lr1 < 0 ? -1 : lr1 + a - 3) : -1);
 }
-__device__ __forceinline__ int sparse_rows(const SparseDev& f) { return f.type == 0 ? 15 : 3; }
+__device__ __forceinline__ int sparse_rows(const SparseDev& f) { return f.type == 0 ? 15 : (f.type == 5 ? 6 : 3); }
+// reduced column of the second parameter block of a factor: a landmark kept in the reduced system, or (Relative6DPose) key-frame b
+__device__ __forceinline__ int sparse_lr0(const DevPtrs& P, const WinDev& W, const SparseDev& f) {
+    if (f.type == 5) { const int fj = P.kf_fidx[f.kf2]; return fj < 0 ? -1 : fj * W.dpf; }
+    return (f.lmk0 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk0] : -1;
+}
 
 // Evaluate sparse factor f at the state (xp, xv, xba, xbg, xl) + optional step `y` (reduced vector, may be null).
 // J (rows x 15) may be null. Returns false if every parameter block is constant.
@@ -1071,10 +1077,19 @@ __device__ __forceinline__ bool sparse_eval_t(const DevPtrs& P, const WinDev& W,
                                               const double* xba, const double* xbg, const double* xl, const double* y,
                                               double* r, double* J) {
     const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
-    const int lr0 = (f.lmk0 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk0] : -1;
+    const int lr0 = sparse_lr0(P, W, f);
     const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
     if (fi < 0 && lr0 < 0 && lr1 < 0) return false;
     const int dpf = W.dpf;
+    if (f.type == 5) {
+        double da[6], db[6];
+        for (int q = 0; q < 6; q++) {
+            da[q] = xp[6 * (long long)f.kf + q] + ((y && fi >= 0) ? y[fi * dpf + q] : 0.0);
+            db[q] = xp[6 * (long long)f.kf2 + q] + ((y && lr0 >= 0) ? y[lr0 + q] : 0.0);
+        }
+        relative_pose_factor(P.kf_T0 + 12 * (long long)f.kf, P.kf_T0 + 12 * (long long)f.kf2, f.T_prior, f.W, da, db, r, J);
+        return true;
+    }
     if (f.type == 0) {
         double prm[15];
         const long long k = f.kf;
@@ -1289,7 +1304,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             const int b = e;
             const SparseDev& f = P.sparse[W.sp_begin + k];
             const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
-            const int lr0 = (f.lmk0 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk0] : -1;
+            const int lr0 = sparse_lr0(P, W, f);
             const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
             const int ca = sparse_col(f, a, fi, W.dpf, lr0, lr1), cb = sparse_col(f, b, fi, W.dpf, lr0, lr1);
             if (ca < 0 || cb < 0) continue;
@@ -1485,7 +1500,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             const SparseDev& f = P.sparse[W.sp_begin + k];
             if (f.type == 4 || q >= sparse_rows(f)) continue;
             const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
-            const int lr0 = (f.lmk0 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk0] : -1;
+            const int lr0 = sparse_lr0(P, W, f);
             const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
             if (fi < 0 && lr0 < 0 && lr1 < 0) continue;
             const double* sc = P.sp_scratch + (long long)(W.sp_begin + k) * SPARSE_J;

@@ -323,4 +323,118 @@ __global__ void k_nfr_trace(const double* J, int nf, int n, const int* lcols, in
     mi[b * K + a] = fabs(tr);
 }
 
+// ---- relative-pose information between two key-frames (marginalizeRelative, …Analytic.cpp:665-809) ---------------------------
+// Every landmark shared by the two frames is marginalised; Amm is block diagonal (3 x 3 per landmark), so the reference's
+// eigen pseudo-inverse of Amm is taken block by block: one thread per landmark evaluates its reprojection factors in the two
+// frames at zero deltas, forms H_ll, E = [J_a^T J_l ; J_b^T J_l] (12 x 3) and the pose blocks, diagonalises H_ll (cyclic
+// Jacobi) and leaves (lambda, V, E) in a scratch row; the second kernel applies the cut (which needs the largest eigenvalue
+// of ALL blocks, marginalization.cpp:237 with the noise floor of oracle/marg.c) and subtracts E H_ll^+ E^T from Ak.
+// `mult`: how many times the reference enters the landmark (once per feature in frame b, marginalization.cpp:548-559).
+constexpr int RELM_ROW = 3 + 9 + 36;
+template <int FACTOR>
+__global__ void k_relmarg_lmk(DevPtrs P, const int* items /*[n][2]: global landmark, multiplicity*/, int n_items, int ga, int gb,
+                              double* scratch, double* Ak /*144, pose blocks accumulated here*/, unsigned long long* evmax_bits) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_items) return;
+    const int gl = items[2 * e];
+    const double mult = (double)items[2 * e + 1];
+    const double pw[3] = {P.lmk_p[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1], P.lmk_p[3 * (long long)gl + 2]};
+    double Hll[9], E[36], Hp[2][36];
+    for (int i = 0; i < 9; i++) Hll[i] = 0.0;
+    for (int i = 0; i < 36; i++) { E[i] = 0.0; Hp[0][i] = 0.0; Hp[1][i] = 0.0; }
+    const double d6[6] = {0, 0, 0, 0, 0, 0};
+    for (int o = P.lmk_ob[gl]; o < P.lmk_oe[gl]; o++) {
+        const int kf = P.obs_kf[o], cam = P.obs_cam[o];
+        if (cam < 0 || (kf != ga && kf != gb)) continue;
+        const int side = kf == ga ? 0 : 1;
+        double tab[POSE_TAB], r[2], Jp[12], Jl[6];
+        pose_table_entry(P.kf_T0 + 12 * (long long)kf, d6, tab);
+        if (FACTOR == 0) {
+            const double* m = P.obs_meas + 2 * (long long)o;
+            pixel_factor<true>(tab, P.cam_K + 4 * (long long)cam, P.cam_T + 12 * (long long)cam, pw, m[0], m[1], P.cam_isig[cam], r, Jp, Jl);
+        } else {
+            const double* m = P.obs_meas + 3 * (long long)o;
+            double bb[3] = {m[0], m[1], m[2]};
+            angular_factor<true>(tab, P.cam_T + 12 * (long long)cam, pw, bb, P.cam_isig[cam], r, Jp, Jl);
+        }
+        for (int q = 0; q < 2; q++) {
+            for (int a = 0; a < 3; a++) {
+                for (int b = 0; b < 3; b++) Hll[3 * a + b] += Jl[3 * q + a] * Jl[3 * q + b];
+                for (int p = 0; p < 6; p++) E[(6 * side + p) * 3 + a] += Jp[6 * q + p] * Jl[3 * q + a];
+            }
+            for (int p = 0; p < 6; p++) for (int p2 = 0; p2 < 6; p2++) Hp[side][6 * p + p2] += Jp[6 * q + p] * Jp[6 * q + p2];
+        }
+    }
+    for (int i = 0; i < 9; i++) Hll[i] *= mult;
+    for (int i = 0; i < 36; i++) { E[i] *= mult; Hp[0][i] *= mult; Hp[1][i] *= mult; }
+    for (int side = 0; side < 2; side++)
+        for (int p = 0; p < 6; p++)
+            for (int p2 = 0; p2 < 6; p2++)
+                if (Hp[side][6 * p + p2] != 0.0) atomic_add_f64(&Ak[(6 * side + p) * 12 + 6 * side + p2], Hp[side][6 * p + p2]);
+    // cyclic Jacobi on the symmetrised 3 x 3 block
+    double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[3 * i + j] = 0.5 * (Hll[3 * i + j] + Hll[3 * j + i]);
+    for (int sweep = 0; sweep < 30; sweep++) {
+        const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5], diag = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+        if (off <= 1e-60 || off <= 1e-32 * diag) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                const double apq = A[3 * p + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; k++) { const double a = A[3 * k + p], b = A[3 * k + q]; A[3 * k + p] = c * a - s * b; A[3 * k + q] = s * a + c * b; }
+                for (int k = 0; k < 3; k++) { const double a = A[3 * p + k], b = A[3 * q + k]; A[3 * p + k] = c * a - s * b; A[3 * q + k] = s * a + c * b; }
+                for (int k = 0; k < 3; k++) { const double a = V[3 * k + p], b = V[3 * k + q]; V[3 * k + p] = c * a - s * b; V[3 * k + q] = s * a + c * b; }
+            }
+    }
+    double* row = scratch + (long long)e * RELM_ROW;
+    double mx = 0.0;
+    for (int k = 0; k < 3; k++) { row[k] = A[4 * k]; mx = fmax(mx, fabs(A[4 * k])); }
+    for (int i = 0; i < 9; i++) row[3 + i] = V[i];
+    for (int i = 0; i < 36; i++) row[12 + i] = E[i];
+    atomic_max_u64(evmax_bits, (unsigned long long)__double_as_longlong(mx));
+}
+
+__global__ void k_relmarg_apply(const double* scratch, int n_items, int m, const unsigned long long* evmax_bits, double* Ak) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_items) return;
+    const double cut = fmax(1e-12, (double)m * 2.220446049250313e-16 * __longlong_as_double((long long)*evmax_bits));
+    const double* row = scratch + (long long)e * RELM_ROW;
+    double Pi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 3; k++) {
+        if (!(row[k] > cut)) continue;
+        const double iv = 1.0 / row[k];
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Pi[3 * a + b] += row[3 + 3 * a + k] * iv * row[3 + 3 * b + k];
+    }
+    const double* E = row + 12;
+    for (int i = 0; i < 12; i++) {
+        double t[3];
+        for (int b = 0; b < 3; b++) t[b] = E[3 * i] * Pi[b] + E[3 * i + 1] * Pi[3 + b] + E[3 * i + 2] * Pi[6 + b];
+        for (int j = 0; j < 12; j++) {
+            const double v = t[0] * E[3 * j] + t[1] * E[3 * j + 1] + t[2] * E[3 * j + 2];
+            if (v != 0.0) atomic_add_f64(&Ak[12 * i + j], -v);
+        }
+    }
+}
+
+// J (6 x 12) of Relative6DPose(T_w_a, T_w_b, T_a_w T_w_b, I) at zero deltas (…Analytic.cpp:784-800)
+__global__ void k_relmarg_jac(DevPtrs P, int ga, int gb, double* J72) {
+    if (threadIdx.x != 0) return;
+    const double* Ta = P.kf_T0 + 12 * (long long)ga;   // T_f_w
+    const double* Tb = P.kf_T0 + 12 * (long long)gb;
+    double Twa[12], Twb[12], Tab[12], v[3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Twa[3 * i + j] = Ta[3 * j + i]; Twb[3 * i + j] = Tb[3 * j + i]; }
+    m3_tvec(Ta, Ta + 9, v); for (int i = 0; i < 3; i++) Twa[9 + i] = -v[i];
+    m3_tvec(Tb, Tb + 9, v); for (int i = 0; i < 3; i++) Twb[9 + i] = -v[i];
+    m3_mul(Ta, Twb, Tab);                                   // T_a_w T_w_b
+    m3_vec(Ta, Twb + 9, v); for (int i = 0; i < 3; i++) Tab[9 + i] = v[i] + Ta[9 + i];
+    const double W[36] = {1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1};
+    const double z[6] = {0, 0, 0, 0, 0, 0};
+    double r[6], J[90];
+    relative_pose_factor(Twa, Twb, Tab, W, z, z, r, J);
+    for (int i = 0; i < 6; i++) for (int c = 0; c < 12; c++) J72[12 * i + c] = J[15 * i + c];
+}
+
 }  // namespace sadvio
