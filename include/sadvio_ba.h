@@ -182,6 +182,11 @@ typedef struct sadvio_solve_options {
      * landmarkOptimization and singleFrameVIOptimization use a = sqrt(1.345) (AOptimizer.cpp:102,223). Applied
      * the way Ceres' Corrector does for rho'' <= 0: residual and Jacobian scaled by sqrt(rho'), cost = rho / 2. */
     double huber_a;                        /* 0 */
+    /* Ceres' max_solver_time_in_seconds (singleFrameVIOptimization sets 0.005, AOptimizer.cpp:254): checked, as in
+     * TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue, after every iteration — the solve ends with
+     * NO_CONVERGENCE once the time since its start exceeds the limit. Measured on the device (constant 100 MHz clock) from
+     * the first kernel of the solve. 0 (and the reference's localMapBA: Ceres' default 1e6 s) = no limit. */
+    double max_solver_time_in_seconds;     /* 0 */
 } sadvio_solve_options;
 
 typedef struct sadvio_solve_summary {

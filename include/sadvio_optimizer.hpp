@@ -172,6 +172,7 @@ class HipOptimizer {
     bool singleFrameVIOptimization(LocalMapSnapshot& map) {
         sadvio_solve_options o; sadvio_ba_default_options(&o);
         o.max_num_iterations = 5; o.huber_a = std::sqrt(1.345);
+        o.max_solver_time_in_seconds = 0.005;                                            // :254
         return solve(map, 0, true, o, false, true);
     }
 

@@ -18,6 +18,7 @@
  */
 #include <float.h>
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include "factors.h"
 #include "sadvio_oracle.h"
@@ -794,8 +795,14 @@ int oracle_solve(const oracle_problem *P, const sadvio_solve_options *o, sadvio_
         double *L = iter_log; L[0] = x_cost; L[1] = 0; L[2] = radius; L[3] = 0; L[4] = 0; L[5] = 1; L[6] = gmax; L[7] = 0;
     }
     int done = 0;
-    /* FinalizeIterationAndCheckIfMinimizerCanContinue after iteration 0 */
-    if (iter >= o->max_num_iterations) { done = 1; term = SADVIO_TERM_NO_CONVERGENCE; }
+    /* FinalizeIterationAndCheckIfMinimizerCanContinue after iteration 0: solver time (options.max_solver_time_in_seconds,
+     * 0 = none), iterations, gradient, radius — in Ceres' order */
+    struct timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+#define ORACLE_TIME_UP() (o->max_solver_time_in_seconds > 0.0 && (clock_gettime(CLOCK_MONOTONIC, &ts1), \
+                          (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec) >= o->max_solver_time_in_seconds))
+    if (ORACLE_TIME_UP()) { done = 1; term = SADVIO_TERM_NO_CONVERGENCE; }
+    else if (iter >= o->max_num_iterations) { done = 1; term = SADVIO_TERM_NO_CONVERGENCE; }
     else if (gmax <= o->gradient_tolerance) { done = 1; term = SADVIO_TERM_GRADIENT_TOL; }
     else if (radius <= o->min_trust_region_radius) { done = 1; term = SADVIO_TERM_MIN_RADIUS; }
 
@@ -873,6 +880,7 @@ int oracle_solve(const oracle_problem *P, const sadvio_solve_options *o, sadvio_
             double *L = iter_log + 8 * iter;
             L[0] = x_cost; L[1] = cost_change; L[2] = radius; L[3] = step_norm; L[4] = rel_dec; L[5] = successful; L[6] = gmax; L[7] = mcc;
         }
+        if (ORACLE_TIME_UP()) { term = SADVIO_TERM_NO_CONVERGENCE; break; }
         if (iter >= o->max_num_iterations) { term = SADVIO_TERM_NO_CONVERGENCE; break; }
         if (gmax <= o->gradient_tolerance) { term = SADVIO_TERM_GRADIENT_TOL; break; }
         if (radius <= o->min_trust_region_radius) { term = SADVIO_TERM_MIN_RADIUS; break; }

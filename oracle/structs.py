@@ -39,7 +39,8 @@ class solve_options(C.Structure):          # sadvio_solve_options
     _fields_ = [("max_num_iterations", i32), ("jacobi_scaling", i32), ("max_num_consecutive_invalid_steps", i32),
                 ("reserved", i32), ("function_tolerance", f64), ("gradient_tolerance", f64), ("parameter_tolerance", f64),
                 ("initial_trust_region_radius", f64), ("max_trust_region_radius", f64), ("min_trust_region_radius", f64),
-                ("min_lm_diagonal", f64), ("max_lm_diagonal", f64), ("min_relative_decrease", f64), ("huber_a", f64)]
+                ("min_lm_diagonal", f64), ("max_lm_diagonal", f64), ("min_relative_decrease", f64), ("huber_a", f64),
+                ("max_solver_time_in_seconds", f64)]
 
 
 class solve_summary(C.Structure):          # sadvio_solve_summary

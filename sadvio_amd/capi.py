@@ -106,7 +106,7 @@ class SolveOptions(C.Structure):
         ("parameter_tolerance", C.c_double), ("initial_trust_region_radius", C.c_double),
         ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
         ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double), ("min_relative_decrease", C.c_double),
-        ("huber_a", C.c_double),
+        ("huber_a", C.c_double), ("max_solver_time_in_seconds", C.c_double),
     ]
 
 
@@ -150,10 +150,11 @@ def landmark_optimization_options() -> SolveOptions:
 
 def single_frame_options(vi: bool = False) -> SolveOptions:
     """singleFrameOptimization (AOptimizer.cpp:152-174: no loss, 5 iterations) / singleFrameVIOptimization
-    (:219-257: Huber on the visual factors, 5 iterations; its 5 ms wall-clock cap is not reproduced)."""
+    (:219-257: Huber on the visual factors, 5 iterations, 5 ms solver-time cap)."""
     o = reference_options()
     o.max_num_iterations = 5
     o.huber_a = 1.345 ** 0.5 if vi else 0.0
+    o.max_solver_time_in_seconds = 0.005 if vi else 0.0
     return o
 
 

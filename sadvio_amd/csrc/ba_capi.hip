@@ -239,6 +239,7 @@ struct sadvio_ba_handle {
     DevBuf<double> d_S, d_gred, d_gfull, d_hdiag, d_delta, d_s_pose;
     DevBuf<LmState> d_states;
     DevBuf<double> d_trace;
+    DevBuf<long long> d_tstart;
     DevBuf<IterAcc> d_acc;
     DevBuf<FinalRec> d_final;
     FinalRec* h_final = nullptr;  // pinned
@@ -319,7 +320,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.S = h->d_S.p; P.gred = h->d_gred.p; P.gfull = h->d_gfull.p; P.hdiag = h->d_hdiag.p;
     P.delta = h->d_delta.p; P.s_pose = h->d_s_pose.p;
     P.dbg_ts = h->d_dbg.p;
-    P.trace = h->d_trace.p;
+    P.trace = h->d_trace.p; P.t_start = h->d_tstart.p;
     P.states = h->d_states.p; P.acc = h->d_acc.p; P.tacc = h->d_tacc.p; P.n_tiles = (int)h->tiles.size();
     P.state_stride = state_stride;
     P.final_out = h->d_final.p;
@@ -598,7 +599,7 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     h->d_lmk_p.release(); h->d_xl.release(); h->d_s_lmk.release(); h->d_lmk_const.release();
     h->d_lmk_ob.release(); h->d_lmk_oe.release(); h->d_obs_kf.release(); h->d_obs_cam.release();
     h->d_obs_meas.release(); h->d_priors.release(); h->d_S.release(); h->d_rank_s.release(); h->d_gred.release(); h->d_gfull.release();
-    h->d_hdiag.release(); h->d_delta.release(); h->d_s_pose.release(); h->d_states.release(); h->d_trace.release(); h->d_acc.release();
+    h->d_hdiag.release(); h->d_delta.release(); h->d_s_pose.release(); h->d_states.release(); h->d_trace.release(); h->d_tstart.release(); h->d_acc.release();
     h->d_probe.release(); h->d_tile_kf.release(); h->d_tile_row.release(); h->d_obs_slot.release(); h->d_ptab.release(); h->d_tacc.release(); h->d_dbg.release(); h->d_imus.release(); h->d_imu_scratch.release();
     delete h;
 }
@@ -1718,6 +1719,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     o.min_lm_diagonal = opts->min_lm_diagonal; o.max_lm_diagonal = opts->max_lm_diagonal;
     o.min_relative_decrease = opts->min_relative_decrease;
     o.huber_a = opts->huber_a;
+    o.max_time_ticks = opts->max_solver_time_in_seconds > 0.0 ? opts->max_solver_time_in_seconds * 1e8 : 0.0;   // wall_clock64: 100 MHz
     if (!(o.huber_a >= 0.0)) { h->err = "solve: huber_a must be >= 0"; return SADVIO_E_INVALID_ARG; }
     const int n_win = (int)h->wins.size();
     // Slot s (s = 0 .. slots-1) is one step attempt; with max_num_iterations = 0 Ceres still evaluates
@@ -1727,6 +1729,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     HIP_TRY(h->d_dbg.alloc(64));
     HIP_TRY(h->d_states.alloc((size_t)n_win * stride));
     HIP_TRY(h->d_trace.alloc((size_t)n_win * stride * 8));
+    HIP_TRY(h->d_tstart.alloc(1));
     HIP_TRY(h->d_acc.alloc((size_t)n_win * stride));
     HIP_TRY(h->d_final.alloc((size_t)n_win));
     HIP_TRY(h->d_big_info.alloc((size_t)n_win));

@@ -25,6 +25,7 @@ struct SolveOpts {
     double initial_radius, max_radius, min_radius;
     double min_lm_diagonal, max_lm_diagonal, min_relative_decrease;
     double huber_a;  // ceres::HuberLoss(a) on the visual factors, 0 = none
+    double max_time_ticks;  // max_solver_time_in_seconds in ticks of the 100 MHz wall clock, 0 = no limit
 };
 
 struct WinDev {
@@ -128,7 +129,7 @@ struct IterAcc {
     double fixed_cost;  // sum r^2 of blocks whose parameters are all constant (slot 0 only)
     unsigned long long gmax_bits;  // max |gradient| as IEEE bits (non-negative doubles order like u64)
     int chol_fail;
-    int pad;
+    int time_up;   // the solver-time limit was exceeded when this slot's k_solve ran (one sample per slot: every decider sees the same)
 };
 
 // Per-tile partial sums of one slot, written with plain stores by the tile's workgroup and summed by the

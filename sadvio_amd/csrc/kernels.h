@@ -64,6 +64,7 @@ struct DevPtrs {
     int n_tiles;
     int state_stride;
     int n_win;
+    long long* t_start; // wall_clock64 at the first kernel of the solve (k_reset)
     double* trace;      // [n_win][state_stride][8] per-iteration log (sadvio_ba_get_trace), written by the slot's single decider
     long long* dbg_ts;  // [64] phase timestamps (wall_clock64, 100 MHz) of workgroup 0 when debug & 4096
     int debug;  // SADVIO_DEBUG env: bit 12 (4096) = in-kernel phase timestamps of workgroup 0 into dbg_ts (results unaffected)
@@ -128,7 +129,7 @@ __device__ __forceinline__ LmState lm_decide(LmState s, const IterAcc& a, const 
             s.n_unsuccess += 1;
         }
     }
-    if (s.iter >= o.max_num_iterations) { s.done = 1; s.termination = 0; }
+    if (s.iter >= o.max_num_iterations || a.time_up) { s.done = 1; s.termination = 0; }   // iterations / solver time: NO_CONVERGENCE
     else if (s.radius <= o.min_radius) { s.done = 1; s.termination = 4; }
     return s;
 }
@@ -1351,6 +1352,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         acc->lin_cost = cs;
         acc->fixed_cost = fs;
         acc->cand_cost = 0.0; acc->mcc = 0.0; acc->step_norm2 = 0.0; acc->cand_norm2 = 0.0;
+        acc->time_up = (P.o.max_time_ticks > 0.0 && P.t_start && (double)(wall_clock64() - *P.t_start) >= P.o.max_time_ticks) ? 1 : 0;
         if (g <= P.o.gradient_tolerance) {
             st.done = 1; st.termination = 3;
             st.x_cost = 0.5 * cs;
@@ -1853,6 +1855,7 @@ __global__ void k_rank_partials(DevPtrs P, int slot, int which) {
 // (one launch instead of eight memsets and a host-to-device copy).
 __global__ void k_reset(DevPtrs P) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long long)gridDim.x * blockDim.x;
+    if (t == 0 && P.t_start) *P.t_start = wall_clock64();
     for (long long i = t; i < P.n_xp; i += nt) P.xp[i] = 0.0;
     for (long long i = t; i < P.n_xv; i += nt) { P.xv[i] = 0.0; P.xba[i] = 0.0; P.xbg[i] = 0.0; }
     for (long long i = t; i < P.n_xl; i += nt) P.xl[i] = 0.0;

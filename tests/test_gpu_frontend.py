@@ -91,3 +91,26 @@ def test_landmark_chi2_gate(backend_cls, oracle_lib, factor):
     assert a0[3] == 1000.0 and i0[3] == 0 and i0[7] == 0
     assert i1.sum() > i0.sum() and i2.sum() <= i1.sum()
     assert np.array_equal(d_again["lmk"], d["lmk"])
+
+
+def test_solver_time_cap(backend_cls, oracle_lib):
+    """max_solver_time_in_seconds (singleFrameVIOptimization: 0.005, AOptimizer.cpp:254): a limit already exceeded after the
+    first iteration ends the solve there with NO_CONVERGENCE, like Ceres' check at the end of every iteration; a generous
+    limit changes nothing."""
+    import numpy as np
+    from sadvio_amd import capi, synthetic
+    w = synthetic.make_window(n_kf=6, n_lmk=500, seed=3)
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    free = capi.reference_options()
+    s_free = be.solve(free)[0]
+    tight = capi.reference_options(); tight.max_solver_time_in_seconds = 1e-9
+    s = be.solve(tight)[0]
+    ref = oracle_lib.solve(w, tight)["summary"]
+    assert (s.iterations, s.termination) == (1, capi.TERM_NAMES and 0) == (ref.iterations, ref.termination)
+    assert s_free.iterations > 1
+    loose = capi.reference_options(); loose.max_solver_time_in_seconds = 100.0
+    s2 = be.solve(loose)[0]
+    assert (s2.iterations, s2.termination) == (s_free.iterations, s_free.termination) and s2.final_cost == s_free.final_cost
+    be.close()
+    assert capi.single_frame_options(vi=True).max_solver_time_in_seconds == 0.005
