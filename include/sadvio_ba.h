@@ -101,6 +101,32 @@ typedef struct sadvio_flat_window {
     const double *obs_meas;     /* [n_obs][2] pixel uv (AFeature2D.h:21) | [n_obs][3] unit bearing (AFeature2D.h:80) */
 } sadvio_flat_window;
 
+/*
+ * Line landmarks ("linexd": Line3D with ModelLine3D, Line3D.h:8-36, Model3D.h:45-51) of one window — SURVEY.md §8f rank 3.
+ * A line is a 6-dof pose parameter block, T_w_l <- T_w_l (exp(w), t) (PoseParametersBlock; write-back AOptimizer.cpp:334-336),
+ * observed as a 2-D segment. Residual blocks, added by addResidualsLocalMap for every feature whose frame is a key-frame of
+ * the window (BundleAdjustmentCERESAnalytic.cpp:273-311 / AngularAdjustmentCERESAnalytic.cpp:293-333):
+ *   pixel windows    ReprojectionErrCeres_linexd_dx (…Analytic.h:102-195): the two model points projected with
+ *                    Camera::project against the two measured end points, 4 residuals, sigma 1. As coded the landmark is
+ *                    moved by T_w_l (I, x[0..2]) — the first three entries of its 6-vector, used as a TRANSLATION — while the
+ *                    Jacobian treats them as a rotation ([-R [pt]x | I]); reproduced. The cost-only branch of the reference
+ *                    (:168-177) reads an uninitialised projection: the residual of the Jacobian branch is used for both.
+ *   angular windows  AngularErrCeres_linexd_dx (…Angular….h:368-469): coplanarity of the observation plane (b0 x b1) with
+ *                    the line, 2 residuals, weight 1 / sigma^2 with sigma 1.
+ * Lines stay in the reduced system (6 columns each after the key-frames and the prior-kept landmarks): they are few.
+ */
+typedef struct sadvio_line_set {
+    int32_t n_line, n_obs;
+    const int64_t *line_id;      /* [n_line] opaque ids, echoed */
+    const double *line_T_w_l;    /* [n_line][12] landmark->getPose() */
+    const double *line_model;    /* [n_line][6] the two model points (ModelLine3D: (-0.5, 0, 0), (0.5, 0, 0)) */
+    const uint8_t *line_const;   /* [n_line] or NULL */
+    const int32_t *line_obs_ptr; /* [n_line + 1] CSR */
+    const int32_t *obs_kf;       /* [n_obs] */
+    const int32_t *obs_cam;      /* [n_obs] */
+    const double *obs_meas;      /* pixel: [n_obs][4] end points (AFeature::getPoints) | angular: [n_obs][6] two bearings */
+} sadvio_line_set;
+
 /* Constants of one IMUFactor + IMUBiasFactor pair (residuals.hpp:133-300); pairing rule
  * AOptimizer::addIMUResiduals (AOptimizer.cpp:55-92): consecutive KFs, dt <= 1 s. kf_i is the
  * older frame (imu_j->getLastKF()). All 3x3 are row-major. */
@@ -217,6 +243,11 @@ void sadvio_ba_destroy(sadvio_ba_handle *h);
 int sadvio_ba_set_windows(sadvio_ba_handle *h, int32_t n_windows, const sadvio_flat_window *windows);
 /* The single-window call the adapter of one optimizer instance uses: set_windows(h, 1, window). */
 int sadvio_ba_set_window(sadvio_ba_handle *h, const sadvio_flat_window *window);
+
+/* Line landmarks of window `w` (NULL or n_line = 0 clears them). Not supported on a window sharded over several GPUs. */
+int sadvio_ba_set_lines(sadvio_ba_handle *h, int32_t w, const sadvio_line_set *lines);
+/* Solved 6-vectors of the lines of window `w` ([n_line][6]), applied as T_w_l <- T_w_l (exp(w), t) (AOptimizer.cpp:334-336). */
+int sadvio_ba_get_line_deltas(sadvio_ba_handle *h, int32_t w, double *line_delta6);
 
 /* PosePriordx blocks of window `w` (…Analytic.cpp:224-228). */
 int sadvio_ba_set_pose_priors(sadvio_ba_handle *h, int32_t w, int32_t n, const sadvio_pose_prior *priors);

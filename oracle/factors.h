@@ -216,6 +216,117 @@ static inline void factor_pose_prior(const double *T0, const double *Tprior, con
 }
 
 /*
+ * ReprojectionErrCeres_linexd_dx::Evaluate, Jacobian branch (BundleAdjustmentCERESAnalytic.h:116-166). Twl: landmark pose,
+ * model: the two model points, uv4: the two measured end points, dline: the landmark's 6-vector. As coded:
+ *   T_w_lmk = T_w_lmk_ * se3_doubleVec3dtoRT(parameters[1])   -> a translation by dline[0..2]   (:121)
+ *   J_lmk block i = jac1 * [-R_w_l [pt_i]x | I]                                                  (:156-160)
+ * r4, Jf (4x6), Jl (4x6) row-major. Returns the number of valid projections (an invalid one has r = 0, Jacobian kept).
+ */
+static inline int factor_line_pixel(const double *T0, const double *K, const double *Tsf, const double *Twl, const double *model,
+                                    const double *uv4, double sigma, const double *dpose, const double *dline, double *r4,
+                                    double *Jf, double *Jl) {
+    static const double z3[3] = {0, 0, 0};
+    int nv = 0;
+    for (int i = 0; i < 2; i++) {
+        const double *pt = model + 3 * i;
+        double q[3] = {pt[0] + dline[0], pt[1] + dline[1], pt[2] + dline[2]}, pw[3];
+        se3_apply(Twl, q, pw);                         /* T_w_lmk * Tpt, :127-131 */
+        double Jp[12], J3[6];
+        nv += factor_pixel(T0, K, Tsf, pw, uv4 + 2 * i, sigma, dpose, z3, r4 + 2 * i, (Jf || Jl) ? Jp : NULL, (Jf || Jl) ? J3 : NULL);
+        if (Jf) for (int a = 0; a < 12; a++) Jf[12 * i + a] = Jp[a];      /* jac0 * J_lf_dlf, :144-152 */
+        if (Jl) {
+            double S[9], RS[9];
+            so3_skew(pt, S);
+            m3_mul(Twl, S, RS);
+            for (int q2 = 0; q2 < 2; q2++)
+                for (int a = 0; a < 3; a++) {
+                    double s = 0;
+                    for (int k = 0; k < 3; k++) s -= J3[3 * q2 + k] * RS[3 * k + a];
+                    Jl[(2 * i + q2) * 6 + a] = s;
+                    Jl[(2 * i + q2) * 6 + 3 + a] = J3[3 * q2 + a];
+                }
+        }
+    }
+    return nv;
+}
+
+/*
+ * AngularErrCeres_linexd_dx::Evaluate (AngularAdjustmentCERESAnalytic.h:378-459). b6: the two bearing vectors of the
+ * feature; weight = 1 / sigma^2 (:382). r2, Jf (2x6), Jl (2x6) row-major. J_normalization is (I - X X^T) / |X| with the
+ * UN-normalised X, as coded (geometry.h:332-334).
+ */
+static inline void factor_line_angular(const double *T0, const double *Tsf, const double *Twl, const double *b6, double sigma,
+                                       const double *dpose, const double *dline, double *r2, double *Jf, double *Jl) {
+    double dT[12], dTl[12], A[12], Bm[12], Cm[12], Tsl[12];
+    se3_from_delta6(dpose, dT); se3_from_delta6(dline, dTl);
+    const double weight = 1.0 / (sigma * sigma);
+    se3_mul(Tsf, T0, A); se3_mul(A, dT, Bm); se3_mul(Bm, Twl, Cm); se3_mul(Cm, dTl, Tsl);   /* :384 */
+    double n_obs[3] = {b6[1] * b6[5] - b6[2] * b6[4], b6[2] * b6[3] - b6[0] * b6[5], b6[0] * b6[4] - b6[1] * b6[3]};
+    double nn = sqrt(n_obs[0] * n_obs[0] + n_obs[1] * n_obs[1] + n_obs[2] * n_obs[2]);
+    for (int i = 0; i < 3; i++) n_obs[i] /= nn;                                            /* :388-389 */
+    const double *t = Tsl + 9;
+    const double tn = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+    double bl[3] = {t[0] / tn, t[1] / tn, t[2] / tn};                                       /* :392 */
+    double dir[3] = {Tsl[0], Tsl[3], Tsl[6]};                                               /* R e_x, normalised (geometry.h:125-129) */
+    { double dn = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]); for (int i = 0; i < 3; i++) dir[i] /= dn; }
+    double nl[3] = {bl[1] * dir[2] - bl[2] * dir[1], bl[2] * dir[0] - bl[0] * dir[2], bl[0] * dir[1] - bl[1] * dir[0]};
+    const double nln = sqrt(nl[0] * nl[0] + nl[1] * nl[1] + nl[2] * nl[2]);
+    double nlh[3] = {nl[0] / nln, nl[1] / nln, nl[2] / nln};                                /* :393-394 */
+    double cx[3] = {n_obs[1] * nlh[2] - n_obs[2] * nlh[1], n_obs[2] * nlh[0] - n_obs[0] * nlh[2], n_obs[0] * nlh[1] - n_obs[1] * nlh[0]};
+    const double cxn = sqrt(cx[0] * cx[0] + cx[1] * cx[1] + cx[2] * cx[2]);
+    r2[0] = weight * cxn;                                                                   /* :400 */
+    r2[1] = weight * (n_obs[0] * bl[0] + n_obs[1] * bl[1] + n_obs[2] * bl[2]);              /* :401 */
+    if (!Jf && !Jl) return;
+    /* J_e0_n_lmk = J_norm(cx) * J_AcrossX(n_obs) * J_normalization(n_ldmk)   (:406-408) */
+    double Sn[9], Jn_nl[9], M1[9], e0[3], e1[3];
+    so3_skew(n_obs, Sn);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Jn_nl[3 * i + j] = ((i == j ? 1.0 : 0.0) - nl[i] * nl[j]) / nln;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s -= Sn[3 * i + k] * Jn_nl[3 * k + j]; M1[3 * i + j] = s; }
+    for (int j = 0; j < 3; j++) e0[j] = (cx[0] * M1[j] + cx[1] * M1[3 + j] + cx[2] * M1[6 + j]) / cxn;
+    /* J_e1_t_lmk = n_obs^T J_normalization(t)   (:410-411) */
+    double Jn_t[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Jn_t[3 * i + j] = ((i == j ? 1.0 : 0.0) - t[i] * t[j]) / tn;
+    for (int j = 0; j < 3; j++) e1[j] = n_obs[0] * Jn_t[j] + n_obs[1] * Jn_t[3 + j] + n_obs[2] * Jn_t[6 + j];
+    /* blocks of :413-436 */
+    double Rsw[9], RswdR[9], lw[3], Jr_dT[9], Jr_dTl[9], v[3], S1[9], S2[9], P1[9], P2[9], Jt_dT[18], JR_dT[18], Jt_dL[18], JR_dL[18];
+    m3_mul(Tsf, T0, Rsw);                      /* (T_s_f T_f_w).rotation() */
+    m3_mul(Rsw, dT, RswdR);
+    so3_log(dT, lw); so3_right_jacobian(lw, Jr_dT);
+    so3_log(dTl, lw); so3_right_jacobian(lw, Jr_dTl);
+    memset(Jt_dT, 0, sizeof(Jt_dT)); memset(JR_dT, 0, sizeof(JR_dT)); memset(Jt_dL, 0, sizeof(Jt_dL)); memset(JR_dL, 0, sizeof(JR_dL));
+    m3_vec(Twl, dTl + 9, v); so3_skew(v, S1);                                  /* [R_w_l t_dl]x */
+    m3_mul(RswdR, S1, P1); m3_mul(P1, Jr_dT, P2);
+    so3_skew(Twl + 9, S2); m3_mul(RswdR, S2, P1);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Jt_dT[6 * i + j] = -P2[3 * i + j] - P1[3 * i + j]; Jt_dT[6 * i + 3 + j] = Rsw[3 * i + j]; }
+    double Rwl_dRl[9], ex[3];
+    m3_mul(Twl, dTl, Rwl_dRl);
+    ex[0] = Rwl_dRl[0]; ex[1] = Rwl_dRl[3]; ex[2] = Rwl_dRl[6];              /* R_w_l dR_l e_x */
+    so3_skew(ex, S1); m3_mul(RswdR, S1, P1); m3_mul(P1, Jr_dT, P2);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) JR_dT[6 * i + j] = -P2[3 * i + j];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Jt_dL[6 * i + 3 + j] = Cm[3 * i + j];   /* (T_s_f T_f_w dT T_w_l).rotation() */
+    { const double e_x[3] = {1, 0, 0}; so3_skew(e_x, S1); }
+    m3_mul(Cm, dTl, P1); m3_mul(P1, S1, P2); m3_mul(P2, Jr_dTl, P1);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) JR_dL[6 * i + j] = -P1[3 * i + j];
+    /* row 0: e0 * ( [R_s_l e_x]x^T (J_normalization(t) J_t) + [n_ldmk_normed]x J_R ), row 1: e1 * J_t   (:441-457) */
+    double Sd[9], Snl[9];
+    { const double rx[3] = {Tsl[0], Tsl[3], Tsl[6]}; so3_skew(rx, Sd); }
+    so3_skew(nlh, Snl);
+    for (int which = 0; which < 2; which++) {
+        const double *Jt = which ? Jt_dL : Jt_dT, *JR = which ? JR_dL : JR_dT;
+        double *out = which ? Jl : Jf;
+        if (!out) continue;
+        for (int c = 0; c < 6; c++) {
+            double a[3], b[3], g[3];
+            for (int i = 0; i < 3; i++) { a[i] = Jn_t[3 * i] * Jt[c] + Jn_t[3 * i + 1] * Jt[6 + c] + Jn_t[3 * i + 2] * Jt[12 + c]; }
+            for (int i = 0; i < 3; i++) b[i] = Sd[i] * a[0] + Sd[3 + i] * a[1] + Sd[6 + i] * a[2];       /* Sd^T a */
+            for (int i = 0; i < 3; i++) g[i] = b[i] + Snl[3 * i] * JR[c] + Snl[3 * i + 1] * JR[6 + c] + Snl[3 * i + 2] * JR[12 + c];
+            out[c] = weight * (e0[0] * g[0] + e0[1] * g[1] + e0[2] * g[2]);
+            out[6 + c] = weight * (e1[0] * Jt[c] + e1[1] * Jt[6 + c] + e1[2] * Jt[12 + c]);
+        }
+    }
+}
+
+/*
  * Relative6DPose::Evaluate (residuals.hpp:70-131). Ta / Tb: the transforms the factor composes its deltas on (the reference
  * passes frame-to-world poses T_w_a, T_w_b, …Analytic.cpp:787-790); Tab: T_a_b_prior; W: 6x6 sqrt information, row-major.
  * r = W [log(R); t] of T = T_a_b_prior^-1 (Ta dTa)^-1 (Tb dTb). Ja, Jb 6x6 row-major (may be NULL).

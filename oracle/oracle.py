@@ -32,7 +32,8 @@ class OracleProblem(C.Structure):
                 ("dp_n_full", C.c_int32), ("dp_n", C.c_int32), ("dp_J", _dp), ("dp_r0", _dp),
                 ("dp_kf_keep", C.c_int32), ("dp_kf_col", C.c_int32), ("dp_n_keep", C.c_int32),
                 ("dp_lmk_index", _ip), ("dp_lmk_col", _ip), ("n_threads", C.c_int32),
-                ("n_sparse", C.c_int32), ("sparse", C.POINTER(SparsePriorC))]
+                ("n_sparse", C.c_int32), ("sparse", C.POINTER(SparsePriorC)),
+                ("lines", C.POINTER(S.line_set)), ("line_delta6", _dp)]
 
 
 class ImuState(C.Structure):
@@ -112,6 +113,11 @@ def make_problem(w: FlatWindow, dense_prior=None, n_threads=1):
     sa, nsp = S.sparse_to_c(getattr(w, "sparse_priors", []))
     P.n_sparse, P.sparse = nsp, sa
     keep = [wc, wkeep, pa, ia, sa]
+    lines = getattr(w, "lines", None)
+    if lines is not None:
+        lc, lkeep = S.lines_to_c(lines)
+        P.lines = C.pointer(lc)
+        keep += [lc, lkeep]
     if dense_prior is not None:
         J = np.ascontiguousarray(dense_prior["J"], dtype=np.float64)
         r0 = np.ascontiguousarray(dense_prior["r0"], dtype=np.float64)
@@ -133,10 +139,27 @@ def solve(w: FlatWindow, opts: SolveOptions = None, dense_prior=None, n_threads=
     dv = np.zeros((w.n_kf, 3)); dba = np.zeros((w.n_kf, 3)); dbg = np.zeros((w.n_kf, 3))
     log = np.zeros((log_cap, 8))
     s = SolveSummary()
+    line = None
+    if getattr(w, "lines", None) is not None:
+        line = np.zeros((np.asarray(w.lines["T_w_l"]).reshape(-1, 12).shape[0], 6))
+        P.line_delta6 = _p(line)
     rc = lib().oracle_solve(C.byref(P), C.byref(opts), C.byref(s), _p(pose), _p(lmk), _p(dv), _p(dba), _p(dbg),
                             _p(log), log_cap)
-    return {"rc": rc, "summary": s, "pose": pose, "lmk": lmk, "dv": dv, "dba": dba, "dbg": dbg,
+    return {"rc": rc, "summary": s, "pose": pose, "lmk": lmk, "dv": dv, "dba": dba, "dbg": dbg, "line": line,
             "log": log[: s.iterations + 1]}
+
+
+def line_factor(w, l: int, o: int, xp=None, xline=None):
+    """(r, J[rows, 12]) of line observation o of line l at the given deltas: columns [key-frame 6 | line 6]."""
+    wc, wkeep = S.window_to_c(w)
+    lc, lkeep = S.lines_to_c(w.lines)
+    r = np.zeros(4); J = np.zeros((4, 12))
+    a = None if xp is None else np.ascontiguousarray(xp, dtype=np.float64)
+    b = None if xline is None else np.ascontiguousarray(xline, dtype=np.float64)
+    f = lib().oracle_line_factor
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]
+    rows = f(C.byref(wc), C.byref(lc), l, o, _p(a), _p(b), _p(r), _p(J))
+    return r[:rows].copy(), J[:rows].copy()
 
 
 def linearize(w: FlatWindow, pose_delta=None, lmk_delta=None):

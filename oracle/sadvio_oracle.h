@@ -40,6 +40,9 @@ typedef struct oracle_problem {
     /* sparse (NFR) prior factors, addMarginalizationResiduals sparse branch (…Analytic.cpp:363-426) */
     int32_t n_sparse;
     const sadvio_sparse_prior *sparse;
+    /* line landmarks; NULL = none. Their solved 6-vectors go to line_delta6 ([n_line][6], may be NULL) */
+    const sadvio_line_set *lines;
+    double *line_delta6;
 } oracle_problem;
 
 /* Per-observation linearisation at the given deltas (NULL = zeros). Any output may be NULL. */

@@ -40,6 +40,7 @@ typedef struct {
     int *lmk_red;     /* [n_lmk] offset in reduced vector (dense-prior landmarks) or -1 */
     int *lmk_elim;    /* [n_lmk] 1 = eliminated by Schur */
     int *lmk_active;  /* [n_lmk] 1 = has a parameter block in the reduced program */
+    int *line_off;    /* [n_line] offset of a line landmark's 6 columns in the reduced vector, -1 = constant / unused */
     /* linearisation storage */
     double *r, *Jp, *Jl; /* per obs */
     double *E;           /* per obs 6x3 = Jp^T Jl */
@@ -70,7 +71,45 @@ static const double *vec3_or_zero(const double *base, int i) {
 /* ----- evaluation of all residual blocks at x ----- */
 typedef struct {
     const double *xp, *xl, *xv, *xba, *xbg;
+    const double *xline;   /* [n_line][6] or NULL */
 } state_t;
+
+/* One line observation as a small block over [key-frame 6 | line 6] (…Analytic.cpp:296-310 / Angular….cpp:316-333).
+ * Returns 0 when both parameter blocks are constant (fixed cost). */
+static int line_small(const ctx_t *c, const state_t *x, int l, int o, small_factor *f, int want_J, double *rho) {
+    static const double z6[6] = {0, 0, 0, 0, 0, 0};
+    const sadvio_flat_window *w = c->w;
+    const sadvio_line_set *L = c->P->lines;
+    const int kf = L->obs_kf[o], cam = L->obs_cam[o], po = c->kf_off[kf], lo = c->line_off[l];
+    const double *dp = x && x->xp ? x->xp + 6 * kf : z6, *dl = x && x->xline ? x->xline + 6 * l : z6;
+    double Jf[24], Jl[24];
+    if (w->factor_type == SADVIO_FACTOR_PIXEL) {
+        f->rows = 4;
+        factor_line_pixel(w->kf_T_f_w + 12 * kf, w->cam_K + 4 * cam, w->cam_T_s_f + 12 * cam, L->line_T_w_l + 12 * l, L->line_model + 6 * l,
+                          L->obs_meas + 4 * o, 1.0, dp, dl, f->r, want_J ? Jf : NULL, want_J ? Jl : NULL);
+    } else {
+        f->rows = 2;
+        factor_line_angular(w->kf_T_f_w + 12 * kf, w->cam_T_s_f + 12 * cam, L->line_T_w_l + 12 * l, L->obs_meas + 6 * o, 1.0, dp, dl, f->r,
+                            want_J ? Jf : NULL, want_J ? Jl : NULL);
+    }
+    f->ncols = 12;
+    for (int q = 0; q < 6; q++) { f->col[q] = po < 0 ? -1 : po + q; f->col[6 + q] = lo < 0 ? -1 : lo + q; }
+    /* the line blocks are added with the caller's loss function like the point blocks (…Analytic.cpp:303-306): ceres::HuberLoss(a)
+     * + Corrector over the whole 4 (2) row block */
+    double ssq = 0, sc = 1.0;
+    for (int q = 0; q < f->rows; q++) ssq += f->r[q] * f->r[q];
+    *rho = ssq;
+    if (c->huber_a > 0.0 && ssq > c->huber_a * c->huber_a) {
+        const double rr = sqrt(ssq);
+        double rho1 = c->huber_a / rr;
+        if (rho1 < 2.2250738585072014e-308) rho1 = 2.2250738585072014e-308;
+        sc = sqrt(rho1);
+        *rho = 2.0 * c->huber_a * rr - c->huber_a * c->huber_a;
+        for (int q = 0; q < f->rows; q++) f->r[q] *= sc;
+    }
+    if (want_J) for (int i = 0; i < f->rows; i++) for (int q = 0; q < 6; q++) { f->J[i * 12 + q] = sc * Jf[i * 6 + q]; f->J[i * 12 + 6 + q] = sc * Jl[i * 6 + q]; }
+    return po >= 0 || lo >= 0;
+}
 
 static void push_sf(ctx_t *c, const small_factor *f) {
     if (c->n_sf == c->cap_sf) {
@@ -207,6 +246,14 @@ static double eval_cost(ctx_t *c, const state_t *x) {
         if (!sparse_small(c, x, P->sparse + k, &sf, 0)) continue;
         for (int q = 0; q < sf.rows; q++) cost += sf.r[q] * sf.r[q];
     }
+    if (P->lines)
+        for (int l = 0; l < P->lines->n_line; l++)
+            for (int o = P->lines->line_obs_ptr[l]; o < P->lines->line_obs_ptr[l + 1]; o++) {
+                small_factor sf;
+                double rho;
+                if (!line_small(c, x, l, o, &sf, 0, &rho)) continue;
+                cost += rho;
+            }
     for (int k = 0; k < P->n_imu; k++) {
         const sadvio_imu_factor *f = P->imus + k;
         int i = f->kf_i, j = f->kf_j;
@@ -352,6 +399,15 @@ static double eval_full(ctx_t *c, const state_t *x) {
         for (int q = 0; q < f.rows; q++) cost += f.r[q] * f.r[q];
         push_sf(c, &f);
     }
+    if (P->lines)
+        for (int l = 0; l < P->lines->n_line; l++)
+            for (int o = P->lines->line_obs_ptr[l]; o < P->lines->line_obs_ptr[l + 1]; o++) {
+                small_factor f;
+                double rho;
+                if (!line_small(c, x, l, o, &f, 1, &rho)) continue;
+                cost += rho;
+                push_sf(c, &f);
+            }
     for (int k = 0; k < P->n_imu; k++) {
         const sadvio_imu_factor *fi = P->imus + k;
         int i = fi->kf_i, j = fi->kf_j;
@@ -636,6 +692,16 @@ static void ctx_init(ctx_t *c, const oracle_problem *P) {
             c->lmk_elim[l] = 0;
         }
     }
+    if (P->lines) {
+        const sadvio_line_set *L = P->lines;
+        c->line_off = (int *)xcalloc((size_t)L->n_line, sizeof(int));
+        for (int l = 0; l < L->n_line; l++) {
+            int used = 0;     /* Ceres drops parameter blocks no residual block of the program uses */
+            for (int o = L->line_obs_ptr[l]; o < L->line_obs_ptr[l + 1]; o++) used = 1;
+            if ((L->line_const && L->line_const[l]) || !used) c->line_off[l] = -1;
+            else { c->line_off[l] = off; off += 6; }
+        }
+    }
     c->Nr = off;
     int Nr = off;
     c->r = (double *)xcalloc((size_t)w->n_obs * 2, sizeof(double));
@@ -678,7 +744,7 @@ static void ctx_free(ctx_t *c) {
     free(c->kf_off); free(c->lmk_red); free(c->lmk_elim); free(c->lmk_active);
     free(c->r); free(c->Jp); free(c->Jl); free(c->E); free(c->Hll); free(c->gl);
     free(c->Hred); free(c->gred); free(c->s_red); free(c->s_lmk); free(c->W_imu);
-    free(c->sf); free(c->dp_colmap); free(c->dp_res); free(c->dp_JtJ);
+    free(c->line_off); free(c->sf); free(c->dp_colmap); free(c->dp_res); free(c->dp_JtJ);
 }
 
 /* cost of residual blocks whose parameter blocks are all constant (Ceres: Summary::fixed_cost) */
@@ -692,6 +758,14 @@ static double fixed_cost(ctx_t *c) {
             eval_obs(w, l, o, NULL, NULL, r, NULL, NULL, NULL);
             cost += r[0] * r[0] + r[1] * r[1];
         }
+    if (c->P->lines)
+        for (int l = 0; l < c->P->lines->n_line; l++)
+            for (int o = c->P->lines->line_obs_ptr[l]; o < c->P->lines->line_obs_ptr[l + 1]; o++) {
+                small_factor sf;
+                double rho;
+                if (line_small(c, NULL, l, o, &sf, 0, &rho)) continue;
+                cost += rho;
+            }
     static const double z6[6] = {0};
     for (int k = 0; k < c->P->n_prior; k++) {
         const sadvio_pose_prior *pr = c->P->priors + k;
@@ -775,8 +849,10 @@ int oracle_solve(const oracle_problem *P, const sadvio_solve_options *o, sadvio_
     double *cp = (double *)xcalloc(np, 8), *cl = (double *)xcalloc(nl, 8), *cv = (double *)xcalloc(nv, 8),
            *cba = (double *)xcalloc(nv, 8), *cbg = (double *)xcalloc(nv, 8);
     double *dred = (double *)xcalloc((size_t)c.Nr, 8), *dlmk = (double *)xcalloc(nl, 8);
-    state_t X = {xp, xl, xv, xba, xbg};
-    state_t C = {cp, cl, cv, cba, cbg};
+    const size_t nln = P->lines ? (size_t)P->lines->n_line * 6 : 0;
+    double *xline = (double *)xcalloc(nln, 8), *cline = (double *)xcalloc(nln, 8);
+    state_t X = {xp, xl, xv, xba, xbg, xline};
+    state_t C = {cp, cl, cv, cba, cbg, cline};
 
     sadvio_solve_summary S;
     memset(&S, 0, sizeof(S));
@@ -825,6 +901,7 @@ int oracle_solve(const oracle_problem *P, const sadvio_solve_options *o, sadvio_
         } else {
             n_invalid = 0;
             apply_delta(&c, dred, dlmk, xp, xl, xv, xba, xbg, cp, cl, cv, cba, cbg);
+            for (size_t i = 0; i < nln; i++) { const int lo = c.line_off[i / 6]; cline[i] = xline[i] + (lo >= 0 ? dred[lo + (int)(i % 6)] : 0.0); }
             double cand_cost = eval_cost(&c, &C);
             /* ParameterToleranceReached: norm over the reduced program's parameters */
             double sn2 = 0;
@@ -851,7 +928,9 @@ int oracle_solve(const oracle_problem *P, const sadvio_solve_options *o, sadvio_
                 /* HandleSuccessfulStep */
                 memcpy(xp, cp, np * 8); memcpy(xl, cl, nl * 8); memcpy(xv, cv, nv * 8);
                 memcpy(xba, cba, nv * 8); memcpy(xbg, cbg, nv * 8);
+                memcpy(xline, cline, nln * 8);
                 double n2 = 0;
+                for (size_t i = 0; i < nln; i++) if (c.line_off[i / 6] >= 0) n2 += xline[i] * xline[i];
                 for (int i = 0; i < w->n_kf; i++) {
                     if (c.kf_off[i] < 0) continue;
                     n2 += vec_norm2(xp + 6 * i, 6);
@@ -891,13 +970,14 @@ int oracle_solve(const oracle_problem *P, const sadvio_solve_options *o, sadvio_
     S.final_radius = radius;
     if (sum) *sum = S;
     if (pose_delta6) memcpy(pose_delta6, xp, np * 8);
+    if (P->line_delta6 && nln) memcpy(P->line_delta6, xline, nln * 8);
     if (lmk_delta3) memcpy(lmk_delta3, xl, nl * 8);
     if (dv3) memcpy(dv3, xv, nv * 8);
     if (dba3) memcpy(dba3, xba, nv * 8);
     if (dbg3) memcpy(dbg3, xbg, nv * 8);
     free(xp); free(xl); free(xv); free(xba); free(xbg);
     free(cp); free(cl); free(cv); free(cba); free(cbg);
-    free(dred); free(dlmk);
+    free(dred); free(dlmk); free(xline); free(cline);
     ctx_free(&c);
     return term == SADVIO_TERM_FAILURE ? SADVIO_E_NOT_USABLE : SADVIO_OK;
 }
@@ -1075,6 +1155,26 @@ void oracle_so3_right_jacobian(const double *w, double *J) { so3_right_jacobian(
 /* Probe of one sparse prior factor at the given deltas (arrays indexed like the window; NULL = zeros):
  * r[rows], J[rows x 15] in the factor's own column order (type 0: pose6 v3 ba3 bg3; 1: pose6 lmk3; 2: lmk3;
  * 3: lmk0 3, lmk1 3). Returns the number of residual rows. */
+/* probe: one line observation at the given deltas (NULL = zeros); J rows x 12 = [key-frame | line]; returns rows */
+int oracle_line_factor(const sadvio_flat_window *w, const sadvio_line_set *L, int32_t l, int32_t o, const double *xp, const double *xline,
+                       double *r, double *J) {
+    static const double z6[6] = {0, 0, 0, 0, 0, 0};
+    const int kf = L->obs_kf[o], cam = L->obs_cam[o];
+    const double *dp = xp ? xp + 6 * kf : z6, *dl = xline ? xline + 6 * l : z6;
+    double Jf[24], Jl[24];
+    int rows;
+    if (w->factor_type == SADVIO_FACTOR_PIXEL) {
+        rows = 4;
+        factor_line_pixel(w->kf_T_f_w + 12 * kf, w->cam_K + 4 * cam, w->cam_T_s_f + 12 * cam, L->line_T_w_l + 12 * l, L->line_model + 6 * l,
+                          L->obs_meas + 4 * o, 1.0, dp, dl, r, Jf, Jl);
+    } else {
+        rows = 2;
+        factor_line_angular(w->kf_T_f_w + 12 * kf, w->cam_T_s_f + 12 * cam, L->line_T_w_l + 12 * l, L->obs_meas + 6 * o, 1.0, dp, dl, r, Jf, Jl);
+    }
+    for (int i = 0; i < rows; i++) for (int q = 0; q < 6; q++) { J[i * 12 + q] = Jf[i * 6 + q]; J[i * 12 + 6 + q] = Jl[i * 6 + q]; }
+    return rows;
+}
+
 int oracle_sparse_factor(const sadvio_flat_window *w, const sadvio_sparse_prior *s, const double *xp, const double *xv,
                          const double *xba, const double *xbg, const double *xl, double *r, double *J) {
     static const double z[15] = {0};

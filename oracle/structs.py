@@ -35,6 +35,33 @@ class sparse_prior(C.Structure):           # sadvio_sparse_prior
                 ("ba_prior", f64 * 3), ("bg_prior", f64 * 3), ("delta", f64 * 3), ("sqrt_inf", f64 * 225), ("kf_b", i32), ("pad", i32)]
 
 
+class line_set(C.Structure):               # sadvio_line_set
+    _fields_ = [("n_line", i32), ("n_obs", i32), ("line_id", P(i64)), ("line_T_w_l", P(f64)), ("line_model", P(f64)),
+                ("line_const", P(u8)), ("line_obs_ptr", P(i32)), ("obs_kf", P(i32)), ("obs_cam", P(i32)), ("obs_meas", P(f64))]
+
+
+def lines_to_c(lines):
+    """(line_set, keep-alive) from a dict with keys T_w_l [n,12], model [n,6], obs_ptr [n+1], obs_kf, obs_cam, obs_meas
+    (+ optional id, const)."""
+    T = np.ascontiguousarray(lines["T_w_l"], dtype=np.float64).reshape(-1, 12)
+    n = T.shape[0]
+    arrs = dict(line_id=np.ascontiguousarray(lines.get("id", np.arange(n)), dtype=np.int64), line_T_w_l=T,
+                line_model=np.ascontiguousarray(lines["model"], dtype=np.float64).reshape(n, 6),
+                line_obs_ptr=np.ascontiguousarray(lines["obs_ptr"], dtype=np.int32), obs_kf=np.ascontiguousarray(lines["obs_kf"], dtype=np.int32),
+                obs_cam=np.ascontiguousarray(lines["obs_cam"], dtype=np.int32), obs_meas=np.ascontiguousarray(lines["obs_meas"], dtype=np.float64))
+    c = line_set()
+    c.n_line, c.n_obs = n, int(arrs["obs_kf"].size)
+    ct = dict(line_id=i64, line_T_w_l=f64, line_model=f64, line_obs_ptr=i32, obs_kf=i32, obs_cam=i32, obs_meas=f64)
+    for k, a in arrs.items():
+        setattr(c, k, a.ctypes.data_as(P(ct[k])))
+    keep = list(arrs.values())
+    if lines.get("const") is not None:
+        lc = np.ascontiguousarray(lines["const"], dtype=np.uint8)
+        c.line_const = lc.ctypes.data_as(P(u8))
+        keep.append(lc)
+    return c, keep
+
+
 class solve_options(C.Structure):          # sadvio_solve_options
     _fields_ = [("max_num_iterations", i32), ("jacobi_scaling", i32), ("max_num_consecutive_invalid_steps", i32),
                 ("reserved", i32), ("function_tolerance", f64), ("gradient_tolerance", f64), ("parameter_tolerance", f64),

@@ -71,6 +71,11 @@ class ViInitResultC(C.Structure):
                 ("R_w_i", C.c_double * 9), ("scale", C.c_double)]
 
 
+class LineSetC(C.Structure):
+    _fields_ = [("n_line", C.c_int32), ("n_obs", C.c_int32), ("line_id", _lp), ("line_T_w_l", _dp), ("line_model", _dp),
+                ("line_const", _bp), ("line_obs_ptr", _ip), ("obs_kf", _ip), ("obs_cam", _ip), ("obs_meas", _dp)]
+
+
 class PosePriorC(C.Structure):
     _fields_ = [("kf", C.c_int32), ("pad", C.c_int32), ("T_prior", C.c_double * 12), ("inf_diag", C.c_double * 6)]
 
@@ -226,6 +231,7 @@ class FlatWindow:
     pose_priors: List[tuple] = field(default_factory=list)   # (kf, T_prior[12], inf_diag[6])
     imu_factors: List[dict] = field(default_factory=list)    # dicts with the ImuFactorC fields
     sparse_priors: List[dict] = field(default_factory=list)  # dicts with the SparsePriorC fields (NFR factors)
+    lines: Optional[dict] = None         # linexd landmarks: T_w_l [n,12], model [n,6], obs_ptr, obs_kf, obs_cam, obs_meas [n_obs,4|6] (+ id, const)
     dense_prior: Optional[dict] = None   # MarginalizationFactor: J [n_full,n], r0, kf_keep, kf_col, lmk_index, lmk_col
     truth: dict = field(default_factory=dict)                # generator ground truth (not uploaded)
     _keep: list = field(default_factory=list, repr=False)
@@ -342,6 +348,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.sadvio_ba_get_deltas.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
     lib.sadvio_ba_get_ids.argtypes = [C.c_void_p, C.c_int32, _lp, _lp]
     lib.sadvio_ba_get_trace.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _ip]
+    lib.sadvio_ba_set_lines.argtypes = [C.c_void_p, C.c_int32, C.POINTER(LineSetC)]
+    lib.sadvio_ba_get_line_deltas.argtypes = [C.c_void_p, C.c_int32, _dp]
     lib.sadvio_ba_marginalize_relative.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]
     lib.sadvio_ba_linearize.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
     lib.sadvio_ba_vi_init.argtypes = [C.c_void_p, C.POINTER(ViInitProblemC), C.POINTER(SolveOptions), C.POINTER(SolveSummary),
@@ -409,6 +417,37 @@ class Backend:
                 self._check(self.lib.sadvio_ba_set_sparse_priors(self.h, i, n, sa), "set_sparse_priors")
             if w.dense_prior is not None:
                 self.set_dense_prior(i, w.dense_prior)
+            if w.lines is not None:
+                self.set_lines(i, w.lines)
+
+    def set_lines(self, w: int, lines: Optional[dict]):
+        """linexd landmarks of window w (sadvio_ba_set_lines); None clears them."""
+        if lines is None:
+            self._check(self.lib.sadvio_ba_set_lines(self.h, w, None), "set_lines")
+            return
+        T = np.ascontiguousarray(lines["T_w_l"], dtype=np.float64).reshape(-1, 12)
+        n = T.shape[0]
+        c = LineSetC()
+        ids = np.ascontiguousarray(lines.get("id", np.arange(n)), dtype=np.int64)
+        model = np.ascontiguousarray(lines["model"], dtype=np.float64).reshape(n, 6)
+        ptr = np.ascontiguousarray(lines["obs_ptr"], dtype=np.int32)
+        okf = np.ascontiguousarray(lines["obs_kf"], dtype=np.int32); ocam = np.ascontiguousarray(lines["obs_cam"], dtype=np.int32)
+        meas = np.ascontiguousarray(lines["obs_meas"], dtype=np.float64)
+        c.n_line, c.n_obs = n, int(okf.size)
+        c.line_id, c.line_T_w_l, c.line_model = ids.ctypes.data_as(_lp), _ptr(T), _ptr(model)
+        c.line_obs_ptr, c.obs_kf, c.obs_cam, c.obs_meas = ptr.ctypes.data_as(_ip), okf.ctypes.data_as(_ip), ocam.ctypes.data_as(_ip), _ptr(meas)
+        keep = [ids, T, model, ptr, okf, ocam, meas]
+        if lines.get("const") is not None:
+            lc = np.ascontiguousarray(lines["const"], dtype=np.uint8)
+            c.line_const = lc.ctypes.data_as(_bp)
+            keep.append(lc)
+        self._check(self.lib.sadvio_ba_set_lines(self.h, w, C.byref(c)), "set_lines")
+
+    def get_line_deltas(self, w: int, n_line: int) -> np.ndarray:
+        """[n_line, 6] accepted line-pose deltas of window w (PointXYZParametersBlock-style 6-dof blocks of linexd)."""
+        out = np.zeros((n_line, 6))
+        self._check(self.lib.sadvio_ba_get_line_deltas(self.h, w, _ptr(out)), "get_line_deltas")
+        return out
 
     def set_dense_prior(self, w: int, dp: Optional[dict]):
         """Dense marginalisation prior of window w (None clears it)."""

@@ -170,6 +170,14 @@ struct DensePriorHost {
     std::vector<int> lmk_index, lmk_col;
 };
 
+struct LineSetHost {   // deep copy of a sadvio_line_set
+    std::vector<int64_t> id;
+    std::vector<double> T, model, meas;
+    std::vector<unsigned char> is_const;
+    std::vector<int> ptr, obs_kf, obs_cam;
+    int n() const { return (int)id.size(); }
+};
+
 struct sadvio_ba_handle {
     sadvio_ba_config cfg{};
     int device = 0;
@@ -208,6 +216,11 @@ struct sadvio_ba_handle {
     std::vector<std::vector<char>> sp_elim;        // per window, per sparse factor: handled as pseudo-observations
     std::vector<int> n_obs_user;                   // caller's observation count per window
     std::vector<std::vector<sadvio_sparse_prior>> sparse_per_win;
+    std::vector<LineSetHost> lines_per_win;        // linexd landmarks
+    DevBuf<LineDev> d_lines;
+    DevBuf<LineObsDev> d_lobs;
+    DevBuf<double> d_xline, d_line_scratch;
+    int n_line_tot = 0, n_lobs_tot = 0;
     DevBuf<SparseDev> d_sparse;
     DevBuf<int> d_sp_list;
     int n_sp_list = 0;   // sparse prior factors evaluated by k_sparse_eval (all windows)
@@ -329,6 +342,8 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.lmk_red = h->d_lmk_red.p; P.kept_obs = h->d_kept_obs.p; P.n_kept = h->n_kept;
     P.dp_data = h->d_dp_data.p; P.dp_ints = h->d_dp_ints.p;
     P.sparse = h->d_sparse.p; P.sp_scratch = h->d_sp_scratch.p; P.sp_list = h->d_sp_list.p;
+    P.lines = h->d_lines.p; P.lobs = h->d_lobs.p; P.xline = h->d_xline.p; P.line_scratch = h->d_line_scratch.p;
+    P.xline_stride = 6LL * h->n_line_tot;
     P.n_xp = (long long)h->d_xp.n; P.n_xv = (long long)h->d_xv.n; P.n_xl = (long long)h->d_xl.n;
     P.n_win = (int)h->wins.size();
     { const char* e = getenv("SADVIO_DEBUG"); P.debug = e ? atoi(e) : 0; }
@@ -362,6 +377,8 @@ int layout_reduced(sadvio_ba_handle* h) {
     std::vector<int> kept, dp_ints;
     std::vector<SparseDev> sparse;
     std::vector<int> sp_list;
+    std::vector<LineDev> lines;
+    std::vector<LineObsDev> lobs;
     std::vector<double> dp_data;
     bool any_red = false;
     struct Prep { long long off; int nf, n; };
@@ -451,6 +468,26 @@ int layout_reduced(sadvio_ba_handle* h) {
         d.kept_end = (int)kept.size() / 3;
         d.n_red = n_red;
         d.Np = d.n_free_kf * d.dpf + 3 * n_red;
+        // linexd landmarks: 6 columns each after the kept landmarks
+        d.line_begin = (int)lines.size(); d.lobs_begin = (int)lobs.size();
+        if (w < (int)h->lines_per_win.size()) {
+            const LineSetHost& LS = h->lines_per_win[w];
+            for (int l = 0; l < LS.n(); l++) {
+                LineDev o{};
+                memcpy(o.T, &LS.T[12 * (size_t)l], 96); memcpy(o.model, &LS.model[6 * (size_t)l], 48);
+                o.win = w; o.col = -1;
+                if (!(LS.is_const.size() && LS.is_const[l])) { o.col = d.Np; d.Np += 6; }
+                const int ms = d.factor_type == SADVIO_FACTOR_PIXEL ? 4 : 6;
+                for (int ob = LS.ptr[l]; ob < LS.ptr[l + 1]; ob++) {
+                    LineObsDev q{};
+                    q.line = (int)lines.size(); q.kf = d.kf_base + LS.obs_kf[ob]; q.cam = d.cam_base + h->src[w].cam_map[LS.obs_cam[ob]]; q.win = w;
+                    memcpy(q.meas, &LS.meas[(size_t)ms * ob], sizeof(double) * ms);
+                    lobs.push_back(q);
+                }
+                lines.push_back(o);
+            }
+        }
+        d.line_end = (int)lines.size(); d.lobs_end = (int)lobs.size();
         // reduced systems that fit LDS are kept as a packed lower triangle (16-byte aligned); larger ones as a
         // full row-major matrix (lower triangle used) that the library factorisation works on in place
         d.ld = d.Np > MAX_LDS_NP ? d.Np : 0;
@@ -480,6 +517,11 @@ int layout_reduced(sadvio_ba_handle* h) {
     HIP_TRY(h->d_sp_list.alloc(std::max<size_t>(sp_list.size(), 1)));
     h->n_sp_list = (int)sp_list.size();
     h->up.add(h->d_sp_list.p, sp_list.data(), sp_list.size() * sizeof(int));
+    h->n_line_tot = (int)lines.size(); h->n_lobs_tot = (int)lobs.size();
+    HIP_TRY(h->d_lines.alloc(std::max<size_t>(lines.size(), 1))); HIP_TRY(h->d_lobs.alloc(std::max<size_t>(lobs.size(), 1)));
+    HIP_TRY(h->d_xline.alloc(std::max<size_t>(12 * lines.size(), 1))); HIP_TRY(h->d_line_scratch.alloc(std::max<size_t>(lobs.size(), 1) * LINE_ROW));
+    h->up.add(h->d_lines.p, lines.data(), lines.size() * sizeof(LineDev));
+    h->up.add(h->d_lobs.p, lobs.data(), lobs.size() * sizeof(LineObsDev));
     if (kept.empty()) kept.assign(3, 0);
     if (dp_ints.empty()) dp_ints.push_back(0);
     if (dp_data.empty()) dp_data.push_back(0.0);
@@ -989,7 +1031,56 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
     h->imus_per_win.assign(n_windows, {});
     h->dprior_per_win.assign(n_windows, {});
     h->sparse_per_win.assign(n_windows, {});
+    h->lines_per_win.assign(n_windows, {});
     return build_layout(h);
+}
+
+int sadvio_ba_set_lines(sadvio_ba_handle* h, int32_t w, const sadvio_line_set* L) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (!h->uploaded) { h->err = "set_lines before set_windows"; return SADVIO_E_STATE; }
+    if (w < 0 || w >= (int)h->wins.size()) { h->err = "set_lines: window out of range"; return SADVIO_E_INVALID_ARG; }
+    const int n = L ? L->n_line : 0;
+    if (h->world > 1 && n > 0) { h->err = "set_lines: not supported on a window sharded over several GPUs"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    const WinDev& d = h->wins[w].d;
+    LineSetHost H;
+    if (n > 0) {
+        if (n < 0 || L->n_obs < 0 || !L->line_T_w_l || !L->line_model || !L->line_obs_ptr || (L->n_obs > 0 && (!L->obs_kf || !L->obs_cam || !L->obs_meas))) {
+            h->err = "set_lines: missing array"; return SADVIO_E_INVALID_ARG;
+        }
+        if (L->line_obs_ptr[0] != 0 || L->line_obs_ptr[n] != L->n_obs) { h->err = "set_lines: line_obs_ptr is not a CSR over n_obs"; return SADVIO_E_INVALID_ARG; }
+        for (int l = 0; l < n; l++) if (L->line_obs_ptr[l + 1] < L->line_obs_ptr[l]) { h->err = "set_lines: CSR not monotone"; return SADVIO_E_INVALID_ARG; }
+        for (int o = 0; o < L->n_obs; o++)
+            if (L->obs_kf[o] < 0 || L->obs_kf[o] >= d.n_kf || L->obs_cam[o] < 0 || L->obs_cam[o] >= (int)h->src[w].cam_map.size()) {
+                h->err = "set_lines: observation index out of range"; return SADVIO_E_INVALID_ARG;
+            }
+        const int ms = d.factor_type == SADVIO_FACTOR_PIXEL ? 4 : 6;
+        H.id.resize(n);
+        for (int l = 0; l < n; l++) H.id[l] = L->line_id ? L->line_id[l] : l;
+        H.T.assign(L->line_T_w_l, L->line_T_w_l + 12 * (size_t)n); H.model.assign(L->line_model, L->line_model + 6 * (size_t)n);
+        if (L->line_const) H.is_const.assign(L->line_const, L->line_const + n);
+        H.ptr.assign(L->line_obs_ptr, L->line_obs_ptr + n + 1);
+        if (L->n_obs) {
+            H.obs_kf.assign(L->obs_kf, L->obs_kf + L->n_obs); H.obs_cam.assign(L->obs_cam, L->obs_cam + L->n_obs);
+            H.meas.assign(L->obs_meas, L->obs_meas + (size_t)ms * L->n_obs);
+        }
+    }
+    h->lines_per_win[w] = std::move(H);
+    h->solved = false;
+    int rc = layout_reduced(h);   // the lines enlarge the reduced system; the landmark tiles are unchanged
+    if (rc != SADVIO_OK) return rc;
+    return upload_priors(h);
+}
+
+int sadvio_ba_get_line_deltas(sadvio_ba_handle* h, int32_t w, double* line_delta6) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (!h->solved) { h->err = "get_line_deltas before solve"; return SADVIO_E_STATE; }
+    if (w < 0 || w >= (int)h->wins.size() || !line_delta6) { h->err = "get_line_deltas: bad argument"; return SADVIO_E_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(h->device));
+    const WinDev& d = h->wins[w].d;
+    const int n = d.line_end - d.line_begin;
+    if (n > 0) HIP_TRY(hipMemcpy(line_delta6, h->d_xline.p + (size_t)h->fin[w].s.cur * 6 * h->n_line_tot + 6 * (size_t)d.line_begin, sizeof(double) * 6 * n, hipMemcpyDeviceToHost));
+    return SADVIO_OK;
 }
 
 int sadvio_ba_set_pose_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const sadvio_pose_prior* pr) {
@@ -1719,7 +1810,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     o.min_lm_diagonal = opts->min_lm_diagonal; o.max_lm_diagonal = opts->max_lm_diagonal;
     o.min_relative_decrease = opts->min_relative_decrease;
     o.huber_a = opts->huber_a;
-    o.max_time_ticks = opts->max_solver_time_in_seconds > 0.0 ? opts->max_solver_time_in_seconds * 1e8 : 0.0;   // wall_clock64: 100 MHz
+    // wall_clock64: 100 MHz. Not applied to a window sharded over several GPUs: the ranks' clocks would disagree on the slot
+    o.max_time_ticks = (opts->max_solver_time_in_seconds > 0.0 && h->world == 1) ? opts->max_solver_time_in_seconds * 1e8 : 0.0;
     if (!(o.huber_a >= 0.0)) { h->err = "solve: huber_a must be >= 0"; return SADVIO_E_INVALID_ARG; }
     const int n_win = (int)h->wins.size();
     // Slot s (s = 0 .. slots-1) is one step attempt; with max_num_iterations = 0 Ceres still evaluates
@@ -1777,7 +1869,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     bool extras = false;  // any pose-only factor family beyond PosePriordx in the batch?
     for (int w = 0; w < n_win; w++) {
         const WinDev& d = h->wins[w].d;
-        if (d.imu_end > d.imu_begin || d.sp_end > d.sp_begin || d.dp_n_full > 0 || d.dpf == 15) extras = true;   // dpf 15: padded pivots live in the EXTRAS kernel
+        if (d.imu_end > d.imu_begin || d.sp_end > d.sp_begin || d.dp_n_full > 0 || d.dpf == 15 || d.lobs_end > d.lobs_begin || d.line_end > d.line_begin) extras = true;   // dpf 15: padded pivots live in the EXTRAS kernel
     }
     auto ks0 = extras ? k_solve<0, true> : k_solve<0, false>;
     auto ks1 = extras ? k_solve<1, true> : k_solve<1, false>;
@@ -1801,7 +1893,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                     const int fi = h->h_kf_fidx[d.kf_base + sp.kf], fj = h->h_kf_fidx[d.kf_base + sp.kf_b];
                     if (fi >= 0 && fj >= 0) hb = std::max(hb, std::abs(fi - fj));
                 }
-        big_bw[w] = (d.n_red > 0 || d.dp_n_full > 0) ? d.Np : std::min(d.Np, (hb + 1) * d.dpf);
+        big_bw[w] = (d.n_red > 0 || d.dp_n_full > 0 || d.line_end > d.line_begin) ? d.Np : std::min(d.Np, (hb + 1) * d.dpf);
     }
     if (h->coll_fn && h->world > 1 && h->n_big) {
         // every rank must factor the all-reduced S with the same (largest) bandwidth: gather the local ones
@@ -1843,13 +1935,15 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         // IMU factors are evaluated on a side stream: the linearisation next to k_build, the candidate cost next to
         // k_backsub (fork / join with events; inside the captured graph these become parallel branches)
         const int n_spl = h->n_sp_list;
-        const bool fork = (n_imu_all > 0 || n_spl > 0) && h->side && !h->cfg.profile_kernels && !h->coll_fn;
+        const int n_lo = h->n_lobs_tot;
+        const bool fork = (n_imu_all > 0 || n_spl > 0 || n_lo > 0) && h->side && !h->cfg.profile_kernels && !h->coll_fn;
         for (int s = 0; s < slots; s++) {
             if (fork) {
                 (void)hipEventRecord(h->ev_fork, h->stream);
                 (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
                 if (n_imu_all) hipLaunchKernelGGL(k_imu_eval<true>, dim3(n_imu_all), dim3(64), 0, h->side, P, s, 1);
                 if (n_spl) hipLaunchKernelGGL(k_sparse_eval<true>, dim3(n_spl), dim3(64), 0, h->side, P, s, 1);
+                if (n_lo) hipLaunchKernelGGL(k_line_eval<true>, dim3(n_lo), dim3(64), 0, h->side, P, s, 1);
                 (void)hipEventRecord(h->ev_lin, h->side);
             }
             { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
@@ -1881,6 +1975,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             else {
                 if (n_imu_all) { ScopedTimer t(h, "k_imu_lin"); hipLaunchKernelGGL(k_imu_eval<true>, dim3(n_imu_all), dim3(64), 0, h->stream, P, s, 0); }
                 if (n_spl) { ScopedTimer t(h, "k_sparse_lin"); hipLaunchKernelGGL(k_sparse_eval<true>, dim3(n_spl), dim3(64), 0, h->stream, P, s, 0); }
+                if (n_lo) { ScopedTimer t(h, "k_line_lin"); hipLaunchKernelGGL(k_line_eval<true>, dim3(n_lo), dim3(64), 0, h->stream, P, s, 0); }
             }
             if (h->n_big < n_win) { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(ks0, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
             if (h->n_big) {
@@ -2016,10 +2111,12 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 (void)hipStreamWaitEvent(h->side, h->ev_solved, 0);
                 if (n_imu_all) hipLaunchKernelGGL(k_imu_eval<false>, dim3(n_imu_all), dim3(64), 0, h->side, P, s, 0);
                 if (n_spl) hipLaunchKernelGGL(k_sparse_eval<false>, dim3(n_spl), dim3(64), 0, h->side, P, s, 0);
+                if (n_lo) hipLaunchKernelGGL(k_line_eval<false>, dim3(n_lo), dim3(64), 0, h->side, P, s, 0);
                 (void)hipEventRecord(h->ev_cost, h->side);
             } else {
                 if (n_imu_all) { ScopedTimer t(h, "k_imu_cost"); hipLaunchKernelGGL(k_imu_eval<false>, dim3(n_imu_all), dim3(64), 0, h->stream, P, s, 0); }
                 if (n_spl) { ScopedTimer t(h, "k_sparse_cost"); hipLaunchKernelGGL(k_sparse_eval<false>, dim3(n_spl), dim3(64), 0, h->stream, P, s, 0); }
+                if (n_lo) { ScopedTimer t(h, "k_line_cost"); hipLaunchKernelGGL(k_line_eval<false>, dim3(n_lo), dim3(64), 0, h->stream, P, s, 0); }
             }
             if (dp_max_nf > 0) { ScopedTimer t(h, "k_prior_m"); hipLaunchKernelGGL(k_prior_m, dim3((dp_max_nf + 3) / 4, n_win), dim3(256), 0, h->stream, P, s); }
             { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
@@ -2037,7 +2134,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         // the whole <= 20-iteration solve is one graph launch; the key covers every kernel argument
         std::vector<int> lay;  // layout-dependent launch parameters of the out-of-LDS windows
         for (int w = 0; w < n_win; w++) { lay.push_back(h->wins[w].d.Np); lay.push_back(h->wins[w].d.ld); lay.push_back(big_bw[w]); }
-        lay.push_back(h->n_kept); lay.push_back(h->n_big); lay.push_back(dp_max_nf); lay.push_back(dp_max_n);
+        lay.push_back(h->n_kept); lay.push_back(h->n_lobs_tot); lay.push_back(h->n_line_tot); lay.push_back(h->n_big); lay.push_back(dp_max_nf); lay.push_back(dp_max_n);
         std::vector<unsigned char> key(sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t) + lay.size() * sizeof(int));
         unsigned char* kp = key.data();
         memcpy(kp + sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t), lay.data(), lay.size() * sizeof(int));

@@ -47,6 +47,8 @@ struct WinDev {
     int kept_begin, kept_end;  // slice of kept_obs (observations of the reduced landmarks)
     int sp_begin, sp_end;      // slice of the sparse prior factors
     int spl_begin, spl_end;    // slice of sp_list: the factors evaluated inside the solve (not riding the Schur elimination)
+    int line_begin, line_end;  // slice of the linexd landmarks (6 reduced columns each after the kept landmarks)
+    int lobs_begin, lobs_end;  // slice of their observations
 };
 
 // One workgroup of k_build / k_backsub: a run of consecutive landmarks of one window. Each landmark is
@@ -97,6 +99,17 @@ struct SparseDev {
     double T_prior[12], v_prior[3], ba_prior[3], bg_prior[3], delta[3];
     double W[225];
 };
+// linexd landmark (a pose T_w_l whose x axis carries the two model points) and one of its observations
+struct LineDev {
+    double T[12], model[6];
+    int col;   // first of its 6 columns in the window's reduced vector, -1 = constant
+    int win;
+};
+struct LineObsDev {
+    int line, kf, cam, win;   // global line / key-frame / camera indices
+    double meas[6];           // pixel: the two end points (4); angular: the two bearing vectors
+};
+constexpr int LINE_ROW = 4 * 12 + 4 + 2;  // scratch row of one line observation: J (rows x 12) | r | rho | in-program flag
 constexpr int SPARSE_J = 15 * 15 + 15 + 2;  // J (rows x 15) + r + in-program flag kept in HBM scratch between phases
 constexpr int IMU_J = 9 * 24 + 9;  // whitened Jacobian + residual kept in HBM scratch between phases
 // scratch row of one IMU factor: J 216 | r 9 | bias residuals 6 | H = J^T J (lower, 300) | g = J^T r (24) | target of each H / g
@@ -129,7 +142,7 @@ struct IterAcc {
     double fixed_cost;  // sum r^2 of blocks whose parameters are all constant (slot 0 only)
     unsigned long long gmax_bits;  // max |gradient| as IEEE bits (non-negative doubles order like u64)
     int chol_fail;
-    int time_up;   // the solver-time limit was exceeded when this slot's k_solve ran (one sample per slot: every decider sees the same)
+    int time_up;   // the solver-time limit was exceeded when this slot's k_solve ran (it then ended the solve)
 };
 
 // Per-tile partial sums of one slot, written with plain stores by the tile's workgroup and summed by the

@@ -605,4 +605,132 @@ __device__ __noinline__ void imu_factor(const ImuT& f, const double* Ti0, const 
     imu_factor_body<ImuT, WHITEN>(f, Ti0, Tj0, vi0, vj0, dpi, dpj, dvi, dvj, dba, dbg, r, J);
 }
 
+// ---- linexd landmarks ------------------------------------------------------------------------
+// ReprojectionErrCeres_linexd_dx (BundleAdjustmentCERESAnalytic.h:104-195), sigma = 1 (…Analytic.cpp:303). tab: pose table
+// of the observing key-frame at its current delta. As coded, the line parameter enters the residual as a translation
+// of the model points in the line frame by dline[0..2] (:121), while its Jacobian block is J_point [-R_w_l [pt]x | I]
+// (:156-160). r4 | Jf 4x6 | Jl 4x6, row-major; an invalid projection has r = 0 and keeps its Jacobian.
+__device__ __forceinline__ void line_pixel_factor(const double* tab, const double* K, const double* Tsf, const double* Twl,
+                                                  const double* model, const double* uv4, const double* dline, double* r4,
+                                                  double* Jf, double* Jl) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const double* pt = model + 3 * i;
+        const double q[3] = {pt[0] + dline[0], pt[1] + dline[1], pt[2] + dline[2]};
+        double pw[3], Jp[12], J3[6];
+        m3_vec(Twl, q, pw);
+        pw[0] += Twl[9]; pw[1] += Twl[10]; pw[2] += Twl[11];
+        (void)pixel_factor<true>(tab, K, Tsf, pw, uv4[2 * i], uv4[2 * i + 1], 1.0, r4 + 2 * i, Jp, J3);
+        if (!Jf) continue;
+        double S[9], RS[9];
+        so3_skew(pt, S);
+        m3_mul(Twl, S, RS);
+#pragma unroll
+        for (int a = 0; a < 12; a++) Jf[12 * i + a] = Jp[a];
+#pragma unroll
+        for (int qq = 0; qq < 2; qq++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                Jl[(2 * i + qq) * 6 + a] = -(J3[3 * qq] * RS[a] + J3[3 * qq + 1] * RS[3 + a] + J3[3 * qq + 2] * RS[6 + a]);
+                Jl[(2 * i + qq) * 6 + 3 + a] = J3[3 * qq + a];
+            }
+    }
+}
+
+// AngularErrCeres_linexd_dx (AngularAdjustmentCERESAnalytic.h:368-469), weight 1 / sigma^2 with sigma = 1
+// (Angular….cpp:326-330). Residual 0: |n_obs x n_line| (parallelism of the two plane normals), residual 1: n_obs . b_line
+// (line centre in the observed plane). The Jacobians are the ones the reference writes, with its helper definitions
+// J_normalization(X) = (I - X X^T) / |X| on the un-normalised X and J_AcrossX(A) = -[A]x (utilities/geometry.h:327-343).
+// r2 | Jf 2x6 | Jl 2x6 (Jf == nullptr: residual only).
+__device__ __noinline__ void line_angular_factor(const double* T0, const double* Tsf, const double* Twl, const double* b6,
+                                                 const double* dpose, const double* dline, double* r2, double* Jf, double* Jl) {
+    double dR[9], dRl[9], Rsw[9], RswdR[9], C[9], Rsl[9];
+    so3_exp(dpose, dR); so3_exp(dline, dRl);
+    m3_mul(Tsf, T0, Rsw); m3_mul(Rsw, dR, RswdR); m3_mul(RswdR, Twl, C); m3_mul(C, dRl, Rsl);
+    // t_s_l = Rsw (dR (R_w_l t_dl + t_w_l) + t_d) + R_s_f t_0 + t_s_f
+    double u[3], v[3], t[3], w0[3];
+    m3_vec(Twl, dline + 3, u);
+    const double p[3] = {u[0] + Twl[9], u[1] + Twl[10], u[2] + Twl[11]};
+    m3_vec(dR, p, v);
+    v[0] += dpose[3]; v[1] += dpose[4]; v[2] += dpose[5];
+    m3_vec(Rsw, v, t);
+    m3_vec(Tsf, T0 + 9, w0);
+#pragma unroll
+    for (int i = 0; i < 3; i++) t[i] += w0[i] + Tsf[9 + i];
+    double n_obs[3] = {b6[1] * b6[5] - b6[2] * b6[4], b6[2] * b6[3] - b6[0] * b6[5], b6[0] * b6[4] - b6[1] * b6[3]};
+    { const double inv = 1.0 / v3_norm(n_obs); n_obs[0] *= inv; n_obs[1] *= inv; n_obs[2] *= inv; }
+    const double tn = v3_norm(t);
+    const double bl[3] = {t[0] / tn, t[1] / tn, t[2] / tn};
+    double dir[3] = {Rsl[0], Rsl[3], Rsl[6]};
+    { const double dn = v3_norm(dir); dir[0] /= dn; dir[1] /= dn; dir[2] /= dn; }
+    const double nl[3] = {bl[1] * dir[2] - bl[2] * dir[1], bl[2] * dir[0] - bl[0] * dir[2], bl[0] * dir[1] - bl[1] * dir[0]};
+    const double nln = v3_norm(nl);
+    const double nlh[3] = {nl[0] / nln, nl[1] / nln, nl[2] / nln};
+    const double cx[3] = {n_obs[1] * nlh[2] - n_obs[2] * nlh[1], n_obs[2] * nlh[0] - n_obs[0] * nlh[2], n_obs[0] * nlh[1] - n_obs[1] * nlh[0]};
+    const double cxn = v3_norm(cx);
+    r2[0] = cxn;
+    r2[1] = n_obs[0] * bl[0] + n_obs[1] * bl[1] + n_obs[2] * bl[2];
+    if (!Jf) return;
+    // e0 = (cx / |cx|)^T (-[n_obs]x) J_normalization(n_l);  e1 = n_obs^T J_normalization(t)
+    double Sn[9], e0[3], e1[3], m[3];
+    so3_skew(n_obs, Sn);
+    // m = -(cx^T [n_obs]x) / |cx|
+#pragma unroll
+    for (int j = 0; j < 3; j++) m[j] = -(cx[0] * Sn[j] + cx[1] * Sn[3 + j] + cx[2] * Sn[6 + j]) / cxn;
+    {
+        const double mn = m[0] * nl[0] + m[1] * nl[1] + m[2] * nl[2];
+#pragma unroll
+        for (int j = 0; j < 3; j++) e0[j] = (m[j] - mn * nl[j]) / nln;
+        const double nt = n_obs[0] * t[0] + n_obs[1] * t[1] + n_obs[2] * t[2];
+#pragma unroll
+        for (int j = 0; j < 3; j++) e1[j] = (n_obs[j] - nt * t[j]) / tn;
+    }
+    // row-0 weights: g = e0^T ( [R_s_l e_x]x^T J_normalization(t) J_t + [n_l / |n_l|]x J_R ) = a^T J_t + c^T J_R
+    double a[3], c[3];
+    {
+        const double rx[3] = {Rsl[0], Rsl[3], Rsl[6]};
+        // e0^T [rx]x^T = ([rx]x e0)^T
+        const double f[3] = {rx[1] * e0[2] - rx[2] * e0[1], rx[2] * e0[0] - rx[0] * e0[2], rx[0] * e0[1] - rx[1] * e0[0]};
+        const double ft = f[0] * t[0] + f[1] * t[1] + f[2] * t[2];
+#pragma unroll
+        for (int j = 0; j < 3; j++) a[j] = (f[j] - ft * t[j]) / tn;
+        // e0^T [n]x = ([n]x^T e0)^T = (e0 x n)^T
+        c[0] = e0[1] * nlh[2] - e0[2] * nlh[1]; c[1] = e0[2] * nlh[0] - e0[0] * nlh[2]; c[2] = e0[0] * nlh[1] - e0[1] * nlh[0];
+    }
+    // J_t, J_R blocks (3x3 each, the others are zero)
+    double Jr_d[9], Jr_l[9], S1[9], S2[9], P1[9], P2[9], Jt_w[9], JR_w[9], JR_lw[9];
+    // so3_rightJacobian(log_so3(dR)) as written (Angular….h:416-435): a line's rotation delta does leave |w| < pi during
+    // a solve (the coded Jacobians are inexact and the line spins about its own axis), where log(exp(w)) != w
+    { double lw[3]; so3_log(dR, lw); so3_right_jacobian(lw, Jr_d); so3_log(dRl, lw); so3_right_jacobian(lw, Jr_l); }
+    so3_skew(u, S1); m3_mul(RswdR, S1, P1); m3_mul(P1, Jr_d, P2);
+    so3_skew(Twl + 9, S2); m3_mul(RswdR, S2, P1);
+#pragma unroll
+    for (int i = 0; i < 9; i++) Jt_w[i] = -P2[i] - P1[i];
+    {
+        double Rwl_dRl[9];
+        m3_mul(Twl, dRl, Rwl_dRl);
+        const double ex[3] = {Rwl_dRl[0], Rwl_dRl[3], Rwl_dRl[6]};
+        so3_skew(ex, S1); m3_mul(RswdR, S1, P1); m3_mul(P1, Jr_d, JR_w);
+#pragma unroll
+        for (int i = 0; i < 9; i++) JR_w[i] = -JR_w[i];
+        const double e_x[3] = {1.0, 0.0, 0.0};
+        so3_skew(e_x, S1); m3_mul(Rsl, S1, P2); m3_mul(P2, Jr_l, JR_lw);
+#pragma unroll
+        for (int i = 0; i < 9; i++) JR_lw[i] = -JR_lw[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        // key-frame block: J_t = [Jt_w | Rsw], J_R = [JR_w | 0]
+        Jf[j] = a[0] * Jt_w[j] + a[1] * Jt_w[3 + j] + a[2] * Jt_w[6 + j] + c[0] * JR_w[j] + c[1] * JR_w[3 + j] + c[2] * JR_w[6 + j];
+        Jf[3 + j] = a[0] * Rsw[j] + a[1] * Rsw[3 + j] + a[2] * Rsw[6 + j];
+        Jf[6 + j] = e1[0] * Jt_w[j] + e1[1] * Jt_w[3 + j] + e1[2] * Jt_w[6 + j];
+        Jf[9 + j] = e1[0] * Rsw[j] + e1[1] * Rsw[3 + j] + e1[2] * Rsw[6 + j];
+        // line block: J_t = [0 | C], J_R = [JR_lw | 0]
+        Jl[j] = c[0] * JR_lw[j] + c[1] * JR_lw[3 + j] + c[2] * JR_lw[6 + j];
+        Jl[3 + j] = a[0] * C[j] + a[1] * C[3 + j] + a[2] * C[6 + j];
+        Jl[6 + j] = 0.0;
+        Jl[9 + j] = e1[0] * C[j] + e1[1] * C[3 + j] + e1[2] * C[6 + j];
+    }
+}
+
 }  // namespace sadvio

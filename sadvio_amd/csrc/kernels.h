@@ -60,6 +60,11 @@ struct DevPtrs {
     const int* sp_list;       // indices (into sparse) of the factors the solve evaluates itself, per window slice
     double* sp_scratch;       // [n_sparse][SPARSE_J]
     const int* dp_ints;
+    const LineDev* lines;     // linexd landmarks: few, kept in the reduced system
+    const LineObsDev* lobs;
+    double* xline;            // [2][n_line_tot][6] line deltas, double-buffered like xp
+    double* line_scratch;     // [n_lobs_tot][LINE_ROW]
+    long long xline_stride;
     long long n_xp, n_xv, n_xl;  // doubles in the (double-buffered) delta arrays, zeroed by k_reset
     int n_tiles;
     int state_stride;
@@ -129,7 +134,7 @@ __device__ __forceinline__ LmState lm_decide(LmState s, const IterAcc& a, const 
             s.n_unsuccess += 1;
         }
     }
-    if (s.iter >= o.max_num_iterations || a.time_up) { s.done = 1; s.termination = 0; }   // iterations / solver time: NO_CONVERGENCE
+    if (s.iter >= o.max_num_iterations) { s.done = 1; s.termination = 0; }   // NO_CONVERGENCE (the solver-time limit is checked by k_solve)
     else if (s.radius <= o.min_radius) { s.done = 1; s.termination = 4; }
     return s;
 }
@@ -1321,6 +1326,35 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
         }
     }
+    // linexd observations: r, J (rows x 12 over [key-frame | line]) from k_line_eval<true>; item = (observation, lower-triangle entry)
+    const int n_lo = W.lobs_end - W.lobs_begin;
+    if (EXTRAS && n_lo > 0) {
+        const int rows = W.factor_type == 0 ? 4 : 2;
+        for (int k = tid; k < n_lo; k += blockDim.x) {
+            const double* sc = P.line_scratch + (long long)(W.lobs_begin + k) * LINE_ROW;
+            if (sc[53] != 0.0) cost_part += sc[52]; else fixed_part += sc[52];
+        }
+        for (int it = tid; it < n_lo * 78; it += blockDim.x) {
+            const int k = it / 78;
+            int e = it - 78 * k, a = 0;
+            while (e >= a + 1) { e -= a + 1; a++; }
+            const int b = e;
+            const LineObsDev& ob = P.lobs[W.lobs_begin + k];
+            const int fi = P.kf_fidx[ob.kf], lc = P.lines[ob.line].col;
+            const int ca = a < 6 ? (fi < 0 ? -1 : fi * W.dpf + a) : (lc < 0 ? -1 : lc + a - 6);
+            const int cb = b < 6 ? (fi < 0 ? -1 : fi * W.dpf + b) : (lc < 0 ? -1 : lc + b - 6);
+            if (ca < 0 || cb < 0) continue;
+            const double* sc = P.line_scratch + (long long)(W.lobs_begin + k) * LINE_ROW;
+            double h = 0.0;
+            for (int q = 0; q < rows; q++) h += sc[q * 12 + a] * sc[q * 12 + b];
+            atomic_add_f64(&A[ca >= cb ? aidx(ca, cb) : aidx(cb, ca)], h);
+            if (a == b) {
+                double g = 0.0;
+                for (int q = 0; q < rows; q++) g += sc[q * 12 + a] * sc[48 + q];
+                atomic_add_f64(&y[ca], g); atomic_add_f64(&gf[ca], g); atomic_add_f64(&hd[ca], h);
+            }
+        }
+    }
     // dense marginalisation prior (K4 / a9): its gradient, diagonal and J^T J were added to gred / gfull / hdiag / S
     // by the wide kernels k_prior_r / k_prior_gh before this kernel; only its cost is picked up here
     if (EXTRAS && W.dp_n_full > 0 && tid == 0) {
@@ -1352,9 +1386,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         acc->lin_cost = cs;
         acc->fixed_cost = fs;
         acc->cand_cost = 0.0; acc->mcc = 0.0; acc->step_norm2 = 0.0; acc->cand_norm2 = 0.0;
-        acc->time_up = (P.o.max_time_ticks > 0.0 && P.t_start && (double)(wall_clock64() - *P.t_start) >= P.o.max_time_ticks) ? 1 : 0;
-        if (g <= P.o.gradient_tolerance) {
-            st.done = 1; st.termination = 3;
+        // FinalizeIterationAndCheckIfMinimizerCanContinue of the previous iteration (of iteration zero at slot 0), in Ceres'
+        // order: solver time, then the gradient tolerance (the iteration limit was applied by lm_decide)
+        const bool time_up = P.o.max_time_ticks > 0.0 && P.t_start && (double)(wall_clock64() - *P.t_start) >= P.o.max_time_ticks;
+        acc->time_up = time_up ? 1 : 0;
+        if (time_up || g <= P.o.gradient_tolerance) {
+            st.done = 1; st.termination = time_up ? 0 : 3;
             st.x_cost = 0.5 * cs;
             if (st.iter == 0) st.initial_cost = st.x_cost;
             *stp = st;
@@ -1444,6 +1481,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
         }
     }
+    if (EXTRAS && W.line_end > W.line_begin) {
+        const double* xlc = P.xline + (long long)cur * P.xline_stride;
+        double* xln = P.xline + (long long)(1 - cur) * P.xline_stride;
+        for (int it = tid; it < (W.line_end - W.line_begin) * 6; it += blockDim.x) {
+            const int l = W.line_begin + it / 6, q = it % 6;
+            const int lc = P.lines[l].col;
+            const double v = xlc[6 * (long long)l + q] + (lc < 0 ? 0.0 : y[lc + q]);
+            xln[6 * (long long)l + q] = v;
+            if (lc >= 0) cn += v * v;
+        }
+    }
     SADVIO_TS(3, 6);
     // priors: model cost change and candidate cost
     double mcc = 0.0, cc = 0.0;
@@ -1514,6 +1562,24 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             mcc += -m * (sc[225 + q] + 0.5 * m);
         }
         // candidate cost of these factors: k_sparse_eval<false>, after this kernel, adds it to acc->cand_cost
+    }
+    if (EXTRAS && W.lobs_end > W.lobs_begin) {
+        const int rows = W.factor_type == 0 ? 4 : 2;
+        for (int it = tid; it < (W.lobs_end - W.lobs_begin) * 4; it += blockDim.x) {
+            const int k = it >> 2, q = it & 3;
+            if (q >= rows) continue;
+            const LineObsDev& ob = P.lobs[W.lobs_begin + k];
+            const int fi = P.kf_fidx[ob.kf], lc = P.lines[ob.line].col;
+            if (fi < 0 && lc < 0) continue;
+            const double* sc = P.line_scratch + (long long)(W.lobs_begin + k) * LINE_ROW;
+            double m = 0.0;
+            for (int a = 0; a < 6; a++) {
+                if (fi >= 0) m += sc[q * 12 + a] * y[fi * W.dpf + a];
+                if (lc >= 0) m += sc[q * 12 + 6 + a] * y[lc + a];
+            }
+            mcc += -m * (sc[48 + q] + 0.5 * m);
+        }
+        // candidate cost of the line factors: k_line_eval<false>, after this kernel
     }
     SADVIO_TS(3, 7);
     sn = wave_sum(sn); cn = wave_sum(cn); mcc = wave_sum(mcc); cc = wave_sum(cc);
@@ -1859,6 +1925,7 @@ __global__ void k_reset(DevPtrs P) {
     for (long long i = t; i < P.n_xp; i += nt) P.xp[i] = 0.0;
     for (long long i = t; i < P.n_xv; i += nt) { P.xv[i] = 0.0; P.xba[i] = 0.0; P.xbg[i] = 0.0; }
     for (long long i = t; i < P.n_xl; i += nt) P.xl[i] = 0.0;
+    for (long long i = t; i < 2 * P.xline_stride; i += nt) P.xline[i] = 0.0;
     unsigned long long* a = (unsigned long long*)P.acc;
     const long long na = (long long)P.n_win * P.state_stride * (long long)(sizeof(IterAcc) / 8);
     for (long long i = t; i < na; i += nt) a[i] = 0ull;
@@ -2072,6 +2139,57 @@ __global__ __launch_bounds__(64) void k_sparse_eval(DevPtrs P, int slot, int own
         if (ln < 15) sc[225 + ln] = rs[ln];
         if (ln == 0) sc[240] = (double)s_in;
     }
+}
+
+// linexd observations, one 64-lane workgroup per observation, same split as k_sparse_eval: LIN -> J (rows x 12:
+// key-frame | line), r, loss-corrected cost and the in-program flag into the scratch row at x; !LIN -> cost at the candidate
+// (k_solve left the candidate key-frame and line deltas in the other buffer). Lines are few (tens per window).
+template <bool LIN>
+__global__ __launch_bounds__(64) void k_line_eval(DevPtrs P, int slot, int own_decide) {
+    const int k = blockIdx.x, ln = threadIdx.x;
+    const LineObsDev& ob = P.lobs[k];
+    const WinDev& W = P.win[ob.win];
+    const long long so = (long long)ob.win * P.state_stride + slot;
+    LmState st;
+    if (LIN && own_decide && slot > 0 && !P.decide_kernel) {
+        __shared__ double s4[4];
+        wave_sum_backsub_partials(P, (slot - 1) & 1, ob.win, W.tile_begin, W.tile_end - W.tile_begin, ln, s4);
+        __syncthreads();
+        IterAcc a = P.acc[so - 1];
+        a.cand_cost += s4[0]; a.mcc += s4[1]; a.step_norm2 += s4[2]; a.cand_norm2 += s4[3];
+        st = lm_decide(P.states[so - 1], a, P.o);
+    } else st = P.states[so];
+    if (st.done || ln != 0) return;
+    const LineDev& L = P.lines[ob.line];
+    const int fi = P.kf_fidx[ob.kf];
+    const bool in_program = fi >= 0 || L.col >= 0;
+    if (!LIN && !in_program) return;
+    const int buf = LIN ? st.cur : 1 - st.cur;
+    const double* dp = P.xp + (long long)buf * P.xp_stride + 6 * (long long)ob.kf;
+    const double* dl = P.xline + (long long)buf * P.xline_stride + 6 * (long long)ob.line;
+    double d6[6], l6[6], r[4] = {0.0, 0.0, 0.0, 0.0}, Jf[24], Jl[24];
+    for (int q = 0; q < 6; q++) { d6[q] = dp[q]; l6[q] = dl[q]; }
+    const bool pixel = W.factor_type == 0;
+    const int rows = pixel ? 4 : 2;
+    const double* Tsf = P.cam_T + 12 * (long long)ob.cam;
+    if (pixel) {
+        double tab[POSE_TAB];
+        pose_table_entry(P.kf_T0 + 12 * (long long)ob.kf, d6, tab);
+        line_pixel_factor(tab, P.cam_K + 4 * (long long)ob.cam, Tsf, L.T, L.model, ob.meas, l6, r, LIN ? Jf : nullptr, Jl);
+    } else {
+        line_angular_factor(P.kf_T0 + 12 * (long long)ob.kf, Tsf, L.T, ob.meas, d6, l6, r, LIN ? Jf : nullptr, Jl);
+    }
+    double ssq = 0.0, sc = 1.0;
+    for (int q = 0; q < rows; q++) ssq += r[q] * r[q];
+    const double rho = huber_rho(P.o.huber_a, ssq, sc);   // the line blocks carry the caller's loss function (…Analytic.cpp:303-306)
+    if (!LIN) { atomic_add_f64(&P.acc[so].cand_cost, rho); return; }
+    double* row = P.line_scratch + (long long)k * LINE_ROW;
+    for (int i = 0; i < rows; i++) {
+        for (int q = 0; q < 6; q++) { row[i * 12 + q] = sc * Jf[i * 6 + q]; row[i * 12 + 6 + q] = sc * Jl[i * 6 + q]; }
+        row[48 + i] = sc * r[i];
+    }
+    row[52] = rho;
+    row[53] = in_program ? 1.0 : 0.0;
 }
 
 // Parity probe: per-observation residual / Jacobians at deltas held in buffer 0.

@@ -18,6 +18,7 @@ PAIRS = {
     "sadvio_flat_window": (P.FlatWindowC, O.flat_window),
     "sadvio_imu_factor": (P.ImuFactorC, O.imu_factor),
     "sadvio_pose_prior": (P.PosePriorC, O.pose_prior),
+    "sadvio_line_set": (P.LineSetC, O.line_set),
     "sadvio_sparse_prior": (P.SparsePriorC, O.sparse_prior),
     "sadvio_solve_options": (P.SolveOptions, O.solve_options),
     "sadvio_solve_summary": (P.SolveSummary, O.solve_summary),
