@@ -14,7 +14,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("k_build", "k_solve", "k_backsub", "k_init_tables", "k_reset", "k_final", "k_linearize_probe"):
+    for k in ("k_build", "k_solve", "k_backsub", "k_init_tables", "k_reset", "k_final", "k_decide", "k_linearize_probe"):
         if k in name:
             return k
     return None
@@ -39,6 +39,11 @@ def main(out):
                     acc[k][1] += 1
         for k, (v, n) in acc.items():
             res["kernels"].setdefault(k, {})[tag + "_bytes_per_launch"] = scale * 1024.0 * v / max(n, 1)
+        if acc:   # per-kernel table of the raw counter (the per-launch rows are not kept)
+            with open(os.path.join(out, "pmc_%s_per_kernel.csv" % tag), "w") as fo:
+                fo.write("kernel,launches,%s_SIZE_sum,%s_SIZE_avg_per_launch\n" % (tag.upper(), tag.upper()))
+                for k, (v, n) in sorted(acc.items()):
+                    fo.write("%s,%d,%.1f,%.3f\n" % (k, n, v, v / max(n, 1)))
     for k, d in res["kernels"].items():
         if "fetch_bytes_per_launch" in d and "write_bytes_per_launch" in d:
             d["hbm_traffic_bytes_per_launch"] = d["fetch_bytes_per_launch"] + d["write_bytes_per_launch"]
