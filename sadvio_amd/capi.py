@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsadvio_ba.so")
+LIB_PATH = os.environ.get("SADVIO_BA_LIB") or os.path.join(_HERE, "csrc", "libsadvio_ba.so")   # override: A/B measurement builds
 
 SADVIO_OK = 0
 E_INVALID_ARG, E_NOT_USABLE, E_HIP, E_RCCL, E_NO_DEVICE, E_STATE, E_REFUSED = -1, -2, -3, -4, -5, -6, -7

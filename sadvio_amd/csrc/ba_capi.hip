@@ -855,6 +855,15 @@ static int build_layout(sadvio_ba_handle* h) {
         // tile's largest observation count); a workgroup of BUILD_WAVES waves holds BUILD_WAVES * 64 / G
         // landmarks per round. A tile is cut when its key-frame list would exceed the LDS tile capacity.
         if (F.n_cam > MAX_WIN_CAM) { h->err = "set_windows: more than 8 distinct cameras per window"; return SADVIO_E_INVALID_ARG; }
+        // rounds per tile: one for a single window (most workgroups = lowest latency); a large batch gets fewer, larger tiles
+        // (~2048 = 4 per resident workgroup slot) so that table staging, merge and flush are paid once per several rounds
+        int tile_rounds = 1;
+        {
+            long long l_tot = 0;
+            for (int ww = 0; ww < n_windows; ww++) l_tot += views[ww].n_lmk;
+            tile_rounds = (int)std::min<long long>(16, std::max<long long>(1, (l_tot + 32LL * 2048 - 1) / (32LL * 2048)));
+            if (const char* e = getenv("SADVIO_TILE_ROUNDS")) tile_rounds = std::max(1, atoi(e));
+        }
         d.tile_begin = (int)h->tiles.size();
         {
             int l = 0;
@@ -873,7 +882,7 @@ static int build_layout(sadvio_ba_handle* h) {
                     if (k > MAX_LMK_OBS) { h->err = "set_windows: a landmark has more than 64 observations"; return SADVIO_E_INVALID_ARG; }
                     int G = t.G;
                     while (G < k) G <<= 1;
-                    const int cap = BUILD_WAVES * (64 / G);  // landmarks per tile (one round per wave)
+                    const int cap = tile_rounds * BUILD_WAVES * (64 / G);  // landmarks per tile (tile_rounds rounds per wave)
                     if (l - l_begin + 1 > cap && l > l_begin) break;
                     // key-frames this landmark would add
                     add.clear();
@@ -1838,7 +1847,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     const int mtk = h->max_tile_kf;
     const size_t nt = 6 * (size_t)h->max_tile_free;
     int Rp = 16 * ((6 * h->max_gemm_free + 15) / 16);                          // padded rows of the Y / E strips
-    int strip_doubles = std::max(STAGE_VALS * 64, 2 * Rp * (32 + 2));          // per wave (also holds the wave's tile copy)
+    int strip_doubles = std::max(STAGE_VALS * 64, 2 * Rp * (32 + 2));          // per wave: Y | E strips, later the wave's copy of the tile
     size_t lds_build = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)BUILD_WAVES * strip_doubles + nt * (nt + 1) / 2 + 3 * nt +
                                                                    0) + 16;
     if (lds_build > 160 * 1024 && h->max_gemm_free > 0) {

@@ -455,6 +455,11 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
     double* wstage = stage + wv * strip_doubles;
     const bool gemm_mode = T.lds_mode == 2;
     double cost_part = 0.0, fixed_part = 0.0, gmax_part = 0.0;
+    // MFMA path: a tile may hold several rounds of landmarks per wave (batched windows: fewer, larger tiles amortise the
+    // table staging, the merge and the flush). The Y E^T products accumulate in registers across the rounds; the
+    // block-diagonal / gradient sums go to the tile with ds_add_f64 (one lane per entry and wave after the DPP sums).
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    d4 accs[3] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};  // <= 2 x 2 lower tile pairs (Nt <= 32)
     for (int base = wv * lpw; base < nl; base += BUILD_WAVES * lpw) {
         const int lm = base + grp;
         const bool lmk_valid = lm < nl;
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
             // (3) the block-diagonal part and the gradients are summed across the wave's 8 landmarks with DPP /
             //     v_permlane swaps when all of them see the same key-frames in the same lanes (the common case for
             //     landmarks created together), else with ds_add_f64.
-            const int Kw = 4 * lpw, KS = Kw + 2;
+            constexpr int Kw = 32, KS = Kw + 2;   // G == 8 on this path: 8 landmarks per wave and round
             double* Yb = wstage;
             double* Eb = wstage + Rp * KS;
             {
@@ -548,16 +553,17 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
             wave_lds_fence();
     SADVIO_TS(3, 38);
             {
-                typedef double d4 __attribute__((ext_vector_type(4)));
                 const int lr = ln & 15, lk = ln >> 4;
                 const int nt16 = (Nt + 15) >> 4;
-                d4 accs[3];  // <= 2 x 2 lower tile pairs (Nt <= 32); results stay in registers until every
-                             // operand has been read, then overwrite this wave's strip (waveS aliases it)
 #pragma unroll
                 for (int pp = 0; pp < 3; pp++) {
                     const int tr = pp < 1 ? 0 : 1, tc = pp - tr;
-                    accs[pp] = (d4){0.0, 0.0, 0.0, 0.0};
                     if (tr < nt16) {
+#ifdef SADVIO_VAR_LOCALACC
+                        d4 loc = (d4){0.0, 0.0, 0.0, 0.0};
+#else
+                        d4& loc = accs[pp];
+#endif
                         double av[8], bv[8];
 #pragma unroll
                         for (int kk = 0; kk < 8; kk++) {  // all operand loads first, then the MFMA chain
@@ -567,23 +573,10 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
                         }
 #pragma unroll
                         for (int kk = 0; kk < 8; kk++)
-                            if (4 * kk < Kw) accs[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], accs[pp], 0, 0, 0);
-                    }
-                }
-                wave_lds_fence();
-                double* wS = wstage;  // per-wave copy of the tile's lower triangle
-                for (int i = ln; i < tri_n + MAX_GEMM_FREE_KF * 33; i += 64) wS[i] = 0.0;  // tile copy + D / gradient block
-                wave_lds_fence();
-#pragma unroll
-                for (int pp = 0; pp < 3; pp++) {
-                    const int tr = pp < 1 ? 0 : 1, tc = pp - tr;
-                    if (tr < nt16) {
-                        const int col = 16 * tc + lr;
-#pragma unroll
-                        for (int rg = 0; rg < 4; rg++) {
-                            const int row = 16 * tr + lk + 4 * rg;
-                            if (row < Nt && col <= row) wS[tri(row, col)] = -accs[pp][rg];
-                        }
+                            if (4 * kk < Kw) loc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], loc, 0, 0, 0);
+#ifdef SADVIO_VAR_LOCALACC
+                        accs[pp] += loc;
+#endif
                     }
                 }
             }
@@ -592,8 +585,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
                 const int rowu = vrow ? L.row : -1;
                 int mism = (dpp_i32<0x128>(rowu) != rowu) | (xor16_other(rowu) != rowu) | (xor32_other(rowu) != rowu);
                 const bool uniform = (G == 8) && (__ballot(mism) == 0ull);
-                double* wD = wstage + tri_n + (head ? myrow / 6 : 0) * 33;  // after the wave's tile copy, inside its strip
-                int e = 0;
+                const bool adder = head && (!uniform || grp == 0);   // uniform: the wave's 8 landmarks were summed with DPP
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
                     const double j0 = vrow ? L.Jp[i] : 0.0, j1 = vrow ? L.Jp[6 + i] : 0.0;
@@ -603,9 +595,8 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
                         if (!vrow) v = 0.0;
                         const double vn = dpp_f64<0x101>(v);
                         if (has_follower) v += vn;
-                        if (uniform) { v = across_groups8_sum(v); if (head && grp == 0) wD[e] = v; }
-                        else if (head) { atomic_add_f64(&Stile[tri(myrow + i, myrow + j)], v); if (i == j) atomic_add_f64(&hdT[myrow + i], v); }
-                        e++;
+                        if (uniform) v = across_groups8_sum(v);
+                        if (adder) { atomic_add_f64(&Stile[tri(myrow + i, myrow + j)], v); if (i == j) atomic_add_f64(&hdT[myrow + i], v); }
                     }
                 }
 #pragma unroll
@@ -614,10 +605,8 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
                     double gr = j0 * rt0 + j1 * rt1, gf = j0 * L.r[0] + j1 * L.r[1];
                     const double grn = dpp_f64<0x101>(gr), gfn = dpp_f64<0x101>(gf);
                     if (has_follower) { gr += grn; gf += gfn; }
-                    if (uniform) {
-                        gr = across_groups8_sum(gr); gf = across_groups8_sum(gf);
-                        if (head && grp == 0) { wD[21 + i] = gr; wD[27 + i] = gf; }
-                    } else if (head) { atomic_add_f64(&gT[myrow + i], gr); atomic_add_f64(&gfT[myrow + i], gf); }
+                    if (uniform) { gr = across_groups8_sum(gr); gf = across_groups8_sum(gf); }
+                    if (adder) { atomic_add_f64(&gT[myrow + i], gr); atomic_add_f64(&gfT[myrow + i], gf); }
                 }
             }
     SADVIO_TS(3, 39);
@@ -684,6 +673,23 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
         wave_lds_fence();  // the strip is reused by the next round
     }
         }
+    if (gemm_mode && wv * lpw < nl) {
+        // the wave's Y E^T sum goes to the tile (ds_add_f64: the 4 waves add to the same entries)
+        const int lr = ln & 15, lk = ln >> 4;
+        const int nt16 = (Nt + 15) >> 4;
+#pragma unroll
+        for (int pp = 0; pp < 3; pp++) {
+            const int tr = pp < 1 ? 0 : 1, tc = pp - tr;
+            if (tr < nt16) {
+                const int col = 16 * tc + lr;
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) {
+                    const int row = 16 * tr + lk + 4 * rg;
+                    if (row < Nt && col <= row) atomic_add_f64(&Stile[tri(row, col)], -accs[pp][rg]);
+                }
+            }
+        }
+    }
     SADVIO_TS(3, 40);
     // cost / gradient-max: per-tile partial, plain store (no same-address atomics across the chip)
     const double c = wave_sum(cost_part), f = wave_sum(fixed_part), gm = wave_max(gmax_part);
@@ -696,30 +702,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
         ta->lin_cost = cs; ta->fixed_cost = fs; ta->gmax = gs;
     }
     SADVIO_TS(3, 41);
-    if (T.lds_mode == 2) {
-        // merge the per-wave results into the tile (plain adds: one thread per element)
-        for (int e = tid; e < tri_n; e += blockDim.x) {
-            double v = 0.0;
-            for (int w = 0; w < BUILD_WAVES; w++)
-                if (w * lpw < nl) v += stage[w * strip_doubles + e];  // waves without landmarks never wrote their strip
-            Stile[e] += v;
-        }
-        __syncthreads();  // the plain read-modify-writes above must land before the adds below touch the diagonal blocks
-        for (int it = tid; it < T.n_free * 33; it += blockDim.x) {
-            const int sl = it / 33, e = it - 33 * sl;
-            double v = 0.0;
-            for (int w = 0; w < BUILD_WAVES; w++)
-                if (w * lpw < nl) v += stage[w * strip_doubles + tri_n + sl * 33 + e];
-            if (e < 21) {
-                int i = 0, r = e;
-                while (r >= i + 1) { r -= i + 1; i++; }
-                atomic_add_f64(&Stile[tri(6 * sl + i, 6 * sl + r)], v);  // LDS, distinct addresses per thread, few
-                if (i == r) atomic_add_f64(&hdT[6 * sl + i], v);
-            } else if (e < 27) atomic_add_f64(&gT[6 * sl + e - 21], v);
-            else atomic_add_f64(&gfT[6 * sl + e - 27], v);
-        }
-        __syncthreads();
-    }
+    // the tile is complete: every wave's ds_add_f64 was issued before the barrier above
     if (lds_mode) {
         // flush non-zeros; in lds_mode rowTab rows are 6*rank with the list sorted by global index, so the
         // local lower triangle maps onto the global lower triangle. One wave per row, lanes along the row.
