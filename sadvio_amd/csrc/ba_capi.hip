@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "dense_chol.h"
 #include "marg_kernels.h"
+#include "lm_kernels.h"
 #include "viinit_kernels.h"
 
 using namespace sadvio;
@@ -242,7 +243,14 @@ struct sadvio_ba_handle {
     DevBuf<double> d_lmk_p, d_xl, d_s_lmk;
     DevBuf<unsigned char> d_lmk_const;
     DevBuf<int> d_lmk_ob, d_lmk_oe, d_obs_kf, d_obs_cam, d_tile_kf, d_tile_row;
-    DevBuf<unsigned char> d_obs_slot;
+    DevBuf<unsigned char> d_obs_slot, d_obs_lslot;
+    DevBuf<int> d_chunk_ob, d_chunk_lm;   // chunk tables of the throughput kernels (lm_kernels.h)
+    DevBuf<int> d_kf_obs, d_obs_lmk;      // k_diag: observations sorted by key-frame (free key-frames only) | landmark of each observation
+    DevBuf<DiagSeg> d_diag_segs;
+    int n_diag_segs = 0;
+    DevBuf<double> d_lm_elim;
+    bool lm_ok = false;                   // every tile is on the MFMA path and chunked: k_elim / k_build_obs / k_backsub_lm may run
+    long long lm_landmarks = 0;
     DevBuf<double> d_ptab;
     int max_tile_kf = 1, max_tile_free = 0, max_gemm_free = 0;
     DevBuf<double> d_obs_meas;
@@ -342,6 +350,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.lmk_red = h->d_lmk_red.p; P.kept_obs = h->d_kept_obs.p; P.n_kept = h->n_kept;
     P.dp_data = h->d_dp_data.p; P.dp_ints = h->d_dp_ints.p;
     P.sparse = h->d_sparse.p; P.sp_scratch = h->d_sp_scratch.p; P.sp_list = h->d_sp_list.p;
+    P.chunk_ob = h->d_chunk_ob.p; P.chunk_lm = h->d_chunk_lm.p; P.obs_lslot = h->d_obs_lslot.p; P.lm_elim = h->d_lm_elim.p;
     P.lines = h->d_lines.p; P.lobs = h->d_lobs.p; P.xline = h->d_xline.p; P.line_scratch = h->d_line_scratch.p;
     P.xline_stride = 6LL * h->n_line_tot;
     P.n_xp = (long long)h->d_xp.n; P.n_xv = (long long)h->d_xv.n; P.n_xl = (long long)h->d_xl.n;
@@ -939,6 +948,59 @@ static int build_layout(sadvio_ba_handle* h) {
         for (int ti = d.tile_begin; ti < d.tile_end; ti++) { h->tiles[ti].win_tile0 = d.tile_begin; h->tiles[ti].win_ntiles = d.tile_end - d.tile_begin; }
     }
     lap("concat+tiles");
+    // chunk tables of the throughput kernels: a tile's consecutive landmarks in chunks of <= LM_CHUNK landmarks and <= 64
+    // observations; obs_lslot = index of the observation's landmark inside its chunk
+    std::vector<int> chunk_ob, chunk_lm;   // chunk starts + one sentinel (landmarks and observations are globally consecutive)
+    std::vector<unsigned char> obs_lslot(std::max(obs_b, 1), 0);
+    h->lm_ok = !h->tiles.empty();
+    h->lm_landmarks = 0;
+    for (auto& t : h->tiles) {
+        t.chunk0 = (int)chunk_lm.size();
+        if (t.lds_mode != 2) h->lm_ok = false;
+        int l = t.lmk0;
+        while (l < t.lmk1) {
+            chunk_lm.push_back(l); chunk_ob.push_back(lmk_ob[l]);
+            int nl = 0, no = 0;
+            while (l < t.lmk1 && nl < LM_CHUNK && no + (lmk_oe[l] - lmk_ob[l]) <= 64) {
+                for (int o = lmk_ob[l]; o < lmk_oe[l]; o++) obs_lslot[o] = (unsigned char)nl;
+                no += lmk_oe[l] - lmk_ob[l]; nl++; l++;
+            }
+            if (nl == 0) { h->lm_ok = false; l++; }   // a landmark with more than 64 observations (never on the MFMA path)
+        }
+        t.chunk1 = (int)chunk_lm.size();
+        h->lm_landmarks += t.lmk1 - t.lmk0;
+    }
+    chunk_lm.push_back(lmk_b); chunk_ob.push_back(obs_b);
+    {
+        // k_diag: per window, its observations sorted by key-frame (free ones), cut into segments of DIAG_SEG
+        std::vector<int> obs_lmk(std::max(obs_b, 1), 0), kf_obs;
+        std::vector<DiagSeg> segs;
+        for (int l = 0; l < lmk_b; l++) for (int o = lmk_ob[l]; o < lmk_oe[l]; o++) obs_lmk[o] = l;
+        for (int w = 0; w < n_windows; w++) {
+            const WinDev& d = h->wins[w].d;
+            std::vector<int> cnt(d.n_kf + 1, 0);
+            for (int o = d.obs_base; o < d.obs_base + d.n_obs; o++) if (obs_cam[o] >= 0) cnt[obs_kf[o] - d.kf_base + 1]++;
+            for (int k = 0; k < d.n_kf; k++) cnt[k + 1] += cnt[k];
+            const int base = (int)kf_obs.size();
+            kf_obs.resize(base + cnt[d.n_kf]);
+            std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+            for (int o = d.obs_base; o < d.obs_base + d.n_obs; o++) if (obs_cam[o] >= 0) kf_obs[base + pos[obs_kf[o] - d.kf_base]++] = o;
+            for (int k = 0; k < d.n_kf; k++) {
+                if (kf_fidx[d.kf_base + k] < 0) continue;
+                for (int b = cnt[k]; b < cnt[k + 1]; b += DIAG_SEG) segs.push_back({w, d.kf_base + k, base + b, base + std::min(b + DIAG_SEG, cnt[k + 1])});
+            }
+        }
+        h->n_diag_segs = (int)segs.size();
+        HIP_TRY(h->d_obs_lmk.alloc(obs_lmk.size())); HIP_TRY(h->d_kf_obs.alloc(std::max<size_t>(kf_obs.size(), 1))); HIP_TRY(h->d_diag_segs.alloc(std::max<size_t>(segs.size(), 1)));
+        h->up.add(h->d_obs_lmk.p, obs_lmk.data(), obs_lmk.size() * sizeof(int));
+        h->up.add(h->d_kf_obs.p, kf_obs.data(), kf_obs.size() * sizeof(int));
+        h->up.add(h->d_diag_segs.p, segs.data(), segs.size() * sizeof(DiagSeg));
+    }
+    HIP_TRY(h->d_chunk_ob.alloc(chunk_ob.size())); HIP_TRY(h->d_chunk_lm.alloc(chunk_lm.size())); HIP_TRY(h->d_obs_lslot.alloc(obs_lslot.size()));
+    HIP_TRY(h->d_lm_elim.alloc((size_t)LM_ELIM * std::max(lmk_b, 1)));
+    h->up.add(h->d_chunk_ob.p, chunk_ob.data(), chunk_ob.size() * sizeof(int));
+    h->up.add(h->d_chunk_lm.p, chunk_lm.data(), chunk_lm.size() * sizeof(int));
+    h->up.add(h->d_obs_lslot.p, obs_lslot.data(), obs_lslot.size());
     if (getenv("SADVIO_DEBUG")) {
         int hist[32] = {0}, modes[3] = {0};
         for (auto& t : h->tiles) { hist[std::min(t.n_free, 31)]++; modes[t.lds_mode]++; }
@@ -1873,6 +1935,20 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     auto kb = pix ? (rare ? k_build<0, true> : k_build<0, false>) : (rare ? k_build<1, true> : k_build<1, false>);
     auto kk = pix ? (rare ? k_backsub<0, true> : k_backsub<0, false>) : (rare ? k_backsub<1, true> : k_backsub<1, false>);
     auto kbk = h->factor_type == SADVIO_FACTOR_PIXEL ? k_build_kept<0> : k_build_kept<1>;
+    // large plain batches: the throughput kernels of lm_kernels.h (SADVIO_LM=1 / 0 forces / forbids them, for tests and A/B runs)
+    bool use_lm = h->lm_ok && !rare && !h->coll_fn && h->world == 1 && h->lm_landmarks >= 65536;
+    if (const char* e = getenv("SADVIO_LM")) use_lm = h->lm_ok && !rare && !h->coll_fn && h->world == 1 && atoi(e) != 0;
+    auto ke = pix ? k_elim<0> : k_elim<1>;
+    auto kbo = pix ? k_build_obs<0> : k_build_obs<1>;
+    auto kkl = pix ? k_backsub_lm<0> : k_backsub_lm<1>;
+    auto kdg = pix ? k_diag<0> : k_diag<1>;
+    const size_t lds_elim = tile_tables_bytes(mtk) + 16;
+    const size_t lds_bobs = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)BUILD_WAVES * Rp * LM_KS + nt * (nt + 1) / 2 + nt) + 16;
+    if (use_lm) {
+        P.decide_kernel = 1;   // the kernels read the decided state of their slot
+        HIP_TRY(hipFuncSetAttribute((const void*)kbo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bobs));
+        HIP_TRY(hipFuncSetAttribute((const void*)kkl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back));
+    }
     HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
     HIP_TRY(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back));
     bool extras = false;  // any pose-only factor family beyond PosePriordx in the batch?
@@ -1955,6 +2031,11 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 if (n_lo) hipLaunchKernelGGL(k_line_eval<true>, dim3(n_lo), dim3(64), 0, h->side, P, s, 1);
                 (void)hipEventRecord(h->ev_lin, h->side);
             }
+            if (use_lm) {
+                { ScopedTimer t(h, "k_elim"); hipLaunchKernelGGL(ke, dim3(n_tiles), dim3(BUILD_THREADS), lds_elim, h->stream, P, s, mtk); }
+                if (h->n_diag_segs) { ScopedTimer t(h, "k_diag"); hipLaunchKernelGGL(kdg, dim3(h->n_diag_segs), dim3(BUILD_THREADS), 0, h->stream, P, h->d_diag_segs.p, h->d_kf_obs.p, h->d_obs_lmk.p, s); }
+                { ScopedTimer t(h, "k_build_obs"); hipLaunchKernelGGL(kbo, dim3(n_tiles), dim3(BUILD_THREADS), lds_bobs, h->stream, P, s, mtk, Rp); }
+            } else
             { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
             if (h->n_kept) { ScopedTimer t(h, "k_build_kept"); hipLaunchKernelGGL(kbk, dim3((h->n_kept + 127) / 128), dim3(128), 0, h->stream, P, s); }
             if (dp_max_nf > 0) {
@@ -2128,6 +2209,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 if (n_lo) { ScopedTimer t(h, "k_line_cost"); hipLaunchKernelGGL(k_line_eval<false>, dim3(n_lo), dim3(64), 0, h->stream, P, s, 0); }
             }
             if (dp_max_nf > 0) { ScopedTimer t(h, "k_prior_m"); hipLaunchKernelGGL(k_prior_m, dim3((dp_max_nf + 3) / 4, n_win), dim3(256), 0, h->stream, P, s); }
+            if (use_lm) { ScopedTimer t(h, "k_backsub_lm"); hipLaunchKernelGGL(kkl, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
+            else
             { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
             if (fork) (void)hipStreamWaitEvent(h->stream, h->ev_cost, 0);
             if (h->coll_fn) {
@@ -2143,12 +2226,12 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         // the whole <= 20-iteration solve is one graph launch; the key covers every kernel argument
         std::vector<int> lay;  // layout-dependent launch parameters of the out-of-LDS windows
         for (int w = 0; w < n_win; w++) { lay.push_back(h->wins[w].d.Np); lay.push_back(h->wins[w].d.ld); lay.push_back(big_bw[w]); }
-        lay.push_back(h->n_kept); lay.push_back(h->n_lobs_tot); lay.push_back(h->n_line_tot); lay.push_back(h->n_big); lay.push_back(dp_max_nf); lay.push_back(dp_max_n);
+        lay.push_back(h->n_kept); lay.push_back(h->n_diag_segs); lay.push_back(h->n_lobs_tot); lay.push_back(h->n_line_tot); lay.push_back(h->n_big); lay.push_back(dp_max_nf); lay.push_back(dp_max_n);
         std::vector<unsigned char> key(sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t) + lay.size() * sizeof(int));
         unsigned char* kp = key.data();
         memcpy(kp + sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t), lay.data(), lay.size() * sizeof(int));
         memcpy(kp, &P, sizeof(DevPtrs)); kp += sizeof(DevPtrs);
-        const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type + 2 * (int)extras + 4 * (int)rare};  // P (incl. decide_kernel) is part of the key
+        const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type + 2 * (int)extras + 4 * (int)rare + 8 * (int)use_lm};  // P (incl. decide_kernel) is part of the key
         memcpy(kp, ints, sizeof(ints)); kp += sizeof(ints);
         const size_t szs[3] = {lds_build, lds_back, lds_solve};
         memcpy(kp, szs, sizeof(szs));

@@ -60,6 +60,10 @@ struct DevPtrs {
     const int* sp_list;       // indices (into sparse) of the factors the solve evaluates itself, per window slice
     double* sp_scratch;       // [n_sparse][SPARSE_J]
     const int* dp_ints;
+    const int* chunk_ob;      // [n_chunks + 1] first observation of each chunk (lm_kernels.h)
+    const int* chunk_lm;      // [n_chunks + 1] first landmark of each chunk
+    const unsigned char* obs_lslot;  // [n_obs_tot] index of the observation's landmark inside its chunk
+    double* lm_elim;          // [n_lmk_tot][9] per-landmark elimination record of k_elim
     const LineDev* lines;     // linexd landmarks: few, kept in the reduced system
     const LineObsDev* lobs;
     double* xline;            // [2][n_line_tot][6] line deltas, double-buffered like xp

@@ -1,3 +1,3 @@
-for v in base v3 v4; do for n in 64 1; do echo "== $v $n"; SADVIO_BA_LIB=$GRAFT_REPO_ROOT/sadvio_amd/csrc/_variants/$v.so python scripts/gpu_time.py $n 2>&1 | grep -v "RCCL\|NCCL" | head -2; done; done
-for r in 1 2 4 16; do echo "== v3 rounds $r"; SADVIO_TILE_ROUNDS=$r SADVIO_BA_LIB=$GRAFT_REPO_ROOT/sadvio_amd/csrc/_variants/v3.so python scripts/gpu_time.py 64 2>&1 | grep -v "RCCL\|NCCL" | head -2; done
-SADVIO_TILE_ROUNDS=4 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edges.py tests/test_gpu_vio.py tests/test_gpu_prior.py tests/test_gpu_sparse.py tests/test_gpu_fuzz.py -m gpu -q -x 2>&1 | grep -v "RCCL\|NCCL" | tail -3
+SADVIO_LM=1 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edges.py tests/test_gpu_fuzz.py tests/test_gpu_replay.py -m gpu -q -x 2>&1 | grep -v "RCCL\|NCCL" | tail -25
+echo "== LM"; timeout 300 python scripts/gpu_time.py 64 2>&1 | grep -v "RCCL\|NCCL" | head -2
+for r in 8 16; do echo "== LM rounds $r"; SADVIO_TILE_ROUNDS=$r timeout 300 python scripts/gpu_time.py 64 2>&1 | grep -v "RCCL\|NCCL" | head -2; done
