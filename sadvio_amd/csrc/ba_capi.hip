@@ -245,7 +245,8 @@ struct sadvio_ba_handle {
     DevBuf<int> d_lmk_ob, d_lmk_oe, d_obs_kf, d_obs_cam, d_tile_kf, d_tile_row;
     DevBuf<unsigned char> d_obs_slot, d_obs_lslot;
     DevBuf<int> d_chunk_ob, d_chunk_lm;   // chunk tables of the throughput kernels (lm_kernels.h)
-    DevBuf<int> d_kf_obs, d_obs_lmk;      // k_diag: observations sorted by key-frame (free key-frames only) | landmark of each observation
+    DevBuf<int> d_kf_lmk, d_kf_cam;       // k_diag: landmark / camera of the observations sorted by key-frame (free key-frames only)
+    DevBuf<double> d_kf_meas;             //         and their measurements, in the same order
     DevBuf<DiagSeg> d_diag_segs;
     int n_diag_segs = 0;
     DevBuf<double> d_lm_elim;
@@ -276,7 +277,8 @@ struct sadvio_ba_handle {
     // profiling
     std::vector<KernelClass> kclasses;
     hipStream_t side = nullptr;            // IMU factor evaluation runs here, concurrently with k_build / k_backsub
-    hipEvent_t ev_fork = nullptr, ev_lin = nullptr, ev_solved = nullptr, ev_cost = nullptr;
+    hipStream_t side2 = nullptr;           // k_diag runs here, concurrently with k_elim / k_build_obs
+    hipEvent_t ev_fork = nullptr, ev_lin = nullptr, ev_solved = nullptr, ev_cost = nullptr, ev_diag0 = nullptr, ev_diag1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<std::pair<int, int>> ev_used;  // (class, pool index)
     size_t ev_next = 0;
@@ -629,6 +631,9 @@ int sadvio_ba_create(const sadvio_ba_config* cfg, sadvio_ba_handle** out) {
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) h->side = nullptr;   // optional: without it everything is serial
     for (hipEvent_t* e : {&h->ev_fork, &h->ev_lin, &h->ev_solved, &h->ev_cost})
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { *e = nullptr; if (h->side) { (void)hipStreamDestroy(h->side); h->side = nullptr; } }
+    if (hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) != hipSuccess) h->side2 = nullptr;
+    for (hipEvent_t* e : {&h->ev_diag0, &h->ev_diag1})
+        if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { *e = nullptr; if (h->side2) { (void)hipStreamDestroy(h->side2); h->side2 = nullptr; } }
     *out = h;
     return SADVIO_OK;
 }
@@ -641,7 +646,8 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     if (h->rccl.comm) (void)h->rccl.destroy(h->rccl.comm);
     if (h->h_final) (void)hipHostFree(h->h_final);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
-    for (hipEvent_t e : {h->ev_fork, h->ev_lin, h->ev_solved, h->ev_cost}) if (e) (void)hipEventDestroy(e);
+    if (h->side2) { (void)hipStreamSynchronize(h->side2); (void)hipStreamDestroy(h->side2); }
+    for (hipEvent_t e : {h->ev_fork, h->ev_lin, h->ev_solved, h->ev_cost, h->ev_diag0, h->ev_diag1}) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     h->d_win.release(); h->d_tiles.release(); h->d_kf_T0.release(); h->d_xp.release(); h->d_xv.release();
@@ -991,9 +997,19 @@ static int build_layout(sadvio_ba_handle* h) {
             }
         }
         h->n_diag_segs = (int)segs.size();
-        HIP_TRY(h->d_obs_lmk.alloc(obs_lmk.size())); HIP_TRY(h->d_kf_obs.alloc(std::max<size_t>(kf_obs.size(), 1))); HIP_TRY(h->d_diag_segs.alloc(std::max<size_t>(segs.size(), 1)));
-        h->up.add(h->d_obs_lmk.p, obs_lmk.data(), obs_lmk.size() * sizeof(int));
-        h->up.add(h->d_kf_obs.p, kf_obs.data(), kf_obs.size() * sizeof(int));
+        const int msz = h->factor_type == SADVIO_FACTOR_PIXEL ? 2 : 3;
+        std::vector<int> kf_lmk(std::max<size_t>(kf_obs.size(), 1)), kf_cam(std::max<size_t>(kf_obs.size(), 1));
+        std::vector<double> kf_meas(std::max<size_t>(kf_obs.size(), 1) * msz + 1);
+        for (size_t i = 0; i < kf_obs.size(); i++) {
+            const int o = kf_obs[i];
+            kf_lmk[i] = obs_lmk[o]; kf_cam[i] = obs_cam[o];
+            memcpy(&kf_meas[i * msz], &obs_meas[(size_t)msz * o], sizeof(double) * msz);
+        }
+        HIP_TRY(h->d_kf_lmk.alloc(kf_lmk.size())); HIP_TRY(h->d_kf_cam.alloc(kf_cam.size())); HIP_TRY(h->d_kf_meas.alloc(kf_meas.size()));
+        HIP_TRY(h->d_diag_segs.alloc(std::max<size_t>(segs.size(), 1)));
+        h->up.add(h->d_kf_lmk.p, kf_lmk.data(), kf_lmk.size() * sizeof(int));
+        h->up.add(h->d_kf_cam.p, kf_cam.data(), kf_cam.size() * sizeof(int));
+        h->up.add(h->d_kf_meas.p, kf_meas.data(), kf_meas.size() * sizeof(double));
         h->up.add(h->d_diag_segs.p, segs.data(), segs.size() * sizeof(DiagSeg));
     }
     HIP_TRY(h->d_chunk_ob.alloc(chunk_ob.size())); HIP_TRY(h->d_chunk_lm.alloc(chunk_lm.size())); HIP_TRY(h->d_obs_lslot.alloc(obs_lslot.size()));
@@ -2032,9 +2048,17 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 (void)hipEventRecord(h->ev_lin, h->side);
             }
             if (use_lm) {
+                // k_diag does not depend on the elimination: it runs on the second stream next to k_elim / k_build_obs
+                const bool par = h->n_diag_segs && h->side2 && !h->cfg.profile_kernels;
+                if (par) {
+                    (void)hipEventRecord(h->ev_diag0, h->stream);
+                    (void)hipStreamWaitEvent(h->side2, h->ev_diag0, 0);
+                    hipLaunchKernelGGL(kdg, dim3(h->n_diag_segs), dim3(BUILD_THREADS), 0, h->side2, P, h->d_diag_segs.p, h->d_kf_lmk.p, h->d_kf_cam.p, h->d_kf_meas.p, s);
+                    (void)hipEventRecord(h->ev_diag1, h->side2);
+                } else if (h->n_diag_segs) { ScopedTimer t(h, "k_diag"); hipLaunchKernelGGL(kdg, dim3(h->n_diag_segs), dim3(BUILD_THREADS), 0, h->stream, P, h->d_diag_segs.p, h->d_kf_lmk.p, h->d_kf_cam.p, h->d_kf_meas.p, s); }
                 { ScopedTimer t(h, "k_elim"); hipLaunchKernelGGL(ke, dim3(n_tiles), dim3(BUILD_THREADS), lds_elim, h->stream, P, s, mtk); }
-                if (h->n_diag_segs) { ScopedTimer t(h, "k_diag"); hipLaunchKernelGGL(kdg, dim3(h->n_diag_segs), dim3(BUILD_THREADS), 0, h->stream, P, h->d_diag_segs.p, h->d_kf_obs.p, h->d_obs_lmk.p, s); }
                 { ScopedTimer t(h, "k_build_obs"); hipLaunchKernelGGL(kbo, dim3(n_tiles), dim3(BUILD_THREADS), lds_bobs, h->stream, P, s, mtk, Rp); }
+                if (par) (void)hipStreamWaitEvent(h->stream, h->ev_diag1, 0);
             } else
             { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
             if (h->n_kept) { ScopedTimer t(h, "k_build_kept"); hipLaunchKernelGGL(kbk, dim3((h->n_kept + 127) / 128), dim3(128), 0, h->stream, P, s); }

@@ -22,8 +22,8 @@
 
 namespace sadvio {
 
-constexpr int LM_CHUNK = 16;            // landmarks per MFMA chunk
-constexpr int LM_KS = 4 * LM_CHUNK + 2; // strip row stride (doubles): 4 columns per landmark (3 + pad), + 2 against bank conflicts
+constexpr int LM_CHUNK = 12;            // landmarks per MFMA chunk (12 x 5 observations fill 60 of 64 lanes)
+constexpr int LM_KS = 3 * LM_CHUNK + 2; // strip row stride (doubles): 3 columns per landmark + 2 (bank spread); 32 x 38 doubles = 9.5 KB per wave
 constexpr int LM_ELIM = 9;              // per landmark: L (6, lower, row-major) | w = L^T g_l (3)
 
 // residual + Jacobians of observation o of a landmark at pw from the LDS tables (plain path: no pseudo-observations, no loss)
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_elim(DevPtrs P, int slot, int
     }
 }
 
-// acc += strip strip^T over the first `ksteps` K = 4 column groups of a wave's strip (<= 16): the operand loads of the next
+// acc += strip strip^T over the first `ksteps` K = 4 column groups of a wave's strip (<= 9 here, <= 16 supported): the operand loads of the next
 // group of four steps are issued before the MFMAs of the current one (the trip count is dynamic, the compiler does not
 // pipeline the loop by itself and every step would expose the LDS latency).
 typedef double lm_d4 __attribute__((ext_vector_type(4)));
@@ -137,16 +137,19 @@ __device__ __forceinline__ void lm_syrk_pass(const double* Zb, int lr, int lk, i
     const double* p1 = Zb + (16 + lr) * LM_KS + lk;
     const bool two = nt16 > 1;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { a0[j] = p0[4 * j]; a1[j] = two ? p1[4 * j] : 0.0; }
+    for (int j = 0; j < 4; j++) { a0[j] = j < ksteps ? p0[4 * j] : 0.0; a1[j] = (two && j < ksteps) ? p1[4 * j] : 0.0; }
 #pragma unroll
     for (int g = 0; g < 4; g++) {
         if (4 * g >= ksteps) break;
         if (g < 3 && 4 * (g + 1) < ksteps) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) { b0[j] = p0[16 * (g + 1) + 4 * j]; b1[j] = two ? p1[16 * (g + 1) + 4 * j] : 0.0; }
+            for (int j = 0; j < 4; j++) {
+                const bool in = 4 * (g + 1) + j < ksteps;   // the strip row ends after the chunk's columns
+                b0[j] = in ? p0[16 * (g + 1) + 4 * j] : 0.0; b1[j] = (two && in) ? p1[16 * (g + 1) + 4 * j] : 0.0;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {   // columns past the chunk's last one are zero: whole groups of four need no guard
+        for (int j = 0; j < 4; j++) {   // steps past the last one multiply zeros: whole groups of four need no guard
             acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[j], a0[j], acc[0], 0, 0, 0);
             if (two) {
                 acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[j], a0[j], acc[1], 0, 0, 0);
@@ -159,14 +162,14 @@ __device__ __forceinline__ void lm_syrk_pass(const double* Zb, int lr, int lk, i
 }
 
 // ---- K5b: the landmark (Schur) part of the reduced system from flat observations -------------------------------------------
-// Per chunk (<= 16 landmarks, <= 64 observations, lane = observation) the wave's strip [row][66] holds, in column
-// 4 * landmark + c, Z = sum_a Jp_a^T (Jl_a L) in the rows of the observing key-frames and w = L^T g_l in a spare row. One
+// Per chunk (<= 12 landmarks, <= 64 observations, lane = observation) the wave's strip [row][38] holds, in column
+// 3 * landmark + c, Z = sum_a Jp_a^T (Jl_a L) in the rows of the observing key-frames and w = L^T g_l in a spare row. One
 // v_mfma_f64_16x16x4_f64 pass with A = B = the strip gives strip strip^T: the tile's rows are Z Z^T = E M^-1 E^T (to be
 // subtracted from S) and the spare row is Z w = E M^-1 g_l (to be subtracted from the reduced gradient). The two cameras of a
 // key-frame (adjacent lanes, the same rows) are summed with DPP before the store; no LDS atomics except one add of the
 // accumulators into the tile at the end. The observation-diagonal terms (J_p^T J_p, J_p^T r) are k_diag's.
 template <int FACTOR>
-__global__ __launch_bounds__(BUILD_THREADS, 2) void k_build_obs(DevPtrs P, int slot, int max_tile_kf, int Rp) {
+__global__ __launch_bounds__(BUILD_THREADS, 3) void k_build_obs(DevPtrs P, int slot, int max_tile_kf, int Rp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Tile T = P.tiles[blockIdx.x];
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
@@ -194,8 +197,8 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build_obs(DevPtrs P, int s
     const int nt16 = (Nt + 15) >> 4;
     const int rows_used = 16 * nt16;          // the strip rows this tile touches; Nt <= rows_used - 2
     const int w_row = rows_used - 1;          // spare row: w = L^T g_l
-    // Global loads run two chunks ahead of the arithmetic: level 1 = the observation's fields, level 2 = its landmark's
-    // position and elimination record.
+    // level 1 = the observation's fields, level 2 = its landmark's position and elimination record (prefetching the next
+    // chunk's was measured: no gain at 3 waves / SIMD, and it costs registers)
     struct In1 { int ob0, ob1, lm0, nlm, sl, cam, ls; double m[3]; };
     struct In2 { double pw[3], E[LM_ELIM]; int lcode; };
     auto load1 = [&](int ch, In1& a) {
@@ -225,14 +228,10 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build_obs(DevPtrs P, int s
             for (int i = 0; i < LM_ELIM; i++) b.E[i] = E[i];
         }
     };
-    In1 A1, B1, C1;
-    In2 A2, B2;
-    const int ch_first = T.chunk0 + wv;
-    if (ch_first < T.chunk1) { load1(ch_first, A1); load2(A1, A2); }
-    if (ch_first + BUILD_WAVES < T.chunk1) load1(ch_first + BUILD_WAVES, B1);
-    for (int ch = ch_first; ch < T.chunk1; ch += BUILD_WAVES) {
-        if (ch + BUILD_WAVES < T.chunk1) load2(B1, B2);
-        if (ch + 2 * BUILD_WAVES < T.chunk1) load1(ch + 2 * BUILD_WAVES, C1);
+    In1 A1;
+    In2 A2;
+    for (int ch = T.chunk0 + wv; ch < T.chunk1; ch += BUILD_WAVES) {
+        load1(ch, A1); load2(A1, A2);
         {
             double2* z = (double2*)Zb;
             const double2 zero2 = make_double2(0.0, 0.0);
@@ -281,26 +280,20 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build_obs(DevPtrs P, int s
         }
         wave_lds_fence();   // the zeros are in place
         if (row >= 0 && !follower) {
-            double* zrow = Zb + row * LM_KS + 4 * ls;
+            double* zrow = Zb + row * LM_KS + 3 * ls;
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                double2* d = (double2*)(zrow + i * LM_KS);
-                d[0] = make_double2(z[3 * i], z[3 * i + 1]);
-                d[1] = make_double2(z[3 * i + 2], 0.0);
-            }
+            for (int i = 0; i < 6; i++) { zrow[i * LM_KS] = z[3 * i]; zrow[i * LM_KS + 1] = z[3 * i + 1]; zrow[i * LM_KS + 2] = z[3 * i + 2]; }
         }
         if (lfree && (ln == 0 || ls_prev != ls)) {   // the landmark's first observation writes w
-            double2* d = (double2*)(Zb + w_row * LM_KS + 4 * ls);
-            d[0] = make_double2(A2.E[6], A2.E[7]);
-            d[1] = make_double2(A2.E[8], 0.0);
+            double* d = Zb + w_row * LM_KS + 3 * ls;
+            d[0] = A2.E[6]; d[1] = A2.E[7]; d[2] = A2.E[8];
         }
         wave_lds_fence();
         SADVIO_TS(3, 36);
-        lm_syrk_pass(Zb, lr, lk, nt16, A1.nlm, accZ);   // accZ += strip strip^T, one K = 4 step per landmark
+        lm_syrk_pass(Zb, lr, lk, nt16, (3 * A1.nlm + 3) >> 2, accZ);   // accZ += strip strip^T over the chunk's 3 * nlm columns
         SADVIO_TS(3, 37);
         wave_lds_fence();   // the strip is zeroed again by the next chunk
         SADVIO_TS(3, 38);
-        A1 = B1; A2 = B2; B1 = C1;
     }
     SADVIO_TS(3, 39);
     if (T.chunk0 + wv < T.chunk1) {
@@ -360,11 +353,11 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build_obs(DevPtrs P, int s
 // key-frame's observations (the window's observations sorted by key-frame, built with the tiles), every lane keeps its 27
 // sums in registers over its share of the segment; one reduction per workgroup, then 39 global atomics (the diagonal block of
 // S, gred, gfull, hdiag). Independent of the landmark elimination.
-struct DiagSeg { int w, kf, begin, end; };   // window, global key-frame (free), slice of kf_obs
-constexpr int DIAG_SEG = 1024;               // observations per workgroup
+struct DiagSeg { int w, kf, begin, end; };   // window, global key-frame (free), slice of the key-frame-sorted observation list
+constexpr int DIAG_SEG = 2048;               // observations per workgroup (8 per lane: the 27-value reduction is paid once per workgroup)
 
 template <int FACTOR>
-__global__ __launch_bounds__(BUILD_THREADS) void k_diag(DevPtrs P, const DiagSeg* segs, const int* kf_obs, const int* obs_lmk, int slot) {
+__global__ __launch_bounds__(BUILD_THREADS, 3) void k_diag(DevPtrs P, const DiagSeg* segs, const int* kf_lmk, const int* kf_cam, const double* kf_meas, int slot) {
     const DiagSeg sg = segs[blockIdx.x];
     const WinDev& W = P.win[sg.w];
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
@@ -390,12 +383,18 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_diag(DevPtrs P, const DiagSeg
 #pragma unroll
     for (int i = 0; i < 6; i++) gf[i] = 0.0;
     for (int i = sg.begin + tid; i < sg.end; i += BUILD_THREADS) {
-        const int o = kf_obs[i];
-        const long long gl = obs_lmk[o];
+        // the observation's constants are stored a second time in key-frame order (unit-stride streams); only the landmark is a gather
+        const long long gl = kf_lmk[i];
         const double pw[3] = {P.lmk_p[3 * gl] + xl[3 * gl], P.lmk_p[3 * gl + 1] + xl[3 * gl + 1], P.lmk_p[3 * gl + 2] + xl[3 * gl + 2]};
-        const double* ct = camTab + (P.obs_cam[o] - W.cam_base) * 17;
+        const double* ct = camTab + (kf_cam[i] - W.cam_base) * 17;
         double r[2], Jp[12], Jl[6];
-        lm_linearize<FACTOR, true>(P, tab, ct, o, pw, r, Jp, Jl);
+        if (FACTOR == 0) {
+            const double2 mm = *(const double2*)(kf_meas + 2 * (long long)i);
+            pixel_factor<true>(tab, ct, ct + 4, pw, mm.x, mm.y, ct[16], r, Jp, Jl);
+        } else {
+            const double b[3] = {kf_meas[3 * (long long)i], kf_meas[3 * (long long)i + 1], kf_meas[3 * (long long)i + 2]};
+            angular_factor<true>(tab, ct + 4, pw, b, ct[16], r, Jp, Jl);
+        }
         int e = 0;
 #pragma unroll
         for (int a = 0; a < 6; a++) {
@@ -405,9 +404,9 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_diag(DevPtrs P, const DiagSeg
         }
     }
 #pragma unroll
-    for (int i = 0; i < 21; i++) { const double v = wave_sum(D[i]); if (ln == 0) red[wv][i] = v; }
+    for (int i = 0; i < 21; i++) { const double v = group_sum(D[i], 64); if (ln == 0) red[wv][i] = v; }   // DPP / permlane swaps: no LDS shuffles
 #pragma unroll
-    for (int i = 0; i < 6; i++) { const double v = wave_sum(gf[i]); if (ln == 0) red[wv][21 + i] = v; }
+    for (int i = 0; i < 6; i++) { const double v = group_sum(gf[i], 64); if (ln == 0) red[wv][21 + i] = v; }
     __syncthreads();
     if (tid < 27) {
         double v = 0.0;
@@ -427,7 +426,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_diag(DevPtrs P, const DiagSeg
 
 // ---- K7: back-substitution, one lane per landmark ------------------------------------------------------------------------
 template <int FACTOR>
-__global__ __launch_bounds__(BUILD_THREADS) void k_backsub_lm(DevPtrs P, int slot, int max_tile_kf) {
+__global__ __launch_bounds__(BUILD_THREADS, 3) void k_backsub_lm(DevPtrs P, int slot, int max_tile_kf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Tile T = P.tiles[blockIdx.x];
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
