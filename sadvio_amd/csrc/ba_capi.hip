@@ -2049,7 +2049,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             }
             if (use_lm) {
                 // k_diag does not depend on the elimination: it runs on the second stream next to k_elim / k_build_obs
-                const bool par = h->n_diag_segs && h->side2 && !h->cfg.profile_kernels;
+                const bool par = h->n_diag_segs && h->side2 && !h->cfg.profile_kernels && !getenv("SADVIO_NO_PAR");
                 if (par) {
                     (void)hipEventRecord(h->ev_diag0, h->stream);
                     (void)hipStreamWaitEvent(h->side2, h->ev_diag0, 0);

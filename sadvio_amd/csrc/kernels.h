@@ -563,11 +563,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
                 for (int pp = 0; pp < 3; pp++) {
                     const int tr = pp < 1 ? 0 : 1, tc = pp - tr;
                     if (tr < nt16) {
-#ifdef SADVIO_VAR_LOCALACC
-                        d4 loc = (d4){0.0, 0.0, 0.0, 0.0};
-#else
                         d4& loc = accs[pp];
-#endif
                         double av[8], bv[8];
 #pragma unroll
                         for (int kk = 0; kk < 8; kk++) {  // all operand loads first, then the MFMA chain
@@ -578,9 +574,6 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
 #pragma unroll
                         for (int kk = 0; kk < 8; kk++)
                             if (4 * kk < Kw) loc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], loc, 0, 0, 0);
-#ifdef SADVIO_VAR_LOCALACC
-                        accs[pp] += loc;
-#endif
                     }
                 }
             }

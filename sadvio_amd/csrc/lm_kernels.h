@@ -40,6 +40,25 @@ __device__ __forceinline__ void lm_linearize(const DevPtrs& P, const double* tab
     }
 }
 
+// the per-observation fields, loaded ahead of their use
+struct ObsIn { int sl, cam; double m[3]; };
+template <int FACTOR>
+__device__ __forceinline__ ObsIn lm_load_obs(const DevPtrs& P, int o, int oe) {
+    ObsIn a;
+    a.sl = 0; a.cam = 0; a.m[0] = a.m[1] = a.m[2] = 0.0;
+    if (o < oe) {
+        a.sl = P.obs_slot[o]; a.cam = P.obs_cam[o];
+        if (FACTOR == 0) { const double2 mm = *(const double2*)(P.obs_meas + 2 * (long long)o); a.m[0] = mm.x; a.m[1] = mm.y; }
+        else { const double* mm = P.obs_meas + 3 * (long long)o; a.m[0] = mm[0]; a.m[1] = mm[1]; a.m[2] = mm[2]; }
+    }
+    return a;
+}
+template <int FACTOR, bool WANT_J>
+__device__ __forceinline__ void lm_linearize_in(const double* tab, const double* ct, const ObsIn& a, const double* pw, double* r, double* Jp, double* Jl) {
+    if (FACTOR == 0) pixel_factor<WANT_J>(tab, ct, ct + 4, pw, a.m[0], a.m[1], ct[16], r, Jp, Jl);
+    else angular_factor<WANT_J>(tab, ct + 4, pw, a.m, ct[16], r, Jp, Jl);
+}
+
 // LM-damped inverse of a landmark's 3 x 3 block (the arithmetic of group_eliminate, one lane)
 __device__ __forceinline__ void lm_damped_inverse(const DevPtrs& P, const double* H, const double* s, double radius, double* Mi) {
     const double ir = 1.0 / radius;
@@ -74,11 +93,14 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_elim(DevPtrs P, int slot, int
         const double pw[3] = {P.lmk_p[3 * (long long)gl] + xl[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1] + xl[3 * (long long)gl + 1],
                               P.lmk_p[3 * (long long)gl + 2] + xl[3 * (long long)gl + 2]};
         double H[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+        ObsIn nx = lm_load_obs<FACTOR>(P, ob, oe);
         for (int o = ob; o < oe; o++) {
-            const int sl = P.obs_slot[o];
-            const double* ct = camTab + (P.obs_cam[o] - T.cam_base) * 17;
+            const ObsIn cu = nx;
+            nx = lm_load_obs<FACTOR>(P, o + 1, oe);   // the next observation's loads are in flight during this one's arithmetic
+            const int sl = cu.sl;
+            const double* ct = camTab + (cu.cam - T.cam_base) * 17;
             double r[2], Jp[12], Jl[6];
-            lm_linearize<FACTOR, true>(P, poseTab + sl * POSE_TAB, ct, o, pw, r, Jp, Jl);
+            lm_linearize_in<FACTOR, true>(poseTab + sl * POSE_TAB, ct, cu, pw, r, Jp, Jl);
             const double c = r[0] * r[0] + r[1] * r[1];
             if (rowTab[sl] >= 0 || lcode != 1) cost_part += c; else fixed_part += c;   // a block of constant parameters: fixed cost
             if (lcode == 0) {
@@ -474,13 +496,16 @@ __global__ __launch_bounds__(BUILD_THREADS, 3) void k_backsub_lm(DevPtrs P, int 
         // sums over the landmark's residual blocks that are in the program (u = Jp dp):
         //   H = sum Jl^T Jl, g = sum Jl^T r, t = sum Jl^T (r + u), a1 = sum u . r, a2 = sum u . u
         double H[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, t[3] = {0, 0, 0}, a1 = 0.0, a2 = 0.0;
+        ObsIn nx = lm_load_obs<FACTOR>(P, ob, oe);
         for (int o = ob; o < oe; o++) {
-            const int sl = P.obs_slot[o];
+            const ObsIn cu = nx;
+            nx = lm_load_obs<FACTOR>(P, o + 1, oe);
+            const int sl = cu.sl;
             const int row = rowTab[sl];
             if (row < 0 && lcode == 1) continue;   // a block of constant parameters
-            const double* ct = camTab + (P.obs_cam[o] - T.cam_base) * 17;
+            const double* ct = camTab + (cu.cam - T.cam_base) * 17;
             double r[2], Jp[12], Jl[6];
-            lm_linearize<FACTOR, true>(P, poseTab + sl * POSE_TAB, ct, o, pw, r, Jp, Jl);
+            lm_linearize_in<FACTOR, true>(poseTab + sl * POSE_TAB, ct, cu, pw, r, Jp, Jl);
             double u0 = 0.0, u1 = 0.0;
             if (row >= 0) {
                 const double* d = dpTab + sl * 6;
@@ -521,12 +546,15 @@ __global__ __launch_bounds__(BUILD_THREADS, 3) void k_backsub_lm(DevPtrs P, int 
         }
         // residuals at the candidate point
         const double pc[3] = {p0[0] + c0, p0[1] + c1, p0[2] + c2};
+        nx = lm_load_obs<FACTOR>(P, ob, oe);
         for (int o = ob; o < oe; o++) {
-            const int sl = P.obs_slot[o];
+            const ObsIn cu = nx;
+            nx = lm_load_obs<FACTOR>(P, o + 1, oe);
+            const int sl = cu.sl;
             if (rowTab[sl] < 0 && lcode == 1) continue;
-            const double* ct = camTab + (P.obs_cam[o] - T.cam_base) * 17;
+            const double* ct = camTab + (cu.cam - T.cam_base) * 17;
             double r[2];
-            lm_linearize<FACTOR, false>(P, candTab + sl * 12, ct, o, pc, r, nullptr, nullptr);
+            lm_linearize_in<FACTOR, false>(candTab + sl * 12, ct, cu, pc, r, nullptr, nullptr);
             cc += r[0] * r[0] + r[1] * r[1];
         }
     }

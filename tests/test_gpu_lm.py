@@ -1,0 +1,79 @@
+"""The throughput kernels of sadvio_amd/csrc/lm_kernels.h (k_elim / k_diag / k_build_obs / k_backsub_lm: the path large plain
+batches take by themselves) forced onto small windows with SADVIO_LM=1: same LM trace as the oracle, key-frame and landmark
+deltas within 1e-6, and the same answer as the latency kernels of kernels.h (SADVIO_LM=0)."""
+import os
+
+import numpy as np
+import pytest
+
+from sadvio_amd import capi
+from sadvio_amd.synthetic import make_window
+from golden_util import assert_trace_matches
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+@pytest.fixture
+def lm_env():
+    old = os.environ.get("SADVIO_LM")
+    yield lambda v: os.environ.__setitem__("SADVIO_LM", v)
+    if old is None:
+        os.environ.pop("SADVIO_LM", None)
+    else:
+        os.environ["SADVIO_LM"] = old
+
+
+def solve(backend_cls, ws, opts, use_graph=False, profile=False):
+    be = backend_cls(device=0, use_graph=use_graph, profile_kernels=profile)
+    try:
+        be.set_windows(ws)
+        ss = be.solve(opts)
+        out = [(ss[i], be.get_deltas(i), be.get_trace(i)) for i in range(len(ws))]
+        names = set(be.kernel_times().keys()) if profile else set()
+    finally:
+        be.close()
+    return out, names
+
+
+@pytest.mark.parametrize("factor", [capi.FACTOR_PIXEL, capi.FACTOR_ANGULAR])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_lm_path_matches_oracle_and_latency_path(backend_cls, oracle_lib, lm_env, factor, use_graph):
+    ws = [make_window(n_kf=9, n_lmk=1500, obs_per_lmk=5, seed=77, factor=factor), make_window(n_kf=6, n_lmk=700, obs_per_lmk=4, seed=78, factor=factor)]
+    ws[1].lmk_const = np.zeros(ws[1].n_lmk, dtype=np.uint8); ws[1].lmk_const[::7] = 1      # some constant landmarks
+    ws[0].kf_const = ws[0].kf_const.copy(); ws[0].kf_const[3] = 1                            # a constant key-frame in the middle
+    opts = capi.reference_options()
+    lm_env("1")
+    fast, _ = solve(backend_cls, ws, opts, use_graph)
+    lm_env("0")
+    slow, _ = solve(backend_cls, ws, opts, use_graph)
+    for w, (s, d, tr), (s0, d0, _) in zip(ws, fast, slow):
+        ref = oracle_lib.solve(w, opts)
+        rs = ref["summary"]
+        assert (s.iterations, s.termination, s.num_successful_steps) == (rs.iterations, rs.termination, rs.num_successful_steps)
+        assert np.isclose(s.initial_cost, rs.initial_cost, rtol=1e-11) and np.isclose(s.final_cost, rs.final_cost, rtol=1e-8)
+        assert_trace_matches(tr, ref["log"], rs.termination)
+        assert np.abs(d["pose"] - ref["pose"]).max() <= TOL and np.abs(d["lmk"] - ref["lmk"]).max() <= TOL
+        assert s.iterations == s0.iterations
+        assert np.abs(d["pose"] - d0["pose"]).max() <= 1e-9 and np.abs(d["lmk"] - d0["lmk"]).max() <= 1e-9
+
+
+def test_lm_kernels_are_the_ones_that_ran(backend_cls, lm_env):
+    w = make_window(n_kf=6, n_lmk=600, obs_per_lmk=5, seed=5)
+    lm_env("1")
+    _, names = solve(backend_cls, [w], capi.reference_options(), profile=True)
+    assert {"k_elim", "k_diag", "k_build_obs", "k_backsub_lm"} <= names and "k_build" not in names
+    lm_env("0")
+    _, names = solve(backend_cls, [w], capi.reference_options(), profile=True)
+    assert "k_build" in names and "k_elim" not in names
+
+
+def test_robust_loss_keeps_the_latency_kernels(backend_cls, oracle_lib, lm_env):
+    """The throughput kernels carry no loss function: with Huber the batch stays on kernels.h even when forced."""
+    w = make_window(n_kf=6, n_lmk=600, obs_per_lmk=5, seed=6)
+    opts = capi.reference_options(); opts.huber_a = 1.0
+    lm_env("1")
+    (res,), names = solve(backend_cls, [w], opts, profile=True)
+    assert "k_build" in names and "k_elim" not in names
+    ref = oracle_lib.solve(w, opts)
+    assert np.abs(res[1]["pose"] - ref["pose"]).max() <= TOL
