@@ -14,7 +14,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("k_build", "k_solve", "k_backsub", "k_init_tables", "k_reset", "k_final", "k_decide", "k_linearize_probe"):
+    for k in ("k_build_obs", "k_backsub_lm", "k_elim", "k_diag", "k_build", "k_solve", "k_backsub", "k_init_tables", "k_reset", "k_final", "k_decide", "k_linearize_probe"):
         if k in name:
             return k
     return None
