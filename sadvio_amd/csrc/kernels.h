@@ -160,14 +160,48 @@ __device__ __forceinline__ void trace_write(const DevPtrs& P, int w, int slot, c
     N[4] = judged ? cc / a.mcc : 0.0; N[5] = next.n_success > prev.n_success ? 1.0 : 0.0; N[6] = -1.0; N[7] = a.mcc;
 }
 
+// Wave-wide sum / max with DPP + the gfx950 v_permlane{16,32}_swap (plain VALU): every lane receives the result. The
+// __shfl_down forms go through ds_bpermute, ~100 cycles per step on the LDS pipe: six steps per value were ~1 us of every
+// kernel tail that reduces a handful of partials.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// v_permlane16_swap / v_permlane32_swap of a register with itself return (own value, value of lane ^ 16 / ^ 32) in an order
+// that depends on the half: symmetric combinations (sum, max) need not know which is which
+__device__ __forceinline__ void swap16_pair_f64(double v, double& x0, double& x1) {
+    unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    x0 = __hiloint2double(b[0], a[0]); x1 = __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ void swap32_pair_f64(double v, double& x0, double& x1) {
+    unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    x0 = __hiloint2double(b[0], a[0]); x1 = __hiloint2double(b[1], a[1]);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    v += dpp_f64_<0xB1>(v);   // xor 1
+    v += dpp_f64_<0x4E>(v);   // xor 2
+    v += dpp_f64_<0x141>(v);  // row_half_mirror
+    v += dpp_f64_<0x140>(v);  // row_mirror
+    double x0, x1;
+    swap16_pair_f64(v, x0, x1); v = x0 + x1;
+    swap32_pair_f64(v, x0, x1); v = x0 + x1;
     return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    v = fmax(v, dpp_f64_<0xB1>(v));
+    v = fmax(v, dpp_f64_<0x4E>(v));
+    v = fmax(v, dpp_f64_<0x141>(v));
+    v = fmax(v, dpp_f64_<0x140>(v));
+    double x0, x1;
+    swap16_pair_f64(v, x0, x1); v = fmax(x0, x1);
+    swap32_pair_f64(v, x0, x1); v = fmax(x0, x1);
     return v;
 }
 
