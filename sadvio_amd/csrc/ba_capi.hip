@@ -958,9 +958,14 @@ static int build_layout(sadvio_ba_handle* h) {
     // observations; obs_lslot = index of the observation's landmark inside its chunk
     std::vector<int> chunk_ob, chunk_lm;   // chunk starts + one sentinel (landmarks and observations are globally consecutive)
     std::vector<unsigned char> obs_lslot(std::max(obs_b, 1), 0);
-    h->lm_ok = !h->tiles.empty();
+    // the tables cost host time (a second, sorted copy of the observation constants): only built where the throughput path can run
+    bool want_lm = lmk_b >= 65536;
+    if (const char* e = getenv("SADVIO_LM")) want_lm = atoi(e) != 0;
+    h->lm_ok = want_lm && !h->tiles.empty();
     h->lm_landmarks = 0;
+    h->n_diag_segs = 0;
     for (auto& t : h->tiles) {
+        if (!want_lm) { t.chunk0 = t.chunk1 = 0; continue; }
         t.chunk0 = (int)chunk_lm.size();
         if (t.lds_mode != 2) h->lm_ok = false;
         int l = t.lmk0;
@@ -977,7 +982,7 @@ static int build_layout(sadvio_ba_handle* h) {
         h->lm_landmarks += t.lmk1 - t.lmk0;
     }
     chunk_lm.push_back(lmk_b); chunk_ob.push_back(obs_b);
-    {
+    if (want_lm) {
         // k_diag: per window, its observations sorted by key-frame (free ones), cut into segments of DIAG_SEG
         std::vector<int> obs_lmk(std::max(obs_b, 1), 0), kf_obs;
         std::vector<DiagSeg> segs;
