@@ -119,6 +119,19 @@ struct LandmarkState {
     std::vector<Feature> features;
 };
 
+struct LineFeature {          // one AFeature of a linexd landmark: the two end points of the 2D segment (AFeature::getPoints)
+    int frame, camera;
+    double u0, v0, u1, v1;
+};
+
+struct LineLandmarkState {    // a "linexd" landmark: pose T_w_l whose x axis carries the segment, model points * scale (Line3D.h)
+    int64_t id = 0;
+    Pose T_w_l;
+    double model[6] = {-0.5, 0, 0, 0.5, 0, 0};   // ModelLine3D end points times landmark->getScale()
+    bool initialized = true, outlier = false;
+    std::vector<LineFeature> features;
+};
+
 struct ImuPair {              // IMUFactor + IMUBiasFactor between two consecutive key-frames (AOptimizer.cpp:55-92)
     int frame_i, frame_j;     // i = older
     sadvio_imu_factor f;      // kf_i / kf_j are filled by the optimizer
@@ -128,6 +141,7 @@ struct LocalMapSnapshot {     // LocalMap::getLastNFramesIn (newest first, amap.
     std::vector<FrameState> frames;
     std::vector<LandmarkState> landmarks;
     std::vector<ImuPair> imu_pairs;
+    std::vector<LineLandmarkState> lines;   // getLandmarks()["linexd"]
 };
 
 class HipOptimizer {
@@ -324,6 +338,25 @@ class HipOptimizer {
         }
         return true;
     }
+    // BundleAdjustmentCERESAnalytic::marginalizeRelative (…Analytic.cpp:665-809): the 6 x 6 information of the relative pose
+    // T_frame0_frame1 recovered from the landmarks both frames observe (Schur complement on the two poses, then the NFR
+    // covariance recovery through the Relative6DPose Jacobian). Returns false — and leaves a zero matrix, as the reference
+    // returns Zero(12, 12) — when the Schur complement is refused. inf36 row-major; Ak144 (optional) = _marginalization->_Ak.
+    bool marginalizeRelative(LocalMapSnapshot& map, int frame0, int frame1, double* inf36, double* Ak144 = nullptr) {
+        const int nkf = (int)map.frames.size();
+        for (int i = 0; i < 36; i++) inf36[i] = 0.0;
+        if (frame0 < 0 || frame0 >= nkf || frame1 < 0 || frame1 >= nkf || frame0 == frame1) { _err = "marginalizeRelative: bad frame index"; return false; }
+        Flat F;
+        flatten(map, 0, false, false, false, F);
+        if (F.non_pinhole_pixel) { _err = "pixel factor with a non-pinhole camera: use the angular backend"; return false; }
+        double Ak[144];
+        int rc = upload(F, false);
+        if (rc == SADVIO_OK) rc = sadvio_ba_marginalize_relative(_h, 0, frame0, frame1, inf36, Ak);
+        if (rc != SADVIO_OK) { _err = sadvio_ba_last_error(_h); for (int i = 0; i < 36; i++) inf36[i] = 0.0; return false; }
+        if (Ak144) std::memcpy(Ak144, Ak, sizeof(Ak));
+        return true;
+    }
+
     bool has_prior() const { return _prior.valid; }
     int prior_rows() const { return _prior.n_full; }
     int prior_cols() const { return _prior.n; }
@@ -350,6 +383,12 @@ class HipOptimizer {
         std::vector<int32_t> ptr, obs_kf, obs_cam;
         std::vector<sadvio_pose_prior> priors;
         std::vector<sadvio_imu_factor> imus;
+        // linexd landmarks (…Analytic.cpp:270-310)
+        std::vector<int> line_src;
+        std::vector<int64_t> line_id;
+        std::vector<double> line_T, line_model, line_meas;
+        std::vector<int32_t> line_ptr, line_obs_kf, line_obs_cam;
+        sadvio_line_set lines{};
     };
     struct Prior {  // the dense prior kept between marginalize() and the next window solves, variables named by id
         bool valid = false;
@@ -408,6 +447,32 @@ class HipOptimizer {
             }
             F.ptr.push_back((int32_t)F.obs_kf.size());
         }
+        F.line_ptr.assign(1, 0);
+        for (int l = 0; l < (int)map.lines.size(); l++) {                                // …Analytic.cpp:270-310
+            const LineLandmarkState& L = map.lines[l];
+            if (!L.initialized || L.outlier) continue;
+            F.line_src.push_back(l); F.line_id.push_back(L.id);
+            F.line_T.insert(F.line_T.end(), L.T_w_l.R, L.T_w_l.R + 9); F.line_T.insert(F.line_T.end(), L.T_w_l.t, L.T_w_l.t + 3);
+            F.line_model.insert(F.line_model.end(), L.model, L.model + 6);
+            for (const LineFeature& ft : L.features) {
+                if (ft.frame < 0 || ft.frame >= nkf || !map.frames[ft.frame].is_keyframe) continue;   // :296-299
+                const CameraModel& c = map.frames[ft.frame].cameras[ft.camera];
+                F.line_obs_kf.push_back(ft.frame); F.line_obs_cam.push_back(F.cam_base[ft.frame] + ft.camera);
+                if (_angular) {                                                          // feature->getBearingVectors()
+                    double b0[3] = {0, 0, 1}, b1[3] = {0, 0, 1};
+                    ray_camera(c.intrinsics(), ft.u0, ft.v0, b0); ray_camera(c.intrinsics(), ft.u1, ft.v1, b1);
+                    F.line_meas.insert(F.line_meas.end(), {b0[0], b0[1], b0[2], b1[0], b1[1], b1[2]});
+                } else {
+                    if (c.kind != CameraKind::Pinhole) F.non_pinhole_pixel = true;
+                    F.line_meas.insert(F.line_meas.end(), {ft.u0, ft.v0, ft.u1, ft.v1});
+                }
+            }
+            F.line_ptr.push_back((int32_t)F.line_obs_kf.size());
+        }
+        F.lines.n_line = (int)F.line_src.size(); F.lines.n_obs = (int)F.line_obs_kf.size();
+        F.lines.line_id = F.line_id.data(); F.lines.line_T_w_l = F.line_T.data(); F.lines.line_model = F.line_model.data();
+        F.lines.line_const = nullptr; F.lines.line_obs_ptr = F.line_ptr.data();
+        F.lines.obs_kf = F.line_obs_kf.data(); F.lines.obs_cam = F.line_obs_cam.data(); F.lines.obs_meas = F.line_meas.data();
         if (vio)
             for (const ImuPair& p : map.imu_pairs) {                                     // AOptimizer.cpp:69-72
                 if (p.frame_i == p.frame_j || p.f.dt > 1.0) continue;
@@ -504,6 +569,8 @@ class HipOptimizer {
         const bool window_solve = !all_const && !lmk_const;
         int rc = upload(F, window_solve);
         if (rc == SADVIO_OK && window_solve) rc = add_marginalization_prior(F);
+        const bool with_lines = window_solve && F.lines.n_line > 0;      // the line blocks are only built by addResidualsLocalMap
+        if (rc == SADVIO_OK && with_lines) rc = sadvio_ba_set_lines(_h, 0, &F.lines);
         if (rc == SADVIO_OK) rc = sadvio_ba_solve(_h, &opt, &_sum);
         if (rc != SADVIO_OK && rc != SADVIO_E_NOT_USABLE) { _err = sadvio_ba_last_error(_h); return false; }   // state untouched
         if (rc == SADVIO_E_NOT_USABLE) return false;
@@ -523,6 +590,11 @@ class HipOptimizer {
                 if (p.frame_i < 0 || p.frame_i >= nkf || p.frame_j < 0 || p.frame_j >= nkf || !map.frames[p.frame_j].has_imu || !map.frames[p.frame_i].has_imu) continue;
                 bias_delta_correction(p.f, &dba[3 * (size_t)p.frame_i], &dbg[3 * (size_t)p.frame_i]);
             }
+        if (with_lines) {                                                                // AOptimizer.cpp:334-336: T_w_l <- T_w_l * (exp(w), t)
+            std::vector<double> d6(6 * (size_t)F.lines.n_line);
+            if (sadvio_ba_get_line_deltas(_h, 0, d6.data()) != SADVIO_OK) { _err = sadvio_ba_last_error(_h); return false; }
+            for (size_t k = 0; k < F.line_src.size(); k++) apply_pose_delta(map.lines[F.line_src[k]].T_w_l, &d6[6 * k]);
+        }
         std::vector<int32_t> inlier(F.lmk_src.size(), 1);
         if (chi2_gate && !F.lmk_src.empty()) {                                           // ALandmark.cpp:130-146
             const Flat* G = &F;

@@ -1345,6 +1345,7 @@ int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int l
         int f = 0;
         if (hipMemcpyAsync(&f, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
         if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+        if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 16384)) fprintf(stderr, "[sadvio dbg] jacobi n %d sweep %d rotations %d\n", n, sweeps, f);
         if (!f) { sweeps++; break; }
     }
     hipLaunchKernelGGL(k_jacobi_eigenvalues, dim3(n), dim3(JAC_THREADS), 0, h->stream, G, V, n, ev);

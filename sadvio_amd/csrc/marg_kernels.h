@@ -67,7 +67,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_step(double* __restrict_
     a = block_sum_256(a, sh); b = block_sum_256(b, sh); c = block_sum_256(c, sh);
     if (a == 0.0 || b == 0.0 || c * c <= tol * tol * a * b) return;
     if (a < *floor2 && b < *floor2) return;
-    if (threadIdx.x == 0) *rotated = 1;
+    if (threadIdx.x == 0) atomicAdd(rotated, 1);   // rotations of this sweep (0 = converged)
     const double zeta = (b - a) / (2.0 * c);
     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
     const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;

@@ -375,6 +375,64 @@ int main(int argc, char** argv) {
         opt.localMapBA(m3, 1);   // pixel backend: refused, state untouched
         check(!opt.last_error().empty() && pose_err(m3.frames[0].T_f_w, before) == 0.0, "pixel backend refuses non-pinhole cameras");
     }
+    // --- linexd landmarks in localMapBA (angular backend): noise-free end points, perturbed line poses; the line blocks are
+    //     in the problem and the lines are written back with T_w_l * (exp(w), t). (The pixel line factor of the reference reads
+    //     its 6-vector as a translation while its Jacobian is written for rotation + translation, …Analytic.h:121,156-160: a
+    //     map whose only error sits in the lines does not move under it; that behaviour is covered by tests/test_gpu_lines.py.) ---
+    {
+        LocalMapSnapshot truth = make_map(rng, 5, 300), m;
+        std::uniform_real_distribution<double> U(-1.0, 1.0);
+        for (int l = 0; l < 6; l++) {
+            LineLandmarkState L;
+            L.id = 9000 + l;
+            const double w[6] = {0.4 * U(rng), 0.4 * U(rng), 0.4 * U(rng), 1.5 * U(rng) + 0.3, 0.8 * U(rng), 5.0 + U(rng)};
+            apply_pose_delta(L.T_w_l, w);
+            const double len = 0.6;
+            L.model[0] = -0.5 * len; L.model[3] = 0.5 * len;
+            for (int i = 0; i < 5; i++) {
+                double pw[2][3], uv[2][2];
+                for (int e = 0; e < 2; e++) {
+                    for (int a = 0; a < 3; a++) pw[e][a] = L.T_w_l.R[3 * a] * L.model[3 * e] + L.T_w_l.t[a];
+                    project(truth.frames[i], 0, pw[e], uv[e][0], uv[e][1]);
+                }
+                L.features.push_back({i, 0, uv[0][0], uv[0][1], uv[1][0], uv[1][1]});
+            }
+            truth.lines.push_back(L);
+        }
+        m = truth;
+        for (auto& L : m.lines) { const double d[6] = {0, 0, 0, 0.02 * G(rng), 0.02 * G(rng), 0.02 * G(rng)}; apply_pose_delta(L.T_w_l, d); }
+        m.lines[2].outlier = true;
+        const Pose l2 = m.lines[2].T_w_l, l0 = m.lines[0].T_w_l;
+        HipOptimizer angl(0, true);
+        check(angl.localMapBA(m, 1), "localMapBA with linexd landmarks returns true");
+        const double c0 = angl.summary().initial_cost, c1 = angl.summary().final_cost;
+        std::printf("   lines: cost %.3e -> %.3e, it %d '%s'\n", c0, c1, angl.summary().iterations, angl.last_error().c_str());
+        check(c0 > 0.0 && c1 <= c0, "linexd: the line residuals are in the cost (the as-coded Jacobians are inexact: it only must not grow)");
+        check(pose_err(m.lines[0].T_w_l, l0) > 1e-4, "linexd: line poses are written back");
+        check(pose_err(m.lines[2].T_w_l, l2) == 0.0, "linexd: outlier line untouched");
+        double worst = 0;
+        for (size_t i = 0; i < m.frames.size(); i++) worst = std::fmax(worst, pose_err(m.frames[i].T_f_w, truth.frames[i].T_f_w));
+        check(worst < 1e-3, "linexd: key-frame poses stay at the ground truth");
+    }
+    // --- marginalizeRelative: the information of T_0_1 from the shared landmarks is symmetric positive definite, larger with
+    //     more landmarks, and refused (zero matrix) when the two frames share nothing ---
+    {
+        LocalMapSnapshot m = make_map(rng, 3, 200);
+        double inf[36], Ak[144];
+        check(opt.marginalizeRelative(m, 0, 1, inf, Ak), "marginalizeRelative returns true");
+        double asym = 0, mind = 1e300, tr = 0;
+        for (int i = 0; i < 6; i++) { mind = std::fmin(mind, inf[7 * i]); tr += inf[7 * i]; for (int j = 0; j < 6; j++) asym = std::fmax(asym, std::fabs(inf[6 * i + j] - inf[6 * j + i])); }
+        std::printf("   relative information: trace %.3e min diag %.3e asym %.3e '%s'\n", tr, mind, asym, opt.last_error().c_str());
+        check(mind > 0.0 && asym <= 1e-9 * tr, "marginalizeRelative: information symmetric with a positive diagonal");
+        LocalMapSnapshot few = m;
+        few.landmarks.resize(40);
+        double inf2[36];
+        check(opt.marginalizeRelative(few, 0, 1, inf2), "marginalizeRelative on fewer landmarks");
+        double tr2 = 0;
+        for (int i = 0; i < 6; i++) tr2 += inf2[7 * i];
+        check(tr2 < tr, "marginalizeRelative: fewer shared landmarks, less information");
+        check(!opt.marginalizeRelative(m, 0, 0, inf2) && inf2[0] == 0.0, "marginalizeRelative: bad frame pair refused with a zero matrix");
+    }
     std::printf("%s (%d failure%s)\n", fails ? "FAILED" : "PASSED", fails, fails == 1 ? "" : "s");
     return fails ? 1 : 0;
 }
