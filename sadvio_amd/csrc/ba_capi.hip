@@ -245,6 +245,8 @@ struct sadvio_ba_handle {
     DevBuf<int> d_lmk_ob, d_lmk_oe, d_obs_kf, d_obs_cam, d_tile_kf, d_tile_row;
     DevBuf<unsigned char> d_obs_slot, d_obs_lslot;
     DevBuf<int> d_chunk_ob, d_chunk_lm;   // chunk tables of the throughput kernels (lm_kernels.h)
+    DevBuf<int> d_jac_ints;               // pivoting / rank of the Cholesky-preconditioned Jacobi
+    DevBuf<double> d_jac_dbl;             // its remaining diagonal + threshold
     DevBuf<int> d_kf_lmk, d_kf_cam;       // k_diag: landmark / camera of the observations sorted by key-frame (free key-frames only)
     DevBuf<double> d_kf_meas;             //         and their measurements, in the same order
     DevBuf<DiagSeg> d_diag_segs;
@@ -1327,6 +1329,42 @@ namespace {
 // and ev (n) are device buffers; returns the number of sweeps (negative = HIP error)
 int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int lower_only, double* G, double* V, double* ev, int* flag) {
     const long long nn = (long long)n * n;
+    // Cholesky-preconditioned block Jacobi (marg_kernels.h): sym(A) -> V (scratch), pivoted Cholesky V -> G = L^T, block
+    // one-sided Jacobi sweeps on the rows of G, then eigen-pairs from the rows -> V, ev
+    if (n >= 32 && n <= PCH_MAXN && !getenv("SADVIO_JACOBI_PLAIN")) {
+        if (h->d_jac_ints.alloc((size_t)n + 8) != hipSuccess) return -1;
+        int* piv = h->d_jac_ints.p; int* rank_d = piv + n;
+        if (h->d_jac_dbl.alloc((size_t)n + 8) != hipSuccess) return -1;
+        double* dg = h->d_jac_dbl.p; double* dctl = dg + n;
+        hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, A, lda, n, V, G, lower_only);
+        if (hipMemsetAsync(rank_d, 0xff, sizeof(int), h->stream) != hipSuccess) return -1;   // -1: still factorising
+        // pivots at the rounding-noise level of the largest one end the factorisation: the floor of marg_cut (n eps lambda_max)
+        // with a margin - the null space of a marginalisation prior sits exactly there
+        const double tau_rel = 4.0 * n * 2.220446049250313e-16;
+        for (int k0 = 0; k0 < n; k0 += PCH_NB) {
+            hipLaunchKernelGGL(k_pchol_panel, dim3(1), dim3(PCH_THREADS), 0, h->stream, V, n, G, piv, dg, rank_d, dctl, k0, tau_rel);
+            const int m = n - (k0 + PCH_NB);
+            if (m > 0) hipLaunchKernelGGL(k_pchol_syrk, dim3((m + 63) / 64, (m + 63) / 64), dim3(256), 0, h->stream, V, n, G, rank_d, k0);
+        }
+        int r = 0;
+        if (hipMemcpyAsync(&r, rank_d, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+        if (r < 0) r = n;
+        const int nb = (r + JB - 1) / JB, nbpad = nb + (nb & 1);
+        int sweeps = 0;
+        for (; sweeps < 40 && nbpad >= 2; sweeps++) {
+            if (hipMemsetAsync(flag, 0, sizeof(int), h->stream) != hipSuccess) return -1;
+            for (int st = 0; st < nbpad - 1; st++) {
+                if (n <= 4 * JAC_THREADS) hipLaunchKernelGGL(k_jacobi_block<4>, dim3(nbpad / 2), dim3(JAC_THREADS), 0, h->stream, G, r, n, nbpad, st, 1e-14, flag);
+                else hipLaunchKernelGGL(k_jacobi_block<8>, dim3(nbpad / 2), dim3(JAC_THREADS), 0, h->stream, G, r, n, nbpad, st, 1e-14, flag);
+            }
+            int f = 0;
+            if (hipMemcpyAsync(&f, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+            if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 16384)) fprintf(stderr, "[sadvio dbg] block jacobi n %d rank %d sweep %d block pairs rotated %d\n", n, r, sweeps, f);
+            if (!f) { sweeps++; break; }
+        }
+        hipLaunchKernelGGL(k_eig_from_rows, dim3(n), dim3(JAC_THREADS), 0, h->stream, G, piv, rank_d, n, V, ev);
+        return sweeps;
+    }
     hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, A, lda, n, G, V, lower_only);
     const int npad = n + (n & 1);
     // noise floor of the column norms (see k_jacobi_floor); flag[2..3] = max norm bits, flag[4..5] = the floor

@@ -81,6 +81,272 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_step(double* __restrict_
     }
 }
 
+// ---- Cholesky-preconditioned one-sided Jacobi (Veselic / Hari / Drmac): A = P L L^T P^T by diagonal pivoting, then the
+// rows of G = L^T are orthogonalised by Jacobi rotations: G -> Sigma U^T with A = U Sigma^2 U^T, so the rows ARE sqrt(lambda) u^T
+// (no accumulation of rotations). On the rank-deficient, 10-decades-graded Schur complements of a marginalisation this takes
+// 9-10 sweeps where Jacobi on A itself takes 30+ (profiled on the config-3 problem).
+
+// Pivoted Cholesky in panels of PCH_NB columns (the LAPACK dpstrf scheme): the panel kernel (ONE workgroup - every step
+// needs the arg max of the remaining diagonal) picks the pivot, applies the symmetric swap to the trailing matrix S and to
+// the rows of G = L^T written so far, and forms row k of G from row k of S minus the contributions of the CURRENT panel's
+// rows only (<= 31 terms); the rank-PCH_NB update of the whole trailing matrix is k_pchol_syrk on all CUs. (One workgroup
+// doing the full left-looking dot products is bound by the L2 bandwidth of a single CU: 20 ms at n = 915 against 3.)
+// S: n x n symmetric working copy (both triangles kept current), G: n x n row-major output, dg: remaining diagonal,
+// piv: permutation, ctl[0] = rank once the factorisation has stopped (else -1), ctl[1] = tau (as double bits in dctl).
+constexpr int PCH_THREADS = 1024;
+constexpr int PCH_MAXN = 2048;
+constexpr int PCH_NB = 32;
+__global__ __launch_bounds__(PCH_THREADS) void k_pchol_panel(double* __restrict__ S, int n, double* __restrict__ G, int* __restrict__ piv,
+                                                             double* __restrict__ dg, int* __restrict__ ctl, double* __restrict__ dctl, int k0, double tau_rel) {
+    __shared__ double d[PCH_MAXN];
+    __shared__ double lk[PCH_NB];         // G[c][k] of the current panel's rows
+    __shared__ int pv[PCH_MAXN];
+    __shared__ double wmax[PCH_THREADS / 64];
+    __shared__ int widx[PCH_THREADS / 64];
+    __shared__ int s_j;
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    if (ctl[0] >= 0) return;              // the factorisation stopped in an earlier panel
+    for (int i = tid; i < n; i += PCH_THREADS) {
+        if (k0 == 0) { d[i] = S[(size_t)i * n + i]; pv[i] = i; } else { d[i] = dg[i]; pv[i] = piv[i]; }
+    }
+    __syncthreads();
+    if (k0 == 0 && tid == 0) { double m = 0.0; for (int i = 0; i < n; i++) m = fmax(m, d[i]); dctl[0] = tau_rel * m; }
+    __syncthreads();
+    const double tau = dctl[0];
+    int rank = -1;
+    const int k1 = min(n, k0 + PCH_NB);
+    for (int k = k0; k < k1; k++) {
+        double best = -1.0; int bi = k;
+        for (int i = k + tid; i < n; i += PCH_THREADS) if (d[i] > best) { best = d[i]; bi = i; }
+        const double wm = wave_max(best);
+        const unsigned long long who = __ballot(best == wm);
+        const int src = __ffsll((long long)who) - 1;
+        const int wi = __builtin_amdgcn_readlane(bi, src);
+        if (ln == 0) { wmax[wv] = wm; widx[wv] = wi; }
+        __syncthreads();
+        if (tid == 0) {
+            double m = wmax[0]; int j = widx[0];
+            for (int q = 1; q < PCH_THREADS / 64; q++) if (wmax[q] > m) { m = wmax[q]; j = widx[q]; }
+            s_j = (m > tau && m > 0.0) ? j : -1;
+        }
+        __syncthreads();
+        const int j = s_j;
+        if (j < 0) { rank = k; break; }
+        if (j != k) {
+            // symmetric swap k <-> j of S (rows, then columns), the same column swap in the rows of G written so far
+            for (int i = tid; i < n; i += PCH_THREADS) { const double a = S[(size_t)k * n + i], b = S[(size_t)j * n + i]; S[(size_t)k * n + i] = b; S[(size_t)j * n + i] = a; }
+            __syncthreads();
+            for (int i = tid; i < n; i += PCH_THREADS) { const double a = S[(size_t)i * n + k], b = S[(size_t)i * n + j]; S[(size_t)i * n + k] = b; S[(size_t)i * n + j] = a; }
+            for (int c = tid; c < k; c += PCH_THREADS) { double* row = G + (size_t)c * n; const double a = row[k], b = row[j]; row[k] = b; row[j] = a; }
+            if (tid == 0) { const double t = d[k]; d[k] = d[j]; d[j] = t; const int q = pv[k]; pv[k] = pv[j]; pv[j] = q; }
+            __syncthreads();
+        }
+        if (tid < k - k0) lk[tid] = G[(size_t)(k0 + tid) * n + k];
+        __syncthreads();
+        const double lkk = sqrt(d[k]);
+        const double inv = 1.0 / lkk;
+        const int np = k - k0;
+        double* rowk = G + (size_t)k * n;
+        for (int i = tid; i < n; i += PCH_THREADS) {
+            double v = 0.0;
+            if (i > k) {
+                double s0 = S[(size_t)k * n + i];
+                for (int c = 0; c < np; c++) s0 -= G[(size_t)(k0 + c) * n + i] * lk[c];
+                v = s0 * inv;
+                d[i] -= v * v;
+            } else if (i == k) v = lkk;
+            rowk[i] = v;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += PCH_THREADS) { dg[i] = d[i]; piv[i] = pv[i]; }
+    if (rank < 0 && k1 == n) rank = n;
+    if (rank >= 0) {
+        for (int c = rank; c < n; c++) for (int i = tid; i < n; i += PCH_THREADS) G[(size_t)c * n + i] = 0.0;
+        if (tid == 0) ctl[0] = rank;
+    }
+}
+
+// trailing update after a panel: S[i][j] -= sum_{c in panel} G[c][i] G[c][j] for i, j >= k1 (both triangles), 64 x 64 tiles
+__global__ __launch_bounds__(256) void k_pchol_syrk(double* __restrict__ S, int n, const double* __restrict__ G, const int* __restrict__ ctl, int k0) {
+    if (ctl[0] >= 0) return;
+    const int k1 = k0 + PCH_NB;
+    __shared__ double Ai[PCH_NB][64], Aj[PCH_NB][64];
+    const int ti = k1 + blockIdx.y * 64, tj = k1 + blockIdx.x * 64;
+    for (int e = threadIdx.x; e < PCH_NB * 64; e += 256) {
+        const int c = e / 64, x = e % 64;
+        Ai[c][x] = ti + x < n ? G[(size_t)(k0 + c) * n + ti + x] : 0.0;
+        Aj[c][x] = tj + x < n ? G[(size_t)(k0 + c) * n + tj + x] : 0.0;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 4 x 4 micro-tile per thread
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
+#pragma unroll 4
+    for (int c = 0; c < PCH_NB; c++) {
+        double vi[4], vj[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) { vi[a] = Ai[c][ty * 4 + a]; vj[a] = Aj[c][tx * 4 + a]; }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc[a][b] += vi[a] * vj[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int i = ti + ty * 4 + a, j = tj + tx * 4 + b;
+            if (i < n && j < n) S[(size_t)i * n + j] -= acc[a][b];
+        }
+}
+
+// Block one-sided Jacobi on the r rows (length n) of G: one launch = one round-robin step over BLOCKS of JB rows, one
+// workgroup per block pair. The workgroup holds its 2 JB rows in registers, forms their Gram matrix (2 JB x 2 JB) with one
+// block reduction, diagonalises it in LDS (cyclic two-sided Jacobi by one wave, rotations accumulated in U), and replaces the
+// rows by U^T rows: afterwards the 2 JB rows are mutually orthogonal. (r / JB - 1) launches per sweep instead of r - 1; a
+// resident-grid version with one launch per solve was measured and dropped: a barrier or a flag across the 8 XCDs costs
+// 60 - 90 us, an order of magnitude more than a launch boundary.)
+constexpr int JB = 4;            // rows per block
+constexpr int JB2 = 2 * JB;
+#ifndef JB_INNER
+#define JB_INNER 1
+#endif
+template <int EPT>               // elements per thread and row: n <= 256 * EPT
+__global__ __launch_bounds__(JAC_THREADS) void k_jacobi_block(double* __restrict__ G, int r, int n, int nbpad, int s, double tol, int* rotated) {
+    __shared__ double part[JAC_THREADS / 64][JB2 * (JB2 + 1) / 2];
+    __shared__ double M[JB2][JB2 + 1], U[JB2][JB2 + 1];
+    __shared__ double rc[JB], rs[JB];
+    __shared__ int s_work;
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    int bp, bq;
+    rr_pair(nbpad, s, blockIdx.x, bp, bq);
+    int rows[JB2];
+#pragma unroll
+    for (int k = 0; k < JB; k++) { rows[k] = bp * JB + k; rows[JB + k] = bq * JB + k; }
+    double x[JB2][EPT];
+#pragma unroll
+    for (int k = 0; k < JB2; k++)
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int i = tid + e * JAC_THREADS;
+            x[k][e] = (rows[k] < r && i < n) ? G[(size_t)rows[k] * n + i] : 0.0;
+        }
+    // Gram matrix of the 2 JB rows
+    {
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < JB2; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) {
+                double v = 0.0;
+#pragma unroll
+                for (int e = 0; e < EPT; e++) v += x[a][e] * x[b][e];
+                v = wave_sum(v);
+                if (ln == 0) part[wv][idx] = v;
+                idx++;
+            }
+    }
+    __syncthreads();
+    if (tid < JB2 * (JB2 + 1) / 2) {
+        int a = 0, b = tid;
+        while (b >= a + 1) { b -= a + 1; a++; }
+        const double v = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+        M[a][b] = v; M[b][a] = v;
+    }
+    if (tid < JB2 * JB2) U[tid / JB2][tid % JB2] = (tid / JB2 == tid % JB2) ? 1.0 : 0.0;
+    __syncthreads();
+    if (tid == 0) {
+        int work = 0;
+        for (int a = 0; a < JB2; a++) for (int b = 0; b < a; b++) if (M[a][a] != 0.0 && M[b][b] != 0.0 && M[a][b] * M[a][b] > tol * tol * M[a][a] * M[b][b]) work = 1;
+        s_work = work;
+        if (work) atomicAdd(rotated, 1);
+    }
+    __syncthreads();
+    if (!s_work) return;
+    // cyclic two-sided Jacobi on M by the first wave: JB disjoint rotations per step (round-robin over 2 JB indices)
+    if (wv == 0) {
+        for (int sw = 0; sw < JB_INNER; sw++) {   // an inexact inner diagonalisation could only cost outer sweeps (measured: none, even with one inner sweep)
+            bool any = false;
+            for (int st = 0; st < JB2 - 1; st++) {
+                if (ln < JB) {
+                    int p, q;
+                    rr_pair(JB2, st, ln, p, q);
+                    const double app = M[p][p], aqq = M[q][q], apq = M[p][q];
+                    double c = 1.0, sn = 0.0;
+                    if (apq != 0.0 && apq * apq > 1e-32 * fabs(app * aqq)) {
+                        const double zeta = (aqq - app) / (2.0 * apq);
+                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        c = 1.0 / sqrt(1.0 + t * t); sn = c * t;
+                    }
+                    rc[ln] = c; rs[ln] = sn;
+                }
+                wave_lds_fence();
+                bool rot = false;
+                for (int k = 0; k < JB; k++) rot |= rs[k] != 0.0;
+                any |= rot;
+                if (rot) {
+                    // rows: M <- J^T M ; then columns: M <- M J ; U <- U J   (lane = (pair k, column j))
+                    const bool act = ln < JB * JB2;
+                    const int k = act ? ln / JB2 : 0, j = ln % JB2;
+                    int p, q;
+                    rr_pair(JB2, st, k, p, q);
+                    const double c = rc[k], sn = rs[k];
+                    const double mp = M[p][j], mq = M[q][j];     // a lane reads and writes its own two entries: no fence between
+                    if (act) { M[p][j] = c * mp - sn * mq; M[q][j] = sn * mp + c * mq; }
+                    wave_lds_fence();
+                    const double cp = M[j][p], cq = M[j][q], up = U[j][p], uq = U[j][q];
+                    if (act) {
+                        M[j][p] = c * cp - sn * cq; M[j][q] = sn * cp + c * cq;
+                        U[j][p] = c * up - sn * uq; U[j][q] = sn * up + c * uq;
+                    }
+                    wave_lds_fence();
+                }
+            }
+            if (!any) break;
+        }
+    }
+    __syncthreads();
+    // rows <- U^T rows  (new row a = sum_b U[b][a] old row b)
+    double u[JB2][JB2];
+#pragma unroll
+    for (int a = 0; a < JB2; a++)
+#pragma unroll
+        for (int b = 0; b < JB2; b++) u[a][b] = U[b][a];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int i = tid + e * JAC_THREADS;
+        if (i >= n) continue;
+#pragma unroll
+        for (int a = 0; a < JB2; a++) {
+            if (rows[a] >= r) continue;
+            double v = 0.0;
+#pragma unroll
+            for (int b = 0; b < JB2; b++) v += u[a][b] * x[b][e];
+            G[(size_t)rows[a] * n + i] = v;
+        }
+    }
+}
+
+// eigen-pairs from the orthogonalised rows: lambda_i = |g_i|^2, v_i = g_i / |g_i| scattered back through the pivoting
+// (rows >= rank: lambda = 0, v = 0 - they are below every cut and only ever multiplied by zero)
+__global__ __launch_bounds__(JAC_THREADS) void k_eig_from_rows(const double* __restrict__ G, const int* __restrict__ piv, const int* __restrict__ rank, int n,
+                                                               double* __restrict__ V, double* __restrict__ ev) {
+    __shared__ double sh[4];
+    const int i = blockIdx.x;
+    const double* g = G + (size_t)i * n;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < n; k += JAC_THREADS) s += g[k] * g[k];
+    s = block_sum_256(s, sh);
+    const bool live = i < *rank && s > 0.0;
+    const double inv = live ? 1.0 / sqrt(s) : 0.0;
+    for (int k = threadIdx.x; k < n; k += JAC_THREADS) V[(size_t)i * n + piv[k]] = live ? g[k] * inv : 0.0;
+    if (threadIdx.x == 0) ev[i] = live ? s : 0.0;
+}
+
 // G = sym(A block), V = I
 __global__ void k_jacobi_init(const double* __restrict__ A, long long lda, int n, double* G, double* V, int lower_only) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
