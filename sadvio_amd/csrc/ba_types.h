@@ -71,7 +71,7 @@ struct Tile {
     int win_tile0, win_ntiles;  // the window's tile range (for summing per-tile partials)
     int ld;           // 0: S packed lower triangle; else full row-major with this leading dimension
     long long S_off;
-    int chunk0, chunk1;   // slice of the chunk tables (lm_kernels.h): <= 16 landmarks and <= 64 observations per chunk
+    int chunk0, chunk1;   // slice of the chunk tables (lm_kernels.h): <= 12 landmarks and <= 64 observations per chunk
 };
 
 struct PriorDev {

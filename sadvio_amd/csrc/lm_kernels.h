@@ -15,7 +15,7 @@
 //   k_diag        key-frame major: sum Jp^T Jp and sum Jp^T r over the observations of one key-frame, in registers
 //   k_backsub_lm  one lane per landmark: delta_l = -M^-1 sum Jl^T (r + Jp dp); the model cost change of the landmark's
 //                 residual blocks from sums accumulated in the same pass; candidate cost in a second residual-only loop
-// The tiles are those of k_build; a tile's landmarks are cut into chunks of <= 16 landmarks and <= 64 observations
+// The tiles are those of k_build; a tile's landmarks are cut into chunks of <= 12 landmarks and <= 64 observations
 // (chunk tables built with the tiles).
 #pragma once
 #include "kernels.h"
@@ -26,21 +26,7 @@ constexpr int LM_CHUNK = 12;            // landmarks per MFMA chunk (12 x 5 obse
 constexpr int LM_KS = 3 * LM_CHUNK + 2; // strip row stride (doubles): 3 columns per landmark + 2 (bank spread); 32 x 38 doubles = 9.5 KB per wave
 constexpr int LM_ELIM = 9;              // per landmark: L (6, lower, row-major) | w = L^T g_l (3)
 
-// residual + Jacobians of observation o of a landmark at pw from the LDS tables (plain path: no pseudo-observations, no loss)
-template <int FACTOR, bool WANT_J>
-__device__ __forceinline__ void lm_linearize(const DevPtrs& P, const double* tab, const double* ct, int o, const double* pw, double* r,
-                                             double* Jp, double* Jl) {
-    if (FACTOR == 0) {
-        const double* m = P.obs_meas + 2 * (long long)o;
-        pixel_factor<WANT_J>(tab, ct, ct + 4, pw, m[0], m[1], ct[16], r, Jp, Jl);
-    } else {
-        const double* m = P.obs_meas + 3 * (long long)o;
-        const double b[3] = {m[0], m[1], m[2]};
-        angular_factor<WANT_J>(tab, ct + 4, pw, b, ct[16], r, Jp, Jl);
-    }
-}
-
-// the per-observation fields, loaded ahead of their use
+// the per-observation fields, loaded ahead of their use (plain path: no pseudo-observations, no loss function)
 struct ObsIn { int sl, cam; double m[3]; };
 template <int FACTOR>
 __device__ __forceinline__ ObsIn lm_load_obs(const DevPtrs& P, int o, int oe) {
