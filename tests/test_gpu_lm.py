@@ -77,3 +77,24 @@ def test_robust_loss_keeps_the_latency_kernels(backend_cls, oracle_lib, lm_env):
     assert "k_build" in names and "k_elim" not in names
     ref = oracle_lib.solve(w, opts)
     assert np.abs(res[1]["pose"] - ref["pose"]).max() <= TOL
+
+
+def test_large_batch_takes_the_throughput_path_by_itself_and_agrees_with_the_latency_path(backend_cls, lm_env):
+    """BASELINE config 2 at full size, 9 windows per submission (72 000 landmarks >= the 65 536 threshold): the throughput kernels
+    run without being asked, and every window's solve equals the one the latency kernels produce (same iterations, costs to
+    1e-12, deltas to 1e-9) - the size-independent property at the size the bench measures."""
+    os.environ.pop("SADVIO_LM", None)
+    ws = [make_window(seed=20250404 + i) for i in range(3)]
+    ws = [ws[i % 3] for i in range(9)]
+    opts = capi.reference_options()
+    fast, names = solve(backend_cls, ws, opts, profile=True)
+    assert {"k_elim", "k_diag", "k_build_obs", "k_backsub_lm"} <= names and "k_build" not in names
+    lm_env("0")
+    slow, names0 = solve(backend_cls, ws[:3], opts, profile=True)
+    assert "k_build" in names0
+    for k, (s, d, tr) in enumerate(fast):
+        s0, d0, tr0 = slow[k % 3]
+        assert (s.iterations, s.termination, s.num_successful_steps) == (s0.iterations, s0.termination, s0.num_successful_steps)
+        assert np.isclose(s.final_cost, s0.final_cost, rtol=1e-12)
+        assert np.allclose(tr[:, 0], tr0[:, 0], rtol=1e-11)
+        assert np.abs(d["pose"] - d0["pose"]).max() <= 1e-9 and np.abs(d["lmk"] - d0["lmk"]).max() <= 1e-8
