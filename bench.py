@@ -163,6 +163,8 @@ def main():
         traffic, traffic_src = None, None
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+            if "batched" in os.path.basename(f):
+                continue   # the 64-window profile (scripts/prof_batched.sh) belongs to the `batched` object
             try:
                 kk = json.load(open(f))["kernels"].get(dom, {})
                 if "hbm_traffic_bytes_per_launch" in kk and len(wins) == 1:
@@ -203,6 +205,19 @@ def main():
 
             # >= 65 536 landmarks in a submission: the throughput kernels (sadvio_amd/csrc/lm_kernels.h) take over by themselves
             batched = batch_leg(args.batch)
+            # measured HBM traffic of one LM step of the 64-window batch (PMC passes of scripts/prof_batched.sh, committed under
+            # profiles/): the throughput kernels' FETCH + WRITE bytes per launch, one launch of each per step
+            try:
+                prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*batched64_summary.json")))[-1]
+                kern = json.load(open(prof))["kernels"]
+                per_step = sum(kern[k]["hbm_traffic_bytes_per_launch"] for k in ("k_elim", "k_diag", "k_build_obs", "k_solve", "k_backsub_lm") if k in kern)
+                if args.batch == 64 and per_step > 0:
+                    step_s = 1e-3 * batched["ms_per_solve_batch"] / GN_ITERS
+                    batched["hbm_traffic"] = {"bytes_per_lm_step": int(per_step), "GBps": round(per_step / step_s / 1e9, 1),
+                                              "frac_of_hbm_peak": round(per_step / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                                              "source": os.path.relpath(prof, ROOT)}
+            except Exception:
+                pass
             if args.batch_large > args.batch:
                 batched["larger"] = batch_leg(args.batch_large)   # the fixed ~40 us of the per-window reduced solve spread over more windows
         # --- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores ---
