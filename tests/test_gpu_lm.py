@@ -98,3 +98,28 @@ def test_large_batch_takes_the_throughput_path_by_itself_and_agrees_with_the_lat
         assert np.isclose(s.final_cost, s0.final_cost, rtol=1e-12)
         assert np.allclose(tr[:, 0], tr0[:, 0], rtol=1e-11)
         assert np.abs(d["pose"] - d0["pose"]).max() <= 1e-9 and np.abs(d["lmk"] - d0["lmk"]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("huber", [0.0, 1.0])
+def test_multi_round_tiles_on_the_latency_kernels(backend_cls, oracle_lib, lm_env, huber):
+    """Large batches that cannot take the throughput kernels (robust loss, kept landmarks) run k_build with several rounds of
+    landmarks per tile (MFMA accumulators carried across the rounds): forced here with SADVIO_TILE_ROUNDS on a small window."""
+    lm_env("0")
+    old = os.environ.get("SADVIO_TILE_ROUNDS")
+    os.environ["SADVIO_TILE_ROUNDS"] = "3"
+    try:
+        w = make_window(n_kf=8, n_lmk=1200, obs_per_lmk=5, seed=31)
+        opts = capi.reference_options(); opts.huber_a = huber
+        (res,), names = solve(backend_cls, [w], opts, profile=True)
+    finally:
+        if old is None:
+            os.environ.pop("SADVIO_TILE_ROUNDS", None)
+        else:
+            os.environ["SADVIO_TILE_ROUNDS"] = old
+    assert "k_build" in names
+    ref = oracle_lib.solve(w, opts)
+    rs = ref["summary"]
+    s, d, tr = res
+    assert (s.iterations, s.termination) == (rs.iterations, rs.termination)
+    assert_trace_matches(tr, ref["log"], rs.termination)
+    assert np.abs(d["pose"] - ref["pose"]).max() <= TOL and np.abs(d["lmk"] - ref["lmk"]).max() <= TOL
