@@ -2224,11 +2224,15 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                             const size_t lds_t = sizeof(double) * (size_t)(CH_TS + WD) * WDS;
                             const size_t lds_s = sizeof(double) * 2 * (size_t)CH_TS * WDS;
                             (void)hipFuncSetAttribute((const void*)k_wchol_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
+                            (void)hipFuncSetAttribute((const void*)k_wchol_diag16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * wd16_lds_doubles() + 64));
+                            const bool wd16 = !getenv("SADVIO_WD_OLD");   // the 96 x 96 diagonal blocks on 16 x 16 MFMA tiles (chol16.h); the 6-column LDS solver for A/B runs
                             (void)hipFuncSetAttribute((const void*)k_wchol_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
                             (void)hipFuncSetAttribute((const void*)k_wchol_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
                             (void)hipFuncSetAttribute((const void*)k_wchol_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * WD * WDS));
                             int st = 0;
                             for (int c0 = 0; c0 < N; c0 += WD, st++) {
+                                if (wd16) hipLaunchKernelGGL(k_wchol_diag16, dim3(1), dim3(SOLVE_THREADS), sizeof(double) * wd16_lds_doubles() + 64, h->stream, Sw, (long long)d.ld, yw, Mw + (size_t)st * WD * WD, N, c0, info, skip);
+                                else
                                 hipLaunchKernelGGL(k_wchol_diag, dim3(1), dim3(SOLVE_THREADS), lds_d, h->stream, Sw, (long long)d.ld, yw, Mw + (size_t)st * WD * WD, N, c0, info, skip);
                                 const int m = N - (c0 + WD);
                                 if (m > 0) {

@@ -283,7 +283,9 @@ __device__ __forceinline__ void c16_to_h(double* A, int I, int J, int ln) {
 // Solve [S] x = rhs for the tile-packed image A (N columns, rhs = row N; diagonal tiles already symmetric). On return
 // xs[0 .. N) = S^-1 rhs. Every thread of the 512-thread workgroup must call it. pub: C16_WORK doubles; yv: 16 * nb
 // doubles. Returns false if the solution is not finite (a non-positive pivot). ts (may be null): phase timestamps.
-template <int GATHER = 1>
+// SOLVE = false stops after the factorisation: the panel tiles hold L_IJ, the diagonal tiles L_JJ^-T, the tiles of row N the
+// forward-substituted right-hand side (L^-1 rhs)^T in their first rows — what the wide-panel dense solver takes (dense_chol.h).
+template <int GATHER = 1, bool SOLVE = true>
 __device__ __forceinline__ bool c16_solve(double* A, int N, double* xs, double* pub, double* yv, long long* ts, long long* dbg = nullptr) {
     const int tid = threadIdx.x, ln = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = blockDim.x >> 6;
@@ -360,13 +362,14 @@ __device__ __forceinline__ bool c16_solve(double* A, int N, double* xs, double* 
                     c16_store(ct, ln, C + C2);
                     J += nbw;
                 }
-                if (kb >= 1)
+                if (SOLVE && kb >= 1)
                     for (int Ic = kb + (nbw - 1 - bw); Ic < nb; Ic += nbw) c16_to_h(A, Ic, kb - 1, ln);   // last waves first: they got fewer tiles above
             }
         }
         __syncthreads();
         if (ts && tid == 0 && kb < 8) ts[2 + 2 * kb] = clock64();
     }
+    if (!SOLVE) { __syncthreads(); return true; }
     // the last block column's panel (at most the tile row of the right-hand side when N is a multiple of 16)
     for (int Ic = nbc + wv; Ic < nb; Ic += nwv) c16_to_h(A, Ic, nbc - 1, ln);
     // ---- back-substitution. z_c = H[N][c] = (L_JJ^-T y_J)[c]; x_I = z_I once the blocks above are in; then every thread

@@ -16,6 +16,7 @@
 // the co-visibility structure; = N for a dense system): the work per step is O(bw^2), not O(N^2), for the
 // block-banded systems of long trajectories (configs 4 / 5).
 #pragma once
+#include "chol16.h"
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -855,6 +856,100 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_diag(double* __restrict
         __syncthreads();
     }
     for (int e = tid; e < WD * WD; e += nt) Mg[e] = Ml[(e / WD) * (WD + 1) + (e % WD)];
+}
+
+// ---- the 96 x 96 diagonal block on 16 x 16 MFMA tiles (chol16.h) -------------------------------------------------------
+// C(16 x 16) = sum over the listed (A, B) tile pairs of A B, tiles column-major in LDS (element (r, c) at c * 16 + r); the
+// result comes back in the MFMA accumulator layout: register s of lane (lr = lane % 16, lk = lane / 16) = C[lk + 4 s][lr].
+// TA: A is given transposed (the tile holds A^T).
+template <bool TA>
+__device__ __forceinline__ c16_d4 wd_tile_mma(const double* At, const double* Bt, c16_d4 acc, int lr, int lk) {
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        const int k = 4 * kk + lk;
+        const double a = TA ? At[lr * 16 + k] : At[k * 16 + lr];   // A[row lr][col k]
+        const double b = Bt[lr * 16 + k];                           // B[row k][col lr]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ void wd_tile_store(double* Ct, c16_d4 acc, int lr, int lk, double scale) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) Ct[lr * 16 + lk + 4 * s] = scale * acc[s];
+}
+
+constexpr int WD_T = WD / 16;   // 6 tile rows
+// LDS: image of the 96-column system + rhs row | chol16 exchange areas | M image (lower block triangle, 21 tiles) | one scratch tile per wave
+__host__ __device__ constexpr size_t wd16_lds_doubles() {
+    return (size_t)c16_size(WD) + WD + C16_WORK + 16 * (WD_T + 1) + (size_t)(WD_T * (WD_T + 1) / 2) * 256 + (size_t)(SOLVE_THREADS / 64) * 256;
+}
+__global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_diag16(double* __restrict__ A, long long ld, double* __restrict__ y,
+                                                                double* __restrict__ Mg, int N, int c0, int* info, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    if (*info != 0) return;
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6, nwv = SOLVE_THREADS / 64;
+    double* Im = (double*)smem;                    // tile-packed image, WD columns + the right-hand-side row
+    double* xs = Im + c16_size(WD);
+    double* pub = xs + WD;
+    double* yv = pub + C16_WORK;
+    double* Mi = yv + 16 * (WD_T + 1);             // M = L^-1, tile (I, J), I >= J, at c16_tile(I, J) * 256
+    double* scr = Mi + (size_t)(WD_T * (WD_T + 1) / 2) * 256 + (size_t)wv * 256;
+    // load: lower triangle of the block (identity beyond N), the rhs entries as row WD, zeros elsewhere
+    for (int e = tid; e < c16_size(WD); e += SOLVE_THREADS) Im[e] = 0.0;
+    __syncthreads();
+    for (int gb = tid; gb < WD * (WD + 1) / 2; gb += 4 * SOLVE_THREADS) {   // four independent loads in flight per thread
+        double v[4]; int ii[4], jj[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int g = gb + u * SOLVE_THREADS;
+            ii[u] = -1;
+            if (g < WD * (WD + 1) / 2) {
+                int i, j;
+                tri_decode(g, i, j);
+                ii[u] = i; jj[u] = j;
+                v[u] = (c0 + i < N) ? A[(long long)(c0 + i) * ld + c0 + j] : (i == j ? 1.0 : 0.0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (ii[u] >= 0) Im[c16_index(ii[u], jj[u])] = v[u];
+    }
+    for (int j = tid; j < WD; j += SOLVE_THREADS) Im[c16_index(WD, j)] = (c0 + j < N) ? y[c0 + j] : 0.0;
+    __syncthreads();
+    c16_symmetrize(Im, WD_T + 1);
+    __syncthreads();
+    (void)c16_solve<1, false>(Im, WD, xs, pub, yv, nullptr);
+    // forward-substituted rhs: first rows of the tiles of row WD
+    for (int j = tid; j < WD && c0 + j < N; j += SOLVE_THREADS) y[c0 + j] = Im[(c16_tile(WD_T, j >> 4) << 8) + (j & 15) * 16];
+    // M = L^-1 by block anti-diagonals: M_II = L_II^-1 (the diagonal tile holds its transpose), M_IJ = -L_II^-1 sum_{K=J}^{I-1} L_IK M_KJ
+    const int lr = ln & 15, lk = ln >> 4;
+    for (int e = tid; e < WD_T * 256; e += SOLVE_THREADS) {
+        const int I = e >> 8, q = e & 255, r = q & 15, c = q >> 4;
+        Mi[(c16_tile(I, I) << 8) + c * 16 + r] = r >= c ? Im[(c16_tile(I, I) << 8) + r * 16 + c] : 0.0;   // transpose, exact zeros above the diagonal
+    }
+    __syncthreads();
+    for (int d = 1; d < WD_T; d++) {
+        for (int J = wv; J + d < WD_T; J += nwv) {
+            const int I = J + d;
+            c16_d4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int K = J; K < I; K++) acc = wd_tile_mma<false>(Im + (c16_tile(I, K) << 8), Mi + (c16_tile(K, J) << 8), acc, lr, lk);
+            wd_tile_store(scr, acc, lr, lk, 1.0);
+            wave_lds_fence();
+            c16_d4 m = {0.0, 0.0, 0.0, 0.0};
+            m = wd_tile_mma<true>(Im + (c16_tile(I, I) << 8), scr, m, lr, lk);       // L_II^-1 T: the tile holds L_II^-T
+            wd_tile_store(Mi + (c16_tile(I, J) << 8), m, lr, lk, -1.0);
+            wave_lds_fence();
+        }
+        __syncthreads();
+    }
+    bool bad = false;
+    for (int e = tid; e < WD * WD; e += SOLVE_THREADS) {
+        const int i = e / WD, j = e - i * WD;
+        const double v = j <= i ? Mi[(c16_tile(i >> 4, j >> 4) << 8) + (j & 15) * 16 + (i & 15)] : 0.0;
+        if (!(fabs(v) < 1e300)) bad = true;    // a non-positive pivot turned into NaN / inf
+        Mg[e] = v;
+    }
+    if (bad) *info = c0 + 1;
 }
 
 // X = A[s .. N, c0 .. c0 + WD) * M^T, 64 rows per workgroup
