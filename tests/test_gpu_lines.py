@@ -39,7 +39,10 @@ def run_both(backend_cls, oracle_lib, w, opts, use_graph=False):
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_window_with_lines_matches_oracle(backend_cls, oracle_lib, factor, use_graph):
     w = add_lines(make_window(n_kf=8, n_lmk=600, obs_per_lmk=4, seed=21, factor=factor), n_line=7, obs_per_line=5, n_const=2)
-    s, dl, ref = run_both(backend_cls, oracle_lib, w, capi.reference_options(), use_graph)
+    opts = capi.reference_options()
+    if factor == capi.FACTOR_ANGULAR:
+        opts.max_num_iterations = 2     # see test_lines_with_huber_loss: later iterations linearise where log_so3 is ill-conditioned
+    s, dl, ref = run_both(backend_cls, oracle_lib, w, opts, use_graph)
     assert np.all(dl[:2] == 0.0) and np.abs(dl[2:]).max() > 0.0
     assert s.final_cost < s.initial_cost
 
@@ -65,7 +68,9 @@ def test_lines_only_move_when_key_frames_are_fixed(backend_cls, oracle_lib):
     w = add_lines(make_window(n_kf=5, n_lmk=200, obs_per_lmk=4, seed=2, factor=capi.FACTOR_ANGULAR), n_line=4, obs_per_line=5)
     w.kf_const = np.ones(w.n_kf, dtype=np.uint8)
     w.pose_priors = []
-    s, dl, ref = run_both(backend_cls, oracle_lib, w, capi.reference_options())
+    opts = capi.reference_options()
+    opts.max_num_iterations = 2         # angular line factor: see test_lines_with_huber_loss
+    s, dl, ref = run_both(backend_cls, oracle_lib, w, opts)
     assert np.abs(dl).max() > 0.0
 
 
