@@ -1271,17 +1271,31 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         // J^T J and J^T r of the IMU factors were formed by k_imu_eval<true> together with the position of every entry in
         // this window's reduced system: one coalesced read + one LDS atomic per entry here (the products themselves,
         // with their dependent global loads, cost 16 us inside this kernel)
-        for (int it = tid; it < n_imu * 324; it += blockDim.x) {
-            const int k = it / 324, e = it - 324 * k;
-            const double* row = P.imu_scratch + (long long)(W.imu_begin + k) * IMU_ROW;
-            const int ix = (int)row[IMU_IX + e];
-            if (ix < 0) continue;
-            const double v = row[IMU_H + e];
-            const int ca = ix >> 16, cb = ix & 0xffff;
-            if (e < 300) {
-                atomic_add_f64(&A[aidx(ca, cb)], v);
-                if (ca == cb) atomic_add_f64(&hd[ca], v);
-            } else { atomic_add_f64(&y[ca], v); atomic_add_f64(&gf[ca], v); }
+        for (int it0 = tid; it0 < n_imu * 324; it0 += 8 * blockDim.x) {   // all loads of eight items in flight before the first LDS atomic
+            double ixd[8], vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int it = it0 + u * blockDim.x;
+                ixd[u] = -1.0; vv[u] = 0.0;
+                if (it < n_imu * 324) {
+                    const int k = it / 324, e = it - 324 * k;
+                    const double* row = P.imu_scratch + (long long)(W.imu_begin + k) * IMU_ROW;
+                    ixd[u] = row[IMU_IX + e]; vv[u] = row[IMU_H + e];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int it = it0 + u * blockDim.x;
+                const int ix = (int)ixd[u];
+                if (ix < 0) continue;
+                const int e = it % 324;
+                const double v = vv[u];
+                const int ca = ix >> 16, cb = ix & 0xffff;
+                if (e < 300) {
+                    atomic_add_f64(&A[aidx(ca, cb)], v);
+                    if (ca == cb) atomic_add_f64(&hd[ca], v);
+                } else { atomic_add_f64(&y[ca], v); atomic_add_f64(&gf[ca], v); }
+            }
         }
         // bias random walk: item = (factor, axis, ba|bg): Jacobians are -/+ s I
         for (int it = tid; it < n_imu * 6; it += blockDim.x) {
