@@ -450,11 +450,12 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
     } else {
         // few tiles: every workgroup recomputes it (cheaper than one more launch on the critical path):
         // totals of the previous slot = window part (k_solve) + the tiles' k_backsub partials
+        // the window record and the previous state are loaded before the barrier: their latency runs under the partial sums
+        IterAcc a = P.acc[(long long)T.w * P.state_stride + slot - 1];
+        const LmState prev = P.states[(long long)T.w * P.state_stride + slot - 1];
         if (wv == 0) wave_sum_backsub_partials(P, (slot - 1) & 1, T.w, T.win_tile0, T.win_ntiles, ln, s_part);
         __syncthreads();
-        IterAcc a = P.acc[(long long)T.w * P.state_stride + slot - 1];
         a.cand_cost += s_part[0]; a.mcc += s_part[1]; a.step_norm2 += s_part[2]; a.cand_norm2 += s_part[3];
-        const LmState prev = P.states[(long long)T.w * P.state_stride + slot - 1];
         st = lm_decide(prev, a, P.o);
         __syncthreads();  // s_part is reused below
         if (T.first_of_window && tid == 0) { P.states[(long long)T.w * P.state_stride + slot] = st; trace_write(P, T.w, slot - 1, prev, a, st); }
@@ -1201,7 +1202,19 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     const int cur = st.cur;
     const double* xp = P.xp + (long long)cur * P.xp_stride;
     const int n_imu = W.imu_end - W.imu_begin;
+    double early_cost = 0.0, early_fixed = 0.0, early_gm = 0.0;
     if (MODE != 2) {
+    // window totals of the linearisation (the tiles' k_build partials / the ranks' of a sharded window): loaded first, their
+    // latency runs under the copy of S
+    if (P.world > 1) {
+        const double* rb = P.rank_b + (long long)w * P.world * 4;
+        for (int r = tid; r < P.world; r += blockDim.x) { early_cost += rb[4 * r]; early_fixed += rb[4 * r + 1]; early_gm = fmax(early_gm, rb[4 * r + 2]); }
+    } else {
+        const TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + W.tile_begin;
+        for (int t = tid; t < W.tile_end - W.tile_begin; t += blockDim.x) {
+            early_cost += ta[t].lin_cost; early_fixed += ta[t].fixed_cost; early_gm = fmax(early_gm, ta[t].gmax);
+        }
+    }
     // load + clear the global accumulator: S is kept in HBM in the same packed lower-triangular layout as in
     // LDS, so this is a linear, fully coalesced 16-byte copy; all loads are issued before the first use.
     if (!BIG) {
@@ -1391,16 +1404,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         pc[0] = 0.0;
     }
     // window totals of the linearisation: tiles' k_build partials + the pose-only factors evaluated here
-    double gm = 0.0;
-    if (P.world > 1) {
-        const double* rb = P.rank_b + (long long)w * P.world * 4;
-        for (int r = tid; r < P.world; r += blockDim.x) { cost_part += rb[4 * r]; fixed_part += rb[4 * r + 1]; gm = fmax(gm, rb[4 * r + 2]); }
-    } else {
-        const TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + W.tile_begin;
-        for (int t = tid; t < W.tile_end - W.tile_begin; t += blockDim.x) {
-            cost_part += ta[t].lin_cost; fixed_part += ta[t].fixed_cost; gm = fmax(gm, ta[t].gmax);
-        }
-    }
+    double gm = early_gm;
+    cost_part += early_cost; fixed_part += early_fixed;   // the tiles' partials were loaded at the top of the kernel
     __syncthreads();
     // gradient tolerance (TrustRegionMinimizer::GradientToleranceReached) on the gradient at x
     for (int i = tid; i < Np; i += blockDim.x) gm = fmax(gm, fabs(gf[i]));
