@@ -365,7 +365,7 @@ struct DiagSeg { int w, kf, begin, end; };   // window, global key-frame (free),
 constexpr int DIAG_SEG = 2048;               // observations per workgroup (8 per lane: the 27-value reduction is paid once per workgroup)
 
 template <int FACTOR>
-__global__ __launch_bounds__(BUILD_THREADS, FACTOR == 0 ? 3 : 2) void k_diag(   // the bearing factor spills 188 B per lane at 168 VGPRs
+__global__ __launch_bounds__(BUILD_THREADS, 2) void k_diag(   // the bearing factor spills 188 B per lane at 168 VGPRs
     DevPtrs P, const DiagSeg* segs, const int* kf_lmk, const int* kf_cam, const double* kf_meas, int slot) {
     const DiagSeg sg = segs[blockIdx.x];
     const WinDev& W = P.win[sg.w];
