@@ -362,7 +362,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 3) void k_build_obs(DevPtrs P, int s
 // sums in registers over its share of the segment; one reduction per workgroup, then 39 global atomics (the diagonal block of
 // S, gred, gfull, hdiag). Independent of the landmark elimination.
 struct DiagSeg { int w, kf, begin, end; };   // window, global key-frame (free), slice of the key-frame-sorted observation list
-constexpr int DIAG_SEG = 2048;               // observations per workgroup (8 per lane: the 27-value reduction is paid once per workgroup)
+constexpr int DIAG_SEG = 4096;               // observations per workgroup (16 per lane: the 27-value reduction is paid once per workgroup, one workgroup per key-frame at config 2)
 
 template <int FACTOR>
 __global__ __launch_bounds__(BUILD_THREADS, 2) void k_diag(   // the bearing factor spills 188 B per lane at 168 VGPRs
