@@ -244,7 +244,7 @@ struct sadvio_ba_handle {
     DevBuf<unsigned char> d_lmk_const;
     DevBuf<int> d_lmk_ob, d_lmk_oe, d_obs_kf, d_obs_cam, d_tile_kf, d_tile_row;
     DevBuf<unsigned char> d_obs_slot, d_obs_lslot;
-    DevBuf<int> d_chunk_ob, d_chunk_lm;   // chunk tables of the throughput kernels (lm_kernels.h)
+    DevBuf<int> d_chunk_ob, d_chunk_lm, d_tile_perm;   // chunk tables of the throughput kernels (lm_kernels.h)
     DevBuf<int> d_jac_ints;               // pivoting / rank of the Cholesky-preconditioned Jacobi
     DevBuf<double> d_jac_dbl;             // its remaining diagonal + threshold
     DevBuf<int> d_kf_lmk, d_kf_cam;       // k_diag: landmark / camera of the observations sorted by key-frame (free key-frames only)
@@ -354,7 +354,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.lmk_red = h->d_lmk_red.p; P.kept_obs = h->d_kept_obs.p; P.n_kept = h->n_kept;
     P.dp_data = h->d_dp_data.p; P.dp_ints = h->d_dp_ints.p;
     P.sparse = h->d_sparse.p; P.sp_scratch = h->d_sp_scratch.p; P.sp_list = h->d_sp_list.p;
-    P.chunk_ob = h->d_chunk_ob.p; P.chunk_lm = h->d_chunk_lm.p; P.obs_lslot = h->d_obs_lslot.p; P.lm_elim = h->d_lm_elim.p;
+    P.chunk_ob = h->d_chunk_ob.p; P.chunk_lm = h->d_chunk_lm.p; P.tile_perm = h->d_tile_perm.p; P.obs_lslot = h->d_obs_lslot.p; P.lm_elim = h->d_lm_elim.p;
     P.lines = h->d_lines.p; P.lobs = h->d_lobs.p; P.xline = h->d_xline.p; P.line_scratch = h->d_line_scratch.p;
     P.xline_stride = 6LL * h->n_line_tot;
     P.n_xp = (long long)h->d_xp.n; P.n_xv = (long long)h->d_xv.n; P.n_xl = (long long)h->d_xl.n;
@@ -1024,6 +1024,19 @@ static int build_layout(sadvio_ba_handle* h) {
     h->up.add(h->d_chunk_ob.p, chunk_ob.data(), chunk_ob.size() * sizeof(int));
     h->up.add(h->d_chunk_lm.p, chunk_lm.data(), chunk_lm.size() * sizeof(int));
     h->up.add(h->d_obs_lslot.p, obs_lslot.data(), obs_lslot.size());
+    {
+        // launch order of the throughput kernels: longest tiles first (LPT), so that the last workgroups to start are short ones
+        std::vector<int> perm(h->tiles.size());
+        for (size_t i = 0; i < perm.size(); i++) perm[i] = (int)i;
+        if (want_lm && !getenv("SADVIO_NO_LPT"))
+            std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
+                return h->tiles[a].chunk1 - h->tiles[a].chunk0 > h->tiles[b].chunk1 - h->tiles[b].chunk0; });
+        if (getenv("SADVIO_DEBUG") && want_lm && !perm.empty())
+            fprintf(stderr, "[sadvio dbg] chunks per tile: largest %d, median %d, smallest %d\n", h->tiles[perm.front()].chunk1 - h->tiles[perm.front()].chunk0,
+                    h->tiles[perm[perm.size() / 2]].chunk1 - h->tiles[perm[perm.size() / 2]].chunk0, h->tiles[perm.back()].chunk1 - h->tiles[perm.back()].chunk0);
+        HIP_TRY(h->d_tile_perm.alloc(std::max<size_t>(perm.size(), 1)));
+        h->up.add(h->d_tile_perm.p, perm.data(), perm.size() * sizeof(int));
+    }
     if (getenv("SADVIO_DEBUG")) {
         int hist[32] = {0}, modes[3] = {0};
         for (auto& t : h->tiles) { hist[std::min(t.n_free, 31)]++; modes[t.lds_mode]++; }

@@ -62,6 +62,7 @@ struct DevPtrs {
     const int* dp_ints;
     const int* chunk_ob;      // [n_chunks + 1] first observation of each chunk (lm_kernels.h)
     const int* chunk_lm;      // [n_chunks + 1] first landmark of each chunk
+    const int* tile_perm;     // [n_tiles] launch order of the throughput kernels: tiles by decreasing chunk count
     const unsigned char* obs_lslot;  // [n_obs_tot] index of the observation's landmark inside its chunk
     double* lm_elim;          // [n_lmk_tot][9] per-landmark elimination record of k_elim
     const LineDev* lines;     // linexd landmarks: few, kept in the reduced system

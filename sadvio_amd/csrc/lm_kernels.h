@@ -60,7 +60,8 @@ __device__ __forceinline__ void lm_damped_inverse(const DevPtrs& P, const double
 template <int FACTOR>
 __global__ __launch_bounds__(BUILD_THREADS) void k_elim(DevPtrs P, int slot, int max_tile_kf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Tile T = P.tiles[blockIdx.x];
+    const int ti = P.tile_perm[blockIdx.x];   // largest tiles first (host: LPT order), so that the launch does not end on a long tile
+    const Tile T = P.tiles[ti];
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
     const LmState st = P.states[(long long)T.w * P.state_stride + slot];   // decided by k_decide (large batches)
     if (st.done) return;
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_elim(DevPtrs P, int slot, int
     if (tid == 0) {
         double cs = 0.0, fs = 0.0, gs = 0.0;
         for (int k = 0; k < BUILD_WAVES; k++) { cs += s_part[k * 4]; fs += s_part[k * 4 + 1]; gs = fmax(gs, s_part[k * 4 + 2]); }
-        TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + blockIdx.x;
+        TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + ti;
         ta->lin_cost = cs; ta->fixed_cost = fs; ta->gmax = gs;
     }
 }
@@ -179,7 +180,8 @@ __device__ __forceinline__ void lm_syrk_pass(const double* Zb, int lr, int lk, i
 template <int FACTOR>
 __global__ __launch_bounds__(BUILD_THREADS, 3) void k_build_obs(DevPtrs P, int slot, int max_tile_kf, int Rp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Tile T = P.tiles[blockIdx.x];
+    const int ti = P.tile_perm[blockIdx.x];   // largest tiles first (host: LPT order), so that the launch does not end on a long tile
+    const Tile T = P.tiles[ti];
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
     const LmState st = P.states[(long long)T.w * P.state_stride + slot];
     if (st.done) return;
@@ -437,13 +439,14 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_diag(   // the bearing fac
 template <int FACTOR>
 __global__ __launch_bounds__(BUILD_THREADS, 3) void k_backsub_lm(DevPtrs P, int slot, int max_tile_kf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const Tile T = P.tiles[blockIdx.x];
+    const int ti = P.tile_perm[blockIdx.x];   // largest tiles first (host: LPT order), so that the launch does not end on a long tile
+    const Tile T = P.tiles[ti];
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
     const LmState st = P.states[(long long)T.w * P.state_stride + slot];
     IterAcc* acc = P.acc + (long long)T.w * P.state_stride + slot;
     if (st.done || acc->chol_fail) {
         if (tid == 0) {
-            TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + blockIdx.x;
+            TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + ti;
             ta->cand_cost = 0.0; ta->mcc = 0.0; ta->step_norm2 = 0.0; ta->cand_norm2 = 0.0;
         }
         return;
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 3) void k_backsub_lm(DevPtrs P, int 
     if (tid == 0) {
         double a0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
         for (int k = 0; k < BUILD_WAVES; k++) { a0 += s_part[k * 4]; b1 += s_part[k * 4 + 1]; b2 += s_part[k * 4 + 2]; b3 += s_part[k * 4 + 3]; }
-        TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + blockIdx.x;
+        TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + ti;
         ta->cand_cost = a0; ta->mcc = b1; ta->step_norm2 = b2; ta->cand_norm2 = b3;
     }
 }
