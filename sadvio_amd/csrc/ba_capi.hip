@@ -1354,20 +1354,46 @@ int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int l
         // pivots at the rounding-noise level of the largest one end the factorisation: the floor of marg_cut (n eps lambda_max)
         // with a margin - the null space of a marginalisation prior sits exactly there
         const double tau_rel = 4.0 * n * 2.220446049250313e-16;
-        for (int k0 = 0; k0 < n; k0 += PCH_NB) {
-            hipLaunchKernelGGL(k_pchol_panel, dim3(1), dim3(PCH_THREADS), 0, h->stream, V, n, G, piv, dg, rank_d, dctl, k0, tau_rel);
-            const int m = n - (k0 + PCH_NB);
-            if (m > 0) hipLaunchKernelGGL(k_pchol_syrk, dim3((m + 63) / 64, (m + 63) / 64), dim3(256), 0, h->stream, V, n, G, rank_d, k0);
+        const bool swap_pchol = getenv("SADVIO_PCHOL_SWAP") != nullptr;   // the data-moving version (kept for comparison)
+        if (swap_pchol) {
+            for (int k0 = 0; k0 < n; k0 += PCH_NB) {
+                hipLaunchKernelGGL(k_pchol_panel, dim3(1), dim3(PCH_THREADS), 0, h->stream, V, n, G, piv, dg, rank_d, dctl, k0, tau_rel);
+                const int m = n - (k0 + PCH_NB);
+                if (m > 0) hipLaunchKernelGGL(k_pchol_syrk, dim3((m + 63) / 64, (m + 63) / 64), dim3(256), 0, h->stream, V, n, G, rank_d, k0);
+            }
+        } else {
+            if (hipMemsetAsync(piv, 0xff, sizeof(int) * (size_t)n, h->stream) != hipSuccess) return -1;   // done[i] = -1
+            const unsigned gt = (unsigned)((n + 63) / 64);
+            if (n <= PCH_THREADS) {
+                for (int k0 = 0; k0 < n; k0 += 32) {
+                    hipLaunchKernelGGL((k_pchol_panel_np<1, 32>), dim3(1), dim3(PCH_THREADS), 0, h->stream, V, n, G, piv, dg, rank_d, dctl, k0, tau_rel);
+                    if (k0 + 32 < n) hipLaunchKernelGGL(k_pchol_syrk_full<32>, dim3(gt, gt), dim3(256), 0, h->stream, V, n, G, rank_d, k0);
+                }
+            } else {
+                for (int k0 = 0; k0 < n; k0 += 16) {
+                    hipLaunchKernelGGL((k_pchol_panel_np<2, 16>), dim3(1), dim3(PCH_THREADS), 0, h->stream, V, n, G, piv, dg, rank_d, dctl, k0, tau_rel);
+                    if (k0 + 16 < n) hipLaunchKernelGGL(k_pchol_syrk_full<16>, dim3(gt, gt), dim3(256), 0, h->stream, V, n, G, rank_d, k0);
+                }
+            }
         }
         int r = 0;
         if (hipMemcpyAsync(&r, rank_d, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
         if (r < 0) r = n;
-        const int nb = (r + JB - 1) / JB, nbpad = nb + (nb & 1);
+        const bool b4 = getenv("SADVIO_JACOBI_B4") != nullptr || n > JM_MAXN;   // the 4-row VALU version (large n; kept for comparison)
+        const int ldx = jm_ldx(n);
+        const size_t jm_lds = (size_t)JM2 * ldx * sizeof(double);
+        if (!b4 && hipFuncSetAttribute((const void*)k_jacobi_mma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jm_lds) != hipSuccess) return -1;
+        const int jb = b4 ? JB : JM;
+        const int nb = (r + jb - 1) / jb, nbpad = nb + (nb & 1);
         int sweeps = 0;
+        long long* jts = nullptr;   // phase timestamps of one launch (SADVIO_KERNEL_TS builds, SADVIO_DEBUG & 4096)
+        if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 4096) && n > 500 && h->d_dbg.alloc(64) == hipSuccess) jts = h->d_dbg.p + 44;
         for (; sweeps < 40 && nbpad >= 2; sweeps++) {
             if (hipMemsetAsync(flag, 0, sizeof(int), h->stream) != hipSuccess) return -1;
             for (int st = 0; st < nbpad - 1; st++) {
-                if (n <= 4 * JAC_THREADS) hipLaunchKernelGGL(k_jacobi_block<4>, dim3(nbpad / 2), dim3(JAC_THREADS), 0, h->stream, G, r, n, nbpad, st, 1e-14, flag);
+                long long* ts = sweeps == 0 && st == 3 ? jts : nullptr;
+                if (!b4) hipLaunchKernelGGL(k_jacobi_mma, dim3(nbpad / 2), dim3(JAC_THREADS), jm_lds, h->stream, G, r, n, ldx, nbpad, st, 1e-14, flag, ts);
+                else if (n <= 4 * JAC_THREADS) hipLaunchKernelGGL(k_jacobi_block<4>, dim3(nbpad / 2), dim3(JAC_THREADS), 0, h->stream, G, r, n, nbpad, st, 1e-14, flag);
                 else hipLaunchKernelGGL(k_jacobi_block<8>, dim3(nbpad / 2), dim3(JAC_THREADS), 0, h->stream, G, r, n, nbpad, st, 1e-14, flag);
             }
             int f = 0;
@@ -1375,7 +1401,15 @@ int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int l
             if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 16384)) fprintf(stderr, "[sadvio dbg] block jacobi n %d rank %d sweep %d block pairs rotated %d\n", n, r, sweeps, f);
             if (!f) { sweeps++; break; }
         }
-        hipLaunchKernelGGL(k_eig_from_rows, dim3(n), dim3(JAC_THREADS), 0, h->stream, G, piv, rank_d, n, V, ev);
+        hipLaunchKernelGGL(k_eig_from_rows, dim3(n), dim3(JAC_THREADS), 0, h->stream, G, swap_pchol ? piv : (const int*)nullptr, rank_d, n, V, ev);
+        if (jts) {
+            long long t8[8];
+            if (hipMemcpy(t8, jts, sizeof(t8), hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "[sadvio dbg] k_jacobi_mma phases (us, cumulative): gram | update loads issued | barrier | M | check | inner sweep | end:");
+                for (int i = 1; i < 8; i++) fprintf(stderr, " %.2f", (t8[i] - t8[0]) * 0.01);
+                fprintf(stderr, "\n");
+            }
+        }
         return sweeps;
     }
     hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, A, lda, n, G, V, lower_only);

@@ -204,6 +204,133 @@ __global__ __launch_bounds__(256) void k_pchol_syrk(double* __restrict__ S, int 
         }
 }
 
+// The same factorisation WITHOUT data movement (the version used): the permutation stays implicit - G is stored by ORIGINAL
+// column index (A = G^T G needs no permutation at all), a pivoted index just drops out of the arg max and gets zeros in the
+// later rows. Thread i owns index i (i + 1024 for n > 1024): its remaining diagonal, its "pivoted" flag and its entries of
+// the current panel's rows live in registers, so a column costs two barriers, the broadcast of the pivot's panel entries
+// through LDS and ONE global round trip (row j of S, known only after the arg max). The trailing update is k_pchol_syrk_full
+// over the whole matrix (rows / columns of pivoted indices are updated too and never read again).
+// done[i] = step at which index i was chosen (or -1); dg, ctl, dctl as above.
+template <int EPT, int NB>
+__global__ __launch_bounds__(PCH_THREADS) void k_pchol_panel_np(const double* __restrict__ S, int n, double* __restrict__ G, int* __restrict__ done_g,
+                                                                double* __restrict__ dg, int* __restrict__ ctl, double* __restrict__ dctl, int k0, double tau_rel) {
+    __shared__ double lk[NB];
+    __shared__ double wmax[PCH_THREADS / 64];
+    __shared__ int widx[PCH_THREADS / 64];
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    if (ctl[0] >= 0) return;              // the factorisation stopped in an earlier panel
+    double d[EPT], g[NB][EPT];
+    bool done[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int i = tid + e * PCH_THREADS;
+        if (i < n) { d[e] = k0 == 0 ? S[(size_t)i * n + i] : dg[i]; done[e] = k0 == 0 ? false : done_g[i] >= 0; }
+        else { d[e] = -1.0; done[e] = true; }
+    }
+    if (k0 == 0) {
+        double m = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) m = fmax(m, d[e]);
+        m = wave_max(m);
+        if (ln == 0) wmax[wv] = m;
+        __syncthreads();
+        if (tid == 0) { double mm = 0.0; for (int q = 0; q < PCH_THREADS / 64; q++) mm = fmax(mm, wmax[q]); dctl[0] = tau_rel * mm; lk[0] = tau_rel * mm; }
+        __syncthreads();
+    }
+    const double tau = k0 == 0 ? lk[0] : dctl[0];
+    __syncthreads();
+    int rank = -1;
+#pragma unroll
+    for (int kk = 0; kk < NB; kk++) {
+        const int k = k0 + kk;
+        if (k >= n) break;
+        double best = -1.0; int bi = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) if (!done[e] && d[e] > best) { best = d[e]; bi = tid + e * PCH_THREADS; }
+        const double wm = wave_max(best);
+        const unsigned long long who = __ballot(best == wm);
+        const int src = __ffsll((long long)who) - 1;
+        const int wi = __builtin_amdgcn_readlane(bi, src);
+        if (ln == 0) { wmax[wv] = wm; widx[wv] = wi; }
+        __syncthreads();
+        double m = wmax[0]; int j = widx[0];
+#pragma unroll
+        for (int q = 1; q < PCH_THREADS / 64; q++) if (wmax[q] > m) { m = wmax[q]; j = widx[q]; }
+        if (!(m > tau && m > 0.0)) { rank = k; break; }
+        double srow[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) { const int i = tid + e * PCH_THREADS; srow[e] = i < n ? S[(size_t)j * n + i] : 0.0; }
+        if (tid == (j & (PCH_THREADS - 1))) {
+#pragma unroll
+            for (int e = 0; e < EPT; e++) if (j == tid + e * PCH_THREADS) {
+#pragma unroll
+                for (int c = 0; c < kk; c++) lk[c] = g[c][e];
+            }
+        }
+        __syncthreads();
+        const double lkk = sqrt(m), inv = 1.0 / lkk;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int i = tid + e * PCH_THREADS;
+            double v = 0.0;
+            if (i == j) { v = lkk; done[e] = true; done_g[i] = k; }
+            else if (!done[e]) {
+                double s0 = srow[e];
+#pragma unroll
+                for (int c = 0; c < kk; c++) s0 -= g[c][e] * lk[c];
+                v = s0 * inv;
+                d[e] -= v * v;
+            }
+            g[kk][e] = v;
+            if (i < n) G[(size_t)k * n + i] = v;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; e++) { const int i = tid + e * PCH_THREADS; if (i < n) dg[i] = d[e]; }
+    if (rank < 0 && k0 + NB >= n) rank = n;
+    if (rank >= 0) {
+        for (int c = rank; c < n; c++) for (int i = tid; i < n; i += PCH_THREADS) G[(size_t)c * n + i] = 0.0;
+        if (tid == 0) ctl[0] = rank;
+    }
+}
+
+// S[i][j] -= sum_{c in panel} G[c][i] G[c][j] over the WHOLE matrix (implicit pivoting: nothing is ordered), 64 x 64 tiles
+template <int NB>
+__global__ __launch_bounds__(256) void k_pchol_syrk_full(double* __restrict__ S, int n, const double* __restrict__ G, const int* __restrict__ ctl, int k0) {
+    if (ctl[0] >= 0) return;
+    __shared__ double Ai[NB][64], Aj[NB][64];
+    const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+    for (int e = threadIdx.x; e < NB * 64; e += 256) {
+        const int c = e / 64, x = e % 64;
+        Ai[c][x] = ti + x < n ? G[(size_t)(k0 + c) * n + ti + x] : 0.0;
+        Aj[c][x] = tj + x < n ? G[(size_t)(k0 + c) * n + tj + x] : 0.0;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 4 x 4 micro-tile per thread
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
+#pragma unroll 4
+    for (int c = 0; c < NB; c++) {
+        double vi[4], vj[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) { vi[a] = Ai[c][ty * 4 + a]; vj[a] = Aj[c][tx * 4 + a]; }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc[a][b] += vi[a] * vj[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int i = ti + ty * 4 + a, j = tj + tx * 4 + b;
+            if (i < n && j < n) S[(size_t)i * n + j] -= acc[a][b];
+        }
+}
+
 // Block one-sided Jacobi on the r rows (length n) of G: one launch = one round-robin step over BLOCKS of JB rows, one
 // workgroup per block pair. The workgroup holds its 2 JB rows in registers, forms their Gram matrix (2 JB x 2 JB) with one
 // block reduction, diagonalises it in LDS (cyclic two-sided Jacobi by one wave, rotations accumulated in U), and replaces the
@@ -331,6 +458,188 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_block(double* __restrict
     }
 }
 
+// The same step on BLOCKS of JM = 8 rows (16 rows per workgroup, n <= JM_MAXN) with the Gram matrix and the row update on the
+// FP64 matrix cores: half the launches per sweep. The 16 rows are read ONCE, coalesced, into an LDS image X[16][ldx]
+// (ldx = 2 mod 32: the operand reads below are conflict-free per half wave); every wave owns a quarter of the 16-column
+// groups for the load, the Gram matrix and the update, so only the Gram reduction and U cross waves. Gram: lane (row = l % 16,
+// k = l / 16) feeds the same register as A and B operand of v_mfma_f64_16x16x4_f64 (X X^T contracts over columns); update
+// X <- U^T X: one 16 x 16 x 16 product per 16-column tile (A = U^T, B = X[4 sl + l / 16][16 t + l % 16]), stored from the
+// accumulators as full 128-byte row segments.
+constexpr int JM = 8, JM2 = 16, JM_MAXN = 1024;
+__host__ __device__ constexpr int jm_ldx(int n) { return ((n + 15) / 16 * 16 + 29) / 32 * 32 + 2; }
+// Jacobi rotation (c, s) annihilating apq of [[app, apq], [apq, aqq]]: t = sign(d) b / (|d| + sqrt(d^2 + b^2)) with d = aqq - app,
+// b = 2 apq (the smaller root of t^2 + 2 zeta t - 1); c = h w, s = sign(d) b w with h = |d| + sqrt(d^2 + b^2), w = rsqrt(h^2 + b^2):
+// no division, two v_rsq_f64 + Newton (c^2 + s^2 = 1 to rounding); d and b are pre-scaled by a power of two.
+__device__ __forceinline__ void jm_rotation(double app, double aqq, double apq, double& c, double& s) {
+    c = 1.0; s = 0.0;
+    if (apq == 0.0 || !(apq * apq > 1e-32 * fabs(app * aqq))) return;
+    double d = aqq - app, b = 2.0 * apq;
+    const int e = -ilogb(fmax(fabs(d), fabs(b)));
+    d = ldexp(d, e); b = ldexp(b, e);
+    const double n2 = d * d + b * b;
+    const double h = fabs(d) + n2 * rsqrt_nr(n2);
+    const double w = rsqrt_nr(h * h + b * b);
+    c = h * w;
+    s = (d >= 0.0 ? b : -b) * w;
+}
+__global__ __launch_bounds__(JAC_THREADS) void k_jacobi_mma(double* __restrict__ G, int r, int n, int ldx, int nbpad, int s, double tol, int* rotated, long long* ts) {
+#ifdef SADVIO_KERNEL_TS
+#define JM_TS(i_) do { if (ts && blockIdx.x == 0 && threadIdx.x == 0) ts[i_] = wall_clock64(); } while (0)
+#else
+#define JM_TS(i_) do { } while (0)
+#endif
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char jm_smem[];
+    double* X = (double*)jm_smem;
+    __shared__ double part[JAC_THREADS / 64][JM2][JM2 + 1];
+    __shared__ double M[JM2][JM2 + 1], U[JM2][JM2 + 1];
+    __shared__ int s_work;
+    JM_TS(0);
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    const int ri = ln & 15, kq = ln >> 4;
+    int bp, bq;
+    rr_pair(nbpad, s, blockIdx.x, bp, bq);
+    const bool full = s == 0;
+    const int ngrp = (n + 15) >> 4;
+    const int g0 = wv * ngrp / (JAC_THREADS / 64), g1 = (wv + 1) * ngrp / (JAC_THREADS / 64);   // <= 16 groups per wave
+    const int c0 = 16 * g0, c1 = min(16 * g1, n), c1p = 16 * g1;
+    // rows -> LDS (this wave's columns; zeros for absent rows and up to the end of the last group)
+    {
+        double v[JM2][4];
+#pragma unroll
+        for (int row = 0; row < JM2; row++) {
+            const int grow = row < JM ? bp * JM + row : bq * JM + row - JM;
+            const double* gp = G + (size_t)(grow < r ? grow : 0) * n;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int c = c0 + 64 * j + ln;
+                v[row][j] = (grow < r && c < c1) ? gp[c] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int row = 0; row < JM2; row++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int c = c0 + 64 * j + ln;
+                if (c < c1p) X[row * ldx + c] = v[row][j];
+            }
+    }
+    wave_lds_fence();
+    JM_TS(1);
+    // Gram matrix of the 16 rows
+    {
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const double* xr = X + ri * ldx + kq;
+        for (int gb = g0; gb < g1; gb += 4) {          // 16 operand reads in flight (the image is zero up to the wave's last group)
+            double a[4][4];
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) {
+                const int g = min(gb + tt, g1 - 1);
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const double v = xr[16 * g + 4 * e]; a[tt][e] = gb + tt < g1 ? v : 0.0; }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt][0], a[tt][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt][1], a[tt][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt][2], a[tt][2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt][3], a[tt][3], acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) part[wv][kq + 4 * v][ri] = acc0[v] + acc1[v];
+    }
+    JM_TS(2);
+    __syncthreads();
+    JM_TS(3);
+    {
+        const int i = tid >> 4, j = tid & 15;
+        M[i][j] = part[0][i][j] + part[1][i][j] + part[2][i][j] + part[3][i][j];
+        U[i][j] = i == j ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    JM_TS(4);
+    if (wv == 0) {
+        bool w = false;
+        {
+            // pairs checked / rotated: all 120 in the first round of a sweep (full), afterwards only the 64 pairs ACROSS the two
+            // blocks - every block is in exactly one pair of round 0, so each within-block pair is still visited once per sweep
+            const int a = ln >> 2, b0 = (ln & 3) * 4;
+            const double maa = M[a][a];
+            double mbb[4], mab[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { mbb[e] = M[b0 + e][b0 + e]; mab[e] = M[a][b0 + e]; }
+#pragma unroll
+            for (int e = 0; e < 4; e++) w |= b0 + e < a && (full || (a >= JM && b0 + e < JM)) && maa != 0.0 && mbb[e] != 0.0 && mab[e] * mab[e] > tol * tol * maa * mbb[e];
+        }
+        const bool work = __ballot(w) != 0ull;
+        if (ln == 0) { s_work = work; if (work) atomicAdd(rotated, 1); }
+        JM_TS(5);
+        if (work) {
+            // one sweep of the cyclic two-sided Jacobi on M: JM disjoint rotations per step (an inexact inner diagonalisation
+            // costs no outer sweeps, measured on the 4-row version). Lane (k1, k2) owns the 2 x 2 block (pair k1 rows x pair k2
+            // columns) of M and a 2 x 2 block of U; it derives both rotations itself from the pairs' diagonal blocks
+            // (broadcast reads), so a step is ONE LDS round trip: all reads, the math, all writes, one fence.
+            const int k1 = ln >> 3, k2 = ln & 7;
+            const int nsteps = full ? JM2 - 1 : JM;
+            for (int st = 0; st < nsteps; st++) {
+                int p1, q1, p2, q2;
+                if (full) { rr_pair(JM2, st, k1, p1, q1); rr_pair(JM2, st, k2, p2, q2); }
+                else { p1 = k1; q1 = JM + ((k1 + st) & (JM - 1)); p2 = k2; q2 = JM + ((k2 + st) & (JM - 1)); }
+                const double a1 = M[p1][p1], b1 = M[q1][q1], x1 = M[p1][q1];
+                const double a2 = M[p2][p2], b2 = M[q2][q2], x2 = M[p2][q2];
+                const double B00 = M[p1][p2], B01 = M[p1][q2], B10 = M[q1][p2], B11 = M[q1][q2];
+                const double u00 = U[2 * k1][p2], u01 = U[2 * k1][q2], u10 = U[2 * k1 + 1][p2], u11 = U[2 * k1 + 1][q2];
+                double c1, s1, c2, s2;
+                jm_rotation(a1, b1, x1, c1, s1);
+                jm_rotation(a2, b2, x2, c2, s2);
+                if (__ballot(s1 != 0.0) == 0ull) continue;     // every pair of this step is already orthogonal
+                const double t00 = c1 * B00 - s1 * B10, t01 = c1 * B01 - s1 * B11, t10 = s1 * B00 + c1 * B10, t11 = s1 * B01 + c1 * B11;
+                M[p1][p2] = c2 * t00 - s2 * t01; M[p1][q2] = s2 * t00 + c2 * t01;
+                M[q1][p2] = c2 * t10 - s2 * t11; M[q1][q2] = s2 * t10 + c2 * t11;
+                U[2 * k1][p2] = c2 * u00 - s2 * u01; U[2 * k1][q2] = s2 * u00 + c2 * u01;
+                U[2 * k1 + 1][p2] = c2 * u10 - s2 * u11; U[2 * k1 + 1][q2] = s2 * u10 + c2 * u11;
+                wave_lds_fence();
+            }
+        }
+    }
+    JM_TS(6);
+    __syncthreads();
+    if (!s_work) return;
+    // rows <- U^T rows: D[a][c] = sum_b U[b][a] X[b][c]
+    double ua[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++) ua[sl] = U[4 * sl + kq][ri];
+    int orow[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) { const int a = kq + 4 * v; orow[v] = a < JM ? bp * JM + a : bq * JM + a - JM; }
+    for (int gb = g0; gb < g1; gb += 4) {              // 4 tiles at a time: independent accumulators, 16 operand reads in flight
+        double x[4][4];
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) {
+            const int g = min(gb + tt, g1 - 1);
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) x[tt][sl] = X[(4 * sl + kq) * ldx + 16 * g + ri];
+        }
+        d4 acc[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) acc[tt] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sl = 0; sl < 4; sl++)
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[sl], x[tt][sl], acc[tt], 0, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) {
+            const int c = 16 * (gb + tt) + ri;
+            if (gb + tt < g1 && c < n) {
+#pragma unroll
+                for (int v = 0; v < 4; v++) if (orow[v] < r) G[(size_t)orow[v] * n + c] = acc[tt][v];
+            }
+        }
+    }
+    JM_TS(7);
+}
+
 // eigen-pairs from the orthogonalised rows: lambda_i = |g_i|^2, v_i = g_i / |g_i| scattered back through the pivoting
 // (rows >= rank: lambda = 0, v = 0 - they are below every cut and only ever multiplied by zero)
 __global__ __launch_bounds__(JAC_THREADS) void k_eig_from_rows(const double* __restrict__ G, const int* __restrict__ piv, const int* __restrict__ rank, int n,
@@ -343,7 +652,7 @@ __global__ __launch_bounds__(JAC_THREADS) void k_eig_from_rows(const double* __r
     s = block_sum_256(s, sh);
     const bool live = i < *rank && s > 0.0;
     const double inv = live ? 1.0 / sqrt(s) : 0.0;
-    for (int k = threadIdx.x; k < n; k += JAC_THREADS) V[(size_t)i * n + piv[k]] = live ? g[k] * inv : 0.0;
+    for (int k = threadIdx.x; k < n; k += JAC_THREADS) V[(size_t)i * n + (piv ? piv[k] : k)] = live ? g[k] * inv : 0.0;
     if (threadIdx.x == 0) ev[i] = live ? s : 0.0;
 }
 
