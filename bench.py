@@ -187,11 +187,11 @@ def main():
                 bw = [bw[i % len(bw)] for i in range(nw)]
                 bb = capi.Backend(device=local_rank, use_graph=False)   # ~40 launches of >= 40 us each: the graph buys nothing here (measured: -2 %)
                 bb.set_windows(bw)
-                for _ in range(2):
+                for _ in range(3):
                     bb.solve(opts)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                reps = 5
+                reps = 20 if nw <= 64 else 8
                 for _ in range(reps):
                     bs = bb.solve(opts)
                 torch.cuda.synchronize()

@@ -484,7 +484,7 @@ __device__ __forceinline__ void jm_rotation(double app, double aqq, double apq, 
 }
 __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_mma(double* __restrict__ G, int r, int n, int ldx, int nbpad, int s, double tol, int* rotated, long long* ts) {
 #ifdef SADVIO_KERNEL_TS
-#define JM_TS(i_) do { if (ts && blockIdx.x == 0 && threadIdx.x == 0) ts[i_] = wall_clock64(); } while (0)
+#define JM_TS(i_) do { if (ts && blockIdx.x == 1 && threadIdx.x == 0) ts[i_] = wall_clock64(); } while (0)
 #else
 #define JM_TS(i_) do { } while (0)
 #endif
