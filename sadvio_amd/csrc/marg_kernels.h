@@ -503,40 +503,37 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_mma(double* __restrict__
     const int ngrp = (n + 15) >> 4;
     const int g0 = wv * ngrp / (JAC_THREADS / 64), g1 = (wv + 1) * ngrp / (JAC_THREADS / 64);   // <= 16 groups per wave
     const int c0 = 16 * g0, c1 = min(16 * g1, n), c1p = 16 * g1;
-    // rows -> LDS (this wave's columns; zeros for absent rows and up to the end of the last group)
+    // rows -> LDS (this wave's columns; zeros for absent rows and up to the end of the last group) and their Gram matrix, in
+    // chunks of 64 columns: all global loads are issued first, chunk j is written to the image and contracted while the
+    // later chunks are still in flight
     {
-        double v[JM2][4];
+        double v[4][JM2];
 #pragma unroll
-        for (int row = 0; row < JM2; row++) {
-            const int grow = row < JM ? bp * JM + row : bq * JM + row - JM;
-            const double* gp = G + (size_t)(grow < r ? grow : 0) * n;
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int row = 0; row < JM2; row++) {
+                const int grow = row < JM ? bp * JM + row : bq * JM + row - JM;
                 const int c = c0 + 64 * j + ln;
-                v[row][j] = (grow < r && c < c1) ? gp[c] : 0.0;
+                v[j][row] = (grow < r && c < c1) ? G[(size_t)grow * n + c] : 0.0;
             }
-        }
-#pragma unroll
-        for (int row = 0; row < JM2; row++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int c = c0 + 64 * j + ln;
-                if (c < c1p) X[row * ldx + c] = v[row][j];
-            }
-    }
-    wave_lds_fence();
-    JM_TS(1);
-    // Gram matrix of the 16 rows
-    {
         d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
         const double* xr = X + ri * ldx + kq;
-        for (int gb = g0; gb < g1; gb += 4) {          // 16 operand reads in flight (the image is zero up to the wave's last group)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int gb = g0 + 4 * j;
+            if (gb >= g1) break;
+            const int c = c0 + 64 * j + ln;
+            if (c < c1p) {
+#pragma unroll
+                for (int row = 0; row < JM2; row++) X[row * ldx + c] = v[j][row];
+            }
+            wave_lds_fence();
             double a[4][4];
 #pragma unroll
             for (int tt = 0; tt < 4; tt++) {
                 const int g = min(gb + tt, g1 - 1);
 #pragma unroll
-                for (int e = 0; e < 4; e++) { const double v = xr[16 * g + 4 * e]; a[tt][e] = gb + tt < g1 ? v : 0.0; }
+                for (int e = 0; e < 4; e++) { const double x = xr[16 * g + 4 * e]; a[tt][e] = gb + tt < g1 ? x : 0.0; }
             }
 #pragma unroll
             for (int tt = 0; tt < 4; tt++) {
@@ -546,8 +543,9 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_mma(double* __restrict__
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tt][3], a[tt][3], acc1, 0, 0, 0);
             }
         }
+        JM_TS(1);
 #pragma unroll
-        for (int v = 0; v < 4; v++) part[wv][kq + 4 * v][ri] = acc0[v] + acc1[v];
+        for (int vv = 0; vv < 4; vv++) part[wv][kq + 4 * vv][ri] = acc0[vv] + acc1[vv];
     }
     JM_TS(2);
     __syncthreads();
@@ -613,14 +611,18 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_mma(double* __restrict__
     int orow[4];
 #pragma unroll
     for (int v = 0; v < 4; v++) { const int a = kq + 4 * v; orow[v] = a < JM ? bp * JM + a : bq * JM + a - JM; }
-    for (int gb = g0; gb < g1; gb += 4) {              // 4 tiles at a time: independent accumulators, 16 operand reads in flight
-        double x[4][4];
+    double x[4][4], xn[4][4];
+    auto load_x = [&](int gb, double (&dst)[4][4]) {
 #pragma unroll
         for (int tt = 0; tt < 4; tt++) {
             const int g = min(gb + tt, g1 - 1);
 #pragma unroll
-            for (int sl = 0; sl < 4; sl++) x[tt][sl] = X[(4 * sl + kq) * ldx + 16 * g + ri];
+            for (int sl = 0; sl < 4; sl++) dst[tt][sl] = X[(4 * sl + kq) * ldx + 16 * g + ri];
         }
+    };
+    load_x(g0, x);
+    for (int gb = g0; gb < g1; gb += 4) {              // 4 tiles at a time: independent accumulators; the next 4 tiles' operands are read ahead
+        if (gb + 4 < g1) load_x(gb + 4, xn);
         d4 acc[4];
 #pragma unroll
         for (int tt = 0; tt < 4; tt++) acc[tt] = d4{0.0, 0.0, 0.0, 0.0};
@@ -636,6 +638,10 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_mma(double* __restrict__
                 for (int v = 0; v < 4; v++) if (orow[v] < r) G[(size_t)orow[v] * n + c] = acc[tt][v];
             }
         }
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++)
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) x[tt][sl] = xn[tt][sl];
     }
     JM_TS(7);
 }
