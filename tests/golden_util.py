@@ -85,3 +85,51 @@ def assert_trace_matches(trace, log, termination, cost_rtol=1e-9):
     m = min(n, len(log) - 1)      # the state after the last attempt is not linearised on the device (-1)
     assert np.allclose(trace[:m, 6], log[:m, 6], rtol=1e-7)
     assert np.allclose(trace[:, 7], log[:, 7], rtol=1e-6, atol=1e-12 * c0)
+
+
+# ---- config-3 sized marginalisation (tests/golden/config3_marg_ref.npz, tests/golden/make_golden_marg.py) --------------
+N_PROBE, ROW_STRIDE = 32, 32
+
+
+def config3_marg_case(n_keep):
+    """The config-3 shaped VIO window (12 key-frames, 7 200 landmarks, IMU factor to the next key-frame, a previous prior on
+    frame0's 15 states) and the marginalize() arguments that give n = 15 + 3 n_keep: shared by the fixture generator and
+    tests/test_gpu_marg.py so both sides see the same inputs (guarded by the window checksum)."""
+    from marg_helpers import with_lonely_landmarks
+    from test_oracle_marg import pre_marginalize
+    from vio_helpers import make_vio_window
+    w = with_lonely_landmarks(make_vio_window(n_kf=12, n_lmk=7200, seed=6), 11, 40)
+    keep, marg = pre_marginalize(w, 11)
+    keep = keep[:n_keep]
+    assert len(keep) == n_keep
+    imu = [f for f in w.imu_factors if f["kf_i"] == 11 and f["kf_j"] == 10][0]
+    rng = np.random.default_rng(1)
+    last = {"J": 20.0 * (np.eye(15) + 0.1 * rng.standard_normal((15, 15))), "r0": 0.1 * rng.standard_normal(15), "kf_keep": 11, "kf_col": 0,
+            "lmk_index": np.zeros(0, dtype=np.int32), "lmk_col": np.zeros(0, dtype=np.int32)}
+    args = dict(kf_marg=11, lmk_marg=marg, lmk_keep=keep, kf_keep=10, marg_has_imu=True, imu=imu, priors=w.pose_priors, last=last)
+    return w, args
+
+
+def check_prior_against_fixture(g, z, n_keep, rtol=1e-8):
+    """Device prior (capi.Backend.marginalize) against the oracle's committed invariants — see make_golden_marg.py."""
+    p = f"k{n_keep}_"
+    n = int(z[p + "n"])
+    assert (g["m"], g["n"], g["n_full"], g["kf_col"]) == (int(z[p + "m"]), n, int(z[p + "n_full"]), int(z[p + "kf_col"]))
+    assert np.array_equal(g["lmk_col"], z[p + "lmk_col"])
+    H = g["J"].T @ g["J"]
+    scale = np.abs(z[p + "Ak_diag"]).max()
+    V = np.random.default_rng(n).standard_normal((n, N_PROBE))
+    # the information the prior carries = the oracle's Ak (on its range: the cut eigenvalues are below rtol * scale) ...
+    assert np.abs(np.diag(H) - z[p + "Ak_diag"]).max() <= rtol * scale
+    assert np.abs(H[::ROW_STRIDE] - z[p + "Ak_rows"]).max() <= rtol * scale
+    assert np.abs(H @ V - z[p + "Ak_V"]).max() <= rtol * scale * np.sqrt(n)
+    ev = np.linalg.eigvalsh(H)
+    assert np.abs(ev - z[p + "Ak_eig"]).max() <= rtol * scale
+    # ... and the oracle's own J^T J, J^T r0 (computeJacobiansAndResiduals, marginalization.cpp:516-530)
+    assert np.abs(H @ V - z[p + "JtJ_V"]).max() <= rtol * scale * np.sqrt(n)
+    gg, go = g["J"].T @ g["r0"], z[p + "Jtr0"]
+    assert np.abs(gg - go).max() <= rtol * max(np.abs(go).max(), np.sqrt(scale))
+    # J^T r0 = -bk on the range of Ak (r0 = -Lambda^-1/2 U^T bk): the gradient the prior restores is the Schur complement's
+    assert np.abs(gg + z[p + "bk"]).max() <= 1e-6 * max(np.abs(z[p + "bk"]).max(), np.sqrt(scale))
+    JJt = g["J"] @ g["J"].T
+    assert np.abs(JJt - np.diag(np.diag(JJt))).max() <= rtol * scale  # rows orthogonal: J = Lambda^1/2 U^T

@@ -2,7 +2,11 @@
 list of random submissions — VO / VIO, pixel / bearing factors, constant masks, pose / dense / sparse priors, Huber on or
 off, batches of 1-3, with and without hipGraph — plus the windows earlier sweeps disagreed on.
 
-Tolerances. Iteration counts, terminations: identical. Pose deltas: 1e-6 (BASELINE.json). Landmark deltas: LMK_TOL = 1e-5,
+Tolerances. Iteration counts, terminations: identical. Pose deltas: 1e-6 (BASELINE.json) — on every direction the data
+determine; a direction only the LM damping holds (relative stiffness < 1e-9 in the damped reduced system, e.g. the 4-D null
+space of a key-frame with one observation) gets the rounding-amplification allowance of tests/conditioning.py, consulted
+only when the strict bar fails (round 2's one pose disagreement, seed 39573273, pinned below and arbitrated against the
+long-double twin in test_pose_seed_against_long_double_twin). Landmark deltas: LMK_TOL = 1e-5,
 RELATIVE to the landmark's own delta once that exceeds 1 m: the sweeps' only landmark disagreements (up to 1.6e-3 m)
 were all on landmarks the optimisation itself sends away — 3-view tracks with (numerically) collinear rays whose H_ll has
 an eigenvalue of 1e-18..1e-21 and whose delta grows to 2e1 .. 8e5 m while poses and cost agree to 1e-13: an absolute
@@ -11,6 +15,7 @@ an eigenvalue of 1e-18..1e-21 and whose delta grows to 2e1 .. 8e5 m while poses 
 import numpy as np
 import pytest
 
+import conditioning
 import fuzz_helpers as fz
 from sadvio_amd import capi
 
@@ -35,7 +40,9 @@ def check_case(case, oracle_lib):
             what = fz.describe(case["specs"][k])
             assert (sums[k].iterations, sums[k].termination) == (rs.iterations, rs.termination), what
             assert abs(sums[k].final_cost - rs.final_cost) <= COST_RTOL * abs(rs.final_cost), what
-            assert np.abs(d["pose"] - ref["pose"]).max() <= POSE_TOL, what
+            if np.abs(d["pose"] - ref["pose"]).max() > POSE_TOL:
+                ok, report = conditioning.pose_difference_within_conditioning(w, oracle_lib, ref, d["pose"], ref["pose"], POSE_TOL)
+                assert ok, (what, float(np.abs(d["pose"] - ref["pose"]).max()), report)
             if w.n_lmk:
                 scale = np.maximum(1.0, np.abs(ref["lmk"]).max(axis=1))
                 assert (np.abs(d["lmk"] - ref["lmk"]).max(axis=1) / scale).max() <= LMK_TOL, what
@@ -53,8 +60,71 @@ def test_random_submissions(oracle_lib, seed):
         check_case(fz.draw_case(rng), oracle_lib)
 
 
-def test_pinned_disagreements(oracle_lib):
+def _pinned():
     import json, os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_pinned.json")
-    for b in json.load(open(path)):
-        check_case(dict(specs=[b["spec"]], huber=b["huber"], use_graph=b["use_graph"]), oracle_lib)
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_pinned.json")))
+
+
+@pytest.mark.parametrize("lm", [0, 1])
+def test_pinned_disagreements(oracle_lib, monkeypatch, lm):
+    """Every window a sweep ever flagged (generator parameters only), on the kernels it was flagged on — and all of them
+    again with the throughput kernels forced (SADVIO_LM=1; windows with features that path does not take fall back)."""
+    if lm:
+        monkeypatch.setenv("SADVIO_LM", "1")
+    for b in _pinned():
+        if lm or not b.get("lm"):
+            check_case(dict(specs=[b["spec"]], huber=b["huber"], use_graph=b["use_graph"]), oracle_lib)
+
+
+def test_flagged_landmarks_are_runaway(oracle_lib):
+    """The sweeps' landmark disagreements (1e-5 .. 0.17 m absolute) must all sit on landmarks the optimisation itself sends
+    away (|delta| >= 1 m, where LMK_TOL is relative): any landmark with a sub-metre delta has to meet 1e-5 absolutely."""
+    for b in _pinned():
+        if b.get("seen", {}).get("dlmk", 0.0) <= LMK_TOL:
+            continue
+        w = fz.build_window(b["spec"])
+        opts = fz.options(b)
+        be = capi.Backend(device=0, use_graph=b["use_graph"])
+        try:
+            be.set_windows([w])
+            be.solve(opts)
+            d = be.get_deltas(0)
+        finally:
+            be.close()
+        ref = oracle_lib.solve(w, opts, dense_prior=w.dense_prior)
+        err = np.abs(d["lmk"] - ref["lmk"]).max(axis=1)
+        mag = np.abs(ref["lmk"]).max(axis=1)
+        sub = mag < 1.0
+        assert err[sub].max(initial=0.0) <= LMK_TOL, (fz.describe(b["spec"]), float(err[sub].max()))
+        assert (err[~sub] / mag[~sub]).max(initial=0.0) <= LMK_TOL, fz.describe(b["spec"])
+
+
+def test_pose_seed_against_long_double_twin(oracle_lib):
+    """Seed 39573273 (19 key-frames, 309 three-view landmarks; key-frame 0 carries ONE observation): the sweep's only pose
+    disagreement above 1e-6. Arbiter: oracle/twin.py in long double on the un-reduced normal equations
+    (tests/golden/fuzz_seed39573273_ld.npz, generated by scripts/fuzz_arbitrate.py). Every key-frame except 0 must meet the
+    strict bar against the arbiter, on the device AND in the oracle; key-frame 0 may differ only inside its damping-held
+    null space (tests/conditioning.py), and the device must not be further from the arbiter than 4x the oracle is."""
+    import os
+    b = [b for b in _pinned() if b["spec"]["seed"] == 39573273][0]
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_seed39573273_ld.npz"))
+    w = fz.build_window(b["spec"])
+    assert np.bincount(w.obs_kf, minlength=w.n_kf)[0] == 1
+    opts = fz.options(b)
+    ref = oracle_lib.solve(w, opts)
+    for graph in (True, False):
+        be = capi.Backend(device=0, use_graph=graph)
+        try:
+            be.set_windows([w])
+            s = be.solve(opts)[0]
+            d = be.get_deltas(0)
+        finally:
+            be.close()
+        assert (s.iterations, s.termination) == (ref["summary"].iterations, ref["summary"].termination)
+        e_dev, e_ora = np.abs(d["pose"] - z["pose"]).max(axis=1), np.abs(ref["pose"] - z["pose"]).max(axis=1)
+        assert e_dev[1:].max() <= 1e-9 and e_ora[1:].max() <= 1e-9, (e_dev[1:].max(), e_ora[1:].max())
+        assert np.abs(d["lmk"] - z["lmk"]).max() <= 1e-8
+        assert e_dev[0] <= max(4 * e_ora[0], POSE_TOL), (e_dev[0], e_ora[0])
+        for a in (d["pose"], ref["pose"]):
+            ok, report = conditioning.pose_difference_within_conditioning(w, oracle_lib, ref, a, z["pose"], POSE_TOL)
+            assert ok, report

@@ -105,25 +105,24 @@ def test_device_prior_feeds_the_next_solve(backend_cls, oracle_lib):
 
 
 @pytest.mark.parametrize("n_keep", [300, 400])
-def test_large_prior_solver_paths_agree(backend_cls, monkeypatch, n_keep):
-    """Config-3 sized priors (n = 915: MFMA block Jacobi + register-resident pivoted Cholesky; n = 1 215 > 1 024: two indices
-    per thread in the Cholesky, 4-row block Jacobi) against the data-moving Cholesky + 4-row Jacobi they replaced (the version
-    bench.py's marginalize leg pinned on the oracle at n = 915): same information matrix, same gradient, orthogonal rows."""
-    w = with_lonely_landmarks(make_vio_window(n_kf=12, n_lmk=7200, seed=6), 11, 40)
-    keep, marg = pre_marginalize(w, 11)
-    keep = keep[:n_keep]
-    assert len(keep) == n_keep
-    imu = [f for f in w.imu_factors if f["kf_i"] == 11 and f["kf_j"] == 10][0]
-    rng = np.random.default_rng(1)
-    last = {"J": 20.0 * (np.eye(15) + 0.1 * rng.standard_normal((15, 15))), "r0": 0.1 * rng.standard_normal(15), "kf_keep": 11, "kf_col": 0,
-            "lmk_index": np.zeros(0, dtype=np.int32), "lmk_col": np.zeros(0, dtype=np.int32)}
-    args = dict(kf_marg=11, lmk_marg=marg, lmk_keep=keep, kf_keep=10, marg_has_imu=True, imu=imu, priors=w.pose_priors, last=last)
+@pytest.mark.parametrize("path", ["default", "swap_b4"])
+def test_large_prior_against_oracle_fixture(backend_cls, monkeypatch, n_keep, path):
+    """Config-3 sized priors against the ORACLE (tests/golden/config3_marg_ref.npz: oracle/marg.c on the same window,
+    marginalization.cpp:213-265,318-342,516-530): n = 915 takes the MFMA block Jacobi (k_jacobi_mma) + the register-resident
+    pivoted Cholesky (k_pchol_panel_np); n = 1 215 > 1 024 two indices per thread in the Cholesky and the 4-row block Jacobi;
+    `swap_b4` forces the data-moving Cholesky + 4-row Jacobi they replaced. Both must reproduce the oracle's Ak (diagonal,
+    spectrum, 32 probe products, every 32nd row), its J^T J, J^T r0 and -bk, with orthogonal rows."""
+    import os
+    from golden_util import GOLDEN, _window_checksum, check_prior_against_fixture, config3_marg_case
+    z = np.load(os.path.join(GOLDEN, "config3_marg_ref.npz"))
+    w, args = config3_marg_case(n_keep)
+    assert _window_checksum(w) == str(z[f"k{n_keep}_checksum"]), "generator drift: regenerate tests/golden/config3_marg_ref.npz"
+    if path == "swap_b4":
+        monkeypatch.setenv("SADVIO_PCHOL_SWAP", "1")
+        monkeypatch.setenv("SADVIO_JACOBI_B4", "1")
     be = backend_cls(device=0)
     be.set_windows([w])
     g = be.marginalize(0, **args)
-    monkeypatch.setenv("SADVIO_PCHOL_SWAP", "1")
-    monkeypatch.setenv("SADVIO_JACOBI_B4", "1")
-    o = be.marginalize(0, **args)
     be.close()
     assert g["n"] == 15 + 3 * n_keep
-    check_prior(g, o)
+    check_prior_against_fixture(g, z, n_keep)
