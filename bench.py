@@ -5,9 +5,9 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N)
 
-A "step" is --solves-per-step (default 100) back-to-back complete solves (each: 10 LM step attempts, every early exit
-disabled, one hipGraph launch) of the windows resident on this GPU, so that the driver's 20-step run times ~1 s of GPU
-work instead of 17 ms; `value` (BA iterations/s) does not depend on that grouping, `ms_per_step` is per step and
+A "step" is --solves-per-step (default 400) back-to-back complete solves (each: 10 LM step attempts, every early exit
+disabled, one hipGraph launch) of the windows resident on this GPU, so that the driver's 20-step run times ~5 s of GPU
+work instead of 12 ms (and a sampling `rocm-smi` sees a busy GPU); the CPU-baseline legs run BEFORE the GPU legs; `value` (BA iterations/s) does not depend on that grouping, `ms_per_step` is per step and
 `ms_per_solve` per solve. The windows are uploaded to HBM before the timed region (`upload_inclusive` reports the rate with
 set_windows + get_deltas inside, the way the reference's own timer brackets problem construction, slamBiMono.cpp:273-275).
 N > 1 shards independent windows (one set per GPU, weak scaling, no data-path collective — BASELINE.json north_star: "independent sub-windows / keyframe
@@ -34,6 +34,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
 GN_ITERS = 10
+# committed rocprofv3 PMC summaries of this same command (scripts/prof_bench.sh / prof_batched.sh), named explicitly: the
+# newest round's files, not whatever sorts last
+PROFILE_SUMMARY = "profiles/r03_summary.json"
+PROFILE_SUMMARY_BATCHED = "profiles/r03_batched64_summary.json"
+PROFILE_FALLBACK = {"profiles/r03_summary.json": "profiles/r02_v6_summary.json",
+                    "profiles/r03_batched64_summary.json": "profiles/r02_v6_batched64_summary.json"}
+
+
+def profile_summary(rel):
+    """(parsed summary, path relative to the repo) of a committed profile; the previous round's if this round's is not there yet."""
+    for cand in (rel, PROFILE_FALLBACK.get(rel)):
+        if cand and os.path.exists(os.path.join(ROOT, cand)):
+            return json.load(open(os.path.join(ROOT, cand))), cand
+    return None, None
 
 
 def algorithmic_bytes(n_obs, n_lmk, n_p):
@@ -48,7 +62,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--solves-per-step", type=int, default=100, help="complete GN-10 solves per timed step")
+    ap.add_argument("--solves-per-step", type=int, default=400, help="complete GN-10 solves per timed step")
     ap.add_argument("--windows", type=int, default=1, help="independent config-2 windows per GPU in the timed run")
     ap.add_argument("--batch", type=int, default=64, help="windows per GPU of the extra batched measurement (0 = skip)")
     ap.add_argument("--batch-large", type=int, default=256, help="windows of the second batched measurement (<= --batch: skip)")
@@ -115,6 +129,12 @@ def main():
     # every rank owns its own windows (different seeds): weak scaling over independent sub-windows
     base_seed = 20250404 + 1000 * rank
     wins = [synthetic.make_window(seed=base_seed + i) for i in range(args.windows)]
+    # CPU legs first (rank 0 at N = 1 only): the GPU legs then run back to back at the end of the command
+    cpu = marg_cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_leg(wins[0], opts)
+        if not args.no_marginalize:
+            marg_cpu = marginalize_cpu_leg()
     be = capi.Backend(device=local_rank, use_graph=True)  # one hipGraph launch per solve
     be.set_windows(wins)
     sps = max(1, args.solves_per_step)
@@ -161,16 +181,11 @@ def main():
         # HBM traffic per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
         # command (scripts/prof_bench.sh -> profiles/*_summary.json); null if no summary is committed
         traffic, traffic_src = None, None
-        import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
-            if "batched" in os.path.basename(f):
-                continue   # the 64-window profile (scripts/prof_batched.sh) belongs to the `batched` object
-            try:
-                kk = json.load(open(f))["kernels"].get(dom, {})
-                if "hbm_traffic_bytes_per_launch" in kk and len(wins) == 1:
-                    traffic, traffic_src = round(kk["hbm_traffic_bytes_per_launch"]), os.path.relpath(f, ROOT)
-            except Exception:
-                pass
+        prof, prof_path = profile_summary(PROFILE_SUMMARY)
+        if prof is not None and len(wins) == 1:
+            kk = prof.get("kernels", {}).get(dom, {})
+            if "hbm_traffic_bytes_per_launch" in kk:
+                traffic, traffic_src = round(kk["hbm_traffic_bytes_per_launch"]), prof_path
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": traffic_src,
@@ -208,49 +223,21 @@ def main():
             # measured HBM traffic of one LM step of the 64-window batch (PMC passes of scripts/prof_batched.sh, committed under
             # profiles/): the throughput kernels' FETCH + WRITE bytes per launch, one launch of each per step
             try:
-                prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*batched64_summary.json")))[-1]
-                kern = json.load(open(prof))["kernels"]
+                bprof, prof = profile_summary(PROFILE_SUMMARY_BATCHED)
+                kern = bprof["kernels"]
                 per_step = sum(kern[k]["hbm_traffic_bytes_per_launch"] for k in ("k_elim", "k_diag", "k_build_obs", "k_solve", "k_backsub_lm") if k in kern)
                 if args.batch == 64 and per_step > 0:
                     step_s = 1e-3 * batched["ms_per_solve_batch"] / GN_ITERS
                     batched["hbm_traffic"] = {"bytes_per_lm_step": int(per_step), "GBps": round(per_step / step_s / 1e9, 1),
                                               "frac_of_hbm_peak": round(per_step / step_s / 1e9 / HBM_PEAK_GBS, 4),
-                                              "source": os.path.relpath(prof, ROOT)}
+                                              "source": prof}
             except Exception:
                 pass
             if args.batch_large > args.batch:
                 batched["larger"] = batch_leg(args.batch_large)   # the fixed ~40 us of the per-window reduced solve spread over more windows
-        # --- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores ---
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (the other ranks would idle on the barrier)
-            from oracle import oracle
-            oracle.build()
-            ncores = os.cpu_count() or 1
-            usable = len(os.sched_getaffinity(0))      # the cores this process may actually run on
-            res = {}
-            counts = sorted({1, 4, min(usable, 16), min(usable, 64)})   # 4 = the reference's Ceres num_threads (AOptimizer.cpp:323)
-            for thr in counts:
-                oracle.solve(w0, opts, n_threads=thr)
-                t0 = time.perf_counter()
-                n = 0
-                while time.perf_counter() - t0 < 4.0:
-                    r = oracle.solve(w0, opts, n_threads=thr)
-                    n += r["summary"].iterations
-                res[thr] = n / (time.perf_counter() - t0)
-            best = max(res, key=res.get)
-            cpu = {"value": round(res[best], 2), "unit": "BA iterations/s", "cores": best, "kind": "port",
-                   "sample": f"config-2 window, GN-{GN_ITERS} solves repeated for ~4 s per thread count",
-                   "threads_it_per_s": {str(k): round(v, 1) for k, v in res.items()},
-                   "host_cores": ncores, "usable_cores": usable,
-                   "ceres_on_box": ceres_probe(),
-                   "sparse_normal_cholesky_emulation": sparse_normal_baseline(oracle, w0, opts),
-                   "note": "the reference (Ceres 2.2 / Eigen / SuiteSparse) cannot be built here or on the GPU box; "
-                           "`value` = the C oracle (explicit Schur complement + dense Cholesky, OpenMP over landmarks); "
-                           "sparse_normal_cholesky_emulation = the reference's own linear-solver choice (un-reduced J^T J + D, "
-                           "sparse direct factorisation) with SciPy's SuperLU standing in for CHOLMOD"}
         marg = None
         if not args.no_marginalize and world == 1:
-            marg = marginalize_leg(local_rank, cpu is not None)
+            marg = marginalize_leg(local_rank, marg_cpu)
         out = {
             "metric": "BA iterations/sec (ms/solve in ms_per_solve), 20-KF/8k-landmark window",
             "value": round(value, 1), "unit": "BA iterations/s", "n_gpus": world, "steps": args.steps,
@@ -275,6 +262,37 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline_leg(w0, opts):
+    """The CPU side, timed on this box's host cores BEFORE any GPU leg: the C oracle (a port of the reference's algorithm —
+    explicit Schur complement + dense Cholesky; OpenMP over landmarks with per-thread copies of the reduced system) at several
+    thread counts, a probe for Ceres / Eigen / CHOLMOD on the box, and an emulation of the reference's own linear-solver choice."""
+    from oracle import oracle
+    oracle.build()
+    ncores = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0))      # the cores this process may actually run on
+    res = {}
+    counts = sorted({1, 4, min(usable, 16), min(usable, 32), min(usable, 64)})   # 4 = the reference's Ceres num_threads (AOptimizer.cpp:323)
+    for thr in counts:
+        oracle.solve(w0, opts, n_threads=thr)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 3.0:
+            r = oracle.solve(w0, opts, n_threads=thr)
+            n += r["summary"].iterations
+        res[thr] = n / (time.perf_counter() - t0)
+    best = max(res, key=res.get)
+    return {"value": round(res[best], 2), "unit": "BA iterations/s", "cores": best, "kind": "port",
+            "sample": f"config-2 window, GN-{GN_ITERS} solves repeated for ~3 s per thread count",
+            "threads_it_per_s": {str(k): round(v, 1) for k, v in res.items()},
+            "host_cores": ncores, "usable_cores": usable,
+            "ceres_on_box": ceres_probe(),
+            "sparse_normal_cholesky_emulation": sparse_normal_baseline(oracle, w0, opts),
+            "note": "the reference (Ceres 2.2 / Eigen / SuiteSparse) cannot be built here or on the GPU box; "
+                    "`value` = the C oracle (explicit Schur complement + dense Cholesky, OpenMP over landmarks with per-thread "
+                    "reduced-system accumulators); sparse_normal_cholesky_emulation = the reference's own linear-solver choice "
+                    "(un-reduced J^T J + D, sparse direct factorisation) with SciPy's SuperLU standing in for CHOLMOD"}
 
 
 def bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves):
@@ -365,13 +383,8 @@ def sparse_normal_baseline(oracle, w, opts, budget_s=5.0):
             "sample": f"{n_it} linearise + assemble + factorise + solve passes on the config-2 window, {n} unknowns"}
 
 
-def marginalize_leg(device, with_cpu):
-    """sadvio_ba_marginalize (K8) on a config-3 shaped window: 12-KF VIO, frame0's IMU + visual factors + previous prior,
-    m = 135 marginalised / n = 915 kept columns (300 kept landmarks); the oracle's CPU restatement of
-    Marginalization::computeSchurComplement etc. (marginalization.cpp:213-265,318-342) timed beside it."""
+def _marg_case():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
-    from sadvio_amd import capi
     from vio_helpers import make_vio_window
     from marg_helpers import with_lonely_landmarks
     from test_oracle_marg import pre_marginalize
@@ -379,29 +392,46 @@ def marginalize_leg(device, with_cpu):
     keep, marg = pre_marginalize(w, 11)
     keep = keep[:300]
     imu = [f for f in w.imu_factors if f["kf_i"] == 11 and f["kf_j"] == 10][0]
+    return w, keep, marg, imu
+
+
+def marginalize_cpu_leg():
+    """The oracle's CPU restatement of Marginalization::computeSchurComplement etc. (marginalization.cpp:213-265,318-342) on the
+    config-3 shaped window, timed before the GPU legs; its prior is kept for the comparison."""
+    import numpy as np
+    from oracle import oracle
+    w, keep, marg, imu = _marg_case()
+    t = time.perf_counter()
+    ref = oracle.marginalize(w, 11, marg, keep, kf_keep=10, marg_has_imu=True, imu=imu, priors=w.pose_priors)
+    rec = {"cpu_oracle_ms": round(1e3 * (time.perf_counter() - t), 1),
+           "cpu_kind": "port (cyclic Jacobi eigen-solver, one thread; the reference uses Eigen::SelfAdjointEigenSolver)"}
+    t = time.perf_counter()
+    A = np.asarray(ref["Ak"])
+    np.linalg.eigh(0.5 * (A + A.T))
+    rec["cpu_lapack_eigh_of_Ak_ms"] = round(1e3 * (time.perf_counter() - t), 1)
+    return rec, ref["J"].T @ ref["J"]
+
+
+def marginalize_leg(device, cpu):
+    """sadvio_ba_marginalize (K8) on a config-3 shaped window: 12-KF VIO, frame0's IMU + visual factors + previous prior,
+    m = 135 marginalised / n = 915 kept columns (300 kept landmarks); `cpu` = marginalize_cpu_leg()'s record or None."""
+    import numpy as np
+    from sadvio_amd import capi
+    w, keep, marg, imu = _marg_case()
     be = capi.Backend(device=device)
     be.set_windows([w])
     times = []
-    for _ in range(4):
+    for _ in range(6):
         t = time.perf_counter()
         g = be.marginalize(0, 11, marg, keep, kf_keep=10, marg_has_imu=True, imu=imu, priors=w.pose_priors)
         times.append(time.perf_counter() - t)
     be.close()
     rec = {"gpu_ms": round(1e3 * min(times[1:]), 2), "m": int(g["m"]), "n": int(g["n"]), "n_full": int(g["n_full"]),
            "jacobi_sweeps": list(g["sweeps"]), "workload": "config-3 shape: 12-KF VIO window, 300 kept landmarks, IMU + visual factors of frame0"}
-    if with_cpu:
-        from oracle import oracle
-        t = time.perf_counter()
-        ref = oracle.marginalize(w, 11, marg, keep, kf_keep=10, marg_has_imu=True, imu=imu, priors=w.pose_priors)
-        rec["cpu_oracle_ms"] = round(1e3 * (time.perf_counter() - t), 1)
-        rec["cpu_kind"] = "port (cyclic Jacobi eigen-solver, one thread; the reference uses Eigen::SelfAdjointEigenSolver)"
-        t = time.perf_counter()
-        A = np.asarray(ref["Ak"])
-        np.linalg.eigh(0.5 * (A + A.T))
-        rec["cpu_lapack_eigh_of_Ak_ms"] = round(1e3 * (time.perf_counter() - t), 1)
-        rec["information_rel_diff_vs_oracle"] = float(np.abs(g["J"].T @ g["J"] - ref["J"].T @ ref["J"]).max() / np.abs(ref["J"].T @ ref["J"]).max())
+    if cpu is not None:
+        rec.update(cpu[0])
+        rec["information_rel_diff_vs_oracle"] = float(np.abs(g["J"].T @ g["J"] - cpu[1]).max() / np.abs(cpu[1]).max())
     return rec
-
 
 if __name__ == "__main__":
     main()

@@ -211,7 +211,12 @@ typedef struct sadvio_solve_options {
     /* Ceres' max_solver_time_in_seconds (singleFrameVIOptimization sets 0.005, AOptimizer.cpp:254): checked, as in
      * TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue, after every iteration — the solve ends with
      * NO_CONVERGENCE once the time since its start exceeds the limit. Measured on the device (constant 100 MHz clock) from
-     * the first kernel of the solve. 0 (and the reference's localMapBA: Ceres' default 1e6 s) = no limit. */
+     * the first kernel of the solve. 0 (and the reference's localMapBA: Ceres' default 1e6 s) = no limit.
+     * Deviations from Ceres: (i) the clock covers DEVICE time only — host-side flattening, the upload of set_windows and the
+     * graph launch are outside it, whereas Ceres counts its preprocessor and wall time from Solve(); a cap therefore binds
+     * later here; (ii) the limit is IGNORED on a window sharded over several GPUs (the ranks' clocks are not synchronised:
+     * a rank-local decision would desynchronise the collective schedule); (iii) with a limit the iteration count depends on
+     * timing, so parity runs keep it at 0. */
     double max_solver_time_in_seconds;     /* 0 */
 } sadvio_solve_options;
 
@@ -322,7 +327,15 @@ int sadvio_ba_sparsify(sadvio_ba_handle *h, int32_t w, int32_t vio, int32_t n_fu
  * Relative6DPose(T_w_a, T_w_b, T_a_b = T_a_w T_w_b, sqrt_inf = I) factor is recovered: inf = (J Sigma_k J^T)^-1.
  * As coded: a landmark enters the list once PER feature it has in kf_b, and its factors are added once per entry (stereo
  * landmarks count twice). Frames with IMU states are refused (the reference indexes their velocity / bias columns
- * outside of its own layout, :705-737). Returns SADVIO_E_REFUSED when no landmark is shared.
+ * outside of its own layout, :705-737). Returns SADVIO_E_REFUSED when no landmark is shared, SADVIO_E_INVALID_ARG on a
+ * window sharded over several GPUs (each rank only holds its landmark partition: the sum would be partial).
+ * Eigenvalue cuts: the reference drops eigenvalues <= 1e-12 absolutely (Marginalization::_eps). In float64 that cut sits
+ * below the rounding noise of the sums it is applied to (on the reference's own test fixture the null
+ * eigenvalue computes to +-1e-11), so this library — and the oracle — use max(1e-12, m eps lambda_max) on the 3m x 3m
+ * landmark block and max(1e-12, 12 eps lambda_max (2 + n_items)) on Ak; sadvio_ba_marginalize uses
+ * max(1e-12, n eps lambda_max) likewise. With thousands of shared landmarks the floor reaches 1e-8 .. 1e-6 relative to
+ * lambda_max ~ 1e7..1e9: directions whose information is below that (far, low-parallax depth) are treated as
+ * unobserved, where the reference would invert their rounding noise.
  * inf36: 6x6 row-major (rotation 3 | translation 3); Ak144 (may be NULL): the 12x12 reduced information. */
 int sadvio_ba_marginalize_relative(sadvio_ba_handle *h, int32_t w, int32_t kf_a, int32_t kf_b, double *inf36, double *Ak144);
 

@@ -124,10 +124,11 @@ struct LineFeature {          // one AFeature of a linexd landmark: the two end 
     double u0, v0, u1, v1;
 };
 
-struct LineLandmarkState {    // a "linexd" landmark: pose T_w_l whose x axis carries the segment, model points * scale (Line3D.h)
+struct LineLandmarkState {    // a "linexd" landmark: pose T_w_l whose x axis carries the segment (Line3D.h)
     int64_t id = 0;
     Pose T_w_l;
-    double model[6] = {-0.5, 0, 0, 0.5, 0, 0};   // ModelLine3D end points times landmark->getScale()
+    double model[6] = {-0.5, 0, 0, 0.5, 0, 0};   // ModelLine3D end points as ReprojectionErrCeres_linexd_dx reads them: model3d_->getModel(), getScale() NOT applied
+                                                 // (BundleAdjustmentCERESAnalytic.h:128,165; Line3D multiplies _scale by 100, Line3D.h:15, but the BA residual never reads it)
     bool initialized = true, outlier = false;
     std::vector<LineFeature> features;
 };
@@ -206,7 +207,7 @@ class HipOptimizer {
         std::vector<sadvio_imu_factor> fs;
         for (const ImuPair& p : map.imu_pairs) {                                          // :485-500
             if (p.frame_i == p.frame_j || p.frame_i < 0 || p.frame_j < 0 || p.frame_i >= n || p.frame_j >= n) continue;
-            if (!map.frames[p.frame_i].has_imu || !map.frames[p.frame_j].has_imu || !map.frames[p.frame_i].has_imu) continue;
+            if (!map.frames[p.frame_i].has_imu || !map.frames[p.frame_j].has_imu) continue;
             sadvio_imu_factor f = p.f; f.kf_i = p.frame_i; f.kf_j = p.frame_j;
             fs.push_back(f);
         }
@@ -379,6 +380,7 @@ class HipOptimizer {
         std::vector<int> cam_base, lmk_src;
         std::vector<double> cam_wh;       // image size per flat camera (sanityCheck)
         int n_non_kf_obs = 0;             // features skipped because their frame is not a key-frame
+        int n_bad_camera = 0;             // features skipped because their camera index is not one of the frame's sensors
         bool any_non_pinhole = false, non_pinhole_pixel = false;
         std::vector<int32_t> ptr, obs_kf, obs_cam;
         std::vector<sadvio_pose_prior> priors;
@@ -433,6 +435,7 @@ class HipOptimizer {
             for (const Feature& ft : L.features) {
                 if (ft.frame < 0 || ft.frame >= nkf) continue;                           // :256-258 (frame not in the window)
                 if (kf_only && !map.frames[ft.frame].is_keyframe) { F.n_non_kf_obs++; continue; }   // :131, :256
+                if (ft.camera < 0 || ft.camera >= (int)map.frames[ft.frame].cameras.size()) { F.n_bad_camera++; continue; }   // a feature of a sensor the frame does not carry
                 const CameraModel& c = map.frames[ft.frame].cameras[ft.camera];
                 F.obs_kf.push_back(ft.frame); F.obs_cam.push_back(F.cam_base[ft.frame] + ft.camera);
                 if (_angular) {                                                          // getRayCamera of the feature's camera model
@@ -456,6 +459,7 @@ class HipOptimizer {
             F.line_model.insert(F.line_model.end(), L.model, L.model + 6);
             for (const LineFeature& ft : L.features) {
                 if (ft.frame < 0 || ft.frame >= nkf || !map.frames[ft.frame].is_keyframe) continue;   // :296-299
+                if (ft.camera < 0 || ft.camera >= (int)map.frames[ft.frame].cameras.size()) { F.n_bad_camera++; continue; }
                 const CameraModel& c = map.frames[ft.frame].cameras[ft.camera];
                 F.line_obs_kf.push_back(ft.frame); F.line_obs_cam.push_back(F.cam_base[ft.frame] + ft.camera);
                 if (_angular) {                                                          // feature->getBearingVectors()
@@ -539,6 +543,7 @@ class HipOptimizer {
             for (const Feature& ft : L.features) {
                 if (ft.frame < 0 || ft.frame >= (int)map.frames.size()) continue;
                 const FrameState& fr = map.frames[ft.frame];
+                if (ft.camera < 0 || ft.camera >= (int)fr.cameras.size()) continue;
                 const CameraModel& c = fr.cameras[ft.camera];
                 double pf[3], pc[3], u, v;
                 for (int a = 0; a < 3; a++) pf[a] = fr.T_f_w.R[3 * a] * L.p[0] + fr.T_f_w.R[3 * a + 1] * L.p[1] + fr.T_f_w.R[3 * a + 2] * L.p[2] + fr.T_f_w.t[a];

@@ -20,6 +20,9 @@
 #include <stdio.h>
 #include <time.h>
 #include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "factors.h"
 #include "sadvio_oracle.h"
 
@@ -220,10 +223,32 @@ static double apply_loss(double a, double *r, double *Jp, double *Jl) {
     return 2.0 * a * rr - a * a;
 }
 
+
+/* ---- multi-threaded accumulation (n_threads > 1 only: the cpu_baseline leg of bench.py and the offline fixture generators) ----
+ * The dense reduced system is summed into per-thread private copies over a static partition of the landmarks and reduced in
+ * thread order afterwards: deterministic for a given thread count; with one thread the code below is the serial loop itself
+ * (same buffers, same order), so every parity test sees the arithmetic it always saw. */
+static int par_threads(const oracle_problem *P, size_t doubles_per_thread) {
+    int T = P->n_threads > 1 ? P->n_threads : 1;
+#ifndef _OPENMP
+    T = 1;
+#endif
+    while (T > 1 && (size_t)T * doubles_per_thread > ((size_t)1 << 26)) T /= 2;   /* <= 512 MB of private copies */
+    return T;
+}
+static int par_tid(void) {
+#ifdef _OPENMP
+    return omp_get_thread_num();
+#else
+    return 0;
+#endif
+}
+
 /* cost only (candidate evaluation). Returns 1/2 sum r^2 over the reduced program. */
 static double eval_cost(ctx_t *c, const state_t *x) {
     const sadvio_flat_window *w = c->w;
     double cost = 0;
+#pragma omp parallel for schedule(static) reduction(+ : cost) if (c->P->n_threads > 1) num_threads(c->P->n_threads > 1 ? c->P->n_threads : 1)
     for (int l = 0; l < w->n_lmk; l++) {
         for (int o = w->lmk_obs_ptr[l]; o < w->lmk_obs_ptr[l + 1]; o++) {
             int kf = w->obs_kf[o];
@@ -353,7 +378,16 @@ static double eval_full(ctx_t *c, const state_t *x) {
             }
         }
     }
-    /* pose (and reduced-landmark) blocks: serial accumulation into the dense reduced system */
+    /* pose (and reduced-landmark) blocks: accumulation into the dense reduced system (serial with one thread) */
+    {
+    const size_t nH = (size_t)Nr * Nr + (size_t)Nr;
+    const int T = par_threads(P, nH);
+    double *priv = T > 1 ? (double *)xcalloc((size_t)T * nH, sizeof(double)) : NULL;
+#pragma omp parallel num_threads(T) if (T > 1)
+    {
+    double *Hred = T > 1 ? priv + (size_t)par_tid() * nH : c->Hred;
+    double *gred = T > 1 ? Hred + (size_t)Nr * Nr : c->gred;
+#pragma omp for schedule(static)
     for (int l = 0; l < w->n_lmk; l++) {
         for (int o = w->lmk_obs_ptr[l]; o < w->lmk_obs_ptr[l + 1]; o++) {
             int kf = w->obs_kf[o];
@@ -361,26 +395,39 @@ static double eval_full(ctx_t *c, const state_t *x) {
             const double *r = c->r + 2 * o, *Jp = c->Jp + 12 * o, *Jl = c->Jl + 6 * o, *E = c->E + 18 * o;
             if (po >= 0) {
                 for (int a = 0; a < 6; a++) {
-                    c->gred[po + a] += Jp[a] * r[0] + Jp[6 + a] * r[1];
+                    gred[po + a] += Jp[a] * r[0] + Jp[6 + a] * r[1];
                     for (int b = 0; b < 6; b++)
-                        c->Hred[(size_t)(po + a) * Nr + po + b] += Jp[a] * Jp[b] + Jp[6 + a] * Jp[6 + b];
+                        Hred[(size_t)(po + a) * Nr + po + b] += Jp[a] * Jp[b] + Jp[6 + a] * Jp[6 + b];
                 }
             }
             int lo = c->lmk_red[l];
             if (lo >= 0) {
                 for (int a = 0; a < 3; a++) {
-                    c->gred[lo + a] += Jl[a] * r[0] + Jl[3 + a] * r[1];
+                    gred[lo + a] += Jl[a] * r[0] + Jl[3 + a] * r[1];
                     for (int b = 0; b < 3; b++)
-                        c->Hred[(size_t)(lo + a) * Nr + lo + b] += Jl[a] * Jl[b] + Jl[3 + a] * Jl[3 + b];
+                        Hred[(size_t)(lo + a) * Nr + lo + b] += Jl[a] * Jl[b] + Jl[3 + a] * Jl[3 + b];
                 }
                 if (po >= 0)
                     for (int a = 0; a < 6; a++)
                         for (int b = 0; b < 3; b++) {
-                            c->Hred[(size_t)(po + a) * Nr + lo + b] += E[a * 3 + b];
-                            c->Hred[(size_t)(lo + b) * Nr + po + a] += E[a * 3 + b];
+                            Hred[(size_t)(po + a) * Nr + lo + b] += E[a * 3 + b];
+                            Hred[(size_t)(lo + b) * Nr + po + a] += E[a * 3 + b];
                         }
             }
         }
+    }
+    }
+    if (T > 1) {
+        for (int t = 0; t < T; t++) for (int i = 0; i < Nr; i++) c->gred[i] += priv[(size_t)t * nH + (size_t)Nr * Nr + i];
+        /* Hred rows: reduce with the private layout [T][Nr*Nr + Nr] */
+#pragma omp parallel for schedule(static) num_threads(T)
+        for (long long i = 0; i < (long long)Nr * Nr; i++) {
+            double a = c->Hred[i];
+            for (int t = 0; t < T; t++) a += priv[(size_t)t * nH + i];
+            c->Hred[i] = a;
+        }
+        free(priv);
+    }
     }
     for (int k = 0; k < P->n_prior; k++) {
         const sadvio_pose_prior *pr = P->priors + k;
@@ -547,8 +594,17 @@ static int compute_step(ctx_t *c, const sadvio_solve_options *o, double radius, 
         S[(size_t)i * Nr + i] += d / radius / s2;
     }
     int fail = 0;
+    {
+    const size_t nS = (size_t)Nr * Nr + (size_t)Nr;
+    const int T = par_threads(c->P, nS);
+    double *priv = T > 1 ? (double *)xcalloc((size_t)T * nS, sizeof(double)) : NULL;
+#pragma omp parallel num_threads(T) if (T > 1)
+    {
+    double *St = T > 1 ? priv + (size_t)par_tid() * nS : S;
+    double *rhst = T > 1 ? St + (size_t)Nr * Nr : rhs;
+#pragma omp for schedule(static)
     for (int l = 0; l < w->n_lmk; l++) {
-        if (!c->lmk_elim[l]) continue;
+        if (!c->lmk_elim[l] || fail) continue;
         double M[9];
         memcpy(M, c->Hll + 9 * l, sizeof(M));
         for (int a = 0; a < 3; a++) {
@@ -558,7 +614,7 @@ static int compute_step(ctx_t *c, const sadvio_solve_options *o, double radius, 
         }
         double *Mi = Minv + 9 * l;
         double det = m3_inverse(M, Mi);
-        if (!(det > 0) || !isfinite(det)) { fail = 1; break; }
+        if (!(det > 0) || !isfinite(det)) { fail = 1; continue; }
         const double *g = c->gl + 3 * l;
         double Mg[3];
         m3_vec(Mi, g, Mg);
@@ -571,17 +627,29 @@ static int compute_step(ctx_t *c, const sadvio_solve_options *o, double radius, 
             for (int i = 0; i < 6; i++)
                 for (int j = 0; j < 3; j++)
                     Y[i * 3 + j] = Ea[i * 3] * Mi[j] + Ea[i * 3 + 1] * Mi[3 + j] + Ea[i * 3 + 2] * Mi[6 + j];
-            for (int i = 0; i < 6; i++) rhs[pa + i] -= Ea[i * 3] * Mg[0] + Ea[i * 3 + 1] * Mg[1] + Ea[i * 3 + 2] * Mg[2];
+            for (int i = 0; i < 6; i++) rhst[pa + i] -= Ea[i * 3] * Mg[0] + Ea[i * 3 + 1] * Mg[1] + Ea[i * 3 + 2] * Mg[2];
             for (int b = o0; b < o1; b++) {
                 int pb = c->kf_off[w->obs_kf[b]];
                 if (pb < 0) continue;
                 const double *Eb = c->E + 18 * b;
                 for (int i = 0; i < 6; i++)
                     for (int j = 0; j < 6; j++)
-                        S[(size_t)(pa + i) * Nr + pb + j] -=
+                        St[(size_t)(pa + i) * Nr + pb + j] -=
                             Y[i * 3] * Eb[j * 3] + Y[i * 3 + 1] * Eb[j * 3 + 1] + Y[i * 3 + 2] * Eb[j * 3 + 2];
             }
         }
+    }
+    }
+    if (T > 1) {
+        for (int t = 0; t < T; t++) for (int i = 0; i < Nr; i++) rhs[i] += priv[(size_t)t * nS + (size_t)Nr * Nr + i];
+#pragma omp parallel for schedule(static) num_threads(T)
+        for (long long i = 0; i < (long long)Nr * Nr; i++) {
+            double a = S[i];
+            for (int t = 0; t < T; t++) a += priv[(size_t)t * nS + i];
+            S[i] = a;
+        }
+        free(priv);
+    }
     }
     if (!fail && Nr > 0) fail = chol_solve(S, rhs, Nr);
     if (!fail) {
@@ -589,7 +657,8 @@ static int compute_step(ctx_t *c, const sadvio_solve_options *o, double radius, 
             dred[i] = -rhs[i];
             if (!isfinite(dred[i])) fail = 1;
         }
-        for (int l = 0; l < w->n_lmk && !fail; l++) {
+#pragma omp parallel for schedule(static) if (c->P->n_threads > 1) num_threads(c->P->n_threads > 1 ? c->P->n_threads : 1)
+        for (int l = 0; l < w->n_lmk; l++) {
             dlmk[3 * l] = dlmk[3 * l + 1] = dlmk[3 * l + 2] = 0;
             if (!c->lmk_elim[l]) continue;
             /* y_l = Minv (g_l - E^T y_p); delta_l = -y_l, with y_p = -dred */
@@ -617,6 +686,7 @@ static double model_cost_change(ctx_t *c, const double *dred, const double *dlmk
     const sadvio_flat_window *w = c->w;
     const oracle_problem *P = c->P;
     double acc = 0;
+#pragma omp parallel for schedule(static) reduction(+ : acc) if (P->n_threads > 1) num_threads(P->n_threads > 1 ? P->n_threads : 1)
     for (int l = 0; l < w->n_lmk; l++) {
         for (int o = w->lmk_obs_ptr[l]; o < w->lmk_obs_ptr[l + 1]; o++) {
             int po = c->kf_off[w->obs_kf[o]];

@@ -1713,6 +1713,7 @@ int sadvio_ba_marginalize_relative(sadvio_ba_handle* h, int32_t w, int32_t kf_a,
     if (!h || !inf36) return SADVIO_E_INVALID_ARG;
     if (!h->uploaded) { h->err = "marginalize_relative before set_windows"; return SADVIO_E_STATE; }
     if (w < 0 || w >= (int)h->wins.size()) { h->err = "marginalize_relative: window out of range"; return SADVIO_E_INVALID_ARG; }
+    if (h->world > 1) { h->err = "marginalize_relative: the window is sharded over several GPUs (each rank holds a landmark partition only)"; return SADVIO_E_INVALID_ARG; }
     const WinDev& d = h->wins[w].d;
     if (kf_a < 0 || kf_a >= d.n_kf || kf_b < 0 || kf_b >= d.n_kf || kf_a == kf_b) { h->err = "marginalize_relative: bad key-frame index"; return SADVIO_E_INVALID_ARG; }
     if (d.has_imu) { h->err = "marginalize_relative: frames with IMU states are not supported (the reference's own column layout for them is inconsistent, BundleAdjustmentCERESAnalytic.cpp:705-737)"; return SADVIO_E_INVALID_ARG; }
