@@ -258,6 +258,7 @@ struct sadvio_ba_handle {
     int max_tile_kf = 1, max_tile_free = 0, max_gemm_free = 0;
     DevBuf<double> d_obs_meas;
     DevBuf<PriorDev> d_priors;
+    DevBuf<double> d_prior_lin;   // [2][n_prior][PRIOR_LIN], see DevPtrs::prior_lin
     DevBuf<ImuDev> d_imus;
     DevBuf<double> d_imu_scratch;
     DevBuf<double> d_S, d_gred, d_gfull, d_hdiag, d_delta, d_s_pose;
@@ -341,7 +342,8 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.obs_kf = h->d_obs_kf.p; P.obs_cam = h->d_obs_cam.p; P.obs_meas = h->d_obs_meas.p;
     P.obs_slot = h->d_obs_slot.p; P.tile_kf = h->d_tile_kf.p; P.tile_row = h->d_tile_row.p;
     P.ptab = h->d_ptab.p; P.ptab_stride = (long long)POSE_TAB * h->n_kf_tot;
-    P.priors = h->d_priors.p; P.imus = h->d_imus.p; P.imu_scratch = h->d_imu_scratch.p;
+    P.priors = h->d_priors.p; P.prior_lin = h->d_prior_lin.p; P.prior_lin_stride = (long long)h->priors.size() * PRIOR_LIN; P.n_prior_tot = (int)h->priors.size();
+    P.imus = h->d_imus.p; P.imu_scratch = h->d_imu_scratch.p;
     P.S = h->d_S.p; P.gred = h->d_gred.p; P.gfull = h->d_gfull.p; P.hdiag = h->d_hdiag.p;
     P.delta = h->d_delta.p; P.s_pose = h->d_s_pose.p;
     P.dbg_ts = h->d_dbg.p;
@@ -563,6 +565,7 @@ int upload_priors(sadvio_ba_handle* h) {
         h->wins[w].d.prior_end = (int)h->priors.size();
     }
     HIP_TRY(h->d_priors.alloc(h->priors.size()));
+    HIP_TRY(h->d_prior_lin.alloc(2 * h->priors.size() * (size_t)PRIOR_LIN));
     if (!h->priors.empty())
         h->up.add(h->d_priors.p, h->priors.data(), h->priors.size() * sizeof(PriorDev));
     h->imus.clear();
@@ -657,7 +660,7 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     h->d_kf_fidx.release(); h->d_cam_K.release(); h->d_cam_T.release(); h->d_cam_isig.release();
     h->d_lmk_p.release(); h->d_xl.release(); h->d_s_lmk.release(); h->d_lmk_const.release();
     h->d_lmk_ob.release(); h->d_lmk_oe.release(); h->d_obs_kf.release(); h->d_obs_cam.release();
-    h->d_obs_meas.release(); h->d_priors.release(); h->d_S.release(); h->d_rank_s.release(); h->d_gred.release(); h->d_gfull.release();
+    h->d_obs_meas.release(); h->d_priors.release(); h->d_prior_lin.release(); h->d_S.release(); h->d_rank_s.release(); h->d_gred.release(); h->d_gfull.release();
     h->d_hdiag.release(); h->d_delta.release(); h->d_s_pose.release(); h->d_states.release(); h->d_trace.release(); h->d_tstart.release(); h->d_acc.release();
     h->d_probe.release(); h->d_tile_kf.release(); h->d_tile_row.release(); h->d_obs_slot.release(); h->d_ptab.release(); h->d_tacc.release(); h->d_dbg.release(); h->d_imus.release(); h->d_imu_scratch.release();
     delete h;
@@ -2034,7 +2037,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     const size_t lds_back = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)mtk * 18) + 16;
     // k_solve<0>: tile-packed image + y / gf / hd / xs + the chol16 exchange areas
     const size_t npq = (size_t)h->max_np;
-    const size_t lds_solve = sizeof(double) * ((size_t)c16_size((int)npq) + 4 * npq + 1 + C16_WORK + 16 * (size_t)c16_blocks((int)npq + 1)) + 64;
+    const size_t lds_solve = sizeof(double) * ((size_t)c16_size((int)npq) + 4 * npq + 1 + C16_WORK + 16 * (size_t)c16_blocks((int)npq + 1) + SOLVE_KFC * 20) + 64;
     // robust loss or prior-kept landmarks in the batch: the kernels carrying those (rare) paths
     bool any_pseudo = false;
     for (const auto& v : h->sp_elim) for (char e : v) any_pseudo |= e != 0;
@@ -2123,7 +2126,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     bool coll_failed = false;
     auto enqueue = [&]() {
         { ScopedTimer t(h, "k_reset"); hipLaunchKernelGGL(k_reset, dim3(reset_blocks), dim3(256), 0, h->stream, P); }
-        { ScopedTimer t(h, "k_init_tables"); hipLaunchKernelGGL(k_init_tables, dim3((h->n_kf_tot + 63) / 64), dim3(64), 0, h->stream, P, h->n_kf_tot); }
+        { ScopedTimer t(h, "k_init_tables"); hipLaunchKernelGGL(k_init_tables, dim3((std::max(h->n_kf_tot, (int)h->priors.size()) + 63) / 64), dim3(64), 0, h->stream, P, h->n_kf_tot); }
         const int n_imu_all = (int)h->imus.size();
         // IMU factors are evaluated on a side stream: the linearisation next to k_build, the candidate cost next to
         // k_backsub (fork / join with events; inside the captured graph these become parallel branches)

@@ -93,8 +93,9 @@ __device__ __forceinline__ void c16_store(double* t, int ln, c16_d4 v) {
 __device__ __forceinline__ void c16_symmetrize(double* A, int nb) {
     for (int e = threadIdx.x; e < nb * 120; e += blockDim.x) {
         const int I = e / 120;
-        int q = e - I * 120, c = 1;
-        while (q >= c) { q -= c; c++; }          // (r, c), r < c <= 15
+        int q = e - I * 120;
+        const int c = (int)((1.0f + __builtin_sqrtf((float)(1 + 8 * q))) * 0.5f);   // q = c (c - 1) / 2 + r, r < c <= 15 (exact: 1 + 8 q <= 953)
+        q -= (c * (c - 1)) >> 1;
         double* t = A + (c16_tile(I, I) << 8);
         t[c * 16 + q] = t[q * 16 + c];
     }

@@ -38,6 +38,9 @@ struct DevPtrs {
     double* ptab;                   // [2][n_kf_tot][POSE_TAB] pose tables of the two delta buffers
     long long ptab_stride;
     const PriorDev* priors;
+    double* prior_lin;              // [2][n_prior_tot][PRIOR_LIN] g = J^T r (6) | H = J^T J lower (21) | |r|^2 of every pose prior at the x of
+    long long prior_lin_stride;     // each delta buffer: written at x = 0 by k_init_tables, at the candidate by k_solve's back half
+    int n_prior_tot;
     const ImuDev* imus;
     double* imu_scratch;  // [n_imu_tot][IMU_ROW], see ba_types.h
     double* S; double* gred; double* gfull; double* hdiag; double* delta; double* s_pose;
@@ -1161,6 +1164,33 @@ __device__ __noinline__ bool sparse_eval(const DevPtrs& P, const WinDev& W, cons
 // run the same front (MODE 1) and back (MODE 2) halves around a library factorisation of S in place.
 // EXTRAS = false compiles the IMU / sparse-prior / dense-prior sections out: the plain visual window (config 2)
 // then runs a kernel without their register and scratch footprint.
+
+// PosePriordx at the deltas d6: its linearisation record (see DevPtrs::prior_lin). k_solve's front half only adds the record
+// of the buffer that holds x — the evaluation itself (log, Jr^-1: ~0.8 us on one lane) is off the critical path: it was done
+// behind the previous factorisation, on the candidate that became x.
+__device__ __forceinline__ double prior_lin_record(const double* T0, const double* Tp, const double* inf, const double* d6, double* rec) {
+    double r[6], J[36];
+    pose_prior_factor(T0, Tp, inf, d6, r, J);
+    double c = 0.0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        c += r[a] * r[a];
+        double g = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) g += J[6 * q + a] * r[q];
+        rec[a] = g;
+#pragma unroll
+        for (int b = 0; b <= a; b++) {
+            double hh = 0.0;
+#pragma unroll
+            for (int q = 0; q < 6; q++) hh += J[6 * q + a] * J[6 * q + b];
+            rec[6 + a * (a + 1) / 2 + b] = hh;
+        }
+    }
+    rec[27] = c;
+    return c;
+}
+
 template <int MODE, bool EXTRAS>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1172,14 +1202,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63, nwv = blockDim.x >> 6;  // wv in an SGPR: row tests below are scalar branches
     LmState* stp = P.states + (long long)w * P.state_stride + slot;
     IterAcc* acc = P.acc + (long long)w * P.state_stride + slot;
-    __shared__ LmState st;
+    __shared__ int s_done;                      // the decision of this kernel's own finalisation step (thread 0)
     __shared__ double s_red[SOLVE_THREADS / 64 * 4];
     SADVIO_TS(3, 0);
 #ifdef SADVIO_KERNEL_TS
     if ((P.debug & 4096) && blockIdx.x == 0 && tid == 0 && slot == 3) P.dbg_ts[20] = clock64();
 #endif
-    if (tid == 0) st = *stp;
-    __syncthreads();
+    LmState st = *stp;                          // uniform address: every thread keeps its own copy (no LDS round trip, no barrier)
     if (MODE == 1 && tid == 0) P.big_info[w] = 0;
     if (st.done) return;
     const int Np = W.Np;
@@ -1199,14 +1228,62 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     double* xs = BIG ? gredg : hd + Np;         // solution (BIG: the library factorisation overwrites the right-hand side)
     double* pub = xs + Np + (Np & 1);           // chol16: exchange area (C16_WORK doubles), 16-byte aligned
     double* yv = pub + C16_WORK;                // chol16: back-substitution exchange (16 * nbt)
+    // MODE 0: what the back half needs from HBM is fetched with the front half's loads and parked in LDS across the
+    // factorisation: the first SOLVE_KFC key-frames (free index, x, T0)
+    double* kfc = yv + 16 * nbt;                // [SOLVE_KFC][20]
     auto aidx = [&](int i, int j) -> long long { return BIG ? (long long)i * ld + j : (long long)c16_index(i, j); };  // i >= j
     const int cur = st.cur;
     const double* xp = P.xp + (long long)cur * P.xp_stride;
     const int n_imu = W.imu_end - W.imu_begin;
     double early_cost = 0.0, early_fixed = 0.0, early_gm = 0.0;
+    // Front half. Every HBM read is issued before the first wait. In-LDS windows: the image of S goes straight into LDS
+    // (global_load_lds_dwordx4: no staging registers, no ds_write pass); the pose priors only contribute their linearisation
+    // records (DevPtrs::prior_lin) of the buffer that holds x.
+    double cost_part = 0.0, fixed_part = 0.0;
+    const int n_pri = W.prior_end - W.prior_begin;
+    const double* plin = P.prior_lin + (long long)cur * P.prior_lin_stride + (long long)W.prior_begin * PRIOR_LIN;
+    // item = (prior, entry of g | H | cost): the first item of this thread is loaded here, windows with more items loop below
+    double pl_v = 0.0;
+    int pl_fi = -1;
+    if (MODE != 2 && tid < n_pri * 28) {
+        const int p = tid / 28, e = tid - 28 * p;
+        pl_v = plin[p * PRIOR_LIN + e];
+        pl_fi = P.kf_fidx[P.priors[W.prior_begin + p].kf];
+    }
+    double* sp = P.s_pose + W.red_off;
+    double c_sp = 1.0;
     if (MODE != 2) {
-    // window totals of the linearisation (the tiles' k_build partials / the ranks' of a sharded window): loaded first, their
-    // latency runs under the copy of S
+    if (!BIG) {
+        // the image: a linear, fully coalesced 16-byte copy (S is kept in HBM in the layout it has in LDS); a wave-instruction
+        // moves 64 consecutive double2 to a wave-uniform LDS base + lane * 16
+        typedef __attribute__((address_space(3))) void lds_void_t;
+        typedef __attribute__((address_space(1))) const void glb_void_t;
+        const double2* g2 = (const double2*)Sg;
+        double2* A2 = (double2*)A;
+        const int n2 = img_n >> 1;              // a whole number of 256-double tiles: a multiple of 64 double2
+        const int stride = nwv * 64;
+        for (int i = wv * 64; i < n2; i += stride)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(g2 + i + ln), (lds_void_t*)(A2 + i), 16, 0, 0);
+    }
+    // the column vectors (N_p <= MAX_LDS_NP < SOLVE_THREADS: one column per thread) and the Jacobi scale of iteration 0
+    double c_y = 0.0, c_gf = 0.0, c_hd = 0.0;
+    if (!BIG && tid < Np) {
+        c_y = gredg[tid]; c_gf = gfullg[tid]; c_hd = hdg[tid];
+        if (slot != 0) c_sp = sp[tid];
+    }
+    // candidate-pose pass (behind the factorisation): this thread's key-frame is fetched now and parked in LDS
+    const bool kf_pre = MODE == 0 && tid < W.n_kf && tid < SOLVE_KFC;
+    int kf_fi = -1;
+    double kf_t6[6], kf_t12[12];
+    if (kf_pre) {
+        const int g = W.kf_base + tid;
+        kf_fi = P.kf_fidx[g];
+#pragma unroll
+        for (int i = 0; i < 6; i++) kf_t6[i] = xp[6 * (long long)g + i];
+#pragma unroll
+        for (int i = 0; i < 12; i++) kf_t12[i] = P.kf_T0[12 * (long long)g + i];
+    }
+    // window totals of the linearisation (the tiles' k_build partials / the ranks' of a sharded window)
     if (P.world > 1) {
         const double* rb = P.rank_b + (long long)w * P.world * 4;
         for (int r = tid; r < P.world; r += blockDim.x) { early_cost += rb[4 * r]; early_fixed += rb[4 * r + 1]; early_gm = fmax(early_gm, rb[4 * r + 2]); }
@@ -1216,58 +1293,47 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             early_cost += ta[t].lin_cost; early_fixed += ta[t].fixed_cost; early_gm = fmax(early_gm, ta[t].gmax);
         }
     }
-    // load + clear the global accumulator: S is kept in HBM in the same packed lower-triangular layout as in
-    // LDS, so this is a linear, fully coalesced 16-byte copy; all loads are issued before the first use.
     if (!BIG) {
-        const int n2 = img_n >> 1;              // the image is a whole number of 256-double tiles
-        constexpr int MAXV = (c16_size(MAX_LDS_NP) / 2 + SOLVE_THREADS - 1) / SOLVE_THREADS;
-        double2 v[MAXV];
-        const double2* g2 = (const double2*)Sg;
-#pragma unroll
-        for (int q = 0; q < MAXV; q++) {
-            const int i = tid + q * SOLVE_THREADS;
-            if (q * SOLVE_THREADS < n2) v[q] = (i < n2) ? g2[i] : make_double2(0.0, 0.0);
+        if (tid < Np) {
+            y[tid] = c_y; gf[tid] = c_gf; hd[tid] = c_hd;
+            gredg[tid] = 0.0; gfullg[tid] = 0.0; hdg[tid] = 0.0;
         }
-        const double2 z2 = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int q = 0; q < MAXV; q++) {
-            const int i = tid + q * SOLVE_THREADS;
-            if (q * SOLVE_THREADS < n2 && i < n2) { ((double2*)A)[i] = v[q]; ((double2*)Sg)[i] = z2; }
+        {
+            // clear the global accumulator for the next k_build: each wave the part it copied, once its own copy has landed
+            // (nothing orders a store of ANOTHER wave behind this wave's reads of the same addresses)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const double2 z2 = make_double2(0.0, 0.0);
+            const int n2 = img_n >> 1;
+            const int stride = nwv * 64;
+            for (int i = wv * 64; i < n2; i += stride) ((double2*)Sg)[i + ln] = z2;
         }
-    }
-    if (!BIG)
-    for (int i = tid; i < Np; i += blockDim.x) {
-        y[i] = gredg[i]; gf[i] = gfullg[i]; hd[i] = hdg[i];
-        gredg[i] = 0.0; gfullg[i] = 0.0; hdg[i] = 0.0;
+        if (kf_pre) {
+            double* c = kfc + tid * 20;
+            c[0] = (double)kf_fi;
+#pragma unroll
+            for (int i = 0; i < 6; i++) c[1 + i] = kf_t6[i];
+#pragma unroll
+            for (int i = 0; i < 12; i++) c[7 + i] = kf_t12[i];
+        }
     }
     __syncthreads();
     SADVIO_TS(3, 1);
-    // pose-only factors at x: PosePriordx (K4). One thread per prior; LDS atomics.
-    double cost_part = 0.0, fixed_part = 0.0;
-    for (int k = W.prior_begin + tid; k < W.prior_end; k += blockDim.x) {
-        const PriorDev pr = P.priors[k];
-        int fi = P.kf_fidx[pr.kf];
-        double d6[6], r[6], J[36];
-#pragma unroll
-        for (int i = 0; i < 6; i++) d6[i] = xp[6 * (long long)pr.kf + i];
-        pose_prior_factor(P.kf_T0 + 12 * (long long)pr.kf, pr.T_prior, pr.inf, d6, r, J);
-        double c = 0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) c += r[i] * r[i];
-        if (fi < 0) { fixed_part += c; continue; }
-        cost_part += c;
-        int base = fi * W.dpf;
-        for (int a = 0; a < 6; a++) {
-            double g = 0, h = 0;
-            for (int q = 0; q < 6; q++) { g += J[6 * q + a] * r[q]; h += J[6 * q + a] * J[6 * q + a]; }
-            atomic_add_f64(&y[base + a], g);
-            atomic_add_f64(&gf[base + a], g);
-            atomic_add_f64(&hd[base + a], h);
-            for (int b = 0; b <= a; b++) {
-                double hh = 0;
-                for (int q = 0; q < 6; q++) hh += J[6 * q + a] * J[6 * q + b];
-                atomic_add_f64(&A[aidx(base + a, base + b)], hh);
-            }
+    // pose-only factors at x: PosePriordx (K4) from their linearisation records: item = (prior, entry), one atomic each
+    for (int it = tid; it < n_pri * 28; it += blockDim.x) {
+        const int p = it / 28, e = it - 28 * p;
+        double v = pl_v;
+        int fi = pl_fi;
+        if (it != tid) { v = plin[p * PRIOR_LIN + e]; fi = P.kf_fidx[P.priors[W.prior_begin + p].kf]; }
+        if (e == 27) { if (fi < 0) fixed_part += v; else cost_part += v; continue; }
+        if (fi < 0) continue;
+        const int base = fi * W.dpf;
+        if (e < 6) { atomic_add_f64(&y[base + e], v); atomic_add_f64(&gf[base + e], v); }
+        else {
+            const int q = e - 6;
+            const int a = (int)((__builtin_sqrtf((float)(8 * q + 1)) - 1.0f) * 0.5f);   // q = a (a + 1) / 2 + b, b <= a <= 5
+            const int b = q - ((a * (a + 1)) >> 1);
+            atomic_add_f64(&A[aidx(base + a, base + b)], v);
+            if (a == b) atomic_add_f64(&hd[base + a], v);
         }
     }
     // IMUFactor + IMUBiasFactor (K3): k_imu_eval<true> (one 64-lane workgroup per factor, launched between k_build and
@@ -1408,12 +1474,28 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     double gm = early_gm;
     cost_part += early_cost; fixed_part += early_fixed;   // the tiles' partials were loaded at the top of the kernel
     __syncthreads();
-    // gradient tolerance (TrustRegionMinimizer::GradientToleranceReached) on the gradient at x
-    for (int i = tid; i < Np; i += blockDim.x) gm = fmax(gm, fabs(gf[i]));
+    // gradient tolerance (TrustRegionMinimizer::GradientToleranceReached) on the gradient at x; in the same pass (LDS image):
+    // Jacobi scaling (iteration 0), LM diagonal, right-hand side into row Np of the packed matrix — none of it depends on the
+    // finalisation test below, which only ends the solve
+    if (!BIG) {
+        if (tid < Np) {
+            gm = fmax(gm, fabs(gf[tid]));
+            const double hdi = hd[tid];
+            double s = c_sp;
+            if (slot == 0) { s = P.o.jacobi_scaling ? 1.0 / (1.0 + sqrt(hdi)) : 1.0; sp[tid] = s; }
+            const double s2 = s * s;
+            A[c16_index(tid, tid)] += fmin(fmax(s2 * hdi, P.o.min_lm_diagonal), P.o.max_lm_diagonal) / st.radius / s2;
+            A[c16_index(Np, tid)] = y[tid];     // right-hand side = row Np (the rest of that row and the padding rows are zero: S is)
+        }
+    } else {
+        for (int i = tid; i < Np; i += blockDim.x) gm = fmax(gm, fabs(gf[i]));
+    }
     gm = wave_max(gm); cost_part = wave_sum(cost_part); fixed_part = wave_sum(fixed_part);
     if (ln == 0) { s_red[wv * 3] = gm; s_red[wv * 3 + 1] = cost_part; s_red[wv * 3 + 2] = fixed_part; }
+    if (tid == 0) s_done = 0;
     __syncthreads();
-    if (tid == 0) {
+    if (!BIG) c16_symmetrize(A, nbt);           // the assembly writes i >= j only; the diagonal tiles are used as full symmetric tiles
+    if (tid == blockDim.x - 1) {   // the last thread has the least symmetrisation work above
         double g = 0, cs = 0, fs = 0;
         for (int k = 0; k < nwv; k++) { g = fmax(g, s_red[k * 3]); cs += s_red[k * 3 + 1]; fs += s_red[k * 3 + 2]; }
         acc->gmax_bits = (unsigned long long)__double_as_longlong(g);
@@ -1425,30 +1507,27 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         const bool time_up = P.o.max_time_ticks > 0.0 && P.t_start && (double)(wall_clock64() - *P.t_start) >= P.o.max_time_ticks;
         acc->time_up = time_up ? 1 : 0;
         if (time_up || g <= P.o.gradient_tolerance) {
-            st.done = 1; st.termination = time_up ? 0 : 3;
-            st.x_cost = 0.5 * cs;
-            if (st.iter == 0) st.initial_cost = st.x_cost;
-            *stp = st;
+            LmState e = st;
+            e.done = 1; e.termination = time_up ? 0 : 3;
+            e.x_cost = 0.5 * cs;
+            if (e.iter == 0) e.initial_cost = e.x_cost;
+            *stp = e;
+            s_done = 1;
         }
     }
     __syncthreads();
-    if (st.done) return;
+    if (s_done) return;
     SADVIO_TS(3, 2);
-    // Jacobi scaling (iteration 0) and LM diagonal; right-hand side into row Np of the packed matrix
-    double* sp = P.s_pose + W.red_off;
-    for (int i = tid; i < Np; i += blockDim.x) {
-        double s;
-        if (slot == 0) { s = P.o.jacobi_scaling ? 1.0 / (1.0 + sqrt(hd[i])) : 1.0; sp[i] = s; }
-        else s = sp[i];
-        double s2 = s * s;
-        A[aidx(i, i)] += fmin(fmax(s2 * hd[i], P.o.min_lm_diagonal), P.o.max_lm_diagonal) / st.radius / s2;
-        if (!BIG) A[c16_index(Np, i)] = y[i];   // right-hand side = row Np (the rest of that row and the padding rows are zero: S is)
-    }
-    if (!BIG) {
+    if (BIG) {
+        for (int i = tid; i < Np; i += blockDim.x) {
+            double s;
+            if (slot == 0) { s = P.o.jacobi_scaling ? 1.0 / (1.0 + sqrt(hd[i])) : 1.0; sp[i] = s; }
+            else s = sp[i];
+            double s2 = s * s;
+            A[aidx(i, i)] += fmin(fmax(s2 * hd[i], P.o.min_lm_diagonal), P.o.max_lm_diagonal) / st.radius / s2;
+        }
         __syncthreads();
-        c16_symmetrize(A, nbt);                 // the assembly writes i >= j only; the diagonal tiles are used as full symmetric tiles
     }
-    __syncthreads();
     SADVIO_TS(3, 3);
     if (MODE == 1) return;  // the host enqueues potrf / potrs on S, gred next
     }  // MODE != 2
@@ -1488,16 +1567,21 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     double* xpc = P.xp + (long long)(1 - cur) * P.xp_stride;
     for (int k = tid; k < W.n_kf; k += blockDim.x) {
         int g = W.kf_base + k;
-        int fi = P.kf_fidx[g];
-        double d6[6], tab[POSE_TAB];
+        const bool pre = MODE == 0 && k < SOLVE_KFC;  // parked in LDS by the front half
+        const double* kc = kfc + (pre ? k : 0) * 20;
+        int fi = pre ? (int)kc[0] : P.kf_fidx[g];
+        double d6[6], tab[POSE_TAB], T0r[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) T0r[i] = pre ? kc[7 + i] : P.kf_T0[12 * (long long)g + i];
+#pragma unroll
         for (int i = 0; i < 6; i++) {
-            double v = xp[6 * (long long)g + i] + (fi < 0 ? 0.0 : y[fi * W.dpf + i]);
+            double v = (pre ? kc[1 + i] : xp[6 * (long long)g + i]) + (fi < 0 ? 0.0 : y[fi * W.dpf + i]);
             xpc[6 * (long long)g + i] = v;
             d6[i] = v;
             if (fi >= 0) cn += v * v;
         }
         // pose table of the candidate buffer (k_backsub reads it now, k_build reads it if the step is accepted)
-        pose_table_entry(P.kf_T0 + 12 * (long long)g, d6, tab);
+        pose_table_entry(T0r, d6, tab);
         {
             double* dst = P.ptab + (long long)(1 - cur) * P.ptab_stride + (long long)g * POSE_TAB;
             for (int i = 0; i < POSE_TAB; i++) dst[i] = tab[i];
@@ -1527,23 +1611,32 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         }
     }
     SADVIO_TS(3, 6);
-    // priors: model cost change and candidate cost
+    // priors: model cost change -(J d)^T (r + J d / 2) = -(d.g + d^T H d / 2) from the record at x, and the linearisation
+    // record AT THE CANDIDATE (its cost is the candidate cost; the next front half adds it if the step is accepted). Priors
+    // are dealt from the LAST thread downwards: a different wave than the pose tables above, so the two run side by side.
     double mcc = 0.0, cc = 0.0;
-    for (int k = W.prior_begin + tid; k < W.prior_end; k += blockDim.x) {
-        const PriorDev pr = P.priors[k];
-        int fi = P.kf_fidx[pr.kf];
-        if (fi < 0) continue;
-        double d6[6], r[6], J[36], rc[6];
-        for (int i = 0; i < 6; i++) d6[i] = xp[6 * (long long)pr.kf + i];
-        pose_prior_factor(P.kf_T0 + 12 * (long long)pr.kf, pr.T_prior, pr.inf, d6, r, J);
-        for (int q = 0; q < 6; q++) {
-            double m = 0;
-            for (int a = 0; a < 6; a++) m += J[6 * q + a] * y[fi * W.dpf + a];
-            mcc += -m * (r[q] + 0.5 * m);
+    {
+        const double* plx = P.prior_lin + (long long)cur * P.prior_lin_stride + (long long)W.prior_begin * PRIOR_LIN;
+        double* plc = P.prior_lin + (long long)(1 - cur) * P.prior_lin_stride + (long long)W.prior_begin * PRIOR_LIN;
+        for (int p = (int)blockDim.x - 1 - tid; p < W.prior_end - W.prior_begin; p += blockDim.x) {
+            const PriorDev pr = P.priors[W.prior_begin + p];
+            const int fi = P.kf_fidx[pr.kf];
+            if (fi < 0) continue;
+            double d[6], d6[6], T0r[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) T0r[i] = P.kf_T0[12 * (long long)pr.kf + i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { d[i] = y[fi * W.dpf + i]; d6[i] = xp[6 * (long long)pr.kf + i] + d[i]; }
+            double lin = 0.0, quad = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                lin += d[a] * plx[p * PRIOR_LIN + a];
+#pragma unroll
+                for (int b = 0; b <= a; b++) quad += (a == b ? 0.5 : 1.0) * d[a] * d[b] * plx[p * PRIOR_LIN + 6 + a * (a + 1) / 2 + b];
+            }
+            mcc += -(lin + quad);
+            cc += prior_lin_record(T0r, pr.T_prior, pr.inf, d6, plc + p * PRIOR_LIN);
         }
-        for (int i = 0; i < 6; i++) d6[i] += y[fi * W.dpf + i];
-        pose_prior_factor(P.kf_T0 + 12 * (long long)pr.kf, pr.T_prior, pr.inf, d6, rc, nullptr);
-        for (int q = 0; q < 6; q++) cc += rc[q] * rc[q];
     }
     if (EXTRAS && n_imu > 0) {
         const double* xv = P.xv + (long long)cur * P.xv_stride;
@@ -1976,8 +2069,13 @@ __global__ void k_reset(DevPtrs P) {
 }
 
 // Pose tables of delta buffer 0 at the start of a solve (all deltas zero).
-__global__ void k_init_tables(DevPtrs P, int n_kf_tot) {
+__global__ __launch_bounds__(64) void k_init_tables(DevPtrs P, int n_kf_tot) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < P.n_prior_tot) {   // linearisation records of the pose priors at x = 0 (buffer 0): see DevPtrs::prior_lin
+        const PriorDev pr = P.priors[g];
+        double d6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        prior_lin_record(P.kf_T0 + 12 * (long long)pr.kf, pr.T_prior, pr.inf, d6, P.prior_lin + (long long)g * PRIOR_LIN);
+    }
     if (g >= n_kf_tot) return;
     double d6[6], tab[POSE_TAB];
     for (int i = 0; i < 6; i++) d6[i] = 0.0;
