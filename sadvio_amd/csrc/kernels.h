@@ -210,20 +210,43 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 
-// Sum the k_backsub partials of a window's tiles (slot parity `par`) into `a`: executed by one wave.
+// Sum the k_backsub partials of a window's tiles (slot parity `par`): executed by one wave. Every kernel that re-derives
+// the LM decision of a slot must get the SAME BITS, so the order is canonical for windows of at most 4 * BUILD_THREADS tiles
+// (the only ones whose decision is taken by more than one kernel): tile t belongs to virtual thread t % 256, which adds its
+// (at most four) tiles pairwise; the 64 virtual threads of a virtual wave are summed with wave_sum; the four virtual waves
+// pairwise. k_build does exactly this with its 256 real threads (all loads in flight at once); a single wave emulates it.
 __device__ __forceinline__ void wave_sum_backsub_partials(const DevPtrs& P, int par, int w, int tile0, int ntiles, int ln,
                                                           double* out4) {
     double c = 0.0, m = 0.0, sn = 0.0, cn = 0.0;
     if (P.world > 1) {
         const double* rs = P.rank_s + (long long)w * P.world * 4;
         for (int r = ln; r < P.world; r += 64) { c += rs[4 * r]; m += rs[4 * r + 1]; sn += rs[4 * r + 2]; cn += rs[4 * r + 3]; }
+        c = wave_sum(c); m = wave_sum(m); sn = wave_sum(sn); cn = wave_sum(cn);
+    } else if (ntiles <= 4 * BUILD_THREADS) {
+        const TileAcc* ta = P.tacc + (long long)par * P.n_tiles + tile0;
+        double W[4][4];
+#pragma unroll
+        for (int vw = 0; vw < 4; vw++) {
+            double v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = vw * 64 + ln + u * BUILD_THREADS;
+                const bool in = t < ntiles;
+                const TileAcc* e = ta + (in ? t : 0);
+                v[u][0] = in ? e->cand_cost : 0.0; v[u][1] = in ? e->mcc : 0.0; v[u][2] = in ? e->step_norm2 : 0.0; v[u][3] = in ? e->cand_norm2 : 0.0;
+            }
+#pragma unroll
+            for (int f = 0; f < 4; f++) W[vw][f] = wave_sum((v[0][f] + v[1][f]) + (v[2][f] + v[3][f]));
+        }
+        c = (W[0][0] + W[1][0]) + (W[2][0] + W[3][0]); m = (W[0][1] + W[1][1]) + (W[2][1] + W[3][1]);
+        sn = (W[0][2] + W[1][2]) + (W[2][2] + W[3][2]); cn = (W[0][3] + W[1][3]) + (W[2][3] + W[3][3]);
     } else {
         const TileAcc* ta = P.tacc + (long long)par * P.n_tiles + tile0;
         for (int t = ln; t < ntiles; t += 64) {
             c += ta[t].cand_cost; m += ta[t].mcc; sn += ta[t].step_norm2; cn += ta[t].cand_norm2;
         }
+        c = wave_sum(c); m = wave_sum(m); sn = wave_sum(sn); cn = wave_sum(cn);
     }
-    c = wave_sum(c); m = wave_sum(m); sn = wave_sum(sn); cn = wave_sum(cn);
     if (ln == 0) { out4[0] = c; out4[1] = m; out4[2] = sn; out4[3] = cn; }
 }
 
@@ -303,12 +326,28 @@ struct ObsLin {
 
 // Lane-local linearisation of observation `o` of landmark `gl` from LDS tables.
 // RARE = false compiles the robust loss out (plain window BA: huber_a = 0, no prior-kept landmarks).
+// The constants of one observation, loaded ahead of use (k_build fetches its first landmark round while the LM decision of
+// the previous slot is still being summed).
+struct ObsPre {
+    int slot, craw;
+    double m[3];
+};
+template <int FACTOR>
+__device__ __forceinline__ ObsPre obs_prefetch(const DevPtrs& P, int o) {
+    ObsPre q;
+    q.slot = P.obs_slot[o];
+    q.craw = P.obs_cam[o];
+    if (FACTOR == 0) { const double* m = P.obs_meas + 2 * (long long)o; q.m[0] = m[0]; q.m[1] = m[1]; q.m[2] = 0.0; }
+    else { const double* m = P.obs_meas + 3 * (long long)o; q.m[0] = m[0]; q.m[1] = m[1]; q.m[2] = m[2]; }
+    return q;
+}
+
 template <int FACTOR, bool RARE>
 __device__ __forceinline__ void lane_linearize(const DevPtrs& P, const double* poseTab, const double* camTab,
-                                               const int* rowTab, int cam_base, int o, const double* pw, bool keep_jl,
+                                               const int* rowTab, int cam_base, const ObsPre& ob, const double* pw, bool keep_jl,
                                                bool lcounted, ObsLin& L) {
-    const int slot = P.obs_slot[o];
-    const int craw = P.obs_cam[o];
+    const int slot = ob.slot;
+    const int craw = ob.craw;
     const int cam = craw < 0 ? 0 : craw - cam_base;
     const double* tab = poseTab + slot * POSE_TAB;
     const double* ct = camTab + cam * 17;  // K[4] Tsf[12] isig
@@ -332,11 +371,9 @@ __device__ __forceinline__ void lane_linearize(const DevPtrs& P, const double* p
         return;
     }
     if (FACTOR == 0) {
-        const double* m = P.obs_meas + 2 * (long long)o;
-        pixel_factor<true>(tab, ct, ct + 4, pw, m[0], m[1], ct[16], L.r, L.Jp, L.Jl);
+        pixel_factor<true>(tab, ct, ct + 4, pw, ob.m[0], ob.m[1], ct[16], L.r, L.Jp, L.Jl);
     } else {
-        const double* m = P.obs_meas + 3 * (long long)o;
-        double b[3] = {m[0], m[1], m[2]};
+        double b[3] = {ob.m[0], ob.m[1], ob.m[2]};
         angular_factor<true>(tab, ct + 4, pw, b, ct[16], L.r, L.Jp, L.Jl);
     }
     L.rho = L.r[0] * L.r[0] + L.r[1] * L.r[1];
@@ -447,30 +484,90 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
     SADVIO_TS(3, 32);
     __shared__ double s_part[BUILD_WAVES * 4];
+    // LDS carve
+    double* poseTab = (double*)smem;
+    double* camTab = poseTab + (size_t)max_tile_kf * POSE_TAB;
+    int* rowTab = (int*)(camTab + MAX_WIN_CAM * 17);
+    double* stage = (double*)(smem + tile_tables_bytes(max_tile_kf));  // [BUILD_WAVES][strip_doubles] wave-private strips
+    const int G = T.G, lpw = 64 / G;
+    const int grp = ln / G, q = ln - grp * G;
+    const int nl = T.lmk1 - T.lmk0;
+    // ---- everything that does not depend on the LM decision of the previous slot is fetched BEFORE that decision is summed:
+    //      the wave's first landmark round (CSR range, position, BOTH delta buffers, the lane's observation) and the pose
+    //      tables of BOTH buffers (first POSE_TAB-chunk per thread); the decision then only selects. A single window spends
+    //      ~2.6 us in the decision and ~2.3 us in these dependent loads: now they overlap. ----
     LmState st;
-    if (slot == 0 || P.decide_kernel) {
+    IterAcc a;
+    LmState prev;
+    const bool own_decision = !(slot == 0 || P.decide_kernel);
+    // few tiles: every workgroup recomputes the decision of the previous slot (cheaper than one more launch on the critical
+    // path): totals = window part (k_solve) + the tiles' k_backsub partials. The partials are read by ALL threads, every
+    // load issued before the first add (< 1 024 tiles in this mode: <= 4 per thread) — one HBM round trip instead of one per
+    // 64 tiles on a single wave — and they are the FIRST loads of the kernel: the memory counter retires in order.
+    double pc = 0.0, pm = 0.0, psn = 0.0, pcn = 0.0;
+    if (!own_decision) {
         // many tiles: the accept / reject decision of the previous slot was taken once per window by k_decide
         st = P.states[(long long)T.w * P.state_stride + slot];
     } else {
-        // few tiles: every workgroup recomputes it (cheaper than one more launch on the critical path):
-        // totals of the previous slot = window part (k_solve) + the tiles' k_backsub partials
-        // the window record and the previous state are loaded before the barrier: their latency runs under the partial sums
-        IterAcc a = P.acc[(long long)T.w * P.state_stride + slot - 1];
-        const LmState prev = P.states[(long long)T.w * P.state_stride + slot - 1];
-        if (wv == 0) wave_sum_backsub_partials(P, (slot - 1) & 1, T.w, T.win_tile0, T.win_ntiles, ln, s_part);
+        a = P.acc[(long long)T.w * P.state_stride + slot - 1];
+        prev = P.states[(long long)T.w * P.state_stride + slot - 1];
+        if (P.world > 1) {
+            if (wv == 0) {
+                const double* rs = P.rank_s + (long long)T.w * P.world * 4;
+                for (int r = ln; r < P.world; r += 64) { pc += rs[4 * r]; pm += rs[4 * r + 1]; psn += rs[4 * r + 2]; pcn += rs[4 * r + 3]; }
+            }
+        } else {
+            const TileAcc* ta = P.tacc + (long long)((slot - 1) & 1) * P.n_tiles + T.win_tile0;
+            double v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = tid + u * BUILD_THREADS;
+                const bool in = t < T.win_ntiles;
+                const TileAcc* e = ta + (in ? t : 0);
+                v[u][0] = in ? e->cand_cost : 0.0; v[u][1] = in ? e->mcc : 0.0; v[u][2] = in ? e->step_norm2 : 0.0; v[u][3] = in ? e->cand_norm2 : 0.0;
+            }
+            pc = (v[0][0] + v[1][0]) + (v[2][0] + v[3][0]); pm = (v[0][1] + v[1][1]) + (v[2][1] + v[3][1]);
+            psn = (v[0][2] + v[1][2]) + (v[2][2] + v[3][2]); pcn = (v[0][3] + v[1][3]) + (v[2][3] + v[3][3]);
+        }
+    }
+    const bool first_valid = wv * lpw + grp < nl;
+    const int gl_first = T.lmk0 + (first_valid ? wv * lpw + grp : 0);
+    const int pre_ob = P.lmk_ob[gl_first], pre_oe = P.lmk_oe[gl_first];
+    const int pre_lcode = P.lmk_const ? P.lmk_const[gl_first] : 0;
+    double pre_p[3], pre_x0[3], pre_x1[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        pre_p[i] = P.lmk_p[3 * (long long)gl_first + i];
+        pre_x0[i] = P.xl[3 * (long long)gl_first + i];
+        pre_x1[i] = P.xl[P.xl_stride + 3 * (long long)gl_first + i];
+    }
+    double pre_t0 = 0.0, pre_t1 = 0.0;
+    if (tid < T.n_kf * POSE_TAB) {
+        const int k = tid / POSE_TAB, e = tid - k * POSE_TAB;
+        const long long src = (long long)P.tile_kf[T.kf_off + k] * POSE_TAB + e;
+        pre_t0 = P.ptab[src]; pre_t1 = P.ptab[P.ptab_stride + src];
+    }
+    for (int i = tid; i < T.n_cam * 17; i += blockDim.x) {
+        const int c = i / 17, e = i - 17 * c;
+        const int gc = T.cam_base + c;
+        camTab[i] = e < 4 ? P.cam_K[4 * (long long)gc + e] : (e < 16 ? P.cam_T[12 * (long long)gc + e - 4] : P.cam_isig[gc]);
+    }
+    for (int i = tid; i < T.n_kf; i += blockDim.x) rowTab[i] = P.tile_row[T.kf_off + i];
+    ObsPre pre_obs;
+    pre_obs.slot = 0; pre_obs.craw = 0; pre_obs.m[0] = pre_obs.m[1] = pre_obs.m[2] = 0.0;
+    if (first_valid && q < pre_oe - pre_ob) pre_obs = obs_prefetch<FACTOR>(P, pre_ob + q);
+    if (own_decision) {
+        pc = wave_sum(pc); pm = wave_sum(pm); psn = wave_sum(psn); pcn = wave_sum(pcn);
+        if (ln == 0) { s_part[wv * 4] = pc; s_part[wv * 4 + 1] = pm; s_part[wv * 4 + 2] = psn; s_part[wv * 4 + 3] = pcn; }
         __syncthreads();
-        a.cand_cost += s_part[0]; a.mcc += s_part[1]; a.step_norm2 += s_part[2]; a.cand_norm2 += s_part[3];
+        a.cand_cost += (s_part[0] + s_part[4]) + (s_part[8] + s_part[12]); a.mcc += (s_part[1] + s_part[5]) + (s_part[9] + s_part[13]);
+        a.step_norm2 += (s_part[2] + s_part[6]) + (s_part[10] + s_part[14]); a.cand_norm2 += (s_part[3] + s_part[7]) + (s_part[11] + s_part[15]);
         st = lm_decide(prev, a, P.o);
         __syncthreads();  // s_part is reused below
         if (T.first_of_window && tid == 0) { P.states[(long long)T.w * P.state_stride + slot] = st; trace_write(P, T.w, slot - 1, prev, a, st); }
     }
     if (st.done) return;
     SADVIO_TS(3, 33);
-    // LDS carve
-    double* poseTab = (double*)smem;
-    double* camTab = poseTab + (size_t)max_tile_kf * POSE_TAB;
-    int* rowTab = (int*)(camTab + MAX_WIN_CAM * 17);
-    double* stage = (double*)(smem + tile_tables_bytes(max_tile_kf));  // [BUILD_WAVES][strip_doubles] wave-private strips
     double* Stile = stage + BUILD_WAVES * strip_doubles;
     const int Nt = 6 * T.n_free;
     const int tri_n = Nt * (Nt + 1) / 2;
@@ -478,7 +575,15 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
     double* gfT = gT + Nt;
     double* hdT = gfT + Nt;
     const bool lds_mode = T.lds_mode != 0;
-    stage_tables(P, T, st.cur, poseTab, camTab, rowTab);
+    // pose tables of the buffer that holds x: the prefetched chunk, the rest (tiles with more than 6 key-frames) from HBM
+    if (tid < T.n_kf * POSE_TAB) poseTab[tid] = st.cur ? pre_t1 : pre_t0;
+    {
+        const double* src = P.ptab + (long long)st.cur * P.ptab_stride;
+        for (int i = tid + blockDim.x; i < T.n_kf * POSE_TAB; i += blockDim.x) {
+            const int k = i / POSE_TAB, e = i - k * POSE_TAB;
+            poseTab[i] = src[(long long)P.tile_kf[T.kf_off + k] * POSE_TAB + e];
+        }
+    }
     if (lds_mode) {
         const int nz = tri_n + 3 * Nt;
         for (int i = tid; i < nz; i += blockDim.x) Stile[i] = 0.0;
@@ -491,9 +596,6 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
     double* gfullg = P.gfull + T.red_off;
     double* hdg = P.hdiag + T.red_off;
     const int dpf = T.dpf, Np = T.Np;
-    const int G = T.G, lpw = 64 / G;
-    const int grp = ln / G, q = ln - grp * G;
-    const int nl = T.lmk1 - T.lmk0;
     const double* xl = P.xl + (long long)st.cur * P.xl_stride;
     double* wstage = stage + wv * strip_doubles;
     const bool gemm_mode = T.lds_mode == 2;
@@ -507,19 +609,29 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
         const int lm = base + grp;
         const bool lmk_valid = lm < nl;
         const int gl = T.lmk0 + (lmk_valid ? lm : 0);
-        const int ob = P.lmk_ob[gl], oe = P.lmk_oe[gl];
+        const bool first = base == wv * lpw;          // this round was fetched at the top of the kernel
+        const int ob = first ? pre_ob : P.lmk_ob[gl], oe = first ? pre_oe : P.lmk_oe[gl];
         const int nobs = lmk_valid ? oe - ob : 0;
         // 0 free (eliminated here), 1 constant, 2 kept in the reduced system by a dense prior: its pose-pose part
         // goes the usual way, the landmark rows / columns are added by k_build_kept
-        const int lcode = P.lmk_const ? P.lmk_const[gl] : 0;
+        const int lcode = first ? pre_lcode : (P.lmk_const ? P.lmk_const[gl] : 0);
         const bool lfree = lcode == 0;
         ObsLin L;
         L.valid = q < nobs;
         L.row = -1; L.slot = 0; L.counted = false;
         if (L.valid) {
-            const double pw[3] = {P.lmk_p[3 * (long long)gl] + xl[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1] + xl[3 * (long long)gl + 1],
-                                  P.lmk_p[3 * (long long)gl + 2] + xl[3 * (long long)gl + 2]};
-            lane_linearize<FACTOR, RARE>(P, poseTab, camTab, rowTab, T.cam_base, ob + q, pw, lfree, lcode != 1, L);
+            double pw[3];
+            ObsPre obq;
+            if (first) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) pw[i] = pre_p[i] + (st.cur ? pre_x1[i] : pre_x0[i]);
+                obq = pre_obs;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; i++) pw[i] = P.lmk_p[3 * (long long)gl + i] + xl[3 * (long long)gl + i];
+                obq = obs_prefetch<FACTOR>(P, ob + q);
+            }
+            lane_linearize<FACTOR, RARE>(P, poseTab, camTab, rowTab, T.cam_base, obq, pw, lfree, lcode != 1, L);
             const double c = L.rho;
             if (L.counted) cost_part += c;
             else { fixed_part += c; L.r[0] = 0.0; L.r[1] = 0.0; }
@@ -1744,6 +1856,22 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
     double* candTab = (double*)(smem + tile_tables_bytes(max_tile_kf));  // [n_kf][12] R|t at the candidate poses
     double* dpTab = candTab + (size_t)max_tile_kf * 12;                  // [n_kf][6] pose step of each listed key-frame
     const int cur = st.cur;
+    const int G = T.G, lpw = 64 / G;
+    const int grp = ln / G, q = ln - grp * G;
+    const int nl = T.lmk1 - T.lmk0;
+    const double* xl = P.xl + (long long)cur * P.xl_stride;
+    double* xlc = P.xl + (long long)(1 - cur) * P.xl_stride;
+    // the wave's first landmark round is fetched before the tables are staged (one HBM round trip instead of three in a row)
+    const bool first_valid = wv * lpw + grp < nl;
+    const int gl_first = T.lmk0 + (first_valid ? wv * lpw + grp : 0);
+    const int pre_ob = P.lmk_ob[gl_first], pre_oe = P.lmk_oe[gl_first];
+    const int pre_lcode = P.lmk_const ? P.lmk_const[gl_first] : 0;
+    double pre_p[3], pre_x[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { pre_p[i] = P.lmk_p[3 * (long long)gl_first + i]; pre_x[i] = xl[3 * (long long)gl_first + i]; }
+    ObsPre pre_obs;
+    pre_obs.slot = 0; pre_obs.craw = 0; pre_obs.m[0] = pre_obs.m[1] = pre_obs.m[2] = 0.0;
+    if (first_valid && q < pre_oe - pre_ob) pre_obs = obs_prefetch<FACTOR>(P, pre_ob + q);
     stage_tables(P, T, cur, poseTab, camTab, rowTab);
     {
         const double* src = P.ptab + (long long)(1 - cur) * P.ptab_stride;
@@ -1759,28 +1887,30 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
         }
     }
     __syncthreads();
-    const int G = T.G, lpw = 64 / G;
-    const int grp = ln / G, q = ln - grp * G;
-    const int nl = T.lmk1 - T.lmk0;
-    const double* xl = P.xl + (long long)cur * P.xl_stride;
-    double* xlc = P.xl + (long long)(1 - cur) * P.xl_stride;
     double sn = 0.0, cn = 0.0, mcc = 0.0, cc = 0.0;
     for (int base = wv * lpw; base < nl; base += BUILD_WAVES * lpw) {
         const int lm = base + grp;
         const bool lmk_valid = lm < nl;
         const int gl = T.lmk0 + (lmk_valid ? lm : 0);
-        const int ob = P.lmk_ob[gl], oe = P.lmk_oe[gl];
+        const bool first = base == wv * lpw;
+        const int ob = first ? pre_ob : P.lmk_ob[gl], oe = first ? pre_oe : P.lmk_oe[gl];
         const int nobs = lmk_valid ? oe - ob : 0;
-        const int lcode = P.lmk_const ? P.lmk_const[gl] : 0;
+        const int lcode = first ? pre_lcode : (P.lmk_const ? P.lmk_const[gl] : 0);
         const bool lfree = lcode == 0;
-        const double p0[3] = {P.lmk_p[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1], P.lmk_p[3 * (long long)gl + 2]};
-        const double x0[3] = {xl[3 * (long long)gl], xl[3 * (long long)gl + 1], xl[3 * (long long)gl + 2]};
+        double p0[3], x0[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            p0[i] = first ? pre_p[i] : P.lmk_p[3 * (long long)gl + i];
+            x0[i] = first ? pre_x[i] : xl[3 * (long long)gl + i];
+        }
         ObsLin L;
         L.valid = q < nobs;
         L.row = -1; L.slot = 0; L.counted = false;
+        ObsPre obq = pre_obs;
         if (L.valid) {
             const double pw[3] = {p0[0] + x0[0], p0[1] + x0[1], p0[2] + x0[2]};
-            lane_linearize<FACTOR, RARE>(P, poseTab, camTab, rowTab, T.cam_base, ob + q, pw, lcode != 1, lcode != 1, L);
+            if (!first) obq = obs_prefetch<FACTOR>(P, ob + q);
+            lane_linearize<FACTOR, RARE>(P, poseTab, camTab, rowTab, T.cam_base, obq, pw, lcode != 1, lcode != 1, L);
             if (!L.counted) { L.r[0] = 0.0; L.r[1] = 0.0; }
         } else {
             L.r[0] = L.r[1] = 0.0;
@@ -1824,8 +1954,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
             const double m1 = (e1 - L.r[1]) + L.Jl[3] * d0 + L.Jl[4] * d1 + L.Jl[5] * d2;
             mcc += -m0 * (L.r[0] + 0.5 * m0) - m1 * (L.r[1] + 0.5 * m1);
             // residual at the candidate point
-            const int o = ob + q;
-            const int craw = P.obs_cam[o];
+            const int craw = obq.craw;
             const int cam = craw < 0 ? 0 : craw - T.cam_base;
             const double* ct = camTab + cam * 17;
             const double pw[3] = {p0[0] + c0, p0[1] + c1, p0[2] + c2};
@@ -1838,11 +1967,9 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
                 cc += r[0] * r[0] + r[1] * r[1];
             } else {
             if (FACTOR == 0) {
-                const double* m = P.obs_meas + 2 * (long long)o;
-                pixel_factor<false>(ctab, ct, ct + 4, pw, m[0], m[1], ct[16], r, nullptr, nullptr);
+                pixel_factor<false>(ctab, ct, ct + 4, pw, obq.m[0], obq.m[1], ct[16], r, nullptr, nullptr);
             } else {
-                const double* m = P.obs_meas + 3 * (long long)o;
-                double bb[3] = {m[0], m[1], m[2]};
+                double bb[3] = {obq.m[0], obq.m[1], obq.m[2]};
                 angular_factor<false>(ctab, ct + 4, pw, bb, ct[16], r, nullptr, nullptr);
             }
             double sc_unused;
