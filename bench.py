@@ -306,6 +306,7 @@ def bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_sol
     if dist is not None:
         dist.broadcast_object_list(uid, src=0)
     be.comm_init_rccl(rank, world, uid[0])
+    comm = be.comm_info()   # what the RCCL communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice)
     be.set_windows([sharding.shard_window(w, rank, world)])
     steps = max(5, args.steps)
     dt = timed_solves(be, opts, steps, 2)
@@ -321,7 +322,8 @@ def bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_sol
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "synthetic 100 KF x 50000 landmarks x 250000 reprojection factors, GN 10 iters, "
                                "landmark-sharded, RCCL all-reduce of the reduced system per LM step",
-                   "parallelism": f"window sharded x{world}", "reduced_dim": n_p, "rccl_ranks": world,
+                   "parallelism": f"window sharded x{world}", "reduced_dim": n_p, "rccl_ranks": comm["nranks"], "rccl_rank0_device": comm["device"],
+                   "rccl_communicator": comm["is_rccl"],
                    "collectives_per_lm_step": 2,
                    # only the band of the reduced system travels (k_band_pack): N_p x bw with bw = 60 for this
                    # window's 10-key-frame co-visibility, + gradient / diagonal vectors + the per-rank partials

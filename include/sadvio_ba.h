@@ -355,6 +355,9 @@ int sadvio_ba_set_collective(sadvio_ba_handle *h, int32_t rank, int32_t world, s
 #define SADVIO_RCCL_ID_BYTES 128
 int sadvio_ba_rccl_unique_id(void *id128);
 int sadvio_ba_comm_init_rccl(sadvio_ba_handle *h, int32_t rank, int32_t world, const void *id128);
+/* What the handle's collective really spans: with the built-in RCCL collective the numbers come from the communicator itself
+ * (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), otherwise from set_collective. Any pointer may be NULL. */
+int sadvio_ba_comm_info(sadvio_ba_handle *h, int32_t *nranks, int32_t *rank, int32_t *device, int32_t *is_rccl);
 
 /* Sparse (NFR) prior factors of window `w`; replaces the previous list (n = 0 clears it). */
 int sadvio_ba_set_sparse_priors(sadvio_ba_handle *h, int32_t w, int32_t n, const sadvio_sparse_prior *factors);

@@ -344,6 +344,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.sadvio_ba_set_collective.argtypes = [C.c_void_p, C.c_int32, C.c_int32, ALLREDUCE_FN, C.c_void_p]
     lib.sadvio_ba_rccl_unique_id.argtypes = [C.c_void_p]
     lib.sadvio_ba_comm_init_rccl.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.sadvio_ba_comm_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 4
     lib.sadvio_ba_solve.argtypes = [C.c_void_p, C.POINTER(SolveOptions), C.POINTER(SolveSummary)]
     lib.sadvio_ba_get_deltas.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
     lib.sadvio_ba_get_ids.argtypes = [C.c_void_p, C.c_int32, _lp, _lp]
@@ -394,6 +395,12 @@ class Backend:
         buf = C.create_string_buffer(RCCL_ID_BYTES)
         self._check(self.lib.sadvio_ba_rccl_unique_id(buf), "rccl_unique_id")
         return buf.raw
+
+    def comm_info(self) -> dict:
+        """{nranks, rank, device, is_rccl} of the handle's collective — from the RCCL communicator itself when it is the built-in one."""
+        v = [C.c_int32(0) for _ in range(4)]
+        self._check(self.lib.sadvio_ba_comm_info(self.h, *[C.byref(x) for x in v]), "comm_info")
+        return {"nranks": v[0].value, "rank": v[1].value, "device": v[2].value, "is_rccl": bool(v[3].value)}
 
     def comm_init_rccl(self, rank: int, world: int, unique_id: bytes):
         assert len(unique_id) == RCCL_ID_BYTES

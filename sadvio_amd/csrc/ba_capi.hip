@@ -84,6 +84,9 @@ struct RcclLib {
     int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*destroy)(void*) = nullptr;
     const char* (*err_string)(int) = nullptr;
+    int (*comm_count)(void*, int*) = nullptr;
+    int (*comm_user_rank)(void*, int*) = nullptr;
+    int (*comm_cu_device)(void*, int*) = nullptr;
 };
 
 // Deep copy of a caller's window (set_windows) + the observation arrays actually tiled: pose-to-landmark NFR factors
@@ -1936,6 +1939,9 @@ static std::string load_rccl(RcclLib& R) {
     R.all_reduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(R.lib, "ncclAllReduce");
     R.destroy = (int (*)(void*))dlsym(R.lib, "ncclCommDestroy");
     R.err_string = (const char* (*)(int))dlsym(R.lib, "ncclGetErrorString");
+    R.comm_count = (int (*)(void*, int*))dlsym(R.lib, "ncclCommCount");
+    R.comm_user_rank = (int (*)(void*, int*))dlsym(R.lib, "ncclCommUserRank");
+    R.comm_cu_device = (int (*)(void*, int*))dlsym(R.lib, "ncclCommCuDevice");
     if (!R.get_id || !R.init_rank || !R.all_reduce || !R.destroy) return "missing RCCL symbol";
     return "";
 }
@@ -1973,6 +1979,23 @@ int sadvio_ba_comm_init_rccl(sadvio_ba_handle* h, int32_t rank, int32_t world, c
         return SADVIO_E_RCCL;
     }
     h->rank = rank; h->world = world; h->coll_fn = rccl_allreduce; h->coll_ctx = h;
+    return SADVIO_OK;
+}
+
+int sadvio_ba_comm_info(sadvio_ba_handle* h, int32_t* nranks, int32_t* rank, int32_t* device, int32_t* is_rccl) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    int n = h->world, r = h->rank, d = h->device;
+    const bool rccl = h->rccl.comm != nullptr;
+    if (rccl) {   // what the COMMUNICATOR says, not what it was asked for
+        if (!h->rccl.comm_count || !h->rccl.comm_user_rank || h->rccl.comm_count(h->rccl.comm, &n) != 0 || h->rccl.comm_user_rank(h->rccl.comm, &r) != 0) {
+            h->err = "comm_info: ncclCommCount / ncclCommUserRank failed"; return SADVIO_E_RCCL;
+        }
+        if (h->rccl.comm_cu_device) (void)h->rccl.comm_cu_device(h->rccl.comm, &d);
+    }
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (device) *device = d;
+    if (is_rccl) *is_rccl = rccl ? 1 : 0;
     return SADVIO_OK;
 }
 

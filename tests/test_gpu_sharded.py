@@ -130,6 +130,8 @@ def test_rccl_collective_world_1(backend_cls, oracle_lib):
     be = backend_cls(device=0)
     uid = be.rccl_unique_id()
     be.comm_init_rccl(0, 1, uid)
+    info = be.comm_info()            # ncclCommCount / ncclCommUserRank of the communicator itself
+    assert info["is_rccl"] and (info["nranks"], info["rank"], info["device"]) == (1, 0, 0)
     be.set_windows([w])
     s = be.solve(opts)[0]
     d = be.get_deltas(0)
@@ -144,4 +146,16 @@ def test_collective_must_precede_set_windows(backend_cls):
     be.set_windows([synthetic.make_window(n_kf=4, n_lmk=100, seed=1)])
     with pytest.raises(capi.SadvioError):
         be.set_collective(0, 2, lambda *a: 0)
+    be.close()
+
+
+def test_marginalize_relative_refused_on_a_sharded_window(backend_cls):
+    """Each rank of a sharded window only holds its landmark partition: the relative-pose information would be a partial sum."""
+    w = synthetic.make_window(n_kf=5, n_lmk=300, seed=42)
+    be = backend_cls(device=0)
+    be.set_collective(0, 2, lambda *a: 0)
+    assert be.comm_info() == {"nranks": 2, "rank": 0, "device": 0, "is_rccl": False}
+    be.set_windows([sharding.shard_window(w, 0, 2)])
+    with pytest.raises(capi.SadvioError):
+        be.marginalize_relative(0, 0, 1)
     be.close()
