@@ -208,8 +208,9 @@ def sparse_factor(w: FlatWindow, k: int, xp=None, xv=None, xba=None, xbg=None, x
     return r[:rows].copy(), J[:rows].copy()
 
 
-def marginalize(w: FlatWindow, kf_marg, lmk_marg, lmk_keep, kf_keep=-1, marg_has_imu=False, imu=None, priors=(), last=None):
-    """oracle_marginalize with the same calling convention as capi.Backend.marginalize. Returns None when refused."""
+def marginalize(w: FlatWindow, kf_marg, lmk_marg, lmk_keep, kf_keep=-1, marg_has_imu=False, imu=None, priors=(), last=None, want_full=False):
+    """oracle_marginalize with the same calling convention as capi.Backend.marginalize. Returns None when refused.
+    want_full: also return A_full [(m+n)^2], b_full [m+n] (the un-reduced information / gradient, computeInformationAndGradient)."""
     wc, wkeep = S.window_to_c(w)
     rq = MargRequest()
     rq.win = C.pointer(wc)
@@ -239,12 +240,19 @@ def marginalize(w: FlatWindow, kf_marg, lmk_marg, lmk_keep, kf_keep=-1, marg_has
     res = MargResult()
     lmk_col = np.zeros(max(len(kp), 1), dtype=np.int32); Jo = np.zeros(max(n * n, 1)); r0o = np.zeros(max(n, 1))
     Ak = np.zeros((max(n, 1), max(n, 1))); bk = np.zeros(max(n, 1))
-    rc = lib().oracle_marginalize(C.byref(rq), C.byref(res), lmk_col.ctypes.data_as(_ip), _dp(), _dp(), _p(Ak), _p(bk), _dp(), _dp(),
-                                  _p(Jo), _p(r0o))
+    m_max = (15 if marg_has_imu else 6) + 3 * len(mk)
+    Af = np.zeros((m_max + n) ** 2) if want_full else None
+    bf = np.zeros(m_max + n) if want_full else None
+    rc = lib().oracle_marginalize(C.byref(rq), C.byref(res), lmk_col.ctypes.data_as(_ip), _p(Af) if want_full else _dp(), _p(bf) if want_full else _dp(),
+                                  _p(Ak), _p(bk), _dp(), _dp(), _p(Jo), _p(r0o))
     if rc != 0:
         return None
     nf = res.n_full
-    return {"J": Jo[: nf * n].reshape(nf, n).copy(), "r0": r0o[:nf].copy(), "kf_keep": kf_keep, "kf_col": res.kf_col,
+    extra = {}
+    if want_full:
+        N = res.m + res.n
+        extra = {"A_full": Af[: N * N].reshape(N, N).copy(), "b_full": bf[:N].copy()}
+    return {**extra, "J": Jo[: nf * n].reshape(nf, n).copy(), "r0": r0o[:nf].copy(), "kf_keep": kf_keep, "kf_col": res.kf_col,
             "lmk_index": kp.copy(), "lmk_col": lmk_col[: len(kp)].copy(), "m": res.m, "n": res.n, "n_full": nf, "Ak": Ak, "bk": bk}
 
 

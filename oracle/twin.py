@@ -9,6 +9,10 @@ path, for which the reference holds no golden vector:
                          Camera::project                            cpp/src/data/sensors/Camera.cpp:84-139
                          AngularErrCeres_pointxd_dx::Evaluate       cpp/include/isaeslam/optimizers/AngularAdjustmentCERESAnalytic.h:55-111
                          PosePriordx::Evaluate                      cpp/include/isaeslam/optimizers/residuals.hpp:607-628
+                         IMUPriordx / PoseToLandmarkFactor / Landmark3DPrior / LandmarkToLandmarkFactor   residuals.hpp:506-700
+                         MarginalizationFactor::Evaluate            cpp/include/isaeslam/optimizers/marginalization.hpp:113-215
+                         Marginalization::computeSchurComplement / rankReveallingDecomposition / computeJacobiansAndResiduals /
+                         sparsifyVIO / sparsifyVO (the factor informations)   cpp/src/optimizers/marginalization.cpp:213-265,318-342,362-530
                          SO(3) helpers                              cpp/include/utilities/geometry.h:17-37,131-166
   * the problem of addResidualsLocalMap (BundleAdjustmentCERESAnalytic.cpp:197-314) on a flat window;
   * Ceres 2.2.0 TrustRegionMinimizer + LevenbergMarquardtStrategy (trust_region_minimizer.cc, levenberg_marquardt_strategy.cc,
@@ -272,6 +276,167 @@ def relative_pose_factor(B, Ta, Tb, Tab_prior, W, da, db):
     Jb[:3, :3] = Jri @ so3_right_jacobian(B, db[:3])                    # :118
     Jb[3:, 3:] = Rpi @ Rau.T @ Rbu                                      # :121
     return err, W @ Ja, W @ Jb
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sparse (NFR) prior factors, residuals.hpp:506-700 — as coded
+# ---------------------------------------------------------------------------------------------------------------
+def imu_prior_factor(B, T_f_w0, v0, ba0, bg0, T_prior, v_prior, ba_prior, bg_prior, sqrt_inf, params15):
+    """IMUPriordx::Evaluate (residuals.hpp:649-695): r[15], J[15,15] over [pose 6 | dv 3 | dba 3 | dbg 3]. As coded the pose
+    block is sqrt_inf * J_pose (all 15 rows), while the v / ba / bg blocks are plain identities in their own rows — NOT
+    multiplied by sqrt_inf although the residual is (:678, :684, :690)."""
+    W = B.a(np.asarray(sqrt_inf).reshape(15, 15)); p = B.a(params15)
+    R0, t0 = split_T(B, T_f_w0); Rp, tp = split_T(B, T_prior)
+    dw = p[:3]
+    dR = exp_so3(B, dw)
+    R = R0 @ dR; t = R0 @ p[3:6] + t0                              # T = _T * dT   (:664)
+    Rpi = Rp.T; tpi = -(Rpi @ tp)
+    Re = R @ Rpi; te = R @ tpi + t
+    err = B.zeros(15)
+    err[:3] = log_so3(B, Re); err[3:6] = te                         # se3_RTtoVec6d(T * T_prior^-1)   (:665)
+    err[6:9] = B.a(v0) + p[6:9] - B.a(v_prior)                      # :666-668
+    err[9:12] = B.a(ba0) + p[9:12] - B.a(ba_prior)
+    err[12:15] = B.a(bg0) + p[12:15] - B.a(bg_prior)
+    r = W @ err                                                     # :669
+    Jp = B.zeros((15, 6))                                           # :674-686
+    wv = log_so3(B, R @ Rp.T)
+    Jp[:3, :3] = inv3(B, so3_right_jacobian(B, wv)) @ Rp @ so3_right_jacobian(B, dw)
+    Jp[3:6, :3] = R @ skew(B, Rp.T @ tp) @ so3_right_jacobian(B, dw)
+    Jp[3:6, 3:6] = R0
+    J = B.zeros((15, 15))
+    J[:, :6] = W @ Jp
+    for q in range(9):
+        J[6 + q, 6 + q] = B.s(1)                                    # :690-707
+    return r, J
+
+
+def pose_to_landmark_factor(B, T_f_w0, p0, delta, sqrt_inf, dpose, dl):
+    """PoseToLandmarkFactor::Evaluate (residuals.hpp:570-595): r[3], J[3,9] over [pose 6 | landmark 3]."""
+    W = B.a(np.asarray(sqrt_inf).reshape(-1)[:9].reshape(3, 3)); dpose = B.a(dpose)
+    R0, t0 = split_T(B, T_f_w0)
+    dR = exp_so3(B, dpose[:3])
+    R = R0 @ dR; t = R0 @ dpose[3:6] + t0                           # :578
+    pl = B.a(p0) + B.a(dl)                                          # :579
+    r = W @ (R @ pl + t - B.a(delta))                               # :581
+    J = B.zeros((3, 9))
+    J[:, :3] = W @ R0 @ (-(dR @ skew(B, pl) @ so3_right_jacobian(B, dpose[:3])))   # :588-589
+    J[:, 3:6] = W @ R0                                              # :590
+    J[:, 6:9] = W @ R                                               # :595
+    return r, J
+
+
+def landmark_prior_factor(B, p0, prior, sqrt_inf, dl):
+    """Landmark3DPrior::Evaluate (residuals.hpp:512-522): r[3], J[3,3]."""
+    W = B.a(np.asarray(sqrt_inf).reshape(-1)[:9].reshape(3, 3))
+    return W @ (B.a(p0) + B.a(dl) - B.a(prior)), W
+
+
+def landmark_to_landmark_factor(B, p0, p1, delta, sqrt_inf, dl0, dl1):
+    """LandmarkToLandmarkFactor::Evaluate (residuals.hpp:537-556): r[3], J[3,6] over [landmark 0 | landmark 1]."""
+    W = B.a(np.asarray(sqrt_inf).reshape(-1)[:9].reshape(3, 3))
+    r = W @ ((B.a(p0) + B.a(dl0)) - (B.a(p1) + B.a(dl1)) - B.a(delta))
+    return r, np.concatenate([W, -W], axis=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# marginalisation algebra, marginalization.cpp:213-265, 318-342, 362-408, 491-514, 516-530 and the factor it feeds,
+# MarginalizationFactor::Evaluate (marginalization.hpp:113-215)
+# ---------------------------------------------------------------------------------------------------------------
+def sym_eig(B, A):
+    """(eigenvalues ascending, eigenvectors in columns) of a symmetric matrix: Eigen::SelfAdjointEigenSolver."""
+    n = A.shape[0]
+    if B.kind == "mp":
+        E, Q = mpmath.eigsy(mpmath.matrix(A.tolist()))
+        lam = np.array([E[i] for i in range(n)], dtype=object)
+        V = np.array([[Q[i, j] for j in range(n)] for i in range(n)], dtype=object)
+        order = sorted(range(n), key=lambda i: lam[i])
+        return lam[order], V[:, order]
+    lam, V = np.linalg.eigh(np.asarray(A, dtype=np.float64))
+    return B.a(lam), B.a(V)
+
+
+def schur_prior(B, A, b, m, cut=1e-12):
+    """computeSchurComplement + rankReveallingDecomposition + computeJacobiansAndResiduals on A = sum J^T J, b = sum J^T r
+    (first m columns marginalised). `cut`: the eigenvalue threshold — the reference's absolute _eps = 1e-12, or a callable
+    lambda_max -> threshold for the documented relative floor of oracle/marg.c. Returns Ak, bk, U, Lambda, J, r0, n_full."""
+    A = B.a(A); b = B.a(b)
+    thr = (lambda lmax: cut(lmax)) if callable(cut) else (lambda lmax: cut)
+    Amm = (A[:m, :m] + A[:m, :m].T) / 2                             # :232
+    lam, V = sym_eig(B, Amm)
+    t = thr(max(abs(x) for x in lam))
+    inv = np.array([1 / x if x > t else B.s(0) for x in lam], dtype=B.dtype)   # :234-238
+    Ammi = (V * inv[None, :]) @ V.T
+    Arm = A[m:, :m]; Arr = A[m:, m:]
+    Ak = Arr - Arm @ Ammi @ Arm.T                                   # :245
+    bk = b[m:] - Arm @ Ammi @ b[:m]                                 # :246
+    lk, Uf = sym_eig(B, (Ak + Ak.T) / 2)                            # rankReveallingDecomposition (:318-342)
+    t = thr(max(abs(x) for x in lk))
+    keep = [i for i in range(len(lk)) if lk[i] > t]
+    U = Uf[:, keep]; Lam = lk[keep]
+    sq = np.array([B.sqrt(x) for x in Lam], dtype=B.dtype)
+    J = sq[:, None] * U.T                                           # :524   J = Lambda^1/2 U^T
+    r0 = -((U.T @ bk) / sq)                                         # :525   r0 = -Lambda^-1/2 U^T bk
+    return dict(Ak=Ak, bk=bk, U=U, Lambda=Lam, J=J, r0=r0, n_full=len(keep))
+
+
+def marginalization_factor(B, J, r0, dx):
+    """MarginalizationFactor::Evaluate (marginalization.hpp:113-215): r = r0 + J dx; the Jacobian of a parameter block is the
+    matching column slice of J."""
+    J = B.a(J)
+    return B.a(r0) + J @ B.a(dx), J
+
+
+def nfr_sqrt_information(B, Jf, U, Sigma, invert_covariance_eigenvalues, cut=1e-12):
+    """The square-root information of one NFR factor with Jacobian Jf (rows x n) against the prior (U, Sigma = Lambda^-1).
+    sparsifyVIO (marginalization.cpp:377-383, :399-404): inf = (J~ Sigma J~^T)^-1 inverted as a MATRIX first, then the symmetric
+    square root of its eigen-decomposition (eigenvalues <= cut dropped). sparsifyVO (:491-498, :506-512): the eigen-decomposition
+    of the covariance J~ Sigma J~^T itself, eigenvalues inverted (`invert_covariance_eigenvalues`), then the square root."""
+    Jt = B.a(Jf) @ U
+    cov = (Jt * B.a(Sigma)[None, :]) @ Jt.T
+    if invert_covariance_eigenvalues:
+        lam, V = sym_eig(B, (cov + cov.T) / 2)
+        s = np.array([B.sqrt(1 / x) if x > cut else B.s(0) for x in lam], dtype=B.dtype)
+    else:
+        n = cov.shape[0]
+        inf = inv3(B, cov) if n == 3 else _inverse(B, cov)
+        lam, V = sym_eig(B, (inf + inf.T) / 2)
+        s = np.array([B.sqrt(x) if x > cut else B.s(0) for x in lam], dtype=B.dtype)
+    return (V * s[None, :]) @ V.T
+
+
+def _inverse(B, A):
+    """Dense inverse by Gauss-Jordan with partial pivoting (Eigen's MatrixXd::inverse() is a PartialPivLU)."""
+    n = A.shape[0]
+    M = np.concatenate([A.copy(), B.eye(n)], axis=1)
+    for c in range(n):
+        p = max(range(c, n), key=lambda i: abs(M[i, c]))
+        if p != c:
+            M[[c, p]] = M[[p, c]]
+        M[c] = M[c] / M[c, c]
+        for i in range(n):
+            if i != c:
+                M[i] = M[i] - M[i, c] * M[c]
+    return M[:, n:]
+
+
+def sparsify_vio_jacobians(B, T_f_w, kf_col, lmk_cols, n):
+    """The factor Jacobians sparsifyVIO projects the prior on (marginalization.cpp:369-376, :393-398): one 3 x n per kept
+    landmark (pose-to-landmark) and the 15 x n of the absolute factor of the kept frame, as coded."""
+    R, t = split_T(B, T_f_w)
+    Js = []
+    for c in lmk_cols:
+        J = B.zeros((3, n))
+        J[:, c:c + 3] = R
+        J[:, kf_col:kf_col + 3] = -(R @ skew(B, t))
+        J[:, kf_col + 3:kf_col + 6] = R
+        Js.append(J)
+    Ja = B.zeros((15, n))
+    for q in range(15):
+        Ja[q, kf_col + q] = B.s(1)
+    Ja[:3, kf_col:kf_col + 3] = R
+    Ja[:3, kf_col + 3:kf_col + 6] = R
+    Ja[3:6, kf_col + 3:kf_col + 6] = R
+    return Js, Ja
 
 
 def huber(B, s, a):

@@ -117,3 +117,129 @@ def test_full_solve_matches_twin_iterate_by_iterate(oracle_lib, name, w, opts):
     assert np.allclose(L[:, 7], T[:, 7], rtol=1e-8)                  # model cost change
     assert np.abs(got["pose"] - ref["pose"]).max() < 1e-9
     assert np.abs(got["lmk"] - ref["lmk"]).max() < 1e-8 * max(1.0, np.abs(ref["lmk"]).max())
+
+
+# ---- round 3: the pieces the reference's tests do not pin either (VERDICT r02 "missing" 3) --------------------------------
+def _f(B, x):
+    return np.array(B.f(x), dtype=np.float64)
+
+
+def test_nfr_factors_match_50_digit_evaluation(oracle_lib):
+    """IMUPriordx / PoseToLandmarkFactor / Landmark3DPrior / LandmarkToLandmarkFactor (residuals.hpp:506-700) — the C oracle
+    against the twin's 50-digit evaluation of the reference's formulas, as coded (un-whitened v / ba / bg Jacobian blocks)."""
+    from sparse_helpers import vio_sparse_priors, vo_sparse_priors
+    from vio_helpers import make_vio_window
+    w = make_vio_window(n_kf=4, n_lmk=60, seed=62)
+    rng = np.random.default_rng(1)
+    w.sparse_priors = vio_sparse_priors(w, 1, [4, 9], rng) + vo_sparse_priors(w, [12, 13, 14], rng)
+    B = twin.Backend("mp", 50)
+    worst = 0.0
+    for scale in (1.0, 1e-3, 0.0):
+        xp = scale * 0.05 * rng.standard_normal((w.n_kf, 6)); xv = scale * 0.1 * rng.standard_normal((w.n_kf, 3))
+        xba = scale * 0.01 * rng.standard_normal((w.n_kf, 3)); xbg = scale * 0.01 * rng.standard_normal((w.n_kf, 3))
+        xl = scale * 0.1 * rng.standard_normal((w.n_lmk, 3))
+        for k, f in enumerate(w.sparse_priors):
+            r, J = oracle_lib.sparse_factor(w, k, xp, xv, xba, xbg, xl)
+            if f["type"] == capi.SPARSE_IMU_PRIOR:
+                kf = f["kf"]
+                rt, Jt = twin.imu_prior_factor(B, w.kf_T_f_w[kf], w.kf_vel[kf], w.kf_ba[kf], w.kf_bg[kf], f["T_prior"], f["v_prior"],
+                                               f["ba_prior"], f["bg_prior"], f["sqrt_inf"], np.concatenate([xp[kf], xv[kf], xba[kf], xbg[kf]]))
+                n = 15
+            elif f["type"] == capi.SPARSE_POSE_TO_LMK:
+                rt, Jt = twin.pose_to_landmark_factor(B, w.kf_T_f_w[f["kf"]], w.lmk_p[f["lmk0"]], f["delta"], f["sqrt_inf"], xp[f["kf"]], xl[f["lmk0"]])
+                n = 9
+            elif f["type"] == capi.SPARSE_LMK_PRIOR:
+                rt, Jt = twin.landmark_prior_factor(B, w.lmk_p[f["lmk0"]], f["delta"], f["sqrt_inf"], xl[f["lmk0"]])
+                n = 3
+            else:
+                rt, Jt = twin.landmark_to_landmark_factor(B, w.lmk_p[f["lmk0"]], w.lmk_p[f["lmk1"]], f["delta"], f["sqrt_inf"], xl[f["lmk0"]], xl[f["lmk1"]])
+                n = 6
+            worst = max(worst, _rel(J[:, :n], _f(B, Jt)), float(np.abs(r - _f(B, rt)).max()) / max(1.0, float(np.abs(_f(B, rt)).max())))
+    assert worst < 5e-13, worst
+
+
+def _marg_case(oracle_lib, vio):
+    from marg_helpers import with_lonely_landmarks
+    from test_oracle_marg import pre_marginalize
+    from vio_helpers import make_vio_window
+    if vio:
+        w = with_lonely_landmarks(make_vio_window(n_kf=5, n_lmk=40, seed=91), 4, 4)
+        keep, marg = pre_marginalize(w, 4)
+        keep = keep[:6]
+        imu = [f for f in w.imu_factors if f["kf_i"] == 4 and f["kf_j"] == 3][0]
+        rng = np.random.default_rng(5)
+        last = {"J": 20.0 * (np.eye(15) + 0.1 * rng.standard_normal((15, 15))), "r0": 0.1 * rng.standard_normal(15), "kf_keep": 4,
+                "kf_col": 0, "lmk_index": np.zeros(0, dtype=np.int32), "lmk_col": np.zeros(0, dtype=np.int32)}
+        return w, oracle_lib.marginalize(w, 4, marg, keep, kf_keep=3, marg_has_imu=True, imu=imu, priors=w.pose_priors, last=last, want_full=True)
+    from test_oracle_marg import toy_window
+    w = toy_window()
+    w.obs_meas = w.obs_meas + np.random.default_rng(0).standard_normal(w.obs_meas.shape)
+    keep, marg = pre_marginalize(w, 0)
+    return w, oracle_lib.marginalize(w, 0, marg, keep, want_full=True)
+
+
+@pytest.mark.parametrize("vio", [False, True])
+def test_marginalisation_algebra_matches_50_digit_evaluation(oracle_lib, vio):
+    """computeSchurComplement / rankReveallingDecomposition / computeJacobiansAndResiduals (marginalization.cpp:213-265,
+    318-342, 516-530) on the oracle's own A = sum J^T J, b = sum J^T r: the prior (J, r0) it returns against the twin's 50-digit
+    evaluation, through the invariants J^T J (= Ak on its range), J^T r0 (= -bk on its range: the sign convention as coded) and
+    the MarginalizationFactor residual r0 + J dx (marginalization.hpp:113-215). vio = False is the reference's own test
+    fixture (marginalization_test.cpp), whose Ak has a null space: in 50 digits it is exactly null and cut, in float64 it
+    computes to +-1e-11 and two noise eigenvalues survive the cut — which is why the comparison is on the invariants."""
+    w, o = _marg_case(oracle_lib, vio)
+    m, n = o["m"], o["n"]
+    B = twin.Backend("mp", 50)
+    t = twin.schur_prior(B, o["A_full"], o["b_full"], m, cut=lambda lmax: max(1e-12, (m + n) * 2.3e-16 * float(lmax)))
+    Ho = o["J"].T @ o["J"]
+    scale = np.abs(Ho).max()
+    assert np.abs(_f(B, t["Ak"]) - o["Ak"][:n, :n]).max() <= 1e-9 * scale
+    assert np.abs(_f(B, t["bk"]) - o["bk"][:n]).max() <= 1e-9 * max(np.abs(o["bk"]).max(), np.sqrt(scale))
+    assert np.abs(_f(B, t["J"].T @ t["J"]) - Ho).max() <= 1e-9 * scale
+    go = o["J"].T @ o["r0"]
+    assert np.abs(_f(B, t["J"].T @ t["r0"]) - go).max() <= 1e-8 * max(np.abs(go).max(), np.sqrt(scale))
+    # the sign convention as coded: J^T r0 = -U U^T bk
+    assert np.abs(_f(B, t["J"].T @ t["r0"] + t["U"] @ (t["U"].T @ t["bk"]))).max() <= 1e-30 * scale
+    # MarginalizationFactor::Evaluate: r = r0 + J dx, compared through the rotation-invariant |r|^2 and J^T r
+    dx = 1e-2 * np.random.default_rng(3).standard_normal(n)
+    rt, _ = twin.marginalization_factor(B, t["J"], t["r0"], dx)
+    ro = o["r0"] + o["J"] @ dx
+    assert abs(float((rt * rt).sum()) - float(ro @ ro)) <= 1e-8 * max(float(ro @ ro), 1e-30) + 1e-9
+    assert np.abs(_f(B, t["J"].T @ rt) - o["J"].T @ ro).max() <= 1e-8 * max(np.abs(go).max(), np.sqrt(scale))
+    if vio:
+        assert t["n_full"] == o["n_full"]
+
+
+def test_sparsify_informations_match_50_digit_evaluation(oracle_lib):
+    """sparsifyVIO / sparsifyVO factor informations (marginalization.cpp:362-408, 491-514): the square-root information of the
+    absolute factor of the kept frame, of the pose-to-landmark factors and of the landmark chain, from the SAME prior rows the
+    oracle sparsifies, evaluated by the twin in 50 digits ((J~ Sigma J~^T)^-1, eigen square root)."""
+    from test_oracle_sparsify import vio_prior, vo_prior
+    B = twin.Backend("mp", 50)
+    for vio in (True, False):
+        w, pr = (vio_prior if vio else vo_prior)(oracle_lib)
+        fs = oracle_lib.sparsify(w, pr, vio=vio)
+        J = pr["J"]
+        lam = (J * J).sum(axis=1)                       # rows of J = sqrt(lambda_c) u_c^T
+        U = B.a((J / np.sqrt(lam)[:, None]).T)
+        Sigma = B.a(1.0 / lam)
+        n = pr["n"]
+        col = {int(l): int(c) for l, c in zip(pr["lmk_index"], pr["lmk_col"]) if c >= 0}
+        if vio:
+            Js, Ja = twin.sparsify_vio_jacobians(B, w.kf_T_f_w[pr["kf_keep"]], pr["kf_col"], [col[f["lmk0"]] for f in fs[1:4]], n)
+            cases = [(fs[0]["sqrt_inf"], Ja, False, 1e-5)] + [(f["sqrt_inf"], Jf, False, 1e-6) for f, Jf in zip(fs[1:4], Js)]
+        else:
+            cases = []
+            Jf = B.zeros((3, n))
+            for q in range(3):
+                Jf[q, col[fs[0]["lmk0"]] + q] = B.s(1)
+            cases.append((fs[0]["sqrt_inf"], Jf, True, 1e-6))
+            for f in fs[1:4]:
+                Jf = B.zeros((3, n))
+                for q in range(3):
+                    Jf[q, col[f["lmk0"]] + q] = B.s(1); Jf[q, col[f["lmk1"]] + q] = B.s(-1)
+                cases.append((f["sqrt_inf"], Jf, True, 1e-6))
+        for W, Jf, inv_eig, tol in cases:
+            Wt = _f(B, twin.nfr_sqrt_information(B, Jf, U, Sigma, inv_eig))
+            # W is a symmetric square root: compare the information W^T W and W itself
+            assert np.abs(W.T @ W - Wt.T @ Wt).max() <= tol * np.abs(Wt.T @ Wt).max()
+            assert np.abs(W - Wt).max() <= 10 * tol * np.abs(Wt).max()
