@@ -182,8 +182,18 @@ struct LineSetHost {   // deep copy of a sadvio_line_set
     int n() const { return (int)id.size(); }
 };
 
+// Host-side work arrays of build_layout, kept between calls: a sliding-window back end calls set_windows once per key-frame,
+// and ~2 MB of fresh std::vectors per call are ~500 page faults (more than the layout arithmetic itself).
+struct LayoutScratch {
+    std::vector<double> kf_T0, kf_vel, kf_ba, kf_bg, cam_K, cam_T, cam_isig, lmk_p, obs_meas;
+    std::vector<int> kf_fidx, lmk_ob, lmk_oe, obs_kf, obs_cam, tile_kf, tile_row, pkf, pcam, run_max, idx, mark, add, kfs, slot_of, chunk_ob, chunk_lm, perm;
+    std::vector<unsigned char> lmk_const, obs_slot, obs_lslot;
+    std::vector<char> held;
+};
+
 struct sadvio_ba_handle {
     sadvio_ba_config cfg{};
+    LayoutScratch ls;
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -271,6 +281,7 @@ struct sadvio_ba_handle {
     DevBuf<IterAcc> d_acc;
     DevBuf<FinalRec> d_final;
     FinalRec* h_final = nullptr;  // pinned
+    double* h_deltas = nullptr; size_t h_deltas_cap = 0; bool deltas_cached = false;   // pinned copy of BOTH delta buffers, fetched by the first get_deltas after a solve
     size_t h_final_n = 0;
     std::vector<FinalRec> fin;    // last solve's records
     DevBuf<TileAcc> d_tacc;
@@ -653,6 +664,7 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->rccl.comm) (void)h->rccl.destroy(h->rccl.comm);
     if (h->h_final) (void)hipHostFree(h->h_final);
+    if (h->h_deltas) (void)hipHostFree(h->h_deltas);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->side2) { (void)hipStreamSynchronize(h->side2); (void)hipStreamDestroy(h->side2); }
     for (hipEvent_t e : {h->ev_fork, h->ev_lin, h->ev_solved, h->ev_cost, h->ev_diag0, h->ev_diag1}) if (e) (void)hipEventDestroy(e);
@@ -714,7 +726,9 @@ static int build_layout(sadvio_ba_handle* h) {
             views[w].cam_K = S.u_cam_K.data(); views[w].cam_T_s_f = S.u_cam_T.data(); views[w].cam_sigma = S.u_cam_sigma.data();
             views[w].obs_cam = S.u_obs_cam.data();
         }
-        std::vector<char> held(std::max(S.v.n_lmk, 1), 0);
+        if (sp.empty()) { S.a_src.clear(); continue; }   // no sparse factors: nothing rides the elimination as a pseudo-observation
+        auto& held = h->ls.held;
+        held.assign(std::max(S.v.n_lmk, 1), 0);
         const DensePriorHost& D = h->dprior_per_win[w];
         for (size_t i = 0; i < D.lmk_index.size(); i++) if (D.n_full > 0 && D.lmk_col[i] >= 0) held[D.lmk_index[i]] = 1;
         for (const auto& s : sp) {
@@ -801,17 +815,23 @@ static int build_layout(sadvio_ba_handle* h) {
     }
     h->n_kf_tot = kf_b; h->n_cam_tot = cam_b; h->n_lmk_tot = lmk_b; h->n_obs_tot = obs_b;
 
+    lap("  validate");
     // concatenate
-    std::vector<double> kf_T0(12 * (size_t)kf_b), kf_vel(3 * (size_t)kf_b, 0.0), kf_ba(3 * (size_t)kf_b, 0.0), kf_bg(3 * (size_t)kf_b, 0.0);
-    std::vector<int> kf_fidx(kf_b);
-    std::vector<double> cam_K(4 * (size_t)cam_b), cam_T(12 * (size_t)cam_b), cam_isig(cam_b);
-    std::vector<double> lmk_p(3 * (size_t)lmk_b);
-    std::vector<unsigned char> lmk_const(std::max(lmk_b, 1), 0);
-    std::vector<int> lmk_ob(std::max(lmk_b, 1)), lmk_oe(std::max(lmk_b, 1)), obs_kf(std::max(obs_b, 1)), obs_cam(std::max(obs_b, 1));
+    LayoutScratch& ls = h->ls;
+    auto& kf_T0 = ls.kf_T0; auto& kf_vel = ls.kf_vel; auto& kf_ba = ls.kf_ba; auto& kf_bg = ls.kf_bg; auto& kf_fidx = ls.kf_fidx;
+    auto& cam_K = ls.cam_K; auto& cam_T = ls.cam_T; auto& cam_isig = ls.cam_isig; auto& lmk_p = ls.lmk_p; auto& lmk_const = ls.lmk_const;
+    auto& lmk_ob = ls.lmk_ob; auto& lmk_oe = ls.lmk_oe; auto& obs_kf = ls.obs_kf; auto& obs_cam = ls.obs_cam; auto& obs_meas = ls.obs_meas;
+    auto& tile_kf = ls.tile_kf; auto& tile_row = ls.tile_row; auto& obs_slot = ls.obs_slot;
+    kf_T0.resize(12 * (size_t)kf_b); kf_vel.assign(3 * (size_t)kf_b, 0.0); kf_ba.assign(3 * (size_t)kf_b, 0.0); kf_bg.assign(3 * (size_t)kf_b, 0.0);
+    kf_fidx.resize(kf_b);
+    cam_K.resize(4 * (size_t)cam_b); cam_T.resize(12 * (size_t)cam_b); cam_isig.resize(cam_b);
+    lmk_p.resize(3 * (size_t)lmk_b);
+    lmk_const.assign(std::max(lmk_b, 1), 0);
+    lmk_ob.resize(std::max(lmk_b, 1)); lmk_oe.resize(std::max(lmk_b, 1)); obs_kf.resize(std::max(obs_b, 1)); obs_cam.resize(std::max(obs_b, 1));
     const int ms = h->factor_type == SADVIO_FACTOR_PIXEL ? 2 : 3;
-    std::vector<double> obs_meas((size_t)ms * std::max(obs_b, 1));
-    std::vector<int> tile_kf, tile_row;
-    std::vector<unsigned char> obs_slot(std::max(obs_b, 1), 0);
+    obs_meas.resize((size_t)ms * std::max(obs_b, 1));
+    tile_kf.clear(); tile_row.clear();
+    obs_slot.assign(std::max(obs_b, 1), 0);
     h->obs_perm.assign(std::max(obs_b, 1), 0);
     h->max_tile_kf = 1; h->max_tile_free = 0; h->max_gemm_free = 0;
     for (int w = 0; w < n_windows; w++) {
@@ -833,47 +853,85 @@ static int build_layout(sadvio_ba_handle* h) {
             lmk_oe[d.lmk_base + l] = d.obs_base + F.lmk_obs_ptr[l + 1];
             if (F.lmk_obs_ptr[l + 1] < F.lmk_obs_ptr[l]) { h->err = "set_windows: CSR not monotone"; return SADVIO_E_INVALID_ARG; }
         }
+        lap("  concat");
         // Observations of a landmark are stored sorted by key-frame (stable), so that the (at most two) cameras
         // of one key-frame sit in adjacent lanes; the landmark / key-frame order of the window is untouched and
         // obs_perm maps device position -> caller position for the per-observation probe.
-        std::vector<int> pkf(F.n_obs), pcam(F.n_obs);
-        std::vector<int> run_max(F.n_lmk, 0);
-        std::vector<int> idx;  // reused across landmarks
+        auto& pkf = ls.pkf; auto& pcam = ls.pcam; auto& run_max = ls.run_max; auto& idx = ls.idx;
+        pkf.resize(std::max(F.n_obs, 1)); pcam.resize(std::max(F.n_obs, 1));
+        run_max.assign(std::max(F.n_lmk, 1), 0);
+        const bool has_asrc = !h->src[w].a_src.empty();
+        const int32_t* asrc = has_asrc ? h->src[w].a_src.data() : nullptr;
+        // first pass (integers only): is every landmark's list already key-frame sorted (what a flattening in frame order
+        // produces)? Its longest same-key-frame run either way.
+        bool all_sorted = true;
+        int hb_win = 0;   // largest spread of free key-frame indices one landmark couples (half bandwidth of the reduced system)
+        const int* fidx_w = kf_fidx.data() + d.kf_base;
         for (int l = 0; l < F.n_lmk; l++) {
             const int o0 = F.lmk_obs_ptr[l], o1 = F.lmk_obs_ptr[l + 1];
-            idx.resize(o1 - o0);
-            for (int k = 0; k < o1 - o0; k++) idx[k] = o0 + k;
-            // tracks are short: insertion sort (stable) by key-frame
-            for (int a = 1; a < o1 - o0; a++) {
-                const int v = idx[a], kv = F.obs_kf[v];
-                int b = a - 1;
-                while (b >= 0 && F.obs_kf[idx[b]] > kv) { idx[b + 1] = idx[b]; b--; }
-                idx[b + 1] = v;
+            int run = 0, rm = 0, prev = -1, lo = 1 << 30, hi = -1;
+            for (int o = o0; o < o1; o++) {
+                const int kf = F.obs_kf[o];
+                if (kf < prev) { all_sorted = false; }
+                run = (kf == prev) ? run + 1 : 1;
+                rm = std::max(rm, run);
+                prev = kf;
+                const int fi = fidx_w[kf];
+                if (fi >= 0) { lo = std::min(lo, fi); hi = std::max(hi, fi); }
             }
-            int run = 0;
-            for (int k = 0; k < o1 - o0; k++) {
-                const int src = idx[k], dst = o0 + k;
-                pkf[dst] = F.obs_kf[src]; pcam[dst] = F.obs_cam[src];
-                h->obs_perm[d.obs_base + dst] = h->src[w].a_src.empty() ? src : h->src[w].a_src[src];  // -1: pseudo-observation
-                obs_kf[d.obs_base + dst] = d.kf_base + F.obs_kf[src];
-                obs_cam[d.obs_base + dst] = F.obs_cam[src] < 0 ? F.obs_cam[src] : d.cam_base + F.obs_cam[src];
-                memcpy(&obs_meas[(size_t)ms * (d.obs_base + dst)], F.obs_meas + (size_t)ms * src, sizeof(double) * ms);
-                run = (k > 0 && pkf[dst] == pkf[dst - 1]) ? run + 1 : 1;
-                run_max[l] = std::max(run_max[l], run);
-            }
+            run_max[l] = rm;
+            if (hi >= 0) hb_win = std::max(hb_win, hi - lo);
         }
-        {
-            int hb = 0;
-            for (int l = 0; l < F.n_lmk; l++) {
-                int lo = 1 << 30, hi = -1;
-                for (int o = F.lmk_obs_ptr[l]; o < F.lmk_obs_ptr[l + 1]; o++) {
-                    const int fi = kf_fidx[d.kf_base + F.obs_kf[o]];
-                    if (fi >= 0) { lo = std::min(lo, fi); hi = std::max(hi, fi); }
+        h->wins[w].hb_lmk = hb_win;
+        if (all_sorted) {
+            // bulk path: the device order IS the caller's order — whole-array copies
+            const int kb = d.kf_base, cb = d.cam_base, ob = d.obs_base, n = F.n_obs;
+            for (int o = 0; o < n; o++) { pkf[o] = F.obs_kf[o]; obs_kf[ob + o] = kb + F.obs_kf[o]; }
+            for (int o = 0; o < n; o++) { const int c = F.obs_cam[o]; pcam[o] = c; obs_cam[ob + o] = c < 0 ? c : cb + c; }
+            if (has_asrc) for (int o = 0; o < n; o++) h->obs_perm[ob + o] = asrc[o];
+            else for (int o = 0; o < n; o++) h->obs_perm[ob + o] = o;
+            if (n) memcpy(&obs_meas[(size_t)ms * ob], F.obs_meas, sizeof(double) * (size_t)ms * n);
+        } else
+        for (int l = 0; l < F.n_lmk; l++) {
+            const int o0 = F.lmk_obs_ptr[l], o1 = F.lmk_obs_ptr[l + 1], k_n = o1 - o0;
+            // tracks are short: insertion sort (stable) on packed keys (key-frame << 8 | position) held in a local array —
+            // no indirection through the caller's arrays inside the sort; longer tracks take the index sort
+            int key[64];
+            const int32_t* okf = F.obs_kf + o0;
+            if (k_n <= 64 && F.n_kf < (1 << 22)) {
+                for (int k = 0; k < k_n; k++) key[k] = (okf[k] << 8) | k;
+                for (int a = 1; a < k_n; a++) {
+                    const int v = key[a];
+                    int b = a - 1;
+                    while (b >= 0 && key[b] > v) { key[b + 1] = key[b]; b--; }
+                    key[b + 1] = v;
                 }
-                if (hi >= 0) hb = std::max(hb, hi - lo);
+            } else {
+                idx.resize(k_n);
+                for (int k = 0; k < k_n; k++) idx[k] = k;
+                std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return okf[a] < okf[b]; });
             }
-            h->wins[w].hb_lmk = hb;
+            int run = 0, rm = 0, prev = -1;
+            const int kb = d.kf_base, cb = d.cam_base, ob = d.obs_base;
+            for (int k = 0; k < k_n; k++) {
+                const int rel = k_n <= 64 && F.n_kf < (1 << 22) ? (key[k] & 255) : idx[k];
+                const int src = o0 + rel, dst = o0 + k;
+                const int kf = okf[rel], c = F.obs_cam[src];
+                pkf[dst] = kf; pcam[dst] = c;
+                h->obs_perm[ob + dst] = has_asrc ? asrc[src] : src;  // -1: pseudo-observation
+                obs_kf[ob + dst] = kb + kf;
+                obs_cam[ob + dst] = c < 0 ? c : cb + c;
+                const double* m = F.obs_meas + (size_t)ms * src;
+                double* md = &obs_meas[(size_t)ms * (ob + dst)];
+                md[0] = m[0]; md[1] = m[1]; if (ms == 3) md[2] = m[2];
+                run = (kf == prev) ? run + 1 : 1;
+                rm = std::max(rm, run);
+                prev = kf;
+            }
+            run_max[l] = rm;
         }
+        lap("  sort+permute");
+        lap("  half-bandwidth");
         // tiles: runs of consecutive landmarks. Every landmark gets a group of G lanes (G = pow2 >= the
         // tile's largest observation count); a workgroup of BUILD_WAVES waves holds BUILD_WAVES * 64 / G
         // landmarks per round. A tile is cut when its key-frame list would exceed the LDS tile capacity.
@@ -890,7 +948,8 @@ static int build_layout(sadvio_ba_handle* h) {
         d.tile_begin = (int)h->tiles.size();
         {
             int l = 0;
-            std::vector<int> mark(F.n_kf, -1), add, kfs, slot_of(F.n_kf, -1);
+            auto& mark = ls.mark; auto& add = ls.add; auto& kfs = ls.kfs; auto& slot_of = ls.slot_of;
+            mark.assign(F.n_kf, -1); slot_of.assign(F.n_kf, -1);
             while (l < F.n_lmk || (int)h->tiles.size() == d.tile_begin) {
                 Tile t{};
                 t.w = w; t.lmk0 = d.lmk_base + l; t.kmax = 1; t.G = 8;
@@ -964,8 +1023,10 @@ static int build_layout(sadvio_ba_handle* h) {
     lap("concat+tiles");
     // chunk tables of the throughput kernels: a tile's consecutive landmarks in chunks of <= LM_CHUNK landmarks and <= 64
     // observations; obs_lslot = index of the observation's landmark inside its chunk
-    std::vector<int> chunk_ob, chunk_lm;   // chunk starts + one sentinel (landmarks and observations are globally consecutive)
-    std::vector<unsigned char> obs_lslot(std::max(obs_b, 1), 0);
+    auto& chunk_ob = ls.chunk_ob; auto& chunk_lm = ls.chunk_lm;   // chunk starts + one sentinel (landmarks and observations are globally consecutive)
+    auto& obs_lslot = ls.obs_lslot;
+    chunk_ob.clear(); chunk_lm.clear();
+    obs_lslot.assign(std::max(obs_b, 1), 0);
     // the tables cost host time (a second, sorted copy of the observation constants): only built where the throughput path can run
     bool want_lm = lmk_b >= 65536;
     if (const char* e = getenv("SADVIO_LM")) want_lm = atoi(e) != 0;
@@ -1032,7 +1093,8 @@ static int build_layout(sadvio_ba_handle* h) {
     h->up.add(h->d_obs_lslot.p, obs_lslot.data(), obs_lslot.size());
     {
         // launch order of the throughput kernels: longest tiles first (LPT), so that the last workgroups to start are short ones
-        std::vector<int> perm(h->tiles.size());
+        auto& perm = ls.perm;
+        perm.resize(h->tiles.size());
         for (size_t i = 0; i < perm.size(); i++) perm[i] = (int)i;
         if (want_lm && !getenv("SADVIO_NO_LPT"))
             std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
@@ -1110,10 +1172,13 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
             }
     }
     // deep copies: later set_* calls rebuild the layout without the caller's buffers
-    h->src.assign(n_windows, SrcWin());
+    if ((int)h->src.size() != n_windows) h->src.assign(n_windows, SrcWin());   // same batch size: the copies below reuse their capacity
     for (int w = 0; w < n_windows; w++) {
         const sadvio_flat_window& F = wins[w];
         SrcWin& S = h->src[w];
+        S.cam_sigma.clear(); S.kf_id.clear(); S.kf_const.clear(); S.kf_vel.clear(); S.kf_ba.clear(); S.kf_bg.clear();
+        S.lmk_p.clear(); S.lmk_id.clear(); S.lmk_const.clear(); S.obs_kf.clear(); S.obs_cam.clear(); S.obs_meas.clear();
+        S.a_src.clear();
         const int ms = F.factor_type == SADVIO_FACTOR_PIXEL ? 2 : 3;
         S.kf_T.assign(F.kf_T_f_w, F.kf_T_f_w + 12 * (size_t)F.n_kf);
         S.cam_K.assign(F.cam_K, F.cam_K + 4 * (size_t)F.n_cam); S.cam_T.assign(F.cam_T_s_f, F.cam_T_s_f + 12 * (size_t)F.n_cam);
@@ -2413,6 +2478,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         }
     }
     h->fin.assign(h->h_final, h->h_final + n_win);
+    h->deltas_cached = false;
     h->last_slots = slots;
     h->solved = true;
     int rc = SADVIO_OK;
@@ -2438,12 +2504,38 @@ int sadvio_ba_get_deltas(sadvio_ba_handle* h, int32_t w, double* pose, double* l
     HIP_TRY(hipSetDevice(h->device));
     const WinDev& d = h->wins[w].d;
     const int cur = h->fin[w].s.cur;
-    if (pose) HIP_TRY(hipMemcpy(pose, h->d_xp.p + (size_t)cur * 6 * h->n_kf_tot + 6 * (size_t)d.kf_base, sizeof(double) * 6 * d.n_kf, hipMemcpyDeviceToHost));
-    if (lmk && d.n_lmk) HIP_TRY(hipMemcpy(lmk, h->d_xl.p + (size_t)cur * 3 * h->n_lmk_tot + 3 * (size_t)d.lmk_base, sizeof(double) * 3 * d.n_lmk, hipMemcpyDeviceToHost));
+    // One read-back per solve: both buffers of every delta array go to a pinned host buffer with asynchronous copies and ONE
+    // synchronisation (a pageable hipMemcpy per array and window costs 30 - 80 us each); every get_deltas of this solve is then
+    // a host memcpy. Layout: xp [2][6 n_kf] | xl [2][3 n_lmk] | xv | xba | xbg [2][3 n_kf] each.
+    const size_t nk = (size_t)h->n_kf_tot, nl = (size_t)h->n_lmk_tot;
+    const size_t o_xp = 0, o_xl = o_xp + 12 * nk, o_xv = o_xl + 6 * nl, o_xba = o_xv + 6 * nk, o_xbg = o_xba + 6 * nk, total = o_xbg + 6 * nk;
+    if (!h->deltas_cached) {
+        if (h->h_deltas_cap < total) {
+            if (h->h_deltas) (void)hipHostFree(h->h_deltas);
+            h->h_deltas = nullptr; h->h_deltas_cap = 0;
+            HIP_TRY(hipHostMalloc((void**)&h->h_deltas, sizeof(double) * (total + total / 2), hipHostMallocDefault));
+            h->h_deltas_cap = total + total / 2;
+        }
+        bool any_imu = false;
+        for (const auto& hw : h->wins) any_imu |= hw.d.has_imu != 0;
+        HIP_TRY(hipMemcpyAsync(h->h_deltas + o_xp, h->d_xp.p, sizeof(double) * 12 * nk, hipMemcpyDeviceToHost, h->stream));
+        if (nl) HIP_TRY(hipMemcpyAsync(h->h_deltas + o_xl, h->d_xl.p, sizeof(double) * 6 * nl, hipMemcpyDeviceToHost, h->stream));
+        if (any_imu) {
+            HIP_TRY(hipMemcpyAsync(h->h_deltas + o_xv, h->d_xv.p, sizeof(double) * 6 * nk, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->h_deltas + o_xba, h->d_xba.p, sizeof(double) * 6 * nk, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->h_deltas + o_xbg, h->d_xbg.p, sizeof(double) * 6 * nk, hipMemcpyDeviceToHost, h->stream));
+        } else {
+            memset(h->h_deltas + o_xv, 0, sizeof(double) * 18 * nk);   // windows without IMU states: their deltas are never touched (zero)
+        }
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->deltas_cached = true;
+    }
+    if (pose) memcpy(pose, h->h_deltas + o_xp + (size_t)cur * 6 * nk + 6 * (size_t)d.kf_base, sizeof(double) * 6 * d.n_kf);
+    if (lmk && d.n_lmk) memcpy(lmk, h->h_deltas + o_xl + (size_t)cur * 3 * nl + 3 * (size_t)d.lmk_base, sizeof(double) * 3 * d.n_lmk);
     double* outs[3] = {dv, dba, dbg};
-    double* srcs[3] = {h->d_xv.p, h->d_xba.p, h->d_xbg.p};
+    const size_t offs[3] = {o_xv, o_xba, o_xbg};
     for (int q = 0; q < 3; q++)
-        if (outs[q]) HIP_TRY(hipMemcpy(outs[q], srcs[q] + (size_t)cur * 3 * h->n_kf_tot + 3 * (size_t)d.kf_base, sizeof(double) * 3 * d.n_kf, hipMemcpyDeviceToHost));
+        if (outs[q]) memcpy(outs[q], h->h_deltas + offs[q] + (size_t)cur * 3 * nk + 3 * (size_t)d.kf_base, sizeof(double) * 3 * d.n_kf);
     return SADVIO_OK;
 }
 

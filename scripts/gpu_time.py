@@ -36,3 +36,16 @@ t=time.perf_counter()
 for _ in range(20): s = be.solve(opts)
 dt=(time.perf_counter()-t)/20
 print(f"   hipGraph   wall/solve {dt*1e3:.3f} ms -> {nw*10/dt:.0f} it/s   final cost {s[0].final_cost}")
+be = capi.Backend(device=0, use_graph=True)
+be.set_windows(ws)
+for _ in range(3): be.solve(opts); be.get_deltas(0)
+t=time.perf_counter()
+for _ in range(30):
+    be.set_windows(ws); be.solve(opts); d = be.get_deltas(0)
+dt=(time.perf_counter()-t)/30
+t=time.perf_counter()
+for _ in range(30): d = be.get_deltas(0)
+dg=(time.perf_counter()-t)/30
+be.solve(opts)
+t=time.perf_counter(); d = be.get_deltas(0); dg1=time.perf_counter()-t
+print(f"   upload-inclusive (set_windows + solve + get_deltas) {dt*1e3:.3f} ms -> {nw*10/dt:.0f} it/s; get_deltas first {dg1*1e6:.0f} us, cached {dg*1e6:.0f} us")
