@@ -1410,15 +1410,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             y[tid] = c_y; gf[tid] = c_gf; hd[tid] = c_hd;
             gredg[tid] = 0.0; gfullg[tid] = 0.0; hdg[tid] = 0.0;
         }
-        {
-            // clear the global accumulator for the next k_build: each wave the part it copied, once its own copy has landed
-            // (nothing orders a store of ANOTHER wave behind this wave's reads of the same addresses)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const double2 z2 = make_double2(0.0, 0.0);
-            const int n2 = img_n >> 1;
-            const int stride = nwv * 64;
-            for (int i = wv * 64; i < n2; i += stride) ((double2*)Sg)[i + ln] = z2;
-        }
+        // (the accumulator in HBM is re-zeroed by the tiles of k_backsub / k_backsub_lm: zero_s_slice)
         if (kf_pre) {
             double* c = kfc + tid * 20;
             c[0] = (double)kf_fi;
@@ -1835,6 +1827,20 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     if (ts && tid == 0) { ts[15] = wall_clock64(); ts[21] = clock64(); }
 }
 
+
+// The reduced system of an in-LDS window is an accumulator in HBM (k_build adds into it with atomics) that has to be zero when
+// the next k_build starts. k_solve only READS it; the re-zeroing is spread over the tiles of the back-substitution kernel that
+// runs in between — a slice of a few hundred bytes per workgroup — so that k_solve's HBM traffic is the image it needs and no more.
+__device__ __forceinline__ void zero_s_slice(const DevPtrs& P, const Tile& T, int tile_index) {
+    if (T.ld != 0) return;                       // out-of-LDS systems are re-zeroed by their own solver
+    const int n2 = c16_size(T.Np) >> 1;          // double2 of the tile-packed image
+    const int per = (n2 + T.win_ntiles - 1) / T.win_ntiles;
+    const int i0 = (tile_index - T.win_tile0) * per, i1 = min(i0 + per, n2);
+    double2* S2 = (double2*)(P.S + T.S_off);
+    const double2 z2 = make_double2(0.0, 0.0);
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += blockDim.x) S2[i] = z2;
+}
+
 // ---- K7: back-substitution + candidate cost -------------------------------------------------------
 template <int FACTOR, bool RARE>
 __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, int max_tile_kf) {
@@ -1843,6 +1849,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
     const LmState st = P.states[(long long)T.w * P.state_stride + slot];
     IterAcc* acc = P.acc + (long long)T.w * P.state_stride + slot;
+    zero_s_slice(P, T, blockIdx.x);
     if (st.done || acc->chol_fail) {
         if (tid == 0) {
             TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + blockIdx.x;

@@ -444,6 +444,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 3) void k_backsub_lm(DevPtrs P, int 
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
     const LmState st = P.states[(long long)T.w * P.state_stride + slot];
     IterAcc* acc = P.acc + (long long)T.w * P.state_stride + slot;
+    zero_s_slice(P, T, ti);
     if (st.done || acc->chol_fail) {
         if (tid == 0) {
             TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + ti;
