@@ -47,14 +47,13 @@ __device__ __forceinline__ double c16_readlane(double v, int lane) {
     hi = __builtin_amdgcn_readlane(hi, lane);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double c16_rsqrt(double d) {   // v_rsq_f64 (2^-24) + 2 Newton steps: 1.4e-16 (measured)
-    double y = __builtin_amdgcn_rsq(d);
-    const double h = 0.5 * d;                              // y <- y + y (1/2 - h y^2): three operations per step
-    double e = __builtin_fma(-(h * y), y, 0.5);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-(h * y), y, 0.5);
-    y = __builtin_fma(y, e, y);
-    return y;
+__device__ __forceinline__ double c16_rsqrt(double d) {   // v_rsq_f64 (2^-24) + ONE third-order (Halley) step: e = 1 - d y^2,
+    double y = __builtin_amdgcn_rsq(d);                    // y <- y (1 + e / 2 + 3 e^2 / 8): error O(e^3) ~ 1e-22 before rounding;
+    const double t = d * y;                                // five dependent operations instead of the six of two Newton steps
+    const double e = __builtin_fma(-t, y, 1.0);
+    const double p = __builtin_fma(0.375, e, 0.5);
+    const double q = e * p;
+    return __builtin_fma(y, q, y);
 }
 // (even-row member, odd-row member) of the lane pair {l, l ^ 16} in both lanes; likewise (lower, upper) of {l, l ^ 32}
 __device__ __forceinline__ void c16_pair16(double v, double& e, double& o) {
@@ -227,21 +226,37 @@ __device__ __forceinline__ void c16_pivot_step(c16_d4& D, c16_d4& E, c16_d4& W, 
 }
 
 // Factor the diagonal tile D (nreal real pivot columns): publishes the steps' y, returns X(L_kk^-T).
+// A 4-column step whose columns are ALL dummies (4 S >= nreal: the last block column of a system whose size is not a multiple
+// of 16) would compute y = 0, M = 0, W[S] = 0 and leave D alone: it is skipped (a step is ~1 000 cycles of pivot chain;
+// N = 114 has three of them in its last block column).
 template <int GATHER>
 __device__ __forceinline__ c16_d4 c16_pivot_block(c16_d4 D, int nreal, double* pub, double* gbuf, int ln, const C16Lane& lc) {
-    c16_d4 E, W;
+    c16_d4 E, W = {0.0, 0.0, 0.0, 0.0};
     const int i = ln & 15, k = ln >> 4;
 #pragma unroll
     for (int s = 0; s < 4; s++) E[s] = (i == 4 * s + k) ? 1.0 : 0.0;
     double mp = 0.0, y = 0.0;
+    c16_d4 zw = {0.0, 0.0, 0.0, 0.0};
     c16_pivot_step<0, GATHER>(D, E, W, mp, y, nreal, pub, gbuf, ln, lc);
-    c16_pivot_step<1, GATHER>(D, E, W, mp, y, nreal - 4, pub, gbuf, ln, lc);
-    c16_pivot_step<2, GATHER>(D, E, W, mp, y, nreal - 8, pub, gbuf, ln, lc);
-    c16_pivot_step<3, GATHER>(D, E, W, mp, y, nreal - 12, pub, gbuf, ln, lc);
-    if (GATHER == 1) {
-        c16_d4 zw = {0.0, 0.0, 0.0, 0.0};
-        zw = __builtin_amdgcn_mfma_f64_16x16x4f64(mp, E[3], zw, 0, 0, 0);
-        W[3] = zw[0];
+    if (nreal > 4) {
+        c16_pivot_step<1, GATHER>(D, E, W, mp, y, nreal - 4, pub, gbuf, ln, lc);
+        if (nreal > 8) {
+            c16_pivot_step<2, GATHER>(D, E, W, mp, y, nreal - 8, pub, gbuf, ln, lc);
+            if (nreal > 12) {
+                c16_pivot_step<3, GATHER>(D, E, W, mp, y, nreal - 12, pub, gbuf, ln, lc);
+                if (GATHER == 1) { zw = __builtin_amdgcn_mfma_f64_16x16x4f64(mp, E[3], zw, 0, 0, 0); W[3] = zw[0]; }
+            } else {
+                if (GATHER == 1) { zw = __builtin_amdgcn_mfma_f64_16x16x4f64(mp, E[2], zw, 0, 0, 0); W[2] = zw[0]; }
+                W[3] = 0.0; pub[3 * C16_STEP + ln] = 0.0;
+            }
+        } else {
+            if (GATHER == 1) { zw = __builtin_amdgcn_mfma_f64_16x16x4f64(mp, E[1], zw, 0, 0, 0); W[1] = zw[0]; }
+            W[2] = 0.0; W[3] = 0.0; pub[2 * C16_STEP + ln] = 0.0; pub[3 * C16_STEP + ln] = 0.0;
+        }
+    } else {
+        if (GATHER == 1) { zw = __builtin_amdgcn_mfma_f64_16x16x4f64(mp, E[0], zw, 0, 0, 0); W[0] = zw[0]; }
+        W[1] = 0.0; W[2] = 0.0; W[3] = 0.0;
+        pub[1 * C16_STEP + ln] = 0.0; pub[2 * C16_STEP + ln] = 0.0; pub[3 * C16_STEP + ln] = 0.0;
     }
     return W;
 }
@@ -267,17 +282,20 @@ __device__ __forceinline__ c16_d4 c16_panel(c16_d4 X, const double* wt, int ln) 
     return Y + Y2;
 }
 
-// H = L_IJ L_JJ^-1 in place of a panel tile (the diagonal tile holds X(L_JJ^-T)): with it the back-substitution is
+// H = L_IJ L_JJ^-1 (stored transposed) in place of a panel tile (the diagonal tile holds X(L_JJ^-T)): with it the back-substitution is
 // x_J = z_J - sum_{I > J} H_IJ^T x_I with z = the right-hand-side row of H — no triangular solve per block.
 __device__ __forceinline__ void c16_to_h(double* A, int I, int J, int ln) {
     double* t = A + (c16_tile(I, J) << 8);
     const c16_d4 L = c16_load(t, ln);
     const c16_d4 W = c16_load(A + (c16_tile(J, J) << 8), ln);
+    // operands swapped: the accumulator then holds H^T, i.e. the tile is stored TRANSPOSED (H[i][c] at i * 16 + c): the
+    // back-substitution reads, for a fixed row i, the 16 columns of a tile with unit stride across lanes (no bank conflicts;
+    // the column-major tile put the 64 lanes' 16-byte reads 128 bytes apart)
     c16_d4 H = {0.0, 0.0, 0.0, 0.0}, H2 = {0.0, 0.0, 0.0, 0.0};
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(W[0], L[0], H, 0, 0, 0);
-    H2 = __builtin_amdgcn_mfma_f64_16x16x4f64(W[1], L[1], H2, 0, 0, 0);
-    H = __builtin_amdgcn_mfma_f64_16x16x4f64(W[2], L[2], H, 0, 0, 0);
-    H2 = __builtin_amdgcn_mfma_f64_16x16x4f64(W[3], L[3], H2, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(L[0], W[0], H, 0, 0, 0);
+    H2 = __builtin_amdgcn_mfma_f64_16x16x4f64(L[1], W[1], H2, 0, 0, 0);
+    H = __builtin_amdgcn_mfma_f64_16x16x4f64(L[2], W[2], H, 0, 0, 0);
+    H2 = __builtin_amdgcn_mfma_f64_16x16x4f64(L[3], W[3], H2, 0, 0, 0);
     c16_store(t, ln, H + H2);
 }
 
@@ -380,7 +398,7 @@ __device__ __forceinline__ bool c16_solve(double* A, int N, double* xs, double* 
     double z = 0.0;
     if (tid < N) {
         const int J = tid >> 4, cl = tid & 15;
-        if (J < IB) z = A[(c16_tile(IB, J) << 8) + cl * 16 + r];
+        if (J < IB) z = A[(c16_tile(IB, J) << 8) + r * 16 + cl];   // H tiles are stored transposed (c16_to_h)
     }
     if (r > 0 && (tid >> 4) == IB) {       // the block that shares its diagonal tile with the right-hand side: z = L_JJ^-T y_J
         const int cl = tid & 15;
@@ -396,9 +414,9 @@ __device__ __forceinline__ bool c16_solve(double* A, int N, double* xs, double* 
     for (int I = nbc - 1; I >= 0; I--) {
         double hcol[16];
         if (tid < 16 * I) {                // issued before the barrier: independent of x_I
-            const double* ht = A + (c16_tile(I, tid >> 4) << 8) + (tid & 15) * 16;
+            const double* ht = A + (c16_tile(I, tid >> 4) << 8) + (tid & 15);
 #pragma unroll
-            for (int i = 0; i < 16; i++) hcol[i] = ht[i];
+            for (int i = 0; i < 16; i++) hcol[i] = ht[i * 16];
         }
         if ((tid >> 4) == I) {
             yv[tid] = z;

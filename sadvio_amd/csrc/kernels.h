@@ -904,12 +904,12 @@ __global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot,
 // On return xs = S^-1 rhs. Returns false if a pivot is not positive.
 __device__ __forceinline__ double rsqrt_nr(double d) {
     double y = __builtin_amdgcn_rsq(d);
-    // two Newton steps: y <- y + y * (1 - d y^2) / 2
-    double e = __builtin_fma(-d * y, y, 1.0);
-    y = __builtin_fma(0.5 * y, e, y);
-    e = __builtin_fma(-d * y, y, 1.0);
-    y = __builtin_fma(0.5 * y, e, y);
-    return y;
+    // one third-order step (see c16_rsqrt, chol16.h): e = 1 - d y^2, y <- y (1 + e / 2 + 3 e^2 / 8); five dependent operations
+    const double t = d * y;
+    const double e = __builtin_fma(-t, y, 1.0);
+    const double p = __builtin_fma(0.375, e, 0.5);
+    const double q = e * p;
+    return __builtin_fma(y, q, y);
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -2114,7 +2114,7 @@ __global__ __launch_bounds__(256) void k_prior_m(DevPtrs P, int slot) {
 // Rows / columns of the prior-kept landmarks in the reduced system: one thread per observation adds
 // Jl^T Jp (3x6), Jl^T Jl (3x3, lower), Jl^T r and the diagonal; few hundred landmarks per window at most.
 template <int FACTOR>
-__global__ void k_build_kept(DevPtrs P, int slot) {
+__global__ __launch_bounds__(128) void k_build_kept(DevPtrs P, int slot) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.n_kept) return;
     const int o = P.kept_obs[3 * e], gl = P.kept_obs[3 * e + 1], w = P.kept_obs[3 * e + 2];

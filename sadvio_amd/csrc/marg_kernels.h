@@ -768,7 +768,7 @@ struct MargSmall {
     double prior_T[4][12], prior_inf[4][6];
 };
 
-__global__ void k_marg_small(DevPtrs P, const MargSmall* Sp, double* A, double* b, int N) {
+__global__ __launch_bounds__(64) void k_marg_small(DevPtrs P, const MargSmall* Sp, double* A, double* b, int N) {
     const MargSmall& S = *Sp;
     const int t = threadIdx.x;
     const double z[6] = {0, 0, 0, 0, 0, 0};
@@ -913,7 +913,7 @@ __global__ void k_nfr_trace(const double* J, int nf, int n, const int* lcols, in
 // `mult`: how many times the reference enters the landmark (once per feature in frame b, marginalization.cpp:548-559).
 constexpr int RELM_ROW = 3 + 9 + 36;
 template <int FACTOR>
-__global__ void k_relmarg_lmk(DevPtrs P, const int* items /*[n][2]: global landmark, multiplicity*/, int n_items, int ga, int gb,
+__global__ __launch_bounds__(64) void k_relmarg_lmk(DevPtrs P, const int* items /*[n][2]: global landmark, multiplicity*/, int n_items, int ga, int gb,
                               double* scratch, double* Ak /*144, pose blocks accumulated here*/, unsigned long long* evmax_bits) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_items) return;
@@ -1001,7 +1001,7 @@ __global__ void k_relmarg_apply(const double* scratch, int n_items, int m, const
 }
 
 // J (6 x 12) of Relative6DPose(T_w_a, T_w_b, T_a_w T_w_b, I) at zero deltas (…Analytic.cpp:784-800)
-__global__ void k_relmarg_jac(DevPtrs P, int ga, int gb, double* J72) {
+__global__ __launch_bounds__(64) void k_relmarg_jac(DevPtrs P, int ga, int gb, double* J72) {
     if (threadIdx.x != 0) return;
     const double* Ta = P.kf_T0 + 12 * (long long)ga;   // T_f_w
     const double* Tb = P.kf_T0 + 12 * (long long)gb;
