@@ -157,6 +157,7 @@ def main():
     ms_per_solve = ms_per_step / sps
     # N > 1: the collective path as well (same processes, same communicator): config 4 sharded over the ranks
     sharded = bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves) if world > 1 else None
+    sharded5 = bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves, config=5) if world > 1 else None
 
     out = None
     if rank == 0:
@@ -254,7 +255,7 @@ def main():
             "upload_inclusive": {"value": round(iters_per_solve / dt_up, 1), "unit": "BA iterations/s",
                                  "ms_per_solve": round(1e3 * dt_up, 4),
                                  "what": "set_windows (host flatten -> HBM) + solve + get_deltas per solve, rank 0"},
-            "marginalize": marg, "sharded_window": sharded,
+            "marginalize": marg, "sharded_window": sharded, "sharded_window_c5": sharded5,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
@@ -295,12 +296,16 @@ def cpu_baseline_leg(w0, opts):
                     "(un-reduced J^T J + D, sparse direct factorisation) with SciPy's SuperLU standing in for CHOLMOD"}
 
 
-def bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves):
-    """BASELINE.json config 4: one 100-KF / 50k-landmark window spanning the GPUs of the node. Returns the
-    record (rank 0) — printed as its own line by --shard-window, nested as `sharded_window` otherwise."""
+def bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves, config=4):
+    """BASELINE.json config 4: one 100-KF / 50k-landmark window spanning the GPUs of the node — or config 5
+    (500 KF / 200k landmarks). Returns the record (rank 0) — printed as its own line by --shard-window, nested as
+    `sharded_window` (config 4) / `sharded_window_c5` otherwise."""
     from sadvio_amd import capi, sharding, synthetic
     opts = capi.gn_options(GN_ITERS)
-    w = synthetic.make_window(n_kf=100, n_lmk=50000, length=50.0, band=6, seed=4)  # same seed on every rank
+    if config == 5:
+        w = synthetic.make_window(n_kf=500, n_lmk=200000, length=250.0, band=6, seed=5)
+    else:
+        w = synthetic.make_window(n_kf=100, n_lmk=50000, length=50.0, band=6, seed=4)  # same seed on every rank
     be = capi.Backend(device=local_rank)
     uid = [be.rccl_unique_id() if rank == 0 else None]
     if dist is not None:
@@ -316,11 +321,11 @@ def bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_sol
         return None
     n_p = 6 * int((w.kf_const == 0).sum())
     return {
-        "metric": "BA iterations/sec, ONE 100-KF/50k-landmark window sharded over the GPUs",
+        "metric": f"BA iterations/sec, ONE {w.n_kf}-KF/{w.n_lmk // 1000}k-landmark window sharded over the GPUs",
         "value": round(s.iterations * steps / dt, 1), "unit": "BA iterations/s", "n_gpus": world,
         "steps": steps, "warmup": 2, "ms_per_step": round(1e3 * dt / steps, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "synthetic 100 KF x 50000 landmarks x 250000 reprojection factors, GN 10 iters, "
+        "config": {"workload": f"synthetic {w.n_kf} KF x {w.n_lmk} landmarks x {w.n_obs} reprojection factors, GN 10 iters, "
                                "landmark-sharded, RCCL all-reduce of the reduced system per LM step",
                    "parallelism": f"window sharded x{world}", "reduced_dim": n_p, "rccl_ranks": comm["nranks"], "rccl_rank0_device": comm["device"],
                    "rccl_communicator": comm["is_rccl"],

@@ -1610,9 +1610,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         // order: solver time, then the gradient tolerance (the iteration limit was applied by lm_decide)
         const bool time_up = P.o.max_time_ticks > 0.0 && P.t_start && (double)(wall_clock64() - *P.t_start) >= P.o.max_time_ticks;
         acc->time_up = time_up ? 1 : 0;
-        if (time_up || g <= P.o.gradient_tolerance) {
+        // (max_num_iterations = 0: Ceres evaluates the initial cost, tests the gradient tolerance and stops with NO_CONVERGENCE)
+        const bool no_iterations = st.iter == 0 && P.o.max_num_iterations <= 0;
+        if (time_up || g <= P.o.gradient_tolerance || no_iterations) {
             LmState e = st;
-            e.done = 1; e.termination = time_up ? 0 : 3;
+            e.done = 1; e.termination = (time_up || g > P.o.gradient_tolerance) ? 0 : 3;
             e.x_cost = 0.5 * cs;
             if (e.iter == 0) e.initial_cost = e.x_cost;
             *stp = e;
