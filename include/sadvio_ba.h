@@ -341,8 +341,11 @@ int sadvio_ba_marginalize_relative(sadvio_ba_handle *h, int32_t w, int32_t kf_a,
 
 /* ---- one window spanning several GPUs (no reference counterpart: the reference is one process) ----
  * The landmarks of a window (with all their observations) are partitioned over `world` processes, one GPU each;
- * key-frames, cameras, pose priors and IMU factors are replicated (a dense prior is not supported on a
- * sharded window yet: set_dense_prior refuses). Every rank calls set_windows with ITS landmarks, then solve(); per LM step the library all-reduces [S | g | diag | per-rank cost partials] once and the
+ * key-frames, cameras, pose priors and IMU factors are replicated. A marginalisation prior rides a sharded window in its
+ * SPARSIFIED form (sadvio_ba_sparsify): the IMUPriordx factor is replicated (every rank passes it), each
+ * PoseToLandmarkFactor goes to the rank that owns its landmark, with the landmark index of that rank's window; factors that
+ * hold landmarks in the reduced system (Landmark3DPrior, landmark chains), a dense prior, line landmarks and
+ * marginalize_relative are refused on a sharded window. Every rank calls set_windows with ITS landmarks, then solve(); per LM step the library all-reduces [S | g | diag | per-rank cost partials] once and the
  * step's candidate-cost partials once; every rank then solves the identical reduced system redundantly
  * (no broadcast) and back-substitutes its own landmarks. Pose deltas and summaries are identical on all ranks.
  *

@@ -1386,11 +1386,19 @@ int sadvio_ba_set_sparse_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const
     if (!h) return SADVIO_E_INVALID_ARG;
     if (!h->uploaded) { h->err = "set_sparse_priors before set_windows"; return SADVIO_E_STATE; }
     if (w < 0 || w >= (int)h->wins.size() || n < 0 || (n > 0 && !f)) { h->err = "set_sparse_priors: bad argument"; return SADVIO_E_INVALID_ARG; }
-    if (h->world > 1 && n > 0) { h->err = "set_sparse_priors: not supported on a window sharded over several GPUs"; return SADVIO_E_INVALID_ARG; }
     HIP_TRY(hipSetDevice(h->device));
     const WinDev& d = h->wins[w].d;
     for (int i = 0; i < n; i++) {
         const sadvio_sparse_prior& s = f[i];
+        // A window sharded over several GPUs carries the SPARSIFIED VIO prior (what sparsifyVIO produces): IMUPriordx is a
+        // pose-only factor every rank evaluates identically after the all-reduce, a PoseToLandmarkFactor on a free landmark
+        // rides the elimination of the rank that owns the landmark. Factors that hold landmarks in the reduced system
+        // (Landmark3DPrior, landmark chains, relative poses of other layouts) would need those landmarks on every rank.
+        if (h->world > 1 && !(s.type == SADVIO_SPARSE_IMU_PRIOR || (s.type == SADVIO_SPARSE_POSE_TO_LMK && s.lmk0 >= 0 && s.lmk0 < d.n_lmk &&
+                                                                     !(h->src[w].v.lmk_const && h->src[w].v.lmk_const[s.lmk0])))) {
+            h->err = "set_sparse_priors: a window sharded over several GPUs takes IMU-prior and pose-to-landmark factors (on free landmarks of this rank) only";
+            return SADVIO_E_INVALID_ARG;
+        }
         const bool rel = s.type == SADVIO_SPARSE_RELATIVE_POSE;
         if (rel && (s.kf_b < 0 || s.kf_b >= d.n_kf || s.kf_b == s.kf || d.dpf != 6)) {
             h->err = "set_sparse_priors: relative-pose factor " + std::to_string(i) + " has a bad key-frame (or the window carries IMU states)";

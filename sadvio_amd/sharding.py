@@ -1,7 +1,8 @@
 """Landmark partition of one window over several GPUs.
 
 Landmarks (with all their observations) are split into `world` contiguous CSR ranges balanced by observation
-count; key-frames, cameras, pose priors and IMU factors are replicated. Contiguous ranges keep the landmark order
+count; key-frames, cameras, pose priors and IMU factors are replicated. A sparsified VIO prior follows: the IMUPriordx
+factor is replicated, every PoseToLandmarkFactor goes to the owner of its landmark (index re-based to the shard). Contiguous ranges keep the landmark order
 and ids of the caller: concatenating the shards' landmark deltas in rank order restores the window's array.
 """
 from dataclasses import replace
@@ -40,4 +41,16 @@ def shard_window(w: FlatWindow, rank: int, world: int) -> FlatWindow:
         _keep=[],
     )
     s.truth = {}
+    # NFR factors (capi.SPARSE_*: 0 = IMU prior, 1 = pose-to-landmark): pose-only ones everywhere, landmark ones with their landmark
+    sp = []
+    for f in getattr(w, "sparse_priors", None) or []:
+        if f["type"] == 0:
+            sp.append(dict(f))
+        elif f["type"] == 1:
+            if l0 <= f["lmk0"] < l1:
+                g = dict(f); g["lmk0"] = int(f["lmk0"]) - l0
+                sp.append(g)
+        else:
+            raise ValueError("a sharded window carries IMU-prior and pose-to-landmark factors only (sadvio_ba.h)")
+    s.sparse_priors = sp
     return s
