@@ -22,6 +22,32 @@ iteration count / termination, which pins the determined directions.
 import numpy as np
 
 KAPPA0 = 1e9
+SELF_K = 8.0
+
+
+def oracle_self_sensitivity(build, opts, oracle_lib, ref, n_draws=3):
+    """How far the ORACLE moves when every measurement of the window is nudged by one unit in the last place (up or down, seeded):
+    (max pose difference, relative final-cost difference, max landmark difference relative to max(1 m, the landmark's own delta),
+    same iteration count / termination) over `n_draws` draws. `build()`
+    returns a fresh copy of the window. A window on which 20 LM iterations amplify a 1-ulp input change to 1e-5 in a pose cannot
+    be reproduced better than that by ANY second implementation — measured on the round-3 sweeps (scripts/gpu_fuzz.py, 24
+    flagged windows): the device-vs-oracle difference tracks this number within a factor 4 over ten decades
+    (1e-15 .. 1e-5), so the sweep accepts SELF_K times it where the fixed bar fails."""
+    dp = dc = dl = 0.0
+    same = True
+    for t in range(n_draws):
+        w2 = build()
+        rng = np.random.default_rng(100 + t)
+        m = np.asarray(w2.obs_meas)
+        w2.obs_meas = np.where(rng.random(m.shape) < 0.5, np.nextafter(m, np.inf), np.nextafter(m, -np.inf))
+        r2 = oracle_lib.solve(w2, opts, dense_prior=getattr(w2, "dense_prior", None))
+        dp = max(dp, float(np.abs(r2["pose"] - ref["pose"]).max()))
+        dc = max(dc, abs(r2["summary"].final_cost - ref["summary"].final_cost) / max(abs(ref["summary"].final_cost), 1e-300))
+        if ref["lmk"].size:
+            scale = np.maximum(1.0, np.abs(ref["lmk"]).max(axis=1))
+            dl = max(dl, float((np.abs(r2["lmk"] - ref["lmk"]).max(axis=1) / scale).max()))
+        same = same and (r2["summary"].iterations, r2["summary"].termination) == (ref["summary"].iterations, ref["summary"].termination)
+    return dp, dc, dl, same
 
 
 def _pose_prior_jtj(w, oracle_lib, pose):
