@@ -1423,7 +1423,33 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     __syncthreads();
     SADVIO_TS(3, 1);
     // pose-only factors at x: PosePriordx (K4) from their linearisation records: item = (prior, entry), one atomic each
-    for (int it = tid; it < n_pri * 28; it += blockDim.x) {
+    // A window sharded over several GPUs must come out of this kernel BIT-IDENTICAL on every rank (the ranks solve the
+    // all-reduced system redundantly and take the LM decisions independently): there the pose-only factors are added one
+    // factor at a time, plain read-modify-writes of the factor's distinct entries between barriers, instead of LDS atomics
+    // whose order depends on wave scheduling.
+    const bool det = P.world > 1;
+    if (det) {
+        for (int p = 0; p < n_pri; p++) {
+            const int fi = P.kf_fidx[P.priors[W.prior_begin + p].kf];
+            if (tid < 28) {
+                const double v = plin[p * PRIOR_LIN + tid];
+                if (tid == 27) { if (fi < 0) fixed_part += v; else cost_part += v; }
+                else if (fi >= 0) {
+                    const int base = fi * W.dpf;
+                    if (tid < 6) { y[base + tid] += v; gf[base + tid] += v; }
+                    else {
+                        const int q = tid - 6;
+                        const int a = (int)((__builtin_sqrtf((float)(8 * q + 1)) - 1.0f) * 0.5f);
+                        const int b = q - ((a * (a + 1)) >> 1);
+                        A[aidx(base + a, base + b)] += v;
+                        if (a == b) hd[base + a] += v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int it = tid; !det && it < n_pri * 28; it += blockDim.x) {
         const int p = it / 28, e = it - 28 * p;
         double v = pl_v;
         int fi = pl_fi;
@@ -1455,7 +1481,35 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         // J^T J and J^T r of the IMU factors were formed by k_imu_eval<true> together with the position of every entry in
         // this window's reduced system: one coalesced read + one LDS atomic per entry here (the products themselves,
         // with their dependent global loads, cost 16 us inside this kernel)
-        for (int it0 = tid; it0 < n_imu * 324; it0 += 8 * blockDim.x) {   // all loads of eight items in flight before the first LDS atomic
+        if (det) {
+            for (int k = 0; k < n_imu; k++) {
+                const double* row = P.imu_scratch + (long long)(W.imu_begin + k) * IMU_ROW;
+                if (tid < 324) {
+                    const int ix = (int)row[IMU_IX + tid];
+                    const double v = row[IMU_H + tid];
+                    if (ix >= 0) {
+                        const int ca = ix >> 16, cb = ix & 0xffff;
+                        if (tid < 300) { A[aidx(ca, cb)] += v; if (ca == cb) hd[ca] += v; }
+                        else { y[ca] += v; gf[ca] += v; }
+                    }
+                }
+                __syncthreads();
+                if (tid < 6) {     // bias random walk of this factor
+                    const int ax = tid % 3, gy = tid / 3;
+                    const ImuDev& f = P.imus[W.imu_begin + k];
+                    const int fi = P.kf_fidx[f.kf_i], fj = P.kf_fidx[f.kf_j];
+                    const double sgm = gy ? f.sg : f.sa;
+                    const double rb = row[IMU_J + 3 * gy + ax];
+                    const int ci = fi < 0 ? -1 : fi * 15 + 9 + 3 * gy + ax, cj = fj < 0 ? -1 : fj * 15 + 9 + 3 * gy + ax;
+                    const double s2 = sgm * sgm;
+                    if (ci >= 0) { A[aidx(ci, ci)] += s2; hd[ci] += s2; y[ci] += -sgm * rb; gf[ci] += -sgm * rb; }
+                    if (cj >= 0) { A[aidx(cj, cj)] += s2; hd[cj] += s2; y[cj] += sgm * rb; gf[cj] += sgm * rb; }
+                    if (ci >= 0 && cj >= 0) A[ci >= cj ? aidx(ci, cj) : aidx(cj, ci)] += -s2;
+                }
+                __syncthreads();
+            }
+        }
+        for (int it0 = tid; !det && it0 < n_imu * 324; it0 += 8 * blockDim.x) {   // all loads of eight items in flight before the first LDS atomic
             double ixd[8], vv[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -1482,7 +1536,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
         }
         // bias random walk: item = (factor, axis, ba|bg): Jacobians are -/+ s I
-        for (int it = tid; it < n_imu * 6; it += blockDim.x) {
+        for (int it = tid; !det && it < n_imu * 6; it += blockDim.x) {
             const int k = it / 6, e = it - 6 * k, ax = e % 3, gy = e / 3;
             const ImuDev& f = P.imus[W.imu_begin + k];
             const int fi = P.kf_fidx[f.kf_i], fj = P.kf_fidx[f.kf_j];
@@ -1514,28 +1568,37 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         }
         // items over the factors evaluated here only: a sparsified VIO prior is one IMUPriordx + hundreds of
         // pose-to-landmark factors that ride the Schur elimination (type 4) and would each cost dependent global loads
-        for (int it = tid; it < (W.spl_end - W.spl_begin) * 120; it += blockDim.x) {
+        // (sharded window: one factor at a time with plain adds, see `det` above; the 120 entries of a factor are distinct)
+        const int n_spl = W.spl_end - W.spl_begin;
+        for (int it = det ? 0 : tid; it < n_spl * 120; it += det ? 120 : (int)blockDim.x) {
             const int kl = it / 120;
             const int k = P.sp_list[W.spl_begin + kl] - W.sp_begin;
-            int e = it - 120 * kl, a = 0;
-            while (e >= a + 1) { e -= a + 1; a++; }
-            const int b = e;
-            const SparseDev& f = P.sparse[W.sp_begin + k];
-            const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
-            const int lr0 = sparse_lr0(P, W, f);
-            const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
-            const int ca = sparse_col(f, a, fi, W.dpf, lr0, lr1), cb = sparse_col(f, b, fi, W.dpf, lr0, lr1);
-            if (ca < 0 || cb < 0) continue;
-            const double* sc = P.sp_scratch + (long long)(W.sp_begin + k) * SPARSE_J;
-            const int rows = sparse_rows(f);
-            double h = 0.0;
-            for (int q = 0; q < rows; q++) h += sc[q * 15 + a] * sc[q * 15 + b];
-            atomic_add_f64(&A[ca >= cb ? aidx(ca, cb) : aidx(cb, ca)], h);
-            if (a == b) {
-                double g = 0.0;
-                for (int q = 0; q < rows; q++) g += sc[q * 15 + a] * sc[225 + q];
-                atomic_add_f64(&y[ca], g); atomic_add_f64(&gf[ca], g); atomic_add_f64(&hd[ca], h);
+            int e = det ? tid : it - 120 * kl, a = 0;
+            if (!det || tid < 120) {
+                while (e >= a + 1) { e -= a + 1; a++; }
+                const int b = e;
+                const SparseDev& f = P.sparse[W.sp_begin + k];
+                const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
+                const int lr0 = sparse_lr0(P, W, f);
+                const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
+                const int ca = sparse_col(f, a, fi, W.dpf, lr0, lr1), cb = sparse_col(f, b, fi, W.dpf, lr0, lr1);
+                if (ca >= 0 && cb >= 0) {
+                    const double* sc = P.sp_scratch + (long long)(W.sp_begin + k) * SPARSE_J;
+                    const int rows = sparse_rows(f);
+                    double h = 0.0;
+                    for (int q = 0; q < rows; q++) h += sc[q * 15 + a] * sc[q * 15 + b];
+                    double g = 0.0;
+                    if (a == b) for (int q = 0; q < rows; q++) g += sc[q * 15 + a] * sc[225 + q];
+                    if (det) {
+                        A[ca >= cb ? aidx(ca, cb) : aidx(cb, ca)] += h;
+                        if (a == b) { y[ca] += g; gf[ca] += g; hd[ca] += h; }
+                    } else {
+                        atomic_add_f64(&A[ca >= cb ? aidx(ca, cb) : aidx(cb, ca)], h);
+                        if (a == b) { atomic_add_f64(&y[ca], g); atomic_add_f64(&gf[ca], g); atomic_add_f64(&hd[ca], h); }
+                    }
+                }
             }
+            if (det) __syncthreads();
         }
     }
     // linexd observations: r, J (rows x 12 over [key-frame | line]) from k_line_eval<true>; item = (observation, lower-triangle entry)
