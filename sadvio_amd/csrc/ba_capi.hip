@@ -364,7 +364,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.trace = h->d_trace.p; P.t_start = h->d_tstart.p;
     P.states = h->d_states.p; P.acc = h->d_acc.p; P.tacc = h->d_tacc.p; P.n_tiles = (int)h->tiles.size();
     P.state_stride = state_stride;
-    P.final_out = h->d_final.p;
+    P.final_out = h->h_final ? h->h_final : h->d_final.p;   // the final records go straight to pinned host memory (device-visible): no copy after the last kernel
     P.big_info = h->d_big_info.p;
     P.world = h->world; P.rank = h->rank; P.rank_b = h->d_rank_b.p; P.rank_s = h->d_rank_s.p;
     P.lmk_red = h->d_lmk_red.p; P.kept_obs = h->d_kept_obs.p; P.n_kept = h->n_kept;
@@ -2221,8 +2221,11 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     for (int w = 0; w < n_win; w++) { dp_max_nf = std::max(dp_max_nf, h->wins[w].d.dp_n_full); dp_max_n = std::max(dp_max_n, h->wins[w].d.dp_n); }
     bool coll_failed = false;
     auto enqueue = [&]() {
-        { ScopedTimer t(h, "k_reset"); hipLaunchKernelGGL(k_reset, dim3(reset_blocks), dim3(256), 0, h->stream, P); }
-        { ScopedTimer t(h, "k_init_tables"); hipLaunchKernelGGL(k_init_tables, dim3((std::max(h->n_kf_tot, (int)h->priors.size()) + 63) / 64), dim3(64), 0, h->stream, P, h->n_kf_tot); }
+        {   // zero deltas / accumulators + initial LM state, and (extra blocks) the pose tables / prior records at x = 0
+            ScopedTimer t(h, "k_reset");
+            const int table_blocks = (std::max(h->n_kf_tot, (int)h->priors.size()) + 63) / 64;
+            hipLaunchKernelGGL(k_reset, dim3(reset_blocks + table_blocks), dim3(256), 0, h->stream, P, reset_blocks, h->n_kf_tot);
+        }
         const int n_imu_all = (int)h->imus.size();
         // IMU factors are evaluated on a side stream: the linearisation next to k_build, the candidate cost next to
         // k_backsub (fork / join with events; inside the captured graph these become parallel branches)
@@ -2470,7 +2473,6 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     }
     HIP_TRY(hipGetLastError());
     if (coll_failed) { h->err = "solve: the all-reduce of the reduced system failed"; return SADVIO_E_RCCL; }
-    HIP_TRY(hipMemcpyAsync(h->h_final, h->d_final.p, sizeof(FinalRec) * (size_t)n_win, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->cfg.profile_kernels) collect_timers(h);
     if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 4096)) {

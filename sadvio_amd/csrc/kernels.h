@@ -2245,8 +2245,17 @@ __global__ void k_rank_partials(DevPtrs P, int slot, int which) {
 
 // Start of a solve: zero the delta buffers and every accumulator, write the initial LM state of each window
 // (one launch instead of eight memsets and a host-to-device copy).
-__global__ void k_reset(DevPtrs P) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long long)gridDim.x * blockDim.x;
+__device__ __forceinline__ void init_tables_item(const DevPtrs& P, int g, int n_kf_tot);
+
+// One launch opens a solve: blocks [0, reset_blocks) zero the deltas / accumulators and write the initial LM state, the
+// blocks behind them (64 work items each) compute the pose tables and the pose priors' linearisation records at x = 0
+// (the two were separate launches: one boundary + ~4 us per solve).
+__global__ __launch_bounds__(256) void k_reset(DevPtrs P, int reset_blocks, int n_kf_tot) {
+    if ((int)blockIdx.x >= reset_blocks) {
+        if (threadIdx.x < 64) init_tables_item(P, ((int)blockIdx.x - reset_blocks) * 64 + threadIdx.x, n_kf_tot);
+        return;
+    }
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (long long)reset_blocks * blockDim.x;
     if (t == 0 && P.t_start) *P.t_start = wall_clock64();
     for (long long i = t; i < P.n_xp; i += nt) P.xp[i] = 0.0;
     for (long long i = t; i < P.n_xv; i += nt) { P.xv[i] = 0.0; P.xba[i] = 0.0; P.xbg[i] = 0.0; }
@@ -2268,8 +2277,7 @@ __global__ void k_reset(DevPtrs P) {
 }
 
 // Pose tables of delta buffer 0 at the start of a solve (all deltas zero).
-__global__ __launch_bounds__(64) void k_init_tables(DevPtrs P, int n_kf_tot) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void init_tables_item(const DevPtrs& P, int g, int n_kf_tot) {
     if (g < P.n_prior_tot) {   // linearisation records of the pose priors at x = 0 (buffer 0): see DevPtrs::prior_lin
         const PriorDev pr = P.priors[g];
         double d6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
