@@ -2112,7 +2112,13 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     DevPtrs P = make_ptrs(h, o, stride);
     const int n_tiles = (int)h->tiles.size();
     // with many tiles, re-summing all partials in every k_build workgroup costs more than one tiny launch per slot
-    P.decide_kernel = n_tiles >= 1024 ? 1 : 0;
+    // The decision of a slot is re-derived by every k_build workgroup from its OWN window's tile partials (read by all 256 threads
+    // with every load in flight: the cost does not depend on how many windows the batch has), as long as a window has at most
+    // 4 * BUILD_THREADS tiles (the canonical summation order of wave_sum_backsub_partials); a separate k_decide launch per slot
+    // only for larger windows (configs 4 / 5) and for the throughput kernels, which read the decided state.
+    int max_win_tiles = 0;
+    for (int w = 0; w < n_win; w++) max_win_tiles = std::max(max_win_tiles, h->wins[w].d.tile_end - h->wins[w].d.tile_begin);
+    P.decide_kernel = max_win_tiles > 4 * BUILD_THREADS ? 1 : 0;
     const int mtk = h->max_tile_kf;
     const size_t nt = 6 * (size_t)h->max_tile_free;
     int Rp = 16 * ((6 * h->max_gemm_free + 15) / 16);                          // padded rows of the Y / E strips
@@ -2440,7 +2446,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 ScopedTimer t(h, "allreduce_step_partials");
                 if (h->coll_fn(h->coll_ctx, h->d_rank_s.p, (int64_t)n_win * h->world * 4, (void*)h->stream) != 0) coll_failed = true;
             }
-            if (P.decide_kernel) { ScopedTimer t(h, "k_decide"); hipLaunchKernelGGL(k_decide, dim3(n_win), dim3(n_tiles / n_win >= 1024 ? 1024 : 64), 0, h->stream, P, s, 0); }
+            if (P.decide_kernel) { ScopedTimer t(h, "k_decide"); hipLaunchKernelGGL(k_decide, dim3(n_win), dim3(max_win_tiles > 4 * BUILD_THREADS ? 1024 : 64), 0, h->stream, P, s, 0); }
         }
         { ScopedTimer t(h, "k_final"); hipLaunchKernelGGL(k_decide, dim3(n_win), dim3(64), 0, h->stream, P, slots - 1, 1); }
     };
