@@ -1063,28 +1063,58 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_backsolve(const double*
     if (skip && *skip) return;
     if (*info != 0) return;
     double (*Ms)[WDS] = (double (*)[WDS])smem;
-    __shared__ double tv[WD], xd[WD];
+    __shared__ double tv[WD], xd[WD], part[4][WD];
     const int tid = threadIdx.x;
     const int nsteps = (N + WD - 1) / WD;
+    // M of a step is fetched into registers while the previous step's update streams its panel (18 loads per thread, issued
+    // before the update loop, stored to LDS behind it); the 96-long dot products of x_d = M^T t_d are split over four threads;
+    // the update keeps 24 panel rows in flight per thread instead of 8 (the kernel is one workgroup: its speed is the number
+    // of loads it keeps outstanding).
+    constexpr int MV = (WD * WD + SOLVE_THREADS - 1) / SOLVE_THREADS;
+    double mreg[MV];
+    auto fetch_m = [&](int st) {
+        const double* Mg = Mg_all + (size_t)st * WD * WD;
+#pragma unroll
+        for (int q = 0; q < MV; q++) { const int e = tid + q * SOLVE_THREADS; mreg[q] = e < WD * WD ? Mg[e] : 0.0; }
+    };
+    auto store_m = [&]() {
+#pragma unroll
+        for (int q = 0; q < MV; q++) { const int e = tid + q * SOLVE_THREADS; if (e < WD * WD) Ms[e / WD][e % WD] = mreg[q]; }
+    };
+    fetch_m(nsteps - 1);
     for (int st = nsteps - 1; st >= 0; st--) {
         const int c0 = st * WD;
         const int nr = min(WD, N - c0);
-        const double* Mg = Mg_all + (size_t)st * WD * WD;
-        for (int e = tid; e < WD * WD; e += SOLVE_THREADS) Ms[e / WD][e % WD] = Mg[e];
+        store_m();
         if (tid < WD) tv[tid] = tid < nr ? y[c0 + tid] : 0.0;
         __syncthreads();
-        if (tid < WD) {
+        if (st > 0) fetch_m(st - 1);       // in flight under the dot products and the update below
+        if (tid < 4 * WD) {
+            const int c = tid % WD, q4 = tid / WD;      // (M^T t)_c = sum_{k >= c} M[k][c] t_k, k = q4, q4 + 4, ...
             double x = 0.0;
-            for (int k = tid; k < WD; k++) x += Ms[k][tid] * tv[k];  // (M^T t)_c = sum_{k >= c} M[k][c] t_k
+            for (int k = c + ((q4 - c) & 3); k < WD; k += 4) x += Ms[k][c] * tv[k];
+            part[q4][c] = x;
+        }
+        __syncthreads();
+        if (tid < WD) {
+            const double x = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
             xd[tid] = x;
             if (tid < nr) y[c0 + tid] = x;
         }
         __syncthreads();
         for (int cc = tid; cc < c0; cc += SOLVE_THREADS) {
-            double acc = 0.0;
-#pragma unroll 8
-            for (int r = 0; r < nr; r++) acc += A[(long long)(c0 + r) * ld + cc] * xd[r];
-            y[cc] -= acc;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            const double* col = A + (long long)c0 * ld + cc;
+            int r = 0;
+            for (; r + 24 <= nr; r += 24) {
+                double v[24];
+#pragma unroll
+                for (int u = 0; u < 24; u++) v[u] = col[(long long)(r + u) * ld];
+#pragma unroll
+                for (int u = 0; u < 24; u += 3) { a0 += v[u] * xd[r + u]; a1 += v[u + 1] * xd[r + u + 1]; a2 += v[u + 2] * xd[r + u + 2]; }
+            }
+            for (; r < nr; r++) a0 += col[(long long)r * ld] * xd[r];
+            y[cc] -= (a0 + a1) + a2;
         }
         __syncthreads();
     }
