@@ -357,7 +357,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.obs_slot = h->d_obs_slot.p; P.tile_kf = h->d_tile_kf.p; P.tile_row = h->d_tile_row.p;
     P.ptab = h->d_ptab.p; P.ptab_stride = (long long)POSE_TAB * h->n_kf_tot;
     P.priors = h->d_priors.p; P.prior_lin = h->d_prior_lin.p; P.prior_lin_stride = (long long)h->priors.size() * PRIOR_LIN; P.n_prior_tot = (int)h->priors.size();
-    P.imus = h->d_imus.p; P.imu_scratch = h->d_imu_scratch.p;
+    P.imus = h->d_imus.p; P.imu_scratch = h->d_imu_scratch.p; P.imu_scratch_stride = (long long)h->imus.size() * IMU_ROW;
     P.S = h->d_S.p; P.gred = h->d_gred.p; P.gfull = h->d_gfull.p; P.hdiag = h->d_hdiag.p;
     P.delta = h->d_delta.p; P.s_pose = h->d_s_pose.p;
     P.dbg_ts = h->d_dbg.p;
@@ -589,7 +589,7 @@ int upload_priors(sadvio_ba_handle* h) {
         h->wins[w].d.imu_end = (int)h->imus.size();
     }
     HIP_TRY(h->d_imus.alloc(h->imus.size()));
-    HIP_TRY(h->d_imu_scratch.alloc(h->imus.size() * (size_t)IMU_ROW));
+    HIP_TRY(h->d_imu_scratch.alloc(2 * h->imus.size() * (size_t)IMU_ROW));
     if (!h->imus.empty())
         h->up.add(h->d_imus.p, h->imus.data(), h->imus.size() * sizeof(ImuDev));
     std::vector<WinDev> wd(h->wins.size());
@@ -2145,8 +2145,11 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     for (const auto& v : h->sp_elim) for (char e : v) any_pseudo |= e != 0;
     const bool rare = o.huber_a > 0.0 || h->n_kept > 0 || any_pseudo;
     const bool pix = h->factor_type == SADVIO_FACTOR_PIXEL;
-    auto kb = pix ? (rare ? k_build<0, true> : k_build<0, false>) : (rare ? k_build<1, true> : k_build<1, false>);
-    auto kk = pix ? (rare ? k_backsub<0, true> : k_backsub<0, false>) : (rare ? k_backsub<1, true> : k_backsub<1, false>);
+    const bool with_imu = !h->imus.empty();   // the IMU factor pairs ride k_build (linearisation) and k_backsub (candidate cost) as extra workgroups
+    auto kb = with_imu ? (pix ? (rare ? k_build<0, true, true> : k_build<0, false, true>) : (rare ? k_build<1, true, true> : k_build<1, false, true>))
+                       : (pix ? (rare ? k_build<0, true, false> : k_build<0, false, false>) : (rare ? k_build<1, true, false> : k_build<1, false, false>));
+    auto kk = with_imu ? (pix ? (rare ? k_backsub<0, true, true> : k_backsub<0, false, true>) : (rare ? k_backsub<1, true, true> : k_backsub<1, false, true>))
+                       : (pix ? (rare ? k_backsub<0, true, false> : k_backsub<0, false, false>) : (rare ? k_backsub<1, true, false> : k_backsub<1, false, false>));
     auto kbk = h->factor_type == SADVIO_FACTOR_PIXEL ? k_build_kept<0> : k_build_kept<1>;
     // large plain batches: the throughput kernels of lm_kernels.h (SADVIO_LM=1 / 0 forces / forbids them, for tests and A/B runs)
     bool use_lm = h->lm_ok && !rare && !h->coll_fn && h->world == 1 && h->lm_landmarks >= 65536;
@@ -2233,16 +2236,16 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             hipLaunchKernelGGL(k_reset, dim3(reset_blocks + table_blocks), dim3(256), 0, h->stream, P, reset_blocks, h->n_kf_tot);
         }
         const int n_imu_all = (int)h->imus.size();
-        // IMU factors are evaluated on a side stream: the linearisation next to k_build, the candidate cost next to
-        // k_backsub (fork / join with events; inside the captured graph these become parallel branches)
+        // IMU factor pairs ride the tile kernels as extra workgroups (kernels.h: imu_pair_eval). Sparse-prior and line factors are still
+        // evaluated on a side stream: the linearisation next to k_build, the candidate cost next to k_backsub (fork / join with events;
+        // parallel branches of the captured graph)
         const int n_spl = h->n_sp_list;
         const int n_lo = h->n_lobs_tot;
-        const bool fork = (n_imu_all > 0 || n_spl > 0 || n_lo > 0) && h->side && !h->cfg.profile_kernels && !h->coll_fn;
+        const bool fork = (n_spl > 0 || n_lo > 0) && h->side && !h->cfg.profile_kernels && !h->coll_fn && !getenv("SADVIO_NO_FORK");
         for (int s = 0; s < slots; s++) {
             if (fork) {
                 (void)hipEventRecord(h->ev_fork, h->stream);
                 (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
-                if (n_imu_all) hipLaunchKernelGGL(k_imu_eval<true>, dim3(n_imu_all), dim3(64), 0, h->side, P, s, 1);
                 if (n_spl) hipLaunchKernelGGL(k_sparse_eval<true>, dim3(n_spl), dim3(64), 0, h->side, P, s, 1);
                 if (n_lo) hipLaunchKernelGGL(k_line_eval<true>, dim3(n_lo), dim3(64), 0, h->side, P, s, 1);
                 (void)hipEventRecord(h->ev_lin, h->side);
@@ -2258,9 +2261,10 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 } else if (h->n_diag_segs) { ScopedTimer t(h, "k_diag"); hipLaunchKernelGGL(kdg, dim3(h->n_diag_segs), dim3(BUILD_THREADS), 0, h->stream, P, h->d_diag_segs.p, h->d_kf_lmk.p, h->d_kf_cam.p, h->d_kf_meas.p, s); }
                 { ScopedTimer t(h, "k_elim"); hipLaunchKernelGGL(ke, dim3(n_tiles), dim3(BUILD_THREADS), lds_elim, h->stream, P, s, mtk); }
                 { ScopedTimer t(h, "k_build_obs"); hipLaunchKernelGGL(kbo, dim3(n_tiles), dim3(BUILD_THREADS), lds_bobs, h->stream, P, s, mtk, Rp); }
+                if (n_imu_all) { ScopedTimer t(h, "k_imu_lin"); hipLaunchKernelGGL(k_imu_eval_lin, dim3(n_imu_all), dim3(64), 0, h->stream, P, s); }
                 if (par) (void)hipStreamWaitEvent(h->stream, h->ev_diag1, 0);
             } else
-            { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
+            { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles + n_imu_all), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
             if (h->n_kept) { ScopedTimer t(h, "k_build_kept"); hipLaunchKernelGGL(kbk, dim3((h->n_kept + 127) / 128), dim3(128), 0, h->stream, P, s); }
             if (dp_max_nf > 0) {
                 ScopedTimer t(h, "k_prior_r+gh");
@@ -2287,7 +2291,6 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             }
             if (fork) (void)hipStreamWaitEvent(h->stream, h->ev_lin, 0);
             else {
-                if (n_imu_all) { ScopedTimer t(h, "k_imu_lin"); hipLaunchKernelGGL(k_imu_eval<true>, dim3(n_imu_all), dim3(64), 0, h->stream, P, s, 0); }
                 if (n_spl) { ScopedTimer t(h, "k_sparse_lin"); hipLaunchKernelGGL(k_sparse_eval<true>, dim3(n_spl), dim3(64), 0, h->stream, P, s, 0); }
                 if (n_lo) { ScopedTimer t(h, "k_line_lin"); hipLaunchKernelGGL(k_line_eval<true>, dim3(n_lo), dim3(64), 0, h->stream, P, s, 0); }
             }
@@ -2427,19 +2430,20 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             if (fork) {
                 (void)hipEventRecord(h->ev_solved, h->stream);
                 (void)hipStreamWaitEvent(h->side, h->ev_solved, 0);
-                if (n_imu_all) hipLaunchKernelGGL(k_imu_eval<false>, dim3(n_imu_all), dim3(64), 0, h->side, P, s, 0);
                 if (n_spl) hipLaunchKernelGGL(k_sparse_eval<false>, dim3(n_spl), dim3(64), 0, h->side, P, s, 0);
                 if (n_lo) hipLaunchKernelGGL(k_line_eval<false>, dim3(n_lo), dim3(64), 0, h->side, P, s, 0);
                 (void)hipEventRecord(h->ev_cost, h->side);
             } else {
-                if (n_imu_all) { ScopedTimer t(h, "k_imu_cost"); hipLaunchKernelGGL(k_imu_eval<false>, dim3(n_imu_all), dim3(64), 0, h->stream, P, s, 0); }
                 if (n_spl) { ScopedTimer t(h, "k_sparse_cost"); hipLaunchKernelGGL(k_sparse_eval<false>, dim3(n_spl), dim3(64), 0, h->stream, P, s, 0); }
                 if (n_lo) { ScopedTimer t(h, "k_line_cost"); hipLaunchKernelGGL(k_line_eval<false>, dim3(n_lo), dim3(64), 0, h->stream, P, s, 0); }
             }
             if (dp_max_nf > 0) { ScopedTimer t(h, "k_prior_m"); hipLaunchKernelGGL(k_prior_m, dim3((dp_max_nf + 3) / 4, n_win), dim3(256), 0, h->stream, P, s); }
-            if (use_lm) { ScopedTimer t(h, "k_backsub_lm"); hipLaunchKernelGGL(kkl, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
+            if (use_lm) {
+                if (n_imu_all) { ScopedTimer t(h, "k_imu_cost"); hipLaunchKernelGGL(k_imu_eval_cost, dim3(n_imu_all), dim3(64), 0, h->stream, P, s); }
+                ScopedTimer t(h, "k_backsub_lm"); hipLaunchKernelGGL(kkl, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk);
+            }
             else
-            { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
+            { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles + n_imu_all), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
             if (fork) (void)hipStreamWaitEvent(h->stream, h->ev_cost, 0);
             if (h->coll_fn) {
                 { ScopedTimer t(h, "k_rank_partials"); hipLaunchKernelGGL(k_rank_partials, dim3(n_win), dim3(64), 0, h->stream, P, s, 1); }

@@ -113,11 +113,17 @@ struct LineObsDev {
 constexpr int LINE_ROW = 4 * 12 + 4 + 2;  // scratch row of one line observation: J (rows x 12) | r | rho | in-program flag
 constexpr int SPARSE_J = 15 * 15 + 15 + 2;  // J (rows x 15) + r + in-program flag kept in HBM scratch between phases
 constexpr int IMU_J = 9 * 24 + 9;  // whitened Jacobian + residual kept in HBM scratch between phases
-// scratch row of one IMU factor: J 216 | r 9 | bias residuals 6 | H = J^T J (lower, 300) | g = J^T r (24) | target of each H / g
-// entry in the window's reduced system ((row << 16) | col, or -1) as doubles (324), all written by k_imu_eval<true>
+// scratch row of one IMU factor, all written by k_imu_eval<true>: J 216 | r 9 | bias residuals 6 | IMU_NE entry values | IMU_NE entry
+// targets | fi, fj, sa, sg. The entries are what the factor pair (IMUFactor + IMUBiasFactor) adds to the window's reduced system:
+// H = J^T J (lower, 300) | g = J^T r (24) | bias random walk: 18 matrix entries, 12 gradient entries | the pair's squared residual
+// sum (1). Target of a matrix entry: (row << 16) | col; of a gradient entry: row << 16; -1 = not in the system (constant
+// key-frame); cost entry: -2 = fixed cost (both key-frames constant), -3 = cost. Stored as doubles.
+constexpr int IMU_NE = 355;
+constexpr int IMU_E_G = 300, IMU_E_BH = 324, IMU_E_BG = 342, IMU_E_COST = 354;
 constexpr int IMU_H = IMU_J + 6;
-constexpr int IMU_IX = IMU_H + 324;
-constexpr int IMU_ROW = IMU_IX + 324;
+constexpr int IMU_IX = IMU_H + IMU_NE;
+constexpr int IMU_META = IMU_IX + IMU_NE;
+constexpr int IMU_ROW = IMU_META + 5;
 
 // Levenberg-Marquardt control state at the beginning of a slot (one step attempt).
 struct LmState {

@@ -42,7 +42,8 @@ struct DevPtrs {
     long long prior_lin_stride;     // each delta buffer: written at x = 0 by k_init_tables, at the candidate by k_solve's back half
     int n_prior_tot;
     const ImuDev* imus;
-    double* imu_scratch;  // [n_imu_tot][IMU_ROW], see ba_types.h
+    double* imu_scratch;  // [2][n_imu_tot][IMU_ROW], see ba_types.h: the linearisation of every IMU factor pair at the deltas of buffer 0 | 1
+    long long imu_scratch_stride;
     double* S; double* gred; double* gfull; double* hdiag; double* delta; double* s_pose;
     LmState* states;  // [n_win][slots+2]
     IterAcc* acc;     // [n_win][slots+1] window totals (written by single workgroups only)
@@ -477,9 +478,16 @@ __host__ __device__ inline size_t tile_tables_bytes(int n_kf) {
 }
 
 // ---- K5: build the reduced system ----------------------------------------------------------------
-template <int FACTOR, bool RARE>
-__global__ __launch_bounds__(BUILD_THREADS, 2) void k_build(DevPtrs P, int slot, int max_tile_kf, int strip_doubles, int Rp) {
+// IMU = true (windows with IMU factors): the workgroups behind the tiles linearise one IMU factor pair each (imu_pair_eval<false>,
+// one wave; its 500 registers leave one workgroup per CU, which is what a single window runs at anyway).
+template <bool COST_ONLY> __device__ __forceinline__ void imu_pair_eval(const DevPtrs& P, int slot, int k, int ln);   // below
+template <int FACTOR, bool RARE, bool IMU>
+__global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P, int slot, int max_tile_kf, int strip_doubles, int Rp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (IMU && (int)blockIdx.x >= P.n_tiles) {
+        if (threadIdx.x < 64) imu_pair_eval<false>(P, slot, (int)blockIdx.x - P.n_tiles, threadIdx.x);
+        return;
+    }
     const Tile T = P.tiles[blockIdx.x];
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
     SADVIO_TS(3, 32);
@@ -1364,7 +1372,29 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     }
     double* sp = P.s_pose + W.red_off;
     double c_sp = 1.0;
+    // A window sharded over several GPUs must come out of this kernel BIT-IDENTICAL on every rank (the ranks solve the
+    // all-reduced system redundantly and take the LM decisions independently): there the pose-only factors are added one
+    // factor at a time, plain read-modify-writes of the factor's distinct entries between barriers, instead of LDS atomics
+    // whose order depends on wave scheduling.
+    const bool det = P.world > 1;
     if (MODE != 2) {
+    // IMUFactor + IMUBiasFactor (K3): k_imu_eval<true> (one 64-lane workgroup per factor, beside k_build) left every entry the
+    // pair adds to the reduced system, with its position, in the factor's scratch row (ba_types.h). Item = (factor, entry); the
+    // first eight items of every thread are fetched here, with the image
+    double im_ix[8], im_v[8];
+    const int n_imu_items = (EXTRAS && !det) ? n_imu * IMU_NE : 0;
+    if (EXTRAS) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int it = tid + u * (int)blockDim.x;
+            im_ix[u] = -1.0; im_v[u] = 0.0;
+            if (it < n_imu_items) {
+                const int k = it / IMU_NE, e = it - IMU_NE * k;
+                const double* row = P.imu_scratch + (long long)cur * P.imu_scratch_stride + (long long)(W.imu_begin + k) * IMU_ROW;
+                im_ix[u] = row[IMU_IX + e]; im_v[u] = row[IMU_H + e];
+            }
+        }
+    }
     if (!BIG) {
         // the image: a linear, fully coalesced 16-byte copy (S is kept in HBM in the layout it has in LDS); a wave-instruction
         // moves 64 consecutive double2 to a wave-uniform LDS base + lane * 16
@@ -1423,11 +1453,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     __syncthreads();
     SADVIO_TS(3, 1);
     // pose-only factors at x: PosePriordx (K4) from their linearisation records: item = (prior, entry), one atomic each
-    // A window sharded over several GPUs must come out of this kernel BIT-IDENTICAL on every rank (the ranks solve the
-    // all-reduced system redundantly and take the LM decisions independently): there the pose-only factors are added one
-    // factor at a time, plain read-modify-writes of the factor's distinct entries between barriers, instead of LDS atomics
-    // whose order depends on wave scheduling.
-    const bool det = P.world > 1;
     if (det) {
         for (int p = 0; p < n_pri; p++) {
             const int fi = P.kf_fidx[P.priors[W.prior_begin + p].kf];
@@ -1466,87 +1491,63 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             if (a == b) atomic_add_f64(&hd[base + a], v);
         }
     }
-    // IMUFactor + IMUBiasFactor (K3): k_imu_eval<true> (one 64-lane workgroup per factor, launched between k_build and
-    // this kernel) left r, the whitened 9x24 Jacobian and the bias residuals in the HBM scratch row; here the costs are
-    // summed and the J^T J accumulation is spread over all threads (LDS atomics into A).
     if (EXTRAS && n_imu > 0) {
-        for (int k = tid; k < n_imu; k += blockDim.x) {
-            const ImuDev& f = P.imus[W.imu_begin + k];
-            const double* sc = P.imu_scratch + (long long)(W.imu_begin + k) * IMU_ROW;
-            double c = 0.0;
-            for (int q = 0; q < 9; q++) c += sc[9 * 24 + q] * sc[9 * 24 + q];
-            for (int q = 0; q < 6; q++) c += sc[IMU_J + q] * sc[IMU_J + q];
-            if (P.kf_fidx[f.kf_i] < 0 && P.kf_fidx[f.kf_j] < 0) fixed_part += c; else cost_part += c;
-        }
-        // J^T J and J^T r of the IMU factors were formed by k_imu_eval<true> together with the position of every entry in
-        // this window's reduced system: one coalesced read + one LDS atomic per entry here (the products themselves,
-        // with their dependent global loads, cost 16 us inside this kernel)
         if (det) {
+            for (int k = tid; k < n_imu; k += blockDim.x) {
+                const double* row = P.imu_scratch + (long long)cur * P.imu_scratch_stride + (long long)(W.imu_begin + k) * IMU_ROW;
+                if (row[IMU_IX + IMU_E_COST] == -2.0) fixed_part += row[IMU_H + IMU_E_COST]; else cost_part += row[IMU_H + IMU_E_COST];
+            }
             for (int k = 0; k < n_imu; k++) {
-                const double* row = P.imu_scratch + (long long)(W.imu_begin + k) * IMU_ROW;
-                if (tid < 324) {
+                const double* row = P.imu_scratch + (long long)cur * P.imu_scratch_stride + (long long)(W.imu_begin + k) * IMU_ROW;
+                if (tid < IMU_E_BH) {
                     const int ix = (int)row[IMU_IX + tid];
                     const double v = row[IMU_H + tid];
                     if (ix >= 0) {
                         const int ca = ix >> 16, cb = ix & 0xffff;
-                        if (tid < 300) { A[aidx(ca, cb)] += v; if (ca == cb) hd[ca] += v; }
+                        if (tid < IMU_E_G) { A[aidx(ca, cb)] += v; if (ca == cb) hd[ca] += v; }
                         else { y[ca] += v; gf[ca] += v; }
                     }
                 }
                 __syncthreads();
-                if (tid < 6) {     // bias random walk of this factor
-                    const int ax = tid % 3, gy = tid / 3;
-                    const ImuDev& f = P.imus[W.imu_begin + k];
-                    const int fi = P.kf_fidx[f.kf_i], fj = P.kf_fidx[f.kf_j];
-                    const double sgm = gy ? f.sg : f.sa;
-                    const double rb = row[IMU_J + 3 * gy + ax];
-                    const int ci = fi < 0 ? -1 : fi * 15 + 9 + 3 * gy + ax, cj = fj < 0 ? -1 : fj * 15 + 9 + 3 * gy + ax;
-                    const double s2 = sgm * sgm;
-                    if (ci >= 0) { A[aidx(ci, ci)] += s2; hd[ci] += s2; y[ci] += -sgm * rb; gf[ci] += -sgm * rb; }
-                    if (cj >= 0) { A[aidx(cj, cj)] += s2; hd[cj] += s2; y[cj] += sgm * rb; gf[cj] += sgm * rb; }
-                    if (ci >= 0 && cj >= 0) A[ci >= cj ? aidx(ci, cj) : aidx(cj, ci)] += -s2;
+                if (tid >= IMU_E_BH && tid < IMU_E_COST) {     // bias random walk of this factor (30 distinct targets)
+                    const int ix = (int)row[IMU_IX + tid];
+                    const double v = row[IMU_H + tid];
+                    if (ix >= 0) {
+                        const int ca = ix >> 16, cb = ix & 0xffff;
+                        if (tid < IMU_E_BG) { A[aidx(ca, cb)] += v; if (ca == cb) hd[ca] += v; }
+                        else { y[ca] += v; gf[ca] += v; }
+                    }
                 }
                 __syncthreads();
             }
         }
-        for (int it0 = tid; !det && it0 < n_imu * 324; it0 += 8 * blockDim.x) {   // all loads of eight items in flight before the first LDS atomic
-            double ixd[8], vv[8];
+        for (int it0 = tid; it0 < n_imu_items; it0 += 8 * blockDim.x) {   // all loads of eight items in flight before the first LDS atomic
+            if (it0 != tid) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int it = it0 + u * blockDim.x;
-                ixd[u] = -1.0; vv[u] = 0.0;
-                if (it < n_imu * 324) {
-                    const int k = it / 324, e = it - 324 * k;
-                    const double* row = P.imu_scratch + (long long)(W.imu_begin + k) * IMU_ROW;
-                    ixd[u] = row[IMU_IX + e]; vv[u] = row[IMU_H + e];
+                for (int u = 0; u < 8; u++) {
+                    const int it = it0 + u * (int)blockDim.x;
+                    im_ix[u] = -1.0; im_v[u] = 0.0;
+                    if (it < n_imu_items) {
+                        const int k = it / IMU_NE, e = it - IMU_NE * k;
+                        const double* row = P.imu_scratch + (long long)cur * P.imu_scratch_stride + (long long)(W.imu_begin + k) * IMU_ROW;
+                        im_ix[u] = row[IMU_IX + e]; im_v[u] = row[IMU_H + e];
+                    }
                 }
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int it = it0 + u * blockDim.x;
-                const int ix = (int)ixd[u];
-                if (ix < 0) continue;
-                const int e = it % 324;
-                const double v = vv[u];
+                const int it = it0 + u * (int)blockDim.x;
+                const int ix = (int)im_ix[u];
+                if (ix == -1) continue;
+                const int e = it % IMU_NE;
+                const double v = im_v[u];
+                if (e == IMU_E_COST) { if (ix == -2) fixed_part += v; else cost_part += v; continue; }
                 const int ca = ix >> 16, cb = ix & 0xffff;
-                if (e < 300) {
+                if (e < IMU_E_G || (e >= IMU_E_BH && e < IMU_E_BG)) {
                     atomic_add_f64(&A[aidx(ca, cb)], v);
                     if (ca == cb) atomic_add_f64(&hd[ca], v);
                 } else { atomic_add_f64(&y[ca], v); atomic_add_f64(&gf[ca], v); }
             }
-        }
-        // bias random walk: item = (factor, axis, ba|bg): Jacobians are -/+ s I
-        for (int it = tid; !det && it < n_imu * 6; it += blockDim.x) {
-            const int k = it / 6, e = it - 6 * k, ax = e % 3, gy = e / 3;
-            const ImuDev& f = P.imus[W.imu_begin + k];
-            const int fi = P.kf_fidx[f.kf_i], fj = P.kf_fidx[f.kf_j];
-            const double sgm = gy ? f.sg : f.sa;
-            const double rb = P.imu_scratch[(long long)(W.imu_begin + k) * IMU_ROW + IMU_J + 3 * gy + ax];
-            const int ci = fi < 0 ? -1 : fi * 15 + 9 + 3 * gy + ax, cj = fj < 0 ? -1 : fj * 15 + 9 + 3 * gy + ax;
-            const double s2 = sgm * sgm;
-            if (ci >= 0) { atomic_add_f64(&A[aidx(ci, ci)], s2); atomic_add_f64(&hd[ci], s2); atomic_add_f64(&y[ci], -sgm * rb); atomic_add_f64(&gf[ci], -sgm * rb); }
-            if (cj >= 0) { atomic_add_f64(&A[aidx(cj, cj)], s2); atomic_add_f64(&hd[cj], s2); atomic_add_f64(&y[cj], sgm * rb); atomic_add_f64(&gf[cj], sgm * rb); }
-            if (ci >= 0 && cj >= 0) atomic_add_f64(&A[ci >= cj ? aidx(ci, cj) : aidx(cj, ci)], -s2);
         }
     }
     // sparse (NFR) prior factors: one thread per factor evaluates r, J into an HBM scratch row, then the J^T J
@@ -1740,6 +1741,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         const double* kc = kfc + (pre ? k : 0) * 20;
         int fi = pre ? (int)kc[0] : P.kf_fidx[g];
         double d6[6], tab[POSE_TAB], T0r[12];
+        double vbb[9];                          // v, ba, bg at x: fetched before the table is computed
+        if (W.dpf == 15) {
+            const double* xs3[3] = {P.xv + (long long)cur * P.xv_stride, P.xba + (long long)cur * P.xv_stride, P.xbg + (long long)cur * P.xv_stride};
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) vbb[3 * q + i] = xs3[q][3 * (long long)g + i];
+        }
 #pragma unroll
         for (int i = 0; i < 12; i++) T0r[i] = pre ? kc[7 + i] : P.kf_T0[12 * (long long)g + i];
 #pragma unroll
@@ -1756,16 +1765,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             for (int i = 0; i < POSE_TAB; i++) dst[i] = tab[i];
         }
         if (W.dpf == 15) {
-            double* xs[3] = {P.xv, P.xba, P.xbg};
-            for (int q = 0; q < 3; q++) {
-                const double* src = xs[q] + (long long)cur * P.xv_stride;
-                double* dst = xs[q] + (long long)(1 - cur) * P.xv_stride;
+            double* xs3[3] = {P.xv + (long long)(1 - cur) * P.xv_stride, P.xba + (long long)(1 - cur) * P.xv_stride, P.xbg + (long long)(1 - cur) * P.xv_stride};
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
                 for (int i = 0; i < 3; i++) {
-                    double v = src[3 * (long long)g + i] + (fi < 0 ? 0.0 : y[fi * 15 + 6 + 3 * q + i]);
-                    dst[3 * (long long)g + i] = v;
+                    const double v = vbb[3 * q + i] + (fi < 0 ? 0.0 : y[fi * 15 + 6 + 3 * q + i]);
+                    xs3[q][3 * (long long)g + i] = v;
                     if (fi >= 0) cn += v * v;
                 }
-            }
         }
     }
     if (EXTRAS && W.line_end > W.line_begin) {
@@ -1811,23 +1819,28 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         const double* xv = P.xv + (long long)cur * P.xv_stride;
         const double* xba = P.xba + (long long)cur * P.xv_stride;
         const double* xbg = P.xbg + (long long)cur * P.xv_stride;
-        // model cost change, item = (factor, residual row); y holds delta
-        for (int it = tid; it < n_imu * 15; it += blockDim.x) {
+        // model cost change, item = (factor, residual row); y holds delta. Dealt from the second wave upwards: the first one is
+        // busy with the candidate poses above, the last one with the priors. Everything an item needs is in the scratch row.
+        const int t0 = blockDim.x > 128 ? 64 : 0;
+        for (int it = tid - t0; it >= 0 && it < n_imu * 15; it += blockDim.x - t0) {
             const int k = it / 15, q = it - 15 * k;
-            const ImuDev& f = P.imus[W.imu_begin + k];
-            const int fi = P.kf_fidx[f.kf_i], fj = P.kf_fidx[f.kf_j];
+            const double* sc = P.imu_scratch + (long long)cur * P.imu_scratch_stride + (long long)(W.imu_begin + k) * IMU_ROW;
+            const int fi = (int)sc[IMU_META], fj = (int)sc[IMU_META + 1];
             if (fi < 0 && fj < 0) continue;
-            const double* sc = P.imu_scratch + (long long)(W.imu_begin + k) * IMU_ROW;
             double m = 0.0, r;
             if (q < 9) {
-                for (int a = 0; a < 24; a++) { const int ca = imu_col(a, fi, fj); if (ca >= 0) m += sc[q * 24 + a] * y[ca]; }
+                double jr[24];
+#pragma unroll
+                for (int a = 0; a < 24; a++) jr[a] = sc[q * 24 + a];
                 r = sc[9 * 24 + q];
+#pragma unroll
+                for (int a = 0; a < 24; a++) { const int ca = imu_col(a, fi, fj); if (ca >= 0) m += jr[a] * y[ca]; }
             } else {
                 const int e = q - 9, ax = e % 3, gy = e / 3;
-                const double sgm = gy ? f.sg : f.sa;
+                const double sgm = sc[IMU_META + 2 + gy];
+                r = sc[IMU_J + e];
                 if (fi >= 0) m -= sgm * y[fi * 15 + 9 + 3 * gy + ax];
                 if (fj >= 0) m += sgm * y[fj * 15 + 9 + 3 * gy + ax];
-                r = sc[IMU_J + e];
             }
             mcc += -m * (r + 0.5 * m);
         }
@@ -1907,9 +1920,15 @@ __device__ __forceinline__ void zero_s_slice(const DevPtrs& P, const Tile& T, in
 }
 
 // ---- K7: back-substitution + candidate cost -------------------------------------------------------
-template <int FACTOR, bool RARE>
+// IMU = true (windows with IMU factors): the workgroups behind the tiles evaluate the cost of one IMU factor pair each at the
+// candidate (imu_pair_eval<true>: one wave, beside the tiles instead of behind them on the stream).
+template <int FACTOR, bool RARE, bool IMU>
 __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, int max_tile_kf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (IMU && (int)blockIdx.x >= P.n_tiles) {
+        if (threadIdx.x < 64) imu_pair_eval<true>(P, slot, (int)blockIdx.x - P.n_tiles, threadIdx.x);
+        return;
+    }
     const Tile T = P.tiles[blockIdx.x];
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
     const LmState st = P.states[(long long)T.w * P.state_stride + slot];
@@ -2336,16 +2355,20 @@ __global__ void k_decide(DevPtrs P, int slot, int final) {
     }
 }
 
-// IMUFactor + IMUBiasFactor of one key-frame pair (residuals.hpp:133-300), one 64-lane workgroup per factor: inside
+// IMUFactor + IMUBiasFactor of one key-frame pair (residuals.hpp:133-300), evaluated by ONE WAVE per pair: inside
 // k_solve (512 threads, 128 VGPRs) this code lived in scratch memory and cost 49 us + 21 us per LM step on a 12-KF
 // window; here the body is inlined and stays in registers.
-//   LIN = true  (between k_build and k_solve): r, bias residuals and the whitened 9x24 Jacobian at x into the scratch row
-//   LIN = false (after k_solve): residuals at the candidate x + delta, their squared sum added to the slot's cand_cost
-// own_decide: the kernel runs on a side stream concurrently with k_build, so (like every k_build workgroup) it takes the
-// accept / reject decision of the previous slot itself instead of reading the state k_build publishes.
-template <bool LIN>
-__global__ __launch_bounds__(64) void k_imu_eval(DevPtrs P, int slot, int own_decide) {
-    const int k = blockIdx.x, ln = threadIdx.x;
+// What the pair adds to the reduced system (r, the whitened 9x24 Jacobian, J^T J, J^T r, the bias random walk, the cost: the
+// scratch row of ba_types.h) is kept per delta buffer, like the pose priors' records (DevPtrs::prior_lin). No kernel of its
+// own and no second stream inside the LM loop - a fork / join through a side stream was measured at the price of running the
+// evaluation serially (~28 us per step) - the pairs ride the two tile kernels as extra workgroups:
+//   COST_ONLY = true  (k_backsub, slot s): the pair's cost at the candidate x + delta, added to the slot's cand_cost
+//   COST_ONLY = false (k_build, slot s)  : the linearisation at the candidate of slot s - 1 (buffer 1 - cur; at x = 0 for slot 0)
+//                 BESIDE the tiles that take that slot's accept / reject decision: it is what k_solve reads if the step was
+//                 accepted; a rejected step leaves the row of x (the other buffer) untouched.
+template <bool COST_ONLY>
+__device__ __forceinline__ void imu_pair_eval(const DevPtrs& P, int slot, int k, int ln) {
+    constexpr bool LIN = !COST_ONLY;
     // the factor's constants (1.2 KB) come in with one coalesced copy: lane 0 evaluating the factor from global memory spends its
     // time on ~200 dependent scalar loads
     __shared__ ImuDev f;
@@ -2354,30 +2377,22 @@ __global__ __launch_bounds__(64) void k_imu_eval(DevPtrs P, int slot, int own_de
         unsigned long long* dst = (unsigned long long*)&f;
         for (int i = ln; i < (int)(sizeof(ImuDev) / 8); i += 64) dst[i] = src[i];
     }
-    __syncthreads();
-    const long long so = (long long)f.win * P.state_stride + slot;
-    LmState st;
-    if (LIN && own_decide && slot > 0 && !P.decide_kernel) {
-        __shared__ double s4[4];
-        const WinDev& W = P.win[f.win];
-        wave_sum_backsub_partials(P, (slot - 1) & 1, f.win, W.tile_begin, W.tile_end - W.tile_begin, ln, s4);
-        __syncthreads();
-        IterAcc a = P.acc[so - 1];
-        a.cand_cost += s4[0]; a.mcc += s4[1]; a.step_norm2 += s4[2]; a.cand_norm2 += s4[3];
-        st = lm_decide(P.states[so - 1], a, P.o);
-    } else st = P.states[so];
+    wave_lds_fence();
+    const bool at_x = LIN && slot == 0;
+    const long long so = (long long)f.win * P.state_stride + (LIN && slot > 0 ? slot - 1 : slot);
+    const LmState st = P.states[so];
     if (st.done) return;
     const int i = f.kf_i, j = f.kf_j;
     const bool all_const = P.kf_fidx[i] < 0 && P.kf_fidx[j] < 0;
-    if (!LIN && all_const) return;
-    const int buf = LIN ? st.cur : 1 - st.cur;
+    if (COST_ONLY && all_const) return;
+    const int buf = at_x ? st.cur : 1 - st.cur;
     const double* xp = P.xp + (long long)buf * P.xp_stride;
     const double* xv = P.xv + (long long)buf * P.xv_stride;
     const double* xba = P.xba + (long long)buf * P.xv_stride;
     const double* xbg = P.xbg + (long long)buf * P.xv_stride;
     __shared__ double U[9 * 24];
-    __shared__ double rs[9];
-    double* sc = P.imu_scratch + (long long)k * IMU_ROW;
+    __shared__ double rs[9], rbs[6], s_cost;
+    double* sc = P.imu_scratch + (long long)buf * P.imu_scratch_stride + (long long)k * IMU_ROW;
     if (ln == 0) {
         double dpi[6], dpj[6], r[9];
         for (int q = 0; q < 6; q++) { dpi[q] = xp[6 * (long long)i + q]; dpj[q] = xp[6 * (long long)j + q]; }
@@ -2386,57 +2401,89 @@ __global__ __launch_bounds__(64) void k_imu_eval(DevPtrs P, int slot, int own_de
                                        xba + 3 * (long long)i, xbg + 3 * (long long)i, r, (LIN && !all_const) ? U : nullptr);
         double c = 0.0;
         for (int q = 0; q < 9; q++) { if (LIN) { sc[9 * 24 + q] = r[q]; rs[q] = r[q]; } c += r[q] * r[q]; }
+        double rba[3], rbg[3];
         for (int q = 0; q < 3; q++) {
-            const double rb_a = f.sa * (P.kf_ba[3 * (long long)j + q] + xba[3 * (long long)j + q] - P.kf_ba[3 * (long long)i + q] - xba[3 * (long long)i + q]);
-            const double rb_g = f.sg * (P.kf_bg[3 * (long long)j + q] + xbg[3 * (long long)j + q] - P.kf_bg[3 * (long long)i + q] - xbg[3 * (long long)i + q]);
-            if (LIN) { sc[IMU_J + q] = rb_a; sc[IMU_J + 3 + q] = rb_g; }
-            c += rb_a * rb_a + rb_g * rb_g;
+            rba[q] = f.sa * (P.kf_ba[3 * (long long)j + q] + xba[3 * (long long)j + q] - P.kf_ba[3 * (long long)i + q] - xba[3 * (long long)i + q]);
+            rbg[q] = f.sg * (P.kf_bg[3 * (long long)j + q] + xbg[3 * (long long)j + q] - P.kf_bg[3 * (long long)i + q] - xbg[3 * (long long)i + q]);
+            if (LIN) { sc[IMU_J + q] = rba[q]; sc[IMU_J + 3 + q] = rbg[q]; rbs[q] = rba[q]; rbs[3 + q] = rbg[q]; }
         }
-        if (!LIN) atomic_add_f64(&P.acc[so].cand_cost, c);
+        for (int q = 0; q < 3; q++) c += rba[q] * rba[q];
+        for (int q = 0; q < 3; q++) c += rbg[q] * rbg[q];
+        s_cost = c;
+        if (COST_ONLY) atomic_add_f64(&P.acc[so].cand_cost, c);
     }
-    if (LIN && all_const) {   // nothing of this factor enters the reduced system (its cost is part of the fixed cost)
-        for (int e = ln; e < 324; e += 64) sc[IMU_IX + e] = -1.0;
+    if (COST_ONLY) return;
+    wave_lds_fence();
+    const int fi = P.kf_fidx[i], fj = P.kf_fidx[j];
+    // the pair's cost, the bias random walk (Jacobians -/+ s I: entries s^2, -s^2 and -/+ s r) and what k_solve's model-cost pass reads
+    if (ln < 30) {
+        const int e = ln < 18 ? ln : ln - 18;                 // matrix entries 0..17 = (combo, kind 0..2); gradient 0..11 = (combo, i | j)
+        const int combo = ln < 18 ? e / 3 : e / 2, kind = ln < 18 ? e % 3 : e % 2;
+        const int ax = combo % 3, gy = combo / 3;
+        const double sgm = gy ? f.sg : f.sa, s2 = sgm * sgm;
+        const int ci = fi < 0 ? -1 : fi * 15 + 9 + 3 * gy + ax, cj = fj < 0 ? -1 : fj * 15 + 9 + 3 * gy + ax;
+        double v; int ix = -1;
+        if (ln < 18) {
+            if (kind == 0) { v = s2; if (ci >= 0) ix = (ci << 16) | ci; }
+            else if (kind == 1) { v = s2; if (cj >= 0) ix = (cj << 16) | cj; }
+            else { v = -s2; if (ci >= 0 && cj >= 0) ix = ci >= cj ? (ci << 16) | cj : (cj << 16) | ci; }
+            sc[IMU_H + IMU_E_BH + e] = v; sc[IMU_IX + IMU_E_BH + e] = (double)ix;
+        } else {
+            const double rb = rbs[3 * gy + ax];
+            if (kind == 0) { v = -sgm * rb; if (ci >= 0) ix = ci << 16; }
+            else { v = sgm * rb; if (cj >= 0) ix = cj << 16; }
+            sc[IMU_H + IMU_E_BG + e] = v; sc[IMU_IX + IMU_E_BG + e] = (double)ix;
+        }
+    } else if (ln == 30) {
+        sc[IMU_H + IMU_E_COST] = s_cost; sc[IMU_IX + IMU_E_COST] = all_const ? -2.0 : -3.0;
+    } else if (ln == 31) {
+        sc[IMU_META] = (double)fi; sc[IMU_META + 1] = (double)fj; sc[IMU_META + 2] = f.sa; sc[IMU_META + 3] = f.sg;
     }
-    if (LIN && !all_const) {
-        __syncthreads();
-        if (ln < 24) {   // J <- W J, one column per lane (kept in LDS for the products below)
-            double u[9];
+    if (all_const) {   // nothing of this factor enters the reduced system (its cost is part of the fixed cost)
+        for (int e = ln; e < IMU_E_BH; e += 64) sc[IMU_IX + e] = -1.0;
+        return;
+    }
+    if (ln < 24) {   // J <- W J, one column per lane (kept in LDS for the products below)
+        double u[9];
 #pragma unroll
-            for (int q = 0; q < 9; q++) u[q] = U[q * 24 + ln];
+        for (int q = 0; q < 9; q++) u[q] = U[q * 24 + ln];
 #pragma unroll
-            for (int q = 0; q < 9; q++) {
-                double s = 0.0;
+        for (int q = 0; q < 9; q++) {
+            double s = 0.0;
 #pragma unroll
-                for (int kk = q; kk < 9; kk++) s += f.W[9 * q + kk] * u[kk];   // W is upper triangular (L^T)
-                sc[q * 24 + ln] = s;
-                U[q * 24 + ln] = s;
-            }
+            for (int kk = q; kk < 9; kk++) s += f.W[9 * q + kk] * u[kk];   // W is upper triangular (L^T)
+            sc[q * 24 + ln] = s;
+            U[q * 24 + ln] = s;
         }
-        __syncthreads();
-        // H = J^T J (lower triangle, 300), g = J^T r (24) and where each entry goes in the reduced system
-        const int fi = P.kf_fidx[i], fj = P.kf_fidx[j];
-        for (int e = ln; e < 324; e += 64) {
-            double v = 0.0;
-            int ix = -1;
-            if (e < 300) {
-                int a = 0, b = e;
-                while (b >= a + 1) { b -= a + 1; a++; }
+    }
+    wave_lds_fence();
+    // H = J^T J (lower triangle, 300), g = J^T r (24) and where each entry goes in the reduced system
+    for (int e = ln; e < IMU_E_BH; e += 64) {
+        double v = 0.0;
+        int ix = -1;
+        if (e < IMU_E_G) {
+            int a = 0, b = e;
+            while (b >= a + 1) { b -= a + 1; a++; }
 #pragma unroll
-                for (int q = 0; q < 9; q++) v += U[q * 24 + a] * U[q * 24 + b];
-                const int ca = imu_col(a, fi, fj), cb = imu_col(b, fi, fj);
-                if (ca >= 0 && cb >= 0) ix = ca >= cb ? (ca << 16) | cb : (cb << 16) | ca;
-            } else {
-                const int a = e - 300;
+            for (int q = 0; q < 9; q++) v += U[q * 24 + a] * U[q * 24 + b];
+            const int ca = imu_col(a, fi, fj), cb = imu_col(b, fi, fj);
+            if (ca >= 0 && cb >= 0) ix = ca >= cb ? (ca << 16) | cb : (cb << 16) | ca;
+        } else {
+            const int a = e - IMU_E_G;
 #pragma unroll
-                for (int q = 0; q < 9; q++) v += U[q * 24 + a] * rs[q];
-                const int ca = imu_col(a, fi, fj);
-                if (ca >= 0) ix = ca << 16;
-            }
-            sc[IMU_H + e] = v;
-            sc[IMU_IX + e] = (double)ix;
+            for (int q = 0; q < 9; q++) v += U[q * 24 + a] * rs[q];
+            const int ca = imu_col(a, fi, fj);
+            if (ca >= 0) ix = ca << 16;
         }
+        sc[IMU_H + e] = v;
+        sc[IMU_IX + e] = (double)ix;
     }
 }
+
+// the same as kernels of their own (one 64-lane workgroup per pair): large batches on the throughput kernels, whose tile kernels carry
+// no extra workgroups
+__global__ __launch_bounds__(64) void k_imu_eval_lin(DevPtrs P, int slot) { imu_pair_eval<false>(P, slot, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void k_imu_eval_cost(DevPtrs P, int slot) { imu_pair_eval<true>(P, slot, blockIdx.x, threadIdx.x); }
 
 // Sparse prior factors that the solve evaluates itself (IMUPriordx, landmark priors / chains), one 64-lane workgroup per
 // listed factor, same split as k_imu_eval: LIN -> r, J into the scratch row at x; !LIN -> cost at the candidate
