@@ -237,7 +237,8 @@ struct sadvio_ba_handle {
     int n_line_tot = 0, n_lobs_tot = 0;
     DevBuf<SparseDev> d_sparse;
     DevBuf<int> d_sp_list;
-    int n_sp_list = 0;   // sparse prior factors evaluated by k_sparse_eval (all windows)
+    int n_sp_list = 0;   // sparse prior factors evaluated by sparse_factor_eval (all windows)
+    size_t n_sparse_tot = 0;
     DevBuf<double> d_sp_scratch;
     std::vector<unsigned char> h_lmk_const_user;  // as given by the caller
     std::vector<int> h_lmk_ob, h_lmk_oe, h_kf_fidx, h_obs_kf;
@@ -370,6 +371,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.lmk_red = h->d_lmk_red.p; P.kept_obs = h->d_kept_obs.p; P.n_kept = h->n_kept;
     P.dp_data = h->d_dp_data.p; P.dp_ints = h->d_dp_ints.p;
     P.sparse = h->d_sparse.p; P.sp_scratch = h->d_sp_scratch.p; P.sp_list = h->d_sp_list.p;
+    P.sp_scratch_stride = (long long)std::max<size_t>(h->n_sparse_tot, 1) * SPARSE_J; P.n_imu_tot = (int)h->imus.size(); P.n_sp_list = h->n_sp_list;
     P.chunk_ob = h->d_chunk_ob.p; P.chunk_lm = h->d_chunk_lm.p; P.tile_perm = h->d_tile_perm.p; P.obs_lslot = h->d_obs_lslot.p; P.lm_elim = h->d_lm_elim.p;
     P.lines = h->d_lines.p; P.lobs = h->d_lobs.p; P.xline = h->d_xline.p; P.line_scratch = h->d_line_scratch.p;
     P.xline_stride = 6LL * h->n_line_tot;
@@ -541,7 +543,7 @@ int layout_reduced(sadvio_ba_handle* h) {
     HIP_TRY(h->d_delta.alloc((size_t)std::max(red_b, 1))); HIP_TRY(h->d_s_pose.alloc((size_t)std::max(red_b, 1)));
     HIP_TRY(hipMemsetAsync(h->d_S.p, 0, sizeof(double) * (size_t)std::max<long long>(h->red_total, 1), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_rank_s.p, 0, sizeof(double) * (size_t)nrb, h->stream));
-    HIP_TRY(h->d_sparse.alloc(std::max<size_t>(sparse.size(), 1))); HIP_TRY(h->d_sp_scratch.alloc(std::max<size_t>(sparse.size(), 1) * SPARSE_J));
+    HIP_TRY(h->d_sparse.alloc(std::max<size_t>(sparse.size(), 1))); HIP_TRY(h->d_sp_scratch.alloc(2 * std::max<size_t>(sparse.size(), 1) * SPARSE_J)); h->n_sparse_tot = sparse.size();
     h->up.add(h->d_sparse.p, sparse.data(), sparse.size() * sizeof(SparseDev));
     HIP_TRY(h->d_sp_list.alloc(std::max<size_t>(sp_list.size(), 1)));
     h->n_sp_list = (int)sp_list.size();
@@ -2145,7 +2147,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     for (const auto& v : h->sp_elim) for (char e : v) any_pseudo |= e != 0;
     const bool rare = o.huber_a > 0.0 || h->n_kept > 0 || any_pseudo;
     const bool pix = h->factor_type == SADVIO_FACTOR_PIXEL;
-    const bool with_imu = !h->imus.empty();   // the IMU factor pairs ride k_build (linearisation) and k_backsub (candidate cost) as extra workgroups
+    const bool with_imu = !h->imus.empty() || h->n_sp_list > 0;   // IMU factor pairs and listed sparse-prior factors ride k_build (linearisation) and k_backsub (candidate cost) as extra workgroups
     auto kb = with_imu ? (pix ? (rare ? k_build<0, true, true> : k_build<0, false, true>) : (rare ? k_build<1, true, true> : k_build<1, false, true>))
                        : (pix ? (rare ? k_build<0, true, false> : k_build<0, false, false>) : (rare ? k_build<1, true, false> : k_build<1, false, false>));
     auto kk = with_imu ? (pix ? (rare ? k_backsub<0, true, true> : k_backsub<0, false, true>) : (rare ? k_backsub<1, true, true> : k_backsub<1, false, true>))
@@ -2236,17 +2238,16 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             hipLaunchKernelGGL(k_reset, dim3(reset_blocks + table_blocks), dim3(256), 0, h->stream, P, reset_blocks, h->n_kf_tot);
         }
         const int n_imu_all = (int)h->imus.size();
-        // IMU factor pairs ride the tile kernels as extra workgroups (kernels.h: imu_pair_eval). Sparse-prior and line factors are still
-        // evaluated on a side stream: the linearisation next to k_build, the candidate cost next to k_backsub (fork / join with events;
-        // parallel branches of the captured graph)
-        const int n_spl = h->n_sp_list;
+        // IMU factor pairs and the listed sparse-prior factors ride the tile kernels as extra workgroups (kernels.h: pose_factor_eval).
+        // Line observations are still evaluated on a side stream: the linearisation next to k_build, the candidate cost next to
+        // k_backsub (fork / join with events; parallel branches of the captured graph)
+        const int n_pf = n_imu_all + h->n_sp_list;
         const int n_lo = h->n_lobs_tot;
-        const bool fork = (n_spl > 0 || n_lo > 0) && h->side && !h->cfg.profile_kernels && !h->coll_fn && !getenv("SADVIO_NO_FORK");
+        const bool fork = n_lo > 0 && h->side && !h->cfg.profile_kernels && !h->coll_fn && !getenv("SADVIO_NO_FORK");
         for (int s = 0; s < slots; s++) {
             if (fork) {
                 (void)hipEventRecord(h->ev_fork, h->stream);
                 (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
-                if (n_spl) hipLaunchKernelGGL(k_sparse_eval<true>, dim3(n_spl), dim3(64), 0, h->side, P, s, 1);
                 if (n_lo) hipLaunchKernelGGL(k_line_eval<true>, dim3(n_lo), dim3(64), 0, h->side, P, s, 1);
                 (void)hipEventRecord(h->ev_lin, h->side);
             }
@@ -2261,10 +2262,10 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 } else if (h->n_diag_segs) { ScopedTimer t(h, "k_diag"); hipLaunchKernelGGL(kdg, dim3(h->n_diag_segs), dim3(BUILD_THREADS), 0, h->stream, P, h->d_diag_segs.p, h->d_kf_lmk.p, h->d_kf_cam.p, h->d_kf_meas.p, s); }
                 { ScopedTimer t(h, "k_elim"); hipLaunchKernelGGL(ke, dim3(n_tiles), dim3(BUILD_THREADS), lds_elim, h->stream, P, s, mtk); }
                 { ScopedTimer t(h, "k_build_obs"); hipLaunchKernelGGL(kbo, dim3(n_tiles), dim3(BUILD_THREADS), lds_bobs, h->stream, P, s, mtk, Rp); }
-                if (n_imu_all) { ScopedTimer t(h, "k_imu_lin"); hipLaunchKernelGGL(k_imu_eval_lin, dim3(n_imu_all), dim3(64), 0, h->stream, P, s); }
+                if (n_pf) { ScopedTimer t(h, "k_pf_lin"); hipLaunchKernelGGL(k_pf_eval<false>, dim3(n_pf), dim3(64), 0, h->stream, P, s); }
                 if (par) (void)hipStreamWaitEvent(h->stream, h->ev_diag1, 0);
             } else
-            { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles + n_imu_all), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
+            { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles + n_pf), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
             if (h->n_kept) { ScopedTimer t(h, "k_build_kept"); hipLaunchKernelGGL(kbk, dim3((h->n_kept + 127) / 128), dim3(128), 0, h->stream, P, s); }
             if (dp_max_nf > 0) {
                 ScopedTimer t(h, "k_prior_r+gh");
@@ -2291,7 +2292,6 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             }
             if (fork) (void)hipStreamWaitEvent(h->stream, h->ev_lin, 0);
             else {
-                if (n_spl) { ScopedTimer t(h, "k_sparse_lin"); hipLaunchKernelGGL(k_sparse_eval<true>, dim3(n_spl), dim3(64), 0, h->stream, P, s, 0); }
                 if (n_lo) { ScopedTimer t(h, "k_line_lin"); hipLaunchKernelGGL(k_line_eval<true>, dim3(n_lo), dim3(64), 0, h->stream, P, s, 0); }
             }
             if (h->n_big < n_win) { ScopedTimer t(h, "k_solve"); hipLaunchKernelGGL(ks0, dim3(n_win), dim3(SOLVE_THREADS), lds_solve, h->stream, P, s); }
@@ -2430,20 +2430,18 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             if (fork) {
                 (void)hipEventRecord(h->ev_solved, h->stream);
                 (void)hipStreamWaitEvent(h->side, h->ev_solved, 0);
-                if (n_spl) hipLaunchKernelGGL(k_sparse_eval<false>, dim3(n_spl), dim3(64), 0, h->side, P, s, 0);
                 if (n_lo) hipLaunchKernelGGL(k_line_eval<false>, dim3(n_lo), dim3(64), 0, h->side, P, s, 0);
                 (void)hipEventRecord(h->ev_cost, h->side);
             } else {
-                if (n_spl) { ScopedTimer t(h, "k_sparse_cost"); hipLaunchKernelGGL(k_sparse_eval<false>, dim3(n_spl), dim3(64), 0, h->stream, P, s, 0); }
                 if (n_lo) { ScopedTimer t(h, "k_line_cost"); hipLaunchKernelGGL(k_line_eval<false>, dim3(n_lo), dim3(64), 0, h->stream, P, s, 0); }
             }
             if (dp_max_nf > 0) { ScopedTimer t(h, "k_prior_m"); hipLaunchKernelGGL(k_prior_m, dim3((dp_max_nf + 3) / 4, n_win), dim3(256), 0, h->stream, P, s); }
             if (use_lm) {
-                if (n_imu_all) { ScopedTimer t(h, "k_imu_cost"); hipLaunchKernelGGL(k_imu_eval_cost, dim3(n_imu_all), dim3(64), 0, h->stream, P, s); }
+                if (n_pf) { ScopedTimer t(h, "k_pf_cost"); hipLaunchKernelGGL(k_pf_eval<true>, dim3(n_pf), dim3(64), 0, h->stream, P, s); }
                 ScopedTimer t(h, "k_backsub_lm"); hipLaunchKernelGGL(kkl, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk);
             }
             else
-            { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles + n_imu_all), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
+            { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles + n_pf), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
             if (fork) (void)hipStreamWaitEvent(h->stream, h->ev_cost, 0);
             if (h->coll_fn) {
                 { ScopedTimer t(h, "k_rank_partials"); hipLaunchKernelGGL(k_rank_partials, dim3(n_win), dim3(64), 0, h->stream, P, s, 1); }

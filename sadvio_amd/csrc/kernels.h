@@ -62,7 +62,9 @@ struct DevPtrs {
     double* dp_data;      // dense priors, see WinDev::dp_off
     const SparseDev* sparse;  // sparse prior factors
     const int* sp_list;       // indices (into sparse) of the factors the solve evaluates itself, per window slice
-    double* sp_scratch;       // [n_sparse][SPARSE_J]
+    double* sp_scratch;       // [2][n_sparse][SPARSE_J] r, J of the listed factors at the deltas of buffer 0 | 1 (as imu_scratch)
+    long long sp_scratch_stride;
+    int n_imu_tot, n_sp_list;  // extra workgroups of k_build / k_backsub: IMU factor pairs, then the listed sparse-prior factors
     const int* dp_ints;
     const int* chunk_ob;      // [n_chunks + 1] first observation of each chunk (lm_kernels.h)
     const int* chunk_lm;      // [n_chunks + 1] first landmark of each chunk
@@ -480,12 +482,12 @@ __host__ __device__ inline size_t tile_tables_bytes(int n_kf) {
 // ---- K5: build the reduced system ----------------------------------------------------------------
 // IMU = true (windows with IMU factors): the workgroups behind the tiles linearise one IMU factor pair each (imu_pair_eval<false>,
 // one wave; its 500 registers leave one workgroup per CU, which is what a single window runs at anyway).
-template <bool COST_ONLY> __device__ __forceinline__ void imu_pair_eval(const DevPtrs& P, int slot, int k, int ln);   // below
+template <bool COST_ONLY> __device__ __forceinline__ void pose_factor_eval(const DevPtrs& P, int slot, int idx, int ln);   // below
 template <int FACTOR, bool RARE, bool IMU>
 __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P, int slot, int max_tile_kf, int strip_doubles, int Rp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (IMU && (int)blockIdx.x >= P.n_tiles) {
-        if (threadIdx.x < 64) imu_pair_eval<false>(P, slot, (int)blockIdx.x - P.n_tiles, threadIdx.x);
+        if (threadIdx.x < 64) pose_factor_eval<false>(P, slot, (int)blockIdx.x - P.n_tiles, threadIdx.x);
         return;
     }
     const Tile T = P.tiles[blockIdx.x];
@@ -1561,7 +1563,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         // r, J of the factors were written to the scratch rows by k_sparse_eval<true> (64-lane workgroup per factor)
         for (int kl = tid; kl < W.spl_end - W.spl_begin; kl += blockDim.x) {
             const int k = P.sp_list[W.spl_begin + kl];
-            const double* sc = P.sp_scratch + (long long)k * SPARSE_J;
+            const double* sc = P.sp_scratch + (long long)cur * P.sp_scratch_stride + (long long)k * SPARSE_J;
             const int rows = sparse_rows(P.sparse[k]);
             double c = 0.0;
             for (int q = 0; q < rows; q++) c += sc[225 + q] * sc[225 + q];
@@ -1584,7 +1586,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
                 const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
                 const int ca = sparse_col(f, a, fi, W.dpf, lr0, lr1), cb = sparse_col(f, b, fi, W.dpf, lr0, lr1);
                 if (ca >= 0 && cb >= 0) {
-                    const double* sc = P.sp_scratch + (long long)(W.sp_begin + k) * SPARSE_J;
+                    const double* sc = P.sp_scratch + (long long)cur * P.sp_scratch_stride + (long long)(W.sp_begin + k) * SPARSE_J;
                     const int rows = sparse_rows(f);
                     double h = 0.0;
                     for (int q = 0; q < rows; q++) h += sc[q * 15 + a] * sc[q * 15 + b];
@@ -1862,7 +1864,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             const int lr0 = sparse_lr0(P, W, f);
             const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
             if (fi < 0 && lr0 < 0 && lr1 < 0) continue;
-            const double* sc = P.sp_scratch + (long long)(W.sp_begin + k) * SPARSE_J;
+            const double* sc = P.sp_scratch + (long long)cur * P.sp_scratch_stride + (long long)(W.sp_begin + k) * SPARSE_J;
             double m = 0.0;
             for (int a = 0; a < 15; a++) {
                 const int ca = sparse_col(f, a, fi, W.dpf, lr0, lr1);
@@ -1926,7 +1928,7 @@ template <int FACTOR, bool RARE, bool IMU>
 __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, int max_tile_kf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (IMU && (int)blockIdx.x >= P.n_tiles) {
-        if (threadIdx.x < 64) imu_pair_eval<true>(P, slot, (int)blockIdx.x - P.n_tiles, threadIdx.x);
+        if (threadIdx.x < 64) pose_factor_eval<true>(P, slot, (int)blockIdx.x - P.n_tiles, threadIdx.x);
         return;
     }
     const Tile T = P.tiles[blockIdx.x];
@@ -2480,37 +2482,26 @@ __device__ __forceinline__ void imu_pair_eval(const DevPtrs& P, int slot, int k,
     }
 }
 
-// the same as kernels of their own (one 64-lane workgroup per pair): large batches on the throughput kernels, whose tile kernels carry
-// no extra workgroups
-__global__ __launch_bounds__(64) void k_imu_eval_lin(DevPtrs P, int slot) { imu_pair_eval<false>(P, slot, blockIdx.x, threadIdx.x); }
-__global__ __launch_bounds__(64) void k_imu_eval_cost(DevPtrs P, int slot) { imu_pair_eval<true>(P, slot, blockIdx.x, threadIdx.x); }
-
-// Sparse prior factors that the solve evaluates itself (IMUPriordx, landmark priors / chains), one 64-lane workgroup per
-// listed factor, same split as k_imu_eval: LIN -> r, J into the scratch row at x; !LIN -> cost at the candidate
-// x + delta (delta = the reduced step k_solve left in P.delta).
-template <bool LIN>
-__global__ __launch_bounds__(64) void k_sparse_eval(DevPtrs P, int slot, int own_decide) {
-    const int k = P.sp_list[blockIdx.x], ln = threadIdx.x;
+// Sparse prior factors that the solve evaluates itself (IMUPriordx, landmark priors / chains), ONE WAVE per listed factor, the
+// same split as imu_pair_eval (extra workgroups of the tile kernels, rows kept per delta buffer):
+//   COST_ONLY = true  (k_backsub, slot s): cost at the candidate x + delta (delta = the reduced step k_solve left in P.delta; the
+//                 landmark candidates are being written by the tiles of the same launch), added to the slot's cand_cost
+//   COST_ONLY = false (k_build, slot s)  : r, J into the scratch row of the candidate buffer of slot s - 1 (of x = 0 at slot 0)
+template <bool COST_ONLY>
+__device__ __forceinline__ void sparse_factor_eval(const DevPtrs& P, int slot, int k, int ln) {
+    constexpr bool LIN = !COST_ONLY;
     __shared__ SparseDev f;   // one coalesced copy of the factor's constants (1.9 KB, the 15 x 15 square-root information) instead of lane 0's scalar loads
     {
         const unsigned long long* src = (const unsigned long long*)(P.sparse + k);
         unsigned long long* dst = (unsigned long long*)&f;
         for (int i = ln; i < (int)(sizeof(SparseDev) / 8); i += 64) dst[i] = src[i];
     }
-    __syncthreads();
+    wave_lds_fence();
     const WinDev& W = P.win[f.win];
-    const long long so = (long long)f.win * P.state_stride + slot;
-    LmState st;
-    if (LIN && own_decide && slot > 0 && !P.decide_kernel) {
-        __shared__ double s4[4];
-        wave_sum_backsub_partials(P, (slot - 1) & 1, f.win, W.tile_begin, W.tile_end - W.tile_begin, ln, s4);
-        __syncthreads();
-        IterAcc a = P.acc[so - 1];
-        a.cand_cost += s4[0]; a.mcc += s4[1]; a.step_norm2 += s4[2]; a.cand_norm2 += s4[3];
-        st = lm_decide(P.states[so - 1], a, P.o);
-    } else st = P.states[so];
+    const long long so = (long long)f.win * P.state_stride + (LIN && slot > 0 ? slot - 1 : slot);
+    const LmState st = P.states[so];
     if (st.done) return;
-    const int cur = st.cur;
+    const int cur = (LIN && slot > 0) ? 1 - st.cur : st.cur;   // LIN: the buffer that is evaluated; COST_ONLY: the buffer of x
     const double* xp = P.xp + (long long)cur * P.xp_stride;
     const double* xv = P.xv + (long long)cur * P.xv_stride;
     const double* xba = P.xba + (long long)cur * P.xv_stride;
@@ -2519,7 +2510,7 @@ __global__ __launch_bounds__(64) void k_sparse_eval(DevPtrs P, int slot, int own
     __shared__ double Js[225];
     __shared__ double rs[16];
     __shared__ int s_in;
-    double* sc = P.sp_scratch + (long long)k * SPARSE_J;
+    double* sc = P.sp_scratch + (long long)cur * P.sp_scratch_stride + (long long)k * SPARSE_J;
     const int rows = sparse_rows(f);
     if (f.type == 0) {
         // IMUPriordx (residuals.hpp:634-700): lane 0 evaluates the 6-row pose part, the 15 x 15 whitening (r = W e, the pose columns of
@@ -2548,7 +2539,7 @@ __global__ __launch_bounds__(64) void k_sparse_eval(DevPtrs P, int slot, int own
             if (LIN) for (int q = 0; q < 36; q++) J6_s[q] = J6[q];
             s_in = fi >= 0 ? 1 : 0;
         }
-        __syncthreads();
+        wave_lds_fence();
         if (ln < 15) {
             double r = 0.0;
 #pragma unroll
@@ -2566,7 +2557,7 @@ __global__ __launch_bounds__(64) void k_sparse_eval(DevPtrs P, int slot, int own
                 for (int a = 6; a < 15; a++) Js[ln * 15 + a] = (ln == a) ? 1.0 : 0.0;
             }
         }
-        __syncthreads();
+        wave_lds_fence();
         if (!LIN && ln == 0 && s_in) {
             double c = 0.0;
             for (int q = 0; q < 15; q++) c += rs[q] * rs[q];
@@ -2586,12 +2577,23 @@ __global__ __launch_bounds__(64) void k_sparse_eval(DevPtrs P, int slot, int own
         }
     }
     if (LIN) {
-        __syncthreads();
+        wave_lds_fence();
         if (s_in) for (int e = ln; e < rows * 15; e += 64) sc[e] = Js[e];
         if (ln < 15) sc[225 + ln] = rs[ln];
         if (ln == 0) sc[240] = (double)s_in;
     }
 }
+
+// extra workgroup `idx` of k_build (COST_ONLY = false) / k_backsub (true): IMU factor pairs first, then the listed sparse-prior factors
+template <bool COST_ONLY>
+__device__ __forceinline__ void pose_factor_eval(const DevPtrs& P, int slot, int idx, int ln) {
+    if (idx < P.n_imu_tot) imu_pair_eval<COST_ONLY>(P, slot, idx, ln);
+    else sparse_factor_eval<COST_ONLY>(P, slot, P.sp_list[idx - P.n_imu_tot], ln);
+}
+// the same as a kernel of its own (one 64-lane workgroup per factor): large batches on the throughput kernels, whose tile kernels
+// carry no extra workgroups
+template <bool COST_ONLY>
+__global__ __launch_bounds__(64) void k_pf_eval(DevPtrs P, int slot) { pose_factor_eval<COST_ONLY>(P, slot, blockIdx.x, threadIdx.x); }
 
 // linexd observations, one 64-lane workgroup per observation, same split as k_sparse_eval: LIN -> J (rows x 12:
 // key-frame | line), r, loss-corrected cost and the in-program flag into the scratch row at x; !LIN -> cost at the candidate
