@@ -111,7 +111,14 @@ struct LineObsDev {
     double meas[6];           // pixel: the two end points (4); angular: the two bearing vectors
 };
 constexpr int LINE_ROW = 4 * 12 + 4 + 2;  // scratch row of one line observation: J (rows x 12) | r | rho | in-program flag
-constexpr int SPARSE_J = 15 * 15 + 15 + 2;  // J (rows x 15) + r + in-program flag kept in HBM scratch between phases
+// scratch row of one listed sparse-prior factor, written by sparse_factor_eval<false>: J (rows x 15) | r 15 | in-program flag, - |
+// SPARSE_NE entry values | SPARSE_NE entry targets | reduced column of each of the 15 Jacobian columns (-1: constant) | rows.
+// Entries (as in the IMU rows): H = J^T J (lower, 120) | g = J^T r (15) | the factor's squared residual sum (1).
+constexpr int SPARSE_NE = 136, SPARSE_E_G = 120, SPARSE_E_COST = 135;
+constexpr int SPARSE_H = 15 * 15 + 15 + 2;
+constexpr int SPARSE_IX = SPARSE_H + SPARSE_NE;
+constexpr int SPARSE_COL = SPARSE_IX + SPARSE_NE;
+constexpr int SPARSE_J = SPARSE_COL + 16;
 constexpr int IMU_J = 9 * 24 + 9;  // whitened Jacobian + residual kept in HBM scratch between phases
 // scratch row of one IMU factor, all written by k_imu_eval<true>: J 216 | r 9 | bias residuals 6 | IMU_NE entry values | IMU_NE entry
 // targets | fi, fj, sa, sg. The entries are what the factor pair (IMUFactor + IMUBiasFactor) adds to the window's reduced system:

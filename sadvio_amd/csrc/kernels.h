@@ -1552,56 +1552,39 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
         }
     }
-    // sparse (NFR) prior factors: one thread per factor evaluates r, J into an HBM scratch row, then the J^T J
-    // accumulation is spread over all threads (same scheme as the IMU factors)
-    const int n_sp = W.sp_end - W.sp_begin;
-    if (EXTRAS && n_sp > 0) {
-        const double* xv = P.xv + (long long)cur * P.xv_stride;
-        const double* xba = P.xba + (long long)cur * P.xv_stride;
-        const double* xbg = P.xbg + (long long)cur * P.xv_stride;
-        const double* xl = P.xl + (long long)cur * P.xl_stride;
-        // r, J of the factors were written to the scratch rows by k_sparse_eval<true> (64-lane workgroup per factor)
-        for (int kl = tid; kl < W.spl_end - W.spl_begin; kl += blockDim.x) {
-            const int k = P.sp_list[W.spl_begin + kl];
-            const double* sc = P.sp_scratch + (long long)cur * P.sp_scratch_stride + (long long)k * SPARSE_J;
-            const int rows = sparse_rows(P.sparse[k]);
-            double c = 0.0;
-            for (int q = 0; q < rows; q++) c += sc[225 + q] * sc[225 + q];
-            if (sc[240] != 0.0) cost_part += c; else fixed_part += c;
-        }
-        // items over the factors evaluated here only: a sparsified VIO prior is one IMUPriordx + hundreds of
-        // pose-to-landmark factors that ride the Schur elimination (type 4) and would each cost dependent global loads
-        // (sharded window: one factor at a time with plain adds, see `det` above; the 120 entries of a factor are distinct)
-        const int n_spl = W.spl_end - W.spl_begin;
-        for (int it = det ? 0 : tid; it < n_spl * 120; it += det ? 120 : (int)blockDim.x) {
-            const int kl = it / 120;
-            const int k = P.sp_list[W.spl_begin + kl] - W.sp_begin;
-            int e = det ? tid : it - 120 * kl, a = 0;
-            if (!det || tid < 120) {
-                while (e >= a + 1) { e -= a + 1; a++; }
-                const int b = e;
-                const SparseDev& f = P.sparse[W.sp_begin + k];
-                const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
-                const int lr0 = sparse_lr0(P, W, f);
-                const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
-                const int ca = sparse_col(f, a, fi, W.dpf, lr0, lr1), cb = sparse_col(f, b, fi, W.dpf, lr0, lr1);
-                if (ca >= 0 && cb >= 0) {
-                    const double* sc = P.sp_scratch + (long long)cur * P.sp_scratch_stride + (long long)(W.sp_begin + k) * SPARSE_J;
-                    const int rows = sparse_rows(f);
-                    double h = 0.0;
-                    for (int q = 0; q < rows; q++) h += sc[q * 15 + a] * sc[q * 15 + b];
-                    double g = 0.0;
-                    if (a == b) for (int q = 0; q < rows; q++) g += sc[q * 15 + a] * sc[225 + q];
-                    if (det) {
-                        A[ca >= cb ? aidx(ca, cb) : aidx(cb, ca)] += h;
-                        if (a == b) { y[ca] += g; gf[ca] += g; hd[ca] += h; }
-                    } else {
-                        atomic_add_f64(&A[ca >= cb ? aidx(ca, cb) : aidx(cb, ca)], h);
-                        if (a == b) { atomic_add_f64(&y[ca], g); atomic_add_f64(&gf[ca], g); atomic_add_f64(&hd[ca], h); }
+    // sparse (NFR) prior factors evaluated outside the Schur elimination (a sparsified VIO prior is one IMUPriordx here + hundreds
+    // of pose-to-landmark factors that ride the elimination as pseudo-observations): sparse_factor_eval<false> left every entry the
+    // factor adds, with its position, in its scratch row: item = (listed factor, entry)
+    const int n_spl = W.spl_end - W.spl_begin;
+    if (EXTRAS && n_spl > 0) {
+        if (det) {   // sharded window: one factor at a time with plain adds (its 135 targets are distinct)
+            for (int kl = 0; kl < n_spl; kl++) {
+                const double* row = P.sp_scratch + (long long)cur * P.sp_scratch_stride + (long long)P.sp_list[W.spl_begin + kl] * SPARSE_J;
+                if (tid < SPARSE_NE) {
+                    const int ix = (int)row[SPARSE_IX + tid];
+                    const double v = row[SPARSE_H + tid];
+                    if (tid == SPARSE_E_COST) { if (ix == -2) fixed_part += v; else cost_part += v; }
+                    else if (ix >= 0) {
+                        const int ca = ix >> 16, cb = ix & 0xffff;
+                        if (tid < SPARSE_E_G) { A[aidx(ca, cb)] += v; if (ca == cb) hd[ca] += v; }
+                        else { y[ca] += v; gf[ca] += v; }
                     }
                 }
+                __syncthreads();
             }
-            if (det) __syncthreads();
+        }
+        for (int it = tid; !det && it < n_spl * SPARSE_NE; it += blockDim.x) {
+            const int kl = it / SPARSE_NE, e = it - SPARSE_NE * kl;
+            const double* row = P.sp_scratch + (long long)cur * P.sp_scratch_stride + (long long)P.sp_list[W.spl_begin + kl] * SPARSE_J;
+            const int ix = (int)row[SPARSE_IX + e];
+            const double v = row[SPARSE_H + e];
+            if (e == SPARSE_E_COST) { if (ix == -2) fixed_part += v; else cost_part += v; continue; }
+            if (ix < 0) continue;
+            const int ca = ix >> 16, cb = ix & 0xffff;
+            if (e < SPARSE_E_G) {
+                atomic_add_f64(&A[aidx(ca, cb)], v);
+                if (ca == cb) atomic_add_f64(&hd[ca], v);
+            } else { atomic_add_f64(&y[ca], v); atomic_add_f64(&gf[ca], v); }
         }
     }
     // linexd observations: r, J (rows x 12 over [key-frame | line]) from k_line_eval<true>; item = (observation, lower-triangle entry)
@@ -1848,31 +1831,24 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         }
         // candidate cost of the IMU factors: k_imu_eval<false>, launched after this kernel, adds it to acc->cand_cost
     }
-    if (EXTRAS && W.sp_end > W.sp_begin) {
-        const int n_sp = W.sp_end - W.sp_begin;
-        const double* xv = P.xv + (long long)cur * P.xv_stride;
-        const double* xba = P.xba + (long long)cur * P.xv_stride;
-        const double* xbg = P.xbg + (long long)cur * P.xv_stride;
-        const double* xl = P.xl + (long long)cur * P.xl_stride;
-        // model cost change, item = (factor, residual row)
-        for (int it = tid; it < (W.spl_end - W.spl_begin) * 15; it += blockDim.x) {
+    if (EXTRAS && W.spl_end > W.spl_begin) {
+        // model cost change, item = (listed factor, residual row), dealt from the fifth wave upwards (see the IMU items); the row holds
+        // the reduced column of every Jacobian column
+        const int t0 = blockDim.x > 320 ? 256 : 0;
+        for (int it = tid - t0; it >= 0 && it < (W.spl_end - W.spl_begin) * 15; it += blockDim.x - t0) {
             const int kl = it / 15, q = it - 15 * kl;
-            const int k = P.sp_list[W.spl_begin + kl] - W.sp_begin;
-            const SparseDev& f = P.sparse[W.sp_begin + k];
-            if (f.type == 4 || q >= sparse_rows(f)) continue;
-            const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
-            const int lr0 = sparse_lr0(P, W, f);
-            const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
-            if (fi < 0 && lr0 < 0 && lr1 < 0) continue;
-            const double* sc = P.sp_scratch + (long long)cur * P.sp_scratch_stride + (long long)(W.sp_begin + k) * SPARSE_J;
+            const double* sc = P.sp_scratch + (long long)cur * P.sp_scratch_stride + (long long)P.sp_list[W.spl_begin + kl] * SPARSE_J;
+            if (q >= (int)sc[SPARSE_COL + 15]) continue;
+            double jr[15], cd[15];
+#pragma unroll
+            for (int a = 0; a < 15; a++) { jr[a] = sc[q * 15 + a]; cd[a] = sc[SPARSE_COL + a]; }
+            const double r = sc[225 + q];
             double m = 0.0;
-            for (int a = 0; a < 15; a++) {
-                const int ca = sparse_col(f, a, fi, W.dpf, lr0, lr1);
-                if (ca >= 0) m += sc[q * 15 + a] * y[ca];
-            }
-            mcc += -m * (sc[225 + q] + 0.5 * m);
+#pragma unroll
+            for (int a = 0; a < 15; a++) { const int ca = (int)cd[a]; if (ca >= 0) m += jr[a] * y[ca]; }
+            mcc += -m * (r + 0.5 * m);
         }
-        // candidate cost of these factors: k_sparse_eval<false>, after this kernel, adds it to acc->cand_cost
+        // candidate cost of these factors: sparse_factor_eval<true> (extra workgroups of k_backsub) adds it to acc->cand_cost
     }
     if (EXTRAS && W.lobs_end > W.lobs_begin) {
         const int rows = W.factor_type == 0 ? 4 : 2;
@@ -2581,6 +2557,37 @@ __device__ __forceinline__ void sparse_factor_eval(const DevPtrs& P, int slot, i
         if (s_in) for (int e = ln; e < rows * 15; e += 64) sc[e] = Js[e];
         if (ln < 15) sc[225 + ln] = rs[ln];
         if (ln == 0) sc[240] = (double)s_in;
+        // what the factor adds to the reduced system, entry by entry with its position (k_solve: one uniform pass)
+        const int fi = f.kf >= 0 ? P.kf_fidx[f.kf] : -1;
+        const int lr0 = sparse_lr0(P, W, f);
+        const int lr1 = (f.lmk1 >= 0 && P.lmk_red) ? P.lmk_red[f.lmk1] : -1;
+        for (int e = ln; e < SPARSE_NE; e += 64) {
+            double v = 0.0;
+            int ix = -1;
+            if (e < SPARSE_E_G) {
+                int a = 0, b = e;
+                while (b >= a + 1) { b -= a + 1; a++; }
+                const int ca = sparse_col(f, a, fi, W.dpf, lr0, lr1), cb = sparse_col(f, b, fi, W.dpf, lr0, lr1);
+                if (s_in && ca >= 0 && cb >= 0) {
+                    for (int q = 0; q < rows; q++) v += Js[q * 15 + a] * Js[q * 15 + b];
+                    ix = ca >= cb ? (ca << 16) | cb : (cb << 16) | ca;
+                }
+            } else if (e < SPARSE_E_COST) {
+                const int a = e - SPARSE_E_G;
+                const int ca = sparse_col(f, a, fi, W.dpf, lr0, lr1);
+                if (s_in && ca >= 0) {
+                    for (int q = 0; q < rows; q++) v += Js[q * 15 + a] * rs[q];
+                    ix = ca << 16;
+                }
+                sc[SPARSE_COL + a] = (double)(s_in ? ca : -1);
+            } else {
+                for (int q = 0; q < rows; q++) v += rs[q] * rs[q];
+                ix = s_in ? -3 : -2;
+                sc[SPARSE_COL + 15] = (double)rows;
+            }
+            sc[SPARSE_H + e] = v;
+            sc[SPARSE_IX + e] = (double)ix;
+        }
     }
 }
 
