@@ -266,6 +266,7 @@ struct sadvio_ba_handle {
     DevBuf<DiagSeg> d_diag_segs;
     int n_diag_segs = 0;
     DevBuf<double> d_lm_elim;
+    bool gemm_run4 = false;               // a tile on the MFMA path holds runs of 3 - 4 observations on one key-frame (k_build<.., RARE = true> only)
     bool lm_ok = false;                   // every tile is on the MFMA path and chunked: k_elim / k_build_obs / k_backsub_lm may run
     long long lm_landmarks = 0;
     DevBuf<double> d_ptab;
@@ -835,7 +836,7 @@ static int build_layout(sadvio_ba_handle* h) {
     tile_kf.clear(); tile_row.clear();
     obs_slot.assign(std::max(obs_b, 1), 0);
     h->obs_perm.assign(std::max(obs_b, 1), 0);
-    h->max_tile_kf = 1; h->max_tile_free = 0; h->max_gemm_free = 0;
+    h->max_tile_kf = 1; h->max_tile_free = 0; h->max_gemm_free = 0; h->gemm_run4 = false;
     for (int w = 0; w < n_windows; w++) {
         const sadvio_flat_window& F = wins[w];
         WinDev& d = h->wins[w].d;
@@ -996,7 +997,8 @@ static int build_layout(sadvio_ba_handle* h) {
                 }
                 t.lmk1 = d.lmk_base + l;
                 std::sort(kfs.begin(), kfs.end());
-                t.lds_mode = ((int)kfs.size() <= MAX_TILE_KF && nfree <= MAX_TILE_FREE_KF) ? ((nfree <= MAX_GEMM_FREE_KF && tile_run_max <= 2 && t.G == 8) ? 2 : 1) : 0;
+                t.lds_mode = ((int)kfs.size() <= MAX_TILE_KF && nfree <= MAX_TILE_FREE_KF) ? ((nfree <= MAX_GEMM_FREE_KF && tile_run_max <= (has_asrc ? 4 : 2) && t.G == 8) ? 2 : 1) : 0;
+                if (t.lds_mode == 2 && tile_run_max > 2) h->gemm_run4 = true;   // needs the RARE variant of k_build (pseudo-observations: it is taken)
                 if (t.lds_mode == 2) h->max_gemm_free = std::max(h->max_gemm_free, nfree);
                 if ((int)kfs.size() > 64) { h->err = "set_windows: a landmark is observed from more than 64 key-frames"; return SADVIO_E_INVALID_ARG; }
                 t.kf_off = (int)tile_kf.size(); t.n_kf = (int)kfs.size(); t.n_free = t.lds_mode ? nfree : 0;
@@ -2145,7 +2147,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     // robust loss or prior-kept landmarks in the batch: the kernels carrying those (rare) paths
     bool any_pseudo = false;
     for (const auto& v : h->sp_elim) for (char e : v) any_pseudo |= e != 0;
-    const bool rare = o.huber_a > 0.0 || h->n_kept > 0 || any_pseudo;
+    const bool rare = o.huber_a > 0.0 || h->n_kept > 0 || any_pseudo || h->gemm_run4;
     const bool pix = h->factor_type == SADVIO_FACTOR_PIXEL;
     const bool with_imu = !h->imus.empty() || h->n_sp_list > 0;   // IMU factor pairs and listed sparse-prior factors ride k_build (linearisation) and k_backsub (candidate cost) as extra workgroups
     auto kb = with_imu ? (pix ? (rare ? k_build<0, true, true> : k_build<0, false, true>) : (rare ? k_build<1, true, true> : k_build<1, false, true>))

@@ -691,6 +691,10 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
             const int row_next = dpp_i32<0x101>(myrow);         // lane + 1
             const bool follower = vrow && q > 0 && row_prev == myrow;
             const bool has_follower = vrow && q + 1 < G && row_next == myrow;
+            // RARE: a landmark held by a prior carries pseudo-observations on the prior's key-frame next to its real ones: runs of up
+            // to four lanes on one key-frame, summed in two steps (lane + 1, then lane + 2)
+            const int row_next2 = RARE ? dpp_i32<0x102>(myrow) : -1;   // lane + 2 (read by every lane, outside the branches)
+            const bool has_follower2 = RARE && vrow && q + 2 < G && row_next2 == myrow;
             const bool head = vrow && !follower;
             const double rt0 = L.r[0] - (N[0] * g[0] + N[1] * g[1] + N[2] * g[2]);
             const double rt1 = L.r[1] - (N[3] * g[0] + N[4] * g[1] + N[5] * g[2]);
@@ -707,6 +711,10 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
                     e[c] = j0 * L.Jl[c] + j1 * L.Jl[3 + c];
                     const double yn = dpp_f64<0x101>(y[c]), en = dpp_f64<0x101>(e[c]);
                     if (has_follower) { y[c] += yn; e[c] += en; }
+                    if (RARE) {
+                        const double yn2 = dpp_f64<0x102>(y[c]), en2 = dpp_f64<0x102>(e[c]);
+                        if (has_follower2) { y[c] += yn2; e[c] += en2; }
+                    }
                 }
                 if (head) {
                     double2* yp = (double2*)(Yb + (myrow + i) * KS + 4 * grp);
@@ -753,6 +761,7 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
                         if (!vrow) v = 0.0;
                         const double vn = dpp_f64<0x101>(v);
                         if (has_follower) v += vn;
+                        if (RARE) { const double vn2 = dpp_f64<0x102>(v); if (has_follower2) v += vn2; }
                         if (uniform) v = across_groups8_sum(v);
                         if (adder) { atomic_add_f64(&Stile[tri(myrow + i, myrow + j)], v); if (i == j) atomic_add_f64(&hdT[myrow + i], v); }
                     }
@@ -763,6 +772,10 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
                     double gr = j0 * rt0 + j1 * rt1, gf = j0 * L.r[0] + j1 * L.r[1];
                     const double grn = dpp_f64<0x101>(gr), gfn = dpp_f64<0x101>(gf);
                     if (has_follower) { gr += grn; gf += gfn; }
+                    if (RARE) {
+                        const double grn2 = dpp_f64<0x102>(gr), gfn2 = dpp_f64<0x102>(gf);
+                        if (has_follower2) { gr += grn2; gf += gfn2; }
+                    }
                     if (uniform) { gr = across_groups8_sum(gr); gf = across_groups8_sum(gf); }
                     if (adder) { atomic_add_f64(&gT[myrow + i], gr); atomic_add_f64(&gfT[myrow + i], gf); }
                 }
