@@ -2492,6 +2492,9 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             for (int i = 1; i < 16; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[0]) * 0.01);
             fprintf(stderr, "  shader clock %.3f GHz\n[sadvio dbg] k_build:", (double)(ts[21] - ts[20]) / ((ts[15] - ts[0]) * 10.0));
             for (int i = 33; i < 43; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[32]) * 0.01);
+            fprintf(stderr, "\n[sadvio dbg] chol16 cycles since its first barrier (panel | trailing + next pivot, per block column):");
+            for (int i = 23; i < 39; i++) fprintf(stderr, " %lld", ts[i] - ts[22]);
+            fprintf(stderr, " | end %lld", ts[42] - ts[22]);
             fprintf(stderr, "\n[sadvio dbg] k_chol_panel / k_band_solve (fwd window 2: carry fresh chol store | fwd end | bwd window 2: load below steps | bwd end):");
             for (int i = 45; i < 55; i++) fprintf(stderr, " %d:%.2f", i - 44, (ts[i] - ts[44]) * 0.01);
             fprintf(stderr, "\n");

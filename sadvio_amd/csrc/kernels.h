@@ -1702,8 +1702,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     long long* ts = SADVIO_TS_PTR((P.debug & 4096) && blockIdx.x == 0 && slot == 3);
     if (MODE == 0) {
         bool ok = true;  // Np == 0 (every key-frame constant, landmarkOptimization): nothing to factor
-        if (Np > 0) ok = c16_solve<1>(A, Np, xs, pub, yv, nullptr);
-        (void)ts;
+        if (Np > 0) ok = c16_solve<1>(A, Np, xs, pub, yv, ts ? ts + 22 : nullptr);   // SADVIO_KERNEL_TS builds: per-block-column cycle stamps (they overwrite k_build's)
         if (!ok) {
             if (tid == 0) acc->chol_fail = 1;
             return;
