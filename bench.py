@@ -20,6 +20,7 @@ One JSON line is printed by rank 0. Besides the contract's fields it carries
   cpu_baseline  the CPU oracle (a port of the reference's algorithm, the reference itself cannot be built
                 here) timed on this box's host cores on the same window
   batched       the same metric with 64 independent windows per launch (the bandwidth-bound regime)
+  vio_window    GN-10 solves of a config-3 shaped VIO window (no prior / sparsified prior), resident in HBM
   marginalize   sadvio_ba_marginalize on a config-3 shaped window (12-KF VIO, 300 kept landmarks) with the oracle's CPU time beside it
   sharded_window (N > 1 only) ONE config-4 window landmark-sharded over the ranks: RCCL all-reduce of the reduced system per LM step
 """
@@ -239,6 +240,7 @@ def main():
         marg = None
         if not args.no_marginalize and world == 1:
             marg = marginalize_leg(local_rank, marg_cpu)
+        vio = vio_window_leg(local_rank, opts) if world == 1 else None
         out = {
             "metric": "BA iterations/sec (ms/solve in ms_per_solve), 20-KF/8k-landmark window",
             "value": round(value, 1), "unit": "BA iterations/s", "n_gpus": world, "steps": args.steps,
@@ -255,7 +257,7 @@ def main():
             "upload_inclusive": {"value": round(iters_per_solve / dt_up, 1), "unit": "BA iterations/s",
                                  "ms_per_solve": round(1e3 * dt_up, 4),
                                  "what": "set_windows (host flatten -> HBM) + solve + get_deltas per solve, rank 0"},
-            "marginalize": marg, "sharded_window": sharded, "sharded_window_c5": sharded5,
+            "marginalize": marg, "vio_window": vio, "sharded_window": sharded, "sharded_window_c5": sharded5,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
@@ -388,6 +390,33 @@ def sparse_normal_baseline(oracle, w, opts, budget_s=5.0):
     return {"value": round(n_it / dt, 2), "unit": "BA iterations/s", "cores": 1,
             "ms_linearize_assemble_factorize": [round(float(1e3 * x / n_it), 1) for x in split],
             "sample": f"{n_it} linearise + assemble + factorise + solve passes on the config-2 window, {n} unknowns"}
+
+
+def vio_window_leg(device, opts):
+    """BASELINE config 3's shape (12-KF VIO window, 7 200 landmarks, 11 IMU + bias factor pairs; synthetic, EuRoC is not on the box):
+    GN-10 solves resident in HBM, without a prior and with the sparsified prior (IMUPriordx + 300 pose-to-landmark factors)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from sadvio_amd import capi
+    from vio_helpers import make_vio_window
+    from sparse_helpers import vio_sparse_priors
+    w = make_vio_window(n_kf=12, n_lmk=7200, seed=6)
+    out = {"window": "12 KF x 7200 landmarks x 36000 factors + 11 IMU / bias factor pairs, 15 states per key-frame", "unit": "BA iterations/s"}
+    for name, sp in (("no_prior", []), ("sparsified_prior", vio_sparse_priors(w, w.n_kf - 2, list(range(0, 600, 2)), np.random.default_rng(4), noise=0.03))):
+        w.sparse_priors = sp
+        be = capi.Backend(device=device, use_graph=True)
+        be.set_windows([w])
+        for _ in range(3):
+            be.solve(opts)
+        reps = 50
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            s = be.solve(opts)
+        dt = (time.perf_counter() - t0) / reps
+        be.close()
+        out[name] = {"value": round(s[0].iterations / dt, 1), "ms_per_solve": round(1e3 * dt, 4)}
+    w.sparse_priors = []
+    return out
 
 
 def _marg_case():
