@@ -2149,7 +2149,12 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     for (const auto& v : h->sp_elim) for (char e : v) any_pseudo |= e != 0;
     const bool rare = o.huber_a > 0.0 || h->n_kept > 0 || any_pseudo || h->gemm_run4;
     const bool pix = h->factor_type == SADVIO_FACTOR_PIXEL;
-    const bool with_imu = !h->imus.empty() || h->n_sp_list > 0;   // IMU factor pairs and listed sparse-prior factors ride k_build (linearisation) and k_backsub (candidate cost) as extra workgroups
+    // IMU factor pairs and listed sparse-prior factors ride k_build (linearisation) and k_backsub (candidate cost) as extra workgroups
+    // when the submission is a window or two: the inlined linearisation leaves those variants of k_build one workgroup per CU, which
+    // a batch of VIO windows would pay for; there the evaluation runs as kernels of its own on the same stream (k_pf_eval)
+    const bool have_pf = !h->imus.empty() || h->n_sp_list > 0;
+    bool with_imu = have_pf && n_tiles <= 3 * 256;
+    if (const char* e = getenv("SADVIO_PF_WG")) with_imu = have_pf && atoi(e) != 0;
     auto kb = with_imu ? (pix ? (rare ? k_build<0, true, true> : k_build<0, false, true>) : (rare ? k_build<1, true, true> : k_build<1, false, true>))
                        : (pix ? (rare ? k_build<0, true, false> : k_build<0, false, false>) : (rare ? k_build<1, true, false> : k_build<1, false, false>));
     auto kk = with_imu ? (pix ? (rare ? k_backsub<0, true, true> : k_backsub<0, false, true>) : (rare ? k_backsub<1, true, true> : k_backsub<1, false, true>))
@@ -2264,10 +2269,10 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 } else if (h->n_diag_segs) { ScopedTimer t(h, "k_diag"); hipLaunchKernelGGL(kdg, dim3(h->n_diag_segs), dim3(BUILD_THREADS), 0, h->stream, P, h->d_diag_segs.p, h->d_kf_lmk.p, h->d_kf_cam.p, h->d_kf_meas.p, s); }
                 { ScopedTimer t(h, "k_elim"); hipLaunchKernelGGL(ke, dim3(n_tiles), dim3(BUILD_THREADS), lds_elim, h->stream, P, s, mtk); }
                 { ScopedTimer t(h, "k_build_obs"); hipLaunchKernelGGL(kbo, dim3(n_tiles), dim3(BUILD_THREADS), lds_bobs, h->stream, P, s, mtk, Rp); }
-                if (n_pf) { ScopedTimer t(h, "k_pf_lin"); hipLaunchKernelGGL(k_pf_eval<false>, dim3(n_pf), dim3(64), 0, h->stream, P, s); }
                 if (par) (void)hipStreamWaitEvent(h->stream, h->ev_diag1, 0);
             } else
-            { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles + n_pf), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
+            { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles + (with_imu ? n_pf : 0)), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
+            if (n_pf && (use_lm || !with_imu)) { ScopedTimer t(h, "k_pf_lin"); hipLaunchKernelGGL(k_pf_eval<false>, dim3(n_pf), dim3(64), 0, h->stream, P, s); }
             if (h->n_kept) { ScopedTimer t(h, "k_build_kept"); hipLaunchKernelGGL(kbk, dim3((h->n_kept + 127) / 128), dim3(128), 0, h->stream, P, s); }
             if (dp_max_nf > 0) {
                 ScopedTimer t(h, "k_prior_r+gh");
@@ -2438,12 +2443,12 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 if (n_lo) { ScopedTimer t(h, "k_line_cost"); hipLaunchKernelGGL(k_line_eval<false>, dim3(n_lo), dim3(64), 0, h->stream, P, s, 0); }
             }
             if (dp_max_nf > 0) { ScopedTimer t(h, "k_prior_m"); hipLaunchKernelGGL(k_prior_m, dim3((dp_max_nf + 3) / 4, n_win), dim3(256), 0, h->stream, P, s); }
+            if (n_pf && (use_lm || !with_imu)) { ScopedTimer t(h, "k_pf_cost"); hipLaunchKernelGGL(k_pf_eval<true>, dim3(n_pf), dim3(64), 0, h->stream, P, s); }
             if (use_lm) {
-                if (n_pf) { ScopedTimer t(h, "k_pf_cost"); hipLaunchKernelGGL(k_pf_eval<true>, dim3(n_pf), dim3(64), 0, h->stream, P, s); }
                 ScopedTimer t(h, "k_backsub_lm"); hipLaunchKernelGGL(kkl, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk);
             }
             else
-            { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles + n_pf), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
+            { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles + (with_imu ? n_pf : 0)), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
             if (fork) (void)hipStreamWaitEvent(h->stream, h->ev_cost, 0);
             if (h->coll_fn) {
                 { ScopedTimer t(h, "k_rank_partials"); hipLaunchKernelGGL(k_rank_partials, dim3(n_win), dim3(64), 0, h->stream, P, s, 1); }
