@@ -73,6 +73,7 @@ def main():
                          "over the ranks, reduced system all-reduced over RCCL per LM step (strong scaling). With N > 1 the "
                          "default run reports it as the `sharded_window` object next to the independent-window line")
     ap.add_argument("--no-marginalize", action="store_true")
+    ap.add_argument("--no-vio", action="store_true", help="skip the config-3 shaped VIO window leg (the profiled runs of scripts/prof_bench.sh: one k_solve variant per trace)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -240,7 +241,7 @@ def main():
         marg = None
         if not args.no_marginalize and world == 1:
             marg = marginalize_leg(local_rank, marg_cpu)
-        vio = vio_window_leg(local_rank, opts) if world == 1 else None
+        vio = vio_window_leg(local_rank, opts) if (world == 1 and not args.no_vio) else None
         out = {
             "metric": "BA iterations/sec (ms/solve in ms_per_solve), 20-KF/8k-landmark window",
             "value": round(value, 1), "unit": "BA iterations/s", "n_gpus": world, "steps": args.steps,

@@ -1470,7 +1470,7 @@ int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int l
         const int nb = (r + jb - 1) / jb, nbpad = nb + (nb & 1);
         int sweeps = 0;
         long long* jts = nullptr;   // phase timestamps of one launch (SADVIO_KERNEL_TS builds, SADVIO_DEBUG & 4096)
-        if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 4096) && n > 500 && h->d_dbg.alloc(64) == hipSuccess) jts = h->d_dbg.p + 44;
+        if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 4096) && n > 500 && h->d_dbg.alloc(128) == hipSuccess) jts = h->d_dbg.p + 44;
         for (; sweeps < 40 && nbpad >= 2; sweeps++) {
             if (hipMemsetAsync(flag, 0, sizeof(int), h->stream) != hipSuccess) return -1;
             for (int st = 0; st < nbpad - 1; st++) {
@@ -2100,7 +2100,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     // iteration 0, so at least one slot is always run and the final decision is taken by k_final.
     const int slots = std::max(1, o.max_num_iterations);
     const int stride = slots + 2;
-    HIP_TRY(h->d_dbg.alloc(64));
+    HIP_TRY(h->d_dbg.alloc(128));
     HIP_TRY(h->d_states.alloc((size_t)n_win * stride));
     HIP_TRY(h->d_trace.alloc((size_t)n_win * stride * 8));
     HIP_TRY(h->d_tstart.alloc(1));
@@ -2491,15 +2491,15 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->cfg.profile_kernels) collect_timers(h);
     if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 4096)) {
-        long long ts[64];
+        long long ts[128];
         if (hipMemcpy(ts, h->d_dbg.p, sizeof(ts), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[sadvio dbg] phase dt (us):");
             for (int i = 1; i < 16; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[0]) * 0.01);
             fprintf(stderr, "  shader clock %.3f GHz\n[sadvio dbg] k_build:", (double)(ts[21] - ts[20]) / ((ts[15] - ts[0]) * 10.0));
             for (int i = 33; i < 43; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[32]) * 0.01);
             fprintf(stderr, "\n[sadvio dbg] chol16 cycles since its first barrier (panel | trailing + next pivot, per block column):");
-            for (int i = 23; i < 39; i++) fprintf(stderr, " %lld", ts[i] - ts[22]);
-            fprintf(stderr, " | end %lld", ts[42] - ts[22]);
+            for (int i = 65; i < 81; i++) fprintf(stderr, " %lld", ts[i] - ts[64]);
+            fprintf(stderr, " | end %lld", ts[84] - ts[64]);
             fprintf(stderr, "\n[sadvio dbg] k_chol_panel / k_band_solve (fwd window 2: carry fresh chol store | fwd end | bwd window 2: load below steps | bwd end):");
             for (int i = 45; i < 55; i++) fprintf(stderr, " %d:%.2f", i - 44, (ts[i] - ts[44]) * 0.01);
             fprintf(stderr, "\n");

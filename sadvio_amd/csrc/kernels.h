@@ -82,7 +82,7 @@ struct DevPtrs {
     int n_win;
     long long* t_start; // wall_clock64 at the first kernel of the solve (k_reset)
     double* trace;      // [n_win][state_stride][8] per-iteration log (sadvio_ba_get_trace), written by the slot's single decider
-    long long* dbg_ts;  // [64] phase timestamps (wall_clock64, 100 MHz) of workgroup 0 when debug & 4096
+    long long* dbg_ts;  // [128] phase timestamps (wall_clock64, 100 MHz) of workgroup 0 when debug & 4096
     int debug;  // SADVIO_DEBUG env: bit 12 (4096) = in-kernel phase timestamps of workgroup 0 into dbg_ts (results unaffected)
     SolveOpts o;
 };
@@ -1702,7 +1702,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     long long* ts = SADVIO_TS_PTR((P.debug & 4096) && blockIdx.x == 0 && slot == 3);
     if (MODE == 0) {
         bool ok = true;  // Np == 0 (every key-frame constant, landmarkOptimization): nothing to factor
-        if (Np > 0) ok = c16_solve<1>(A, Np, xs, pub, yv, ts ? ts + 22 : nullptr);   // SADVIO_KERNEL_TS builds: per-block-column cycle stamps (they overwrite k_build's)
+        if (Np > 0) ok = c16_solve<1>(A, Np, xs, pub, yv, ts ? ts + 64 : nullptr);   // SADVIO_KERNEL_TS builds: per-block-column cycle stamps
         if (!ok) {
             if (tid == 0) acc->chol_fail = 1;
             return;
