@@ -108,3 +108,39 @@ def test_all_constant_imu_factor_on_a_reused_handle(backend_cls, oracle_lib):
     finally:
         be.close()
     assert_match(s, d, oracle_lib.solve(w2, opts))
+
+
+@pytest.mark.parametrize("prior", ["none", "sparsified"])
+def test_pose_only_factors_as_extra_workgroups_and_as_kernels(backend_cls, oracle_lib, monkeypatch, prior):
+    """IMU pairs and listed sparse-prior factors are evaluated by extra workgroups of k_build / k_backsub (a window or two)
+    or by kernels of their own on the same stream (batches; SADVIO_PF_WG forces either): both against the oracle, with
+    accepted AND rejected steps in the solve (the linearisation rows are kept per delta buffer)."""
+    from sparse_helpers import vio_sparse_priors
+    w = make_vio_window(n_kf=7, n_lmk=420, seed=31, lmk_perturb=0.3, rot_perturb_deg=2.0)   # a strongly perturbed start: 8 - 9 rejected steps
+    if prior == "sparsified":
+        w.sparse_priors = vio_sparse_priors(w, w.n_kf - 2, list(range(0, 60, 2)), np.random.default_rng(8), noise=0.03)
+    opts = capi.reference_options()
+    ref = oracle_lib.solve(w, opts)
+    assert ref["summary"].num_unsuccessful_steps > 0 and ref["summary"].num_successful_steps > 0
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SADVIO_PF_WG", mode)
+        s, d = gpu_solve(backend_cls, w, opts)
+        assert_match(s, d, ref)
+        got[mode] = d
+    for k in ("pose", "dv", "dba", "dbg"):
+        assert np.abs(got["1"][k] - got["0"][k]).max() <= 1e-9, k
+
+
+def test_batch_of_vio_windows(backend_cls, oracle_lib):
+    """Several VIO windows in one submission (more tiles than the extra-workgroup variants are used for)."""
+    ws = [make_vio_window(n_kf=8, n_lmk=3000, seed=40 + i) for i in range(9)]
+    opts = capi.gn_options(4)
+    be = backend_cls(device=0)
+    try:
+        be.set_windows(ws)
+        ss = be.solve(opts)
+        for i in (0, 4, 8):
+            assert_match(ss[i], be.get_deltas(i), oracle_lib.solve(ws[i], opts))
+    finally:
+        be.close()
