@@ -2395,8 +2395,24 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                             (void)hipFuncSetAttribute((const void*)k_wchol_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
                             (void)hipFuncSetAttribute((const void*)k_wchol_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
                             (void)hipFuncSetAttribute((const void*)k_wchol_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * WD * WDS));
+                            const bool wdla = wd16 && !getenv("SADVIO_WD_NOLA");   // look-ahead: the next diagonal block inside the trailing-update launch
+                            const size_t lds_la = std::max(sizeof(double) * wdla_lds_doubles() + 64, lds_s);
+                            (void)hipFuncSetAttribute((const void*)k_wchol_syrk_la, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_la);
+                            (void)hipFuncSetAttribute((const void*)k_wchol_trsm8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
                             int st = 0;
                             for (int c0 = 0; c0 < N; c0 += WD, st++) {
+                                if (wdla) {
+                                    if (c0 == 0) hipLaunchKernelGGL(k_wchol_diag16, dim3(1), dim3(SOLVE_THREADS), sizeof(double) * wd16_lds_doubles() + 64, h->stream, Sw, (long long)d.ld, yw, Mw, N, 0, info, skip);
+                                    const int m = N - (c0 + WD);
+                                    if (m > 0) {
+                                        const int nt = (m + CH_TS - 1) / CH_TS;
+                                        hipLaunchKernelGGL(k_wchol_trsm8, dim3(nt), dim3(SOLVE_THREADS), lds_t, h->stream, Sw, (long long)d.ld, Mw + (size_t)st * WD * WD, N, c0, info, skip);
+                                        hipLaunchKernelGGL(k_wchol_syrk_la, dim3(nt * (nt + 1) / 2 + (m + SOLVE_THREADS - 1) / SOLVE_THREADS + 1), dim3(SOLVE_THREADS), lds_la, h->stream,
+                                                           Sw, (long long)d.ld, yw, Mw + (size_t)(st + 1) * WD * WD, N, c0, info, skip,
+                                                           (P.debug & 4096) && s == 3 && c0 == WD ? h->d_dbg.p + 90 : (long long*)nullptr);
+                                    }
+                                    continue;
+                                }
                                 if (wd16) hipLaunchKernelGGL(k_wchol_diag16, dim3(1), dim3(SOLVE_THREADS), sizeof(double) * wd16_lds_doubles() + 64, h->stream, Sw, (long long)d.ld, yw, Mw + (size_t)st * WD * WD, N, c0, info, skip);
                                 else
                                 hipLaunchKernelGGL(k_wchol_diag, dim3(1), dim3(SOLVE_THREADS), lds_d, h->stream, Sw, (long long)d.ld, yw, Mw + (size_t)st * WD * WD, N, c0, info, skip);
@@ -2497,6 +2513,9 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             for (int i = 1; i < 16; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[0]) * 0.01);
             fprintf(stderr, "  shader clock %.3f GHz\n[sadvio dbg] k_build:", (double)(ts[21] - ts[20]) / ((ts[15] - ts[0]) * 10.0));
             for (int i = 33; i < 43; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[32]) * 0.01);
+            fprintf(stderr, "\n[sadvio dbg] look-ahead workgroup of k_wchol_syrk_la, us since its start (loads landed, X slab in LDS | tiles updated | factored + inverted):");
+            fprintf(stderr, " %.2f %.2f %.2f", (ts[91] - ts[90]) * 0.01, (ts[94] - ts[90]) * 0.01, (ts[95] - ts[90]) * 0.01);
+            fprintf(stderr, " | waves after their tiles:"); for (int i = 98; i < 106; i++) fprintf(stderr, " %.2f", (ts[i] - ts[90]) * 0.01);
             fprintf(stderr, "\n[sadvio dbg] chol16 cycles since its first barrier (panel | trailing + next pivot, per block column):");
             for (int i = 65; i < 81; i++) fprintf(stderr, " %lld", ts[i] - ts[64]);
             fprintf(stderr, " | end %lld", ts[84] - ts[64]);

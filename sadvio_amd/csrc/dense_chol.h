@@ -883,18 +883,14 @@ constexpr int WD_T = WD / 16;   // 6 tile rows
 __host__ __device__ constexpr size_t wd16_lds_doubles() {
     return (size_t)c16_size(WD) + WD + C16_WORK + 16 * (WD_T + 1) + (size_t)(WD_T * (WD_T + 1) / 2) * 256 + (size_t)(SOLVE_THREADS / 64) * 256;
 }
+__device__ __forceinline__ void wd16_factor_and_invert(double* Im, double* __restrict__ y, double* __restrict__ Mg, int N, int c0, int* info);
 __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_diag16(double* __restrict__ A, long long ld, double* __restrict__ y,
                                                                 double* __restrict__ Mg, int N, int c0, int* info, const int* skip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
     if (*info != 0) return;
-    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6, nwv = SOLVE_THREADS / 64;
+    const int tid = threadIdx.x;
     double* Im = (double*)smem;                    // tile-packed image, WD columns + the right-hand-side row
-    double* xs = Im + c16_size(WD);
-    double* pub = xs + WD;
-    double* yv = pub + C16_WORK;
-    double* Mi = yv + 16 * (WD_T + 1);             // M = L^-1, tile (I, J), I >= J, at c16_tile(I, J) * 256
-    double* scr = Mi + (size_t)(WD_T * (WD_T + 1) / 2) * 256 + (size_t)wv * 256;
     // load: lower triangle of the block (identity beyond N), the rhs entries as row WD, zeros elsewhere
     for (int e = tid; e < c16_size(WD); e += SOLVE_THREADS) Im[e] = 0.0;
     __syncthreads();
@@ -916,6 +912,18 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_diag16(double* __restri
     }
     for (int j = tid; j < WD; j += SOLVE_THREADS) Im[c16_index(WD, j)] = (c0 + j < N) ? y[c0 + j] : 0.0;
     __syncthreads();
+    wd16_factor_and_invert(Im, y, Mg, N, c0, info);
+}
+
+// The image of a diagonal block (lower halves of the tiles + the right-hand-side row) -> its factor in place, the forward-substituted
+// right-hand side in y, M = L^-1 in Mg. The LDS carve behind the image is the one of k_wchol_diag16 (wd16_lds_doubles).
+__device__ __forceinline__ void wd16_factor_and_invert(double* Im, double* __restrict__ y, double* __restrict__ Mg, int N, int c0, int* info) {
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6, nwv = SOLVE_THREADS / 64;
+    double* xs = Im + c16_size(WD);
+    double* pub = xs + WD;
+    double* yv = pub + C16_WORK;
+    double* Mi = yv + 16 * (WD_T + 1);             // M = L^-1, tile (I, J), I >= J, at c16_tile(I, J) * 256
+    double* scr = Mi + (size_t)(WD_T * (WD_T + 1) / 2) * 256 + (size_t)wv * 256;
     c16_symmetrize(Im, WD_T + 1);
     __syncthreads();
     (void)c16_solve<1, false>(Im, WD, xs, pub, yv, nullptr);
@@ -991,6 +999,65 @@ __global__ __launch_bounds__(CH_THREADS) void k_wchol_trsm(double* __restrict__ 
         }
 }
 
+// The same with 512-thread workgroups for the look-ahead loop, where this kernel sits between two diagonal blocks: every global load of
+// the two slabs (30 per thread) is in flight before the first wait, and a wave takes three of the six column blocks of its 16 rows.
+__global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_trsm8(double* __restrict__ A, long long ld, const double* __restrict__ Mg,
+                                                               int N, int c0, const int* info, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    if (*info != 0) return;
+    const int s = c0 + WD;
+    const int r0 = s + blockIdx.x * CH_TS;
+    if (r0 >= N) return;
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    double (*Xa)[WDS] = (double (*)[WDS])smem;
+    double (*Ms)[WDS] = (double (*)[WDS])(smem + sizeof(double) * CH_TS * WDS);
+    {
+        constexpr int NXA = CH_TS * WD / SOLVE_THREADS, NM = WD * WD / SOLVE_THREADS;   // 12, 18
+        double vx[NXA], vm[NM];
+        const int valid = N - r0;
+#pragma unroll
+        for (int u = 0; u < NXA; u++) {
+            const int e = tid + u * SOLVE_THREADS;
+            const int r = e / WD, cc = e - r * WD;
+            vx[u] = r < valid ? A[(long long)(r0 + r) * ld + c0 + cc] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NM; u++) vm[u] = Mg[tid + u * SOLVE_THREADS];
+#pragma unroll
+        for (int u = 0; u < NXA; u++) { const int e = tid + u * SOLVE_THREADS; Xa[e / WD][e - (e / WD) * WD] = vx[u]; }
+#pragma unroll
+        for (int u = 0; u < NM; u++) { const int e = tid + u * SOLVE_THREADS; Ms[e / WD][e - (e / WD) * WD] = vm[u]; }
+    }
+    __syncthreads();
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int lr = ln & 15, lk = ln >> 4;
+    const int rb = wv & 3, cb0 = 3 * (wv >> 2);
+    d4 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int cb = cb0 + q;
+        d4 c4 = {0.0, 0.0, 0.0, 0.0}, c5 = {0.0, 0.0, 0.0, 0.0};
+        for (int kk = 0; kk < 16 * (cb + 1); kk += 16) {   // M is lower triangular: k <= column; 4 k-steps per batch of loads
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { av[u] = Xa[16 * rb + lr][kk + 4 * u + lk]; bv[u] = Ms[16 * cb + lr][kk + 4 * u + lk]; }
+            c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], c4, 0, 0, 0);
+            c5 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], c5, 0, 0, 0);
+            c4 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], c4, 0, 0, 0);
+            c5 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], c5, 0, 0, 0);
+        }
+        acc[q] = c4 + c5;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int row = r0 + 16 * rb + lk + 4 * rg;
+            if (row < N) A[(long long)row * ld + c0 + 16 * (cb0 + q) + lr] = acc[q][rg];
+        }
+}
+
 // trailing update by the WD-wide panel X and rhs row; K = WD
 __global__ __launch_bounds__(CH_THREADS) void k_wchol_syrk(double* __restrict__ A, long long ld, double* __restrict__ y, int N, int c0,
                                                            const int* info, const int* skip) {
@@ -1037,6 +1104,153 @@ __global__ __launch_bounds__(CH_THREADS) void k_wchol_syrk(double* __restrict__ 
         for (int rg = 0; rg < 4; rg++) {
             const int row = rbase + lk + 4 * rg, col = cbase + lr;
             ok[rg] = row < m && col < m && col <= row;
+            addr[rg] = (long long)(s + (row < m ? row : m - 1)) * ld + s + (col < m ? col : m - 1);
+            c[rg] = ok[rg] ? A[addr[rg]] : 0.0;
+        }
+        for (int kk = 0; kk < WD; kk += 24) {   // 6 k-steps per batch of LDS loads
+            double a[6], b[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++) { a[u] = -Pi[16 * ib + lr][kk + 4 * u + lk]; b[u] = Pj[16 * jb + lr][kk + 4 * u + lk]; }
+#pragma unroll
+            for (int u = 0; u < 6; u++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+            if (ok[rg]) A[addr[rg]] = c[rg];
+    }
+}
+
+// ---- trailing update + LOOK-AHEAD: the next diagonal block is factored inside the same launch ---------------------------------
+// The panel loop diag -> trsm -> syrk is a chain of single-workgroup diagonal kernels (33 us each, half of the solve) with two wide
+// kernels between them. Here the last workgroup of the trailing update takes the NEXT diagonal block: it applies this panel's update to
+// it itself (X_next X_next^T from the panel rows the preceding k_wchol_trsm left, 96 x 96 x 96 on the matrix cores, and the right-hand
+// side), then factors and inverts it (wd16_factor_and_invert) while the other workgroups update the rest of the trailing matrix;
+// they leave the elements of that block and its right-hand-side rows alone. 512-thread workgroups: a 64 x 64 tile is 8 waves x 2
+// sub-tiles. LDS: max(two 64 x 96 slabs, the image + the 96 x 96 slab of X_next, over which M is built later).
+constexpr int WXS = 113;   // row stride of the transposed X_next slab of the look-ahead workgroup (see there)
+__host__ __device__ constexpr size_t wdla_lds_doubles() { return wd16_lds_doubles() + (size_t)WD * WXS - (size_t)(WD_T * (WD_T + 1) / 2 + SOLVE_THREADS / 64) * 256; }
+__global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_syrk_la(double* __restrict__ A, long long ld, double* __restrict__ y, double* __restrict__ Mg_next,
+                                                                 int N, int c0, int* info, const int* skip, long long* dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    if (*info != 0) return;
+    const int s = c0 + WD;
+    const int m = N - s;
+    if (m <= 0) return;
+    const int nt = (m + CH_TS - 1) / CH_TS;
+    const int npair = nt * (nt + 1) / 2;
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int lr = ln & 15, lk = ln >> 4;
+    const int bid = (int)blockIdx.x - 1;   // workgroup 0 is dispatched first: the look-ahead block, the longest chain of the launch
+    if (bid < 0) {
+        // ---- the next diagonal block [s, s + WD) ----
+        double* Im = (double*)smem;
+        // X_next TRANSPOSED, XT[panel column][block row], with the panel's right-hand side as block row WD (rows WD + 1 .. WD + 15 zero):
+        // the MFMA fragments (16 consecutive block rows of one column per 16-lane group) are contiguous 128-byte reads, and the
+        // right-hand-side update is the seventh tile row of the same product - as in chol16. Row stride WXS = 113 doubles: 16 consecutive
+        // columns of one block row (what a wave stores from its unit-stride HBM reads) fall into 16 different bank pairs. (Row-major with
+        // the stride of the trsm / syrk slabs the compiler's ds_read2_b64 pairs hit four bank pairs per 16 lanes: 9.4 us for the tile
+        // updates.) M and the scratch tiles reuse the area later.
+        double (*XT)[WXS] = (double (*)[WXS])(Im + c16_size(WD) + WD + C16_WORK + 16 * (WD_T + 1));
+        if (dbg && tid == 0) dbg[0] = wall_clock64();
+        // every global load of the prologue is issued before the first wait: X_next = the panel rows s .. s + WD (18 per thread, unit
+        // stride), the panel's right-hand side, and this wave's tiles of the block itself straight in the accumulator layout (register q of
+        // lane (lr, lk) = element (lk + 4 q, lr): 128-byte row segments), which spares a staging pass through LDS. Addresses are clamped
+        // into the stored triangle and the values selected afterwards: no branch around a load.
+        constexpr int NX = WD * WD / SOLVE_THREADS, NTL = WD_T * (WD_T + 1) / 2 + WD_T, NW = SOLVE_THREADS / 64, TPW = (NTL + NW - 1) / NW;
+        double vx[NX];
+#pragma unroll
+        for (int u = 0; u < NX; u++) {
+            const int e = tid + u * SOLVE_THREADS;
+            const int r = e / WD, c = e - r * WD;
+            const double v = A[(long long)min(s + r, N - 1) * ld + c0 + c];
+            vx[u] = (s + r < N) ? v : 0.0;
+        }
+        const double vy = y[c0 + min(tid, WD - 1)];
+        d4 acc0[TPW];
+#pragma unroll
+        for (int w = 0; w < TPW; w++) {
+            const int t = min(wv + w * NW, NTL - 1);
+            int I = 0, r = t;
+            while (r >= I + 1) { r -= I + 1; I++; }          // t < 21: lower tile (I, J) of the block; t = 21 + J: the right-hand-side tile (WD_T, J)
+            const int J = r;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 16 * I + lk + 4 * q, j = 16 * J + lr;
+                const double v = A[(long long)min(s + i, N - 1) * ld + s + min(j, i)];
+                const double vr = y[min(s + j, N - 1)];
+                acc0[w][q] = I == WD_T ? ((lk + 4 * q == 0 && s + j < N) ? vr : 0.0) : (j <= i ? ((s + i < N) ? v : (i == j ? 1.0 : 0.0)) : 0.0);
+            }
+        }
+        for (int e = tid; e < 256; e += SOLVE_THREADS) Im[(c16_tile(WD_T, WD_T) << 8) + e] = 0.0;   // the tile behind the right-hand side's last column block
+        for (int e = tid; e < 15 * WD; e += SOLVE_THREADS) XT[e / 15][WD + 1 + e % 15] = 0.0;
+#pragma unroll
+        for (int u = 0; u < NX; u++) { const int e = tid + u * SOLVE_THREADS; XT[e - (e / WD) * WD][e / WD] = vx[u]; }
+        if (tid < WD) XT[tid][WD] = vy;
+        __syncthreads();
+        if (dbg && tid == 0) dbg[1] = wall_clock64();
+        // image tile (I, J) = block tile (right-hand-side tile) - sum_K X(I, K) X(J, K)^T: the 48 operand fragments of a tile are fetched
+        // before its 24 MFMAs (two chains)
+#pragma unroll
+        for (int w = 0; w < TPW; w++) {
+            const int t = wv + w * NW;
+            if (t >= NTL) break;
+            int I = 0, r = t;
+            while (r >= I + 1) { r -= I + 1; I++; }
+            const int J = r;
+            double a[4 * WD_T], b[4 * WD_T];
+#pragma unroll
+            for (int k4 = 0; k4 < 4 * WD_T; k4++) { a[k4] = -XT[4 * k4 + lk][16 * I + lr]; b[k4] = XT[4 * k4 + lk][16 * J + lr]; }
+            d4 acc = acc0[w], acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k4 = 0; k4 < 4 * WD_T; k4 += 2) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k4], b[k4], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k4 + 1], b[k4 + 1], acc2, 0, 0, 0);
+            }
+            double* ct = Im + (c16_tile(I, J) << 8);
+#pragma unroll
+            for (int q = 0; q < 4; q++) ct[lr * 16 + lk + 4 * q] = acc[q] + acc2[q];   // register q of lane (lr, lk) = C[lk + 4 q][lr]
+        }
+        if (dbg && ln == 0) dbg[8 + wv] = wall_clock64();
+        __syncthreads();
+        if (dbg && tid == 0) dbg[4] = wall_clock64();
+        wd16_factor_and_invert(Im, y, Mg_next, N, s, info);
+        if (dbg && tid == 0) dbg[5] = wall_clock64();
+        return;
+    }
+    if (bid >= npair) {
+        const int j = (bid - npair) * SOLVE_THREADS + tid;
+        if (j < m && j >= WD) {          // the first WD rows belong to the look-ahead workgroup
+            const double* xrow = A + (long long)(s + j) * ld + c0;
+            double acc = 0.0;
+#pragma unroll 8
+            for (int cc = 0; cc < WD; cc++) acc += y[c0 + cc] * xrow[cc];
+            y[s + j] -= acc;
+        }
+        return;
+    }
+    double (*Pi)[WDS] = (double (*)[WDS])smem;
+    double (*Pj)[WDS] = (double (*)[WDS])(smem + sizeof(double) * CH_TS * WDS);
+    int ti = 0, rem = bid;
+    while (rem >= ti + 1) { rem -= ti + 1; ti++; }
+    const int tj = rem;
+    const int i0 = ti * CH_TS, j0 = tj * CH_TS;
+    stage_slab(Pi, A + (long long)(s + i0) * ld + c0, ld, CH_TS, m - i0);
+    stage_slab(Pj, A + (long long)(s + j0) * ld + c0, ld, CH_TS, m - j0);
+    __syncthreads();
+    const int ib = wv & 3;
+    for (int jb = 2 * (wv >> 2); jb < 2 * (wv >> 2) + 2; jb++) {
+        if (ti == tj && jb > ib) continue;
+        const int rbase = i0 + 16 * ib, cbase = j0 + 16 * jb;
+        if (rbase >= m || cbase >= m) continue;
+        d4 c;
+        long long addr[4];
+        bool ok[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int row = rbase + lk + 4 * rg, col = cbase + lr;
+            ok[rg] = row < m && col < m && col <= row && !(row < WD && col < WD);   // (the look-ahead workgroup's block)
             addr[rg] = (long long)(s + (row < m ? row : m - 1)) * ld + s + (col < m ? col : m - 1);
             c[rg] = ok[rg] ? A[addr[rg]] : 0.0;
         }
