@@ -2077,6 +2077,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
 //               per element, plain read-modify-write: nothing else touches S between k_build and k_solve)
 //   k_prior_m   after the step: m = J delta (one wave per row) -> model cost change / candidate cost of the slot
 // dp_data layout per window: J | J^T | J^T J | r0 | dx | r | cost(1).
+constexpr int DP_LDS_N = 2048;   // prior variables whose gathered deltas are staged in LDS by k_prior_r / k_prior_m (16 KB); larger priors gather per row
 __device__ __forceinline__ double* dp_ptr(const DevPtrs& P, const WinDev& W, int which) {
     const size_t nf = W.dp_n_full, n = W.dp_n;
     double* D = P.dp_data + W.dp_off;
@@ -2100,19 +2101,40 @@ __global__ __launch_bounds__(256) void k_prior_r(DevPtrs P, int slot) {
     const int n = W.dp_n, nf = W.dp_n_full, ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wv;
     __shared__ double s_c[4];
+    __shared__ double dxs[DP_LDS_N];   // the gathered dx of the window (kind -> index -> delta array: two dependent loads), once per workgroup
     double c = 0.0;
-    if (i < nf) {
-        const double* J = dp_ptr(P, W, 0);
-        const int* kind = P.dp_ints + W.dp_int_off;
-        const int* index = kind + n;
-        const int cur = st.cur;
-        const double* srcs[5] = {P.xp + (long long)cur * P.xp_stride, P.xv + (long long)cur * P.xv_stride, P.xba + (long long)cur * P.xv_stride,
-                                 P.xbg + (long long)cur * P.xv_stride, P.xl + (long long)cur * P.xl_stride};
-        double s = 0.0;
-        for (int a = ln; a < n; a += 64) {
+    const int* kind = P.dp_ints + W.dp_int_off;
+    const int* index = kind + n;
+    const int cur = st.cur;
+    const double* srcs[5] = {P.xp + (long long)cur * P.xp_stride, P.xv + (long long)cur * P.xv_stride, P.xba + (long long)cur * P.xv_stride,
+                             P.xbg + (long long)cur * P.xv_stride, P.xl + (long long)cur * P.xl_stride};
+    const bool staged = n <= DP_LDS_N;
+    if (staged) {
+#pragma unroll 4
+        for (int a = threadIdx.x; a < n; a += 256) {
             const int k = kind[a];
-            const double dx = k < 0 ? 0.0 : srcs[k][index[a]];
-            s += J[(size_t)i * n + a] * dx;
+            dxs[a] = k < 0 ? 0.0 : srcs[max(k, 0)][index[a]];
+        }
+        __syncthreads();
+    }
+    if (i < nf) {
+        const double* Jr = dp_ptr(P, W, 0) + (size_t)i * n;
+        double s = 0.0;
+        if (staged) {
+            double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int a = ln;
+            for (; a + 192 < n; a += 256) {   // four row loads in flight per lane
+                const double j0 = Jr[a], j1 = Jr[a + 64], j2 = Jr[a + 128], j3 = Jr[a + 192];
+                s += j0 * dxs[a]; s1 += j1 * dxs[a + 64]; s2 += j2 * dxs[a + 128]; s3 += j3 * dxs[a + 192];
+            }
+            for (; a < n; a += 64) s += Jr[a] * dxs[a];
+            s = (s + s1) + (s2 + s3);
+        } else {
+            for (int a = ln; a < n; a += 64) {
+                const int k = kind[a];
+                const double dx = k < 0 ? 0.0 : srcs[k][index[a]];
+                s += Jr[a] * dx;
+            }
         }
         s = wave_sum(s);
         if (ln == 0) { s += dp_ptr(P, W, 3)[i]; dp_ptr(P, W, 5)[i] = s; c = s * s; }
@@ -2165,14 +2187,35 @@ __global__ __launch_bounds__(256) void k_prior_m(DevPtrs P, int slot) {
     const int i = blockIdx.x * 4 + wv;
     __shared__ double s_m[4], s_c[4];
     double mc = 0.0, cc = 0.0;
-    if (i < nf) {
-        const double* J = dp_ptr(P, W, 0);
-        const int* col = P.dp_ints + W.dp_int_off + 2 * n;
-        const double* dl = P.delta + W.red_off;
-        double m = 0.0;
-        for (int a = ln; a < n; a += 64) {
+    __shared__ double dls[DP_LDS_N];   // the step of every prior variable (col -> delta), gathered once per workgroup
+    const int* col = P.dp_ints + W.dp_int_off + 2 * n;
+    const double* dl = P.delta + W.red_off;
+    const bool staged = n <= DP_LDS_N;
+    if (staged) {
+#pragma unroll 4
+        for (int a = threadIdx.x; a < n; a += 256) {
             const int ca = col[a];
-            if (ca >= 0) m += J[(size_t)i * n + a] * dl[ca];
+            dls[a] = ca >= 0 ? dl[max(ca, 0)] : 0.0;
+        }
+        __syncthreads();
+    }
+    if (i < nf) {
+        const double* Jr = dp_ptr(P, W, 0) + (size_t)i * n;
+        double m = 0.0;
+        if (staged) {
+            double m1 = 0.0, m2 = 0.0, m3 = 0.0;
+            int a = ln;
+            for (; a + 192 < n; a += 256) {
+                const double j0 = Jr[a], j1 = Jr[a + 64], j2 = Jr[a + 128], j3 = Jr[a + 192];
+                m += j0 * dls[a]; m1 += j1 * dls[a + 64]; m2 += j2 * dls[a + 128]; m3 += j3 * dls[a + 192];
+            }
+            for (; a < n; a += 64) m += Jr[a] * dls[a];
+            m = (m + m1) + (m2 + m3);
+        } else {
+            for (int a = ln; a < n; a += 64) {
+                const int ca = col[a];
+                if (ca >= 0) m += Jr[a] * dl[ca];
+            }
         }
         m = wave_sum(m);
         if (ln == 0) { const double r = dp_ptr(P, W, 5)[i]; mc = -m * (r + 0.5 * m); cc = (r + m) * (r + m); }
