@@ -262,12 +262,21 @@ int main(int argc, char** argv) {
         if (sparsif) perturb(m, 4);
         double before = 0, worst = 0;
         for (size_t i = 0; i < m.frames.size(); i++) before = std::fmax(before, pose_err(m.frames[i].T_f_w, truth.frames[i].T_f_w));
-        for (int rep = 0; rep < (sparsif ? 4 : 1); rep++) opt.localMapBA(m, 0);   // no fixed frame: only the prior anchors the window
+        bool failed = false;
+        for (int rep = 0; rep < (sparsif ? 4 : 1); rep++) {
+            opt.localMapBA(m, 0);   // no fixed frame: only the prior anchors the window
+            if (rep == 0) failed = opt.summary().termination == SADVIO_TERM_FAILURE;
+        }
         for (size_t i = 0; i < m.frames.size(); i++) worst = std::fmax(worst, pose_err(m.frames[i].T_f_w, truth.frames[i].T_f_w));
         std::printf("   pose err %.3e -> %.3e (prior rows %d, sparse factors %zu, cost %.3e)\n", before, worst, opt.prior_rows(), opt.sparse_factor_count(), opt.summary().final_cost);
         // (the landmark chain may leave a weakly constrained direction: links whose marginal covariance has an eigenvalue below
         //  the 1e-12 cut drop it, marginalization.cpp:485,505 -- the window is pulled back, not necessarily to 1e-6)
-        check((sparsif ? worst < 0.3 * before : worst < 1e-6) && opt.summary().termination != SADVIO_TERM_FAILURE,
+        // Only the FIRST solve is required not to fail: the later repetitions start within 1e-10 of the converged point of a window whose
+        // gauge is held by the prior alone (condition number ~1e10 along the landmark chain, see below). There the model cost change
+        // of a step is rounding noise around zero, Ceres' `!(model_cost_change > 0)` makes it an invalid step, and five of them in a
+        // row end the solve with FAILURE - or not, depending on the summation order of the device's atomics (2 runs in 16). The
+        // adapter then leaves the state where it was (5e-11 instead of 3e-15 from the truth).
+        check((sparsif ? worst < 0.3 * before : worst < 1e-6) && !failed,
               sparsif ? "window anchored by the sparsified prior is pulled back towards the ground truth" : "gauge-free window + dense prior: usable solve, state stays at the converged point");
     }
     {
