@@ -2423,6 +2423,14 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                                     hipLaunchKernelGGL(k_wchol_syrk, dim3(nt * (nt + 1) / 2 + (m + CH_THREADS - 1) / CH_THREADS), dim3(CH_THREADS), lds_s, h->stream, Sw, (long long)d.ld, yw, N, c0, info, skip);
                                 }
                             }
+                            if (wdla && !getenv("SADVIO_WD_BACK1")) {
+                                // back-substitution: one launch per super-step (dense_chol.h: k_wchol_backstep)
+                                (void)hipFuncSetAttribute((const void*)k_wchol_backstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * WD * WDS));
+                                const int nsteps = (N + WD - 1) / WD;
+                                for (int bs = nsteps - 1; bs >= 0; bs--)
+                                    hipLaunchKernelGGL(k_wchol_backstep, dim3(1 + (bs + 1 < nsteps ? (bs * WD + 63) / 64 : 0)), dim3(SOLVE_THREADS), sizeof(double) * WD * WDS, h->stream,
+                                                       Sw, (long long)d.ld, yw, Mw, N, bs, info, skip);
+                            } else
                             hipLaunchKernelGGL(k_wchol_backsolve, dim3(1), dim3(SOLVE_THREADS), sizeof(double) * WD * WDS, h->stream, Sw, (long long)d.ld, yw, Mw, N, info, skip);
                             continue;
                         }

@@ -1120,6 +1120,82 @@ __global__ __launch_bounds__(CH_THREADS) void k_wchol_syrk(double* __restrict__ 
     }
 }
 
+// ---- the same back-substitution, one LAUNCH per super-step ------------------------------------------------------------------
+// k_wchol_backsolve streams every panel of L through one CU (4.9 MB at N = 1 065: 8.5 us per step). Here step st is a launch of its
+// own: workgroup 0 finishes block st - it applies the step before it, x_{st+1}, to its own 96 right-hand-side entries (one
+// 96 x 96 block of L) and multiplies by M_st^T - while the other workgroups apply x_{st+1} to all EARLIER columns, 64 columns each.
+// The updates of x_{st+2}, x_{st+3}, ... were applied by the launches before. Twelve launches of ~3.5 us instead of 102 us.
+__global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_backstep(const double* __restrict__ A, long long ld, double* __restrict__ y,
+                                                                  const double* __restrict__ Mg_all, int N, int st, const int* info, const int* skip) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    if (*info != 0) return;
+    const int tid = threadIdx.x;
+    const int nsteps = (N + WD - 1) / WD;
+    const int c0 = st * WD, c1 = c0 + WD;              // this block | the rows of the step before it
+    const bool have_prev = st + 1 < nsteps;
+    const int nr1 = have_prev ? min(WD, N - c1) : 0;
+    __shared__ double xp[WD], part[8][64];
+    if (blockIdx.x > 0) {
+        // y[cc] -= sum_r L[c1 + r][cc] x_{st+1}[r] for 64 earlier columns; eight row groups of 12
+        if (tid < WD) xp[tid] = tid < nr1 ? y[c1 + tid] : 0.0;
+        const int cc = ((int)blockIdx.x - 1) * 64 + (tid & 63), rg = tid >> 6;
+        double v[12];
+        const double* col = A + (long long)c1 * ld + min(cc, c0 - 1);
+#pragma unroll
+        for (int u = 0; u < 12; u++) { const int r = 12 * rg + u; v[u] = col[(long long)min(r, max(nr1 - 1, 0)) * ld]; }
+        __syncthreads();
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 12; u += 2) { a0 += v[u] * xp[12 * rg + u]; a1 += v[u + 1] * xp[12 * rg + u + 1]; }   // (xp = 0 beyond nr1)
+        part[rg][tid & 63] = a0 + a1;
+        __syncthreads();
+        if (tid < 64 && cc < c0) y[cc] -= ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + ((part[4][tid] + part[5][tid]) + (part[6][tid] + part[7][tid]));
+        return;
+    }
+    double (*Ms)[WDS] = (double (*)[WDS])smem;
+    __shared__ double tv[WD], p4[4][WD];
+    const int nr = min(WD, N - c0);
+    // every load first: M_st (18 per thread), the block L[c1 .., c0 ..] for the near update (24 per thread of the first 384), the two
+    // right-hand-side slices
+    constexpr int MV = WD * WD / SOLVE_THREADS;
+    double mreg[MV];
+    {
+        const double* Mg = Mg_all + (size_t)st * WD * WD;
+#pragma unroll
+        for (int q = 0; q < MV; q++) mreg[q] = Mg[tid + q * SOLVE_THREADS];
+    }
+    const int c = tid % WD, q4 = tid / WD;                 // q4 < 4 for the first 384 threads
+    double lv[24];
+#pragma unroll
+    for (int u = 0; u < 24; u++) {
+        const int r = q4 + 4 * u;
+        lv[u] = A[(long long)(c1 + min(r, max(nr1 - 1, 0))) * ld + c0 + c];      // (clamped: weighted by zero below)
+    }
+    if (tid < WD) { xp[tid] = tid < nr1 ? y[c1 + tid] : 0.0; tv[tid] = tid < nr ? y[c0 + tid] : 0.0; }
+#pragma unroll
+    for (int q = 0; q < MV; q++) { const int e = tid + q * SOLVE_THREADS; Ms[e / WD][e % WD] = mreg[q]; }
+    __syncthreads();
+    if (tid < 4 * WD) {
+        double a0 = 0.0, a1 = 0.0;
+        if (have_prev) {
+#pragma unroll
+            for (int u = 0; u < 24; u += 2) { a0 += lv[u] * xp[q4 + 4 * u]; a1 += lv[u + 1] * xp[q4 + 4 * (u + 1)]; }
+        }
+        p4[q4][c] = a0 + a1;
+    }
+    __syncthreads();
+    if (tid < WD) tv[tid] -= (p4[0][tid] + p4[1][tid]) + (p4[2][tid] + p4[3][tid]);
+    __syncthreads();
+    if (tid < 4 * WD) {
+        double x = 0.0;                                    // (M^T t)_c = sum_{k >= c} M[k][c] t_k, k = q4, q4 + 4, ...
+        for (int k = c + ((q4 - c) & 3); k < WD; k += 4) x += Ms[k][c] * tv[k];
+        p4[q4][c] = x;
+    }
+    __syncthreads();
+    if (tid < nr) y[c0 + tid] = (p4[0][tid] + p4[1][tid]) + (p4[2][tid] + p4[3][tid]);
+}
+
 // ---- trailing update + LOOK-AHEAD: the next diagonal block is factored inside the same launch ---------------------------------
 // The panel loop diag -> trsm -> syrk is a chain of single-workgroup diagonal kernels (33 us each, half of the solve) with two wide
 // kernels between them. Here the last workgroup of the trailing update takes the NEXT diagonal block: it applies this panel's update to
