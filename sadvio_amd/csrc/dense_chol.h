@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_backstep(const double* 
 #pragma unroll
     for (int u = 0; u < 24; u++) {
         const int r = q4 + 4 * u;
-        lv[u] = A[(long long)(c1 + min(r, max(nr1 - 1, 0))) * ld + c0 + c];      // (clamped: weighted by zero below)
+        lv[u] = A[(long long)(have_prev ? c1 + min(r, nr1 - 1) : c0) * ld + min(c0 + c, N - 1)];      // (clamped into the matrix: weighted by zero below; the last block has no rows behind it)
     }
     if (tid < WD) { xp[tid] = tid < nr1 ? y[c1 + tid] : 0.0; tv[tid] = tid < nr ? y[c0 + tid] : 0.0; }
 #pragma unroll
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_syrk_la(double* __restr
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int i = 16 * I + lk + 4 * q, j = 16 * J + lr;
-                const double v = A[(long long)min(s + i, N - 1) * ld + s + min(j, i)];
+                const double v = A[(long long)min(s + i, N - 1) * ld + min(s + min(j, i), N - 1)];
                 const double vr = y[min(s + j, N - 1)];
                 acc0[w][q] = I == WD_T ? ((lk + 4 * q == 0 && s + j < N) ? vr : 0.0) : (j <= i ? ((s + i < N) ? v : (i == j ? 1.0 : 0.0)) : 0.0);
             }
