@@ -114,3 +114,13 @@ def test_vo_prior_hbm_path(backend_cls, oracle_lib):
     w = synthetic.make_window(n_kf=5, n_lmk=600, seed=35)
     w.dense_prior = random_prior(w, 250, -1, np.random.default_rng(9), rank_deficit=0)
     compare(backend_cls, oracle_lib, w, capi.reference_options())
+
+
+@pytest.mark.parametrize("n_keep", [39, 70, 71, 72, 103])
+def test_dense_reduced_system_edge_sizes(backend_cls, oracle_lib, n_keep):
+    """The wide-panel dense solver (look-ahead panel loop, per-step back-substitution) at N_p = 75 + 3 n_keep = 192 (two panels
+    exactly), 285 / 288 / 291 (three short of / exactly / three beyond a multiple of the 96-column panel) and 384: the last
+    block's clamped loads sit at the end of the matrix (a fault found on a window at the end of the S allocation)."""
+    w = make_vio_window(n_kf=6, n_lmk=900, seed=100 + n_keep)
+    w.dense_prior = random_prior(w, n_keep, w.n_kf - 2, np.random.default_rng(n_keep), rank_deficit=3)
+    compare(backend_cls, oracle_lib, w, capi.reference_options(), vio=True)
