@@ -34,6 +34,32 @@ def test_landmark_ranges_ragged_and_degenerate():
     assert sharding.landmark_ranges(np.array([0], dtype=np.int32), 3) == [(0, 0)] * 3  # no landmarks at all
 
 
+def test_sparsified_prior_follows_its_landmarks():
+    """shard_window: the IMUPriordx factor of a sparsified VIO prior is replicated, every PoseToLandmarkFactor goes to the owner of
+    its landmark with the index re-based to the shard; landmark-holding factor types are refused (sadvio_ba.h)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from sparse_helpers import vio_sparse_priors
+    from vio_helpers import make_vio_window
+    w = make_vio_window(n_kf=5, n_lmk=90, seed=4)
+    kept = list(range(0, 90, 3))
+    w.sparse_priors = vio_sparse_priors(w, w.n_kf - 2, kept, np.random.default_rng(2), noise=0.01)
+    world = 3
+    rg = sharding.landmark_ranges(w.lmk_obs_ptr, world)
+    seen = []
+    for r in range(world):
+        sh = sharding.shard_window(w, r, world)
+        assert sum(1 for f in sh.sparse_priors if f["type"] == 0) == 1          # replicated on every rank
+        for f in sh.sparse_priors:
+            if f["type"] == 1:
+                assert 0 <= f["lmk0"] < sh.n_lmk
+                seen.append(rg[r][0] + f["lmk0"])
+    assert sorted(seen) == kept                                                  # each pose-to-landmark factor exactly once
+    bad = dict(w.sparse_priors[1]); bad["type"] = 2
+    w.sparse_priors = [bad]
+    with pytest.raises(ValueError):
+        sharding.shard_window(w, 0, 2)
+
+
 def test_shards_concatenate_back_to_the_window():
     w = synthetic.make_window(n_kf=5, n_lmk=101, seed=9)
     parts = [sharding.shard_window(w, r, 3) for r in range(3)]
