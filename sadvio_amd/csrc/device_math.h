@@ -597,7 +597,7 @@ __device__ __forceinline__ void imu_factor_body(const ImuT& f, const double* Ti0
 }
 
 // Out-of-line copy for the big kernels (k_solve, k_marg_small: inlining it there costs more registers than the call);
-// k_imu_eval inlines the body into a 64-lane kernel where everything stays in registers.
+// imu_pair_eval (kernels.h) inlines the body into one wave where everything stays in registers.
 template <typename ImuT, bool WHITEN = true>
 __device__ __noinline__ void imu_factor(const ImuT& f, const double* Ti0, const double* Tj0, const double* vi0,
                                         const double* vj0, const double* dpi, const double* dpj, const double* dvi,

@@ -1393,7 +1393,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     // whose order depends on wave scheduling.
     const bool det = P.world > 1;
     if (MODE != 2) {
-    // IMUFactor + IMUBiasFactor (K3): k_imu_eval<true> (one 64-lane workgroup per factor, beside k_build) left every entry the
+    // IMUFactor + IMUBiasFactor (K3): imu_pair_eval<false> (one wave per factor pair, an extra workgroup of k_build) left every entry the
     // pair adds to the reduced system, with its position, in the factor's scratch row (ba_types.h). Item = (factor, entry); the
     // first eight items of every thread are fetched here, with the image
     double im_ix[8], im_v[8];
@@ -1841,7 +1841,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
             mcc += -m * (r + 0.5 * m);
         }
-        // candidate cost of the IMU factors: k_imu_eval<false>, launched after this kernel, adds it to acc->cand_cost
+        // candidate cost of the IMU factors: imu_pair_eval<true> (extra workgroups of k_backsub, after this kernel) adds it to acc->cand_cost
     }
     if (EXTRAS && W.spl_end > W.spl_begin) {
         // model cost change, item = (listed factor, residual row), dealt from the fifth wave upwards (see the IMU items); the row holds
@@ -2657,7 +2657,7 @@ __device__ __forceinline__ void pose_factor_eval(const DevPtrs& P, int slot, int
 template <bool COST_ONLY>
 __global__ __launch_bounds__(64) void k_pf_eval(DevPtrs P, int slot) { pose_factor_eval<COST_ONLY>(P, slot, blockIdx.x, threadIdx.x); }
 
-// linexd observations, one 64-lane workgroup per observation, same split as k_sparse_eval: LIN -> J (rows x 12:
+// linexd observations, one 64-lane workgroup per observation, kernels of their own on a side stream: LIN -> J (rows x 12:
 // key-frame | line), r, loss-corrected cost and the in-program flag into the scratch row at x; !LIN -> cost at the candidate
 // (k_solve left the candidate key-frame and line deltas in the other buffer). Lines are few (tens per window).
 template <bool LIN>
