@@ -10,6 +10,7 @@ path, for which the reference holds no golden vector:
                          AngularErrCeres_pointxd_dx::Evaluate       cpp/include/isaeslam/optimizers/AngularAdjustmentCERESAnalytic.h:55-111
                          PosePriordx::Evaluate                      cpp/include/isaeslam/optimizers/residuals.hpp:607-628
                          IMUPriordx / PoseToLandmarkFactor / Landmark3DPrior / LandmarkToLandmarkFactor   residuals.hpp:506-700
+                         IMUFactor / IMUBiasFactor::Evaluate (the VIO window of localMapVIOptimization)      residuals.hpp:133-296
                          MarginalizationFactor::Evaluate            cpp/include/isaeslam/optimizers/marginalization.hpp:113-215
                          Marginalization::computeSchurComplement / rankReveallingDecomposition / computeJacobiansAndResiduals /
                          sparsifyVIO / sparsifyVO (the factor informations)   cpp/src/optimizers/marginalization.cpp:213-265,318-342,362-530
@@ -310,6 +311,83 @@ def imu_prior_factor(B, T_f_w0, v0, ba0, bg0, T_prior, v_prior, ba_prior, bg_pri
     return r, J
 
 
+def chol_lower(B, A):
+    """L (lower) with A = L L^T — Eigen::LLT::matrixL()."""
+    n = A.shape[0]
+    L = B.zeros((n, n))
+    for j in range(n):
+        d = A[j, j] - sum(L[j, k] * L[j, k] for k in range(j))
+        L[j, j] = B.sqrt(d)
+        for i in range(j + 1, n):
+            L[i, j] = (A[i, j] - sum(L[i, k] * L[j, k] for k in range(j))) / L[j, j]
+    return L
+
+
+GRAVITY = (0.0, 0.0, -9.81)                                       # `g`, cpp/include/isaeslam/data/sensors/IMU.h:8
+
+
+def imu_factor(B, f, T_fi_w0, T_fj_w0, v_i0, v_j0, dpose_i, dpose_j, dv_i, dv_j, dba, dbg):
+    """IMUFactor::Evaluate (residuals.hpp:137-241): r[9] and the six Jacobian blocks [pose_i 9x6, pose_j 9x6, v_i 9x3, v_j 9x3, ba_i 9x3,
+    bg_i 9x3], whitened by inf_sqrt = LLT(cov^-1).matrixL()^T (:151-154). `f`: the pre-integration of frame j (delta_R / delta_v /
+    delta_p, the five bias Jacobians, cov 9x9, dt). As coded: the pose_i translation block is the UNPERTURBED R_i0 (:185), the
+    pose_i rotation block of r_dp uses p_j - v_i dt - g dt^2 / 2 without p_i (:181-184), pose_j's translation block is
+    -R_i exp(w_j)^T (:198)."""
+    g = B.a(GRAVITY)
+    Ri0, ti0 = split_T(B, T_fi_w0); Rj0, tj0 = split_T(B, T_fj_w0)
+    dpi, dpj = B.a(dpose_i), B.a(dpose_j)
+    Ri = Ri0 @ exp_so3(B, dpi[:3]); ti = Ri0 @ dpi[3:6] + ti0       # T_fi_w = T0 * (exp w, t)   (:140-143)
+    Rj = Rj0 @ exp_so3(B, dpj[:3]); tj = Rj0 @ dpj[3:6] + tj0
+    vi = B.a(v_i0) + B.a(dv_i); vj = B.a(v_j0) + B.a(dv_j)          # :144-145
+    dba, dbg = B.a(dba), B.a(dbg)
+    dt = B.s(f["dt"])
+    cov = B.a(np.asarray(f["cov"], dtype=np.float64).reshape(9, 9))
+    W = chol_lower(B, _inverse(B, cov)).T                           # :151-154
+    DR = B.a(np.asarray(f["delta_R"], dtype=np.float64).reshape(3, 3))
+    Dv = B.a(np.asarray(f["delta_v"], dtype=np.float64)); Dp = B.a(np.asarray(f["delta_p"], dtype=np.float64))
+    JRg = B.a(np.asarray(f["J_dR_bg"], dtype=np.float64).reshape(3, 3))
+    Jva = B.a(np.asarray(f["J_dv_ba"], dtype=np.float64).reshape(3, 3)); Jvg = B.a(np.asarray(f["J_dv_bg"], dtype=np.float64).reshape(3, 3))
+    Jpa = B.a(np.asarray(f["J_dp_ba"], dtype=np.float64).reshape(3, 3)); Jpg = B.a(np.asarray(f["J_dp_bg"], dtype=np.float64).reshape(3, 3))
+    dR = (DR @ exp_so3(B, JRg @ dbg)).T @ Ri @ Rj.T                 # :157-158
+    r_dr = log_so3(B, dR)
+    pi = -(inv3(B, Ri) @ ti); pj = -(inv3(B, Rj) @ tj)              # T.inverse().translation() of an Eigen::Affine3d
+    r_dv = Ri @ (vj - vi - g * dt) - (Dv + Jvg @ dbg + Jva @ dba)   # :160-161
+    r_dp = Ri @ (pj - pi - vi * dt - g * (dt * dt) / 2) - (Dp + Jpg @ dbg + Jpa @ dba)   # :162-164
+    r = W @ np.concatenate([r_dr, r_dv, r_dp])
+    Jri = inv3(B, so3_right_jacobian(B, r_dr))
+    Jwi = so3_right_jacobian(B, dpi[:3]); Jwj = so3_right_jacobian(B, dpj[:3])
+    Ji = B.zeros((9, 6))                                             # :174-187
+    Ji[0:3, 0:3] = Jri @ Rj @ Jwi
+    Ji[3:6, 0:3] = -(Ri @ skew(B, vj - vi - g * dt) @ Jwi)
+    Ji[6:9, 0:3] = -(Ri @ skew(B, pj - vi * dt - g * (dt * dt) / 2) @ Jwi)
+    Ji[6:9, 3:6] = Ri0
+    Jj = B.zeros((9, 6))                                             # :190-200
+    Jj[0:3, 0:3] = -(Jri @ Rj @ Jwj)
+    Jj[6:9, 0:3] = -(Ri @ Rj.T @ skew(B, tj) @ Rj @ Jwj)
+    Jj[6:9, 3:6] = -(Ri @ exp_so3(B, dpj[:3]).T)
+    Jvi = B.zeros((9, 3)); Jvi[3:6] = -Ri; Jvi[6:9] = -(Ri * dt)     # :203-209
+    Jvj = B.zeros((9, 3)); Jvj[3:6] = Ri                             # :212-217
+    Jba = B.zeros((9, 3)); Jba[3:6] = -Jva; Jba[6:9] = -Jpa          # :220-226
+    Jbg = B.zeros((9, 3))                                            # :229-237
+    Jbg[0:3] = -(Jri @ dR.T @ so3_right_jacobian(B, JRg @ dbg) @ JRg)
+    Jbg[3:6] = -Jvg; Jbg[6:9] = -Jpg
+    return r, [W @ Ji, W @ Jj, W @ Jvi, W @ Jvj, W @ Jba, W @ Jbg]
+
+
+def imu_bias_factor(B, f, ba_i0, bg_i0, ba_j0, bg_j0, dba_i, dbg_i, dba_j, dbg_j):
+    """IMUBiasFactor::Evaluate (residuals.hpp:252-296): r[6] = [(ba_j + dba_j - ba_i - dba_i) / sqrt(dt s_ba^2); (bg ...) / sqrt(dt s_bg^2)],
+    Jacobian blocks [dba_i, dbg_i, dba_j, dbg_j], each 6x3."""
+    dt = B.s(f["dt"])
+    sa = 1 / B.sqrt(dt * B.s(f["bacc_noise"]) * B.s(f["bacc_noise"]))
+    sg = 1 / B.sqrt(dt * B.s(f["bgyr_noise"]) * B.s(f["bgyr_noise"]))
+    r = np.concatenate([sa * (B.a(ba_j0) + B.a(dba_j) - B.a(ba_i0) - B.a(dba_i)), sg * (B.a(bg_j0) + B.a(dbg_j) - B.a(bg_i0) - B.a(dbg_i))])
+    I3 = B.eye(3)
+    Ja_i = B.zeros((6, 3)); Ja_i[0:3] = -sa * I3
+    Jg_i = B.zeros((6, 3)); Jg_i[3:6] = -sg * I3
+    Ja_j = B.zeros((6, 3)); Ja_j[0:3] = sa * I3
+    Jg_j = B.zeros((6, 3)); Jg_j[3:6] = sg * I3
+    return r, [Ja_i, Jg_i, Ja_j, Jg_j]
+
+
 def pose_to_landmark_factor(B, T_f_w0, p0, delta, sqrt_inf, dpose, dl):
     """PoseToLandmarkFactor::Evaluate (residuals.hpp:570-595): r[3], J[3,9] over [pose 6 | landmark 3]."""
     W = B.a(np.asarray(sqrt_inf).reshape(-1)[:9].reshape(3, 3)); dpose = B.a(dpose)
@@ -477,6 +555,18 @@ class Problem:
             if not lc[l] and has_obs[l]:
                 self.lmk_col[l] = n
                 n += 3
+        # VIO windows (localMapVIOptimization, AOptimizer.cpp:352-446): v, ba, bg of every free key-frame (3 each); constant with the frame
+        self.has_imu = bool(getattr(w, "has_imu", 0))
+        self.v_col = np.full(self.n_kf, -1); self.ba_col = np.full(self.n_kf, -1); self.bg_col = np.full(self.n_kf, -1)
+        if self.has_imu:
+            for k in range(self.n_kf):
+                if not kc[k]:
+                    self.v_col[k], self.ba_col[k], self.bg_col[k] = n, n + 3, n + 6
+                    n += 9
+            self.vel = np.asarray(w.kf_vel, dtype=np.float64).reshape(-1, 3)
+            self.ba0 = np.asarray(w.kf_ba, dtype=np.float64).reshape(-1, 3)
+            self.bg0 = np.asarray(w.kf_bg, dtype=np.float64).reshape(-1, 3)
+            self.imu = list(getattr(w, "imu_factors", []))
         self.n = n
         self.T = np.asarray(w.kf_T_f_w, dtype=np.float64).reshape(-1, 12)
         self.K = np.asarray(w.cam_K, dtype=np.float64).reshape(-1, 4)
@@ -499,6 +589,15 @@ class Problem:
             if self.lmk_col[l] >= 0:
                 xl[l] = x[self.lmk_col[l]: self.lmk_col[l] + 3]
         return xp, xl
+
+    def split_vio(self, x):
+        """x -> per key-frame dv, dba, dbg (zeros when constant / no IMU)."""
+        B = self.B
+        xv = B.zeros((self.n_kf, 3)); xa = B.zeros((self.n_kf, 3)); xg = B.zeros((self.n_kf, 3))
+        for k in range(self.n_kf):
+            if self.v_col[k] >= 0:
+                xv[k] = x[self.v_col[k]: self.v_col[k] + 3]; xa[k] = x[self.ba_col[k]: self.ba_col[k] + 3]; xg[k] = x[self.bg_col[k]: self.bg_col[k] + 3]
+        return xv, xa, xg
 
     def blocks(self, x, want_j=True):
         """Yield (r, [(col, J)], in_program) for every residual block at x, loss function already applied (Corrector)."""
@@ -529,6 +628,16 @@ class Problem:
             r, J = pose_prior_factor(B, self.T[k], Tp, inf, xp[k])
             cols = [(self.kf_col[k], J)] if self.kf_col[k] >= 0 else []
             yield r, cols, bool(cols), sum(v * v for v in r)
+        if self.has_imu:                                          # addIMUResiduals (AOptimizer.cpp:22-96): IMUFactor + IMUBiasFactor per pair
+            xv, xa, xg = self.split_vio(x)
+            for f in self.imu:
+                i, j = int(f["kf_i"]), int(f["kf_j"])
+                r, Js = imu_factor(B, f, self.T[i], self.T[j], self.vel[i], self.vel[j], xp[i], xp[j], xv[i], xv[j], xa[i], xg[i])
+                cols = [(c, Jb) for c, Jb in zip((self.kf_col[i], self.kf_col[j], self.v_col[i], self.v_col[j], self.ba_col[i], self.bg_col[i]), Js) if c >= 0]
+                yield r, cols, bool(cols), sum(v * v for v in r)
+                r, Js = imu_bias_factor(B, f, self.ba0[i], self.bg0[i], self.ba0[j], self.bg0[j], xa[i], xg[i], xa[j], xg[j])
+                cols = [(c, Jb) for c, Jb in zip((self.ba_col[i], self.bg_col[i], self.ba_col[j], self.bg_col[j]), Js) if c >= 0]
+                yield r, cols, bool(cols), sum(v * v for v in r)
         if self.dense is not None:                                # MarginalizationFactor: r = r0 + J dx (marginalization.hpp:113-215), VO layout
             d = self.dense
             J = B.a(np.asarray(d["J"], dtype=np.float64)); r0 = B.a(np.asarray(d["r0"], dtype=np.float64))
@@ -753,6 +862,9 @@ def lm_solve(w, opts=None, kind="f64", digits=50, use_schur=False, max_iteration
                 out["n_unsuccess"] += 1
                 log.append([B.f(cost), B.f(cost_change), B.f(radius), B.f(step_norm), B.f(rho), 0.0, B.f(gmax), B.f(mcc)])
     xp, xl = P.split(x)
+    if P.has_imu:
+        xv, xa, xg = P.split_vio(x)
+        out.update(dv=B.f(xv), dba=B.f(xa), dbg=B.f(xg))
     out.update(pose=B.f(xp), lmk=B.f(xl), iterations=it, final_cost=B.f(cost), final_radius=B.f(radius), log=np.array(log),
                x_scalar=x, backend=B, problem=P)
     return out

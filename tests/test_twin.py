@@ -243,3 +243,58 @@ def test_sparsify_informations_match_50_digit_evaluation(oracle_lib):
             # W is a symmetric square root: compare the information W^T W and W itself
             assert np.abs(W.T @ W - Wt.T @ Wt).max() <= tol * np.abs(Wt.T @ Wt).max()
             assert np.abs(W - Wt).max() <= 10 * tol * np.abs(Wt).max()
+
+
+# ---- round 3: the VIO window (IMUFactor + IMUBiasFactor, residuals.hpp:133-296) -------------------------------------------------
+def _small_vio_window(seed=3, **kw):
+    from vio_helpers import make_vio_window
+    return make_vio_window(n_kf=4, n_lmk=36, seed=seed, **kw)
+
+
+def test_imu_factors_match_50_digit_evaluation(oracle_lib):
+    """IMUFactor / IMUBiasFactor of the C oracle against the twin at 50 digits, at non-zero deltas of every block (the Jacobians as
+    coded, incl. the whitening by LLT(cov^-1)^T)."""
+    w = _small_vio_window()
+    rng = np.random.default_rng(5)
+    B = twin.Backend("mp", 50)
+    T = np.asarray(w.kf_T_f_w).reshape(-1, 12)
+    for f in w.imu_factors:
+        i, j = int(f["kf_i"]), int(f["kf_j"])
+        p = np.concatenate([0.02 * rng.standard_normal(3), 0.05 * rng.standard_normal(3), 0.02 * rng.standard_normal(3), 0.05 * rng.standard_normal(3),
+                            0.1 * rng.standard_normal(6), 0.01 * rng.standard_normal(3), 0.001 * rng.standard_normal(3)])
+        r, J = oracle_lib.factor_imu(f, T[i], T[j], w.kf_vel[i], w.kf_vel[j], p)
+        rt, Js = twin.imu_factor(B, f, T[i], T[j], w.kf_vel[i], w.kf_vel[j], p[0:6], p[6:12], p[12:15], p[15:18], p[18:21], p[21:24])
+        Jt = np.concatenate([_f(B, Jb) for Jb in Js], axis=1)
+        scale = np.abs(Jt).max()
+        assert np.abs(r - _f(B, rt)).max() <= 1e-9 * max(1.0, np.abs(_f(B, rt)).max())
+        assert np.abs(J - Jt).max() <= 1e-9 * scale
+        q = 0.01 * rng.standard_normal(12)
+        rb, Jb = oracle_lib.factor_imu_bias(f, w.kf_ba[i], w.kf_bg[i], w.kf_ba[j], w.kf_bg[j], q)
+        rbt, Jbs = twin.imu_bias_factor(B, f, w.kf_ba[i], w.kf_bg[i], w.kf_ba[j], w.kf_bg[j], q[0:3], q[3:6], q[6:9], q[9:12])
+        assert np.abs(rb - _f(B, rbt)).max() <= 1e-11 * max(1.0, np.abs(rb).max())
+        assert np.abs(Jb - np.concatenate([_f(B, x) for x in Jbs], axis=1)).max() <= 1e-11 * np.abs(Jb).max()
+
+
+@pytest.mark.parametrize("mode", ["reference", "perturbed"])
+def test_vio_solve_matches_twin_iterate_by_iterate(oracle_lib, mode):
+    """localMapVIOptimization's problem (visual + IMU + bias factors, 15 states per key-frame) through the twin's un-reduced dense
+    solve and through the C oracle's Schur complement, iterate by iterate (the solver-level tests of the reference pin this path
+    to 1e-2 / 1e-5 only, imu_test.cpp:481-487, 562-567)."""
+    w = _small_vio_window(seed=7) if mode == "reference" else _small_vio_window(seed=8, lmk_perturb=0.2, rot_perturb_deg=1.5)
+    opts = capi.reference_options()
+    ref = twin.lm_solve(w, opts, kind="f64")
+    got = oracle_lib.solve(w, opts)
+    s = got["summary"]
+    assert (s.iterations, s.termination, s.num_successful_steps, s.num_unsuccessful_steps) == \
+        (ref["iterations"], ref["termination"], ref["n_success"], ref["n_unsuccess"])
+    assert np.isclose(s.initial_cost, ref["initial_cost"], rtol=1e-11) and np.isclose(s.final_cost, ref["final_cost"], rtol=1e-9)
+    L, T = got["log"], ref["log"]
+    assert L.shape == T.shape
+    n = len(L) - (1 if s.termination in (1, 2) else 0)
+    assert np.allclose(L[:n, 0], T[:n, 0], rtol=1e-9)                # cost after each iteration (SURVEY.md §8d)
+    assert np.allclose(L[:n, 2], T[:n, 2], rtol=1e-6)                # trust-region radius
+    assert np.allclose(L[:, 7], T[:, 7], rtol=1e-6)                  # model cost change
+    assert np.abs(got["pose"] - ref["pose"]).max() < 1e-8
+    for k in ("dv", "dba", "dbg"):
+        assert np.abs(got[k] - ref[k]).max() < 1e-8, k
+    assert np.abs(got["lmk"] - ref["lmk"]).max() < 1e-7 * max(1.0, np.abs(ref["lmk"]).max())
