@@ -543,6 +543,11 @@ class Problem:
         self.ptr = ptr
         # a landmark is a parameter block only if some residual block uses it
         has_obs = (ptr[1:] - ptr[:-1]) > 0
+        dp0 = getattr(w, "dense_prior", None)
+        if dp0 is not None:                                       # ... the marginalisation factor does
+            for li, lc0 in zip(dp0["lmk_index"], dp0["lmk_col"]):
+                if lc0 >= 0:
+                    has_obs[int(li)] = True
         self.kf_col = np.full(self.n_kf, -1)
         self.lmk_col = np.full(self.n_lmk, -1)
         n = 0
@@ -641,9 +646,15 @@ class Problem:
         if self.dense is not None:                                # MarginalizationFactor: r = r0 + J dx (marginalization.hpp:113-215), VO layout
             d = self.dense
             J = B.a(np.asarray(d["J"], dtype=np.float64)); r0 = B.a(np.asarray(d["r0"], dtype=np.float64))
-            if int(d.get("kf_keep", -1)) >= 0:
-                raise NotImplementedError("twin: dense prior with a kept frame (VIO) is not restated")
             dx = B.zeros(J.shape[1]); cols = []
+            kk = int(d.get("kf_keep", -1))
+            if kk >= 0:                                           # the kept frame's blocks: pose 6 | v 3 | ba 3 | bg 3 (marginalization.hpp:121-136, 157-197)
+                fc = int(d["kf_col"])
+                xv, xa, xg = self.split_vio(x)
+                dx[fc: fc + 6] = xp[kk]; dx[fc + 6: fc + 9] = xv[kk]; dx[fc + 9: fc + 12] = xa[kk]; dx[fc + 12: fc + 15] = xg[kk]
+                for c, o, wdt in ((self.kf_col[kk], 0, 6), (self.v_col[kk], 6, 3), (self.ba_col[kk], 9, 3), (self.bg_col[kk], 12, 3)):
+                    if c >= 0:
+                        cols.append((c, J[:, fc + o: fc + o + wdt]))
             for li, lc in zip(d["lmk_index"], d["lmk_col"]):
                 if lc < 0:
                     continue

@@ -298,3 +298,26 @@ def test_vio_solve_matches_twin_iterate_by_iterate(oracle_lib, mode):
     for k in ("dv", "dba", "dbg"):
         assert np.abs(got[k] - ref[k]).max() < 1e-8, k
     assert np.abs(got["lmk"] - ref["lmk"]).max() < 1e-7 * max(1.0, np.abs(ref["lmk"]).max())
+
+
+def test_vio_solve_with_the_dense_marginalisation_prior_matches_twin(oracle_lib):
+    """BASELINE config 3 as written - the VIO window + the dense MarginalizationFactor on the kept frame (pose, v, ba, bg) and the kept
+    landmarks (marginalization.hpp:113-215) - at a size the twin's dense un-reduced solve handles: oracle against twin."""
+    from test_gpu_prior import random_prior     # (tests/ is on sys.path: conftest)
+    w = _small_vio_window(seed=9)
+    w.dense_prior = random_prior(w, 7, w.n_kf - 2, np.random.default_rng(6))
+    opts = capi.reference_options()
+    ref = twin.lm_solve(w, opts, kind="f64")
+    got = oracle_lib.solve(w, opts, dense_prior=w.dense_prior)
+    s = got["summary"]
+    assert (s.iterations, s.termination, s.num_successful_steps, s.num_unsuccessful_steps) == \
+        (ref["iterations"], ref["termination"], ref["n_success"], ref["n_unsuccess"])
+    assert np.isclose(s.initial_cost, ref["initial_cost"], rtol=1e-11) and np.isclose(s.final_cost, ref["final_cost"], rtol=1e-9)
+    n = len(got["log"]) - (1 if s.termination in (1, 2) else 0)
+    assert np.allclose(got["log"][:n, 0], ref["log"][:n, 0], rtol=1e-9)
+    assert np.abs(got["pose"] - ref["pose"]).max() < 1e-8
+    for k in ("dv", "dba", "dbg"):
+        assert np.abs(got[k] - ref[k]).max() < 1e-8, k
+    assert np.abs(got["lmk"] - ref["lmk"]).max() < 1e-7 * max(1.0, np.abs(ref["lmk"]).max())
+    plain = oracle_lib.solve(_small_vio_window(seed=9), opts)
+    assert np.abs(plain["pose"] - got["pose"]).max() > 1e-6          # the prior matters
