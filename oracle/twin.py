@@ -1,4 +1,4 @@
-"""oracle/twin.py — an INDEPENDENT second restatement of the visual-BA arithmetic (TEST INFRASTRUCTURE ONLY).
+"""oracle/twin.py — an INDEPENDENT second restatement of the BA arithmetic: visual, inertial and prior factors, the LM loop (TEST INFRASTRUCTURE ONLY).
 
 Written from the reference's source lines and from Ceres Solver 2.2.0's published trust-region algorithm, WITHOUT going
 through oracle/*.c: plain NumPy, generic in the scalar type — float64, numpy.longdouble (x87 80-bit) or mpmath `mpf`
@@ -543,6 +543,11 @@ class Problem:
         self.ptr = ptr
         # a landmark is a parameter block only if some residual block uses it
         has_obs = (ptr[1:] - ptr[:-1]) > 0
+        self.sparse = list(getattr(w, "sparse_priors", None) or [])
+        for f in self.sparse:                                     # ... an NFR factor of the sparsified prior does
+            for key in ("lmk0", "lmk1"):
+                if int(f.get(key, -1)) >= 0:
+                    has_obs[int(f[key])] = True
         dp0 = getattr(w, "dense_prior", None)
         if dp0 is not None:                                       # ... the marginalisation factor does
             for li, lc0 in zip(dp0["lmk_index"], dp0["lmk_col"]):
@@ -643,6 +648,29 @@ class Problem:
                 r, Js = imu_bias_factor(B, f, self.ba0[i], self.bg0[i], self.ba0[j], self.bg0[j], xa[i], xg[i], xa[j], xg[j])
                 cols = [(c, Jb) for c, Jb in zip((self.ba_col[i], self.bg_col[i], self.ba_col[j], self.bg_col[j]), Js) if c >= 0]
                 yield r, cols, bool(cols), sum(v * v for v in r)
+        for f in self.sparse:                                     # sparse branch of addMarginalizationResiduals (…Analytic.cpp:363-426)
+            t = int(f["type"])
+            if t == 0:                                            # IMUPriordx on the kept frame
+                k = int(f["kf"])
+                xv, xa, xg = self.split_vio(x)
+                r, J = imu_prior_factor(B, self.T[k], self.vel[k], self.ba0[k], self.bg0[k], f["T_prior"], f["v_prior"], f["ba_prior"], f["bg_prior"],
+                                        f["sqrt_inf"], np.concatenate([xp[k], xv[k], xa[k], xg[k]]))
+                cols = [(c, J[:, o: o + wdt]) for c, o, wdt in ((self.kf_col[k], 0, 6), (self.v_col[k], 6, 3), (self.ba_col[k], 9, 3), (self.bg_col[k], 12, 3)) if c >= 0]
+            elif t == 1:                                          # PoseToLandmarkFactor
+                k, l = int(f["kf"]), int(f["lmk0"])
+                r, J = pose_to_landmark_factor(B, self.T[k], self.P[l], f["delta"], f["sqrt_inf"], xp[k], xl[l])
+                cols = [(c, Jb) for c, Jb in ((self.kf_col[k], J[:, :6]), (self.lmk_col[l], J[:, 6:9])) if c >= 0]
+            elif t == 2:                                          # Landmark3DPrior
+                l = int(f["lmk0"])
+                r, J = landmark_prior_factor(B, self.P[l], f["delta"], f["sqrt_inf"], xl[l])
+                cols = [(self.lmk_col[l], J)] if self.lmk_col[l] >= 0 else []
+            elif t == 3:                                          # LandmarkToLandmarkFactor
+                l0, l1 = int(f["lmk0"]), int(f["lmk1"])
+                r, J = landmark_to_landmark_factor(B, self.P[l0], self.P[l1], f["delta"], f["sqrt_inf"], xl[l0], xl[l1])
+                cols = [(c, Jb) for c, Jb in ((self.lmk_col[l0], J[:, :3]), (self.lmk_col[l1], J[:, 3:6])) if c >= 0]
+            else:
+                raise NotImplementedError(f"twin: sparse factor type {t} inside a solve")
+            yield r, cols, bool(cols), sum(v * v for v in r)
         if self.dense is not None:                                # MarginalizationFactor: r = r0 + J dx (marginalization.hpp:113-215), VO layout
             d = self.dense
             J = B.a(np.asarray(d["J"], dtype=np.float64)); r0 = B.a(np.asarray(d["r0"], dtype=np.float64))

@@ -321,3 +321,31 @@ def test_vio_solve_with_the_dense_marginalisation_prior_matches_twin(oracle_lib)
     assert np.abs(got["lmk"] - ref["lmk"]).max() < 1e-7 * max(1.0, np.abs(ref["lmk"]).max())
     plain = oracle_lib.solve(_small_vio_window(seed=9), opts)
     assert np.abs(plain["pose"] - got["pose"]).max() > 1e-6          # the prior matters
+
+
+@pytest.mark.parametrize("kind", ["vio", "vo"])
+def test_solve_with_the_sparsified_prior_matches_twin(oracle_lib, kind):
+    """The sparse branch of addMarginalizationResiduals inside the solve: VIO = IMUPriordx + pose-to-landmark factors, VO = landmark
+    prior + landmark-to-landmark chain; oracle (pseudo-observations / kept landmarks in the reduced system) against the twin's
+    un-reduced dense solve."""
+    from sparse_helpers import vio_sparse_priors, vo_sparse_priors
+    if kind == "vio":
+        w = _small_vio_window(seed=11)
+        w.sparse_priors = vio_sparse_priors(w, w.n_kf - 2, [0, 4, 8, 12, 16], np.random.default_rng(3), noise=0.02)
+    else:
+        w = synthetic.make_window(n_kf=4, n_lmk=40, seed=12)
+        w.sparse_priors = vo_sparse_priors(w, [1, 5, 9, 13], np.random.default_rng(4), noise=0.02)
+    opts = capi.reference_options()
+    ref = twin.lm_solve(w, opts, kind="f64")
+    got = oracle_lib.solve(w, opts)
+    s = got["summary"]
+    assert (s.iterations, s.termination, s.num_successful_steps, s.num_unsuccessful_steps) == \
+        (ref["iterations"], ref["termination"], ref["n_success"], ref["n_unsuccess"])
+    assert np.isclose(s.initial_cost, ref["initial_cost"], rtol=1e-11) and np.isclose(s.final_cost, ref["final_cost"], rtol=1e-9)
+    n = len(got["log"]) - (1 if s.termination in (1, 2) else 0)
+    assert np.allclose(got["log"][:n, 0], ref["log"][:n, 0], rtol=1e-9)
+    assert np.abs(got["pose"] - ref["pose"]).max() < 1e-8
+    assert np.abs(got["lmk"] - ref["lmk"]).max() < 1e-7 * max(1.0, np.abs(ref["lmk"]).max())
+    if kind == "vio":
+        for k in ("dv", "dba", "dbg"):
+            assert np.abs(got[k] - ref[k]).max() < 1e-8, k
