@@ -668,6 +668,10 @@ class Problem:
                 l0, l1 = int(f["lmk0"]), int(f["lmk1"])
                 r, J = landmark_to_landmark_factor(B, self.P[l0], self.P[l1], f["delta"], f["sqrt_inf"], xl[l0], xl[l1])
                 cols = [(c, Jb) for c, Jb in ((self.lmk_col[l0], J[:, :3]), (self.lmk_col[l1], J[:, 3:6])) if c >= 0]
+            elif t == 4:                                          # Relative6DPose between key-frames a and b (the slots hold T_w_a, T_w_b)
+                a, b = int(f["kf"]), int(f["kf_b"])
+                r, Ja, Jb = relative_pose_factor(B, self.T[a], self.T[b], f["T_prior"], f["sqrt_inf"], xp[a], xp[b])
+                cols = [(c, Jx) for c, Jx in ((self.kf_col[a], Ja), (self.kf_col[b], Jb)) if c >= 0]
             else:
                 raise NotImplementedError(f"twin: sparse factor type {t} inside a solve")
             yield r, cols, bool(cols), sum(v * v for v in r)

@@ -349,3 +349,26 @@ def test_solve_with_the_sparsified_prior_matches_twin(oracle_lib, kind):
     if kind == "vio":
         for k in ("dv", "dba", "dbg"):
             assert np.abs(got[k] - ref[k]).max() < 1e-8, k
+
+
+def test_pose_graph_solve_matches_twin(oracle_lib):
+    """A pose graph of Relative6DPose factors (residuals.hpp:70-131) with noisy relative measurements: oracle against
+    the twin's dense solve, iterate by iterate."""
+    from test_oracle_relative import loop_graph, perturbed, rel_window
+    rng = np.random.default_rng(21)
+    Twf, factors = loop_graph(8, rng)
+    for f in factors:                                                        # inconsistent measurements: a non-zero optimum
+        T = synthetic.T12_to_4(f["T_prior"])
+        D = np.eye(4); D[:3, :3] = synthetic.exp_so3(0.01 * rng.standard_normal(3)); D[:3, 3] = 0.02 * rng.standard_normal(3)
+        f["T_prior"] = synthetic.T_to_12(T @ D)
+    w = rel_window(perturbed(Twf, rng), factors, fixed=(0,))
+    opts = capi.reference_options()
+    ref = twin.lm_solve(w, opts, kind="f64")
+    got = oracle_lib.solve(w, opts)
+    s = got["summary"]
+    assert (s.iterations, s.termination, s.num_successful_steps, s.num_unsuccessful_steps) == \
+        (ref["iterations"], ref["termination"], ref["n_success"], ref["n_unsuccess"])
+    assert s.iterations >= 3 and np.isclose(s.final_cost, ref["final_cost"], rtol=1e-9) and s.final_cost > 1e-3
+    n = len(got["log"]) - (1 if s.termination in (1, 2) else 0)
+    assert np.allclose(got["log"][:n, 0], ref["log"][:n, 0], rtol=1e-9)
+    assert np.abs(got["pose"] - ref["pose"]).max() < 1e-9
