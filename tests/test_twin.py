@@ -95,6 +95,12 @@ def _variants():
     w.dense_prior = {"J": rng.standard_normal((n - 2, n)), "r0": 0.3 * rng.standard_normal(n - 2), "kf_keep": -1, "kf_col": 0,
                      "lmk_index": li, "lmk_col": np.arange(0, n, 3, dtype=np.int32)}
     yield "VO dense prior", w, capi.reference_options()
+    # the front-end solves (AOptimizer.cpp:98-297): the same factors behind constant masks, Huber(sqrt 1.345), 10 / 5 iterations
+    from frontend_helpers import landmark_optimization_window, single_frame_window
+    o = capi.reference_options(); o.huber_a = 1.345 ** 0.5; o.max_num_iterations = 10
+    yield "landmarkOptimization (every key-frame constant, outliers, Huber)", landmark_optimization_window(n_kf=4, n_lmk=40, seed=51), o
+    o = capi.reference_options(); o.huber_a = 1.345 ** 0.5; o.max_num_iterations = 5
+    yield "singleFrameOptimization (one free frame, constant landmarks, Huber)", single_frame_window(n_lmk=60, seed=52), o
 
 
 @pytest.mark.parametrize("name,w,opts", list(_variants()), ids=[v[0] for v in _variants()])
