@@ -378,3 +378,26 @@ def test_pose_graph_solve_matches_twin(oracle_lib):
     n = len(got["log"]) - (1 if s.termination in (1, 2) else 0)
     assert np.allclose(got["log"][:n, 0], ref["log"][:n, 0], rtol=1e-9)
     assert np.abs(got["pose"] - ref["pose"]).max() < 1e-9
+
+
+def test_single_frame_vi_optimization_shape_matches_twin(oracle_lib):
+    """singleFrameVIOptimization (AOptimizer.cpp:219-297): moving frame + last key-frame free, landmarks constant, one IMU / bias factor
+    pair, Huber on the visual factors, 5 iterations - the Huber-corrected visual blocks beside the unweighted inertial ones."""
+    from frontend_helpers import with_outliers
+    from vio_helpers import make_vio_window
+    w = with_outliers(make_vio_window(n_kf=2, n_lmk=60, seed=55, fixed=0, obs_per_lmk=4), frac=0.05, seed=3)
+    w.lmk_const = np.ones(w.n_lmk, dtype=np.uint8)
+    w.pose_priors = []
+    opts = capi.single_frame_options(vi=True)
+    opts.max_solver_time_in_seconds = 0.0          # (the 5 ms cap is wall-clock: not part of the arithmetic)
+    ref = twin.lm_solve(w, opts, kind="f64")
+    got = oracle_lib.solve(w, opts)
+    s = got["summary"]
+    assert (s.iterations, s.termination, s.num_successful_steps, s.num_unsuccessful_steps) == \
+        (ref["iterations"], ref["termination"], ref["n_success"], ref["n_unsuccess"])
+    assert np.isclose(s.final_cost, ref["final_cost"], rtol=1e-9)
+    n = len(got["log"]) - (1 if s.termination in (1, 2) else 0)
+    assert np.allclose(got["log"][:n, 0], ref["log"][:n, 0], rtol=1e-9)
+    assert np.abs(got["pose"] - ref["pose"]).max() < 1e-9
+    for k in ("dv", "dba", "dbg"):
+        assert np.abs(got[k] - ref[k]).max() < 1e-9, k
