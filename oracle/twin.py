@@ -373,6 +373,46 @@ def imu_factor(B, f, T_fi_w0, T_fj_w0, v_i0, v_j0, dpose_i, dpose_j, dv_i, dv_j,
     return r, [W @ Ji, W @ Jj, W @ Jvi, W @ Jvj, W @ Jba, W @ Jbg]
 
 
+def imu_factor_init(B, f, T_fi_w, T_fj_w, v_i0, v_j0, r_wi2, dv_i, dv_j, dba, dbg, lam):
+    """IMUFactorInit::Evaluate (residuals.hpp:302-410), the factor of AOptimizer::VIInit: r[9] and the Jacobian blocks [r_wi 9x2, v_i 9x3,
+    v_j 9x3, ba 9x3, bg 9x3, lambda 9x1]. As coded the scale block has no exp(lambda) factor (:397-400)."""
+    g = B.a(GRAVITY)
+    Ri, ti = split_T(B, T_fi_w); Rj, tj = split_T(B, T_fj_w)
+    w_wi = np.array([B.s(r_wi2[0]), B.s(r_wi2[1]), B.s(0)], dtype=B.dtype)      # :309
+    Rwi = exp_so3(B, w_wi)
+    vi = B.a(v_i0) + B.a(dv_i); vj = B.a(v_j0) + B.a(dv_j)
+    dba, dbg = B.a(dba), B.a(dbg)
+    lam = B.s(lam)
+    el = mpmath.exp(lam) if B.kind == "mp" else np.exp(lam)
+    dt = B.s(f["dt"])
+    cov = B.a(np.asarray(f["cov"], dtype=np.float64).reshape(9, 9))
+    W = chol_lower(B, _inverse(B, cov)).T
+    DR = B.a(np.asarray(f["delta_R"], dtype=np.float64).reshape(3, 3))
+    Dv = B.a(np.asarray(f["delta_v"], dtype=np.float64)); Dp = B.a(np.asarray(f["delta_p"], dtype=np.float64))
+    JRg = B.a(np.asarray(f["J_dR_bg"], dtype=np.float64).reshape(3, 3))
+    Jva = B.a(np.asarray(f["J_dv_ba"], dtype=np.float64).reshape(3, 3)); Jvg = B.a(np.asarray(f["J_dv_bg"], dtype=np.float64).reshape(3, 3))
+    Jpa = B.a(np.asarray(f["J_dp_ba"], dtype=np.float64).reshape(3, 3)); Jpg = B.a(np.asarray(f["J_dp_bg"], dtype=np.float64).reshape(3, 3))
+    dR = (DR @ exp_so3(B, JRg @ dbg)).T @ Ri @ Rj.T                 # :326-327
+    r_dr = log_so3(B, dR)
+    pi = -(inv3(B, Ri) @ ti); pj = -(inv3(B, Rj) @ tj)
+    RR = Ri @ Rwi
+    a = (vj - vi) - g * dt
+    b = el * (pj - pi) - vi * dt - g * (dt * dt) / 2
+    r_dv = RR @ a - (Dv + Jvg @ dbg + Jva @ dba)                    # :329-330
+    r_dp = RR @ b - (Dp + Jpg @ dbg + Jpa @ dba)                    # :331-335
+    r = W @ np.concatenate([r_dr, r_dv, r_dp])
+    Jr2 = so3_right_jacobian(B, w_wi)[:, :2]
+    Jw = B.zeros((9, 2)); Jw[3:6] = -(RR @ skew(B, a) @ Jr2); Jw[6:9] = -(RR @ skew(B, b) @ Jr2)     # :346-357
+    Jvi = B.zeros((9, 3)); Jvi[3:6] = -RR; Jvi[6:9] = -(RR * dt)                                   # :360-366
+    Jvj = B.zeros((9, 3)); Jvj[3:6] = RR                                                          # :369-374
+    Jba = B.zeros((9, 3)); Jba[3:6] = -Jva; Jba[6:9] = -Jpa                                       # :377-383
+    Jbg = B.zeros((9, 3))                                                                         # :386-394
+    Jbg[0:3] = -(inv3(B, so3_right_jacobian(B, r_dr)) @ dR.T @ so3_right_jacobian(B, JRg @ dbg) @ JRg)
+    Jbg[3:6] = -Jvg; Jbg[6:9] = -Jpg
+    Jl = B.zeros((9, 1)); Jl[6:9, 0] = RR @ (pj - pi)                                             # :397-400 (no exp(lambda))
+    return r, [W @ Jw, W @ Jvi, W @ Jvj, W @ Jba, W @ Jbg, W @ Jl]
+
+
 def imu_bias_factor(B, f, ba_i0, bg_i0, ba_j0, bg_j0, dba_i, dbg_i, dba_j, dbg_j):
     """IMUBiasFactor::Evaluate (residuals.hpp:252-296): r[6] = [(ba_j + dba_j - ba_i - dba_i) / sqrt(dt s_ba^2); (bg ...) / sqrt(dt s_bg^2)],
     Jacobian blocks [dba_i, dbg_i, dba_j, dbg_j], each 6x3."""

@@ -401,3 +401,20 @@ def test_single_frame_vi_optimization_shape_matches_twin(oracle_lib):
     assert np.abs(got["pose"] - ref["pose"]).max() < 1e-9
     for k in ("dv", "dba", "dbg"):
         assert np.abs(got[k] - ref[k]).max() < 1e-9, k
+
+
+def test_imu_factor_init_matches_50_digit_evaluation(oracle_lib):
+    """IMUFactorInit (residuals.hpp:302-410), the factor of AOptimizer::VIInit, as coded (the scale Jacobian without exp(lambda))."""
+    w = _small_vio_window(seed=13)
+    rng = np.random.default_rng(14)
+    B = twin.Backend("mp", 50)
+    T = np.asarray(w.kf_T_f_w).reshape(-1, 12)
+    for f in w.imu_factors:
+        i, j = int(f["kf_i"]), int(f["kf_j"])
+        p = np.concatenate([0.05 * rng.standard_normal(2), 0.1 * rng.standard_normal(6), 0.01 * rng.standard_normal(3), 0.001 * rng.standard_normal(3),
+                            [0.05 * rng.standard_normal()]])
+        r, J = oracle_lib.factor_imu_init(f, T[i], T[j], w.kf_vel[i], w.kf_vel[j], p)
+        rt, Js = twin.imu_factor_init(B, f, T[i], T[j], w.kf_vel[i], w.kf_vel[j], p[0:2], p[2:5], p[5:8], p[8:11], p[11:14], p[14])
+        Jt = np.concatenate([_f(B, Jb) for Jb in Js], axis=1)
+        assert np.abs(r - _f(B, rt)).max() <= 1e-9 * max(1.0, np.abs(r).max())
+        assert np.abs(J - Jt).max() <= 1e-9 * np.abs(Jt).max()
