@@ -838,15 +838,82 @@ def options_dict(opts=None):
     return o
 
 
-def lm_solve(w, opts=None, kind="f64", digits=50, use_schur=False, max_iterations=None):
+class ViInitProblem:
+    """AOptimizer::VIInit's problem (AOptimizer.cpp:448-581): gravity direction r_wi (2), the scale exponent lambda (1, constant
+    unless optim_scale), the window's bias deltas dba / dbg (3 + 3; constant in the reference, `optim_bias` frees them as the C ABI
+    allows), one velocity delta per frame (3); IMUFactorInit between consecutive key-frames, Landmark3DPrior(0, 0, I / sigma) on dba, dbg."""
+
+    def __init__(self, B, T_f_w, vel, factors, optim_scale=False, optim_bias=False, sigma_dba=1.0, sigma_dbg=1.0):
+        self.B = B
+        self.T = np.asarray(T_f_w, dtype=np.float64).reshape(-1, 12)
+        self.vel = np.asarray(vel, dtype=np.float64).reshape(-1, 3)
+        self.factors = list(factors)
+        self.n_f = self.T.shape[0]
+        n = 2
+        self.c_lam = -1
+        if optim_scale:
+            self.c_lam = n; n += 1
+        self.c_ba = self.c_bg = -1
+        if optim_bias:
+            self.c_ba, self.c_bg = n, n + 3; n += 6
+        used = sorted({int(f["kf_i"]) for f in self.factors} | {int(f["kf_j"]) for f in self.factors})
+        self.c_v = np.full(self.n_f, -1)
+        for k in used:                                             # a parameter block exists only if a residual block uses it
+            self.c_v[k] = n; n += 3
+        self.n = n
+        self.sa, self.sg = 1.0 / sigma_dba, 1.0 / sigma_dbg
+        self.has_imu = False
+
+    def unpack(self, x):
+        B = self.B
+        lam = x[self.c_lam] if self.c_lam >= 0 else B.s(0)
+        dba = x[self.c_ba: self.c_ba + 3] if self.c_ba >= 0 else B.zeros(3)
+        dbg = x[self.c_bg: self.c_bg + 3] if self.c_bg >= 0 else B.zeros(3)
+        dv = B.zeros((self.n_f, 3))
+        for k in range(self.n_f):
+            if self.c_v[k] >= 0:
+                dv[k] = x[self.c_v[k]: self.c_v[k] + 3]
+        return x[0:2], lam, dba, dbg, dv
+
+    def evaluate(self, x, want_j=True):
+        B = self.B
+        r_wi, lam, dba, dbg, dv = self.unpack(x)
+        rs, rows, cost, fixed = [], [], B.s(0), B.s(0)
+        for f in self.factors:
+            i, j = int(f["kf_i"]), int(f["kf_j"])
+            r, Js = imu_factor_init(B, f, self.T[i], self.T[j], self.vel[i], self.vel[j], r_wi, dv[i], dv[j], dba, dbg, lam)
+            cols = [(c, Jb) for c, Jb in zip((0, self.c_v[i], self.c_v[j], self.c_ba, self.c_bg, self.c_lam), Js) if c >= 0]
+            cost = cost + sum(v * v for v in r) / 2
+            rs.append(r); rows.append(cols)
+        for c, sc, val in ((self.c_ba, self.sa, dba), (self.c_bg, self.sg, dbg)):    # Landmark3DPrior(0, 0, I / sigma)
+            r = B.s(sc) * val
+            if c >= 0:
+                cost = cost + sum(v * v for v in r) / 2
+                rs.append(r); rows.append([(c, B.s(sc) * B.eye(3))])
+            else:
+                fixed = fixed + sum(v * v for v in r) / 2
+        m = sum(len(r) for r in rs)
+        res = np.concatenate(rs) if rs else B.zeros(0)
+        if not want_j:
+            return cost, fixed, res, None
+        J = B.zeros((m, self.n))
+        i = 0
+        for r, cols in zip(rs, rows):
+            for (c, Jb) in cols:
+                J[i: i + len(r), c: c + Jb.shape[1]] = Jb
+            i += len(r)
+        return cost, fixed, res, J
+
+
+def lm_solve(w, opts=None, kind="f64", digits=50, use_schur=False, max_iterations=None, problem=None):
     """Minimise the window's cost with Ceres' trust-region / LM schedule. Returns a dict: pose[n_kf,6], lmk[n_lmk,3]
     (float64), summary fields and `log` (one row per iteration: cost, cost_change, radius, step_norm, relative_decrease,
     successful, gradient_max, model_cost_change — the layout of the C oracle's log)."""
     o = options_dict(opts)
     if max_iterations is not None:
         o["max_num_iterations"] = max_iterations
-    B = Backend(kind, digits)
-    P = Problem(B, w, huber_a=o["huber_a"])
+    B = Backend(kind, digits) if problem is None else problem.B
+    P = Problem(B, w, huber_a=o["huber_a"]) if problem is None else problem
     n = P.n
     x = B.zeros(n)
     x_norm = B.s(0)
@@ -944,6 +1011,9 @@ def lm_solve(w, opts=None, kind="f64", digits=50, use_schur=False, max_iteration
                 step_successful = False
                 out["n_unsuccess"] += 1
                 log.append([B.f(cost), B.f(cost_change), B.f(radius), B.f(step_norm), B.f(rho), 0.0, B.f(gmax), B.f(mcc)])
+    if problem is not None:                                       # a problem of its own (VIInit): raw solution, unpacked by the caller
+        out.update(iterations=it, final_cost=B.f(cost), final_radius=B.f(radius), log=np.array(log), x_scalar=x, backend=B, problem=P)
+        return out
     xp, xl = P.split(x)
     if P.has_imu:
         xv, xa, xg = P.split_vio(x)

@@ -418,3 +418,29 @@ def test_imu_factor_init_matches_50_digit_evaluation(oracle_lib):
         Jt = np.concatenate([_f(B, Jb) for Jb in Js], axis=1)
         assert np.abs(r - _f(B, rt)).max() <= 1e-9 * max(1.0, np.abs(r).max())
         assert np.abs(J - Jt).max() <= 1e-9 * np.abs(Jt).max()
+
+
+@pytest.mark.parametrize("optim_scale,optim_bias", [(True, False), (False, False), (True, True)])
+def test_viinit_solve_matches_twin(oracle_lib, optim_scale, optim_bias):
+    """AOptimizer::VIInit (AOptimizer.cpp:448-581) on a synthetic 8-key-frame trajectory: the C oracle's solve against the twin's dense
+    LM solve of the same problem (gravity direction, scale exponent, velocities; biases constant as in the reference, or freed)."""
+    from viinit_helpers import make_viinit
+    pb = make_viinit(n_kf=8, scale=0.6, tilt=(0.04, -0.06), seed=2)
+    opts = capi.viinit_options()
+    kw = dict(optim_scale=optim_scale, optim_bias=optim_bias, sigma_dba=0.05, sigma_dbg=0.005)
+    got = oracle_lib.viinit(pb["T_f_w"], pb["vel"], pb["factors"], opts, **kw)
+    B = twin.Backend("f64")
+    P = twin.ViInitProblem(B, pb["T_f_w"], pb["vel"], pb["factors"], **kw)
+    ref = twin.lm_solve(None, opts, problem=P)
+    r_wi, lam, dba, dbg, dv = P.unpack(ref["x_scalar"])
+    s = got["summary"]
+    assert got["rc"] == 0
+    assert (s.iterations, s.termination, s.num_successful_steps, s.num_unsuccessful_steps) == \
+        (ref["iterations"], ref["termination"], ref["n_success"], ref["n_unsuccess"])
+    assert np.isclose(s.initial_cost, ref["initial_cost"], rtol=1e-11) and np.isclose(s.final_cost, ref["final_cost"], rtol=1e-8)
+    assert np.abs(got["r_wi"] - np.array(r_wi, dtype=np.float64)).max() < 1e-9
+    assert abs(got["lambda"] - float(lam)) < 1e-9
+    assert np.abs(got["dv"] - np.array(B.f(dv))).max() < 1e-8
+    assert np.abs(got["dba"] - np.array(dba, dtype=np.float64)).max() < 1e-9 and np.abs(got["dbg"] - np.array(dbg, dtype=np.float64)).max() < 1e-9
+    if not optim_scale:
+        assert got["lambda"] == 0.0
