@@ -264,7 +264,13 @@ int sadvio_ba_set_imu_factors(sadvio_ba_handle *h, int32_t w, int32_t n, const s
  * added by addMarginalizationResiduals, …Analytic.cpp:316-360): r = r0 + J dx, J is
  * n_full x n row-major. `kf_keep` (or -1 in pure VO) is the key-frame whose 15 states occupy
  * columns [kf_col, kf_col+15) (pose6, v3, ba3, bg3); kept landmark `lmk_index[i]` occupies
- * columns [lmk_col[i], lmk_col[i]+3); lmk_col[i] = -1 means "skipped" (marginalization.hpp:138). */
+ * columns [lmk_col[i], lmk_col[i]+3); lmk_col[i] = -1 means "skipped" (marginalization.hpp:138).
+ * J == NULL with n_full == SADVIO_PRIOR_RESIDENT attaches THE HANDLE'S PRIOR — the (J, r0) the last sadvio_ba_marginalize
+ * (or sadvio_ba_set_prior) left on the device, the way the reference keeps `_marginalization_last` inside the optimizer
+ * (AOptimizer.h:88-90): nothing crosses PCIe; `n` is then ignored, `r0` must be NULL, and the caller only names the
+ * variables of THIS window that the prior's columns refer to (it owns the id -> index bookkeeping, like the reference's
+ * _map_frame_idx / _map_lmk_idx). */
+#define SADVIO_PRIOR_RESIDENT (-1)
 int sadvio_ba_set_dense_prior(sadvio_ba_handle *h, int32_t w, int32_t n_full, int32_t n,
                               const double *J, const double *r0, int32_t kf_keep, int32_t kf_col,
                               int32_t n_keep, const int32_t *lmk_index, const int32_t *lmk_col);
@@ -277,6 +283,30 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle *h, int32_t w, int32_t n_full, in
  * logic and stays with the caller, who passes the two index lists in the reference's order.
  * Column layout (marginalization.cpp:38-113): marginalised = [frame0 pose 6 (+ v, ba, bg 9 if marg_has_imu) |
  * lmk_marg 3 each]; kept = [frame1 15 states if kf_keep >= 0 | lmk_keep 3 each]. */
+/* Eigenvalue cut of the pseudo-inverse of Amm and of the rank-revealing decomposition of Ak.
+ *   SADVIO_EIG_CUT_REFERENCE   (0, the default of a zero-initialised request): the reference's arithmetic — keep
+ *       lambda > 1e-12, ABSOLUTE (Marginalization::_eps, marginalization.hpp:58, applied at marginalization.cpp:237,322).
+ *       In float64 that constant sits below the rounding noise of the sums it is applied to (|A| ~ 1e5..1e8 => noise
+ *       ~ 1e-11..1e-8): exactly-null directions are kept or dropped by the sign of a rounding error, in the reference as here;
+ *       the prior's INFORMATION (J^T J, J^T r0) is unaffected to rounding (a kept noise direction carries ~1e-11 of it),
+ *       only n_full varies. Weakly observed directions (far, low-parallax depth: 1e-12 < lambda < n eps lambda_max) are
+ *       KEPT, as the reference keeps them.
+ *   SADVIO_EIG_CUT_NOISE_FLOOR (1): keep lambda > max(1e-12, n eps lambda_max) — the numerically meaningful rank; n_full
+ *       is reproducible across implementations, at the price of dropping directions whose information is below the floor
+ *       (|Ak_ref - Ak_floor|_2 <= n eps lambda_max by construction; tests/test_gpu_marg.py bounds the effect on the next
+ *       solve on a low-parallax window).
+ * Form of the prior handed back / kept on the device (both give the same MarginalizationFactor cost, gradient and
+ * Gauss-Newton matrix: r0 + J dx enters the solve only through J^T J, J^T r0 and |r0|^2):
+ *   SADVIO_PRIOR_FORM_EIGEN    (0): the reference's J = Lambda^1/2 U^T, r0 = -Lambda^-1/2 U^T bk, rows in ascending
+ *       eigenvalue order (marginalization.cpp:318-342,516-530) — one-sided block Jacobi on the device, ~20 ms at n ~ 900.
+ *   SADVIO_PRIOR_FORM_CHOLESKY (1): J = G, the rank-revealing (diagonally pivoted) Cholesky factor G^T G = Ak with the cut
+ *       applied to its pivots, r0 = -G^-T bk by carrying bk through the factorisation as an extra column — no
+ *       eigen-decomposition; sadvio_ba_sparsify then takes Sigma_k = Ak^-1 from the triangular inverse of G. */
+#define SADVIO_EIG_CUT_REFERENCE 0
+#define SADVIO_EIG_CUT_NOISE_FLOOR 1
+#define SADVIO_PRIOR_FORM_EIGEN 0
+#define SADVIO_PRIOR_FORM_CHOLESKY 1
+
 typedef struct sadvio_marg_request {
     int32_t kf_marg;                 /* frame0 */
     int32_t kf_keep;                 /* frame1 when it carries an IMU (15 columns), else -1 */
@@ -288,33 +318,50 @@ typedef struct sadvio_marg_request {
     const sadvio_imu_factor *imu;    /* IMUFactor + IMUBiasFactor(frame0, frame1) or NULL (…Analytic.cpp:451-508) */
     int32_t n_prior;                 /* PosePriordx blocks (<= 4), .kf = kf_marg or kf_keep (:605-617) */
     const sadvio_pose_prior *priors;
-    int32_t last_n_full, last_n;     /* previous MarginalizationFactor (:574-603); last_n_full = 0 if none */
+    int32_t last_n_full, last_n;     /* previous MarginalizationFactor (:574-603); last_n_full = 0 if none;
+                                        last_n_full = SADVIO_PRIOR_RESIDENT: the handle's prior (last_J / last_r0 / last_n ignored) */
     const double *last_J, *last_r0;
     int32_t last_kf, last_kf_col;    /* window index of its kept frame (= kf_marg now) or -1, its first column */
     int32_t last_n_keep;
     const int32_t *last_lmk_index;   /* window landmark indices of its kept landmarks */
     const int32_t *last_lmk_col;     /* their columns (-1 = skipped) */
+    int32_t eig_cut_mode;            /* SADVIO_EIG_CUT_* */
+    int32_t prior_form;              /* SADVIO_PRIOR_FORM_* */
 } sadvio_marg_request;
 
 typedef struct sadvio_marg_result {
     int32_t m, n, n_full;
     int32_t kf_col;   /* column of kf_keep's 15 states in the new prior, -1 if none */
-    int32_t sweeps_mm, sweeps_k;  /* Jacobi sweeps of the two eigen-decompositions */
+    int32_t sweeps_mm, sweeps_k;  /* Jacobi sweeps of the two eigen-decompositions (sweeps_k = 0 in the Cholesky form) */
 } sadvio_marg_result;
 
-/* Returns SADVIO_E_REFUSED when n < 4 (marginalization.cpp:215-216; the reference then clears its prior).
- * Outputs (caller-allocated): lmk_col[n_keep] column of each kept landmark in the new prior; J[n*n] receives the
- * n_full x n prior Jacobian (row-major, packed); r0[n] the n_full prior residuals. Feed them to
- * sadvio_ba_set_dense_prior of the next window. */
+/* Returns SADVIO_E_REFUSED when n < 4 (marginalization.cpp:215-216; the reference then clears its prior, and so does the
+ * handle). Outputs (caller-allocated): lmk_col[n_keep] column of each kept landmark in the new prior.
+ * The new prior STAYS ON THE DEVICE as the handle's prior (AOptimizer.h:88-90: `_marginalization_last`), replacing the
+ * previous one: the next window attaches it with sadvio_ba_set_dense_prior(.., SADVIO_PRIOR_RESIDENT, ..) or sparsifies it
+ * with sadvio_ba_sparsify(.., J = NULL, ..), the next marginalisation folds it in with last_n_full = SADVIO_PRIOR_RESIDENT.
+ * J / r0 may be NULL (the default path: no read-back); when given, J[n*n] receives the n_full x n prior Jacobian
+ * (row-major, packed) and r0[n] the n_full prior residuals.
+ * Refused (SADVIO_E_INVALID_ARG) on a window sharded over several GPUs: each rank holds a landmark partition only. */
 int sadvio_ba_marginalize(sadvio_ba_handle *h, int32_t w, const sadvio_marg_request *rq, sadvio_marg_result *res,
                           int32_t *lmk_col, double *J, double *r0);
+
+/* The handle's prior: read-back on request (any pointer may be NULL; J has room for n_full * n, r0 for n_full doubles),
+ * upload of a prior kept elsewhere (e.g. restored from a dump; n_full = 0 clears it), and its shape. */
+typedef struct sadvio_prior_info {
+    int32_t valid, n_full, n, form;
+} sadvio_prior_info;
+int sadvio_ba_get_prior(sadvio_ba_handle *h, sadvio_prior_info *info, double *J, double *r0);
+int sadvio_ba_set_prior(sadvio_ba_handle *h, int32_t n_full, int32_t n, int32_t form, const double *J, const double *r0);
 
 /* NFR sparsification of a dense prior (Marginalization::sparsifyVIO / sparsifyVO, marginalization.cpp:362-514) into
  * the factor list of the sparse branch of addMarginalizationResiduals (…Analytic.cpp:363-426): vio != 0 -> one
  * IMUPriordx on kf_keep + one PoseToLandmarkFactor per kept landmark; vio == 0 -> greedy landmark chain ordered by
  * |tr Lambda_ij|, a Landmark3DPrior on the minimum-entropy landmark + LandmarkToLandmarkFactor links. The prior is
- * the (J, column map) pair produced by sadvio_ba_marginalize / passed to sadvio_ba_set_dense_prior; linearisation
- * values (T_f_w, v, ba, bg, landmark positions) are those of window `w`. `out` has room for n_keep + 1 factors. */
+ * the (J, column map) pair produced by sadvio_ba_marginalize / passed to sadvio_ba_set_dense_prior; J == NULL = the
+ * handle's prior (n_full / n are then taken from it and the arguments ignored; nothing is uploaded). A host J must be in
+ * the EIGEN form (orthogonal rows); the handle's prior may be in either form. Linearisation values (T_f_w, v, ba, bg,
+ * landmark positions) are those of window `w`. `out` has room for n_keep + 1 factors. Refused on a sharded window. */
 int sadvio_ba_sparsify(sadvio_ba_handle *h, int32_t w, int32_t vio, int32_t n_full, int32_t n, const double *J,
                        int32_t kf_keep, int32_t kf_col, int32_t n_keep, const int32_t *lmk_index, const int32_t *lmk_col,
                        int32_t *n_out, sadvio_sparse_prior *out);
@@ -329,15 +376,17 @@ int sadvio_ba_sparsify(sadvio_ba_handle *h, int32_t w, int32_t vio, int32_t n_fu
  * landmarks count twice). Frames with IMU states are refused (the reference indexes their velocity / bias columns
  * outside of its own layout, :705-737). Returns SADVIO_E_REFUSED when no landmark is shared, SADVIO_E_INVALID_ARG on a
  * window sharded over several GPUs (each rank only holds its landmark partition: the sum would be partial).
- * Eigenvalue cuts: the reference drops eigenvalues <= 1e-12 absolutely (Marginalization::_eps). In float64 that cut sits
- * below the rounding noise of the sums it is applied to (on the reference's own test fixture the null
- * eigenvalue computes to +-1e-11), so this library — and the oracle — use max(1e-12, m eps lambda_max) on the 3m x 3m
- * landmark block and max(1e-12, 12 eps lambda_max (2 + n_items)) on Ak; sadvio_ba_marginalize uses
- * max(1e-12, n eps lambda_max) likewise. With thousands of shared landmarks the floor reaches 1e-8 .. 1e-6 relative to
- * lambda_max ~ 1e7..1e9: directions whose information is below that (far, low-parallax depth) are treated as
- * unobserved, where the reference would invert their rounding noise.
+ * Eigenvalue cuts (`eig_cut_mode`, SADVIO_EIG_CUT_* above): REFERENCE drops eigenvalues <= 1e-12 absolutely
+ * (Marginalization::_eps) on the 3m x 3m landmark block and on Ak; NOISE_FLOOR uses max(1e-12, m eps lambda_max) on the
+ * landmark block and max(1e-12, 12 eps lambda_max (2 + n_items)) on Ak (in float64 the absolute cut sits
+ * below the rounding noise of the sums it is applied to — on the reference's own test fixture the null eigenvalue computes
+ * to +-1e-11, and the gauge null space of a summed Schur complement to 1e-7 .. 4e-6). With thousands of shared landmarks
+ * that floor reaches 1e-8 .. 1e-6 relative to lambda_max ~ 1e7..1e9: directions whose information is below it (far,
+ * low-parallax depth) are treated as unobserved, where the reference mode inverts them (and, for an exactly-null
+ * direction, inverts its rounding noise: the recovered information is then only meaningful if the pair is well posed).
  * inf36: 6x6 row-major (rotation 3 | translation 3); Ak144 (may be NULL): the 12x12 reduced information. */
-int sadvio_ba_marginalize_relative(sadvio_ba_handle *h, int32_t w, int32_t kf_a, int32_t kf_b, double *inf36, double *Ak144);
+int sadvio_ba_marginalize_relative(sadvio_ba_handle *h, int32_t w, int32_t kf_a, int32_t kf_b, int32_t eig_cut_mode, double *inf36,
+                                   double *Ak144);
 
 /* ---- one window spanning several GPUs (no reference counterpart: the reference is one process) ----
  * The landmarks of a window (with all their observations) are partitioned over `world` processes, one GPU each;

@@ -301,7 +301,7 @@ class HipOptimizer {
         // the previous prior is folded in whenever it kept landmarks (:573); its kept frame — VIO only — is frame0 now.
         // A VO prior (kf_col < 0) has no frame to match
         if (_prior.valid && !_prior.lmk_id.empty() && (_prior.kf_col < 0 || _prior.kf_id == map.frames[frame0].id)) {
-            rq.last_n_full = _prior.n_full; rq.last_n = _prior.n; rq.last_J = _prior.J.data(); rq.last_r0 = _prior.r0.data();
+            rq.last_n_full = SADVIO_PRIOR_RESIDENT;   // the prior never left the device (the handle holds it, AOptimizer.h:88-90)
             rq.last_kf = _prior.kf_col >= 0 ? frame0 : -1; rq.last_kf_col = std::max(_prior.kf_col, 0);
             for (size_t q = 0; q < _prior.lmk_id.size(); q++) {
                 int fi = -1;
@@ -310,26 +310,27 @@ class HipOptimizer {
             }
             rq.last_n_keep = (int)last_idx.size(); rq.last_lmk_index = last_idx.data(); rq.last_lmk_col = last_col.data();
         }
-        const int n = (rq.kf_keep >= 0 ? 15 : 0) + 3 * rq.n_keep;
+        rq.eig_cut_mode = _eig_cut_mode; rq.prior_form = _prior_form;
         std::vector<int32_t> lcol(std::max<size_t>(keep.size(), 1));
-        std::vector<double> J((size_t)std::max(n * n, 1)), r0((size_t)std::max(n, 1));
         sadvio_marg_result res{};
         if (F.non_pinhole_pixel) {   // the reference's own pixel factor has no Jacobian for these models (fisheye.cpp:352-405)
             _err = "pixel factor with a non-pinhole camera: use the angular backend (HipOptimizer(device, true))";
             return false;
         }
         int rc = upload(F);
-        if (rc == SADVIO_OK) rc = sadvio_ba_marginalize(_h, 0, &rq, &res, lcol.data(), J.data(), r0.data());
+        if (rc == SADVIO_OK) rc = sadvio_ba_marginalize(_h, 0, &rq, &res, lcol.data(), nullptr, nullptr);   // J, r0 stay on the device
         _prior = Prior(); _sparse.clear(); _sparse_lmk_id.clear();
-        if (rc != SADVIO_OK) { if (rc != SADVIO_E_REFUSED) _err = sadvio_ba_last_error(_h); return false; }
-        _prior.valid = true; _prior.n_full = res.n_full; _prior.n = res.n;
-        _prior.J.assign(J.begin(), J.begin() + (size_t)res.n_full * res.n); _prior.r0.assign(r0.begin(), r0.begin() + res.n_full);
+        if (rc != SADVIO_OK) {
+            if (rc != SADVIO_E_REFUSED) { _err = sadvio_ba_last_error(_h); sadvio_ba_set_prior(_h, 0, 0, 0, nullptr, nullptr); }   // no stale prior behind a failed call
+            return false;
+        }
+        _prior.valid = res.n_full > 0; _prior.n_full = res.n_full; _prior.n = res.n;
         _prior.kf_id = rq.kf_keep >= 0 ? map.frames[frame1].id : -1; _prior.kf_col = res.kf_col;
         for (size_t k = 0; k < keep.size(); k++) { _prior.lmk_id.push_back(F.lmk_id[keep[k]]); _prior.lmk_col.push_back(lcol[k]); }
         if (enable_sparsif && keep.size() > 1) {
             std::vector<sadvio_sparse_prior> out(keep.size() + 1);
             int32_t n_out = 0;
-            rc = sadvio_ba_sparsify(_h, 0, rq.kf_keep >= 0, res.n_full, res.n, _prior.J.data(), rq.kf_keep, std::max(res.kf_col, 0),
+            rc = sadvio_ba_sparsify(_h, 0, rq.kf_keep >= 0, 0, 0, nullptr /* the handle's prior */, rq.kf_keep, std::max(res.kf_col, 0),
                                     (int)keep.size(), keep.data(), lcol.data(), &n_out, out.data());
             if (rc == SADVIO_OK) {
                 _sparse.assign(out.begin(), out.begin() + n_out);
@@ -352,7 +353,7 @@ class HipOptimizer {
         if (F.non_pinhole_pixel) { _err = "pixel factor with a non-pinhole camera: use the angular backend"; return false; }
         double Ak[144];
         int rc = upload(F, false);
-        if (rc == SADVIO_OK) rc = sadvio_ba_marginalize_relative(_h, 0, frame0, frame1, inf36, Ak);
+        if (rc == SADVIO_OK) rc = sadvio_ba_marginalize_relative(_h, 0, frame0, frame1, _eig_cut_mode, inf36, Ak);
         if (rc != SADVIO_OK) { _err = sadvio_ba_last_error(_h); for (int i = 0; i < 36; i++) inf36[i] = 0.0; return false; }
         if (Ak144) std::memcpy(Ak144, Ak, sizeof(Ak));
         return true;
@@ -361,7 +362,23 @@ class HipOptimizer {
     bool has_prior() const { return _prior.valid; }
     int prior_rows() const { return _prior.n_full; }
     int prior_cols() const { return _prior.n; }
-    const std::vector<double>& prior_J() const { return _prior.J; }               // n_full x n row-major
+    // n_full x n row-major, read back from the device on request (sadvio_ba_get_prior): the solve path never needs it on the host
+    std::vector<double> prior_J() const {
+        std::vector<double> J((size_t)std::max(_prior.n_full * _prior.n, 0));
+        if (_prior.valid && sadvio_ba_get_prior(_h, nullptr, J.data(), nullptr) != SADVIO_OK) J.clear();
+        return J;
+    }
+    std::vector<double> prior_r0() const {
+        std::vector<double> r((size_t)std::max(_prior.n_full, 0));
+        if (_prior.valid && sadvio_ba_get_prior(_h, nullptr, nullptr, r.data()) != SADVIO_OK) r.clear();
+        return r;
+    }
+    // Eigenvalue cut of marginalize / marginalizeRelative (SADVIO_EIG_CUT_*; default: the reference's absolute 1e-12,
+    // marginalization.hpp:58) and form of the stored prior (SADVIO_PRIOR_FORM_*; default: the rank-revealing Cholesky factor —
+    // same MarginalizationFactor cost / gradient / Gauss-Newton matrix as the reference's Lambda^1/2 U^T, 5 x faster to form;
+    // SADVIO_PRIOR_FORM_EIGEN reproduces the reference's rows).
+    void set_eig_cut_mode(int mode) { _eig_cut_mode = mode; }
+    void set_prior_form(int form) { _prior_form = form; }
     const std::vector<int64_t>& prior_landmark_ids() const { return _prior.lmk_id; }
     const std::vector<int32_t>& prior_landmark_cols() const { return _prior.lmk_col; }
     size_t sparse_factor_count() const { return _sparse.size(); }
@@ -396,8 +413,7 @@ class HipOptimizer {
         bool valid = false;
         int n_full = 0, n = 0, kf_col = -1;
         int64_t kf_id = -1;
-        std::vector<double> J, r0;
-        std::vector<int64_t> lmk_id;
+        std::vector<int64_t> lmk_id;   // J, r0 themselves live in the backend handle (device resident)
         std::vector<int32_t> lmk_col;
     };
 
@@ -529,7 +545,7 @@ class HipOptimizer {
             for (size_t k = 0; k < F.lmk_id.size(); k++) if (F.lmk_id[k] == _prior.lmk_id[q]) fi = (int)k;
             idx.push_back(fi < 0 ? 0 : fi); col.push_back(fi < 0 ? -1 : _prior.lmk_col[q]);   // absent landmark: zero delta
         }
-        return sadvio_ba_set_dense_prior(_h, 0, _prior.n_full, _prior.n, _prior.J.data(), _prior.r0.data(), kf, std::max(_prior.kf_col, 0),
+        return sadvio_ba_set_dense_prior(_h, 0, SADVIO_PRIOR_RESIDENT, 0, nullptr, nullptr, kf, std::max(_prior.kf_col, 0),
                                          (int)idx.size(), idx.data(), col.data());
     }
 
@@ -624,6 +640,7 @@ class HipOptimizer {
 
     std::string _dump_dir;
     int _dump_count = 0;
+    int _eig_cut_mode = SADVIO_EIG_CUT_REFERENCE, _prior_form = SADVIO_PRIOR_FORM_CHOLESKY;
     sadvio_ba_handle* _h = nullptr;
     sadvio_solve_summary _sum{};
     std::string _err;

@@ -23,13 +23,17 @@
 #define MARG_EPS 1e-12 /* marginalization.hpp:56 */
 static void small_inverse(const double *A, int n, double *Ai);
 
-/* Eigenvalue cut of the pseudo-inverse / rank-revealing decomposition. The reference keeps
- * lambda > 1e-12 (absolute, marginalization.cpp:237,322). On its own test fixture
- * (marginalization_test.cpp, |Amm| ~ 1e5) the null eigenvalue computes to +-1e-11 — rounding noise
- * ABOVE that absolute cut — so the reference's result there depends on the sign of a rounding error.
- * The restatement keeps the reference's constant and adds the standard noise floor n*eps*lambda_max,
- * i.e. what the reference's cut is meant to do (drop the null space). */
-static double marg_cut(const double *ev, int n) {
+/* Eigenvalue cut of the pseudo-inverse / rank-revealing decomposition (sadvio_ba.h: SADVIO_EIG_CUT_*).
+ *   SADVIO_EIG_CUT_REFERENCE (0): the reference's arithmetic — keep lambda > 1e-12, absolute (Marginalization::_eps,
+ *     marginalization.hpp:58, applied at marginalization.cpp:237,322). On the reference's own test fixture
+ *     (marginalization_test.cpp, |Amm| ~ 1e5) the null eigenvalue computes to +-1e-11 — rounding noise ABOVE that cut — so
+ *     whether an exactly-null direction is kept depends on the sign of a rounding error, there as here; n_full is therefore
+ *     not reproducible across eigen-solvers in this mode, the prior's information (J^T J, J^T r0) is, to rounding.
+ *   SADVIO_EIG_CUT_NOISE_FLOOR (1): the reference's constant with the standard noise floor n*eps*lambda_max, i.e. what the
+ *     cut is meant to do (drop the null space) — reproducible n_full, at the price of dropping directions whose information
+ *     lies between 1e-12 and the floor (far, low-parallax depth), which the reference keeps. */
+static double marg_cut(const double *ev, int n, int mode) {
+    if (mode != SADVIO_EIG_CUT_NOISE_FLOOR) return MARG_EPS;
     double mx = 0;
     for (int i = 0; i < n; i++) mx = fmax(mx, fabs(ev[i]));
     return fmax(MARG_EPS, (double)n * 2.220446049250313e-16 * mx);
@@ -237,7 +241,7 @@ int oracle_marginalize(const oracle_marg_request *rq, oracle_marg_result *res, i
     double *ev = (double *)malloc(sizeof(double) * (size_t)m), *V = (double *)malloc(sizeof(double) * (size_t)m * m);
     oracle_sym_eig(Amm, m, ev, V);
     double *Ainv = (double *)calloc((size_t)m * m, sizeof(double));
-    double cut_m = marg_cut(ev, m);
+    double cut_m = marg_cut(ev, m, rq->eig_cut_mode);
     for (int k = 0; k < m; k++) {
         if (!(ev[k] > cut_m)) continue;
         double iv = 1.0 / ev[k];
@@ -273,7 +277,7 @@ int oracle_marginalize(const oracle_marg_request *rq, oracle_marg_result *res, i
     double *ev2 = (double *)malloc(sizeof(double) * (size_t)n), *V2 = (double *)malloc(sizeof(double) * (size_t)n * n);
     oracle_sym_eig(Aks, n, ev2, V2);
     int nf = 0;
-    double cut_n = marg_cut(ev2, n);
+    double cut_n = marg_cut(ev2, n, rq->eig_cut_mode);
     for (int k = 0; k < n; k++)
         if (ev2[k] > cut_n) nf++;
     if (res) res->n_full = nf;
@@ -306,8 +310,8 @@ int oracle_marginalize(const oracle_marg_request *rq, oracle_marg_result *res, i
  * entries), so the decomposition is done block by block — the same eigenvalues, the same cut, the same pseudo-inverse.
  * Then Sigma_k = U diag(1 / lambda) U^T (:255-262) and inf = (J Sigma_k J^T)^-1 with J = [Ja Jb] of
  * Relative6DPose(T_w_a, T_w_b, T_a_b, I) at zero deltas (:784-807). */
-int oracle_marginalize_relative(const sadvio_flat_window *w, int32_t kf_a, int32_t kf_b, double *inf36, double *Ak_out /*144 or NULL*/,
-                                int32_t *m_out) {
+int oracle_marginalize_relative(const sadvio_flat_window *w, int32_t kf_a, int32_t kf_b, int32_t eig_cut_mode, double *inf36,
+                                double *Ak_out /*144 or NULL*/, int32_t *m_out) {
     static const double z[6] = {0, 0, 0, 0, 0, 0};
     if (w->has_imu) return SADVIO_E_INVALID_ARG;
     /* entries: (landmark, first index) in the order of preMarginalizeRelative */
@@ -366,7 +370,7 @@ int oracle_marginalize_relative(const sadvio_flat_window *w, int32_t kf_a, int32
         oracle_sym_eig(B, 3, e3, V3);
         for (int k = 0; k < 3; k++) { ev[c0 + k] = e3[k]; for (int a = 0; a < 3; a++) V[(size_t)(c0 + a) * 3 + k] = V3[3 * a + k]; }
     }
-    const double cut = marg_cut(ev, m);
+    const double cut = marg_cut(ev, m, eig_cut_mode);
     double Ak[144];
     memcpy(Ak, Arr, sizeof(Ak));
     for (int c0 = 0; c0 < m; c0 += 3) {
@@ -393,9 +397,10 @@ int oracle_marginalize_relative(const sadvio_flat_window *w, int32_t kf_a, int32
      * lambda_max, i.e. ~ eps * lambda_max * (number of terms), 1e-7 .. 4e-6 on the test windows against 1e3 for the
      * smallest real eigenvalue. The reference's absolute 1e-12 (marginalization.cpp:322) keeps whichever of them come out
      * positive (1 / lambda ~ 1e6: its information matrix is then noise); the cut here is the noise floor of that sum, which
-     * returns the exact-arithmetic value of the reference's formula (cf. marg_cut). */
-    double cut_n = marg_cut(ev2, 12);
-    {
+     * returns the exact-arithmetic value of the reference's formula (cf. marg_cut) — SADVIO_EIG_CUT_NOISE_FLOOR; SADVIO_EIG_CUT_REFERENCE
+     * applies the absolute constant as coded. */
+    double cut_n = marg_cut(ev2, 12, eig_cut_mode);
+    if (eig_cut_mode == SADVIO_EIG_CUT_NOISE_FLOOR) {
         int n_l = 0;
         for (int l = 0; l < w->n_lmk; l++) n_l += first[l] >= 0;
         cut_n = fmax(cut_n, cut_n * (2.0 + n_l));

@@ -51,7 +51,11 @@ class MargRequest(C.Structure):
                 ("lmk_keep", _ip), ("imu", C.POINTER(ImuFactorC)), ("n_prior", C.c_int32),
                 ("priors", C.POINTER(PosePriorC)), ("last_n_full", C.c_int32), ("last_n", C.c_int32),
                 ("last_J", _dp), ("last_r0", _dp), ("last_kf", C.c_int32), ("last_kf_col", C.c_int32),
-                ("last_n_keep", C.c_int32), ("last_lmk_index", _ip), ("last_lmk_col", _ip)]
+                ("last_n_keep", C.c_int32), ("last_lmk_index", _ip), ("last_lmk_col", _ip),
+                ("eig_cut_mode", C.c_int32), ("pad", C.c_int32)]
+
+
+EIG_CUT = {"reference": 0, "noise_floor": 1}   # SADVIO_EIG_CUT_* (include/sadvio_ba.h)
 
 
 class MargResult(C.Structure):
@@ -208,7 +212,8 @@ def sparse_factor(w: FlatWindow, k: int, xp=None, xv=None, xba=None, xbg=None, x
     return r[:rows].copy(), J[:rows].copy()
 
 
-def marginalize(w: FlatWindow, kf_marg, lmk_marg, lmk_keep, kf_keep=-1, marg_has_imu=False, imu=None, priors=(), last=None, want_full=False):
+def marginalize(w: FlatWindow, kf_marg, lmk_marg, lmk_keep, kf_keep=-1, marg_has_imu=False, imu=None, priors=(), last=None, want_full=False,
+                eig_cut="noise_floor"):
     """oracle_marginalize with the same calling convention as capi.Backend.marginalize. Returns None when refused.
     want_full: also return A_full [(m+n)^2], b_full [m+n] (the un-reduced information / gradient, computeInformationAndGradient)."""
     wc, wkeep = S.window_to_c(w)
@@ -218,6 +223,7 @@ def marginalize(w: FlatWindow, kf_marg, lmk_marg, lmk_keep, kf_keep=-1, marg_has
     rq.kf_marg, rq.kf_keep, rq.marg_has_imu = kf_marg, kf_keep, int(bool(marg_has_imu))
     rq.n_marg, rq.lmk_marg = len(mk), mk.ctypes.data_as(_ip)
     rq.n_keep, rq.lmk_keep = len(kp), kp.ctypes.data_as(_ip)
+    rq.eig_cut_mode = EIG_CUT[eig_cut]
     keep = [wc, wkeep, mk, kp]
     if imu is not None:
         ia = (ImuFactorC * 1)()
@@ -256,13 +262,13 @@ def marginalize(w: FlatWindow, kf_marg, lmk_marg, lmk_keep, kf_keep=-1, marg_has
             "lmk_index": kp.copy(), "lmk_col": lmk_col[: len(kp)].copy(), "m": res.m, "n": res.n, "n_full": nf, "Ak": Ak, "bk": bk}
 
 
-def marginalize_relative(w: FlatWindow, kf_a: int, kf_b: int):
+def marginalize_relative(w: FlatWindow, kf_a: int, kf_b: int, eig_cut="noise_floor"):
     """(inf[6,6], Ak[12,12], m) of oracle_marginalize_relative, or None when no landmark is shared."""
     wc, wkeep = S.window_to_c(w)
     inf = np.zeros((6, 6)); Ak = np.zeros((12, 12)); m = C.c_int32(0)
     f = lib().oracle_marginalize_relative
-    f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(C.c_int32)]
-    rc = f(C.byref(wc), kf_a, kf_b, _p(inf), _p(Ak), C.byref(m))
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.POINTER(C.c_int32)]
+    rc = f(C.byref(wc), kf_a, kf_b, EIG_CUT[eig_cut], _p(inf), _p(Ak), C.byref(m))
     if rc != 0:
         return None
     return inf, Ak, m.value

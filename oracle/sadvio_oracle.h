@@ -57,7 +57,8 @@ int oracle_solve(const oracle_problem *prob, const sadvio_solve_options *opts, s
                  double *iter_log, int32_t iter_log_cap);
 
 /* marginalizeRelative (…Analytic.cpp:665-809): 6x6 information of the relative pose of two VO key-frames. */
-int oracle_marginalize_relative(const sadvio_flat_window *win, int32_t kf_a, int32_t kf_b, double *inf36, double *Ak144, int32_t *m_out);
+int oracle_marginalize_relative(const sadvio_flat_window *win, int32_t kf_a, int32_t kf_b, int32_t eig_cut_mode, double *inf36, double *Ak144,
+                                int32_t *m_out);
 
 /* ALandmark::sanityCheck per landmark (ALandmark.cpp:98-146): mean chi2 of the landmark's observations (failed
  * projection = 1000) and the 95 % gate (n_obs >= 2 && mean <= 2). Either output may be NULL. */
@@ -131,6 +132,8 @@ typedef struct oracle_marg_request {
     int32_t last_n_keep;
     const int32_t *last_lmk_index; /* window landmark indices of the previous prior's kept landmarks */
     const int32_t *last_lmk_col;
+    int32_t eig_cut_mode; /* SADVIO_EIG_CUT_* (sadvio_ba.h): 0 = the reference's absolute 1e-12, 1 = with the noise floor */
+    int32_t pad;
 } oracle_marg_request;
 
 typedef struct oracle_marg_result {

@@ -95,7 +95,20 @@ class MargRequestC(C.Structure):
                 ("lmk_marg", _ip), ("n_keep", C.c_int32), ("lmk_keep", _ip), ("imu", C.POINTER(ImuFactorC)),
                 ("n_prior", C.c_int32), ("priors", C.POINTER(PosePriorC)), ("last_n_full", C.c_int32), ("last_n", C.c_int32),
                 ("last_J", _dp), ("last_r0", _dp), ("last_kf", C.c_int32), ("last_kf_col", C.c_int32),
-                ("last_n_keep", C.c_int32), ("last_lmk_index", _ip), ("last_lmk_col", _ip)]
+                ("last_n_keep", C.c_int32), ("last_lmk_index", _ip), ("last_lmk_col", _ip),
+                ("eig_cut_mode", C.c_int32), ("prior_form", C.c_int32)]
+
+
+class PriorInfoC(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("n_full", C.c_int32), ("n", C.c_int32), ("form", C.c_int32)]
+
+
+PRIOR_RESIDENT = -1
+# SADVIO_EIG_CUT_*: the C ABI's default (a zero-initialised request) is the reference's absolute 1e-12; this harness and the
+# oracle's wrapper default to "noise_floor" because the parity tests compare n_full, which only that mode makes reproducible
+# across eigen-solvers (sadvio_ba.h); tests of the reference mode pass eig_cut="reference" on both sides.
+EIG_CUT = {"reference": 0, "noise_floor": 1}
+PRIOR_FORM = {"eigen": 0, "cholesky": 1}          # SADVIO_PRIOR_FORM_*
 
 
 class MargResultC(C.Structure):
@@ -351,7 +364,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.sadvio_ba_get_trace.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _dp, _ip]
     lib.sadvio_ba_set_lines.argtypes = [C.c_void_p, C.c_int32, C.POINTER(LineSetC)]
     lib.sadvio_ba_get_line_deltas.argtypes = [C.c_void_p, C.c_int32, _dp]
-    lib.sadvio_ba_marginalize_relative.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]
+    lib.sadvio_ba_marginalize_relative.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]
+    lib.sadvio_ba_get_prior.argtypes = [C.c_void_p, C.POINTER(PriorInfoC), _dp, _dp]
+    lib.sadvio_ba_set_prior.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]
     lib.sadvio_ba_linearize.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
     lib.sadvio_ba_vi_init.argtypes = [C.c_void_p, C.POINTER(ViInitProblemC), C.POINTER(SolveOptions), C.POINTER(SolveSummary),
                                       C.POINTER(ViInitResultC), _dp]
@@ -457,28 +472,36 @@ class Backend:
         return out
 
     def set_dense_prior(self, w: int, dp: Optional[dict]):
-        """Dense marginalisation prior of window w (None clears it)."""
+        """Dense marginalisation prior of window w (None clears it). A dict without "J" (or with resident=True) attaches the
+        handle's own prior (SADVIO_PRIOR_RESIDENT): only the kept frame / landmark lists are passed."""
         if dp is None:
             self._check(self.lib.sadvio_ba_set_dense_prior(self.h, w, 0, 0, None, None, -1, 0, 0, None, None), "set_dense_prior")
             return
-        J = np.ascontiguousarray(dp["J"], dtype=np.float64)
-        r0 = np.ascontiguousarray(dp["r0"], dtype=np.float64)
         li = np.ascontiguousarray(dp.get("lmk_index", []), dtype=np.int32)
         lc = np.ascontiguousarray(dp.get("lmk_col", []), dtype=np.int32)
+        if dp.get("resident") or dp.get("J") is None:
+            self._check(self.lib.sadvio_ba_set_dense_prior(self.h, w, PRIOR_RESIDENT, 0, None, None, int(dp.get("kf_keep", -1)), int(dp.get("kf_col", 0)),
+                                                           len(li), li.ctypes.data_as(_ip), lc.ctypes.data_as(_ip)), "set_dense_prior")
+            return
+        J = np.ascontiguousarray(dp["J"], dtype=np.float64)
+        r0 = np.ascontiguousarray(dp["r0"], dtype=np.float64)
         self._check(self.lib.sadvio_ba_set_dense_prior(self.h, w, J.shape[0], J.shape[1], _ptr(J), _ptr(r0),
                                                        int(dp.get("kf_keep", -1)), int(dp.get("kf_col", 0)), len(li),
                                                        li.ctypes.data_as(_ip), lc.ctypes.data_as(_ip)), "set_dense_prior")
 
     def marginalize(self, w: int, kf_marg: int, lmk_marg, lmk_keep, kf_keep: int = -1, marg_has_imu: bool = False,
-                    imu: Optional[dict] = None, priors=(), last: Optional[dict] = None):
+                    imu: Optional[dict] = None, priors=(), last: Optional[dict] = None, eig_cut: str = "noise_floor",
+                    form: str = "eigen", readback: bool = True):
         """Dense prior from marginalising key-frame kf_marg of window w (sadvio_ba_marginalize). `last` = previous
-        prior as a dense_prior dict. Returns None when refused (n < 4), else a dense_prior dict for the NEXT window
-        (landmark indices still refer to this window) + bookkeeping."""
+        prior as a dense_prior dict (without "J": the handle's resident prior). Returns None when refused (n < 4), else a
+        dense_prior dict for the NEXT window (landmark indices still refer to this window) + bookkeeping; with
+        readback=False the dict carries no J / r0 (resident=True): the prior only lives on the device."""
         rq = MargRequestC()
         mk = np.ascontiguousarray(lmk_marg, dtype=np.int32); kp = np.ascontiguousarray(lmk_keep, dtype=np.int32)
         rq.kf_marg, rq.kf_keep, rq.marg_has_imu = kf_marg, kf_keep, int(bool(marg_has_imu))
         rq.n_marg, rq.lmk_marg = len(mk), mk.ctypes.data_as(_ip)
         rq.n_keep, rq.lmk_keep = len(kp), kp.ctypes.data_as(_ip)
+        rq.eig_cut_mode, rq.prior_form = EIG_CUT[eig_cut], PRIOR_FORM[form]
         keep = [mk, kp]
         if imu is not None:
             ia = (ImuFactorC * 1)()
@@ -490,41 +513,74 @@ class Backend:
             pa[i].kf = int(kf); pa[i].T_prior[:] = list(np.asarray(T, dtype=np.float64).ravel()); pa[i].inf_diag[:] = list(np.asarray(inf, dtype=np.float64).ravel())
         rq.n_prior, rq.priors = len(priors), pa
         if last is not None:
-            J = np.ascontiguousarray(last["J"], dtype=np.float64); r0 = np.ascontiguousarray(last["r0"], dtype=np.float64)
             li = np.ascontiguousarray(last.get("lmk_index", []), dtype=np.int32); lc = np.ascontiguousarray(last.get("lmk_col", []), dtype=np.int32)
-            rq.last_n_full, rq.last_n = J.shape
-            rq.last_J, rq.last_r0 = _ptr(J), _ptr(r0)
+            if last.get("resident") or last.get("J") is None:
+                rq.last_n_full, rq.last_n = PRIOR_RESIDENT, 0
+            else:
+                J = np.ascontiguousarray(last["J"], dtype=np.float64); r0 = np.ascontiguousarray(last["r0"], dtype=np.float64)
+                rq.last_n_full, rq.last_n = J.shape
+                rq.last_J, rq.last_r0 = _ptr(J), _ptr(r0)
+                keep += [J, r0]
             rq.last_kf, rq.last_kf_col = int(last.get("kf_keep", -1)), int(last.get("kf_col", 0))
             rq.last_n_keep, rq.last_lmk_index, rq.last_lmk_col = len(li), li.ctypes.data_as(_ip), lc.ctypes.data_as(_ip)
-            keep += [J, r0, li, lc]
+            keep += [li, lc]
         n = (15 if kf_keep >= 0 else 0) + 3 * len(kp)
         res = MargResultC()
-        lmk_col = np.zeros(max(len(kp), 1), dtype=np.int32); Jo = np.zeros(max(n * n, 1)); r0o = np.zeros(max(n, 1))
+        lmk_col = np.zeros(max(len(kp), 1), dtype=np.int32)
+        Jo = np.zeros(max(n * n, 1)) if readback else None
+        r0o = np.zeros(max(n, 1)) if readback else None
         rc = self.lib.sadvio_ba_marginalize(self.h, w, C.byref(rq), C.byref(res), lmk_col.ctypes.data_as(_ip), _ptr(Jo), _ptr(r0o))
         if rc == E_REFUSED:
             return None
         self._check(rc, "marginalize")
         nf = res.n_full
-        return {"J": Jo[: nf * n].reshape(nf, n).copy(), "r0": r0o[:nf].copy(), "kf_keep": kf_keep, "kf_col": res.kf_col,
-                "lmk_index": kp.copy(), "lmk_col": lmk_col[: len(kp)].copy(), "m": res.m, "n": res.n, "n_full": nf,
-                "sweeps": (res.sweeps_mm, res.sweeps_k)}
+        out = {"kf_keep": kf_keep, "kf_col": res.kf_col, "lmk_index": kp.copy(), "lmk_col": lmk_col[: len(kp)].copy(), "m": res.m, "n": res.n,
+               "n_full": nf, "sweeps": (res.sweeps_mm, res.sweeps_k), "form": form}
+        if readback:
+            out["J"] = Jo[: nf * n].reshape(nf, n).copy(); out["r0"] = r0o[:nf].copy()
+        else:
+            out["resident"] = True
+        return out
 
-    def marginalize_relative(self, w: int, kf_a: int, kf_b: int):
+    def get_prior(self, readback: bool = True):
+        """The handle's prior (sadvio_ba_get_prior): {"valid", "n_full", "n", "form"[, "J", "r0"]}."""
+        info = PriorInfoC()
+        self._check(self.lib.sadvio_ba_get_prior(self.h, C.byref(info), None, None), "get_prior")
+        out = {"valid": bool(info.valid), "n_full": info.n_full, "n": info.n, "form": "cholesky" if info.form == 1 else "eigen"}
+        if info.valid and readback:
+            J = np.zeros((info.n_full, info.n)); r0 = np.zeros(info.n_full)
+            self._check(self.lib.sadvio_ba_get_prior(self.h, None, _ptr(J), _ptr(r0)), "get_prior")
+            out["J"], out["r0"] = J, r0
+        return out
+
+    def set_prior(self, J: Optional[np.ndarray], r0: Optional[np.ndarray] = None):
+        """Upload an eigen-form prior as the handle's (None clears it)."""
+        if J is None:
+            self._check(self.lib.sadvio_ba_set_prior(self.h, 0, 0, 0, None, None), "set_prior")
+            return
+        J = np.ascontiguousarray(J, dtype=np.float64); r0 = np.ascontiguousarray(r0, dtype=np.float64)
+        self._check(self.lib.sadvio_ba_set_prior(self.h, J.shape[0], J.shape[1], 0, _ptr(J), _ptr(r0)), "set_prior")
+
+    def marginalize_relative(self, w: int, kf_a: int, kf_b: int, eig_cut: str = "noise_floor"):
         """(inf[6,6], Ak[12,12]) of sadvio_ba_marginalize_relative, or None when refused (no shared landmark)."""
         inf = np.zeros((6, 6)); Ak = np.zeros((12, 12))
-        rc = self.lib.sadvio_ba_marginalize_relative(self.h, w, kf_a, kf_b, _ptr(inf), _ptr(Ak))
+        rc = self.lib.sadvio_ba_marginalize_relative(self.h, w, kf_a, kf_b, EIG_CUT[eig_cut], _ptr(inf), _ptr(Ak))
         if rc == E_REFUSED:
             return None
         self._check(rc, "marginalize_relative")
         return inf, Ak
 
     def sparsify(self, w: int, prior: dict, vio: bool):
-        """NFR sparsification of a dense prior dict (as returned by marginalize) into sparse_priors dicts."""
-        J = np.ascontiguousarray(prior["J"], dtype=np.float64)
+        """NFR sparsification of a dense prior dict (as returned by marginalize; without "J": the handle's resident prior)
+        into sparse_priors dicts."""
         li = np.ascontiguousarray(prior.get("lmk_index", []), dtype=np.int32); lc = np.ascontiguousarray(prior.get("lmk_col", []), dtype=np.int32)
         out = (SparsePriorC * (len(li) + 1))()
         n_out = C.c_int32(0)
-        rc = self.lib.sadvio_ba_sparsify(self.h, w, int(bool(vio)), J.shape[0], J.shape[1], _ptr(J), int(prior.get("kf_keep", -1)),
+        if prior.get("resident") or prior.get("J") is None:
+            J = None; nf = nn = 0
+        else:
+            J = np.ascontiguousarray(prior["J"], dtype=np.float64); nf, nn = J.shape
+        rc = self.lib.sadvio_ba_sparsify(self.h, w, int(bool(vio)), nf, nn, _ptr(J), int(prior.get("kf_keep", -1)),
                                          int(prior.get("kf_col", 0)), len(li), li.ctypes.data_as(_ip), lc.ctypes.data_as(_ip),
                                          C.byref(n_out), out)
         if rc == E_REFUSED:

@@ -54,6 +54,7 @@ struct DevBuf {
     bool view = false;  // non-owning window into another buffer
     void set_view(T* ptr, size_t count) { if (p && !view) (void)hipFree(p); p = ptr; n = count; view = true; }
     void release() { if (p && !view) (void)hipFree(p); p = nullptr; n = 0; view = false; }
+    void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(view, o.view); }
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
@@ -170,8 +171,38 @@ struct UploadBatch {
 
 struct DensePriorHost {
     int n_full = 0, n = 0, kf_keep = -1, kf_col = 0;
+    bool resident = false;      // J, r0 = the handle's prior (PriorState), copied device to device
+    unsigned long long serial = 0;   // ... as it was when set_dense_prior named it
     std::vector<double> J, r0;
     std::vector<int> lmk_index, lmk_col;
+};
+
+// The handle's marginalisation prior: what the reference keeps in `_marginalization_last` inside the optimizer between
+// marginalize() and the next window solve / the next marginalize() (AOptimizer.h:88-90, …Analytic.cpp:627-660). Device
+// resident; the variables its columns refer to are named by the caller per window (it owns the id bookkeeping).
+struct PriorState {
+    bool valid = false;
+    int n_full = 0, n = 0, form = 0;
+    DevBuf<double> J, r0;        // n_full x n row-major packed, n_full
+    DevBuf<double> Z;            // n_full x n with Z^T Z = Sigma_k (built by the first sparsify of this prior)
+    bool z_valid = false;
+    DevBuf<int> step_of;         // Cholesky form: pivot step of every column
+    unsigned long long serial = 0;   // bumped whenever the prior changes: a window that attached it checks it is still the same one
+};
+
+// Work buffers of marginalize / sparsify, kept in the handle: both run once per key-frame, and ~20 hipMalloc / hipFree pairs
+// per call cost more than the kernels between them.
+struct TriLevel { int first, count, max_m, max_n; };
+struct MargScratch {
+    DevBuf<double> A, b, G, V, ev, Vs, Ainv, T, Ak, bk, newJ, newr, lastJ, lastr, L, Tb, Zt, S, mi, jsel;
+    DevBuf<int> ditems, flag, sel, lastcol, piv_of, lc;
+    DevBuf<MargSmall> small;
+    DevBuf<TriNode> nodes;
+    DevBuf<NfrSpecC> spec;
+    std::vector<int> lcol, items, items_l, col;
+    std::vector<double> hev, hS;
+    std::vector<TriLevel> tri_levels;
+    int tri_npad = 0, tri_leaves = 0;
 };
 
 struct LineSetHost {   // deep copy of a sadvio_line_set
@@ -226,6 +257,8 @@ struct sadvio_ba_handle {
     DevBuf<double> d_rank_b, d_rank_s;
     // dense marginalisation priors (host copies, one per window) and the layout they induce
     std::vector<DensePriorHost> dprior_per_win;
+    PriorState prior;   // the handle's own prior (sadvio_ba_marginalize leaves it here)
+    MargScratch mg;
     std::vector<SrcWin> src;                       // caller windows (deep copies)
     std::vector<std::vector<char>> sp_elim;        // per window, per sparse factor: handled as pseudo-observations
     std::vector<int> n_obs_user;                   // caller's observation count per window
@@ -411,9 +444,9 @@ int layout_reduced(sadvio_ba_handle* h) {
     std::vector<int> sp_list;
     std::vector<LineDev> lines;
     std::vector<LineObsDev> lobs;
-    std::vector<double> dp_data;
+    long long dp_total = 0;   // doubles of d_dp_data: per window [J | J^T | J^T J | r0 | dx | r | cost slot]
     bool any_red = false;
-    struct Prep { long long off; int nf, n; };
+    struct Prep { long long off; int nf, n, w; };
     std::vector<Prep> preps;
     for (int w = 0; w < n_windows; w++) {
         WinDev& d = h->wins[w].d;
@@ -452,13 +485,10 @@ int layout_reduced(sadvio_ba_handle* h) {
             dp_ints.insert(dp_ints.end(), kind.begin(), kind.end());
             dp_ints.insert(dp_ints.end(), index.begin(), index.end());
             dp_ints.insert(dp_ints.end(), col.begin(), col.end());
-            d.dp_off = (long long)dp_data.size();
-            preps.push_back({d.dp_off, nf, n});
-            dp_data.insert(dp_data.end(), D.J.begin(), D.J.end());
-            dp_data.resize(dp_data.size() + (size_t)n * nf + (size_t)n * n, 0.0);  // Jt, H: filled on the device
-            dp_data.insert(dp_data.end(), D.r0.begin(), D.r0.end());
-            dp_data.resize(dp_data.size() + (size_t)n + nf + 1, 0.0);             // dx, r scratch, cost slot
-            if (dp_data.size() & 1) dp_data.push_back(0.0);
+            d.dp_off = dp_total;
+            preps.push_back({d.dp_off, nf, n, w});
+            dp_total += (long long)nf * n + (long long)n * nf + (long long)n * n + nf + n + nf + 1;   // J, Jt, H (device-filled), r0, dx, r scratch, cost slot
+            dp_total += dp_total & 1;
         }
         // landmarks touched by sparse prior factors stay in the reduced system as well
         d.sp_begin = (int)sparse.size();
@@ -556,13 +586,30 @@ int layout_reduced(sadvio_ba_handle* h) {
     h->up.add(h->d_lobs.p, lobs.data(), lobs.size() * sizeof(LineObsDev));
     if (kept.empty()) kept.assign(3, 0);
     if (dp_ints.empty()) dp_ints.push_back(0);
-    if (dp_data.empty()) dp_data.push_back(0.0);
     HIP_TRY(h->d_tiles.alloc(h->tiles.size())); HIP_TRY(h->d_lmk_red.alloc(lmk_red.size())); HIP_TRY(h->d_lmk_const.alloc(lmk_const.size()));
-    HIP_TRY(h->d_kept_obs.alloc(kept.size())); HIP_TRY(h->d_dp_ints.alloc(dp_ints.size())); HIP_TRY(h->d_dp_data.alloc(dp_data.size()));
+    HIP_TRY(h->d_kept_obs.alloc(kept.size())); HIP_TRY(h->d_dp_ints.alloc(dp_ints.size())); HIP_TRY(h->d_dp_data.alloc((size_t)std::max<long long>(dp_total, 1)));
 #define UP(dst, src) h->up.add((dst).p, (src).data(), (src).size() * sizeof((src)[0]))
     UP(h->d_tiles, h->tiles); UP(h->d_lmk_red, lmk_red); UP(h->d_lmk_const, lmk_const); UP(h->d_kept_obs, kept);
-    UP(h->d_dp_ints, dp_ints); UP(h->d_dp_data, dp_data);
+    UP(h->d_dp_ints, dp_ints);
 #undef UP
+    // the dense priors' data never exists as one host array: scratch parts are zeroed on the device, J and r0 come from the
+    // caller's copy (staged upload) or from the handle's prior (device to device, no PCIe traffic)
+    if (!preps.empty()) HIP_TRY(hipMemsetAsync(h->d_dp_data.p, 0, sizeof(double) * (size_t)dp_total, h->stream));
+    for (const Prep& pr : preps) {
+        const DensePriorHost& D = h->dprior_per_win[pr.w];
+        double* J = h->d_dp_data.p + pr.off;
+        double* r0 = J + 2 * (size_t)pr.nf * pr.n + (size_t)pr.n * pr.n;
+        if (D.resident) {
+            if (!h->prior.valid || h->prior.serial != D.serial || h->prior.n_full != pr.nf || h->prior.n != pr.n) {
+                h->err = "the handle's prior changed after set_dense_prior(SADVIO_PRIOR_RESIDENT) attached it to a window: attach it again"; return SADVIO_E_STATE;
+            }
+            HIP_TRY(hipMemcpyAsync(J, h->prior.J.p, sizeof(double) * (size_t)pr.nf * pr.n, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(r0, h->prior.r0.p, sizeof(double) * (size_t)pr.nf, hipMemcpyDeviceToDevice, h->stream));
+        } else {
+            h->up.add(J, D.J.data(), sizeof(double) * (size_t)pr.nf * pr.n);
+            h->up.add(r0, D.r0.data(), sizeof(double) * (size_t)pr.nf);
+        }
+    }
     if (!preps.empty()) HIP_TRY(h->up.flush(h->stream));  // the prepare kernels read J on the device
     for (const Prep& pr : preps) {
         double* J = h->d_dp_data.p + pr.off;
@@ -1357,13 +1404,20 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t w, int32_t n_full, in
                               int32_t kf_keep, int32_t kf_col, int32_t n_keep, const int32_t* lmk_index, const int32_t* lmk_col) {
     if (!h) return SADVIO_E_INVALID_ARG;
     if (!h->uploaded) { h->err = "set_dense_prior before set_windows"; return SADVIO_E_STATE; }
-    if (w < 0 || w >= (int)h->wins.size() || n_full < 0 || n < 0 || n_keep < 0) { h->err = "set_dense_prior: bad argument"; return SADVIO_E_INVALID_ARG; }
+    if (w < 0 || w >= (int)h->wins.size() || (n_full < 0 && n_full != SADVIO_PRIOR_RESIDENT) || (n < 0 && n_full != SADVIO_PRIOR_RESIDENT) || n_keep < 0) { h->err = "set_dense_prior: bad argument"; return SADVIO_E_INVALID_ARG; }
     HIP_TRY(hipSetDevice(h->device));
     if (h->world > 1 && n_full > 0) { h->err = "set_dense_prior: not supported on a window sharded over several GPUs"; return SADVIO_E_INVALID_ARG; }
     const WinDev& d = h->wins[w].d;
     DensePriorHost D;
+    const bool resident = n_full == SADVIO_PRIOR_RESIDENT;
+    if (resident) {
+        if (J || r0) { h->err = "set_dense_prior: SADVIO_PRIOR_RESIDENT takes J = r0 = NULL"; return SADVIO_E_INVALID_ARG; }
+        if (!h->prior.valid) { h->err = "set_dense_prior: SADVIO_PRIOR_RESIDENT but the handle holds no prior"; return SADVIO_E_STATE; }
+        if (h->world > 1) { h->err = "set_dense_prior: not supported on a window sharded over several GPUs"; return SADVIO_E_INVALID_ARG; }
+        n_full = h->prior.n_full; n = h->prior.n;
+    }
     if (n_full > 0) {
-        if (!J || !r0 || n <= 0 || (n_keep > 0 && (!lmk_index || !lmk_col))) { h->err = "set_dense_prior: missing array"; return SADVIO_E_INVALID_ARG; }
+        if ((!resident && (!J || !r0)) || n <= 0 || (n_keep > 0 && (!lmk_index || !lmk_col))) { h->err = "set_dense_prior: missing array"; return SADVIO_E_INVALID_ARG; }
         if (kf_keep >= d.n_kf || (kf_keep >= 0 && (kf_col < 0 || kf_col + 15 > n))) { h->err = "set_dense_prior: kept key-frame block out of range"; return SADVIO_E_INVALID_ARG; }
         std::vector<char> used(n, 0);
         if (kf_keep >= 0) for (int q = 0; q < 15; q++) used[kf_col + q] = 1;
@@ -1376,7 +1430,8 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t w, int32_t n_full, in
             }
         }
         D.n_full = n_full; D.n = n; D.kf_keep = kf_keep; D.kf_col = kf_col;
-        D.J.assign(J, J + (size_t)n_full * n); D.r0.assign(r0, r0 + n_full);
+        D.resident = resident; D.serial = h->prior.serial;
+        if (!resident) { D.J.assign(J, J + (size_t)n_full * n); D.r0.assign(r0, r0 + n_full); }
         D.lmk_index.assign(lmk_index, lmk_index + n_keep); D.lmk_col.assign(lmk_col, lmk_col + n_keep);
     }
     h->dprior_per_win[w] = std::move(D);
@@ -1421,78 +1476,102 @@ int sadvio_ba_set_sparse_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const
 }
 
 namespace {
+// Diagonally pivoted Cholesky S = G^T G without data movement (marg_kernels.h: k_pchol_panel_np / k_pchol_syrk_full), in place on
+// the n x n scratch S (destroyed); G (n x n) receives the factor's rows by ORIGINAL column index, h->d_jac_ints[0..n) the pivot
+// step of every index (-1 = never chosen). tau >= 0: stop at pivots <= tau * max diagonal; tau < 0: at pivots <= -tau
+// (absolute). Returns the rank (number of pivots taken), negative on a HIP error. One host synchronisation (the rank).
+int run_pchol(sadvio_ba_handle* h, double* S, int n, double* G, double tau) {
+    if (h->d_jac_ints.alloc((size_t)n + 8) != hipSuccess) return -1;
+    int* piv = h->d_jac_ints.p; int* rank_d = piv + n;
+    if (h->d_jac_dbl.alloc((size_t)n + 8) != hipSuccess) return -1;
+    double* dg = h->d_jac_dbl.p; double* dctl = dg + n;
+    if (hipMemsetAsync(rank_d, 0xff, sizeof(int), h->stream) != hipSuccess) return -1;   // -1: still factorising
+    const bool swap_pchol = getenv("SADVIO_PCHOL_SWAP") != nullptr;   // the data-moving version (kept for comparison)
+    if (swap_pchol) {
+        for (int k0 = 0; k0 < n; k0 += PCH_NB) {
+            hipLaunchKernelGGL(k_pchol_panel, dim3(1), dim3(PCH_THREADS), 0, h->stream, S, n, G, piv, dg, rank_d, dctl, k0, tau);
+            const int m = n - (k0 + PCH_NB);
+            if (m > 0) hipLaunchKernelGGL(k_pchol_syrk, dim3((m + 63) / 64, (m + 63) / 64), dim3(256), 0, h->stream, S, n, G, rank_d, k0);
+        }
+    } else {
+        if (hipMemsetAsync(piv, 0xff, sizeof(int) * (size_t)n, h->stream) != hipSuccess) return -1;   // done[i] = -1
+        const unsigned gt = (unsigned)((n + 63) / 64);
+        if (n <= PCH_THREADS) {
+            for (int k0 = 0; k0 < n; k0 += 32) {
+                hipLaunchKernelGGL((k_pchol_panel_np<1, 32>), dim3(1), dim3(PCH_THREADS), 0, h->stream, S, n, G, piv, dg, rank_d, dctl, k0, tau);
+                if (k0 + 32 < n) hipLaunchKernelGGL(k_pchol_syrk_full<32>, dim3(gt, gt), dim3(256), 0, h->stream, S, n, G, rank_d, k0);
+            }
+        } else {
+            for (int k0 = 0; k0 < n; k0 += 16) {
+                hipLaunchKernelGGL((k_pchol_panel_np<2, 16>), dim3(1), dim3(PCH_THREADS), 0, h->stream, S, n, G, piv, dg, rank_d, dctl, k0, tau);
+                if (k0 + 16 < n) hipLaunchKernelGGL(k_pchol_syrk_full<16>, dim3(gt, gt), dim3(256), 0, h->stream, S, n, G, rank_d, k0);
+            }
+        }
+    }
+    int r = 0;
+    if (hipMemcpyAsync(&r, rank_d, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    if (r < 0) r = n;
+    return r;
+}
+
+// Block one-sided Jacobi on the r rows (length n, packed) of G until they are mutually orthogonal: the rows converge to
+// sqrt(lambda_i) u_i^T of G^T G. Returns the number of sweeps (negative = HIP error). One host synchronisation per sweep.
+int run_jacobi_rows(sadvio_ba_handle* h, double* G, int r, int n, int* flag) {
+    const bool b4 = getenv("SADVIO_JACOBI_B4") != nullptr || n > JM_MAXN;   // the 4-row VALU version (large n; kept for comparison)
+    const int ldx = jm_ldx(n);
+    const size_t jm_lds = (size_t)JM2 * ldx * sizeof(double);
+    if (!b4 && hipFuncSetAttribute((const void*)k_jacobi_mma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jm_lds) != hipSuccess) return -1;
+    const int jb = b4 ? JB : JM;
+    const int nb = (r + jb - 1) / jb, nbpad = nb + (nb & 1);
+    int sweeps = 0;
+    long long* jts = nullptr;   // phase timestamps of one launch (SADVIO_KERNEL_TS builds, SADVIO_DEBUG & 4096)
+    if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 4096) && n > 500 && h->d_dbg.alloc(128) == hipSuccess) jts = h->d_dbg.p + 44;
+    for (; sweeps < 40 && nbpad >= 2; sweeps++) {
+        if (hipMemsetAsync(flag, 0, sizeof(int), h->stream) != hipSuccess) return -1;
+        for (int st = 0; st < nbpad - 1; st++) {
+            long long* ts = sweeps == 0 && st == 3 ? jts : nullptr;
+            if (!b4) hipLaunchKernelGGL(k_jacobi_mma, dim3(nbpad / 2), dim3(JAC_THREADS), jm_lds, h->stream, G, r, n, ldx, nbpad, st, 1e-14, flag, ts);
+            else if (n <= 4 * JAC_THREADS) hipLaunchKernelGGL(k_jacobi_block<4>, dim3(nbpad / 2), dim3(JAC_THREADS), 0, h->stream, G, r, n, nbpad, st, 1e-14, flag);
+            else hipLaunchKernelGGL(k_jacobi_block<8>, dim3(nbpad / 2), dim3(JAC_THREADS), 0, h->stream, G, r, n, nbpad, st, 1e-14, flag);
+        }
+        int f = 0;
+        if (hipMemcpyAsync(&f, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+        if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 16384)) fprintf(stderr, "[sadvio dbg] block jacobi n %d rank %d sweep %d block pairs rotated %d\n", n, r, sweeps, f);
+        if (!f) { sweeps++; break; }
+    }
+    if (jts) {
+        long long t8[8];
+        if (hipMemcpy(t8, jts, sizeof(t8), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[sadvio dbg] k_jacobi_mma phases (us, cumulative): gram | update loads issued | barrier | M | check | inner sweep | end:");
+            for (int i = 1; i < 8; i++) fprintf(stderr, " %.2f", (t8[i] - t8[0]) * 0.01);
+            fprintf(stderr, "\n");
+        }
+    }
+    return sweeps;
+}
+
+// pivot tolerance of the rank-revealing Cholesky for an eigenvalue-cut mode: the noise floor's pivots end at 4 n eps of the
+// largest one (the null space of a marginalisation prior sits exactly there); the reference's absolute 1e-12 (Marginalization::
+// _eps) becomes a pivot floor of 1e-12 / n — a remaining eigenvalue above 1e-12 keeps the remaining trace, hence the largest
+// remaining diagonal entry, above it.
+double pchol_tau(int n, int eig_cut_mode) {
+    return eig_cut_mode == SADVIO_EIG_CUT_NOISE_FLOOR ? 4.0 * n * 2.220446049250313e-16 : -1e-12 / std::max(n, 1);
+}
+
 // one-sided Jacobi eigen-decomposition of the symmetric n x n block at A (leading dimension lda): G, V (n x n each)
 // and ev (n) are device buffers; returns the number of sweeps (negative = HIP error)
-int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int lower_only, double* G, double* V, double* ev, int* flag) {
+int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int lower_only, double* G, double* V, double* ev, int* flag, int eig_cut_mode) {
     const long long nn = (long long)n * n;
     // Cholesky-preconditioned block Jacobi (marg_kernels.h): sym(A) -> V (scratch), pivoted Cholesky V -> G = L^T, block
     // one-sided Jacobi sweeps on the rows of G, then eigen-pairs from the rows -> V, ev
     if (n >= 32 && n <= PCH_MAXN && !getenv("SADVIO_JACOBI_PLAIN")) {
-        if (h->d_jac_ints.alloc((size_t)n + 8) != hipSuccess) return -1;
-        int* piv = h->d_jac_ints.p; int* rank_d = piv + n;
-        if (h->d_jac_dbl.alloc((size_t)n + 8) != hipSuccess) return -1;
-        double* dg = h->d_jac_dbl.p; double* dctl = dg + n;
         hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, A, lda, n, V, G, lower_only);
-        if (hipMemsetAsync(rank_d, 0xff, sizeof(int), h->stream) != hipSuccess) return -1;   // -1: still factorising
-        // pivots at the rounding-noise level of the largest one end the factorisation: the floor of marg_cut (n eps lambda_max)
-        // with a margin - the null space of a marginalisation prior sits exactly there
-        const double tau_rel = 4.0 * n * 2.220446049250313e-16;
-        const bool swap_pchol = getenv("SADVIO_PCHOL_SWAP") != nullptr;   // the data-moving version (kept for comparison)
-        if (swap_pchol) {
-            for (int k0 = 0; k0 < n; k0 += PCH_NB) {
-                hipLaunchKernelGGL(k_pchol_panel, dim3(1), dim3(PCH_THREADS), 0, h->stream, V, n, G, piv, dg, rank_d, dctl, k0, tau_rel);
-                const int m = n - (k0 + PCH_NB);
-                if (m > 0) hipLaunchKernelGGL(k_pchol_syrk, dim3((m + 63) / 64, (m + 63) / 64), dim3(256), 0, h->stream, V, n, G, rank_d, k0);
-            }
-        } else {
-            if (hipMemsetAsync(piv, 0xff, sizeof(int) * (size_t)n, h->stream) != hipSuccess) return -1;   // done[i] = -1
-            const unsigned gt = (unsigned)((n + 63) / 64);
-            if (n <= PCH_THREADS) {
-                for (int k0 = 0; k0 < n; k0 += 32) {
-                    hipLaunchKernelGGL((k_pchol_panel_np<1, 32>), dim3(1), dim3(PCH_THREADS), 0, h->stream, V, n, G, piv, dg, rank_d, dctl, k0, tau_rel);
-                    if (k0 + 32 < n) hipLaunchKernelGGL(k_pchol_syrk_full<32>, dim3(gt, gt), dim3(256), 0, h->stream, V, n, G, rank_d, k0);
-                }
-            } else {
-                for (int k0 = 0; k0 < n; k0 += 16) {
-                    hipLaunchKernelGGL((k_pchol_panel_np<2, 16>), dim3(1), dim3(PCH_THREADS), 0, h->stream, V, n, G, piv, dg, rank_d, dctl, k0, tau_rel);
-                    if (k0 + 16 < n) hipLaunchKernelGGL(k_pchol_syrk_full<16>, dim3(gt, gt), dim3(256), 0, h->stream, V, n, G, rank_d, k0);
-                }
-            }
-        }
-        int r = 0;
-        if (hipMemcpyAsync(&r, rank_d, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
-        if (r < 0) r = n;
-        const bool b4 = getenv("SADVIO_JACOBI_B4") != nullptr || n > JM_MAXN;   // the 4-row VALU version (large n; kept for comparison)
-        const int ldx = jm_ldx(n);
-        const size_t jm_lds = (size_t)JM2 * ldx * sizeof(double);
-        if (!b4 && hipFuncSetAttribute((const void*)k_jacobi_mma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jm_lds) != hipSuccess) return -1;
-        const int jb = b4 ? JB : JM;
-        const int nb = (r + jb - 1) / jb, nbpad = nb + (nb & 1);
-        int sweeps = 0;
-        long long* jts = nullptr;   // phase timestamps of one launch (SADVIO_KERNEL_TS builds, SADVIO_DEBUG & 4096)
-        if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 4096) && n > 500 && h->d_dbg.alloc(128) == hipSuccess) jts = h->d_dbg.p + 44;
-        for (; sweeps < 40 && nbpad >= 2; sweeps++) {
-            if (hipMemsetAsync(flag, 0, sizeof(int), h->stream) != hipSuccess) return -1;
-            for (int st = 0; st < nbpad - 1; st++) {
-                long long* ts = sweeps == 0 && st == 3 ? jts : nullptr;
-                if (!b4) hipLaunchKernelGGL(k_jacobi_mma, dim3(nbpad / 2), dim3(JAC_THREADS), jm_lds, h->stream, G, r, n, ldx, nbpad, st, 1e-14, flag, ts);
-                else if (n <= 4 * JAC_THREADS) hipLaunchKernelGGL(k_jacobi_block<4>, dim3(nbpad / 2), dim3(JAC_THREADS), 0, h->stream, G, r, n, nbpad, st, 1e-14, flag);
-                else hipLaunchKernelGGL(k_jacobi_block<8>, dim3(nbpad / 2), dim3(JAC_THREADS), 0, h->stream, G, r, n, nbpad, st, 1e-14, flag);
-            }
-            int f = 0;
-            if (hipMemcpyAsync(&f, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
-            if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 16384)) fprintf(stderr, "[sadvio dbg] block jacobi n %d rank %d sweep %d block pairs rotated %d\n", n, r, sweeps, f);
-            if (!f) { sweeps++; break; }
-        }
-        hipLaunchKernelGGL(k_eig_from_rows, dim3(n), dim3(JAC_THREADS), 0, h->stream, G, swap_pchol ? piv : (const int*)nullptr, rank_d, n, V, ev);
-        if (jts) {
-            long long t8[8];
-            if (hipMemcpy(t8, jts, sizeof(t8), hipMemcpyDeviceToHost) == hipSuccess) {
-                fprintf(stderr, "[sadvio dbg] k_jacobi_mma phases (us, cumulative): gram | update loads issued | barrier | M | check | inner sweep | end:");
-                for (int i = 1; i < 8; i++) fprintf(stderr, " %.2f", (t8[i] - t8[0]) * 0.01);
-                fprintf(stderr, "\n");
-            }
-        }
+        const int r = run_pchol(h, V, n, G, pchol_tau(n, eig_cut_mode));
+        if (r < 0) return -1;
+        const int sweeps = run_jacobi_rows(h, G, r, n, flag);
+        if (sweeps < 0) return -1;
+        const bool swap_pchol = getenv("SADVIO_PCHOL_SWAP") != nullptr;
+        hipLaunchKernelGGL(k_eig_from_rows, dim3(n), dim3(JAC_THREADS), 0, h->stream, G, swap_pchol ? h->d_jac_ints.p : (const int*)nullptr, h->d_jac_ints.p + n, n, V, ev);
         return sweeps;
     }
     hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, A, lda, n, G, V, lower_only);
@@ -1501,7 +1580,7 @@ int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int l
     unsigned long long* amax = (unsigned long long*)(flag + 2);
     double* floor2 = (double*)(flag + 4);
     if (hipMemsetAsync(flag, 0, 8 * sizeof(int), h->stream) != hipSuccess) return -1;
-    if (n > 0) {
+    if (n > 0 && eig_cut_mode == SADVIO_EIG_CUT_NOISE_FLOOR) {   // the reference's cut sits below that floor: every pair keeps rotating
         hipLaunchKernelGGL(k_jacobi_floor, dim3(n), dim3(JAC_THREADS), 0, h->stream, G, n, amax, floor2, 0);
         hipLaunchKernelGGL(k_jacobi_floor, dim3(1), dim3(JAC_THREADS), 0, h->stream, G, n, amax, floor2, 1);
     }
@@ -1520,9 +1599,11 @@ int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int l
     return sweeps;
 }
 
-// eigenvalue cut of the pseudo-inverse / rank-revealing decomposition: the reference's absolute 1e-12
-// (marginalization.hpp:56) with the rounding-noise floor n eps lambda_max (see oracle/marg.c)
-double marg_cut(const std::vector<double>& ev) {
+// eigenvalue cut of the pseudo-inverse / rank-revealing decomposition (sadvio_ba.h: SADVIO_EIG_CUT_*): the reference's absolute
+// 1e-12 (marginalization.hpp:58, applied at marginalization.cpp:237,322), or that constant with the rounding-noise floor
+// n eps lambda_max (see oracle/marg.c)
+double marg_cut(const std::vector<double>& ev, int eig_cut_mode) {
+    if (eig_cut_mode != SADVIO_EIG_CUT_NOISE_FLOOR) return 1e-12;
     double mx = 0.0;
     for (double v : ev) mx = std::max(mx, std::fabs(v));
     return std::max(1e-12, (double)ev.size() * 2.220446049250313e-16 * mx);
@@ -1550,6 +1631,11 @@ bool make_imu_dev(const sadvio_imu_factor& f, int kf_base, ImuDev& o) {
     o.win = 0; o.pad = 0;
     return true;
 }
+
+inline void launch_mgemm(sadvio_ba_handle* h, double* C, long long ldc, const double* A, long long sai, long long sak, const double* B, long long sbk,
+                         long long sbj, int M, int N, int K, double alpha, double beta) {
+    hipLaunchKernelGGL(k_mgemm, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, h->stream, C, ldc, A, sai, sak, B, sbk, sbj, M, N, K, alpha, beta);
+}
 }  // namespace
 
 int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_request* rq, sadvio_marg_result* res, int32_t* lmk_col_out,
@@ -1557,17 +1643,23 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     if (!h) return SADVIO_E_INVALID_ARG;
     if (!h->uploaded) { h->err = "marginalize before set_windows"; return SADVIO_E_STATE; }
     if (!rq || w < 0 || w >= (int)h->wins.size()) { h->err = "marginalize: bad argument"; return SADVIO_E_INVALID_ARG; }
+    if (h->world > 1) { h->err = "marginalize: the window is sharded over several GPUs (each rank holds a landmark partition only)"; return SADVIO_E_INVALID_ARG; }
     const WinDev& d = h->wins[w].d;
     if (rq->kf_marg < 0 || rq->kf_marg >= d.n_kf || rq->kf_keep >= d.n_kf || rq->n_marg < 0 || rq->n_keep < 0 || rq->n_prior < 0 ||
-        rq->n_prior > 4 || (rq->n_marg > 0 && !rq->lmk_marg) || (rq->n_keep > 0 && !rq->lmk_keep) || (rq->n_prior > 0 && !rq->priors)) {
+        rq->n_prior > 4 || (rq->n_marg > 0 && !rq->lmk_marg) || (rq->n_keep > 0 && !rq->lmk_keep) || (rq->n_prior > 0 && !rq->priors) ||
+        (rq->eig_cut_mode != SADVIO_EIG_CUT_REFERENCE && rq->eig_cut_mode != SADVIO_EIG_CUT_NOISE_FLOOR) ||
+        (rq->prior_form != SADVIO_PRIOR_FORM_EIGEN && rq->prior_form != SADVIO_PRIOR_FORM_CHOLESKY)) {
         h->err = "marginalize: request out of range"; return SADVIO_E_INVALID_ARG;
     }
     HIP_TRY(hipSetDevice(h->device));
+    MargScratch& M = h->mg;
+    PriorState& PR = h->prior;
     // index layout, marginalization.cpp:38-113
     const int m = 6 + (rq->marg_has_imu ? 9 : 0) + 3 * rq->n_marg;
     const int n = (rq->kf_keep >= 0 ? 15 : 0) + 3 * rq->n_keep;
     const int N = m + n;
-    std::vector<int> lcol(std::max(d.n_lmk, 1), -1);
+    std::vector<int>& lcol = M.lcol;
+    lcol.assign(std::max(d.n_lmk, 1), -1);
     int idx = 6 + (rq->marg_has_imu ? 9 : 0);
     for (int k = 0; k < rq->n_marg; k++) {
         if (rq->lmk_marg[k] < 0 || rq->lmk_marg[k] >= d.n_lmk) { h->err = "marginalize: landmark index out of range"; return SADVIO_E_INVALID_ARG; }
@@ -1581,69 +1673,68 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     }
     if (res) { res->m = m; res->n = n; res->n_full = 0; res->kf_col = kf_keep_col >= 0 ? kf_keep_col - m : -1; res->sweeps_mm = res->sweeps_k = 0; }
     if (lmk_col_out) for (int k = 0; k < rq->n_keep; k++) lmk_col_out[k] = lcol[rq->lmk_keep[k]] - m;
-    if (n < 4) { h->err = "marginalize: fewer than 4 kept columns, refused (marginalization.cpp:215-216)"; return SADVIO_E_REFUSED; }
+    if (n < 4) {   // the reference clears its prior state too (…Analytic.cpp:620-625)
+        PR.valid = false; PR.z_valid = false; PR.serial++;
+        h->err = "marginalize: fewer than 4 kept columns, refused (marginalization.cpp:215-216)"; return SADVIO_E_REFUSED;
+    }
+    const bool chol_form = rq->prior_form == SADVIO_PRIOR_FORM_CHOLESKY && n + 1 <= PCH_MAXN;
+    if (rq->prior_form == SADVIO_PRIOR_FORM_CHOLESKY && !chol_form) { h->err = "marginalize: the Cholesky form handles n < 2048"; return SADVIO_E_INVALID_ARG; }
 
     SolveOpts so{};
     DevPtrs P = make_ptrs(h, so, 2);
-    DevBuf<double> dA, db, G, V, ev, Vs, Ainv, T, Ak, bk, dJ, dr0, dlastJ, dlastr;
-    DevBuf<int> ditems, dflag, dsel, dlastcol;
-    DevBuf<MargSmall> dsmall;
-    HIP_TRY(dA.alloc((size_t)N * N)); HIP_TRY(db.alloc(N)); HIP_TRY(dflag.alloc(8));
-    HIP_TRY(hipMemsetAsync(dA.p, 0, sizeof(double) * (size_t)N * N, h->stream));
-    HIP_TRY(hipMemsetAsync(db.p, 0, sizeof(double) * N, h->stream));
+    const int big = std::max(m, n + 1);
+    HIP_TRY(M.A.alloc((size_t)N * N)); HIP_TRY(M.b.alloc(N)); HIP_TRY(M.flag.alloc(8));
+    HIP_TRY(M.G.alloc((size_t)big * big)); HIP_TRY(M.V.alloc((size_t)big * big)); HIP_TRY(M.ev.alloc(big)); HIP_TRY(M.Vs.alloc((size_t)big * big));
+    HIP_TRY(M.Ainv.alloc((size_t)m * m)); HIP_TRY(M.T.alloc((size_t)n * m)); HIP_TRY(M.Ak.alloc((size_t)n * n)); HIP_TRY(M.bk.alloc(n));
+    HIP_TRY(M.newJ.alloc((size_t)n * n)); HIP_TRY(M.newr.alloc(n));
+    HIP_TRY(hipMemsetAsync(M.A.p, 0, sizeof(double) * (size_t)N * N, h->stream));
+    HIP_TRY(hipMemsetAsync(M.b.p, 0, sizeof(double) * N, h->stream));
+    // ---- host-side lists of the blocks, ONE staged upload -----------------------------------------------------------
     // reprojection factors of kept then marginalised landmarks seen from frame0
-    {
-        std::vector<int> it2, itl;
-        for (int pass = 0; pass < 2; pass++) {
-            const int cnt = pass == 0 ? rq->n_keep : rq->n_marg;
-            const int32_t* list = pass == 0 ? rq->lmk_keep : rq->lmk_marg;
-            for (int k = 0; k < cnt; k++) {
-                const int gl = d.lmk_base + list[k];
-                for (int o = h->h_lmk_ob[gl]; o < h->h_lmk_oe[gl]; o++)
-                    if (h->h_obs_kf[o] == d.kf_base + rq->kf_marg && h->obs_perm[o] >= 0) { it2.push_back(o); it2.push_back(lcol[list[k]]); itl.push_back(gl); }  // pseudo-observations excluded
-            }
-        }
-        const int n_items = (int)itl.size();
-        if (n_items > 0) {
-            it2.insert(it2.end(), itl.begin(), itl.end());
-            HIP_TRY(ditems.alloc(it2.size()));
-            HIP_TRY(hipMemcpyAsync(ditems.p, it2.data(), it2.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-            auto ko = h->factor_type == SADVIO_FACTOR_PIXEL ? k_marg_obs<0> : k_marg_obs<1>;
-            hipLaunchKernelGGL(ko, dim3((n_items + 127) / 128), dim3(128), 0, h->stream, P, ditems.p, n_items, dA.p, db.p, N);
-            HIP_TRY(hipStreamSynchronize(h->stream));  // it2 goes out of scope
+    std::vector<int>& it2 = M.items; std::vector<int>& itl = M.items_l;
+    it2.clear(); itl.clear();
+    for (int pass = 0; pass < 2; pass++) {
+        const int cnt = pass == 0 ? rq->n_keep : rq->n_marg;
+        const int32_t* list = pass == 0 ? rq->lmk_keep : rq->lmk_marg;
+        for (int k = 0; k < cnt; k++) {
+            const int gl = d.lmk_base + list[k];
+            for (int o = h->h_lmk_ob[gl]; o < h->h_lmk_oe[gl]; o++)
+                if (h->h_obs_kf[o] == d.kf_base + rq->kf_marg && h->obs_perm[o] >= 0) { it2.push_back(o); it2.push_back(lcol[list[k]]); itl.push_back(gl); }  // pseudo-observations excluded
         }
     }
+    const int n_items = (int)itl.size();
+    it2.insert(it2.end(), itl.begin(), itl.end());
     // IMU factor + bias factor, pose priors
-    {
-        MargSmall S{};
-        if (rq->imu && rq->kf_keep >= 0 && rq->marg_has_imu) {
-            sadvio_imu_factor f = *rq->imu;
-            f.kf_i = rq->kf_marg; f.kf_j = rq->kf_keep;
-            if (!make_imu_dev(f, d.kf_base, S.imu)) { h->err = "marginalize: IMU covariance is not positive definite"; return SADVIO_E_INVALID_ARG; }
-            S.has_imu = 1; S.kf_i = d.kf_base + rq->kf_marg; S.kf_j = d.kf_base + rq->kf_keep; S.kf_keep_col = kf_keep_col;
-        }
-        for (int k = 0; k < rq->n_prior; k++) {
-            const sadvio_pose_prior& pr = rq->priors[k];
-            const int base = pr.kf == rq->kf_marg ? 0 : (pr.kf == rq->kf_keep ? kf_keep_col : -1);
-            if (base < 0) continue;
-            const int q = S.n_prior++;
-            S.prior_kf[q] = d.kf_base + pr.kf; S.prior_base[q] = base;
-            memcpy(S.prior_T[q], pr.T_prior, sizeof(S.prior_T[q])); memcpy(S.prior_inf[q], pr.inf_diag, sizeof(S.prior_inf[q]));
-        }
-        if (S.has_imu || S.n_prior) {
-            HIP_TRY(dsmall.alloc(1));
-            HIP_TRY(hipMemcpyAsync(dsmall.p, &S, sizeof(S), hipMemcpyHostToDevice, h->stream));
-            hipLaunchKernelGGL(k_marg_small, dim3(1), dim3(64), 0, h->stream, P, dsmall.p, dA.p, db.p, N);
-            HIP_TRY(hipStreamSynchronize(h->stream));
-        }
+    MargSmall S{};
+    if (rq->imu && rq->kf_keep >= 0 && rq->marg_has_imu) {
+        sadvio_imu_factor f = *rq->imu;
+        f.kf_i = rq->kf_marg; f.kf_j = rq->kf_keep;
+        if (!make_imu_dev(f, d.kf_base, S.imu)) { h->err = "marginalize: IMU covariance is not positive definite"; return SADVIO_E_INVALID_ARG; }
+        S.has_imu = 1; S.kf_i = d.kf_base + rq->kf_marg; S.kf_j = d.kf_base + rq->kf_keep; S.kf_keep_col = kf_keep_col;
     }
-    // previous prior at zero deltas
-    if (rq->last_n_full > 0) {
-        const int nl = rq->last_n, nf = rq->last_n_full;
+    for (int k = 0; k < rq->n_prior; k++) {
+        const sadvio_pose_prior& pr = rq->priors[k];
+        const int base = pr.kf == rq->kf_marg ? 0 : (pr.kf == rq->kf_keep ? kf_keep_col : -1);
+        if (base < 0) continue;
+        const int q = S.n_prior++;
+        S.prior_kf[q] = d.kf_base + pr.kf; S.prior_base[q] = base;
+        memcpy(S.prior_T[q], pr.T_prior, sizeof(S.prior_T[q])); memcpy(S.prior_inf[q], pr.inf_diag, sizeof(S.prior_inf[q]));
+    }
+    // previous prior at zero deltas: the handle's (no upload) or the caller's arrays
+    const double* lastJ = nullptr; const double* lastr = nullptr;
+    int nl = 0, nfl = 0;
+    if (rq->last_n_full == SADVIO_PRIOR_RESIDENT) {
+        if (!PR.valid) { h->err = "marginalize: last_n_full = SADVIO_PRIOR_RESIDENT but the handle holds no prior"; return SADVIO_E_STATE; }
+        nl = PR.n; nfl = PR.n_full; lastJ = PR.J.p; lastr = PR.r0.p;
+    } else if (rq->last_n_full > 0) {
+        nl = rq->last_n; nfl = rq->last_n_full;
         if (!rq->last_J || !rq->last_r0 || nl <= 0) { h->err = "marginalize: previous prior arrays missing"; return SADVIO_E_INVALID_ARG; }
+    } else if (rq->last_n_full < 0) { h->err = "marginalize: last_n_full < 0"; return SADVIO_E_INVALID_ARG; }
+    std::vector<int>& col = M.col;
+    if (nfl > 0) {
         if (rq->last_n_keep > 0 && (!rq->last_lmk_index || !rq->last_lmk_col)) { h->err = "marginalize: previous prior landmark lists missing"; return SADVIO_E_INVALID_ARG; }
         if (rq->last_kf >= 0 && rq->last_kf_col < 0) { h->err = "marginalize: last_kf_col < 0"; return SADVIO_E_INVALID_ARG; }
-        std::vector<int> col(nl, -1);
+        col.assign(nl, -1);
         if (rq->last_kf >= 0) {
             const int base = (rq->last_kf == rq->kf_marg) ? 0 : ((rq->last_kf == rq->kf_keep) ? kf_keep_col : -1);
             const int width = (rq->last_kf == rq->kf_marg) ? (rq->marg_has_imu ? 15 : 6) : 15;
@@ -1658,71 +1749,132 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
             if (lc < 0) continue;
             for (int a = 0; a < 3; a++) col[rq->last_lmk_col[k] + a] = lc + a;
         }
-        HIP_TRY(dlastJ.alloc((size_t)nf * nl)); HIP_TRY(dlastr.alloc(nf)); HIP_TRY(dlastcol.alloc(nl));
-        HIP_TRY(hipMemcpyAsync(dlastJ.p, rq->last_J, sizeof(double) * (size_t)nf * nl, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(dlastr.p, rq->last_r0, sizeof(double) * nf, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(dlastcol.p, col.data(), sizeof(int) * nl, hipMemcpyHostToDevice, h->stream));
-        const long long items = (long long)nl * nl;
-        hipLaunchKernelGGL(k_marg_last_prior, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, dlastJ.p, dlastr.p, dlastcol.p, nf, nl, dA.p, db.p, N);
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(M.lastcol.alloc(nl));
+        h->up.add(M.lastcol.p, col.data(), sizeof(int) * (size_t)nl);
+        if (!lastJ) {
+            HIP_TRY(M.lastJ.alloc((size_t)nfl * nl)); HIP_TRY(M.lastr.alloc(nfl));
+            h->up.add(M.lastJ.p, rq->last_J, sizeof(double) * (size_t)nfl * nl);
+            h->up.add(M.lastr.p, rq->last_r0, sizeof(double) * (size_t)nfl);
+            lastJ = M.lastJ.p; lastr = M.lastr.p;
+        }
     }
-    // Schur complement with the eigen pseudo-inverse of Amm (marginalization.cpp:234-248)
-    const int big = std::max(m, n);
-    HIP_TRY(G.alloc((size_t)big * big)); HIP_TRY(V.alloc((size_t)big * big)); HIP_TRY(ev.alloc(big)); HIP_TRY(Vs.alloc((size_t)big * big));
-    HIP_TRY(Ainv.alloc((size_t)m * m)); HIP_TRY(T.alloc((size_t)n * m)); HIP_TRY(Ak.alloc((size_t)n * n)); HIP_TRY(bk.alloc(n));
-    int sw = run_jacobi(h, dA.p, N, m, 0, G.p, V.p, ev.p, dflag.p);
+    if (n_items > 0) { HIP_TRY(M.ditems.alloc(it2.size())); h->up.add(M.ditems.p, it2.data(), it2.size() * sizeof(int)); }
+    if (S.has_imu || S.n_prior) { HIP_TRY(M.small.alloc(1)); h->up.add(M.small.p, &S, sizeof(S)); }
+    HIP_TRY(h->up.flush(h->stream));
+    if (n_items > 0) {
+        auto ko = h->factor_type == SADVIO_FACTOR_PIXEL ? k_marg_obs<0> : k_marg_obs<1>;
+        hipLaunchKernelGGL(ko, dim3((n_items + 127) / 128), dim3(128), 0, h->stream, P, M.ditems.p, n_items, M.A.p, M.b.p, N);
+    }
+    if (S.has_imu || S.n_prior) hipLaunchKernelGGL(k_marg_small, dim3(1), dim3(64), 0, h->stream, P, M.small.p, M.A.p, M.b.p, N);
+    if (nfl > 0) {
+        const long long items = (long long)nl * nl;
+        hipLaunchKernelGGL(k_marg_last_prior, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, lastJ, lastr, M.lastcol.p, nfl, nl, M.A.p, M.b.p, N);
+    }
+    // ---- Schur complement with the eigen pseudo-inverse of Amm (marginalization.cpp:234-248) -----------------------------
+    int sw = run_jacobi(h, M.A.p, N, m, 0, M.G.p, M.V.p, M.ev.p, M.flag.p, rq->eig_cut_mode);
     if (sw < 0) { h->err = "marginalize: HIP error in the eigen-solver"; return SADVIO_E_HIP; }
     if (res) res->sweeps_mm = sw;
-    std::vector<double> hev(m);
-    HIP_TRY(hipMemcpyAsync(hev.data(), ev.p, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
+    std::vector<double>& hev = M.hev;
+    hev.resize(std::max(m, n));
+    HIP_TRY(hipMemcpyAsync(hev.data(), M.ev.p, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     {
-        const double cut = marg_cut(hev);
+        hev.resize(m);
+        const double cut = marg_cut(hev, rq->eig_cut_mode);
         std::vector<double> sel(m);
         for (int i = 0; i < m; i++) sel[i] = hev[i] > cut ? 1.0 / sqrt(hev[i]) : 0.0;
-        HIP_TRY(hipMemcpyAsync(ev.p, sel.data(), sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(M.ev.p, sel.data(), sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
         const long long mm = (long long)m * m;
-        hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, h->stream, V.p, ev.p, m, Vs.p);
-        // Ainv = Vs^T Vs ; T = Arm Ainv ; Ak = Arr - T Arm^T ; bk = brr - T bmm
-        hipLaunchKernelGGL(k_gemm, dim3((m + 15) / 16, (m + 15) / 16), dim3(256), 0, h->stream, Ainv.p, (long long)m, Vs.p, 1LL, (long long)m, Vs.p,
-                           (long long)m, 1LL, m, m, m, 1.0, 0.0);
-        hipLaunchKernelGGL(k_gemm, dim3((m + 15) / 16, (n + 15) / 16), dim3(256), 0, h->stream, T.p, (long long)m, dA.p + (size_t)m * N, (long long)N, 1LL,
-                           Ainv.p, (long long)m, 1LL, n, m, m, 1.0, 0.0);
-        HIP_TRY(hipMemcpy2DAsync(Ak.p, sizeof(double) * n, dA.p + (size_t)m * N + m, sizeof(double) * N, sizeof(double) * n, n, hipMemcpyDeviceToDevice, h->stream));
-        hipLaunchKernelGGL(k_gemm, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, h->stream, Ak.p, (long long)n, T.p, (long long)m, 1LL,
-                           dA.p + (size_t)m * N, 1LL, (long long)N, n, n, m, -1.0, 1.0);
-        hipLaunchKernelGGL(k_marg_bk, dim3((n + 127) / 128), dim3(128), 0, h->stream, T.p, db.p, n, m, bk.p);
+        hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, h->stream, M.V.p, M.ev.p, m, M.Vs.p);
+        // Ainv = Vs^T Vs ; T = Arm Ainv ; Ak = Arr - T Arm^T ; bk = brr - T bmm   (FP64 matrix cores)
+        launch_mgemm(h, M.Ainv.p, m, M.Vs.p, 1LL, (long long)m, M.Vs.p, (long long)m, 1LL, m, m, m, 1.0, 0.0);
+        launch_mgemm(h, M.T.p, m, M.A.p + (size_t)m * N, (long long)N, 1LL, M.Ainv.p, (long long)m, 1LL, n, m, m, 1.0, 0.0);
+        HIP_TRY(hipMemcpy2DAsync(M.Ak.p, sizeof(double) * n, M.A.p + (size_t)m * N + m, sizeof(double) * N, sizeof(double) * n, n, hipMemcpyDeviceToDevice, h->stream));
+        launch_mgemm(h, M.Ak.p, n, M.T.p, (long long)m, 1LL, M.A.p + (size_t)m * N, 1LL, (long long)N, n, n, m, -1.0, 1.0);
+        hipLaunchKernelGGL(k_marg_bk, dim3((n + 127) / 128), dim3(128), 0, h->stream, M.T.p, M.b.p, n, m, M.bk.p);
+        HIP_TRY(hipStreamSynchronize(h->stream));   // `sel` goes out of scope
+    }
+    int nf = 0;
+    if (chol_form) {
+        // ---- Cholesky form: J = G with G^T G = Ak (rank-revealing, pivots cut like the eigenvalues), r0 = -G^-T bk as the
+        // factor's extra column. No eigen-decomposition.
+        const int n1 = n + 1;
+        const long long nn1 = (long long)n1 * n1;
+        hipLaunchKernelGGL(k_marg_aug_init, dim3((unsigned)((nn1 + 255) / 256)), dim3(256), 0, h->stream, M.Ak.p, M.bk.p, n, M.V.p);
+        nf = run_pchol(h, M.V.p, n1, M.G.p, pchol_tau(n, rq->eig_cut_mode));
+        if (nf < 0) { h->err = "marginalize: HIP error in the pivoted Cholesky"; return SADVIO_E_HIP; }
+        if (nf > n) nf = n;
+        if (nf > 0) {
+            const long long cnt = (long long)nf * n1;
+            hipLaunchKernelGGL(k_marg_pack_chol, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, M.G.p, n, h->d_jac_ints.p + n1, M.newJ.p, M.newr.p);
+            HIP_TRY(PR.step_of.alloc(n));
+            HIP_TRY(hipMemcpyAsync(PR.step_of.p, h->d_jac_ints.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+        }
+    } else {
+        // ---- rank-revealing decomposition of Ak (lower triangle, as Eigen reads it), marginalization.cpp:318-342
+        sw = run_jacobi(h, M.Ak.p, n, n, 1, M.G.p, M.V.p, M.ev.p, M.flag.p, rq->eig_cut_mode);
+        if (sw < 0) { h->err = "marginalize: HIP error in the eigen-solver"; return SADVIO_E_HIP; }
+        if (res) res->sweeps_k = sw;
+        hev.resize(n);
+        HIP_TRY(hipMemcpyAsync(hev.data(), M.ev.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        std::vector<int> sel_rows;
+        {
+            const double cut = marg_cut(hev, rq->eig_cut_mode);
+            // ascending eigenvalue order, like Eigen::SelfAdjointEigenSolver (row order of J only)
+            std::vector<int> order(n);
+            for (int i = 0; i < n; i++) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return hev[a] < hev[b]; });
+            for (int i : order) if (hev[i] > cut) sel_rows.push_back(i);
+        }
+        nf = (int)sel_rows.size();
+        if (nf > 0) {
+            HIP_TRY(M.sel.alloc(nf));
+            HIP_TRY(hipMemcpyAsync(M.sel.p, sel_rows.data(), sizeof(int) * nf, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_marg_prior, dim3(nf), dim3(JAC_THREADS), 0, h->stream, M.V.p, M.ev.p, M.sel.p, nf, n, M.bk.p, M.newJ.p, M.newr.p);
+            HIP_TRY(hipStreamSynchronize(h->stream));   // sel_rows goes out of scope
+        }
     }
-    // rank-revealing decomposition of Ak (lower triangle, as Eigen reads it), marginalization.cpp:318-342
-    sw = run_jacobi(h, Ak.p, n, n, 1, G.p, V.p, ev.p, dflag.p);
-    if (sw < 0) { h->err = "marginalize: HIP error in the eigen-solver"; return SADVIO_E_HIP; }
-    if (res) res->sweeps_k = sw;
-    std::vector<double> hev2(n);
-    HIP_TRY(hipMemcpyAsync(hev2.data(), ev.p, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    std::vector<int> sel_rows;
-    {
-        const double cut = marg_cut(hev2);
-        // ascending eigenvalue order, like Eigen::SelfAdjointEigenSolver (row order of J only)
-        std::vector<int> order(n);
-        for (int i = 0; i < n; i++) order[i] = i;
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return hev2[a] < hev2[b]; });
-        for (int i : order) if (hev2[i] > cut) sel_rows.push_back(i);
-    }
-    const int nf = (int)sel_rows.size();
     if (res) res->n_full = nf;
+    // the new prior becomes the handle's (AOptimizer.h:88-90: _marginalization_last), the old one's buffers become scratch
+    PR.J.swap(M.newJ); PR.r0.swap(M.newr);
+    PR.serial++;
+    PR.valid = nf > 0; PR.z_valid = false; PR.n_full = nf; PR.n = n; PR.form = chol_form ? SADVIO_PRIOR_FORM_CHOLESKY : SADVIO_PRIOR_FORM_EIGEN;
     if (nf > 0) {
-        HIP_TRY(dsel.alloc(nf)); HIP_TRY(dJ.alloc((size_t)nf * n)); HIP_TRY(dr0.alloc(nf));
-        HIP_TRY(hipMemcpyAsync(dsel.p, sel_rows.data(), sizeof(int) * nf, hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_marg_prior, dim3(nf), dim3(JAC_THREADS), 0, h->stream, V.p, ev.p, dsel.p, nf, n, bk.p, dJ.p, dr0.p);
-        if (J_out) HIP_TRY(hipMemcpyAsync(J_out, dJ.p, sizeof(double) * (size_t)nf * n, hipMemcpyDeviceToHost, h->stream));
-        if (r0_out) HIP_TRY(hipMemcpyAsync(r0_out, dr0.p, sizeof(double) * nf, hipMemcpyDeviceToHost, h->stream));
+        if (J_out) HIP_TRY(hipMemcpyAsync(J_out, PR.J.p, sizeof(double) * (size_t)nf * n, hipMemcpyDeviceToHost, h->stream));
+        if (r0_out) HIP_TRY(hipMemcpyAsync(r0_out, PR.r0.p, sizeof(double) * nf, hipMemcpyDeviceToHost, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipGetLastError());
-    dA.release(); db.release(); G.release(); V.release(); ev.release(); Vs.release(); Ainv.release(); T.release(); Ak.release(); bk.release();
-    dJ.release(); dr0.release(); dlastJ.release(); dlastr.release(); ditems.release(); dflag.release(); dsel.release(); dlastcol.release(); dsmall.release();
+    return SADVIO_OK;
+}
+
+int sadvio_ba_get_prior(sadvio_ba_handle* h, sadvio_prior_info* info, double* J, double* r0) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    const PriorState& PR = h->prior;
+    if (info) { info->valid = PR.valid ? 1 : 0; info->n_full = PR.valid ? PR.n_full : 0; info->n = PR.valid ? PR.n : 0; info->form = PR.form; }
+    if (!PR.valid) { if (J || r0) { h->err = "get_prior: the handle holds no prior"; return SADVIO_E_STATE; } return SADVIO_OK; }
+    HIP_TRY(hipSetDevice(h->device));
+    if (J) HIP_TRY(hipMemcpyAsync(J, PR.J.p, sizeof(double) * (size_t)PR.n_full * PR.n, hipMemcpyDeviceToHost, h->stream));
+    if (r0) HIP_TRY(hipMemcpyAsync(r0, PR.r0.p, sizeof(double) * PR.n_full, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return SADVIO_OK;
+}
+
+int sadvio_ba_set_prior(sadvio_ba_handle* h, int32_t n_full, int32_t n, int32_t form, const double* J, const double* r0) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    PriorState& PR = h->prior;
+    PR.serial++;
+    if (n_full <= 0) { PR.valid = false; PR.z_valid = false; return SADVIO_OK; }
+    if (n <= 0 || !J || !r0 || form != SADVIO_PRIOR_FORM_EIGEN) {   // a Cholesky-form prior carries its pivot order: only the device produces one
+        h->err = "set_prior: needs J, r0 in the eigen form (orthogonal rows)"; return SADVIO_E_INVALID_ARG;
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(PR.J.alloc((size_t)n_full * n)); HIP_TRY(PR.r0.alloc(n_full));
+    HIP_TRY(hipMemcpyAsync(PR.J.p, J, sizeof(double) * (size_t)n_full * n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(PR.r0.p, r0, sizeof(double) * n_full, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    PR.valid = true; PR.z_valid = false; PR.n_full = n_full; PR.n = n; PR.form = form;
     return SADVIO_OK;
 }
 
@@ -1792,10 +1944,11 @@ bool nfr_sqrt_info(const double* S, int rows, bool invert_first, double* W) {
 }
 }  // namespace
 
-int sadvio_ba_marginalize_relative(sadvio_ba_handle* h, int32_t w, int32_t kf_a, int32_t kf_b, double* inf36, double* Ak144) {
+int sadvio_ba_marginalize_relative(sadvio_ba_handle* h, int32_t w, int32_t kf_a, int32_t kf_b, int32_t eig_cut_mode, double* inf36, double* Ak144) {
     if (!h || !inf36) return SADVIO_E_INVALID_ARG;
     if (!h->uploaded) { h->err = "marginalize_relative before set_windows"; return SADVIO_E_STATE; }
     if (w < 0 || w >= (int)h->wins.size()) { h->err = "marginalize_relative: window out of range"; return SADVIO_E_INVALID_ARG; }
+    if (eig_cut_mode != SADVIO_EIG_CUT_REFERENCE && eig_cut_mode != SADVIO_EIG_CUT_NOISE_FLOOR) { h->err = "marginalize_relative: bad eig_cut_mode"; return SADVIO_E_INVALID_ARG; }
     if (h->world > 1) { h->err = "marginalize_relative: the window is sharded over several GPUs (each rank holds a landmark partition only)"; return SADVIO_E_INVALID_ARG; }
     const WinDev& d = h->wins[w].d;
     if (kf_a < 0 || kf_a >= d.n_kf || kf_b < 0 || kf_b >= d.n_kf || kf_a == kf_b) { h->err = "marginalize_relative: bad key-frame index"; return SADVIO_E_INVALID_ARG; }
@@ -1824,7 +1977,7 @@ int sadvio_ba_marginalize_relative(sadvio_ba_handle* h, int32_t w, int32_t kf_a,
     DevPtrs P = make_ptrs(h, o, 1);
     auto kl = h->factor_type == SADVIO_FACTOR_PIXEL ? k_relmarg_lmk<0> : k_relmarg_lmk<1>;
     hipLaunchKernelGGL(kl, dim3((n_items + 63) / 64), dim3(64), 0, h->stream, P, ditems.p, n_items, ga, gb, dscr.p, dAk.p, dmax.p);
-    hipLaunchKernelGGL(k_relmarg_apply, dim3((n_items + 63) / 64), dim3(64), 0, h->stream, dscr.p, n_items, m, dmax.p, dAk.p);
+    hipLaunchKernelGGL(k_relmarg_apply, dim3((n_items + 63) / 64), dim3(64), 0, h->stream, dscr.p, n_items, m, dmax.p, dAk.p, eig_cut_mode == SADVIO_EIG_CUT_NOISE_FLOOR ? 1 : 0);
     hipLaunchKernelGGL(k_relmarg_jac, dim3(1), dim3(64), 0, h->stream, P, ga, gb, dJ.p);
     HIP_TRY(hipGetLastError());
     double Ak[144], J[72];
@@ -1838,9 +1991,9 @@ int sadvio_ba_marginalize_relative(sadvio_ba_handle* h, int32_t w, int32_t kf_a,
     host_sym_eig(As, 12, ev, V);
     double mx = 0.0;
     for (int k = 0; k < 12; k++) mx = std::max(mx, std::fabs(ev[k]));
-    // noise floor of the Schur complement = a sum over the marginalised landmarks (see oracle/marg.c): the gauge null space
-    // of Ak computes to ~ eps * lambda_max * n_items
-    const double cut = std::max(1e-12, 12 * 2.220446049250313e-16 * mx * (2.0 + n_items));
+    // SADVIO_EIG_CUT_NOISE_FLOOR: the floor of the Schur complement = a sum over the marginalised landmarks (see oracle/marg.c):
+    // the gauge null space of Ak computes to ~ eps * lambda_max * n_items; SADVIO_EIG_CUT_REFERENCE: the reference's absolute 1e-12
+    const double cut = eig_cut_mode == SADVIO_EIG_CUT_NOISE_FLOOR ? std::max(1e-12, 12 * 2.220446049250313e-16 * mx * (2.0 + n_items)) : 1e-12;
     memset(Sk, 0, sizeof(Sk));
     for (int k = 0; k < 12; k++) {
         if (!(ev[k] > cut)) continue;
@@ -1854,67 +2007,150 @@ int sadvio_ba_marginalize_relative(sadvio_ba_handle* h, int32_t w, int32_t kf_a,
     return SADVIO_OK;
 }
 
+namespace {
+// Z (n_full x n) with Z^T Z = Sigma_k = pseudo-inverse of the prior's information, for the NFR covariances of sparsify:
+// eigen form: rows J_c / lambda_c; Cholesky form of full rank: the triangular inverse of G (k_tri_*: recursive halving on the
+// matrix cores); a rank-deficient Cholesky-form prior is first orthogonalised by the block Jacobi (its rows then ARE the eigen form).
+int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form, const int* step_of, double* Z) {
+    MargScratch& M = h->mg;
+    if (form == SADVIO_PRIOR_FORM_CHOLESKY && nf == n) {
+        const int npad = (n + 31) / 32 * 32;
+        HIP_TRY(M.L.alloc((size_t)npad * npad)); HIP_TRY(M.Tb.alloc((size_t)npad * npad)); HIP_TRY(M.piv_of.alloc(n));
+        if (M.tri_npad != npad) {
+            // node table of the recursion over [0, npad): leaves of <= 32 rows, inner nodes grouped by height
+            std::vector<std::vector<TriNode>> lev;
+            std::vector<TriNode> leaves;
+            struct Rec { static int go(int lo, int hi, std::vector<std::vector<TriNode>>& lev, std::vector<TriNode>& leaves) {
+                if (hi - lo <= 32) { leaves.push_back({lo, lo, hi, 0}); return 0; }
+                const int blocks = (hi - lo + 31) / 32, mid = lo + 32 * ((blocks + 1) / 2);
+                const int hl = go(lo, mid, lev, leaves), hr = go(mid, hi, lev, leaves);
+                const int ht = std::max(hl, hr) + 1;
+                if ((int)lev.size() < ht) lev.resize(ht);
+                lev[ht - 1].push_back({lo, mid, hi, 0});
+                return ht;
+            } };
+            Rec::go(0, npad, lev, leaves);
+            std::vector<TriNode> all(leaves);
+            M.tri_levels.clear();
+            for (auto& l : lev) {
+                int mm = 0, mn = 0;
+                for (auto& nd : l) { mm = std::max(mm, nd.hi - nd.mid); mn = std::max(mn, nd.mid - nd.lo); }
+                M.tri_levels.push_back({(int)all.size(), (int)l.size(), mm, mn});
+                all.insert(all.end(), l.begin(), l.end());
+            }
+            M.tri_leaves = (int)leaves.size();
+            HIP_TRY(M.nodes.alloc(all.size()));
+            h->up.add(M.nodes.p, all.data(), all.size() * sizeof(TriNode));
+            HIP_TRY(h->up.flush(h->stream));
+            M.tri_npad = npad;
+        }
+        hipLaunchKernelGGL(k_tri_gather, dim3((n + 255) / 256), dim3(256), 0, h->stream, J, n, step_of, M.piv_of.p, npad, M.L.p, 0);
+        const long long np2 = (long long)npad * npad;
+        hipLaunchKernelGGL(k_tri_gather, dim3((unsigned)((np2 + 255) / 256)), dim3(256), 0, h->stream, J, n, step_of, M.piv_of.p, npad, M.L.p, 1);
+        hipLaunchKernelGGL(k_tri_leaf, dim3(M.tri_leaves), dim3(64), 0, h->stream, M.L.p, npad, M.nodes.p);
+        for (const auto& lv : M.tri_levels) {
+            const dim3 grid((lv.max_n + 63) / 64, (lv.max_m + 63) / 64, lv.count);
+            hipLaunchKernelGGL(k_tri_level, grid, dim3(256), 0, h->stream, M.L.p, M.Tb.p, npad, M.nodes.p + lv.first, 0);
+            hipLaunchKernelGGL(k_tri_level, grid, dim3(256), 0, h->stream, M.L.p, M.Tb.p, npad, M.nodes.p + lv.first, 1);
+        }
+        const long long nn = (long long)n * n;
+        hipLaunchKernelGGL(k_tri_scatter, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, M.L.p, npad, n, step_of, Z);
+        return SADVIO_OK;
+    }
+    const double* rows = J;
+    if (form == SADVIO_PRIOR_FORM_CHOLESKY) {   // rank-deficient: orthogonalise a copy of the rows
+        HIP_TRY(M.G.alloc((size_t)nf * n)); HIP_TRY(M.flag.alloc(8));
+        HIP_TRY(hipMemcpyAsync(M.G.p, J, sizeof(double) * (size_t)nf * n, hipMemcpyDeviceToDevice, h->stream));
+        if (run_jacobi_rows(h, M.G.p, nf, n, M.flag.p) < 0) { h->err = "sparsify: HIP error in the eigen-solver"; return SADVIO_E_HIP; }
+        rows = M.G.p;
+    }
+    hipLaunchKernelGGL(k_z_from_eig, dim3(nf), dim3(JAC_THREADS), 0, h->stream, rows, n, Z);
+    return SADVIO_OK;
+}
+}  // namespace
+
 int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, int32_t n, const double* J, int32_t kf_keep,
                        int32_t kf_col, int32_t n_keep, const int32_t* lmk_index, const int32_t* lmk_col, int32_t* n_out,
                        sadvio_sparse_prior* out) {
     if (!h) return SADVIO_E_INVALID_ARG;
     if (n_out) *n_out = 0;
     if (!h->uploaded) { h->err = "sparsify before set_windows"; return SADVIO_E_STATE; }
-    if (w < 0 || w >= (int)h->wins.size() || !J || !n_out || !out || n_keep < 0 || (n_keep > 0 && (!lmk_index || !lmk_col))) { h->err = "sparsify: bad argument"; return SADVIO_E_INVALID_ARG; }
+    if (w < 0 || w >= (int)h->wins.size() || !n_out || !out || n_keep < 0 || (n_keep > 0 && (!lmk_index || !lmk_col))) { h->err = "sparsify: bad argument"; return SADVIO_E_INVALID_ARG; }
+    if (h->world > 1) { h->err = "sparsify: the window is sharded over several GPUs (linearisation values of a landmark partition only)"; return SADVIO_E_INVALID_ARG; }
+    PriorState& PR = h->prior;
+    MargScratch& M = h->mg;
+    const bool resident = J == nullptr;
+    if (resident) {
+        if (!PR.valid) { h->err = "sparsify: J = NULL but the handle holds no prior"; return SADVIO_E_STATE; }
+        nf = PR.n_full; n = PR.n;
+    }
     if (n <= 0 || nf <= 0) { h->err = "sparsify: empty prior"; return SADVIO_E_REFUSED; }
     const HostWin& HW = h->wins[w];
     const WinDev& d = HW.d;
+    const SrcWin& SW = h->src[w];
     if (vio && (kf_keep < 0 || kf_keep >= d.n_kf || kf_col < 0 || kf_col + 15 > n)) { h->err = "sparsify: kept key-frame out of range"; return SADVIO_E_INVALID_ARG; }
     for (int k = 0; k < n_keep; k++)
         if (lmk_col[k] >= 0 && (lmk_index[k] < 0 || lmk_index[k] >= d.n_lmk || lmk_col[k] + 3 > n)) { h->err = "sparsify: kept landmark out of range"; return SADVIO_E_INVALID_ARG; }
     HIP_TRY(hipSetDevice(h->device));
-    // linearisation values of the window (host read-back of the few entries needed)
-    double T[12], v3[3], ba3[3], bg3[3];
+    // linearisation values of the window: the handle's deep copy of the caller's arrays (no read-back)
+    double T[12], v3[3] = {0, 0, 0}, ba3[3] = {0, 0, 0}, bg3[3] = {0, 0, 0};
     if (vio) {
-        const long long g = d.kf_base + kf_keep;
-        HIP_TRY(hipMemcpy(T, h->d_kf_T0.p + 12 * g, sizeof(T), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(v3, h->d_kf_vel.p + 3 * g, 24, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(ba3, h->d_kf_ba.p + 3 * g, 24, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(bg3, h->d_kf_bg.p + 3 * g, 24, hipMemcpyDeviceToHost));
+        memcpy(T, &SW.kf_T[12 * (size_t)kf_keep], sizeof(T));
+        if (!SW.kf_vel.empty()) memcpy(v3, &SW.kf_vel[3 * (size_t)kf_keep], 24);
+        if (!SW.kf_ba.empty()) memcpy(ba3, &SW.kf_ba[3 * (size_t)kf_keep], 24);
+        if (!SW.kf_bg.empty()) memcpy(bg3, &SW.kf_bg[3 * (size_t)kf_keep], 24);
     }
-    std::vector<double> lp(3 * (size_t)std::max(d.n_lmk, 1));
-    if (d.n_lmk) HIP_TRY(hipMemcpy(lp.data(), h->d_lmk_p.p + 3 * (size_t)d.lmk_base, sizeof(double) * 3 * d.n_lmk, hipMemcpyDeviceToHost));
-    DevBuf<double> dJ, dlam, dS, dmi;
-    DevBuf<NfrSpec> dspec;
-    DevBuf<int> dlc;
-    HIP_TRY(dJ.alloc((size_t)nf * n)); HIP_TRY(dlam.alloc(nf));
-    HIP_TRY(hipMemcpyAsync(dJ.p, J, sizeof(double) * (size_t)nf * n, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_row_norm2, dim3(nf), dim3(JAC_THREADS), 0, h->stream, dJ.p, nf, n, dlam.p);
-    std::vector<NfrSpec> specs;
+    const double* lp = SW.lmk_p.data();
+    // the prior's rows and Z with Z^T Z = Sigma_k on the device
+    const double* dJ = nullptr; const double* dZ = nullptr;
+    if (resident) {
+        dJ = PR.J.p;
+        if (!PR.z_valid) {
+            HIP_TRY(PR.Z.alloc((size_t)nf * n));
+            const int rc = prior_build_Z(h, PR.J.p, nf, n, PR.form, PR.step_of.p, PR.Z.p);
+            if (rc != SADVIO_OK) return rc;
+            PR.z_valid = true;
+        }
+        dZ = PR.Z.p;
+    } else {
+        HIP_TRY(M.lastJ.alloc((size_t)nf * n)); HIP_TRY(M.Zt.alloc((size_t)nf * n));
+        HIP_TRY(hipMemcpyAsync(M.lastJ.p, J, sizeof(double) * (size_t)nf * n, hipMemcpyHostToDevice, h->stream));
+        const int rc = prior_build_Z(h, M.lastJ.p, nf, n, SADVIO_PRIOR_FORM_EIGEN, nullptr, M.Zt.p);
+        if (rc != SADVIO_OK) return rc;
+        dJ = M.lastJ.p; dZ = M.Zt.p;
+    }
+    std::vector<NfrSpecC> specs;
+    std::vector<double> jsel(4 * 225, 0.0);
     std::vector<int> kept;  // positions k with lmk_col >= 0
     for (int k = 0; k < n_keep; k++) if (lmk_col[k] >= 0) kept.push_back(k);
     std::vector<int> order;  // VO: chain order (indices into kept)
+    int out_off = 0;
+    auto push = [&](int rows, int cols, int js) { NfrSpecC s{}; s.rows = rows; s.cols = cols; s.jsel = js; s.out_off = out_off; out_off += rows * rows; specs.push_back(s); return &specs.back(); };
     if (vio) {
         double tsk[9] = {0, -T[11], T[10], T[11], 0, -T[9], -T[10], T[9], 0}, Rt[9];
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += T[3 * i + k] * tsk[3 * k + j]; Rt[3 * i + j] = s; }
-        NfrSpec f{};
-        f.rows = 15; f.cols = 15;
-        for (int a = 0; a < 15; a++) { f.Jsel[a * 15 + a] = 1.0; f.cidx[a] = kf_col + a; }
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { f.Jsel[i * 15 + j] = T[3 * i + j]; f.Jsel[i * 15 + 3 + j] = T[3 * i + j]; f.Jsel[(3 + i) * 15 + 3 + j] = T[3 * i + j]; }
-        specs.push_back(f);
+        double* J0 = &jsel[0];       // IMUPriordx selector 15 x 15 (marginalization.cpp:366-378)
+        for (int a = 0; a < 15; a++) J0[a * 15 + a] = 1.0;
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { J0[i * 15 + j] = T[3 * i + j]; J0[i * 15 + 3 + j] = T[3 * i + j]; J0[(3 + i) * 15 + 3 + j] = T[3 * i + j]; }
+        double* J1 = &jsel[225];     // PoseToLandmarkFactor selector 3 x 9: [R | -R [t]x | R] on (landmark, rotation, translation)
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { J1[i * 9 + j] = T[3 * i + j]; J1[i * 9 + 3 + j] = -Rt[3 * i + j]; J1[i * 9 + 6 + j] = T[3 * i + j]; }
+        NfrSpecC* f = push(15, 15, 0);
+        for (int a = 0; a < 15; a++) f->cidx[a] = kf_col + a;
         for (int k : kept) {
-            NfrSpec s{};
-            s.rows = 3; s.cols = 9;
-            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { s.Jsel[i * 9 + j] = T[3 * i + j]; s.Jsel[i * 9 + 3 + j] = -Rt[3 * i + j]; s.Jsel[i * 9 + 6 + j] = T[3 * i + j]; }
-            for (int a = 0; a < 3; a++) { s.cidx[a] = lmk_col[k] + a; s.cidx[3 + a] = kf_col + a; s.cidx[6 + a] = kf_col + 3 + a; }
-            specs.push_back(s);
+            NfrSpecC* s = push(3, 9, 1);
+            for (int a = 0; a < 3; a++) { s->cidx[a] = lmk_col[k] + a; s->cidx[3 + a] = kf_col + a; s->cidx[6 + a] = kf_col + 3 + a; }
         }
     } else {
         const int K = (int)kept.size();
         if (K < 2) { h->err = "sparsify: fewer than two kept landmarks"; return SADVIO_E_REFUSED; }
         std::vector<int> lc(K);
         for (int a = 0; a < K; a++) lc[a] = lmk_col[kept[a]];
-        HIP_TRY(dlc.alloc(K)); HIP_TRY(dmi.alloc((size_t)K * K));
-        HIP_TRY(hipMemcpyAsync(dlc.p, lc.data(), sizeof(int) * K, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemsetAsync(dmi.p, 0, sizeof(double) * (size_t)K * K, h->stream));
-        hipLaunchKernelGGL(k_nfr_trace, dim3((K * K + 255) / 256), dim3(256), 0, h->stream, dJ.p, nf, n, dlc.p, K, dmi.p);
+        HIP_TRY(M.lc.alloc(K)); HIP_TRY(M.mi.alloc((size_t)K * K));
+        HIP_TRY(hipMemcpyAsync(M.lc.p, lc.data(), sizeof(int) * K, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(M.mi.p, 0, sizeof(double) * (size_t)K * K, h->stream));
+        hipLaunchKernelGGL(k_nfr_trace, dim3((K * K + 255) / 256), dim3(256), 0, h->stream, dJ, nf, n, M.lc.p, K, M.mi.p);
         std::vector<double> mi((size_t)K * K);
-        HIP_TRY(hipMemcpyAsync(mi.data(), dmi.p, sizeof(double) * (size_t)K * K, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(mi.data(), M.mi.p, sizeof(double) * (size_t)K * K, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         // greedy chain (marginalization.cpp:432-456); Eigen's maxCoeff visits a column-major matrix column by column
         int mr = 0, mc = 0; double best = -1;
@@ -1931,26 +2167,28 @@ int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, 
             for (int i = 0; i < K; i++) mi[(size_t)i * K + bc] = 0;
             cur = bc;
         }
+        double* J2 = &jsel[2 * 225];   // identity 3 x 3
+        double* J3 = &jsel[3 * 225];   // [I -I] 3 x 6
+        for (int q = 0; q < 3; q++) { J2[q * 3 + q] = 1.0; J3[q * 6 + q] = 1.0; J3[q * 6 + 3 + q] = -1.0; }
         // covariance of every ordered landmark (entropy root, unary factor) then of every chain link
         for (int a : order) {
-            NfrSpec s{};
-            s.rows = 3; s.cols = 3;
-            for (int q = 0; q < 3; q++) { s.Jsel[q * 3 + q] = 1.0; s.cidx[q] = lmk_col[kept[a]] + q; }
-            specs.push_back(s);
+            NfrSpecC* s = push(3, 3, 2);
+            for (int q = 0; q < 3; q++) s->cidx[q] = lmk_col[kept[a]] + q;
         }
         for (size_t k = 0; k + 1 < order.size(); k++) {
-            NfrSpec s{};
-            s.rows = 3; s.cols = 6;
-            for (int q = 0; q < 3; q++) { s.Jsel[q * 6 + q] = 1.0; s.Jsel[q * 6 + 3 + q] = -1.0; s.cidx[q] = lmk_col[kept[order[k]]] + q; s.cidx[3 + q] = lmk_col[kept[order[k + 1]]] + q; }
-            specs.push_back(s);
+            NfrSpecC* s = push(3, 6, 3);
+            for (int q = 0; q < 3; q++) { s->cidx[q] = lmk_col[kept[order[k]]] + q; s->cidx[3 + q] = lmk_col[kept[order[k + 1]]] + q; }
         }
     }
     const int ns = (int)specs.size();
-    HIP_TRY(dspec.alloc(ns)); HIP_TRY(dS.alloc((size_t)ns * 225));
-    HIP_TRY(hipMemcpyAsync(dspec.p, specs.data(), sizeof(NfrSpec) * ns, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_nfr_cov, dim3(ns), dim3(JAC_THREADS), 0, h->stream, dJ.p, nf, n, dlam.p, dspec.p, dS.p);
-    std::vector<double> S((size_t)ns * 225);
-    HIP_TRY(hipMemcpyAsync(S.data(), dS.p, sizeof(double) * (size_t)ns * 225, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(M.spec.alloc(ns)); HIP_TRY(M.jsel.alloc(4 * 225)); HIP_TRY(M.S.alloc((size_t)std::max(out_off, 1)));
+    h->up.add(M.spec.p, specs.data(), sizeof(NfrSpecC) * (size_t)ns);
+    h->up.add(M.jsel.p, jsel.data(), sizeof(double) * jsel.size());
+    HIP_TRY(h->up.flush(h->stream));
+    hipLaunchKernelGGL(k_nfr_cov_z, dim3(ns), dim3(JAC_THREADS), 0, h->stream, dZ, nf, n, M.spec.p, M.jsel.p, M.S.p);
+    std::vector<double>& S = M.hS;
+    S.resize((size_t)out_off);
+    HIP_TRY(hipMemcpyAsync(S.data(), M.S.p, sizeof(double) * (size_t)out_off, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipGetLastError());
     int cnt = 0;
@@ -1960,7 +2198,7 @@ int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, 
         memset(o, 0, sizeof(*o));
         o->type = SADVIO_SPARSE_IMU_PRIOR; o->kf = kf_keep; o->lmk0 = o->lmk1 = -1;
         memcpy(o->T_prior, T, sizeof(T)); memcpy(o->v_prior, v3, 24); memcpy(o->ba_prior, ba3, 24); memcpy(o->bg_prior, bg3, 24);
-        if (!nfr_sqrt_info(&S[0], 15, true, o->sqrt_inf)) return fail();
+        if (!nfr_sqrt_info(&S[specs[0].out_off], 15, true, o->sqrt_inf)) return fail();
         for (size_t i = 0; i < kept.size(); i++) {
             const int k = kept[i];
             o = out + cnt++;
@@ -1968,13 +2206,13 @@ int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, 
             o->type = SADVIO_SPARSE_POSE_TO_LMK; o->kf = kf_keep; o->lmk0 = lmk_index[k]; o->lmk1 = -1;
             const double* p = &lp[3 * (size_t)lmk_index[k]];
             for (int a = 0; a < 3; a++) o->delta[a] = T[3 * a] * p[0] + T[3 * a + 1] * p[1] + T[3 * a + 2] * p[2] + T[9 + a];
-            if (!nfr_sqrt_info(&S[(i + 1) * 225], 3, true, o->sqrt_inf)) return fail();
+            if (!nfr_sqrt_info(&S[specs[i + 1].out_off], 3, true, o->sqrt_inf)) return fail();
         }
     } else {
         const int no = (int)order.size();
         int root = 0; double best_det = 0;
         for (int k = 0; k < no; k++) {
-            const double* s = &S[(size_t)k * 225];
+            const double* s = &S[specs[k].out_off];
             const double det = s[0] * (s[4] * s[8] - s[5] * s[7]) - s[1] * (s[3] * s[8] - s[5] * s[6]) + s[2] * (s[3] * s[7] - s[4] * s[6]);
             if (k == 0 || det < best_det) { best_det = det; root = k; }
         }
@@ -1983,14 +2221,14 @@ int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, 
         const int lr = lmk_index[kept[order[root]]];
         o->type = SADVIO_SPARSE_LMK_PRIOR; o->kf = -1; o->lmk0 = lr; o->lmk1 = -1;
         memcpy(o->delta, &lp[3 * (size_t)lr], 24);
-        if (!nfr_sqrt_info(&S[(size_t)root * 225], 3, false, o->sqrt_inf)) return fail();
+        if (!nfr_sqrt_info(&S[specs[root].out_off], 3, false, o->sqrt_inf)) return fail();
         for (int k = 0; k + 1 < no; k++) {
             const int la = lmk_index[kept[order[k]]], lb = lmk_index[kept[order[k + 1]]];
             o = out + cnt++;
             memset(o, 0, sizeof(*o));
             o->type = SADVIO_SPARSE_LMK_TO_LMK; o->kf = -1; o->lmk0 = la; o->lmk1 = lb;
             for (int a = 0; a < 3; a++) o->delta[a] = lp[3 * (size_t)la + a] - lp[3 * (size_t)lb + a];
-            if (!nfr_sqrt_info(&S[(size_t)(no + k) * 225], 3, false, o->sqrt_inf)) return fail();
+            if (!nfr_sqrt_info(&S[specs[no + k].out_off], 3, false, o->sqrt_inf)) return fail();
         }
     }
     *n_out = cnt;

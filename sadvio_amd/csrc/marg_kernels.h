@@ -110,7 +110,7 @@ __global__ __launch_bounds__(PCH_THREADS) void k_pchol_panel(double* __restrict_
         if (k0 == 0) { d[i] = S[(size_t)i * n + i]; pv[i] = i; } else { d[i] = dg[i]; pv[i] = piv[i]; }
     }
     __syncthreads();
-    if (k0 == 0 && tid == 0) { double m = 0.0; for (int i = 0; i < n; i++) m = fmax(m, d[i]); dctl[0] = tau_rel * m; }
+    if (k0 == 0 && tid == 0) { double m = 0.0; for (int i = 0; i < n; i++) m = fmax(m, d[i]); dctl[0] = tau_rel >= 0.0 ? tau_rel * m : -tau_rel; }
     __syncthreads();
     const double tau = dctl[0];
     int rank = -1;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(PCH_THREADS) void k_pchol_panel_np(const double* __
         m = wave_max(m);
         if (ln == 0) wmax[wv] = m;
         __syncthreads();
-        if (tid == 0) { double mm = 0.0; for (int q = 0; q < PCH_THREADS / 64; q++) mm = fmax(mm, wmax[q]); dctl[0] = tau_rel * mm; lk[0] = tau_rel * mm; }
+        if (tid == 0) { double mm = 0.0; for (int q = 0; q < PCH_THREADS / 64; q++) mm = fmax(mm, wmax[q]); const double t0 = tau_rel >= 0.0 ? tau_rel * mm : -tau_rel; dctl[0] = t0; lk[0] = t0; }
         __syncthreads();
     }
     const double tau = k0 == 0 ? lk[0] : dctl[0];
@@ -702,6 +702,170 @@ __global__ __launch_bounds__(256) void k_gemm(double* C, long long ldc, const do
     if (i < M && j < N) C[(size_t)i * ldc + j] = (beta == 0.0 ? 0.0 : beta * C[(size_t)i * ldc + j]) + alpha * acc;
 }
 
+// ---- FP64 matrix-core GEMM (round 4) -----------------------------------------------------------------------------------
+// One 64 x 64 tile of C = alpha op(A) op(B) + beta C per 256-thread workgroup, K streamed through LDS in chunks of 16:
+// wave w owns rows [16 w, 16 w + 16) of the tile, four v_mfma_f64_16x16x4_f64 accumulators across its 64 columns. Arbitrary
+// element strides cover every transpose (the staging loop picks the lane order that is unit-stride in memory); [kbeg, kend)
+// restricts the contraction (triangular operands). Used by the Schur complement of the marginalisation and by the
+// triangular inverse below — the contractions of K8 that ARE dense ("GEMM Arm Amm+ Arm^T (MFMA-eligible)").
+__device__ __forceinline__ void mgemm_tile(double* __restrict__ C, long long ldc, const double* __restrict__ A, long long sai, long long sak,
+                                           const double* __restrict__ B, long long sbk, long long sbj, int M, int N, int kbeg, int kend,
+                                           double alpha, double beta, int ti, int tj, double (*As)[17], double (*Bs)[17]) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, lr = ln & 15, lk = ln >> 4;
+    d4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int idx = tid + 256 * e;
+            int r, c;
+            if (sak == 1) { r = idx >> 4; c = idx & 15; } else { c = idx >> 6; r = idx & 63; }
+            As[r][c] = (ti + r < M && k0 + c < kend) ? A[(long long)(ti + r) * sai + (long long)(k0 + c) * sak] : 0.0;
+            int j, k;
+            if (sbj == 1) { k = idx >> 6; j = idx & 63; } else { j = idx >> 4; k = idx & 15; }
+            Bs[j][k] = (tj + j < N && k0 + k < kend) ? B[(long long)(k0 + k) * sbk + (long long)(tj + j) * sbj] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double a = As[16 * wv + lr][4 * u + lk];
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bs[16 * q + lr][4 * u + lk], acc[q], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int row = ti + 16 * wv + lk + 4 * rg, col = tj + 16 * q + lr;
+            if (row < M && col < N) {
+                double* c = C + (long long)row * ldc + col;
+                *c = (beta == 0.0 ? 0.0 : beta * *c) + alpha * acc[q][rg];
+            }
+        }
+}
+
+// C[i][j] = beta C[i][j] + alpha sum_k A(i,k) B(k,j), same calling convention as k_gemm; grid (ceil(N/64), ceil(M/64))
+__global__ __launch_bounds__(256) void k_mgemm(double* C, long long ldc, const double* A, long long sai, long long sak, const double* B, long long sbk,
+                                               long long sbj, int M, int N, int K, double alpha, double beta) {
+    __shared__ double As[64][17], Bs[64][17];
+    mgemm_tile(C, ldc, A, sai, sak, B, sbk, sbj, M, N, 0, K, alpha, beta, blockIdx.y * 64, blockIdx.x * 64, As, Bs);
+}
+
+// ---- Cholesky form of the prior (SADVIO_PRIOR_FORM_CHOLESKY) ---------------------------------------------------------------------
+// S' = [[sym_lower(Ak), bk], [bk^T, -1]] ((n + 1) x (n + 1)): the pivoted Cholesky kernels above run on it unchanged — the extra
+// index has a negative diagonal, so it is never chosen as a pivot, and as a not-yet-pivoted column it receives
+// G[k][n] = (bk[p_k] - sum_{c<k} G[c][p_k] G[c][n]) / G[k][p_k], i.e. G^-T bk restricted to the pivots: r0 = -G[:, n].
+__global__ void k_marg_aug_init(const double* __restrict__ Ak, const double* __restrict__ bk, int n, double* __restrict__ S) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n1 = n + 1;
+    if (idx >= (long long)n1 * n1) return;
+    const int i = (int)(idx / n1), j = (int)(idx - (long long)i * n1);
+    double v;
+    if (i < n && j < n) v = i >= j ? Ak[(size_t)i * n + j] : Ak[(size_t)j * n + i];   // Eigen reads the lower triangle (marginalization.cpp:321)
+    else if (i == n && j == n) v = -1.0;
+    else v = bk[i < n ? i : j];
+    S[idx] = v;
+}
+
+// J[k][i] = G'[k][i], r0[k] = -G'[k][n] for the rank rows (the factor's rows beyond the rank are zero)
+__global__ void k_marg_pack_chol(const double* __restrict__ G, int n, const int* __restrict__ rank, double* __restrict__ J, double* __restrict__ r0) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n1 = n + 1, r = *rank;
+    if (idx >= (long long)r * n1) return;
+    const int k = (int)(idx / n1), i = (int)(idx - (long long)k * n1);
+    const double v = G[idx];
+    if (i < n) J[(size_t)k * n + i] = v; else r0[k] = -v;
+}
+
+// ---- triangular inverse: Sigma_k = Ak^-1 = Z^T Z for sadvio_ba_sparsify from the Cholesky form --------------------------------
+// With p(q) = the index chosen at pivot step q, L[q][k] = G[k][p(q)] is lower triangular and Ak[p(a)][p(b)] = (L L^T)[a][b], so
+// Z[k][p(a)] = (L^-1)[k][a]. L^-1 by recursive halving on 32-row leaves: inv([[A, 0], [C, B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]]
+// — every level is two batched matrix-core GEMMs over its nodes (k_tri_level), ceil(log2(n / 32)) levels, no pivot chain.
+__global__ void k_tri_gather(const double* __restrict__ G, int n, const int* __restrict__ step_of, int* __restrict__ piv_of, int npad, double* __restrict__ L, int phase) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (phase == 0) { if (idx < n && step_of[idx] >= 0 && step_of[idx] < n) piv_of[step_of[idx]] = (int)idx; return; }
+    if (idx >= (long long)npad * npad) return;
+    const int q = (int)(idx / npad), k = (int)(idx - (long long)q * npad);
+    double v = q == k ? 1.0 : 0.0;
+    if (q < n && k < n) v = k <= q ? G[(size_t)k * n + piv_of[q]] : 0.0;
+    L[idx] = v;
+}
+
+struct TriNode { int lo, mid, hi, pad; };
+
+// leaves: in-place inverse of the lower-triangular diagonal block [lo, hi) (hi - lo <= 32), one wave per leaf
+__global__ __launch_bounds__(64) void k_tri_leaf(double* __restrict__ L, int npad, const TriNode* __restrict__ leaves) {
+    __shared__ double B[32][33];
+    const TriNode nd = leaves[blockIdx.x];
+    const int s = nd.hi - nd.lo, t = threadIdx.x;
+    for (int e = t; e < s * s; e += 64) { const int r = e / s, c = e - r * s; B[r][c] = L[(size_t)(nd.lo + r) * npad + nd.lo + c]; }
+    __syncthreads();
+    if (t < s) {
+        double x[32];
+#pragma unroll
+        for (int r = 0; r < 32; r++) x[r] = 0.0;
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            if (r < s && r >= t) {
+                double acc = r == t ? 1.0 : 0.0;
+#pragma unroll
+                for (int j = 0; j < 32; j++) if (j < r && j >= t) acc -= B[r][j] * x[j];
+                x[r] = acc / B[r][r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 32; r++) if (r < s) L[(size_t)(nd.lo + r) * npad + nd.lo + t] = r >= t ? x[r] : 0.0;
+    }
+}
+
+// one level: phase 0: T = C A^-1 (C = L[mid:hi, lo:mid], A^-1 = L[lo:mid, lo:mid]) into Tb at the same coordinates;
+// phase 1: L[mid:hi, lo:mid] = -B^-1 T (B^-1 = L[mid:hi, mid:hi]). grid (tiles j, tiles i, node); the contraction range follows
+// the triangles (A^-1[k][j] = 0 for k < j, B^-1[i][k] = 0 for k > i).
+__global__ __launch_bounds__(256) void k_tri_level(double* __restrict__ L, double* __restrict__ Tb, int npad, const TriNode* __restrict__ nodes, int phase) {
+    __shared__ double As[64][17], Bs[64][17];
+    const TriNode nd = nodes[blockIdx.z];
+    const int M = nd.hi - nd.mid, N = nd.mid - nd.lo;
+    const int ti = blockIdx.y * 64, tj = blockIdx.x * 64;
+    if (ti >= M || tj >= N) return;
+    const long long ld = npad;
+    if (phase == 0) {
+        double* C = Tb + (size_t)nd.mid * ld + nd.lo;
+        const double* A = L + (size_t)nd.mid * ld + nd.lo;        // C block, M x N (K = N)
+        const double* Bm = L + (size_t)nd.lo * ld + nd.lo;        // A^-1, N x N lower
+        mgemm_tile(C, ld, A, ld, 1, Bm, ld, 1, M, N, tj & ~15, N, 1.0, 0.0, ti, tj, As, Bs);
+    } else {
+        double* C = L + (size_t)nd.mid * ld + nd.lo;
+        const double* A = L + (size_t)nd.mid * ld + nd.mid;       // B^-1, M x M lower (K = M)
+        const double* Bm = Tb + (size_t)nd.mid * ld + nd.lo;      // T, M x N
+        const int kend = ti + 64 < M ? ti + 64 : M;
+        mgemm_tile(C, ld, A, ld, 1, Bm, ld, 1, M, N, 0, kend, -1.0, 0.0, ti, tj, As, Bs);
+    }
+}
+
+// Z[k][i] = (L^-1)[k][step_of[i]] (n x n, original column order)
+__global__ void k_tri_scatter(const double* __restrict__ Li, int npad, int n, const int* __restrict__ step_of, double* __restrict__ Z) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * n) return;
+    const int k = (int)(idx / n), i = (int)(idx - (long long)k * n);
+    const int a = step_of[i];
+    Z[idx] = (a >= 0 && a <= k) ? Li[(size_t)k * npad + a] : 0.0;
+}
+
+// eigen form: Z[c][:] = J[c][:] / |J_c|^2 (Sigma = Lambda^-1, U[:, c] = J_c / sqrt(lambda_c): Sigma_k = sum_c z_c z_c^T)
+__global__ __launch_bounds__(JAC_THREADS) void k_z_from_eig(const double* __restrict__ J, int n, double* __restrict__ Z) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += JAC_THREADS) { const double v = J[(size_t)c * n + i]; s += v * v; }
+    s = block_sum_256(s, sh);
+    const double il = s > 0.0 ? 1.0 / s : 0.0;
+    for (int i = threadIdx.x; i < n; i += JAC_THREADS) Z[(size_t)c * n + i] = J[(size_t)c * n + i] * il;
+}
+
 // rows of V (eigenvectors) scaled by sel[i] (0 = dropped): Vs[i][:] = sel[i] * V[i][:]
 __global__ void k_scale_rows(const double* V, const double* sel, int n, double* Vs) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -891,6 +1055,61 @@ __global__ __launch_bounds__(JAC_THREADS) void k_nfr_cov(const double* J, int nf
     }
 }
 
+// Round 4: the same covariances from Z with Z^T Z = Sigma_k (either form of the prior), compact factor descriptions — the
+// selector matrices of a sparsification come from a table of at most four shapes (IMUPriordx 15 x 15, PoseToLandmark 3 x 9,
+// identity 3 x 3, [I -I] 3 x 6) instead of 225 doubles per factor: cov_f = (Jsel Z[:, cidx]^T)(..)^T, packed rows x rows at out_off.
+struct NfrSpecC {
+    int rows, cols, jsel, out_off;
+    int cidx[16];
+};
+
+__global__ __launch_bounds__(JAC_THREADS) void k_nfr_cov_z(const double* __restrict__ Z, int nf, int n, const NfrSpecC* __restrict__ specs,
+                                                           const double* __restrict__ jsel_tab /*[4][225]*/, double* __restrict__ S) {
+    __shared__ double acc[225];
+    __shared__ double Js[225];
+    __shared__ int ci[16];
+    const NfrSpecC& sp = specs[blockIdx.x];
+    const int rows = sp.rows, cols = sp.cols;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < rows * cols; i += JAC_THREADS) Js[i] = jsel_tab[(size_t)sp.jsel * 225 + i];
+    for (int i = tid; i < 225; i += JAC_THREADS) acc[i] = 0.0;
+    if (tid < 16) ci[tid] = sp.cidx[tid];
+    __syncthreads();
+    if (rows == 3) {   // the n_keep landmark factors: six partial sums in registers, one wave reduction each
+        double p00 = 0, p10 = 0, p11 = 0, p20 = 0, p21 = 0, p22 = 0;
+        for (int c = tid; c < nf; c += JAC_THREADS) {
+            double w0 = 0, w1 = 0, w2 = 0;
+            for (int k = 0; k < cols; k++) {
+                const double u = Z[(size_t)c * n + ci[k]];
+                w0 += Js[k] * u; w1 += Js[cols + k] * u; w2 += Js[2 * cols + k] * u;
+            }
+            p00 += w0 * w0; p10 += w1 * w0; p11 += w1 * w1; p20 += w2 * w0; p21 += w2 * w1; p22 += w2 * w2;
+        }
+        p00 = wave_sum(p00); p10 = wave_sum(p10); p11 = wave_sum(p11); p20 = wave_sum(p20); p21 = wave_sum(p21); p22 = wave_sum(p22);
+        if ((tid & 63) == 0) {
+            atomic_add_f64(&acc[0], p00); atomic_add_f64(&acc[15], p10); atomic_add_f64(&acc[16], p11);
+            atomic_add_f64(&acc[30], p20); atomic_add_f64(&acc[31], p21); atomic_add_f64(&acc[32], p22);
+        }
+    } else {           // the one 15-row factor of a VIO prior
+        for (int c = tid; c < nf; c += JAC_THREADS) {
+            double u[15], w[15];
+            for (int k = 0; k < cols; k++) u[k] = Z[(size_t)c * n + ci[k]];
+            for (int a = 0; a < rows; a++) {
+                double s = 0.0;
+                for (int k = 0; k < cols; k++) s += Js[a * cols + k] * u[k];
+                w[a] = s;
+            }
+            for (int a = 0; a < rows; a++)
+                for (int b = 0; b <= a; b++) atomic_add_f64(&acc[a * 15 + b], w[a] * w[b]);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < rows * rows; i += JAC_THREADS) {
+        const int a = i / rows, b = i - a * rows;
+        S[(size_t)sp.out_off + i] = a >= b ? acc[a * 15 + b] : acc[b * 15 + a];
+    }
+}
+
 // |trace of the 3x3 block (a, b) of J^T J| for every pair of kept landmarks (computeOffDiag, :304-316)
 __global__ void k_nfr_trace(const double* J, int nf, int n, const int* lcols, int K, double* mi) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -978,10 +1197,10 @@ __global__ __launch_bounds__(64) void k_relmarg_lmk(DevPtrs P, const int* items 
     atomic_max_u64(evmax_bits, (unsigned long long)__double_as_longlong(mx));
 }
 
-__global__ void k_relmarg_apply(const double* scratch, int n_items, int m, const unsigned long long* evmax_bits, double* Ak) {
+__global__ void k_relmarg_apply(const double* scratch, int n_items, int m, const unsigned long long* evmax_bits, double* Ak, int noise_floor) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_items) return;
-    const double cut = fmax(1e-12, (double)m * 2.220446049250313e-16 * __longlong_as_double((long long)*evmax_bits));
+    const double cut = noise_floor ? fmax(1e-12, (double)m * 2.220446049250313e-16 * __longlong_as_double((long long)*evmax_bits)) : 1e-12;   // SADVIO_EIG_CUT_*
     const double* row = scratch + (long long)e * RELM_ROW;
     double Pi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < 3; k++) {

@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Wall time of one back-end key-frame step as the reference's timers bracket it (slamBiMonoVIO.cpp:569-594: marginalize
+(+ sparsify), then localMapVIOptimization = graph build + solve + write-back) on the config-3 shaped window: 12-KF VIO,
+7 200 landmarks, 300 kept landmarks (m = 135, n = 915). Phases: marginalize -> [sparsify] -> set_windows (with the prior) ->
+solve -> get_deltas; the prior stays on the device. Prints one JSON line per variant."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from sadvio_amd import capi
+from golden_util import config3_marg_case
+
+n_keep = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+w, args = config3_marg_case(n_keep)
+
+
+def next_window():
+    w2, _ = config3_marg_case(n_keep)
+    w2.pose_priors = []; w2.kf_const = np.zeros(w2.n_kf, dtype=np.uint8); w2.kf_const[11] = 1
+    w2.imu_factors = [f for f in w2.imu_factors if f["kf_i"] != 11]
+    return w2
+
+
+w2 = next_window()
+opts = capi.gn_options(10)
+IDX = ("kf_keep", "kf_col", "lmk_index", "lmk_col")
+
+
+def run(form, sparsif, readback=False, eig_cut="reference"):
+    be = capi.Backend(device=0, use_graph=True)
+    best = None
+    for rep in range(reps + 1):
+        ph = {}
+        be.set_windows([w])          # the window that still holds frame0 (already on the device in a live system)
+        t0 = time.perf_counter()
+        g = be.marginalize(0, form=form, eig_cut=eig_cut, readback=readback, **args)
+        t1 = time.perf_counter(); ph["marginalize"] = t1 - t0
+        fs = None
+        if sparsif:
+            fs = be.sparsify(0, g, vio=True)
+            t2 = time.perf_counter(); ph["sparsify"] = t2 - t1; t1 = t2
+        w2.dense_prior = None if sparsif else {k: g[k] for k in (IDX if not readback else IDX + ("J", "r0"))}
+        w2.sparse_priors = fs if sparsif else []
+        be.set_windows([w2])
+        t2 = time.perf_counter(); ph["set_windows"] = t2 - t1
+        s = be.solve(opts)[0]
+        t3 = time.perf_counter(); ph["solve"] = t3 - t2
+        d = be.get_deltas(0)
+        t4 = time.perf_counter(); ph["get_deltas"] = t4 - t3
+        ph["total"] = t4 - t0
+        if rep > 0 and (best is None or ph["total"] < best["total"]):
+            best = ph
+    be.close()
+    rec = {"form": form, "sparsification": bool(sparsif), "readback_of_J": bool(readback), "eig_cut": eig_cut, "n": g["n"], "n_full": g["n_full"],
+           "iterations": s.iterations, "ms": {k: round(1e3 * v, 3) for k, v in best.items()}}
+    print(json.dumps(rec), flush=True)
+    return rec
+
+
+if __name__ == "__main__":
+    out = []
+    for form in ("cholesky", "eigen"):
+        for sp in (True, False):
+            out.append(run(form, sp))
+    out.append(run("eigen", True, readback=True, eig_cut="noise_floor"))   # the round-3 path: J through the host three times
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "backend_step.json"), "w"), indent=1)

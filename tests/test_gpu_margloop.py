@@ -1,0 +1,298 @@
+"""Round 4 — the per-key-frame marginalisation loop on the device (SURVEY.md §8 a14 / a15 / b "Ownership"):
+  * the prior is HANDLE STATE (AOptimizer.h:88-90 `_marginalization_last`): marginalize leaves (J, r0) on the device, the next
+    window attaches it (SADVIO_PRIOR_RESIDENT), sparsify reads it, the next marginalize folds it in — no host copy of J;
+  * SADVIO_PRIOR_FORM_CHOLESKY (J = rank-revealing Cholesky factor of Ak, r0 = -G^-T bk) gives the same MarginalizationFactor as
+    the reference's eigen form: J^T J, J^T r0, |r0|^2, hence the same next solve and the same NFR factors;
+  * SADVIO_EIG_CUT_REFERENCE (the reference's absolute 1e-12, marginalization.hpp:58) against SADVIO_EIG_CUT_NOISE_FLOOR on a
+    low-parallax window with a stated bound on the difference."""
+import os
+
+import numpy as np
+import pytest
+
+from marg_helpers import with_lonely_landmarks
+from sadvio_amd import capi, synthetic
+from test_oracle_marg import pre_marginalize
+from vio_helpers import make_vio_window
+
+pytestmark = pytest.mark.gpu
+
+PRIOR_KEYS = ("J", "r0", "kf_keep", "kf_col", "lmk_index", "lmk_col")
+
+
+def invariants(p):
+    J, r0 = p["J"], p["r0"]
+    return J.T @ J, J.T @ r0, float(r0 @ r0)
+
+
+def same_information(a, b, rtol=1e-8):
+    Ha, ga, ca = invariants(a)
+    Hb, gb, cb = invariants(b)
+    scale = np.abs(Hb).max()
+    assert np.abs(Ha - Hb).max() <= rtol * scale
+    assert np.abs(ga - gb).max() <= rtol * max(np.abs(gb).max(), np.sqrt(scale))
+    assert abs(ca - cb) <= 1e-7 * max(cb, 1.0)
+
+
+def small_vio_case(seed=72, n_lmk=400, n_lonely=10):
+    w = with_lonely_landmarks(make_vio_window(n_kf=6, n_lmk=n_lmk, seed=seed), 5, n_lonely)
+    keep, marg = pre_marginalize(w, 5)
+    imu = [f for f in w.imu_factors if f["kf_i"] == 5 and f["kf_j"] == 4][0]
+    rng = np.random.default_rng(seed)
+    last = {"J": 20.0 * (np.eye(15) + 0.1 * rng.standard_normal((15, 15))), "r0": 0.1 * rng.standard_normal(15), "kf_keep": 5,
+            "kf_col": 0, "lmk_index": np.zeros(0, dtype=np.int32), "lmk_col": np.zeros(0, dtype=np.int32)}
+    args = dict(kf_marg=5, lmk_marg=marg, lmk_keep=keep, kf_keep=4, marg_has_imu=True, imu=imu, priors=w.pose_priors, last=last)
+    return w, args
+
+
+def next_window(seed, n_lmk, n_lonely, dense_prior=None, sparse=None):
+    w2 = with_lonely_landmarks(make_vio_window(n_kf=6, n_lmk=n_lmk, seed=seed), 5, n_lonely)
+    w2.pose_priors = []; w2.kf_const = np.zeros(w2.n_kf, dtype=np.uint8); w2.kf_const[5] = 1
+    w2.imu_factors = [f for f in w2.imu_factors if f["kf_i"] != 5]
+    if dense_prior is not None:
+        w2.dense_prior = dense_prior
+    if sparse is not None:
+        w2.sparse_priors = sparse
+    return w2
+
+
+@pytest.mark.parametrize("eig_cut", ["noise_floor", "reference"])
+def test_cholesky_form_carries_the_same_information(backend_cls, oracle_lib, eig_cut):
+    w, args = small_vio_case()
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    ge = be.marginalize(0, eig_cut=eig_cut, form="eigen", **args)
+    gc = be.marginalize(0, eig_cut=eig_cut, form="cholesky", **args)
+    info = be.get_prior()
+    be.close()
+    o = oracle_lib.marginalize(w, eig_cut=eig_cut, **args)
+    assert gc["n"] == ge["n"] == o["n"] and gc["n_full"] == ge["n_full"] == o["n_full"] == o["n"]   # well posed: full rank either way
+    assert info["valid"] and info["form"] == "cholesky" and np.array_equal(info["J"], gc["J"]) and np.array_equal(info["r0"], gc["r0"])
+    same_information(gc, ge)
+    same_information(gc, o)
+    same_information(ge, o)
+    # the Cholesky factor is triangular in its pivot order: row k has at least k structural zeros
+    nz = (gc["J"] != 0).sum(axis=1)
+    assert np.all(np.sort(nz)[::-1] <= np.arange(gc["n"], 0, -1))
+
+
+def test_resident_prior_feeds_solve_sparsify_and_the_next_marginalize(backend_cls, oracle_lib):
+    """Nothing but index lists crosses the boundary after marginalize(readback=False): the resident path must give what the
+    host round trip gives, bit for bit (same kernels, same data)."""
+    seed, n_lmk, n_lonely = 73, 400, 10
+    w, args = small_vio_case(seed, n_lmk, n_lonely)
+    opts = capi.reference_options()
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    g = be.marginalize(0, form="eigen", **args)                      # host copy for the comparison path
+    r = be.marginalize(0, form="eigen", readback=False, **args)      # resident only
+    assert "J" not in r and r["resident"] and r["n_full"] == g["n_full"]
+    # sparsify: resident vs uploaded J
+    fr = be.sparsify(0, r, vio=True)
+    fh = be.sparsify(0, g, vio=True)
+    assert len(fr) == len(fh) == len(args["lmk_keep"]) + 1
+    for a, b in zip(fr, fh):
+        assert (a["type"], a["kf"], a["lmk0"]) == (b["type"], b["kf"], b["lmk0"]) and np.array_equal(a["sqrt_inf"], b["sqrt_inf"])
+    # next solve: resident dense prior vs uploaded
+    be.set_windows([next_window(seed, n_lmk, n_lonely, dense_prior={k: r[k] for k in ("kf_keep", "kf_col", "lmk_index", "lmk_col")})])
+    s1 = be.solve(opts)[0]; d1 = be.get_deltas(0)
+    be.set_windows([next_window(seed, n_lmk, n_lonely, dense_prior={k: g[k] for k in PRIOR_KEYS})])
+    s2 = be.solve(opts)[0]; d2 = be.get_deltas(0)
+    assert s1.iterations == s2.iterations and s1.final_cost == s2.final_cost
+    assert np.array_equal(d1["pose"], d2["pose"]) and np.array_equal(d1["lmk"], d2["lmk"])
+    # and the oracle agrees
+    o = oracle_lib.marginalize(w, **args)
+    ref = oracle_lib.solve(next_window(seed, n_lmk, n_lonely), opts, dense_prior={k: o[k] for k in PRIOR_KEYS})
+    assert s1.iterations == ref["summary"].iterations and np.isclose(s1.final_cost, ref["summary"].final_cost, rtol=1e-8)
+    assert np.abs(d1["pose"] - ref["pose"]).max() <= 1e-6
+    # the next marginalisation folds the resident prior in (last_n_full = SADVIO_PRIOR_RESIDENT): key-frame 4 goes, 3 is kept
+    w3 = make_vio_window(n_kf=6, n_lmk=n_lmk, seed=seed)
+    keep3, marg3 = pre_marginalize(w3, 4)
+    imu3 = [f for f in w3.imu_factors if f["kf_i"] == 4 and f["kf_j"] == 3][0]
+    common = dict(kf_marg=4, lmk_marg=marg3, lmk_keep=keep3, kf_keep=3, marg_has_imu=True, imu=imu3, priors=[])
+    be.set_windows([w3])
+    be.set_prior(g["J"], g["r0"])
+    last_res = {k: g[k] for k in ("kf_keep", "kf_col", "lmk_index", "lmk_col")}
+    n1 = be.marginalize(0, last=last_res, **common)
+    n2 = be.marginalize(0, last={k: g[k] for k in PRIOR_KEYS}, **common)
+    be.close()
+    assert np.array_equal(n1["J"], n2["J"]) and np.array_equal(n1["r0"], n2["r0"])
+    same_information(n1, oracle_lib.marginalize(w3, last={k: o[k] for k in PRIOR_KEYS}, **common))
+
+
+def test_resident_prior_is_cleared_by_a_refusal_and_guarded(backend_cls):
+    w, args = small_vio_case()
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    r = be.marginalize(0, readback=False, **args)
+    assert be.get_prior(readback=False)["valid"]
+    assert be.marginalize(0, 5, [], []) is None                        # n < 4: refused, and the prior is gone (…Analytic.cpp:620-625)
+    assert not be.get_prior(readback=False)["valid"]
+    with pytest.raises(capi.SadvioError, match="holds no prior"):
+        be.set_dense_prior(0, {k: r[k] for k in ("kf_keep", "kf_col", "lmk_index", "lmk_col")})
+    with pytest.raises(capi.SadvioError, match="holds no prior"):
+        be.sparsify(0, r, vio=True)
+    be.close()
+
+
+def test_sparsify_from_the_cholesky_form(backend_cls, oracle_lib):
+    """Sigma_k = Ak^-1 from the triangular inverse of G (k_tri_*) against the oracle's U Lambda^-1 U^T (sparsifyVIO,
+    marginalization.cpp:362-408): the 15 x 15 and the 3 x 3 information square roots."""
+    w, args = small_vio_case(84, 300, 8)
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    rc = be.marginalize(0, form="cholesky", readback=False, **args)
+    fc = be.sparsify(0, rc, vio=True)
+    re_ = be.marginalize(0, form="eigen", readback=False, **args)
+    fe = be.sparsify(0, re_, vio=True)
+    be.close()
+    po = oracle_lib.marginalize(w, **args)
+    fo = oracle_lib.sparsify(w, po, vio=True)
+    assert len(fc) == len(fe) == len(fo)
+    for a, b, c in zip(fc, fe, fo):
+        assert (a["type"], a["kf"], a["lmk0"]) == (c["type"], c["kf"], c["lmk0"])
+        assert np.allclose(a["delta"], c["delta"], rtol=1e-12, atol=1e-12)
+        sc = np.abs(c["sqrt_inf"]).max()
+        assert np.abs(a["sqrt_inf"] - b["sqrt_inf"]).max() <= 1e-6 * sc     # two forms of the same prior
+        assert np.abs(a["sqrt_inf"] - c["sqrt_inf"]).max() <= 1e-5 * sc     # against the oracle (as the eigen-form test holds it)
+
+
+def test_sparsify_from_a_rank_deficient_cholesky_prior_vo(backend_cls, oracle_lib):
+    """A VO prior on landmarks alone has the gauge in its null space: n_full < n, so the Cholesky form cannot be inverted
+    and sparsify orthogonalises its rows first (block Jacobi on G): same chain, same informations as from the eigen form."""
+    w = with_lonely_landmarks(synthetic.make_window(n_kf=6, n_lmk=300, seed=85), 5, 8)
+    keep, marg = pre_marginalize(w, 5)
+    keep = keep[:40]
+    args = dict(kf_marg=5, lmk_marg=marg, lmk_keep=keep, priors=[])
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    gc = be.marginalize(0, form="cholesky", **args)
+    fc = be.sparsify(0, {k: gc[k] for k in ("kf_keep", "kf_col", "lmk_index", "lmk_col")}, vio=False)
+    ge = be.marginalize(0, form="eigen", **args)
+    fe = be.sparsify(0, {k: ge[k] for k in ("kf_keep", "kf_col", "lmk_index", "lmk_col")}, vio=False)
+    be.close()
+    assert gc["n_full"] == ge["n_full"] < gc["n"]
+    same_information(gc, ge)
+    assert len(fc) == len(fe)
+    for a, b in zip(fc, fe):
+        assert (a["type"], a["lmk0"], a["lmk1"]) == (b["type"], b["lmk0"], b["lmk1"])
+        assert np.abs(a["sqrt_inf"] - b["sqrt_inf"]).max() <= 1e-6 * np.abs(b["sqrt_inf"]).max()
+
+
+@pytest.mark.parametrize("n_keep", [300])
+def test_config3_next_solve_from_cholesky_prior_equals_eigen_prior(backend_cls, n_keep):
+    """VERDICT r03 item 2's bar at config-3 size (n = 915): the next solve from the Cholesky-form prior equals the one from the
+    eigen-form prior — pose <= 1e-6, cost 1e-9, same iteration count — and both priors reproduce the ORACLE's Ak / bk
+    (tests/golden/config3_marg_ref.npz)."""
+    from golden_util import GOLDEN, _window_checksum, config3_marg_case
+    z = np.load(os.path.join(GOLDEN, "config3_marg_ref.npz"))
+    w, args = config3_marg_case(n_keep)
+    assert _window_checksum(w) == str(z[f"k{n_keep}_checksum"]), "generator drift: regenerate tests/golden/config3_marg_ref.npz"
+    opts = capi.reference_options()
+    be = backend_cls(device=0)
+    out = {}
+    for form in ("eigen", "cholesky"):
+        be.set_windows([w])
+        g = be.marginalize(0, form=form, **args)
+        assert g["n"] == g["n_full"] == 15 + 3 * n_keep
+        H = g["J"].T @ g["J"]
+        scale = np.abs(z[f"k{n_keep}_Ak_diag"]).max()
+        assert np.abs(np.diag(H) - z[f"k{n_keep}_Ak_diag"]).max() <= 1e-8 * scale
+        assert np.abs(H[::32] - z[f"k{n_keep}_Ak_rows"]).max() <= 1e-8 * scale
+        bk = z[f"k{n_keep}_bk"]
+        assert np.abs(g["J"].T @ g["r0"] + bk).max() <= 1e-6 * max(np.abs(bk).max(), np.sqrt(scale))
+        # next window: frame 11 constant and without factors of its own, the prior attached from the device
+        w2, _ = config3_marg_case(n_keep)
+        w2.pose_priors = []; w2.kf_const = np.zeros(w2.n_kf, dtype=np.uint8); w2.kf_const[11] = 1
+        w2.imu_factors = [f for f in w2.imu_factors if f["kf_i"] != 11]
+        w2.dense_prior = {k: g[k] for k in ("kf_keep", "kf_col", "lmk_index", "lmk_col")}
+        be.set_windows([w2])
+        s = be.solve(opts)[0]
+        out[form] = (s, be.get_deltas(0), g)
+    be.close()
+    (se, de, ge), (sc, dc, gc) = out["eigen"], out["cholesky"]
+    same_information(gc, ge)
+    assert se.iterations == sc.iterations and se.termination == sc.termination
+    assert abs(se.final_cost - sc.final_cost) <= 1e-9 * se.final_cost
+    assert np.abs(de["pose"] - dc["pose"]).max() <= 1e-6 and np.abs(de["lmk"] - dc["lmk"]).max() <= 1e-5
+
+
+def far_landmark_window(seed=91, n_lmk=1500):
+    """Low parallax: most landmarks 150 - 400 m away from a 0.11 m stereo rig — their depth information f b / z^2 per pixel is
+    1e-7 .. 1e-5 of the lateral one, i.e. BETWEEN the reference's absolute cut (1e-12) and the noise floor n eps lambda_max."""
+    w = with_lonely_landmarks(make_vio_window(n_kf=6, n_lmk=n_lmk, seed=seed), 5, 10)
+    rng = np.random.default_rng(seed)
+    T0 = w.kf_T_f_w[5].reshape(-1)   # world -> frame of the marginalised key-frame
+    R, t = T0[:9].reshape(3, 3), T0[9:]
+    far = rng.random(w.n_lmk) < 0.85
+    for l in np.nonzero(far)[0]:
+        pc = R @ w.lmk_p[l] + t
+        scale = rng.uniform(150.0, 400.0) / max(pc[2], 0.5)
+        w.lmk_p[l] = R.T @ (pc * scale - t)
+    # re-project the moved landmarks so that the measurements stay consistent (pixel noise kept)
+    K = w.cam_K; Ts = w.cam_T_s_f
+    for l in np.nonzero(far)[0]:
+        for o in range(w.lmk_obs_ptr[l], w.lmk_obs_ptr[l + 1]):
+            Tk = w.kf_T_f_w[w.obs_kf[o]].reshape(-1); c = w.obs_cam[o]
+            pf = Tk[:9].reshape(3, 3) @ w.lmk_p[l] + Tk[9:]
+            Tc = Ts[c].reshape(-1)
+            ps = Tc[:9].reshape(3, 3) @ pf + Tc[9:]
+            w.obs_meas[o] = [K[c][0] * ps[0] / ps[2] + K[c][2], K[c][1] * ps[1] / ps[2] + K[c][3]] + 0.3 * rng.standard_normal(2)
+    return w
+
+
+def test_reference_cut_against_noise_floor_on_a_low_parallax_window(backend_cls, oracle_lib):
+    """The two eigenvalue-cut modes on a window where they genuinely differ. Stated bounds (sadvio_ba.h):
+      |Ak_ref - Ak_floor|_2 <= 4 n eps lambda_max (what the floor drops, plus the same through Amm+), n_full_ref >= n_full_floor,
+      and the next solve from either prior: pose difference <= 1e-6, relative cost difference <= 1e-8.
+    Device and oracle are compared in BOTH modes through the information they carry."""
+    w = far_landmark_window()
+    keep, marg = pre_marginalize(w, 5)
+    assert len(keep) > 200
+    imu = [f for f in w.imu_factors if f["kf_i"] == 5 and f["kf_j"] == 4][0]
+    args = dict(kf_marg=5, lmk_marg=marg, lmk_keep=keep, kf_keep=4, marg_has_imu=True, imu=imu, priors=w.pose_priors)
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    got = {(cut, form): be.marginalize(0, eig_cut=cut, form=form, **args) for cut in ("reference", "noise_floor") for form in ("eigen", "cholesky")}
+    ora = {cut: oracle_lib.marginalize(w, eig_cut=cut, **args) for cut in ("reference", "noise_floor")}
+    n = ora["reference"]["n"]
+    lam = np.linalg.eigvalsh(0.5 * (ora["reference"]["Ak"] + ora["reference"]["Ak"].T))
+    floor = n * np.finfo(float).eps * lam.max()
+    between = int(((lam > 1e-12) & (lam <= floor)).sum())
+    assert between > 0, "the window must hold information between the two cuts for this test to mean anything"
+    for cut in ("reference", "noise_floor"):
+        for form in ("eigen", "cholesky"):
+            same_information(got[(cut, form)], ora[cut], rtol=1e-7)
+    assert ora["reference"]["n_full"] >= ora["noise_floor"]["n_full"] and got[("reference", "eigen")]["n_full"] >= got[("noise_floor", "eigen")]["n_full"]
+    assert got[("noise_floor", "eigen")]["n_full"] == ora["noise_floor"]["n_full"]          # the floor's rank is reproducible
+    Hr, _, _ = invariants(got[("reference", "eigen")]); Hf, _, _ = invariants(got[("noise_floor", "eigen")])
+    diff = np.linalg.norm(Hr - Hf, 2)
+    assert diff <= 4.0 * floor, (diff, floor)
+    # next solve from the two priors
+    opts = capi.reference_options()
+    sols = {}
+    for cut in ("reference", "noise_floor"):
+        w2 = far_landmark_window()
+        w2.pose_priors = []; w2.kf_const = np.zeros(w2.n_kf, dtype=np.uint8); w2.kf_const[5] = 1
+        w2.imu_factors = [f for f in w2.imu_factors if f["kf_i"] != 5]
+        w2.dense_prior = {k: got[(cut, "eigen")][k] for k in PRIOR_KEYS}
+        be.set_windows([w2])
+        s = be.solve(opts)[0]
+        sols[cut] = (s, be.get_deltas(0))
+    be.close()
+    (sr, dr), (sf, df) = sols["reference"], sols["noise_floor"]
+    assert sr.iterations == sf.iterations
+    assert abs(sr.final_cost - sf.final_cost) <= 1e-8 * sr.final_cost
+    assert np.abs(dr["pose"] - df["pose"]).max() <= 1e-6
+
+
+def test_marginalize_and_sparsify_refused_on_a_sharded_window(backend_cls):
+    w, args = small_vio_case()
+    be = backend_cls(device=0)
+    be.set_collective(0, 2, lambda *a: 0)
+    be.set_windows([w])
+    with pytest.raises(capi.SadvioError, match="sharded"):
+        be.marginalize(0, **args)
+    with pytest.raises(capi.SadvioError, match="sharded"):
+        be.sparsify(0, {"J": np.eye(4), "r0": np.zeros(4), "lmk_index": [], "lmk_col": []}, vio=False)
+    be.close()

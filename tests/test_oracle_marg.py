@@ -52,11 +52,12 @@ def pre_marginalize(w, kf0):
     return keep, marg
 
 
-def run_marg(oracle_lib, w, kf_marg, keep, marg, kf_keep=-1):
+def run_marg(oracle_lib, w, kf_marg, keep, marg, kf_keep=-1, eig_cut="noise_floor"):
     wc, _keep = oracle_lib.S.window_to_c(w)
     rq = oracle_lib.MargRequest()
     rq.win = C.pointer(wc)
     rq.kf_marg, rq.kf_keep, rq.marg_has_imu = kf_marg, kf_keep, 0
+    rq.eig_cut_mode = oracle_lib.EIG_CUT[eig_cut]
     mk = np.array(marg, dtype=np.int32); kp = np.array(keep, dtype=np.int32)
     rq.n_marg, rq.lmk_marg = len(marg), mk.ctypes.data_as(_ip)
     rq.n_keep, rq.lmk_keep = len(keep), kp.ctypes.data_as(_ip)

@@ -26,6 +26,7 @@ PAIRS = {
     "sadvio_viinit_result": (P.ViInitResultC, O.viinit_result),
     "sadvio_marg_request": (P.MargRequestC, None),
     "sadvio_marg_result": (P.MargResultC, None),
+    "sadvio_prior_info": (P.PriorInfoC, None),
     "sadvio_ba_config": (P.Config, None),
 }
 RENAME = {"lambda": "lambda_"}
