@@ -293,8 +293,9 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle *h, int32_t w, int32_t n_full, in
  *       KEPT, as the reference keeps them.
  *   SADVIO_EIG_CUT_NOISE_FLOOR (1): keep lambda > max(1e-12, n eps lambda_max) — the numerically meaningful rank; n_full
  *       is reproducible across implementations, at the price of dropping directions whose information is below the floor
- *       (|Ak_ref - Ak_floor|_2 <= n eps lambda_max by construction; tests/test_gpu_marg.py bounds the effect on the next
- *       solve on a low-parallax window).
+ *       (what it drops from Ak itself is <= n eps lambda_max by construction; a direction v dropped from Amm^+ leaves
+ *       (Arm v)(Arm v)^T / lambda in Ak. tests/test_gpu_margloop.py measures both modes on a low-parallax window — 300
+ *       directions between the cuts: |Ak_ref - Ak_floor|_2 = 2e-10 lambda_max — and bounds the effect on the next solve).
  * Form of the prior handed back / kept on the device (both give the same MarginalizationFactor cost, gradient and
  * Gauss-Newton matrix: r0 + J dx enters the solve only through J^T J, J^T r0 and |r0|^2):
  *   SADVIO_PRIOR_FORM_EIGEN    (0): the reference's J = Lambda^1/2 U^T, r0 = -Lambda^-1/2 U^T bk, rows in ascending

@@ -353,7 +353,7 @@ class HipOptimizer {
         if (F.non_pinhole_pixel) { _err = "pixel factor with a non-pinhole camera: use the angular backend"; return false; }
         double Ak[144];
         int rc = upload(F, false);
-        if (rc == SADVIO_OK) rc = sadvio_ba_marginalize_relative(_h, 0, frame0, frame1, _eig_cut_mode, inf36, Ak);
+        if (rc == SADVIO_OK) rc = sadvio_ba_marginalize_relative(_h, 0, frame0, frame1, _rel_eig_cut_mode, inf36, Ak);
         if (rc != SADVIO_OK) { _err = sadvio_ba_last_error(_h); for (int i = 0; i < 36; i++) inf36[i] = 0.0; return false; }
         if (Ak144) std::memcpy(Ak144, Ak, sizeof(Ak));
         return true;
@@ -378,6 +378,11 @@ class HipOptimizer {
     // same MarginalizationFactor cost / gradient / Gauss-Newton matrix as the reference's Lambda^1/2 U^T, 5 x faster to form;
     // SADVIO_PRIOR_FORM_EIGEN reproduces the reference's rows).
     void set_eig_cut_mode(int mode) { _eig_cut_mode = mode; }
+    // marginalizeRelative keeps the noise floor by default: Ak of two poses has an EXACT 6-dimensional gauge null space whose
+    // eigenvalues compute to +-1e-7 .. 1e-6; the reference's absolute 1e-12 inverts the positive ones (1 / lambda ~ 1e6) and the
+    // recovered 6 x 6 'information' is then rounding noise (measured through this layer: trace 6.9e6, min diagonal -4.9e5) —
+    // the reference's own function has no caller. SADVIO_EIG_CUT_REFERENCE reproduces it on request.
+    void set_relative_eig_cut_mode(int mode) { _rel_eig_cut_mode = mode; }
     void set_prior_form(int form) { _prior_form = form; }
     const std::vector<int64_t>& prior_landmark_ids() const { return _prior.lmk_id; }
     const std::vector<int32_t>& prior_landmark_cols() const { return _prior.lmk_col; }
@@ -640,7 +645,7 @@ class HipOptimizer {
 
     std::string _dump_dir;
     int _dump_count = 0;
-    int _eig_cut_mode = SADVIO_EIG_CUT_REFERENCE, _prior_form = SADVIO_PRIOR_FORM_CHOLESKY;
+    int _eig_cut_mode = SADVIO_EIG_CUT_REFERENCE, _rel_eig_cut_mode = SADVIO_EIG_CUT_NOISE_FLOOR, _prior_form = SADVIO_PRIOR_FORM_CHOLESKY;
     sadvio_ba_handle* _h = nullptr;
     sadvio_solve_summary _sum{};
     std::string _err;

