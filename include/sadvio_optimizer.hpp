@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -387,6 +388,8 @@ class HipOptimizer {
     const std::vector<int64_t>& prior_landmark_ids() const { return _prior.lmk_id; }
     const std::vector<int32_t>& prior_landmark_cols() const { return _prior.lmk_col; }
     size_t sparse_factor_count() const { return _sparse.size(); }
+    // features the last flattened window left out because their camera index was outside the frame's sensor list (also warned on stderr)
+    int skipped_bad_camera_features() const { return _skipped_bad_camera; }
 
     const sadvio_solve_summary& summary() const { return _sum; }
     const std::string& last_error() const { return _err; }
@@ -517,6 +520,10 @@ class HipOptimizer {
     // with_pose_priors: PosePriordx blocks are only added by addResidualsLocalMap (…Analytic.cpp:224-228) and marginalize
     // (:605-617); addSingleFrameResiduals / addLandmarkResiduals (:5-50, 102-150) add none
     int upload(const Flat& F, bool with_pose_priors = true) {
+        // a feature whose camera index is not one of its frame's sensors cannot be evaluated: it is skipped (the reference would
+        // throw from .at()), and the count is REPORTED — a corrupted map must not solve silently with fewer observations
+        _skipped_bad_camera = F.n_bad_camera;
+        if (F.n_bad_camera) std::fprintf(stderr, "[sadvio] warning: %d feature(s) skipped: camera index outside the frame's sensor list\n", F.n_bad_camera);
         int rc = sadvio_ba_set_windows(_h, 1, &F.w);
         if (rc == SADVIO_OK && with_pose_priors) rc = sadvio_ba_set_pose_priors(_h, 0, (int)F.priors.size(), F.priors.data());
         if (rc == SADVIO_OK && !F.imus.empty()) rc = sadvio_ba_set_imu_factors(_h, 0, (int)F.imus.size(), F.imus.data());
@@ -645,6 +652,7 @@ class HipOptimizer {
 
     std::string _dump_dir;
     int _dump_count = 0;
+    int _skipped_bad_camera = 0;
     int _eig_cut_mode = SADVIO_EIG_CUT_REFERENCE, _rel_eig_cut_mode = SADVIO_EIG_CUT_NOISE_FLOOR, _prior_form = SADVIO_PRIOR_FORM_CHOLESKY;
     sadvio_ba_handle* _h = nullptr;
     sadvio_solve_summary _sum{};

@@ -602,7 +602,9 @@ static int compute_step(ctx_t *c, const sadvio_solve_options *o, double radius, 
     {
     double *St = T > 1 ? priv + (size_t)par_tid() * nS : S;
     double *rhst = T > 1 ? St + (size_t)Nr * Nr : rhs;
-#pragma omp for schedule(static)
+    /* `fail` is a reduction: each thread skips its remaining landmarks once ITS copy is set (the serial semantics at one
+     * thread), the copies are OR-ed at the end of the loop — no unsynchronised write / read of a shared flag */
+#pragma omp for schedule(static) reduction(| : fail)
     for (int l = 0; l < w->n_lmk; l++) {
         if (!c->lmk_elim[l] || fail) continue;
         double M[9];
@@ -657,7 +659,7 @@ static int compute_step(ctx_t *c, const sadvio_solve_options *o, double radius, 
             dred[i] = -rhs[i];
             if (!isfinite(dred[i])) fail = 1;
         }
-#pragma omp parallel for schedule(static) if (c->P->n_threads > 1) num_threads(c->P->n_threads > 1 ? c->P->n_threads : 1)
+#pragma omp parallel for schedule(static) reduction(| : fail) if (c->P->n_threads > 1) num_threads(c->P->n_threads > 1 ? c->P->n_threads : 1)
         for (int l = 0; l < w->n_lmk; l++) {
             dlmk[3 * l] = dlmk[3 * l + 1] = dlmk[3 * l + 2] = 0;
             if (!c->lmk_elim[l]) continue;

@@ -2730,7 +2730,11 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         unsigned char* kp = key.data();
         memcpy(kp + sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t), lay.data(), lay.size() * sizeof(int));
         memcpy(kp, &P, sizeof(DevPtrs)); kp += sizeof(DevPtrs);
-        const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type + 2 * (int)extras + 4 * (int)rare + 8 * (int)use_lm};  // P (incl. decide_kernel) is part of the key
+        // launch-shape switches read from the environment inside enqueue() are part of the key too: a handle that already captured a
+        // graph must not replay it when an A/B switch changes
+        const int env_bits = (int)with_imu + 2 * (getenv("SADVIO_NO_FORK") != nullptr) + 4 * (getenv("SADVIO_WD_NOLA") != nullptr) + 8 * (getenv("SADVIO_WD_BACK1") != nullptr) +
+                             16 * (getenv("SADVIO_WD_OLD") != nullptr) + 32 * (getenv("SADVIO_NO_BCR") != nullptr) + 64 * (getenv("SADVIO_NO_PAR") != nullptr) + 128 * (getenv("SADVIO_NO_LPT") != nullptr);
+        const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type + 2 * (int)extras + 4 * (int)rare + 8 * (int)use_lm + 16 * env_bits};  // P (incl. decide_kernel) is part of the key
         memcpy(kp, ints, sizeof(ints)); kp += sizeof(ints);
         const size_t szs[3] = {lds_build, lds_back, lds_solve};
         memcpy(kp, szs, sizeof(szs));

@@ -23,6 +23,11 @@ from sadvio_amd import capi
 
 pytestmark = pytest.mark.gpu
 POSE_TOL, LMK_TOL, COST_RTOL = 1e-6, 1e-5, 1e-8
+# caps of the rounding-sensitivity allowance (only consulted after the fixed bars fail, and only while the 1-ulp-nudged oracle
+# still takes the same LM path): the three windows of ~30 000 swept that need it measure 1.7e-5 / 2.9e-8 at worst (seeds
+# 234496164, 319802335, 261931991) — anything beyond these caps fails and has to be arbitrated explicitly.
+ALLOW_POSE, ALLOW_COST, ALLOW_LMK = 1e-4, 1e-6, 1e-3
+ALLOWANCE_LOG = []   # every use of the allowance in this session (printed, and summarised by test_zz_allowance_report)
 
 # the windows randomised sweeps disagreed on live in tests/golden/fuzz_pinned.json (specs = generator parameters only):
 # runaway landmarks; dense priors whose rejected steps exposed an oracle bug (fixed since)
@@ -49,14 +54,23 @@ def check_case(case, oracle_lib):
                 dl = float((np.abs(d["lmk"] - ref["lmk"]).max(axis=1) / scale).max())
             if dp > POSE_TOL or dc > COST_RTOL or dl > LMK_TOL:
                 # the fixed bars failed: is the WINDOW that sensitive? (i) the oracle against itself under a 1-ulp nudge of the
-                # measurements, (ii) for the poses alone, the damping-held directions of the reduced system
-                sp, sc, sl, _ = conditioning.oracle_self_sensitivity(lambda s_=case["specs"][k]: fz.build_window(s_), opts, oracle_lib, ref)
+                # measurements, (ii) for the poses alone, the damping-held directions of the reduced system. The allowance is
+                # CAPPED: it only exists while the nudged oracle itself still takes the same LM path (`same`), and it
+                # never exceeds ALLOW_* — a window beyond that has to be pinned and arbitrated against the long-double twin.
+                sp, sc, sl, same = conditioning.oracle_self_sensitivity(lambda s_=case["specs"][k]: fz.build_window(s_), opts, oracle_lib, ref)
+                a_pose = min(conditioning.SELF_K * sp, ALLOW_POSE) if same else 0.0
+                a_cost = min(conditioning.SELF_K * sc, ALLOW_COST) if same else 0.0
+                a_lmk = min(conditioning.SELF_K * sl, ALLOW_LMK) if same else 0.0
                 cond_ok, report = (False, "")
-                if dp > max(POSE_TOL, conditioning.SELF_K * sp):
+                if dp > max(POSE_TOL, a_pose):
                     cond_ok, report = conditioning.pose_difference_within_conditioning(w, oracle_lib, ref, d["pose"], ref["pose"], POSE_TOL)
-                assert dp <= max(POSE_TOL, conditioning.SELF_K * sp) or cond_ok, (what, dp, sp, report)
-                assert dc <= max(COST_RTOL, conditioning.SELF_K * sc), (what, dc, sc)
-                assert dl <= max(LMK_TOL, conditioning.SELF_K * sl), (what, dl, sl)
+                    cond_ok = cond_ok and dc <= 1e-8   # conditioning.py: the failing window must also agree on the cost to 1e-8
+                ALLOWANCE_LOG.append({"window": what, "dpose": dp, "dcost": dc, "dlmk": dl, "oracle_self": [sp, sc, sl], "same_path": bool(same),
+                                      "by": "eigen-direction bound" if cond_ok else "oracle self-sensitivity"})
+                print(f"[fuzz] conditioning allowance used: {ALLOWANCE_LOG[-1]}")
+                assert dp <= max(POSE_TOL, a_pose) or cond_ok, (what, dp, sp, same, report)
+                assert dc <= max(COST_RTOL, a_cost), (what, dc, sc, same)
+                assert dl <= max(LMK_TOL, a_lmk), (what, dl, sl, same)
             if w.has_imu:
                 for key in ("dv", "dba", "dbg"):
                     assert np.abs(d[key] - ref[key]).max() <= POSE_TOL, (what, key)
@@ -142,3 +156,13 @@ def test_pose_seed_against_long_double_twin(oracle_lib):
         for a in (d["pose"], ref["pose"]):
             ok, report = conditioning.pose_difference_within_conditioning(w, oracle_lib, ref, a, z["pose"], POSE_TOL)
             assert ok, report
+
+
+def test_zz_allowance_report():
+    """Keeps the list of windows that needed the conditioning allowance visible: runs last in this module, prints them,
+    and fails if their number grows beyond the handful that were arbitrated (a kernel regression would show up here first)."""
+    for e in ALLOWANCE_LOG:
+        print("[fuzz allowance]", e)
+    print(f"[fuzz allowance] {len(ALLOWANCE_LOG)} comparisons used the conditioning allowance")
+    distinct = {e["window"] for e in ALLOWANCE_LOG}
+    assert len(distinct) <= 6, sorted(distinct)
