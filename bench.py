@@ -155,6 +155,29 @@ def main():
         be.get_deltas(0)
     dt_up = (time.perf_counter() - t0) / n_up
     be.close()
+    # the same with two handles driven from two host threads (the reference runs a front-end and a back-end optimizer instance
+    # concurrently, slamParameters.cpp:273-275; a handle owns its stream and window state, so the two act as a double buffer):
+    # one handle's host-side layout build runs under the other's solve
+    dt_up2 = None
+    if world == 1:
+        import threading
+        bes = [capi.Backend(device=local_rank, use_graph=True) for _ in range(2)]
+        preps = [b.prepare(wins) for b in bes]
+
+        def loop(b, pr, n):
+            for _ in range(n):
+                b.set_prepared(pr); b.solve(opts); b.get_deltas(0)
+        for b, pr in zip(bes, preps):
+            loop(b, pr, 3)
+        ths = [threading.Thread(target=loop, args=(b, pr, n_up)) for b, pr in zip(bes, preps)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt_up2 = (time.perf_counter() - t0) / (2 * n_up)
+        for b in bes:
+            b.close()
     iters_per_solve = sum(s.iterations for s in sums)
     total_iters = iters_per_solve * args.steps * sps * world
     value = total_iters / dt
@@ -265,7 +288,10 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "batched": batched,
             "upload_inclusive": {"value": round(iters_per_solve / dt_up, 1), "unit": "BA iterations/s",
                                  "ms_per_solve": round(1e3 * dt_up, 4),
-                                 "what": "set_windows (host flatten -> HBM) + solve + get_deltas per solve, rank 0"},
+                                 "what": "set_windows (host flatten -> HBM) + solve + get_deltas per solve, rank 0",
+                                 "two_handles": (None if dt_up2 is None else
+                                                 {"value": round(iters_per_solve / dt_up2, 1), "ms_per_solve": round(1e3 * dt_up2, 4),
+                                                  "what": "two handles on two host threads, each set_windows + solve + get_deltas in turn: one handle's layout build runs under the other's solve"})},
             "marginalize": marg, "backend_step": bstep, "vio_window": vio, "sharded_window": sharded, "sharded_window_c5": sharded5,
         }
         if cpu:

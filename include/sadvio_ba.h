@@ -246,6 +246,14 @@ void sadvio_ba_destroy(sadvio_ba_handle *h);
  * concurrently; n_windows = 1 is the reference's case). Replaces addResidualsLocalMap
  * (…Analytic.cpp:197-314). Clears any factors set by earlier set_* calls. */
 int sadvio_ba_set_windows(sadvio_ba_handle *h, int32_t n_windows, const sadvio_flat_window *windows);
+/* One layout build per key-frame: between begin_update and commit_update, set_windows and the factor setters that follow it
+ * (set_pose_priors, set_imu_factors, set_sparse_priors, set_dense_prior, set_lines) only RECORD their arguments (validated and
+ * copied as usual); commit_update builds the device layout once and uploads everything in one staged copy. Without the
+ * bracket every setter rebuilds what it changes — set_sparse_priors the whole tiling, because eliminable pose-to-landmark
+ * factors become pseudo-observations of their landmarks — which is what addResidualsLocalMap + addMarginalizationResiduals
+ * (…Analytic.cpp:197-426) amount to when they are called back to back. Compute calls are refused inside the bracket. */
+int sadvio_ba_begin_update(sadvio_ba_handle *h);
+int sadvio_ba_commit_update(sadvio_ba_handle *h);
 /* The single-window call the adapter of one optimizer instance uses: set_windows(h, 1, window). */
 int sadvio_ba_set_window(sadvio_ba_handle *h, const sadvio_flat_window *window);
 

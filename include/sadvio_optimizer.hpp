@@ -519,15 +519,19 @@ class HipOptimizer {
 
     // with_pose_priors: PosePriordx blocks are only added by addResidualsLocalMap (…Analytic.cpp:224-228) and marginalize
     // (:605-617); addSingleFrameResiduals / addLandmarkResiduals (:5-50, 102-150) add none
-    int upload(const Flat& F, bool with_pose_priors = true) {
+    int upload(const Flat& F, bool with_pose_priors = true, const Flat* prior_of = nullptr) {
         // a feature whose camera index is not one of its frame's sensors cannot be evaluated: it is skipped (the reference would
         // throw from .at()), and the count is REPORTED — a corrupted map must not solve silently with fewer observations
         _skipped_bad_camera = F.n_bad_camera;
         if (F.n_bad_camera) std::fprintf(stderr, "[sadvio] warning: %d feature(s) skipped: camera index outside the frame's sensor list\n", F.n_bad_camera);
-        int rc = sadvio_ba_set_windows(_h, 1, &F.w);
+        // one layout build for the window and all its factor lists (sadvio_ba_begin_update .. commit_update)
+        int rc = sadvio_ba_begin_update(_h);
+        if (rc == SADVIO_OK) rc = sadvio_ba_set_windows(_h, 1, &F.w);
         if (rc == SADVIO_OK && with_pose_priors) rc = sadvio_ba_set_pose_priors(_h, 0, (int)F.priors.size(), F.priors.data());
         if (rc == SADVIO_OK && !F.imus.empty()) rc = sadvio_ba_set_imu_factors(_h, 0, (int)F.imus.size(), F.imus.data());
-        return rc;
+        if (rc == SADVIO_OK && prior_of) rc = add_marginalization_prior(*prior_of);
+        const int rc2 = sadvio_ba_commit_update(_h);
+        return rc != SADVIO_OK ? rc : rc2;
     }
 
     // addMarginalizationResiduals (…Analytic.cpp:316-426): the stored prior on the variables still in the window
@@ -600,8 +604,7 @@ class HipOptimizer {
             return false;
         }
         const bool window_solve = !all_const && !lmk_const;
-        int rc = upload(F, window_solve);
-        if (rc == SADVIO_OK && window_solve) rc = add_marginalization_prior(F);
+        int rc = upload(F, window_solve, window_solve ? &F : nullptr);   // the stored prior rides the same layout build
         const bool with_lines = window_solve && F.lines.n_line > 0;      // the line blocks are only built by addResidualsLocalMap
         if (rc == SADVIO_OK && with_lines) rc = sadvio_ba_set_lines(_h, 0, &F.lines);
         if (rc == SADVIO_OK) rc = sadvio_ba_solve(_h, &opt, &_sum);

@@ -440,9 +440,24 @@ class Backend:
             prep["per"].append(item)
         return prep
 
-    def set_prepared(self, prep):
+    def set_prepared(self, prep, one_build: bool = True):
+        """set_windows + the factor setters of every window; one_build brackets them with begin_update / commit_update (ONE
+        layout build and staged upload instead of one per setter)."""
         windows = prep["windows"]
         self.windows = windows
+        if one_build:
+            self._check(self.lib.sadvio_ba_begin_update(self.h), "begin_update")
+            try:
+                self._set_prepared(prep)
+            except Exception:
+                self.lib.sadvio_ba_commit_update(self.h)   # leave the bracket; the error of the setter is the one reported
+                raise
+            self._check(self.lib.sadvio_ba_commit_update(self.h), "commit_update")
+        else:
+            self._set_prepared(prep)
+
+    def _set_prepared(self, prep):
+        windows = prep["windows"]
         self._check(self.lib.sadvio_ba_set_windows(self.h, len(windows), prep["arr"]), "set_windows")
         for i, w in enumerate(windows):
             item = prep["per"][i]
@@ -457,8 +472,8 @@ class Backend:
             if w.lines is not None:
                 self.set_lines(i, w.lines)
 
-    def set_windows(self, windows: Sequence[FlatWindow]):
-        self.set_prepared(self.prepare(windows))
+    def set_windows(self, windows: Sequence[FlatWindow], one_build: bool = True):
+        self.set_prepared(self.prepare(windows), one_build=one_build)
 
     def set_lines(self, w: int, lines: Optional[dict]):
         """linexd landmarks of window w (sadvio_ba_set_lines); None clears them."""

@@ -247,6 +247,7 @@ struct sadvio_ba_handle {
     DevBuf<double> d_bcr;       // block-cyclic-reduction workspace of the long banded systems
     DevBuf<double> d_big_mid;   // the two Schur complements on the middle block of the twisted banded factorisation
     bool uploaded = false, solved = false;
+    bool defer = false, pending = false;   // begin_update .. commit_update: set_* calls only record, ONE layout build + staged upload at commit
     UploadBatch up;   // pending host -> device uploads of the current layout build
     // window sharded over several GPUs: collective hook (user callback or the built-in RCCL one)
     int world = 1, rank = 0;
@@ -1261,6 +1262,39 @@ int sadvio_ba_set_windows(sadvio_ba_handle* h, int32_t n_windows, const sadvio_f
     h->dprior_per_win.assign(n_windows, {});
     h->sparse_per_win.assign(n_windows, {});
     h->lines_per_win.assign(n_windows, {});
+    if (h->defer) {
+        // the factor setters that follow validate against the windows' sizes and convert indices with their offsets in the batch:
+        // the same numbers build_layout derives at commit
+        h->wins.assign(n_windows, HostWin());
+        int kf_b = 0, lmk_b = 0, obs_b = 0;
+        for (int w = 0; w < n_windows; w++) {
+            const sadvio_flat_window& F = wins[w];
+            WinDev& d = h->wins[w].d;
+            memset(&d, 0, sizeof(d));
+            d.n_kf = F.n_kf; d.n_cam = F.n_cam; d.n_lmk = F.n_lmk; d.n_obs = F.n_obs;
+            d.kf_base = kf_b; d.lmk_base = lmk_b; d.obs_base = obs_b;
+            d.factor_type = F.factor_type; d.has_imu = F.has_imu; d.dpf = F.has_imu ? 15 : 6;
+            kf_b += F.n_kf; lmk_b += F.n_lmk; obs_b += F.n_obs;
+        }
+        h->uploaded = true; h->pending = true;
+        return SADVIO_OK;
+    }
+    return build_layout(h);
+}
+
+int sadvio_ba_begin_update(sadvio_ba_handle* h) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    h->defer = true; h->pending = false;
+    return SADVIO_OK;
+}
+
+int sadvio_ba_commit_update(sadvio_ba_handle* h) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (!h->defer) { h->err = "commit_update without begin_update"; return SADVIO_E_STATE; }
+    h->defer = false;
+    if (!h->pending) return SADVIO_OK;
+    h->pending = false;
+    HIP_TRY(hipSetDevice(h->device));
     return build_layout(h);
 }
 
@@ -1296,9 +1330,10 @@ int sadvio_ba_set_lines(sadvio_ba_handle* h, int32_t w, const sadvio_line_set* L
     }
     h->lines_per_win[w] = std::move(H);
     h->solved = false;
+    if (h->defer) return SADVIO_OK;
     int rc = layout_reduced(h);   // the lines enlarge the reduced system; the landmark tiles are unchanged
     if (rc != SADVIO_OK) return rc;
-    return upload_priors(h);
+    return h->defer ? SADVIO_OK : upload_priors(h);
 }
 
 int sadvio_ba_get_line_deltas(sadvio_ba_handle* h, int32_t w, double* line_delta6) {
@@ -1327,7 +1362,7 @@ int sadvio_ba_set_pose_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const s
         memcpy(d.inf, pr[i].inf_diag, sizeof(d.inf));
         v.push_back(d);
     }
-    return upload_priors(h);
+    return h->defer ? SADVIO_OK : upload_priors(h);
 }
 
 // 9x9 square-root information W = L^T with L L^T = cov^-1 (residuals.hpp:151-154): Gauss-Jordan inverse with
@@ -1397,7 +1432,7 @@ int sadvio_ba_set_imu_factors(sadvio_ba_handle* h, int32_t w, int32_t n, const s
         o.sg = 1.0 / sqrt(f.dt * f.bgyr_noise * f.bgyr_noise);
         v.push_back(o);
     }
-    return upload_priors(h);
+    return h->defer ? SADVIO_OK : upload_priors(h);
 }
 
 int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t w, int32_t n_full, int32_t n, const double* J, const double* r0,
@@ -1435,10 +1470,11 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t w, int32_t n_full, in
         D.lmk_index.assign(lmk_index, lmk_index + n_keep); D.lmk_col.assign(lmk_col, lmk_col + n_keep);
     }
     h->dprior_per_win[w] = std::move(D);
+    if (h->defer) return SADVIO_OK;
     if (!h->sparse_per_win[w].empty()) return build_layout(h);  // which sparse factors are eliminable may change
     int rc = layout_reduced(h);
     if (rc != SADVIO_OK) return rc;
-    return upload_priors(h);
+    return h->defer ? SADVIO_OK : upload_priors(h);
 }
 
 int sadvio_ba_set_sparse_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const sadvio_sparse_prior* f) {
@@ -1472,6 +1508,7 @@ int sadvio_ba_set_sparse_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const
         }
     }
     h->sparse_per_win[w].assign(f, f + n);
+    if (h->defer) return SADVIO_OK;
     return build_layout(h);  // eliminable pose-to-landmark factors become pseudo-observations: the tiles change
 }
 
@@ -1642,6 +1679,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
                           double* J_out, double* r0_out) {
     if (!h) return SADVIO_E_INVALID_ARG;
     if (!h->uploaded) { h->err = "marginalize before set_windows"; return SADVIO_E_STATE; }
+    if (h->defer) { h->err = "marginalize between begin_update and commit_update"; return SADVIO_E_STATE; }
     if (!rq || w < 0 || w >= (int)h->wins.size()) { h->err = "marginalize: bad argument"; return SADVIO_E_INVALID_ARG; }
     if (h->world > 1) { h->err = "marginalize: the window is sharded over several GPUs (each rank holds a landmark partition only)"; return SADVIO_E_INVALID_ARG; }
     const WinDev& d = h->wins[w].d;
@@ -1947,6 +1985,7 @@ bool nfr_sqrt_info(const double* S, int rows, bool invert_first, double* W) {
 int sadvio_ba_marginalize_relative(sadvio_ba_handle* h, int32_t w, int32_t kf_a, int32_t kf_b, int32_t eig_cut_mode, double* inf36, double* Ak144) {
     if (!h || !inf36) return SADVIO_E_INVALID_ARG;
     if (!h->uploaded) { h->err = "marginalize_relative before set_windows"; return SADVIO_E_STATE; }
+    if (h->defer) { h->err = "marginalize_relative between begin_update and commit_update"; return SADVIO_E_STATE; }
     if (w < 0 || w >= (int)h->wins.size()) { h->err = "marginalize_relative: window out of range"; return SADVIO_E_INVALID_ARG; }
     if (eig_cut_mode != SADVIO_EIG_CUT_REFERENCE && eig_cut_mode != SADVIO_EIG_CUT_NOISE_FLOOR) { h->err = "marginalize_relative: bad eig_cut_mode"; return SADVIO_E_INVALID_ARG; }
     if (h->world > 1) { h->err = "marginalize_relative: the window is sharded over several GPUs (each rank holds a landmark partition only)"; return SADVIO_E_INVALID_ARG; }
@@ -2075,6 +2114,7 @@ int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, 
     if (!h) return SADVIO_E_INVALID_ARG;
     if (n_out) *n_out = 0;
     if (!h->uploaded) { h->err = "sparsify before set_windows"; return SADVIO_E_STATE; }
+    if (h->defer) { h->err = "sparsify between begin_update and commit_update"; return SADVIO_E_STATE; }
     if (w < 0 || w >= (int)h->wins.size() || !n_out || !out || n_keep < 0 || (n_keep > 0 && (!lmk_index || !lmk_col))) { h->err = "sparsify: bad argument"; return SADVIO_E_INVALID_ARG; }
     if (h->world > 1) { h->err = "sparsify: the window is sharded over several GPUs (linearisation values of a landmark partition only)"; return SADVIO_E_INVALID_ARG; }
     PriorState& PR = h->prior;
@@ -2317,6 +2357,7 @@ int sadvio_ba_comm_info(sadvio_ba_handle* h, int32_t* nranks, int32_t* rank, int
 int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvio_solve_summary* summaries) {
     if (!h) return SADVIO_E_INVALID_ARG;
     if (!h->uploaded) { h->err = "solve before set_windows"; return SADVIO_E_STATE; }
+    if (h->defer) { h->err = "solve between begin_update and commit_update"; return SADVIO_E_STATE; }
     sadvio_solve_options defo;
     if (!opts) { sadvio_ba_default_options(&defo); opts = &defo; }
     if (opts->max_num_iterations < 0 || opts->max_num_iterations > 1000) { h->err = "solve: max_num_iterations out of range"; return SADVIO_E_INVALID_ARG; }
@@ -2861,6 +2902,7 @@ int sadvio_ba_linearize(sadvio_ba_handle* h, int32_t w, const double* pose_delta
                         double* Jp12, double* Jl6) {
     if (!h) return SADVIO_E_INVALID_ARG;
     if (!h->uploaded) { h->err = "linearize before set_windows"; return SADVIO_E_STATE; }
+    if (h->defer) { h->err = "linearize between begin_update and commit_update"; return SADVIO_E_STATE; }
     if (w < 0 || w >= (int)h->wins.size()) { h->err = "linearize: window out of range"; return SADVIO_E_INVALID_ARG; }
     HIP_TRY(hipSetDevice(h->device));
     const WinDev& d = h->wins[w].d;
@@ -2975,6 +3017,7 @@ int sadvio_ba_landmark_chi2(sadvio_ba_handle* h, int32_t w, const double* pose_d
                             double pixel_sigma, double* avg_chi2, int32_t* inlier) {
     if (!h) return SADVIO_E_INVALID_ARG;
     if (!h->uploaded) { h->err = "landmark_chi2 before set_windows"; return SADVIO_E_STATE; }
+    if (h->defer) { h->err = "landmark_chi2 between begin_update and commit_update"; return SADVIO_E_STATE; }
     if (w < 0 || w >= (int)h->wins.size()) { h->err = "landmark_chi2: window out of range"; return SADVIO_E_INVALID_ARG; }
     HIP_TRY(hipSetDevice(h->device));
     const WinDev& d = h->wins[w].d;
