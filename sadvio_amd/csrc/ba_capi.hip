@@ -1314,7 +1314,7 @@ int sadvio_ba_set_lines(sadvio_ba_handle* h, int32_t w, const sadvio_line_set* L
         if (L->line_obs_ptr[0] != 0 || L->line_obs_ptr[n] != L->n_obs) { h->err = "set_lines: line_obs_ptr is not a CSR over n_obs"; return SADVIO_E_INVALID_ARG; }
         for (int l = 0; l < n; l++) if (L->line_obs_ptr[l + 1] < L->line_obs_ptr[l]) { h->err = "set_lines: CSR not monotone"; return SADVIO_E_INVALID_ARG; }
         for (int o = 0; o < L->n_obs; o++)
-            if (L->obs_kf[o] < 0 || L->obs_kf[o] >= d.n_kf || L->obs_cam[o] < 0 || L->obs_cam[o] >= (int)h->src[w].cam_map.size()) {
+            if (L->obs_kf[o] < 0 || L->obs_kf[o] >= d.n_kf || L->obs_cam[o] < 0 || L->obs_cam[o] >= h->src[w].v.n_cam) {   // the caller's camera count (cam_map, built with the layout, has as many entries)
                 h->err = "set_lines: observation index out of range"; return SADVIO_E_INVALID_ARG;
             }
         const int ms = d.factor_type == SADVIO_FACTOR_PIXEL ? 4 : 6;
