@@ -2448,6 +2448,10 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     auto kdg = pix ? k_diag<0> : k_diag<1>;
     const size_t lds_elim = tile_tables_bytes(mtk) + 16;
     const size_t lds_bobs = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)BUILD_WAVES * Rp * LM_KS + nt * (nt + 1) / 2 + nt) + 16;
+    // lane-per-landmark kernels (k_elim, k_backsub_lm): 128 threads per tile — measured on the 64-window batch (tiles of ~165 landmarks
+    // after the key-frame cuts): 256 threads 46.7 / 74.2 us, 192 threads 46.9 / 76.2 us, 128 threads 42.2 / 63.2 us per launch. The
+    // kernels are bound by the latency of a lane's serial chain, not by lane count: half-size workgroups double the residency.
+    const int lm_threads = getenv("SADVIO_LM_THREADS") ? std::max(64, std::min(256, atoi(getenv("SADVIO_LM_THREADS")) & ~63)) : 128;
     if (use_lm) {
         P.decide_kernel = 1;   // the kernels read the decided state of their slot
         HIP_TRY(hipFuncSetAttribute((const void*)kbo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bobs));
@@ -2546,7 +2550,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                     hipLaunchKernelGGL(kdg, dim3(h->n_diag_segs), dim3(BUILD_THREADS), 0, h->side2, P, h->d_diag_segs.p, h->d_kf_lmk.p, h->d_kf_cam.p, h->d_kf_meas.p, s);
                     (void)hipEventRecord(h->ev_diag1, h->side2);
                 } else if (h->n_diag_segs) { ScopedTimer t(h, "k_diag"); hipLaunchKernelGGL(kdg, dim3(h->n_diag_segs), dim3(BUILD_THREADS), 0, h->stream, P, h->d_diag_segs.p, h->d_kf_lmk.p, h->d_kf_cam.p, h->d_kf_meas.p, s); }
-                { ScopedTimer t(h, "k_elim"); hipLaunchKernelGGL(ke, dim3(n_tiles), dim3(BUILD_THREADS), lds_elim, h->stream, P, s, mtk); }
+                { ScopedTimer t(h, "k_elim"); hipLaunchKernelGGL(ke, dim3(n_tiles), dim3(lm_threads), lds_elim, h->stream, P, s, mtk); }
                 { ScopedTimer t(h, "k_build_obs"); hipLaunchKernelGGL(kbo, dim3(n_tiles), dim3(BUILD_THREADS), lds_bobs, h->stream, P, s, mtk, Rp); }
                 if (par) (void)hipStreamWaitEvent(h->stream, h->ev_diag1, 0);
             } else
@@ -2748,7 +2752,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             if (dp_max_nf > 0) { ScopedTimer t(h, "k_prior_m"); hipLaunchKernelGGL(k_prior_m, dim3((dp_max_nf + 3) / 4, n_win), dim3(256), 0, h->stream, P, s); }
             if (n_pf && (use_lm || !with_imu)) { ScopedTimer t(h, "k_pf_cost"); hipLaunchKernelGGL(k_pf_eval<true>, dim3(n_pf), dim3(64), 0, h->stream, P, s); }
             if (use_lm) {
-                ScopedTimer t(h, "k_backsub_lm"); hipLaunchKernelGGL(kkl, dim3(n_tiles), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk);
+                ScopedTimer t(h, "k_backsub_lm"); hipLaunchKernelGGL(kkl, dim3(n_tiles), dim3(lm_threads), lds_back, h->stream, P, s, mtk);
             }
             else
             { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles + (with_imu ? n_pf : 0)), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }

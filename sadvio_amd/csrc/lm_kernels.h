@@ -73,7 +73,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_elim(DevPtrs P, int slot, int
     const int nl = T.lmk1 - T.lmk0;
     const double* xl = P.xl + (long long)st.cur * P.xl_stride;
     double cost_part = 0.0, fixed_part = 0.0, gmax_part = 0.0;
-    for (int lm = tid; lm < nl; lm += BUILD_THREADS) {
+    for (int lm = tid; lm < nl; lm += (int)blockDim.x) {
         const int gl = T.lmk0 + lm;
         const int ob = P.lmk_ob[gl], oe = P.lmk_oe[gl];
         const int lcode = P.lmk_const ? P.lmk_const[gl] : 0;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_elim(DevPtrs P, int slot, int
     __syncthreads();
     if (tid == 0) {
         double cs = 0.0, fs = 0.0, gs = 0.0;
-        for (int k = 0; k < BUILD_WAVES; k++) { cs += s_part[k * 4]; fs += s_part[k * 4 + 1]; gs = fmax(gs, s_part[k * 4 + 2]); }
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) { cs += s_part[k * 4]; fs += s_part[k * 4 + 1]; gs = fmax(gs, s_part[k * 4 + 2]); }
         TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + ti;
         ta->lin_cost = cs; ta->fixed_cost = fs; ta->gmax = gs;
     }
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 3) void k_backsub_lm(DevPtrs P, int 
     const double* xl = P.xl + (long long)cur * P.xl_stride;
     double* xlc = P.xl + (long long)(1 - cur) * P.xl_stride;
     double sn = 0.0, cn = 0.0, mcc = 0.0, cc = 0.0;
-    for (int lm = tid; lm < nl; lm += BUILD_THREADS) {
+    for (int lm = tid; lm < nl; lm += (int)blockDim.x) {
         const int gl = T.lmk0 + lm;
         const int ob = P.lmk_ob[gl], oe = P.lmk_oe[gl];
         const int lcode = P.lmk_const ? P.lmk_const[gl] : 0;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 3) void k_backsub_lm(DevPtrs P, int 
     __syncthreads();
     if (tid == 0) {
         double a0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-        for (int k = 0; k < BUILD_WAVES; k++) { a0 += s_part[k * 4]; b1 += s_part[k * 4 + 1]; b2 += s_part[k * 4 + 2]; b3 += s_part[k * 4 + 3]; }
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) { a0 += s_part[k * 4]; b1 += s_part[k * 4 + 1]; b2 += s_part[k * 4 + 2]; b3 += s_part[k * 4 + 3]; }
         TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + ti;
         ta->cand_cost = a0; ta->mcc = b1; ta->step_norm2 = b2; ta->cand_norm2 = b3;
     }
