@@ -234,6 +234,75 @@ def angular_factor(B, T_f_w0, T_s_f, p0, bearing, sigma, dpose, dl):
     return r, w * (Jel @ Jbf), w * (Jel @ dR)                    # :102, :107
 
 
+def T4(B, R, t):
+    T = B.eye(4)
+    T[:3, :3] = R; T[:3, 3] = t
+    return T
+
+
+def line_pixel_factor(B, T_f_w0, K, T_s_f, T_w_l0, model6, uv4, sigma, dpose, dline):
+    """ReprojectionErrCeres_linexd_dx::Evaluate (BundleAdjustmentCERESAnalytic.h:116-166), Jacobian branch: the two model points,
+    carried by T_w_lmk = T_w_lmk0 * se3_doubleVec3dtoRT(parameters[1]) — the first THREE entries of the line's 6-vector read as a
+    translation (:121) — projected with Camera::project against the two measured end points. Blocks as coded:
+    J_frame = jac0 * blockdiag(Jr(log R_f_w)^-1 Jr(w), R_f_w0) (:145-151), J_lmk = jac1 * [-R_w_lmk [pt]x | I] (:154-161).
+    Returns r[4], J_frame[4,6], J_line[4,6]."""
+    Rl, tl = split_T(B, T_w_l0)
+    model6 = B.a(model6); uv4 = B.a(uv4); dline = B.a(dline)
+    t_w_l = tl + Rl @ dline[:3]                                  # T_w_lmk_ * (I, x[0..2])
+    r = B.zeros(4); Jf = B.zeros((4, 6)); Jl = B.zeros((4, 6))
+    for i in range(2):
+        pt = model6[3 * i: 3 * i + 3]
+        pw = Rl @ pt + t_w_l                                     # T_w_lmk * Tpt, translation part (:124-129)
+        ri, Jpi, Jli, _ = pixel_factor(B, T_f_w0, K, T_s_f, pw, uv4[2 * i: 2 * i + 2], sigma, dpose, B.zeros(3))
+        r[2 * i: 2 * i + 2] = ri                                 # invalid projection: zero residual, Jacobian kept (:137-141)
+        Jf[2 * i: 2 * i + 2] = Jpi
+        JP = B.zeros((3, 6))
+        JP[:, :3] = -(Rl @ skew(B, pt)); JP[:, 3:] = B.eye(3)
+        Jl[2 * i: 2 * i + 2] = Jli @ JP
+    return r, Jf, Jl
+
+
+def line_angular_factor(B, T_f_w0, T_s_f, T_w_l0, bearings6, sigma, dpose, dline):
+    """AngularErrCeres_linexd_dx::Evaluate (AngularAdjustmentCERESAnalytic.h:378-459) with the helper definitions of
+    utilities/geometry.h:328-342 AS CODED (J_norm(X) = X^T / |X|, J_normalization(X) = (I - X X^T) / |X| with X not normalised,
+    J_AcrossX(A) = -[A]x). Returns r[2], J_frame[2,6], J_line[2,6]."""
+    R0, t0 = split_T(B, T_f_w0); Rs, ts = split_T(B, T_s_f); Rl, tl = split_T(B, T_w_l0)
+    dpose = B.a(dpose); dline = B.a(dline); bb = B.a(bearings6)
+    cross = lambda u, v: np.array([u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]], dtype=B.dtype)
+    Jnz = lambda X: (B.eye(3) - np.outer(X, X)) / norm(B, X)
+    dT = T4(B, exp_so3(B, dpose[:3]), dpose[3:6]); dL = T4(B, exp_so3(B, dline[:3]), dline[3:6])
+    Tsf, Tfw, Twl = T4(B, Rs, ts), T4(B, R0, t0), T4(B, Rl, tl)
+    weight = 1 / (B.s(sigma) * B.s(sigma))                       # :382
+    Tsl = Tsf @ Tfw @ dT @ Twl @ dL                              # :384
+    Rsl, tsl = Tsl[:3, :3], Tsl[:3, 3]
+    n_obs = cross(bb[:3], bb[3:6]); n_obs = n_obs / norm(B, n_obs)   # :388-389
+    b_l = tsl / norm(B, tsl)                                     # :392
+    ex = np.array([B.s(1), B.s(0), B.s(0)], dtype=B.dtype)
+    d = Rsl @ ex; d = d / norm(B, d)                             # Rotation2directionVector, geometry.h:125-129
+    n_l = cross(b_l, d); n_ln = n_l / norm(B, n_l)               # :393-394
+    cx = cross(n_obs, n_ln)
+    r = np.array([weight * norm(B, cx), weight * (n_obs @ b_l)], dtype=B.dtype)   # :400-401
+    J_e0 = (cx / norm(B, cx))[None, :] @ (-skew(B, n_obs)) @ Jnz(n_l)             # :407-408
+    J_e1 = n_obs[None, :] @ Jnz(tsl)                                              # :411
+    Rsw = Rs @ R0
+    dR = dT[:3, :3]; dRl = dL[:3, :3]
+    Jr_dT = so3_right_jacobian(B, log_so3(B, dR)); Jr_dL = so3_right_jacobian(B, log_so3(B, dRl))
+    Jt_dT = B.zeros((3, 6))                                      # :413-419
+    Jt_dT[:, :3] = -(Rsw @ dR @ skew(B, Rl @ dL[:3, 3]) @ Jr_dT) - (Rsw @ dR @ skew(B, tl))
+    Jt_dT[:, 3:] = Rsw
+    JR_dT = B.zeros((3, 6))                                      # :421-425
+    JR_dT[:, :3] = -(Rsw @ dR @ skew(B, Rl @ dRl @ ex) @ Jr_dT)
+    Rsl0 = Rsw @ dR @ Rl                                         # (_T_s_f * _T_f_w * dT * _T_w_lmk).rotation()
+    Jt_dL = B.zeros((3, 6)); Jt_dL[:, 3:] = Rsl0                 # :427-428
+    JR_dL = B.zeros((3, 6)); JR_dL[:, :3] = -(Rsl0 @ dRl @ skew(B, ex) @ Jr_dL)   # :430-433
+    out = []
+    for Jt, JR in ((Jt_dT, JR_dT), (Jt_dL, JR_dL)):              # :439-458
+        row0 = weight * (J_e0 @ (skew(B, Rsl @ ex).T @ (Jnz(tsl) @ Jt) + skew(B, n_ln) @ JR))
+        row1 = weight * (J_e1 @ Jt)
+        out.append(np.vstack([row0, row1]))
+    return r, out[0], out[1]
+
+
 def pose_prior_factor(B, T_f_w0, T_prior, inf_diag, dpose):
     """PosePriordx::Evaluate, sqrt_inf = diag(inf_diag) (BundleAdjustmentCERESAnalytic.cpp:226). Returns r[6], J[6,6]."""
     R0, t0 = split_T(B, T_f_w0)
@@ -617,6 +686,23 @@ class Problem:
             self.ba0 = np.asarray(w.kf_ba, dtype=np.float64).reshape(-1, 3)
             self.bg0 = np.asarray(w.kf_bg, dtype=np.float64).reshape(-1, 3)
             self.imu = list(getattr(w, "imu_factors", []))
+        # linexd landmarks (PoseParametersBlock, 6 each): a parameter block iff free and observed
+        self.lines = getattr(w, "lines", None)
+        self.n_line = 0
+        self.line_col = np.zeros(0, dtype=np.int64)
+        if self.lines is not None:
+            L = self.lines
+            self.line_T = np.asarray(L["T_w_l"], dtype=np.float64).reshape(-1, 12)
+            self.n_line = self.line_T.shape[0]
+            self.line_model = np.asarray(L["model"], dtype=np.float64).reshape(-1, 6)
+            self.line_ptr = np.asarray(L["obs_ptr"]); self.line_okf = np.asarray(L["obs_kf"]); self.line_ocam = np.asarray(L["obs_cam"])
+            self.line_meas = np.asarray(L["obs_meas"], dtype=np.float64)
+            lconst = np.zeros(self.n_line, bool) if L.get("const") is None else np.asarray(L["const"]).astype(bool)
+            self.line_col = np.full(self.n_line, -1)
+            for l in range(self.n_line):
+                if not lconst[l] and self.line_ptr[l + 1] > self.line_ptr[l]:
+                    self.line_col[l] = n
+                    n += 6
         self.n = n
         self.T = np.asarray(w.kf_T_f_w, dtype=np.float64).reshape(-1, 12)
         self.K = np.asarray(w.cam_K, dtype=np.float64).reshape(-1, 4)
@@ -639,6 +725,13 @@ class Problem:
             if self.lmk_col[l] >= 0:
                 xl[l] = x[self.lmk_col[l]: self.lmk_col[l] + 3]
         return xp, xl
+
+    def split_lines(self, x):
+        xs = self.B.zeros((self.n_line, 6))
+        for l in range(self.n_line):
+            if self.line_col[l] >= 0:
+                xs[l] = x[self.line_col[l]: self.line_col[l] + 6]
+        return xs
 
     def split_vio(self, x):
         """x -> per key-frame dv, dba, dbg (zeros when constant / no IMU)."""
@@ -673,6 +766,23 @@ class Problem:
                 if self.lmk_col[l] >= 0:
                     cols.append((self.lmk_col[l], Jl))
                 yield r, cols, bool(cols), rho
+        if self.n_line:                                           # linexd blocks (…Analytic.cpp:273-311 / Angular….cpp:293-333), the caller's loss function
+            xs = self.split_lines(x)
+            for l in range(self.n_line):
+                for o in range(self.line_ptr[l], self.line_ptr[l + 1]):
+                    k, c = int(self.line_okf[o]), int(self.line_ocam[o])
+                    if pixel:
+                        r, Jf, Jl = line_pixel_factor(B, self.T[k], self.K[c], self.Ts[c], self.line_T[l], self.line_model[l], self.line_meas[o][:4], 1.0, xp[k], xs[l])
+                    else:
+                        r, Jf, Jl = line_angular_factor(B, self.T[k], self.Ts[c], self.line_T[l], self.line_meas[o][:6], 1.0, xp[k], xs[l])
+                    s = sum(v * v for v in r)
+                    rho = s
+                    if self.huber_a > 0:
+                        rho, d1 = huber(B, s, self.huber_a)
+                        sc = B.sqrt(d1)
+                        r, Jf, Jl = sc * r, sc * Jf, sc * Jl
+                    cols = [(cc, Jb) for cc, Jb in ((self.kf_col[k], Jf), (self.line_col[l], Jl)) if cc >= 0]
+                    yield r, cols, bool(cols), rho
         for (k, Tp, inf) in self.priors:                          # PosePriordx blocks (…Analytic.cpp:224-228)
             k = int(k)
             r, J = pose_prior_factor(B, self.T[k], Tp, inf, xp[k])
@@ -1015,6 +1125,8 @@ def lm_solve(w, opts=None, kind="f64", digits=50, use_schur=False, max_iteration
         out.update(iterations=it, final_cost=B.f(cost), final_radius=B.f(radius), log=np.array(log), x_scalar=x, backend=B, problem=P)
         return out
     xp, xl = P.split(x)
+    if P.n_line:
+        out.update(line=B.f(P.split_lines(x)))
     if P.has_imu:
         xv, xa, xg = P.split_vio(x)
         out.update(dv=B.f(xv), dba=B.f(xa), dbg=B.f(xg))

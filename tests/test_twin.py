@@ -444,3 +444,64 @@ def test_viinit_solve_matches_twin(oracle_lib, optim_scale, optim_bias):
     assert np.abs(got["dba"] - np.array(dba, dtype=np.float64)).max() < 1e-9 and np.abs(got["dbg"] - np.array(dbg, dtype=np.float64)).max() < 1e-9
     if not optim_scale:
         assert got["lambda"] == 0.0
+
+
+# ---- round 4: the linexd blocks (VERDICT r03 "missing" 7: the last solve entry point without an oracle-against-twin solve) ----
+def _line_window(factor, **kw):
+    from line_helpers import add_lines
+    from sadvio_amd.synthetic import make_window
+    w = make_window(n_kf=5, n_lmk=60, obs_per_lmk=4, seed=3, factor=factor)
+    return add_lines(w, **kw)
+
+
+@pytest.mark.parametrize("factor", [capi.FACTOR_PIXEL, capi.FACTOR_ANGULAR])
+def test_line_factors_match_50_digit_evaluation(oracle_lib, factor):
+    """ReprojectionErrCeres_linexd_dx (BundleAdjustmentCERESAnalytic.h:104-195) / AngularErrCeres_linexd_dx
+    (AngularAdjustmentCERESAnalytic.h:368-469): the C oracle against the twin's 50-digit evaluation of the reference's
+    formulas AS CODED, at zero and non-zero deltas of the key-frame and of the line (incl. the Jr = I branch below 1e-5)."""
+    w = _line_window(factor)
+    B = twin.Backend("mp", 50)
+    rng = np.random.default_rng(2)
+    n_line = w.lines["T_w_l"].shape[0]
+    worst = 0.0
+    for scale in (1.0, 1e-3, 1e-7, 0.0):
+        xp = scale * 0.05 * rng.standard_normal((w.n_kf, 6)); xs = scale * 0.05 * rng.standard_normal((n_line, 6))
+        for l in range(n_line):
+            for o in range(w.lines["obs_ptr"][l], w.lines["obs_ptr"][l + 1]):
+                r, J = oracle_lib.line_factor(w, l, o, xp, xs)
+                kf, cam = int(w.lines["obs_kf"][o]), int(w.lines["obs_cam"][o])
+                if factor == capi.FACTOR_PIXEL:
+                    rt, Jf, Jl = twin.line_pixel_factor(B, w.kf_T_f_w[kf], w.cam_K[cam], w.cam_T_s_f[cam], w.lines["T_w_l"][l], w.lines["model"][l],
+                                                        w.lines["obs_meas"][o][:4], 1.0, xp[kf], xs[l])
+                else:
+                    rt, Jf, Jl = twin.line_angular_factor(B, w.kf_T_f_w[kf], w.cam_T_s_f[cam], w.lines["T_w_l"][l], w.lines["obs_meas"][o][:6], 1.0, xp[kf], xs[l])
+                Jt = np.hstack([_f(B, Jf), _f(B, Jl)])
+                worst = max(worst, _rel(J, Jt), float(np.abs(r - _f(B, rt)).max()) / max(1.0, float(np.abs(_f(B, rt)).max())))
+    assert worst < 2e-12, worst
+
+
+@pytest.mark.parametrize("factor,huber", [(capi.FACTOR_PIXEL, 0.0), (capi.FACTOR_PIXEL, 1.345 ** 0.5), (capi.FACTOR_ANGULAR, 0.0), (capi.FACTOR_ANGULAR, 2e-3)])
+def test_solve_with_line_landmarks_matches_twin_iterate_by_iterate(oracle_lib, factor, huber):
+    """localMapBA with linexd landmarks next to the points (…Analytic.cpp:273-311 / Angular….cpp:293-333): the oracle (lines as 6
+    reduced columns after the Schur elimination of the points) against the twin's plain un-reduced normal equations, iterate by
+    iterate — one constant line, the caller's loss function on the line blocks as on the point blocks."""
+    w = _line_window(factor, n_line=5, obs_per_line=4, n_const=1)
+    opts = capi.reference_options(); opts.max_num_iterations = 12; opts.huber_a = huber
+    ref = twin.lm_solve(w, opts, kind="f64")
+    got = oracle_lib.solve(w, opts)
+    s = got["summary"]
+    assert (s.iterations, s.termination, s.num_successful_steps, s.num_unsuccessful_steps) == \
+        (ref["iterations"], ref["termination"], ref["n_success"], ref["n_unsuccess"])
+    assert s.iterations >= 4
+    assert np.isclose(s.initial_cost, ref["initial_cost"], rtol=1e-12) and np.isclose(s.final_cost, ref["final_cost"], rtol=1e-10)
+    L, T = got["log"], ref["log"]
+    assert L.shape == T.shape
+    n = len(L) - (1 if s.termination in (1, 2) else 0)
+    assert np.allclose(L[:n, 0], T[:n, 0], rtol=1e-10)               # cost after each iteration
+    assert np.allclose(L[:n, 2], T[:n, 2], rtol=1e-6)                # trust-region radius: 1 / max(1/3, 1 - (2 rho - 1)^3) amplifies rho's last digits
+    assert np.allclose(L[:, 3], T[:, 3], rtol=1e-7)                  # step norm
+    assert np.allclose(L[:, 7], T[:, 7], rtol=1e-7)                  # model cost change
+    assert np.abs(got["pose"] - ref["pose"]).max() < 1e-9
+    assert np.abs(got["line"] - ref["line"]).max() < 1e-8 * max(1.0, np.abs(ref["line"]).max())
+    assert np.all(got["line"][0] == 0.0) and np.all(ref["line"][0] == 0.0)     # the constant line
+    assert np.abs(got["lmk"] - ref["lmk"]).max() < 1e-8 * max(1.0, np.abs(ref["lmk"]).max())
