@@ -487,9 +487,9 @@ def test_solve_with_line_landmarks_matches_twin_iterate_by_iterate(oracle_lib, f
     iterate — one constant line, the caller's loss function on the line blocks as on the point blocks."""
     w = _line_window(factor, n_line=5, obs_per_line=4, n_const=1)
     # the bearing-line blocks leave the line poses weakly determined: with the loss function on, this window's LM path takes
-    # 500 - 1000 m trial steps from the third iteration on (all rejected) and amplifies the last digits of rho from the seventh;
+    # 500 - 1000 m trial steps from the third iteration on (all rejected) and amplifies the last digits of rho from the sixth (a 533 m step is accepted there);
     # the two implementations agree to 1e-9 up to there, which is what is compared
-    opts = capi.reference_options(); opts.max_num_iterations = 6 if (factor == capi.FACTOR_ANGULAR and huber > 0) else 12; opts.huber_a = huber
+    opts = capi.reference_options(); opts.max_num_iterations = 5 if (factor == capi.FACTOR_ANGULAR and huber > 0) else 12; opts.huber_a = huber
     ref = twin.lm_solve(w, opts, kind="f64")
     got = oracle_lib.solve(w, opts)
     s = got["summary"]
