@@ -39,10 +39,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measur
 GN_ITERS = 10
 # committed rocprofv3 PMC summaries of this same command (scripts/prof_bench.sh / prof_batched.sh), named explicitly: the
 # newest round's files, not whatever sorts last
-PROFILE_SUMMARY = "profiles/r03_summary.json"
-PROFILE_SUMMARY_BATCHED = "profiles/r03_batched64_summary.json"
-PROFILE_FALLBACK = {"profiles/r03_summary.json": "profiles/r02_v6_summary.json",
-                    "profiles/r03_batched64_summary.json": "profiles/r02_v6_batched64_summary.json"}
+PROFILE_SUMMARY = "profiles/r04_summary.json"
+PROFILE_SUMMARY_BATCHED = "profiles/r04_batched64_summary.json"
+PROFILE_FALLBACK = {"profiles/r04_summary.json": "profiles/r03_summary.json",
+                    "profiles/r04_batched64_summary.json": "profiles/r03_batched64_summary.json"}
 
 
 def profile_summary(rel):

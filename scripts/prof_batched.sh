@@ -4,7 +4,7 @@
 # (FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x 2 on gfx950) and the issue counters VERDICT r01 item 4 asks for
 # (VALU / MFMA / LDS busy), each aggregated per kernel; the per-launch raw tables are dropped.
 TAG=$1
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_batched_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $GRAFT_REPO_ROOT/scripts/batched_run.py 64"

@@ -8,7 +8,7 @@ mkdir -p $OUT
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 # a short run of the same command: 5 x 20 timed solves (~10^4 kernel launches; the default 2000 solves make traces of > 64 MiB)
-CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-vio --batch 0 --steps 5 --warmup 1 --solves-per-step 20"
+CMD="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-vio --no-marginalize --batch 0 --steps 5 --warmup 1 --solves-per-step 20"   # the config-2 legs only: one variant per kernel in the trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $CMD > $OUT/pmc_write.log 2>&1

@@ -26,9 +26,14 @@ def main(out):
         for row in csv.DictReader(open(f)):
             k = short(row["Name"])
             if k:
-                res["kernels"].setdefault(k, {}).update(
-                    calls=int(row["Calls"]), avg_us=float(row["AverageNs"]) / 1e3,
-                    min_us=float(row["MinNs"]) / 1e3, max_us=float(row["MaxNs"]) / 1e3)
+                # template variants of one kernel (k_solve<0, false> / <0, true> ...): calls-weighted average; prof_bench.sh profiles
+                # the config-2 legs only, so that normally ONE variant is present
+                d = res["kernels"].setdefault(k, {"calls": 0, "avg_us": 0.0, "min_us": 1e30, "max_us": 0.0})
+                c = int(row["Calls"])
+                d["avg_us"] = (d["avg_us"] * d["calls"] + float(row["AverageNs"]) / 1e3 * c) / max(d["calls"] + c, 1)
+                d["calls"] += c
+                d["min_us"] = min(d["min_us"], float(row["MinNs"]) / 1e3); d["max_us"] = max(d["max_us"], float(row["MaxNs"]) / 1e3)
+                d.setdefault("variants", []).append(row["Name"].split("(")[0].replace("void ", "").replace("sadvio::", ""))
     for tag, scale in (("fetch", 2.0), ("write", 1.0)):
         acc = defaultdict(lambda: [0.0, 0])
         for f in glob.glob(os.path.join(out, "pmc_" + tag, "**", "*counter_collection.csv"), recursive=True):
