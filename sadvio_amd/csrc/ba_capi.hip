@@ -195,14 +195,13 @@ struct PriorState {
 struct TriLevel { int first, count, max_m, max_n; };
 struct MargScratch {
     DevBuf<double> A, b, G, V, ev, Vs, Ainv, T, Ak, bk, newJ, newr, lastJ, lastr, L, Tb, Zt, S, mi, jsel;
-    DevBuf<int> ditems, flag, sel, lastcol, piv_of, lc;
+    DevBuf<int> ditems, flag, sel, lastcol, piv_of, lc, piv_mm;
     DevBuf<MargSmall> small;
-    DevBuf<TriNode> nodes;
     DevBuf<NfrSpecC> spec;
     std::vector<int> lcol, items, items_l, col;
     std::vector<double> hev, hS;
-    std::vector<TriLevel> tri_levels;
-    int tri_npad = 0, tri_leaves = 0;
+    struct TriPlan { DevBuf<TriNode> nodes; std::vector<TriLevel> levels; int leaves = 0; };
+    std::map<int, TriPlan> tri_plans;   // node tables of the triangular inverse, by padded size (m of Amm and n of the prior alternate)
 };
 
 struct LineSetHost {   // deep copy of a sadvio_line_set
@@ -417,18 +416,13 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     return P;
 }
 
-// H = J^T J and J^T of a dense prior, once per upload (J is constant during the solve).
-__global__ void k_dense_prior_prepare(const double* J, double* Jt, double* H, int nf, int n) {
+// J^T of a dense prior, once per upload (J is constant during the solve); H = J^T J is a k_mgemm launch (FP64 matrix cores:
+// the one-thread-per-entry loop this replaces took 0.92 ms at n = 915, more than the layout build itself).
+__global__ void k_dense_prior_prepare(const double* J, double* Jt, int nf, int n) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (long long)nf * n) {
         const int i = (int)(idx / n), a = (int)(idx - (long long)i * n);
         Jt[(size_t)a * nf + i] = J[idx];
-    }
-    if (idx < (long long)n * n) {
-        const int a = (int)(idx / n), b = (int)(idx - (long long)a * n);
-        double s = 0.0;
-        for (int i = 0; i < nf; i++) s += J[(size_t)i * n + a] * J[(size_t)i * n + b];
-        H[idx] = s;
     }
 }
 
@@ -616,8 +610,10 @@ int layout_reduced(sadvio_ba_handle* h) {
         double* J = h->d_dp_data.p + pr.off;
         double* Jt = J + (size_t)pr.nf * pr.n;
         double* H = Jt + (size_t)pr.n * pr.nf;
-        const long long items = std::max((long long)pr.nf * pr.n, (long long)pr.n * pr.n);
-        hipLaunchKernelGGL(k_dense_prior_prepare, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, J, Jt, H, pr.nf, pr.n);
+        const long long items = (long long)pr.nf * pr.n;
+        hipLaunchKernelGGL(k_dense_prior_prepare, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, J, Jt, pr.nf, pr.n);
+        hipLaunchKernelGGL(k_mgemm, dim3((pr.n + 63) / 64, (pr.n + 63) / 64), dim3(256), 0, h->stream, H, (long long)pr.n, J, 1LL, (long long)pr.n, J, (long long)pr.n, 1LL,
+                           pr.n, pr.n, pr.nf, 1.0, 0.0);
     }
     return SADVIO_OK;
 }
@@ -1517,13 +1513,14 @@ namespace {
 // the n x n scratch S (destroyed); G (n x n) receives the factor's rows by ORIGINAL column index, h->d_jac_ints[0..n) the pivot
 // step of every index (-1 = never chosen). tau >= 0: stop at pivots <= tau * max diagonal; tau < 0: at pivots <= -tau
 // (absolute). Returns the rank (number of pivots taken), negative on a HIP error. One host synchronisation (the rank).
-int run_pchol(sadvio_ba_handle* h, double* S, int n, double* G, double tau) {
+int run_pchol(sadvio_ba_handle* h, double* S, int n, double* G, double tau, bool allow_swap = true) {
     if (h->d_jac_ints.alloc((size_t)n + 8) != hipSuccess) return -1;
     int* piv = h->d_jac_ints.p; int* rank_d = piv + n;
     if (h->d_jac_dbl.alloc((size_t)n + 8) != hipSuccess) return -1;
     double* dg = h->d_jac_dbl.p; double* dctl = dg + n;
     if (hipMemsetAsync(rank_d, 0xff, sizeof(int), h->stream) != hipSuccess) return -1;   // -1: still factorising
-    const bool swap_pchol = getenv("SADVIO_PCHOL_SWAP") != nullptr;   // the data-moving version (kept for comparison)
+    const bool swap_pchol = allow_swap && getenv("SADVIO_PCHOL_SWAP") != nullptr;   // the data-moving version (kept for comparison; the eigen path only:
+                                                                                      // the Cholesky-form routes read the factor by original column index)
     if (swap_pchol) {
         for (int k0 = 0; k0 < n; k0 += PCH_NB) {
             hipLaunchKernelGGL(k_pchol_panel, dim3(1), dim3(PCH_THREADS), 0, h->stream, S, n, G, piv, dg, rank_d, dctl, k0, tau);
@@ -1675,6 +1672,8 @@ inline void launch_mgemm(sadvio_ba_handle* h, double* C, long long ldc, const do
 }
 }  // namespace
 
+namespace { int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form, const int* step_of, double* Z); }
+
 int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_request* rq, sadvio_marg_result* res, int32_t* lmk_col_out,
                           double* J_out, double* r0_out) {
     if (!h) return SADVIO_E_INVALID_ARG;
@@ -1808,23 +1807,46 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         const long long items = (long long)nl * nl;
         hipLaunchKernelGGL(k_marg_last_prior, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, lastJ, lastr, M.lastcol.p, nfl, nl, M.A.p, M.b.p, N);
     }
-    // ---- Schur complement with the eigen pseudo-inverse of Amm (marginalization.cpp:234-248) -----------------------------
-    int sw = run_jacobi(h, M.A.p, N, m, 0, M.G.p, M.V.p, M.ev.p, M.flag.p, rq->eig_cut_mode);
-    if (sw < 0) { h->err = "marginalize: HIP error in the eigen-solver"; return SADVIO_E_HIP; }
-    if (res) res->sweeps_mm = sw;
+    // ---- Schur complement with the pseudo-inverse of Amm (marginalization.cpp:234-248) ----------------------------------
+    // A well-conditioned Amm (every pivot of the rank-revealing Cholesky above the noise floor: the usual case — frame0's states and
+    // its lonely stereo landmarks are fully observed) has Amm^+ = Amm^-1 under either cut, and the inverse comes from the triangular
+    // inverse of that factor (Z^T Z, k_tri_*): 0.3 ms instead of ~1.1 ms of Jacobi launches. Anything else takes the reference's
+    // eigen-decomposition with the request's cut.
     std::vector<double>& hev = M.hev;
     hev.resize(std::max(m, n));
-    HIP_TRY(hipMemcpyAsync(hev.data(), M.ev.p, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    bool mm_by_cholesky = false;
+    if (m >= 32 && m <= PCH_MAXN && !getenv("SADVIO_MARG_EIG_MM")) {
+        const long long mm2 = (long long)m * m;
+        hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((mm2 + 255) / 256)), dim3(256), 0, h->stream, M.A.p, (long long)N, m, M.V.p, M.G.p, 0);
+        const int r = run_pchol(h, M.V.p, m, M.G.p, pchol_tau(m, SADVIO_EIG_CUT_NOISE_FLOOR), false);
+        if (r < 0) { h->err = "marginalize: HIP error in the pivoted Cholesky"; return SADVIO_E_HIP; }
+        if (r == m) {
+            HIP_TRY(M.piv_mm.alloc(m));
+            HIP_TRY(hipMemcpyAsync(M.piv_mm.p, h->d_jac_ints.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, h->stream));
+            const int rc = prior_build_Z(h, M.G.p, m, m, SADVIO_PRIOR_FORM_CHOLESKY, M.piv_mm.p, M.Vs.p);
+            if (rc != SADVIO_OK) return rc;
+            mm_by_cholesky = true;
+        }
+    }
+    int sw = 0;
+    if (!mm_by_cholesky) {
+        sw = run_jacobi(h, M.A.p, N, m, 0, M.G.p, M.V.p, M.ev.p, M.flag.p, rq->eig_cut_mode);
+        if (sw < 0) { h->err = "marginalize: HIP error in the eigen-solver"; return SADVIO_E_HIP; }
+        HIP_TRY(hipMemcpyAsync(hev.data(), M.ev.p, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (res) res->sweeps_mm = sw;
     {
-        hev.resize(m);
-        const double cut = marg_cut(hev, rq->eig_cut_mode);
         std::vector<double> sel(m);
-        for (int i = 0; i < m; i++) sel[i] = hev[i] > cut ? 1.0 / sqrt(hev[i]) : 0.0;
-        HIP_TRY(hipMemcpyAsync(M.ev.p, sel.data(), sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
-        const long long mm = (long long)m * m;
-        hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, h->stream, M.V.p, M.ev.p, m, M.Vs.p);
-        // Ainv = Vs^T Vs ; T = Arm Ainv ; Ak = Arr - T Arm^T ; bk = brr - T bmm   (FP64 matrix cores)
+        if (!mm_by_cholesky) {
+            hev.resize(m);
+            const double cut = marg_cut(hev, rq->eig_cut_mode);
+            for (int i = 0; i < m; i++) sel[i] = hev[i] > cut ? 1.0 / sqrt(hev[i]) : 0.0;
+            HIP_TRY(hipMemcpyAsync(M.ev.p, sel.data(), sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+            const long long mm = (long long)m * m;
+            hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, h->stream, M.V.p, M.ev.p, m, M.Vs.p);
+        }
+        // Ainv = Vs^T Vs (Vs = Lambda^-1/2 U^T, or Z = G^-T of the Cholesky route) ; T = Arm Ainv ; Ak = Arr - T Arm^T ; bk = brr - T bmm   (FP64 matrix cores)
         launch_mgemm(h, M.Ainv.p, m, M.Vs.p, 1LL, (long long)m, M.Vs.p, (long long)m, 1LL, m, m, m, 1.0, 0.0);
         launch_mgemm(h, M.T.p, m, M.A.p + (size_t)m * N, (long long)N, 1LL, M.Ainv.p, (long long)m, 1LL, n, m, m, 1.0, 0.0);
         HIP_TRY(hipMemcpy2DAsync(M.Ak.p, sizeof(double) * n, M.A.p + (size_t)m * N + m, sizeof(double) * N, sizeof(double) * n, n, hipMemcpyDeviceToDevice, h->stream));
@@ -1839,7 +1861,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         const int n1 = n + 1;
         const long long nn1 = (long long)n1 * n1;
         hipLaunchKernelGGL(k_marg_aug_init, dim3((unsigned)((nn1 + 255) / 256)), dim3(256), 0, h->stream, M.Ak.p, M.bk.p, n, M.V.p);
-        nf = run_pchol(h, M.V.p, n1, M.G.p, pchol_tau(n, rq->eig_cut_mode));
+        nf = run_pchol(h, M.V.p, n1, M.G.p, pchol_tau(n, rq->eig_cut_mode), false);
         if (nf < 0) { h->err = "marginalize: HIP error in the pivoted Cholesky"; return SADVIO_E_HIP; }
         if (nf > n) nf = n;
         if (nf > 0) {
@@ -2055,7 +2077,8 @@ int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form,
     if (form == SADVIO_PRIOR_FORM_CHOLESKY && nf == n) {
         const int npad = (n + 31) / 32 * 32;
         HIP_TRY(M.L.alloc((size_t)npad * npad)); HIP_TRY(M.Tb.alloc((size_t)npad * npad)); HIP_TRY(M.piv_of.alloc(n));
-        if (M.tri_npad != npad) {
+        MargScratch::TriPlan& TP = M.tri_plans[npad];
+        if (TP.leaves == 0) {
             // node table of the recursion over [0, npad): leaves of <= 32 rows, inner nodes grouped by height
             std::vector<std::vector<TriNode>> lev;
             std::vector<TriNode> leaves;
@@ -2070,27 +2093,26 @@ int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form,
             } };
             Rec::go(0, npad, lev, leaves);
             std::vector<TriNode> all(leaves);
-            M.tri_levels.clear();
+            TP.levels.clear();
             for (auto& l : lev) {
                 int mm = 0, mn = 0;
                 for (auto& nd : l) { mm = std::max(mm, nd.hi - nd.mid); mn = std::max(mn, nd.mid - nd.lo); }
-                M.tri_levels.push_back({(int)all.size(), (int)l.size(), mm, mn});
+                TP.levels.push_back({(int)all.size(), (int)l.size(), mm, mn});
                 all.insert(all.end(), l.begin(), l.end());
             }
-            M.tri_leaves = (int)leaves.size();
-            HIP_TRY(M.nodes.alloc(all.size()));
-            h->up.add(M.nodes.p, all.data(), all.size() * sizeof(TriNode));
+            TP.leaves = (int)leaves.size();
+            HIP_TRY(TP.nodes.alloc(all.size()));
+            h->up.add(TP.nodes.p, all.data(), all.size() * sizeof(TriNode));
             HIP_TRY(h->up.flush(h->stream));
-            M.tri_npad = npad;
         }
         hipLaunchKernelGGL(k_tri_gather, dim3((n + 255) / 256), dim3(256), 0, h->stream, J, n, step_of, M.piv_of.p, npad, M.L.p, 0);
         const long long np2 = (long long)npad * npad;
         hipLaunchKernelGGL(k_tri_gather, dim3((unsigned)((np2 + 255) / 256)), dim3(256), 0, h->stream, J, n, step_of, M.piv_of.p, npad, M.L.p, 1);
-        hipLaunchKernelGGL(k_tri_leaf, dim3(M.tri_leaves), dim3(64), 0, h->stream, M.L.p, npad, M.nodes.p);
-        for (const auto& lv : M.tri_levels) {
+        hipLaunchKernelGGL(k_tri_leaf, dim3(TP.leaves), dim3(64), 0, h->stream, M.L.p, npad, TP.nodes.p);
+        for (const auto& lv : TP.levels) {
             const dim3 grid((lv.max_n + 63) / 64, (lv.max_m + 63) / 64, lv.count);
-            hipLaunchKernelGGL(k_tri_level, grid, dim3(256), 0, h->stream, M.L.p, M.Tb.p, npad, M.nodes.p + lv.first, 0);
-            hipLaunchKernelGGL(k_tri_level, grid, dim3(256), 0, h->stream, M.L.p, M.Tb.p, npad, M.nodes.p + lv.first, 1);
+            hipLaunchKernelGGL(k_tri_level, grid, dim3(256), 0, h->stream, M.L.p, M.Tb.p, npad, TP.nodes.p + lv.first, 0);
+            hipLaunchKernelGGL(k_tri_level, grid, dim3(256), 0, h->stream, M.L.p, M.Tb.p, npad, TP.nodes.p + lv.first, 1);
         }
         const long long nn = (long long)n * n;
         hipLaunchKernelGGL(k_tri_scatter, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, M.L.p, npad, n, step_of, Z);
@@ -2225,7 +2247,16 @@ int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, 
     h->up.add(M.spec.p, specs.data(), sizeof(NfrSpecC) * (size_t)ns);
     h->up.add(M.jsel.p, jsel.data(), sizeof(double) * jsel.size());
     HIP_TRY(h->up.flush(h->stream));
-    hipLaunchKernelGGL(k_nfr_cov_z, dim3(ns), dim3(JAC_THREADS), 0, h->stream, dZ, nf, n, M.spec.p, M.jsel.p, M.S.p);
+    int first3 = 0;
+    if (vio) {
+        // the one 15-row factor (IMUPriordx) as two matrix-core products — W = Jsel Z[:, kf]^T (15 x nf), cov = W W^T — instead of
+        // 120 LDS atomics per row of Z from one workgroup (measured 1.0 ms of the 1.6 ms call)
+        HIP_TRY(M.T.alloc((size_t)15 * nf));
+        launch_mgemm(h, M.T.p, nf, M.jsel.p, 15LL, 1LL, dZ + kf_col, 1LL, (long long)n, 15, nf, 15, 1.0, 0.0);
+        launch_mgemm(h, M.S.p + specs[0].out_off, 15, M.T.p, (long long)nf, 1LL, M.T.p, 1LL, (long long)nf, 15, 15, nf, 1.0, 0.0);
+        first3 = 1;
+    }
+    if (ns > first3) hipLaunchKernelGGL(k_nfr_cov_z, dim3(ns - first3), dim3(JAC_THREADS), 0, h->stream, dZ, nf, n, M.spec.p + first3, M.jsel.p, M.S.p);
     std::vector<double>& S = M.hS;
     S.resize((size_t)out_off);
     HIP_TRY(hipMemcpyAsync(S.data(), M.S.p, sizeof(double) * (size_t)out_off, hipMemcpyDeviceToHost, h->stream));
