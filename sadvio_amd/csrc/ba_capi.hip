@@ -1557,6 +1557,7 @@ int run_jacobi_rows(sadvio_ba_handle* h, double* G, int r, int n, int* flag) {
     if (!b4 && hipFuncSetAttribute((const void*)k_jacobi_mma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jm_lds) != hipSuccess) return -1;
     const int jb = b4 ? JB : JM;
     const int nb = (r + jb - 1) / jb, nbpad = nb + (nb & 1);
+    const double jtol = getenv("SADVIO_JACOBI_TOL") ? atof(getenv("SADVIO_JACOBI_TOL")) : 1e-14;   // |g_p . g_q| <= jtol |g_p| |g_q| ends a pair
     int sweeps = 0;
     long long* jts = nullptr;   // phase timestamps of one launch (SADVIO_KERNEL_TS builds, SADVIO_DEBUG & 4096)
     if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 4096) && n > 500 && h->d_dbg.alloc(128) == hipSuccess) jts = h->d_dbg.p + 44;
@@ -1564,9 +1565,9 @@ int run_jacobi_rows(sadvio_ba_handle* h, double* G, int r, int n, int* flag) {
         if (hipMemsetAsync(flag, 0, sizeof(int), h->stream) != hipSuccess) return -1;
         for (int st = 0; st < nbpad - 1; st++) {
             long long* ts = sweeps == 0 && st == 3 ? jts : nullptr;
-            if (!b4) hipLaunchKernelGGL(k_jacobi_mma, dim3(nbpad / 2), dim3(JAC_THREADS), jm_lds, h->stream, G, r, n, ldx, nbpad, st, 1e-14, flag, ts);
-            else if (n <= 4 * JAC_THREADS) hipLaunchKernelGGL(k_jacobi_block<4>, dim3(nbpad / 2), dim3(JAC_THREADS), 0, h->stream, G, r, n, nbpad, st, 1e-14, flag);
-            else hipLaunchKernelGGL(k_jacobi_block<8>, dim3(nbpad / 2), dim3(JAC_THREADS), 0, h->stream, G, r, n, nbpad, st, 1e-14, flag);
+            if (!b4) hipLaunchKernelGGL(k_jacobi_mma, dim3(nbpad / 2), dim3(JAC_THREADS), jm_lds, h->stream, G, r, n, ldx, nbpad, st, jtol, flag, ts);
+            else if (n <= 4 * JAC_THREADS) hipLaunchKernelGGL(k_jacobi_block<4>, dim3(nbpad / 2), dim3(JAC_THREADS), 0, h->stream, G, r, n, nbpad, st, jtol, flag);
+            else hipLaunchKernelGGL(k_jacobi_block<8>, dim3(nbpad / 2), dim3(JAC_THREADS), 0, h->stream, G, r, n, nbpad, st, jtol, flag);
         }
         int f = 0;
         if (hipMemcpyAsync(&f, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
