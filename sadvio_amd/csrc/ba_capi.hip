@@ -182,7 +182,7 @@ struct DensePriorHost {
 // resident; the variables its columns refer to are named by the caller per window (it owns the id bookkeeping).
 struct PriorState {
     bool valid = false;
-    int n_full = 0, n = 0, form = 0;
+    int n_full = 0, n = 0, form = 0, cut_mode = 0;   // cut_mode: the SADVIO_EIG_CUT_* it was built with (sparsify applies the same cut)
     DevBuf<double> J, r0;        // n_full x n row-major packed, n_full
     DevBuf<double> Z;            // n_full x n with Z^T Z = Sigma_k (built by the first sparsify of this prior)
     bool z_valid = false;
@@ -194,7 +194,7 @@ struct PriorState {
 // per call cost more than the kernels between them.
 struct TriLevel { int first, count, max_m, max_n; };
 struct MargScratch {
-    DevBuf<double> A, b, G, V, ev, Vs, Ainv, T, Ak, bk, newJ, newr, lastJ, lastr, L, Tb, Zt, S, mi, jsel;
+    DevBuf<double> A, b, G, V, ev, Vs, Ainv, T, Ak, bk, newJ, newr, lastJ, lastr, L, Tb, Zt, S, mi, jsel, lam;
     DevBuf<int> ditems, flag, sel, lastcol, piv_of, lc, piv_mm;
     DevBuf<MargSmall> small;
     DevBuf<NfrSpecC> spec;
@@ -1673,7 +1673,7 @@ inline void launch_mgemm(sadvio_ba_handle* h, double* C, long long ldc, const do
 }
 }  // namespace
 
-namespace { int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form, const int* step_of, double* Z); }
+namespace { int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form, const int* step_of, double* Z, int cut_mode); }
 
 int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_request* rq, sadvio_marg_result* res, int32_t* lmk_col_out,
                           double* J_out, double* r0_out) {
@@ -1824,7 +1824,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         if (r == m) {
             HIP_TRY(M.piv_mm.alloc(m));
             HIP_TRY(hipMemcpyAsync(M.piv_mm.p, h->d_jac_ints.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, h->stream));
-            const int rc = prior_build_Z(h, M.G.p, m, m, SADVIO_PRIOR_FORM_CHOLESKY, M.piv_mm.p, M.Vs.p);
+            const int rc = prior_build_Z(h, M.G.p, m, m, SADVIO_PRIOR_FORM_CHOLESKY, M.piv_mm.p, M.Vs.p, rq->eig_cut_mode);
             if (rc != SADVIO_OK) return rc;
             mm_by_cholesky = true;
         }
@@ -1900,7 +1900,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     // the new prior becomes the handle's (AOptimizer.h:88-90: _marginalization_last), the old one's buffers become scratch
     PR.J.swap(M.newJ); PR.r0.swap(M.newr);
     PR.serial++;
-    PR.valid = nf > 0; PR.z_valid = false; PR.n_full = nf; PR.n = n; PR.form = chol_form ? SADVIO_PRIOR_FORM_CHOLESKY : SADVIO_PRIOR_FORM_EIGEN;
+    PR.valid = nf > 0; PR.z_valid = false; PR.n_full = nf; PR.n = n; PR.form = chol_form ? SADVIO_PRIOR_FORM_CHOLESKY : SADVIO_PRIOR_FORM_EIGEN; PR.cut_mode = rq->eig_cut_mode;
     if (nf > 0) {
         if (J_out) HIP_TRY(hipMemcpyAsync(J_out, PR.J.p, sizeof(double) * (size_t)nf * n, hipMemcpyDeviceToHost, h->stream));
         if (r0_out) HIP_TRY(hipMemcpyAsync(r0_out, PR.r0.p, sizeof(double) * nf, hipMemcpyDeviceToHost, h->stream));
@@ -1935,7 +1935,7 @@ int sadvio_ba_set_prior(sadvio_ba_handle* h, int32_t n_full, int32_t n, int32_t 
     HIP_TRY(hipMemcpyAsync(PR.J.p, J, sizeof(double) * (size_t)n_full * n, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(PR.r0.p, r0, sizeof(double) * n_full, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    PR.valid = true; PR.z_valid = false; PR.n_full = n_full; PR.n = n; PR.form = form;
+    PR.valid = true; PR.z_valid = false; PR.n_full = n_full; PR.n = n; PR.form = form; PR.cut_mode = SADVIO_EIG_CUT_REFERENCE;
     return SADVIO_OK;
 }
 
@@ -2073,7 +2073,7 @@ namespace {
 // Z (n_full x n) with Z^T Z = Sigma_k = pseudo-inverse of the prior's information, for the NFR covariances of sparsify:
 // eigen form: rows J_c / lambda_c; Cholesky form of full rank: the triangular inverse of G (k_tri_*: recursive halving on the
 // matrix cores); a rank-deficient Cholesky-form prior is first orthogonalised by the block Jacobi (its rows then ARE the eigen form).
-int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form, const int* step_of, double* Z) {
+int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form, const int* step_of, double* Z, int cut_mode) {
     MargScratch& M = h->mg;
     if (form == SADVIO_PRIOR_FORM_CHOLESKY && nf == n) {
         const int npad = (n + 31) / 32 * 32;
@@ -2126,7 +2126,10 @@ int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form,
         if (run_jacobi_rows(h, M.G.p, nf, n, M.flag.p) < 0) { h->err = "sparsify: HIP error in the eigen-solver"; return SADVIO_E_HIP; }
         rows = M.G.p;
     }
-    hipLaunchKernelGGL(k_z_from_eig, dim3(nf), dim3(JAC_THREADS), 0, h->stream, rows, n, Z);
+    HIP_TRY(M.lam.alloc((size_t)nf + 2));
+    hipLaunchKernelGGL(k_row_norm2, dim3(nf), dim3(JAC_THREADS), 0, h->stream, rows, nf, n, M.lam.p);
+    hipLaunchKernelGGL(k_z_cut, dim3(1), dim3(256), 0, h->stream, M.lam.p, nf, cut_mode == SADVIO_EIG_CUT_NOISE_FLOOR ? 1 : 0, M.lam.p + nf);
+    hipLaunchKernelGGL(k_z_from_eig, dim3(nf), dim3(JAC_THREADS), 0, h->stream, rows, n, M.lam.p, M.lam.p + nf, Z);
     return SADVIO_OK;
 }
 }  // namespace
@@ -2170,7 +2173,7 @@ int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, 
         dJ = PR.J.p;
         if (!PR.z_valid) {
             HIP_TRY(PR.Z.alloc((size_t)nf * n));
-            const int rc = prior_build_Z(h, PR.J.p, nf, n, PR.form, PR.step_of.p, PR.Z.p);
+            const int rc = prior_build_Z(h, PR.J.p, nf, n, PR.form, PR.step_of.p, PR.Z.p, PR.cut_mode);
             if (rc != SADVIO_OK) return rc;
             PR.z_valid = true;
         }
@@ -2178,7 +2181,7 @@ int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, 
     } else {
         HIP_TRY(M.lastJ.alloc((size_t)nf * n)); HIP_TRY(M.Zt.alloc((size_t)nf * n));
         HIP_TRY(hipMemcpyAsync(M.lastJ.p, J, sizeof(double) * (size_t)nf * n, hipMemcpyHostToDevice, h->stream));
-        const int rc = prior_build_Z(h, M.lastJ.p, nf, n, SADVIO_PRIOR_FORM_EIGEN, nullptr, M.Zt.p);
+        const int rc = prior_build_Z(h, M.lastJ.p, nf, n, SADVIO_PRIOR_FORM_EIGEN, nullptr, M.Zt.p, SADVIO_EIG_CUT_REFERENCE);
         if (rc != SADVIO_OK) return rc;
         dJ = M.lastJ.p; dZ = M.Zt.p;
     }

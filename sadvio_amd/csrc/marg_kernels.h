@@ -855,14 +855,24 @@ __global__ void k_tri_scatter(const double* __restrict__ Li, int npad, int n, co
     Z[idx] = (a >= 0 && a <= k) ? Li[(size_t)k * npad + a] : 0.0;
 }
 
-// eigen form: Z[c][:] = J[c][:] / |J_c|^2 (Sigma = Lambda^-1, U[:, c] = J_c / sqrt(lambda_c): Sigma_k = sum_c z_c z_c^T)
-__global__ __launch_bounds__(JAC_THREADS) void k_z_from_eig(const double* __restrict__ J, int n, double* __restrict__ Z) {
-    __shared__ double sh[4];
+// eigen form: Z[c][:] = J[c][:] / |J_c|^2 (Sigma = Lambda^-1, U[:, c] = J_c / sqrt(lambda_c): Sigma_k = sum_c z_c z_c^T). Rows whose
+// lambda_c = |J_c|^2 is not above the eigenvalue cut are dropped, as rankReveallingDecomposition drops them (marginalization.cpp:318-342):
+// the rows of an orthogonalised rank-deficient Cholesky factor reach below it (its pivots are cut lower than the eigenvalues).
+// cut[0] = the cut (k_z_cut); lam = |J_c|^2 from k_row_norm2.
+__global__ void k_z_cut(const double* __restrict__ lam, int nf, int noise_floor, double* __restrict__ cut) {
+    __shared__ double sh[256];
+    double m = 0.0;
+    for (int c = threadIdx.x; c < nf; c += blockDim.x) m = fmax(m, lam[c]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s2 = blockDim.x >> 1; s2 > 0; s2 >>= 1) { if ((int)threadIdx.x < s2) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s2]); __syncthreads(); }
+    if (threadIdx.x == 0) cut[0] = noise_floor ? fmax(1e-12, (double)nf * 2.220446049250313e-16 * sh[0]) : 1e-12;
+}
+__global__ __launch_bounds__(JAC_THREADS) void k_z_from_eig(const double* __restrict__ J, int n, const double* __restrict__ lam, const double* __restrict__ cut,
+                                                            double* __restrict__ Z) {
     const int c = blockIdx.x;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += JAC_THREADS) { const double v = J[(size_t)c * n + i]; s += v * v; }
-    s = block_sum_256(s, sh);
-    const double il = s > 0.0 ? 1.0 / s : 0.0;
+    const double s = lam[c];
+    const double il = s > cut[0] ? 1.0 / s : 0.0;
     for (int i = threadIdx.x; i < n; i += JAC_THREADS) Z[(size_t)c * n + i] = J[(size_t)c * n + i] * il;
 }
 
