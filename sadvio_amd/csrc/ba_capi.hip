@@ -1516,8 +1516,9 @@ namespace {
 int run_pchol(sadvio_ba_handle* h, double* S, int n, double* G, double tau, bool allow_swap = true) {
     if (h->d_jac_ints.alloc((size_t)n + 8) != hipSuccess) return -1;
     int* piv = h->d_jac_ints.p; int* rank_d = piv + n;
-    if (h->d_jac_dbl.alloc((size_t)n + 8) != hipSuccess) return -1;
-    double* dg = h->d_jac_dbl.p; double* dctl = dg + n;
+    if (h->d_jac_dbl.alloc(2 * (size_t)n + 8) != hipSuccess) return -1;
+    double* dg = h->d_jac_dbl.p; double* dctl = dg + 2 * (size_t)n;      // remaining diagonal | original diagonal | tau
+    if (hipMemsetAsync(rank_d, 0, sizeof(int) * 8, h->stream) != hipSuccess) return -1;
     if (hipMemsetAsync(rank_d, 0xff, sizeof(int), h->stream) != hipSuccess) return -1;   // -1: still factorising
     const bool swap_pchol = allow_swap && getenv("SADVIO_PCHOL_SWAP") != nullptr;   // the data-moving version (kept for comparison; the eigen path only:
                                                                                       // the Cholesky-form routes read the factor by original column index)
@@ -1530,7 +1531,31 @@ int run_pchol(sadvio_ba_handle* h, double* S, int n, double* G, double tau, bool
     } else {
         if (hipMemsetAsync(piv, 0xff, sizeof(int) * (size_t)n, h->stream) != hipSuccess) return -1;   // done[i] = -1
         const unsigned gt = (unsigned)((n + 63) / 64);
-        if (n <= PCH_THREADS) {
+        if (!getenv("SADVIO_PCHOL_STRICT")) {
+            // relaxed pivoting (marg_kernels.h: k_pchol_panel_rx): a panel picks its pivots up front; the first row of a panel is device state
+            const double safe = 1024.0 * n * 2.220446049250313e-16;
+            const int nb = n <= PCH_THREADS ? 32 : 16;
+            int launched = 0, r = -1;
+            for (int round = 0; round < 64 && r < 0; round++) {
+                const int np = round == 0 ? (n + nb - 1) / nb + 4 : 4;
+                for (int pnl = 0; pnl < np; pnl++, launched++) {
+                    if (n <= PCH_THREADS) {
+                        hipLaunchKernelGGL((k_pchol_panel_rx<1, 32>), dim3(1), dim3(PCH_THREADS), 0, h->stream, S, n, G, piv, dg, rank_d, dctl, launched == 0 ? 1 : 0, tau, safe);
+                        hipLaunchKernelGGL(k_pchol_syrk_mma<32>, dim3(gt, gt), dim3(256), 0, h->stream, S, n, G, rank_d);
+                    } else {
+                        hipLaunchKernelGGL((k_pchol_panel_rx<2, 16>), dim3(1), dim3(PCH_THREADS), 0, h->stream, S, n, G, piv, dg, rank_d, dctl, launched == 0 ? 1 : 0, tau, safe);
+                        hipLaunchKernelGGL(k_pchol_syrk_mma<16>, dim3(gt, gt), dim3(256), 0, h->stream, S, n, G, rank_d);
+                    }
+                }
+                if (hipMemcpyAsync(&r, rank_d, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+            }
+            if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 16384)) {
+                int c8[8];
+                if (hipMemcpy(c8, rank_d, sizeof(c8), hipMemcpyDeviceToHost) == hipSuccess)
+                    fprintf(stderr, "[sadvio dbg] relaxed pivoted cholesky n %d rank %d: %d panels launched, %d ran (%d strict), %d candidates skipped\n", n, r, launched, c8[3] + 1, c8[4], c8[5]);
+            }
+            return r < 0 ? -1 : r;
+        } else if (n <= PCH_THREADS) {
             for (int k0 = 0; k0 < n; k0 += 32) {
                 hipLaunchKernelGGL((k_pchol_panel_np<1, 32>), dim3(1), dim3(PCH_THREADS), 0, h->stream, S, n, G, piv, dg, rank_d, dctl, k0, tau);
                 if (k0 + 32 < n) hipLaunchKernelGGL(k_pchol_syrk_full<32>, dim3(gt, gt), dim3(256), 0, h->stream, S, n, G, rank_d, k0);

@@ -294,6 +294,221 @@ __global__ __launch_bounds__(PCH_THREADS) void k_pchol_panel_np(const double* __
     }
 }
 
+// ---- relaxed pivoting (round 4): a whole panel's pivots are chosen at once ----------------------------------------------------------
+// k_pchol_panel_np spends 1.6 us per column, most of it waiting for ONE global round trip: row j of S can only be requested once the
+// arg max of the remaining diagonal is known. Any index whose remaining diagonal is safely above its own rounding noise is a valid
+// pivot of a positive semi-definite matrix (the factorisation is backward stable in every order; the order only decides WHICH
+// dependent indices are left over at the end), so here a panel picks its NB pivots up front - the two (one for n > 1024) largest
+// "safe" remaining diagonals of every wave, sorted - requests their NB rows of S together, and then runs the NB columns with one
+// barrier each: the owner of pivot c publishes its remaining diagonal and its entries of the panel's earlier rows, every thread
+// finishes its entry of row c from registers. A candidate whose diagonal has meanwhile dropped below the safe bound (it depends on
+// the pivots taken before it in this panel) is skipped and competes again in the next panel. "Safe": d_i > tau and
+// d_i >= safe_rel * a_ii (a_ii = the original diagonal, safe_rel ~ 1e3 n eps). When no safe index is left but some diagonal is still
+// above tau, the panel falls back to strict pivoting (arg max per column, as k_pchol_panel_np): the rank decision is taken by the
+// same rule as before, on the handful of near-dependent indices only.
+// The panel's first row is no longer known to the host: ctl[1] = rows written so far, ctl[2] = first row of the last panel (what
+// the trailing update reads); rows [ctl[1], ctl[2] + NB) are zeroed so that the update can always contract NB rows.
+// dg: [0, n) remaining diagonal, [n, 2n) original diagonal.
+template <int EPT, int NB>
+__global__ __launch_bounds__(PCH_THREADS) void k_pchol_panel_rx(const double* __restrict__ S, int n, double* __restrict__ G, int* __restrict__ done_g,
+                                                                double* __restrict__ dg, int* __restrict__ ctl, double* __restrict__ dctl, int first, double tau_rel,
+                                                                double safe_rel) {
+    constexpr int NW = PCH_THREADS / 64;
+    __shared__ double lk[2][NB];
+    __shared__ double pd[2][2];
+    __shared__ double cval[NB];
+    __shared__ int cidx[NB], ord[NB];
+    __shared__ double wmax[NW];
+    __shared__ int widx[NW];
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    if (ctl[0] >= 0) return;              // the factorisation stopped in an earlier panel
+    const int k0 = first ? 0 : ctl[1];
+    double d[EPT], a0[EPT], g[NB][EPT];
+    bool done[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int i = tid + e * PCH_THREADS;
+        if (i < n) {
+            d[e] = first ? S[(size_t)i * n + i] : dg[i];
+            a0[e] = first ? d[e] : dg[n + i];
+            done[e] = first ? false : done_g[i] >= 0;
+        } else { d[e] = -1.0; a0[e] = 0.0; done[e] = true; }
+    }
+    if (first) {
+        double m = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) m = fmax(m, d[e]);
+        m = wave_max(m);
+        if (ln == 0) wmax[wv] = m;
+        __syncthreads();
+        if (tid == 0) { double mm = 0.0; for (int q = 0; q < NW; q++) mm = fmax(mm, wmax[q]); const double t0 = tau_rel >= 0.0 ? tau_rel * mm : -tau_rel; dctl[0] = t0; pd[0][0] = t0; }
+        __syncthreads();
+    }
+    const double tau = first ? pd[0][0] : dctl[0];
+    __syncthreads();
+    // ---- candidates: the PW largest safe remaining diagonals of every wave; beside them the arg max over ALL remaining indices ----
+    {
+        double ball = -1.0; int iall = 0;
+        bool taken[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) { taken[e] = false; if (!done[e] && d[e] > ball) { ball = d[e]; iall = tid + e * PCH_THREADS; } }
+        const double wm = wave_max(ball);
+        const int src = __ffsll((long long)__ballot(ball == wm)) - 1;
+        const int wi = __builtin_amdgcn_readlane(iall, src);
+        if (ln == 0) { wmax[wv] = wm; widx[wv] = wi; }
+        if (tid < NB) cval[tid] = -1.0;
+        __syncthreads();
+        // slot r * nwa + wv: round r of wave wv, nwa = waves that own indices at all (a small system gives its few waves more rounds)
+        const int nwa = EPT > 1 ? NW : min(NW, (n + 63) >> 6);
+        const int pw = (NB + nwa - 1) / nwa;
+        for (int r = 0; r < pw; r++) {
+            const int slot = r * nwa + wv;
+            double best = -1.0; int bi = 0, be = 0;
+#pragma unroll
+            for (int e = 0; e < EPT; e++)
+                if (!done[e] && !taken[e] && d[e] > tau && d[e] >= safe_rel * a0[e] && d[e] > best) { best = d[e]; bi = tid + e * PCH_THREADS; be = e; }
+            const double cm = wave_max(best);
+            const int cs = __ffsll((long long)__ballot(best == cm)) - 1;
+            const int ci = __builtin_amdgcn_readlane(bi, cs);
+            if (ln == cs && cm > 0.0) {
+#pragma unroll
+                for (int e = 0; e < EPT; e++) if (e == be) taken[e] = true;
+            }
+            if (ln == 0 && wv < nwa && slot < NB) { cval[slot] = cm > 0.0 ? cm : -1.0; cidx[slot] = ci; }
+        }
+    }
+    __syncthreads();
+    double m_all = wmax[0]; int j_all = widx[0];
+#pragma unroll
+    for (int q = 1; q < NW; q++) if (wmax[q] > m_all) { m_all = wmax[q]; j_all = widx[q]; }
+    int nc = 0;
+#pragma unroll
+    for (int q = 0; q < NB; q++) nc += cval[q] > 0.0 ? 1 : 0;
+    if (tid < NB) {
+        const double v = cval[tid];
+        int rk = 0;
+#pragma unroll
+        for (int q = 0; q < NB; q++) { const double u = cval[q]; rk += (u > v || (u == v && q < tid)) ? 1 : 0; }
+        ord[rk] = tid;        // descending by value; the invalid candidates (-1) come last
+    }
+    __syncthreads();
+    int rank = -1, cnt = 0;
+    if (!(m_all > tau && m_all > 0.0)) rank = k0;
+    else if (nc > 0) {
+        // ---- fast panel ----
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            const int j = c < nc ? cidx[ord[c]] : -1;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) { const int i = tid + e * PCH_THREADS; g[c][e] = (j >= 0 && i < n) ? S[(size_t)j * n + i] : 0.0; }
+        }
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            if (c < nc) {      // (uniform)
+            const int j = cidx[ord[c]], p = c & 1;
+            if (tid == (j & (PCH_THREADS - 1))) {
+#pragma unroll
+                for (int e = 0; e < EPT; e++) if (j == tid + e * PCH_THREADS) {
+                    pd[p][0] = d[e]; pd[p][1] = a0[e];
+#pragma unroll
+                    for (int q = 0; q < c; q++) lk[p][q] = g[q][e];
+                }
+            }
+            __syncthreads();
+            const double dj = pd[p][0];
+            if (dj > tau && dj >= safe_rel * pd[p][1]) {
+                const double lkk = sqrt(dj), inv = 1.0 / lkk;
+                const int k = k0 + cnt;
+#pragma unroll
+                for (int e = 0; e < EPT; e++) {
+                    const int i = tid + e * PCH_THREADS;
+                    double v = 0.0;
+                    if (i == j) { v = lkk; done[e] = true; done_g[i] = k; }
+                    else if (!done[e]) {
+                        double s0 = g[c][e];
+#pragma unroll
+                        for (int q = 0; q < c; q++) s0 -= g[q][e] * lk[p][q];
+                        v = s0 * inv;
+                        d[e] -= v * v;
+                    }
+                    g[c][e] = v;
+                    if (i < n) G[(size_t)k * n + i] = v;
+                }
+                cnt++;
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPT; e++) g[c][e] = 0.0;
+            }
+            }
+        }
+    } else {
+        // ---- strict panel: arg max of the remaining diagonal per column ----
+        bool active = true;     // (uniform)
+#pragma unroll
+        for (int kk = 0; kk < NB; kk++) {
+            const int k = k0 + kk;
+            if (k >= n) active = false;
+            double m = m_all; int j = j_all;
+            if (active && kk > 0) {
+                double best = -1.0; int bi = 0;
+#pragma unroll
+                for (int e = 0; e < EPT; e++) if (!done[e] && d[e] > best) { best = d[e]; bi = tid + e * PCH_THREADS; }
+                const double wm = wave_max(best);
+                const int src = __ffsll((long long)__ballot(best == wm)) - 1;
+                const int wi = __builtin_amdgcn_readlane(bi, src);
+                __syncthreads();      // (the reads of wmax / lk of the column before)
+                if (ln == 0) { wmax[wv] = wm; widx[wv] = wi; }
+                __syncthreads();
+                m = wmax[0]; j = widx[0];
+#pragma unroll
+                for (int q = 1; q < NW; q++) if (wmax[q] > m) { m = wmax[q]; j = widx[q]; }
+                if (!(m > tau && m > 0.0)) { rank = k; active = false; }
+            }
+            if (active) {
+            double srow[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) { const int i = tid + e * PCH_THREADS; srow[e] = i < n ? S[(size_t)j * n + i] : 0.0; }
+            if (tid == (j & (PCH_THREADS - 1))) {
+#pragma unroll
+                for (int e = 0; e < EPT; e++) if (j == tid + e * PCH_THREADS) {
+#pragma unroll
+                    for (int q = 0; q < kk; q++) lk[0][q] = g[q][e];
+                }
+            }
+            __syncthreads();
+            const double lkk = sqrt(m), inv = 1.0 / lkk;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const int i = tid + e * PCH_THREADS;
+                double v = 0.0;
+                if (i == j) { v = lkk; done[e] = true; done_g[i] = k; }
+                else if (!done[e]) {
+                    double s0 = srow[e];
+#pragma unroll
+                    for (int q = 0; q < kk; q++) s0 -= g[q][e] * lk[0][q];
+                    v = s0 * inv;
+                    d[e] -= v * v;
+                }
+                g[kk][e] = v;
+                if (i < n) G[(size_t)k * n + i] = v;
+            }
+            cnt++;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; e++) { const int i = tid + e * PCH_THREADS; if (i < n) { dg[i] = d[e]; if (first) dg[n + i] = a0[e]; } }
+    const int k1 = k0 + cnt;
+    if (rank < 0 && k1 >= n) rank = n;
+    if (rank >= 0) {
+        for (int c = rank; c < n; c++) for (int i = tid; i < n; i += PCH_THREADS) G[(size_t)c * n + i] = 0.0;
+        if (tid == 0) ctl[0] = rank;
+    } else {
+        for (int c = k1; c < k0 + NB && c < n; c++) for (int i = tid; i < n; i += PCH_THREADS) G[(size_t)c * n + i] = 0.0;
+        if (tid == 0) { ctl[1] = k1; ctl[2] = k0; ctl[3] += 1; if (nc == 0) ctl[4] += 1; ctl[5] += nc - cnt > 0 ? nc - cnt : 0; }   // [3..5]: panels, strict panels, skipped candidates (SADVIO_DEBUG & 16384)
+    }
+}
+
 // S[i][j] -= sum_{c in panel} G[c][i] G[c][j] over the WHOLE matrix (implicit pivoting: nothing is ordered), 64 x 64 tiles
 template <int NB>
 __global__ __launch_bounds__(256) void k_pchol_syrk_full(double* __restrict__ S, int n, const double* __restrict__ G, const int* __restrict__ ctl, int k0) {
@@ -753,6 +968,18 @@ __global__ __launch_bounds__(256) void k_mgemm(double* C, long long ldc, const d
                                                long long sbj, int M, int N, int K, double alpha, double beta) {
     __shared__ double As[64][17], Bs[64][17];
     mgemm_tile(C, ldc, A, sai, sak, B, sbk, sbj, M, N, 0, K, alpha, beta, blockIdx.y * 64, blockIdx.x * 64, As, Bs);
+}
+
+// the panel's update of the WHOLE working matrix on the FP64 matrix cores: S -= Gp^T Gp, Gp = rows [ctl[2], ctl[2] + NB) of G
+// (rows at or beyond n: none)
+template <int NB>
+__global__ __launch_bounds__(256) void k_pchol_syrk_mma(double* __restrict__ S, int n, const double* __restrict__ G, const int* __restrict__ ctl) {
+    if (ctl[0] >= 0) return;
+    __shared__ double As[64][17], Bs[64][17];
+    const int base = ctl[2];
+    const int K = min(NB, n - base);
+    const double* Gp = G + (size_t)base * n;
+    mgemm_tile(S, n, Gp, 1, n, Gp, n, 1, n, n, 0, K, -1.0, 1.0, blockIdx.y * 64, blockIdx.x * 64, As, Bs);
 }
 
 // ---- Cholesky form of the prior (SADVIO_PRIOR_FORM_CHOLESKY) ---------------------------------------------------------------------
