@@ -240,7 +240,8 @@ struct sadvio_ba_handle {
     int factor_type = 0;
     int max_n_kf = 0, max_npose = 0, max_np = 0, n_big = 0;
     DevBuf<int> d_big_info;
-    DevBuf<double> d_big_M;     // inverse diagonal blocks of the wide-panel dense solver, 96 x 96 per 96 columns
+    DevBuf<double> d_big_M;     // inverse diagonal blocks of the wide-panel dense solver, 96 x 96 per 96 columns (+ the factors' tiles)
+    DevBuf<double> d_big_Lx;    // its out-of-place panels
     DevBuf<double> d_big_linv;  // inverse pivot blocks of the banded solver, N * NB doubles per out-of-LDS window
     DevBuf<double> d_coll_band; // band-packed copy of the reduced system for the sharded all-reduce
     DevBuf<double> d_bcr;       // block-cyclic-reduction workspace of the long banded systems
@@ -1537,7 +1538,7 @@ int run_pchol(sadvio_ba_handle* h, double* S, int n, double* G, double tau, bool
             const int nb = n <= PCH_THREADS ? 32 : 16;
             int launched = 0, r = -1;
             for (int round = 0; round < 64 && r < 0; round++) {
-                const int np = round == 0 ? (n + nb - 1) / nb + 4 : 4;
+                const int np = round == 0 ? (n + nb - 1) / nb + 8 : 4;   // threshold pivoting leaves some panels partly filled; a launch after the end returns at once
                 for (int pnl = 0; pnl < np; pnl++, launched++) {
                     if (n <= PCH_THREADS) {
                         hipLaunchKernelGGL((k_pchol_panel_rx<1, 32>), dim3(1), dim3(PCH_THREADS), 0, h->stream, S, n, G, piv, dg, rank_d, dctl, launched == 0 ? 1 : 0, tau, safe);
@@ -2559,7 +2560,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         for (int w = 0; w < n_win; w++)
             for (int r = 0; r < h->world; r++) big_bw[w] = std::max(big_bw[w], (int)slots[((size_t)w * h->world + r) * 4]);
     }
-    std::vector<long long> big_linv_off(n_win, 0), big_M_off(n_win, 0), big_mid_off(n_win, 0);
+    std::vector<long long> big_linv_off(n_win, 0), big_M_off(n_win, 0), big_mid_off(n_win, 0), big_Lx_off(n_win, 0);
     {
         long long totm = 0;
         for (int w = 0; w < n_win; w++)
@@ -2572,8 +2573,15 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             if (b > 0 && K >= 22 && 2 * b <= (size_t)MAX_LDS_NP - 1) HIP_TRY(h->d_bcr.alloc(K * (8 * b * b + b * (b + 1) / 2 + (b / 6) * 36 + 5 * b)));
         }
         long long totM = 0;
-        for (int w = 0; w < n_win; w++) if (h->wins[w].d.ld) { big_M_off[w] = totM; totM += (long long)((h->wins[w].d.Np + WD - 1) / WD) * WD * WD; }
+        for (int w = 0; w < n_win; w++) if (h->wins[w].d.ld) { big_M_off[w] = totM; totM += (long long)((h->wins[w].d.Np + WD - 1) / WD) * (WD * WD + WD_LT); }   // M | the factors' tiles
         HIP_TRY(h->d_big_M.alloc((size_t)std::max<long long>(totM, 1)));
+        long long totL = 0;      // out-of-place panels of the dense wide-panel solver (k_wchol_step)
+        for (int w = 0; w < n_win; w++) {
+            const WinDev& d = h->wins[w].d;
+            const int nbp = d.dpf == 6 ? 6 : 5;
+            if (d.ld && !(big_bw[w] < d.Np && big_bw[w] + nbp <= MAX_LDS_NP) && d.Np >= 2 * WD) { big_Lx_off[w] = totL; totL += (long long)d.Np * d.ld; }
+        }
+        HIP_TRY(h->d_big_Lx.alloc((size_t)std::max<long long>(totL, 1)));
         long long tot = 0;
         for (int w = 0; w < n_win; w++) if (h->wins[w].d.ld) { big_linv_off[w] = tot; tot += 6LL * h->wins[w].d.Np; }
         HIP_TRY(h->d_big_linv.alloc((size_t)std::max<long long>(tot, 1)));
@@ -2742,6 +2750,27 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                             const size_t lds_la = std::max(sizeof(double) * wdla_lds_doubles() + 64, lds_s);
                             (void)hipFuncSetAttribute((const void*)k_wchol_syrk_la, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_la);
                             (void)hipFuncSetAttribute((const void*)k_wchol_trsm8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+                            const bool wdstep = wdla && !getenv("SADVIO_WD_R3");     // one launch per panel (round 4); SADVIO_WD_R3 = the trsm8 + syrk_la loop
+                            if (wdstep) {
+                                const int nsteps = (N + WD - 1) / WD;
+                                double* Ltw = Mw + (size_t)nsteps * WD * WD;
+                                double* Lx = h->d_big_Lx.p + big_Lx_off[w];
+                                const size_t lds_st = sizeof(double) * wdstep_lds_doubles() + 64;
+                                (void)hipFuncSetAttribute((const void*)k_wchol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_st);
+                                (void)hipFuncSetAttribute((const void*)k_wchol_backstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * WD * WDS));
+                                hipLaunchKernelGGL(k_wchol_diag16, dim3(1), dim3(SOLVE_THREADS), sizeof(double) * wd16_lds_doubles() + 64, h->stream, Sw, (long long)d.ld, yw, (double*)nullptr, N, 0, info, skip, Ltw);
+                                for (int st = 0; st + 1 < nsteps; st++) {
+                                    const int c0 = st * WD, m = N - (c0 + WD);
+                                    const int nt = (m + CH_TS - 1) / CH_TS;
+                                    hipLaunchKernelGGL(k_wchol_step, dim3(nt * (nt + 1) / 2 + 2), dim3(SOLVE_THREADS), lds_st, h->stream, Sw, (long long)d.ld, Lx, yw,
+                                                       Ltw + (size_t)st * WD_LT, Ltw + (size_t)(st + 1) * WD_LT, Mw + (size_t)st * WD * WD, Mw + (size_t)(st + 1) * WD * WD, N, c0, info, skip,
+                                                       (P.debug & 4096) && s == 3 && st == 1 ? h->d_dbg.p + 106 : (long long*)nullptr);
+                                }
+                                for (int bs = nsteps - 1; bs >= 0; bs--)
+                                    hipLaunchKernelGGL(k_wchol_backstep, dim3(1 + (bs + 1 < nsteps ? (bs * WD + 63) / 64 : 0)), dim3(SOLVE_THREADS), sizeof(double) * WD * WDS, h->stream,
+                                                       Lx, (long long)d.ld, yw, Mw, N, bs, info, skip);
+                                continue;
+                            }
                             int st = 0;
                             for (int c0 = 0; c0 < N; c0 += WD, st++) {
                                 if (wdla) {
@@ -2838,7 +2867,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         // launch-shape switches read from the environment inside enqueue() are part of the key too: a handle that already captured a
         // graph must not replay it when an A/B switch changes
         const int env_bits = (int)with_imu + 2 * (getenv("SADVIO_NO_FORK") != nullptr) + 4 * (getenv("SADVIO_WD_NOLA") != nullptr) + 8 * (getenv("SADVIO_WD_BACK1") != nullptr) +
-                             16 * (getenv("SADVIO_WD_OLD") != nullptr) + 32 * (getenv("SADVIO_NO_BCR") != nullptr) + 64 * (getenv("SADVIO_NO_PAR") != nullptr) + 128 * (getenv("SADVIO_NO_LPT") != nullptr);
+                             16 * (getenv("SADVIO_WD_OLD") != nullptr) + 32 * (getenv("SADVIO_NO_BCR") != nullptr) + 64 * (getenv("SADVIO_NO_PAR") != nullptr) + 128 * (getenv("SADVIO_NO_LPT") != nullptr) +
+                             256 * (getenv("SADVIO_WD_R3") != nullptr);
         const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type + 2 * (int)extras + 4 * (int)rare + 8 * (int)use_lm + 16 * env_bits};  // P (incl. decide_kernel) is part of the key
         memcpy(kp, ints, sizeof(ints)); kp += sizeof(ints);
         const size_t szs[3] = {lds_build, lds_back, lds_solve};
@@ -2871,6 +2901,10 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             fprintf(stderr, "\n[sadvio dbg] look-ahead workgroup of k_wchol_syrk_la, us since its start (loads landed, X slab in LDS | tiles updated | factored + inverted):");
             fprintf(stderr, " %.2f %.2f %.2f", (ts[91] - ts[90]) * 0.01, (ts[94] - ts[90]) * 0.01, (ts[95] - ts[90]) * 0.01);
             fprintf(stderr, " | waves after their tiles:"); for (int i = 98; i < 106; i++) fprintf(stderr, " %.2f", (ts[i] - ts[90]) * 0.01);
+            fprintf(stderr, "\n[sadvio dbg] k_wchol_step (panel 1), us since the workgroup's start: look-ahead (operands in LDS | substituted | block updated | factored) %.2f %.2f %.2f %.2f",
+                    (ts[107] - ts[106]) * 0.01, (ts[108] - ts[106]) * 0.01, (ts[109] - ts[106]) * 0.01, (ts[110] - ts[106]) * 0.01);
+            fprintf(stderr, " | tile workgroup 7, %.2f us after it (operands | substituted | end) %.2f %.2f %.2f | inverse workgroup, %.2f us after it: %.2f",
+                    (ts[114] - ts[106]) * 0.01, (ts[115] - ts[114]) * 0.01, (ts[116] - ts[114]) * 0.01, (ts[117] - ts[114]) * 0.01, (ts[120] - ts[106]) * 0.01, (ts[121] - ts[120]) * 0.01);
             fprintf(stderr, "\n[sadvio dbg] chol16 cycles since its first barrier (panel | trailing + next pivot, per block column):");
             for (int i = 65; i < 81; i++) fprintf(stderr, " %lld", ts[i] - ts[64]);
             fprintf(stderr, " | end %lld", ts[84] - ts[64]);

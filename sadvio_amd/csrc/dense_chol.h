@@ -883,9 +883,9 @@ constexpr int WD_T = WD / 16;   // 6 tile rows
 __host__ __device__ constexpr size_t wd16_lds_doubles() {
     return (size_t)c16_size(WD) + WD + C16_WORK + 16 * (WD_T + 1) + (size_t)(WD_T * (WD_T + 1) / 2) * 256 + (size_t)(SOLVE_THREADS / 64) * 256;
 }
-__device__ __forceinline__ void wd16_factor_and_invert(double* Im, double* __restrict__ y, double* __restrict__ Mg, int N, int c0, int* info);
+__device__ __forceinline__ void wd16_factor_and_invert(double* Im, double* __restrict__ y, double* __restrict__ Mg, int N, int c0, int* info, double* __restrict__ Lt = nullptr);
 __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_diag16(double* __restrict__ A, long long ld, double* __restrict__ y,
-                                                                double* __restrict__ Mg, int N, int c0, int* info, const int* skip) {
+                                                                double* __restrict__ Mg, int N, int c0, int* info, const int* skip, double* __restrict__ Lt = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (skip && *skip) return;
     if (*info != 0) return;
@@ -912,24 +912,32 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_diag16(double* __restri
     }
     for (int j = tid; j < WD; j += SOLVE_THREADS) Im[c16_index(WD, j)] = (c0 + j < N) ? y[c0 + j] : 0.0;
     __syncthreads();
-    wd16_factor_and_invert(Im, y, Mg, N, c0, info);
+    wd16_factor_and_invert(Im, y, Mg, N, c0, info, Lt);
 }
 
-// The image of a diagonal block (lower halves of the tiles + the right-hand-side row) -> its factor in place, the forward-substituted
-// right-hand side in y, M = L^-1 in Mg. The LDS carve behind the image is the one of k_wchol_diag16 (wd16_lds_doubles).
-__device__ __forceinline__ void wd16_factor_and_invert(double* Im, double* __restrict__ y, double* __restrict__ Mg, int N, int c0, int* info) {
+// The factor of a diagonal block as the later launches take it (k_wchol_step): the 21 tiles of the image after c16_solve<., false> —
+// panel tiles L_IJ, diagonal tiles L_JJ^-T with exact zeros below the diagonal — copied to Lt (WD_LT doubles). Returns "not finite".
+constexpr int WD_LT = (WD_T * (WD_T + 1) / 2) * 256;
+__device__ __forceinline__ bool wd16_store_tiles(const double* Im, double* __restrict__ Lt) {
+    bool bad = false;
+    for (int e = threadIdx.x; e < WD_LT; e += SOLVE_THREADS) {
+        const int t = e >> 8, q = e & 255, r = q & 15, c = q >> 4;
+        int I = 0, rem = t;
+        while (rem >= I + 1) { rem -= I + 1; I++; }
+        double v = Im[e];
+        if (rem == I && r > c) v = 0.0;        // diagonal tile: L_II^-T is upper triangular (element (r, c) at c * 16 + r)
+        if (!(fabs(v) < 1e300)) bad = true;    // a non-positive pivot turned into NaN / inf
+        Lt[e] = v;
+    }
+    return bad;
+}
+
+// M = L^-1 (row-major WD x WD -> Mg) from the tiles of a factored block (Im: panel tiles L_IJ, diagonal tiles L_JJ^-T) by block
+// anti-diagonals: M_II = L_II^-1 (the diagonal tile holds its transpose), M_IJ = -L_II^-1 sum_{K=J}^{I-1} L_IK M_KJ. Mi: 21 tiles of
+// LDS, scr: one tile per wave. Every thread of the workgroup calls it.
+__device__ __forceinline__ void wd16_invert(const double* Im, double* Mi, double* scr_base, double* __restrict__ Mg, int c0, int* info) {
     const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6, nwv = SOLVE_THREADS / 64;
-    double* xs = Im + c16_size(WD);
-    double* pub = xs + WD;
-    double* yv = pub + C16_WORK;
-    double* Mi = yv + 16 * (WD_T + 1);             // M = L^-1, tile (I, J), I >= J, at c16_tile(I, J) * 256
-    double* scr = Mi + (size_t)(WD_T * (WD_T + 1) / 2) * 256 + (size_t)wv * 256;
-    c16_symmetrize(Im, WD_T + 1);
-    __syncthreads();
-    (void)c16_solve<1, false>(Im, WD, xs, pub, yv, nullptr);
-    // forward-substituted rhs: first rows of the tiles of row WD
-    for (int j = tid; j < WD && c0 + j < N; j += SOLVE_THREADS) y[c0 + j] = Im[(c16_tile(WD_T, j >> 4) << 8) + (j & 15) * 16];
-    // M = L^-1 by block anti-diagonals: M_II = L_II^-1 (the diagonal tile holds its transpose), M_IJ = -L_II^-1 sum_{K=J}^{I-1} L_IK M_KJ
+    double* scr = scr_base + (size_t)wv * 256;
     const int lr = ln & 15, lk = ln >> 4;
     for (int e = tid; e < WD_T * 256; e += SOLVE_THREADS) {
         const int I = e >> 8, q = e & 255, r = q & 15, c = q >> 4;
@@ -958,6 +966,25 @@ __device__ __forceinline__ void wd16_factor_and_invert(double* Im, double* __res
         Mg[e] = v;
     }
     if (bad) *info = c0 + 1;
+}
+
+// The image of a diagonal block (lower halves of the tiles + the right-hand-side row) -> its factor in place, the forward-substituted
+// right-hand side in y, M = L^-1 in Mg (if given), the factor's tiles in Lt (if given). The LDS carve behind the image is the one of
+// k_wchol_diag16 (wd16_lds_doubles).
+__device__ __forceinline__ void wd16_factor_and_invert(double* Im, double* __restrict__ y, double* __restrict__ Mg, int N, int c0, int* info, double* __restrict__ Lt) {
+    const int tid = threadIdx.x;
+    double* xs = Im + c16_size(WD);
+    double* pub = xs + WD;
+    double* yv = pub + C16_WORK;
+    double* Mi = yv + 16 * (WD_T + 1);             // M = L^-1, tile (I, J), I >= J, at c16_tile(I, J) * 256
+    double* scr = Mi + (size_t)(WD_T * (WD_T + 1) / 2) * 256;
+    c16_symmetrize(Im, WD_T + 1);
+    __syncthreads();
+    (void)c16_solve<1, false>(Im, WD, xs, pub, yv, nullptr);
+    // forward-substituted rhs: first rows of the tiles of row WD
+    for (int j = tid; j < WD && c0 + j < N; j += SOLVE_THREADS) y[c0 + j] = Im[(c16_tile(WD_T, j >> 4) << 8) + (j & 15) * 16];
+    if (Lt && wd16_store_tiles(Im, Lt)) *info = c0 + 1;
+    if (Mg) wd16_invert(Im, Mi, scr, Mg, c0, info);
 }
 
 // X = A[s .. N, c0 .. c0 + WD) * M^T, 64 rows per workgroup
@@ -1341,6 +1368,237 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_syrk_la(double* __restr
         for (int rg = 0; rg < 4; rg++)
             if (ok[rg]) A[addr[rg]] = c[rg];
     }
+}
+
+// ---- round 4: ONE launch per 96 columns ---------------------------------------------------------------------------------------------
+// The round-3 loop was trsm8 -> syrk_la per panel: two dependent launches, and the look-ahead workgroup's chain was
+// factor (13.7 us) + M = L^-1 (12 us) because the NEXT launch's panel product X = A M^T needed the explicit inverse. Here the panel
+// solve is a block SUBSTITUTION against the factor's own tiles (wd_subst_strip: X_j = (A_j - sum_{q<j} X_q L_jq^T) L_jj^-T on 16 x 16
+// MFMA tiles, L_jj^-T being what chol16 leaves in the diagonal tile), so
+//   * the inverse leaves the chain: M (which only the back-substitution reads) is built by a spare workgroup of the FOLLOWING launch,
+//   * the panel solve needs no launch of its own: every tile workgroup substitutes the two 64-row strips of the panel it is about to
+//     contract (redundantly - 136 workgroups on 256 CUs - instead of waiting for a launch that does it once),
+//   * the substituted panel goes OUT of place (Lx), because other workgroups still read the unsubstituted rows.
+// Launch st (columns c0 = 96 st): workgroup 0 = look-ahead (substitute the next block's 96 panel rows, update the block, factor it,
+// store its tiles for launch st + 1; the last block is inverted on the spot), workgroups 1 .. npair = 64 x 64 tiles of the trailing
+// update (the diagonal ones also write their strip of X and apply it to the right-hand side), the last workgroup = M_st.
+// strip element (r < 16, c < WD) at `at(r, c)`; Lt: the factor's tiles in LDS
+template <class At>
+__device__ __forceinline__ void wd_subst_strip(const double* Lt, At at, int lr, int lk) {
+#pragma unroll
+    for (int j = 0; j < WD_T; j++) {
+        c16_d4 t, t2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) t[rg] = *at(lk + 4 * rg, 16 * j + lr);
+#pragma unroll
+        for (int q = 0; q < j; q++) {
+            const double* Lq = Lt + (c16_tile(j, q) << 8);
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { a[u] = -*at(lr, 16 * q + 4 * u + lk); b[u] = Lq[(4 * u + lk) * 16 + lr]; }   // X_q[row][k], L_jq[col][k]
+            t = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], t, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], t2, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], t, 0, 0, 0);
+            t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], t2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) *at(lk + 4 * rg, 16 * j + lr) = t[rg] + t2[rg];
+        wave_lds_fence();
+        const double* Ld = Lt + (c16_tile(j, j) << 8);
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = *at(lr, 16 * j + 4 * u + lk); b[u] = Ld[lr * 16 + 4 * u + lk]; }          // T[row][k], (L_jj^-T)[k][col]
+        c16_d4 x = {0.0, 0.0, 0.0, 0.0}, x2 = {0.0, 0.0, 0.0, 0.0};
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], x, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], x2, 0, 0, 0);
+        x = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], x, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], x2, 0, 0, 0);
+        wave_lds_fence();
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) *at(lk + 4 * rg, 16 * j + lr) = x[rg] + x2[rg];
+        wave_lds_fence();
+    }
+}
+
+__host__ __device__ constexpr size_t wdstep_lds_doubles() {
+    return wdla_lds_doubles() > (size_t)2 * CH_TS * WDS + WD_LT ? wdla_lds_doubles() : (size_t)2 * CH_TS * WDS + WD_LT;
+}
+__global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_step(double* __restrict__ A, long long ld, double* __restrict__ Lx, double* __restrict__ y,
+                                                              const double* __restrict__ Lt_cur, double* __restrict__ Lt_next, double* __restrict__ Mg_cur,
+                                                              double* __restrict__ Mg_next, int N, int c0, int* info, const int* skip, long long* dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (skip && *skip) return;
+    if (*info != 0) return;
+    const int s = c0 + WD;
+    const int m = N - s;
+    if (m <= 0) return;
+    const int nt = (m + CH_TS - 1) / CH_TS;
+    const int npair = nt * (nt + 1) / 2;
+    const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int lr = ln & 15, lk = ln >> 4;
+    const int bid = (int)blockIdx.x - 1;   // workgroup 0 is dispatched first: the look-ahead block, the longest chain of the launch
+    long long* dts = dbg && tid == 0 ? (bid < 0 ? dbg : bid == 7 ? dbg + 8 : bid == npair ? dbg + 14 : nullptr) : nullptr;   // SADVIO_DEBUG & 4096: phase stamps
+    if (dts) dts[0] = wall_clock64();
+    constexpr int NLT = (WD_LT + SOLVE_THREADS - 1) / SOLVE_THREADS;   // 11 loads per thread bring the factor's tiles
+    if (bid < 0) {
+        // ---- the next diagonal block [s, s + WD) ----
+        double* Im = (double*)smem;
+        double (*XT)[WXS] = (double (*)[WXS])(Im + c16_size(WD) + WD + C16_WORK + 16 * (WD_T + 1));   // transposed slab, see k_wchol_syrk_la
+        constexpr int NX = WD * WD / SOLVE_THREADS, NTL = WD_T * (WD_T + 1) / 2 + WD_T, NW = SOLVE_THREADS / 64, TPW = (NTL + NW - 1) / NW;
+        double vx[NX], vl[NLT];
+#pragma unroll
+        for (int u = 0; u < NLT; u++) { const int e = tid + u * SOLVE_THREADS; vl[u] = Lt_cur[min(e, WD_LT - 1)]; }
+#pragma unroll
+        for (int u = 0; u < NX; u++) {
+            const int e = tid + u * SOLVE_THREADS;
+            const int r = e / WD, c = e - r * WD;
+            const double v = A[(long long)min(s + r, N - 1) * ld + c0 + c];
+            vx[u] = (s + r < N) ? v : 0.0;
+        }
+        const double vy = y[c0 + min(tid, WD - 1)];
+        d4 acc0[TPW];
+#pragma unroll
+        for (int w = 0; w < TPW; w++) {
+            const int t = min(wv + w * NW, NTL - 1);
+            int I = 0, r = t;
+            while (r >= I + 1) { r -= I + 1; I++; }          // t < 21: lower tile (I, J) of the block; t = 21 + J: the right-hand-side tile (WD_T, J)
+            const int J = r;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 16 * I + lk + 4 * q, j = 16 * J + lr;
+                const double v = A[(long long)min(s + i, N - 1) * ld + min(s + min(j, i), N - 1)];
+                const double vr = y[min(s + j, N - 1)];
+                acc0[w][q] = I == WD_T ? ((lk + 4 * q == 0 && s + j < N) ? vr : 0.0) : (j <= i ? ((s + i < N) ? v : (i == j ? 1.0 : 0.0)) : 0.0);
+            }
+        }
+        for (int e = tid; e < 256; e += SOLVE_THREADS) Im[(c16_tile(WD_T, WD_T) << 8) + e] = 0.0;   // the tile behind the right-hand side's last column block
+        for (int e = tid; e < 15 * WD; e += SOLVE_THREADS) XT[e / 15][WD + 1 + e % 15] = 0.0;
+#pragma unroll
+        for (int u = 0; u < NLT; u++) { const int e = tid + u * SOLVE_THREADS; if (e < WD_LT) Im[e] = vl[u]; }   // the factor's tiles sit in the image area until the update
+#pragma unroll
+        for (int u = 0; u < NX; u++) { const int e = tid + u * SOLVE_THREADS; XT[e - (e / WD) * WD][e / WD] = vx[u]; }
+        if (tid < WD) XT[tid][WD] = vy;
+        __syncthreads();
+        if (dts) dts[1] = wall_clock64();
+        if (wv < WD_T) wd_subst_strip(Im, [&](int r, int c) { return &XT[c][16 * wv + r]; }, lr, lk);   // the block's 96 panel rows -> X_next
+        __syncthreads();
+        if (dts) dts[2] = wall_clock64();
+#pragma unroll
+        for (int w = 0; w < TPW; w++) {
+            const int t = wv + w * NW;
+            if (t >= NTL) break;
+            int I = 0, r = t;
+            while (r >= I + 1) { r -= I + 1; I++; }
+            const int J = r;
+            double a[4 * WD_T], b[4 * WD_T];
+#pragma unroll
+            for (int k4 = 0; k4 < 4 * WD_T; k4++) { a[k4] = -XT[4 * k4 + lk][16 * I + lr]; b[k4] = XT[4 * k4 + lk][16 * J + lr]; }
+            d4 acc = acc0[w], acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k4 = 0; k4 < 4 * WD_T; k4 += 2) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k4], b[k4], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k4 + 1], b[k4 + 1], acc2, 0, 0, 0);
+            }
+            double* ct = Im + (c16_tile(I, J) << 8);     // (the factor's tiles that sat here were last read before the barrier above)
+#pragma unroll
+            for (int q = 0; q < 4; q++) ct[lr * 16 + lk + 4 * q] = acc[q] + acc2[q];   // register q of lane (lr, lk) = C[lk + 4 q][lr]
+        }
+        __syncthreads();
+        if (dts) dts[3] = wall_clock64();
+        const bool last = s + WD >= N;
+        wd16_factor_and_invert(Im, y, last ? Mg_next : (double*)nullptr, N, s, info, last ? (double*)nullptr : Lt_next);
+        if (dts) dts[4] = wall_clock64();
+        return;
+    }
+    if (bid == npair) {
+        // ---- M of THIS panel's block, for the back-substitution ----
+        double* Ls = (double*)smem;
+        double* Mi = Ls + WD_LT;
+        double* scr = Mi + WD_LT;
+        for (int e = tid; e < WD_LT; e += SOLVE_THREADS) Ls[e] = Lt_cur[e];
+        __syncthreads();
+        wd16_invert(Ls, Mi, scr, Mg_cur, c0, info);
+        if (dts) dts[1] = wall_clock64();
+        return;
+    }
+    // ---- tile (ti, tj) of the trailing matrix ----
+    double (*Pi)[WDS] = (double (*)[WDS])smem;
+    double (*Pj)[WDS] = (double (*)[WDS])(smem + sizeof(double) * CH_TS * WDS);
+    double* Ls = (double*)(smem + sizeof(double) * 2 * CH_TS * WDS);
+    int ti = 0, rem = bid;
+    while (rem >= ti + 1) { rem -= ti + 1; ti++; }
+    const int tj = rem;
+    const int i0 = ti * CH_TS, j0 = tj * CH_TS;
+    {
+        constexpr int NP = CH_TS * WD / SOLVE_THREADS;   // 12
+        double vi[NP], vj[NP], vl[NLT];
+#pragma unroll
+        for (int u = 0; u < NLT; u++) { const int e = tid + u * SOLVE_THREADS; vl[u] = Lt_cur[min(e, WD_LT - 1)]; }
+#pragma unroll
+        for (int u = 0; u < NP; u++) {
+            const int e = tid + u * SOLVE_THREADS;
+            const int r = e / WD, c = e - r * WD;
+            const double a = A[(long long)(s + min(i0 + r, m - 1)) * ld + c0 + c];
+            const double b = A[(long long)(s + min(j0 + r, m - 1)) * ld + c0 + c];
+            vi[u] = i0 + r < m ? a : 0.0;
+            vj[u] = j0 + r < m ? b : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NLT; u++) { const int e = tid + u * SOLVE_THREADS; if (e < WD_LT) Ls[e] = vl[u]; }
+#pragma unroll
+        for (int u = 0; u < NP; u++) { const int e = tid + u * SOLVE_THREADS; const int r = e / WD, c = e - r * WD; Pi[r][c] = vi[u]; Pj[r][c] = vj[u]; }
+    }
+    __syncthreads();
+    if (dts) dts[1] = wall_clock64();
+    {
+        const int rb = wv & 3;
+        if (wv < 4) wd_subst_strip(Ls, [&](int r, int c) { return &Pi[16 * rb + r][c]; }, lr, lk);
+        else if (ti != tj) wd_subst_strip(Ls, [&](int r, int c) { return &Pj[16 * rb + r][c]; }, lr, lk);
+    }
+    __syncthreads();
+    if (dts) dts[2] = wall_clock64();
+    if (ti == tj) Pj = Pi;
+    const int ib = wv & 3;
+    for (int jb = 2 * (wv >> 2); jb < 2 * (wv >> 2) + 2; jb++) {
+        if (ti == tj && jb > ib) continue;
+        const int rbase = i0 + 16 * ib, cbase = j0 + 16 * jb;
+        if (rbase >= m || cbase >= m) continue;
+        d4 c;
+        long long addr[4];
+        bool ok[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+            const int row = rbase + lk + 4 * rg, col = cbase + lr;
+            ok[rg] = row < m && col < m && col <= row && !(row < WD && col < WD);   // (the look-ahead workgroup's block)
+            addr[rg] = (long long)(s + (row < m ? row : m - 1)) * ld + s + (col < m ? col : m - 1);
+            c[rg] = ok[rg] ? A[addr[rg]] : 0.0;
+        }
+        for (int kk = 0; kk < WD; kk += 24) {   // 6 k-steps per batch of LDS loads
+            double a[6], b[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++) { a[u] = -Pi[16 * ib + lr][kk + 4 * u + lk]; b[u] = Pj[16 * jb + lr][kk + 4 * u + lk]; }
+#pragma unroll
+            for (int u = 0; u < 6; u++) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+            if (ok[rg]) A[addr[rg]] = c[rg];
+    }
+    if (ti == tj) {
+        // this strip of the substituted panel -> Lx, and its share of the right-hand side (rows of the look-ahead block: that workgroup's)
+        for (int e = tid; e < CH_TS * WD; e += SOLVE_THREADS) {
+            const int r = e / WD, c = e - r * WD;
+            if (i0 + r < m) Lx[(long long)(s + i0 + r) * ld + c0 + c] = Pi[r][c];
+        }
+        const int r = tid >> 3, part = tid & 7;      // 64 rows x 8 column groups of 12
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < WD / 8; u++) { const int c = part + 8 * u; acc += Pi[r][c] * y[c0 + c]; }
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+        if (part == 0 && i0 + r < m && i0 + r >= WD) y[s + i0 + r] -= acc;
+    }
+    if (dts) dts[3] = wall_clock64();
 }
 
 // x = L^-T z in place: super-steps in reverse, one workgroup. Right-looking: once the 96 unknowns x_d of a step are

@@ -96,6 +96,8 @@ __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_step(double* __restrict_
 constexpr int PCH_THREADS = 1024;
 constexpr int PCH_MAXN = 2048;
 constexpr int PCH_NB = 32;
+constexpr double PCH_THETA = 0.1;    // relaxed pivoting: a pivot is at least this fraction of the largest remaining diagonal
+constexpr int PCH_STRICT_TAIL = 32;   // relaxed pivoting (k_pchol_panel_rx): the last indices are pivoted one arg max at a time
 __global__ __launch_bounds__(PCH_THREADS) void k_pchol_panel(double* __restrict__ S, int n, double* __restrict__ G, int* __restrict__ piv,
                                                              double* __restrict__ dg, int* __restrict__ ctl, double* __restrict__ dctl, int k0, double tau_rel) {
     __shared__ double d[PCH_MAXN];
@@ -302,10 +304,10 @@ __global__ __launch_bounds__(PCH_THREADS) void k_pchol_panel_np(const double* __
 // "safe" remaining diagonals of every wave, sorted - requests their NB rows of S together, and then runs the NB columns with one
 // barrier each: the owner of pivot c publishes its remaining diagonal and its entries of the panel's earlier rows, every thread
 // finishes its entry of row c from registers. A candidate whose diagonal has meanwhile dropped below the safe bound (it depends on
-// the pivots taken before it in this panel) is skipped and competes again in the next panel. "Safe": d_i > tau and
-// d_i >= safe_rel * a_ii (a_ii = the original diagonal, safe_rel ~ 1e3 n eps). When no safe index is left but some diagonal is still
-// above tau, the panel falls back to strict pivoting (arg max per column, as k_pchol_panel_np): the rank decision is taken by the
-// same rule as before, on the handful of near-dependent indices only.
+// the pivots taken before it in this panel) is skipped and competes again in the next panel. "Safe": d_i > tau,
+// d_i >= PCH_THETA max_j d_j (threshold pivoting) and d_i >= safe_rel * a_ii (a_ii = the original diagonal, safe_rel ~ 1e3 n eps). When no safe index is left but some diagonal is still
+// above tau - and always for the last PCH_STRICT_TAIL indices - the panel falls back to strict pivoting (arg max per column, as
+// k_pchol_panel_np): the rank decision is taken by the same rule, in the same greedy order, as before.
 // The panel's first row is no longer known to the host: ctl[1] = rows written so far, ctl[2] = first row of the last panel (what
 // the trailing update reads); rows [ctl[1], ctl[2] + NB) are zeroed so that the update can always contract NB rows.
 // dg: [0, n) remaining diagonal, [n, 2n) original diagonal.
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(PCH_THREADS) void k_pchol_panel_rx(const double* __
     __shared__ double cval[NB];
     __shared__ int cidx[NB], ord[NB];
     __shared__ double wmax[NW];
-    __shared__ int widx[NW];
+    __shared__ int widx[NW], wcnt[NW];
     const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
     if (ctl[0] >= 0) return;              // the factorisation stopped in an earlier panel
     const int k0 = first ? 0 : ctl[1];
@@ -346,18 +348,34 @@ __global__ __launch_bounds__(PCH_THREADS) void k_pchol_panel_rx(const double* __
     }
     const double tau = first ? pd[0][0] : dctl[0];
     __syncthreads();
-    // ---- candidates: the PW largest safe remaining diagonals of every wave; beside them the arg max over ALL remaining indices ----
+    // ---- the arg max over ALL remaining indices (the stop test, the threshold, the strict panel's first pivot) ----
     {
-        double ball = -1.0; int iall = 0;
-        bool taken[EPT];
+        double ball = -1.0; int iall = 0, lw = 0;
 #pragma unroll
-        for (int e = 0; e < EPT; e++) { taken[e] = false; if (!done[e] && d[e] > ball) { ball = d[e]; iall = tid + e * PCH_THREADS; } }
+        for (int e = 0; e < EPT; e++) {
+            if (!done[e] && d[e] > ball) { ball = d[e]; iall = tid + e * PCH_THREADS; }
+            lw += __popcll(__ballot(!done[e]));
+        }
         const double wm = wave_max(ball);
         const int src = __ffsll((long long)__ballot(ball == wm)) - 1;
         const int wi = __builtin_amdgcn_readlane(iall, src);
-        if (ln == 0) { wmax[wv] = wm; widx[wv] = wi; }
+        if (ln == 0) { wmax[wv] = wm; widx[wv] = wi; wcnt[wv] = lw; }
         if (tid < NB) cval[tid] = -1.0;
-        __syncthreads();
+    }
+    __syncthreads();
+    double m_all = wmax[0]; int j_all = widx[0], left = 0;
+#pragma unroll
+    for (int q = 1; q < NW; q++) if (wmax[q] > m_all) { m_all = wmax[q]; j_all = widx[q]; }
+#pragma unroll
+    for (int q = 0; q < NW; q++) left += wcnt[q];
+    // ---- candidates: the largest remaining diagonals of every wave that pass the threshold test d_i >= theta max_j d_j (threshold
+    //      pivoting: the growth of the factor, hence the accuracy of the pivots that follow, stays within 1 / theta of the greedy order's)
+    //      and the safety test against their own rounding noise ----
+    const double thr = PCH_THETA * m_all;
+    {
+        bool taken[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) taken[e] = false;
         // slot r * nwa + wv: round r of wave wv, nwa = waves that own indices at all (a small system gives its few waves more rounds)
         const int nwa = EPT > 1 ? NW : min(NW, (n + 63) >> 6);
         const int pw = (NB + nwa - 1) / nwa;
@@ -366,7 +384,7 @@ __global__ __launch_bounds__(PCH_THREADS) void k_pchol_panel_rx(const double* __
             double best = -1.0; int bi = 0, be = 0;
 #pragma unroll
             for (int e = 0; e < EPT; e++)
-                if (!done[e] && !taken[e] && d[e] > tau && d[e] >= safe_rel * a0[e] && d[e] > best) { best = d[e]; bi = tid + e * PCH_THREADS; be = e; }
+                if (!done[e] && !taken[e] && d[e] > tau && d[e] >= thr && d[e] >= safe_rel * a0[e] && d[e] > best) { best = d[e]; bi = tid + e * PCH_THREADS; be = e; }
             const double cm = wave_max(best);
             const int cs = __ffsll((long long)__ballot(best == cm)) - 1;
             const int ci = __builtin_amdgcn_readlane(bi, cs);
@@ -378,12 +396,12 @@ __global__ __launch_bounds__(PCH_THREADS) void k_pchol_panel_rx(const double* __
         }
     }
     __syncthreads();
-    double m_all = wmax[0]; int j_all = widx[0];
-#pragma unroll
-    for (int q = 1; q < NW; q++) if (wmax[q] > m_all) { m_all = wmax[q]; j_all = widx[q]; }
     int nc = 0;
 #pragma unroll
     for (int q = 0; q < NB; q++) nc += cval[q] > 0.0 ? 1 : 0;
+    // The END of the factorisation stays strictly pivoted: which index is left over when a null direction finally shows decides how
+    // well its (zero) pivot is computed - the greedy order keeps the eliminated block well conditioned, an arbitrary one need not.
+    nc = min(nc, max(left - PCH_STRICT_TAIL, 0));
     if (tid < NB) {
         const double v = cval[tid];
         int rk = 0;
@@ -416,7 +434,7 @@ __global__ __launch_bounds__(PCH_THREADS) void k_pchol_panel_rx(const double* __
             }
             __syncthreads();
             const double dj = pd[p][0];
-            if (dj > tau && dj >= safe_rel * pd[p][1]) {
+            if (dj > tau && dj >= thr && dj >= safe_rel * pd[p][1]) {
                 const double lkk = sqrt(dj), inv = 1.0 / lkk;
                 const int k = k0 + cnt;
 #pragma unroll
