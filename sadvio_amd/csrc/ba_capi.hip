@@ -1887,11 +1887,51 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         // factor's extra column. No eigen-decomposition.
         const int n1 = n + 1;
         const long long nn1 = (long long)n1 * n1;
+        bool unpivoted = false;
+        if (n >= 2 * WD && !getenv("SADVIO_MARG_PIVOTED")) {
+            // A prior that carries an earlier prior is normally of full rank: then the factor needs no pivoting and the wide-panel
+            // solver of the dense reduced systems (dense_chol.h: k_wchol_diag16 + k_wchol_step, one launch per 96 columns, bk riding
+            // along as its right-hand side) delivers L and z = L^-1 bk in a third of the pivoted factorisation's time. Every pivot is
+            // tested afterwards (k_wfac_diag); one that is not safely positive sends the call to the rank-revealing route below.
+            const int nsteps = (n + WD - 1) / WD;
+            const double tau_rel = pchol_tau(n, rq->eig_cut_mode);
+            HIP_TRY(M.Vs.alloc(std::max((size_t)nsteps * (WD_LT + WD_T * 256) + 8, (size_t)big * big)));
+            double* Ltw = M.Vs.p; double* Ld = Ltw + (size_t)nsteps * WD_LT;
+            int* info = M.flag.p;
+            HIP_TRY(hipMemsetAsync(info, 0, sizeof(int) * 2, h->stream));
+            HIP_TRY(hipMemcpyAsync(M.V.p, M.Ak.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(M.newr.p, M.bk.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+            const size_t lds_st = sizeof(double) * wdstep_lds_doubles() + 64;
+            (void)hipFuncSetAttribute((const void*)k_wchol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_st);
+            (void)hipFuncSetAttribute((const void*)k_wchol_diag16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * wd16_lds_doubles() + 64));
+            hipLaunchKernelGGL(k_wchol_diag16, dim3(1), dim3(SOLVE_THREADS), sizeof(double) * wd16_lds_doubles() + 64, h->stream, M.V.p, (long long)n, M.newr.p, (double*)nullptr, n, 0, info,
+                               (const int*)nullptr, Ltw);
+            for (int st = 0; st + 1 < nsteps; st++) {
+                const int c0 = st * WD, mrem = n - (c0 + WD);
+                const int nt = (mrem + CH_TS - 1) / CH_TS;
+                hipLaunchKernelGGL(k_wchol_step, dim3(nt * (nt + 1) / 2 + 2), dim3(SOLVE_THREADS), lds_st, h->stream, M.V.p, (long long)n, M.G.p, M.newr.p, Ltw + (size_t)st * WD_LT,
+                                   Ltw + (size_t)(st + 1) * WD_LT, (double*)nullptr, (double*)nullptr, n, c0, info, (const int*)nullptr, (long long*)nullptr);
+            }
+            hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(256), 0, h->stream, M.Ak.p, n, M.ev.p);
+            hipLaunchKernelGGL(k_wfac_diag, dim3(nsteps * WD_T), dim3(64), 0, h->stream, Ltw, n, M.Ak.p, (long long)n, tau_rel, M.ev.p, 1024.0 * n * 2.220446049250313e-16, Ld, info + 1);
+            int st2[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(st2, info, sizeof(st2), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (st2[0] == 0 && st2[1] == 0) {
+                unpivoted = true;
+                nf = n;
+                hipLaunchKernelGGL(k_wfac_pack, dim3((unsigned)(((long long)n * n + 255) / 256)), dim3(256), 0, h->stream, M.G.p, (long long)n, Ltw, Ld, M.newr.p, n, M.newJ.p, M.newr.p);
+                HIP_TRY(PR.step_of.alloc(n));
+                hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, h->stream, PR.step_of.p, n);
+            }
+        }
+        if (!unpivoted) {
         hipLaunchKernelGGL(k_marg_aug_init, dim3((unsigned)((nn1 + 255) / 256)), dim3(256), 0, h->stream, M.Ak.p, M.bk.p, n, M.V.p);
         nf = run_pchol(h, M.V.p, n1, M.G.p, pchol_tau(n, rq->eig_cut_mode), false);
         if (nf < 0) { h->err = "marginalize: HIP error in the pivoted Cholesky"; return SADVIO_E_HIP; }
         if (nf > n) nf = n;
-        if (nf > 0) {
+        }
+        if (!unpivoted && nf > 0) {
             const long long cnt = (long long)nf * n1;
             hipLaunchKernelGGL(k_marg_pack_chol, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, M.G.p, n, h->d_jac_ints.p + n1, M.newJ.p, M.newr.p);
             HIP_TRY(PR.step_of.alloc(n));

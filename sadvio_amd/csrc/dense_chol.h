@@ -1507,12 +1507,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_step(double* __restrict
         __syncthreads();
         if (dts) dts[3] = wall_clock64();
         const bool last = s + WD >= N;
-        wd16_factor_and_invert(Im, y, last ? Mg_next : (double*)nullptr, N, s, info, last ? (double*)nullptr : Lt_next);
+        wd16_factor_and_invert(Im, y, last ? Mg_next : (double*)nullptr, N, s, info, Lt_next);
         if (dts) dts[4] = wall_clock64();
         return;
     }
     if (bid == npair) {
         // ---- M of THIS panel's block, for the back-substitution ----
+        if (!Mg_cur) return;       // (factor only: sadvio_ba_marginalize)
         double* Ls = (double*)smem;
         double* Mi = Ls + WD_LT;
         double* scr = Mi + WD_LT;
@@ -1666,6 +1667,66 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_backsolve(const double*
         }
         __syncthreads();
     }
+}
+
+// ---- the wide-panel factor as a prior (sadvio_ba_marginalize, Cholesky form, full-rank Ak) ------------------------------------------
+// k_wchol_diag16 + k_wchol_step leave L in three places: the panels below the 96 x 96 diagonal blocks (Lx, row-major), the tiles of
+// the diagonal blocks (Lt: L_IK for I > K; the diagonal tiles hold U = L_II^-T), and z = L^-1 rhs in y. k_wfac_diag inverts the
+// diagonal tiles back (L_II = (U^-1)^T, 16 threads per tile) and tests the pivots; k_wfac_pack writes J = L^T, r0 = -z.
+// flag |= 1: a pivot is not finite, not above tau, or below safe_rel of its original diagonal entry (the caller falls back to the
+// pivoted factorisation).
+__global__ void k_diag_max(const double* __restrict__ A, int n, double* __restrict__ out) {      // out[0] = max_i A[i][i], one workgroup
+    __shared__ double sh[256];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmax(m, A[(size_t)i * n + i]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s2 = blockDim.x >> 1; s2 > 0; s2 >>= 1) { if ((int)threadIdx.x < s2) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s2]); __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+__global__ void k_iota(int* __restrict__ v, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] = i; }
+// tau_rel >= 0: tau = tau_rel * dmax[0], else tau = -tau_rel (the pivoted factorisation's convention)
+__global__ __launch_bounds__(64) void k_wfac_diag(const double* __restrict__ Ltw, int N, const double* __restrict__ A0, long long ld0, double tau_rel,
+                                                  const double* __restrict__ dmax, double safe_rel, double* __restrict__ Ld, int* __restrict__ flag) {
+    const double tau = tau_rel >= 0.0 ? tau_rel * dmax[0] : -tau_rel;
+    const int b = blockIdx.x / WD_T, I = blockIdx.x - b * WD_T, c = threadIdx.x;
+    const double* U = Ltw + (size_t)b * WD_LT + ((size_t)c16_tile(I, I) << 8);   // element (r, c) at c * 16 + r, upper triangular
+    double* out = Ld + (size_t)blockIdx.x * 256;
+    if (c >= 16) return;
+    const int g = b * WD + 16 * I + c;          // global index of this thread's column
+    // column c of U^-1: x[c] = 1 / U[c][c], x[r] = -(sum_{q = r + 1 .. c} U[r][q] x[q]) / U[r][r]
+    double x[16];
+#pragma unroll
+    for (int r = 15; r >= 0; r--) {
+        double acc = r == c ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 15; q > r; q--) acc -= (q <= c) ? U[q * 16 + r] * x[q] : 0.0;
+        x[r] = r <= c ? acc / U[r * 16 + r] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[c * 16 + k] = x[k];       // L_II[i = c][k] = (U^-1)[k][c]
+    if (g < N) {
+        const double lkk = 1.0 / U[c * 16 + c], piv = lkk * lkk, a0 = A0[(long long)g * ld0 + g];
+        if (!(piv > tau && piv >= safe_rel * a0 && piv < 1e300 && lkk > 0.0)) atomicOr(flag, 1);
+    }
+}
+
+__global__ void k_wfac_pack(const double* __restrict__ Lx, long long ld, const double* __restrict__ Ltw, const double* __restrict__ Ld, const double* z, int N,
+                            double* __restrict__ J, double* r0) {      // (r0 may be z: entry k is read and written by one thread)
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * N) return;
+    const int k = (int)(idx / N), i = (int)(idx - (long long)k * N);     // J[k][i] = L[i][k]
+    double v = 0.0;
+    if (i >= k) {
+        const int bi = i / WD, bk = k / WD;
+        if (bi > bk) v = Lx[(long long)i * ld + k];
+        else {
+            const int I = (i - bi * WD) >> 4, K = (k - bk * WD) >> 4;
+            v = I > K ? Ltw[(size_t)bi * WD_LT + ((size_t)c16_tile(I, K) << 8) + (k & 15) * 16 + (i & 15)] : Ld[((size_t)bi * WD_T + I) * 256 + (i & 15) * 16 + (k & 15)];
+        }
+    }
+    J[idx] = v;
+    if (i == 0) r0[k] = -z[k];
 }
 
 }  // namespace sadvio
