@@ -194,7 +194,7 @@ struct PriorState {
 // per call cost more than the kernels between them.
 struct TriLevel { int first, count, max_m, max_n; };
 struct MargScratch {
-    DevBuf<double> A, b, G, V, ev, Vs, Ainv, T, Ak, bk, newJ, newr, lastJ, lastr, L, Tb, Zt, S, mi, jsel, lam;
+    DevBuf<double> A, b, G, V, ev, Vs, Ainv, T, Ak, bk, newJ, newr, lastJ, lastr, L, Tb, Zt, S, mi, jsel, lam, wtmp;
     DevBuf<int> ditems, flag, sel, lastcol, piv_of, lc, piv_mm;
     DevBuf<MargSmall> small;
     DevBuf<NfrSpecC> spec;
@@ -1619,6 +1619,34 @@ double pchol_tau(int n, int eig_cut_mode) {
     return eig_cut_mode == SADVIO_EIG_CUT_NOISE_FLOOR ? 4.0 * n * 2.220446049250313e-16 : -1e-12 / std::max(n, 1);
 }
 
+// Unpivoted Cholesky of the symmetric positive definite n x n matrix whose lower triangle sits in V (leading dimension n; destroyed)
+// by the wide-panel solver of the dense reduced systems (dense_chol.h: k_wchol_diag16 + k_wchol_step, one launch per 96 columns), the
+// vector y riding along as its right-hand side (-> L^-1 y). Lx (n x n): the panels; Ltw: ceil(n / 96) * (WD_LT + 6 * 256) doubles for
+// the diagonal blocks' tiles and their re-inverted diagonal tiles; A0 (leading dimension ld0): the original matrix, for the pivot test
+// (k_wfac_diag). Returns 1 = every pivot is safely positive (the factor is in Lx / Ltw, packed by k_wfac_pack), 0 = not (the caller
+// takes the rank-revealing route), -1 = HIP error. One host synchronisation.
+int run_wfac(sadvio_ba_handle* h, double* V, int n, double* y, double* Lx, double* Ltw, const double* A0, long long ld0, double tau_rel, double* dmax, int* info) {
+    const int nsteps = (n + WD - 1) / WD;
+    double* Ld = Ltw + (size_t)nsteps * WD_LT;
+    if (hipMemsetAsync(info, 0, sizeof(int) * 2, h->stream) != hipSuccess) return -1;
+    const size_t lds_st = sizeof(double) * wdstep_lds_doubles() + 64;
+    (void)hipFuncSetAttribute((const void*)k_wchol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_st);
+    (void)hipFuncSetAttribute((const void*)k_wchol_diag16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * wd16_lds_doubles() + 64));
+    hipLaunchKernelGGL(k_wchol_diag16, dim3(1), dim3(SOLVE_THREADS), sizeof(double) * wd16_lds_doubles() + 64, h->stream, V, (long long)n, y, (double*)nullptr, n, 0, info, (const int*)nullptr, Ltw);
+    for (int st = 0; st + 1 < nsteps; st++) {
+        const int c0 = st * WD, mrem = n - (c0 + WD);
+        const int nt = (mrem + CH_TS - 1) / CH_TS;
+        hipLaunchKernelGGL(k_wchol_step, dim3(nt * (nt + 1) / 2 + 2), dim3(SOLVE_THREADS), lds_st, h->stream, V, (long long)n, Lx, y, Ltw + (size_t)st * WD_LT, Ltw + (size_t)(st + 1) * WD_LT,
+                           (double*)nullptr, (double*)nullptr, n, c0, info, (const int*)nullptr, (long long*)nullptr);
+    }
+    hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(256), 0, h->stream, A0, ld0, n, dmax);
+    hipLaunchKernelGGL(k_wfac_diag, dim3(nsteps * WD_T), dim3(64), 0, h->stream, Ltw, n, A0, ld0, tau_rel, dmax, 1024.0 * n * 2.220446049250313e-16, Ld, info + 1);
+    int st2[2] = {0, 0};
+    if (hipMemcpyAsync(st2, info, sizeof(st2), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    return st2[0] == 0 && st2[1] == 0 ? 1 : 0;
+}
+size_t wfac_scratch_doubles(int n) { return (size_t)((n + WD - 1) / WD) * (WD_LT + WD_T * 256) + 8; }
+
 // one-sided Jacobi eigen-decomposition of the symmetric n x n block at A (leading dimension lda): G, V (n x n each)
 // and ev (n) are device buffers; returns the number of sweeps (negative = HIP error)
 int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int lower_only, double* G, double* V, double* ev, int* flag, int eig_cut_mode) {
@@ -1842,7 +1870,26 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     std::vector<double>& hev = M.hev;
     hev.resize(std::max(m, n));
     bool mm_by_cholesky = false;
-    if (m >= 32 && m <= PCH_MAXN && !getenv("SADVIO_MARG_EIG_MM")) {
+    HIP_TRY(M.wtmp.alloc((size_t)big + 16));
+    if (m > 0 && !getenv("SADVIO_MARG_EIG_MM") && !getenv("SADVIO_MARG_PIVOTED")) {
+        // Amm is positive definite whenever frame0 carries a prior or enough observations: unpivoted wide-panel factor first (run_wfac)
+        const long long mm2 = (long long)m * m;
+        HIP_TRY(M.Vs.alloc(std::max(wfac_scratch_doubles(m), (size_t)big * big)));
+        hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((mm2 + 255) / 256)), dim3(256), 0, h->stream, M.A.p, (long long)N, m, M.V.p, M.G.p, 0);
+        HIP_TRY(hipMemsetAsync(M.wtmp.p + 8, 0, sizeof(double) * (size_t)m, h->stream));
+        const int okf = run_wfac(h, M.V.p, m, M.wtmp.p + 8, M.Ainv.p, M.Vs.p, M.A.p, (long long)N, pchol_tau(m, SADVIO_EIG_CUT_NOISE_FLOOR), M.wtmp.p, M.flag.p);
+        if (okf < 0) { h->err = "marginalize: HIP error in the unpivoted Cholesky"; return SADVIO_E_HIP; }
+        if (okf == 1) {
+            hipLaunchKernelGGL(k_wfac_pack, dim3((unsigned)((mm2 + 255) / 256)), dim3(256), 0, h->stream, M.Ainv.p, (long long)m, M.Vs.p, M.Vs.p + (size_t)((m + WD - 1) / WD) * WD_LT,
+                               M.wtmp.p + 8, m, M.G.p, M.wtmp.p + 8);
+            HIP_TRY(M.piv_mm.alloc(m));
+            hipLaunchKernelGGL(k_iota, dim3((m + 255) / 256), dim3(256), 0, h->stream, M.piv_mm.p, m);
+            const int rc = prior_build_Z(h, M.G.p, m, m, SADVIO_PRIOR_FORM_CHOLESKY, M.piv_mm.p, M.Vs.p, rq->eig_cut_mode);
+            if (rc != SADVIO_OK) return rc;
+            mm_by_cholesky = true;
+        }
+    }
+    if (!mm_by_cholesky && m >= 32 && m <= PCH_MAXN && !getenv("SADVIO_MARG_EIG_MM")) {
         const long long mm2 = (long long)m * m;
         hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((mm2 + 255) / 256)), dim3(256), 0, h->stream, M.A.p, (long long)N, m, M.V.p, M.G.p, 0);
         const int r = run_pchol(h, M.V.p, m, M.G.p, pchol_tau(m, SADVIO_EIG_CUT_NOISE_FLOOR), false);
@@ -1888,36 +1935,18 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         const int n1 = n + 1;
         const long long nn1 = (long long)n1 * n1;
         bool unpivoted = false;
-        if (n >= 2 * WD && !getenv("SADVIO_MARG_PIVOTED")) {
+        if (!getenv("SADVIO_MARG_PIVOTED")) {
             // A prior that carries an earlier prior is normally of full rank: then the factor needs no pivoting and the wide-panel
             // solver of the dense reduced systems (dense_chol.h: k_wchol_diag16 + k_wchol_step, one launch per 96 columns, bk riding
             // along as its right-hand side) delivers L and z = L^-1 bk in a third of the pivoted factorisation's time. Every pivot is
             // tested afterwards (k_wfac_diag); one that is not safely positive sends the call to the rank-revealing route below.
-            const int nsteps = (n + WD - 1) / WD;
-            const double tau_rel = pchol_tau(n, rq->eig_cut_mode);
-            HIP_TRY(M.Vs.alloc(std::max((size_t)nsteps * (WD_LT + WD_T * 256) + 8, (size_t)big * big)));
-            double* Ltw = M.Vs.p; double* Ld = Ltw + (size_t)nsteps * WD_LT;
-            int* info = M.flag.p;
-            HIP_TRY(hipMemsetAsync(info, 0, sizeof(int) * 2, h->stream));
+            HIP_TRY(M.Vs.alloc(std::max(wfac_scratch_doubles(n), (size_t)big * big)));
+            double* Ltw = M.Vs.p; double* Ld = Ltw + (size_t)((n + WD - 1) / WD) * WD_LT;
             HIP_TRY(hipMemcpyAsync(M.V.p, M.Ak.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, h->stream));
             HIP_TRY(hipMemcpyAsync(M.newr.p, M.bk.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
-            const size_t lds_st = sizeof(double) * wdstep_lds_doubles() + 64;
-            (void)hipFuncSetAttribute((const void*)k_wchol_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_st);
-            (void)hipFuncSetAttribute((const void*)k_wchol_diag16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * wd16_lds_doubles() + 64));
-            hipLaunchKernelGGL(k_wchol_diag16, dim3(1), dim3(SOLVE_THREADS), sizeof(double) * wd16_lds_doubles() + 64, h->stream, M.V.p, (long long)n, M.newr.p, (double*)nullptr, n, 0, info,
-                               (const int*)nullptr, Ltw);
-            for (int st = 0; st + 1 < nsteps; st++) {
-                const int c0 = st * WD, mrem = n - (c0 + WD);
-                const int nt = (mrem + CH_TS - 1) / CH_TS;
-                hipLaunchKernelGGL(k_wchol_step, dim3(nt * (nt + 1) / 2 + 2), dim3(SOLVE_THREADS), lds_st, h->stream, M.V.p, (long long)n, M.G.p, M.newr.p, Ltw + (size_t)st * WD_LT,
-                                   Ltw + (size_t)(st + 1) * WD_LT, (double*)nullptr, (double*)nullptr, n, c0, info, (const int*)nullptr, (long long*)nullptr);
-            }
-            hipLaunchKernelGGL(k_diag_max, dim3(1), dim3(256), 0, h->stream, M.Ak.p, n, M.ev.p);
-            hipLaunchKernelGGL(k_wfac_diag, dim3(nsteps * WD_T), dim3(64), 0, h->stream, Ltw, n, M.Ak.p, (long long)n, tau_rel, M.ev.p, 1024.0 * n * 2.220446049250313e-16, Ld, info + 1);
-            int st2[2] = {0, 0};
-            HIP_TRY(hipMemcpyAsync(st2, info, sizeof(st2), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            if (st2[0] == 0 && st2[1] == 0) {
+            const int okf = run_wfac(h, M.V.p, n, M.newr.p, M.G.p, Ltw, M.Ak.p, (long long)n, pchol_tau(n, rq->eig_cut_mode), M.wtmp.p, M.flag.p);
+            if (okf < 0) { h->err = "marginalize: HIP error in the unpivoted Cholesky"; return SADVIO_E_HIP; }
+            if (okf == 1) {
                 unpivoted = true;
                 nf = n;
                 hipLaunchKernelGGL(k_wfac_pack, dim3((unsigned)(((long long)n * n + 255) / 256)), dim3(256), 0, h->stream, M.G.p, (long long)n, Ltw, Ld, M.newr.p, n, M.newJ.p, M.newr.p);

@@ -1675,10 +1675,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_backsolve(const double*
 // diagonal tiles back (L_II = (U^-1)^T, 16 threads per tile) and tests the pivots; k_wfac_pack writes J = L^T, r0 = -z.
 // flag |= 1: a pivot is not finite, not above tau, or below safe_rel of its original diagonal entry (the caller falls back to the
 // pivoted factorisation).
-__global__ void k_diag_max(const double* __restrict__ A, int n, double* __restrict__ out) {      // out[0] = max_i A[i][i], one workgroup
+__global__ void k_diag_max(const double* __restrict__ A, long long ld, int n, double* __restrict__ out) {      // out[0] = max_i A[i][i], one workgroup
     __shared__ double sh[256];
     double m = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmax(m, A[(size_t)i * n + i]);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmax(m, A[(size_t)i * ld + i]);
     sh[threadIdx.x] = m;
     __syncthreads();
     for (int s2 = blockDim.x >> 1; s2 > 0; s2 >>= 1) { if ((int)threadIdx.x < s2) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s2]); __syncthreads(); }
