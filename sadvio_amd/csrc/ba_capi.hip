@@ -1935,7 +1935,9 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         const int n1 = n + 1;
         const long long nn1 = (long long)n1 * n1;
         bool unpivoted = false;
-        if (!getenv("SADVIO_MARG_PIVOTED")) {
+        // (without an earlier prior frame1's velocity / bias directions are only held relative to frame0's: Ak is rank deficient, the
+        // attempt would be wasted; SADVIO_MARG_UNPIVOTED=1 tries it regardless)
+        if (!getenv("SADVIO_MARG_PIVOTED") && (rq->last_n_full != 0 || getenv("SADVIO_MARG_UNPIVOTED"))) {
             // A prior that carries an earlier prior is normally of full rank: then the factor needs no pivoting and the wide-panel
             // solver of the dense reduced systems (dense_chol.h: k_wchol_diag16 + k_wchol_step, one launch per 96 columns, bk riding
             // along as its right-hand side) delivers L and z = L^-1 bk in a third of the pivoted factorisation's time. Every pivot is
