@@ -507,10 +507,37 @@ def marginalize_leg(device, cpu):
         gi = be.marginalize(0, form=form, **common)
         info[form] = gi["J"].T @ gi["J"]
     be.close()
-    rec = {"gpu_ms": round(1e3 * min(times["cholesky"][1:]), 2), "gpu_ms_eigen_form": round(1e3 * min(times["eigen"][1:]), 2),
+    # the per-key-frame case: the same window with the PREVIOUS prior folded in (tests/golden_util.config3_marg_case, what
+    # backend_step times): Ak is of full rank and takes the unpivoted wide-panel factorisation
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_util import config3_marg_case
+    w3, margs3 = config3_marg_case(300)
+    be = capi.Backend(device=device)
+    be.set_windows([w3])
+    t_steady = []
+    for _ in range(6):
+        t = time.perf_counter()
+        g3 = be.marginalize(0, form="cholesky", readback=False, eig_cut="reference", **margs3)
+        t_steady.append(time.perf_counter() - t)
+    # ... and with a previous prior of FULL size (n_last = n = 915: frame0's 15 states + the 300 kept landmarks, all still in the
+    # window), resident on the device: what every key-frame of a running back-end folds in
+    margs_big = dict(margs3, last={"kf_keep": 11, "kf_col": g3["kf_col"], "lmk_index": g3["lmk_index"], "lmk_col": g3["lmk_col"]})
+    t_big = []
+    for _ in range(5):
+        t = time.perf_counter()
+        g4 = be.marginalize(0, form="cholesky", readback=False, eig_cut="reference", **margs_big)
+        t_big.append(time.perf_counter() - t)
+    be.close()
+    rec = {"gpu_ms": round(1e3 * min(t_steady[1:]), 2), "n_full_steady_state": int(g3["n_full"]),
+           "gpu_ms_full_size_previous_prior": round(1e3 * min(t_big[1:]), 2), "n_full_full_size_previous_prior": int(g4["n_full"]),
+           "gpu_ms_first_marginalisation": round(1e3 * min(times["cholesky"][1:]), 2), "gpu_ms_eigen_form": round(1e3 * min(times["eigen"][1:]), 2),
            "m": int(g["m"]), "n": int(g["n"]), "n_full": int(g["n_full"]), "jacobi_sweeps_eigen_form": list(g["sweeps"]),
            "eig_cut": "reference (absolute 1e-12, marginalization.hpp:58)",
            "forms_information_rel_diff": float(np.abs(info["cholesky"] - info["eigen"]).max() / np.abs(info["eigen"]).max()),
+           "what": "`gpu_ms` = the per-key-frame call (Cholesky form, a previous prior on frame0's 15 states folded in: full rank, unpivoted "
+                   "factorisation, every pivot tested); `gpu_ms_full_size_previous_prior` = the same with a resident previous prior over all 915 "
+                   "kept columns (J^T J of the previous prior on the matrix cores); `gpu_ms_first_marginalisation` = the same window without an earlier prior (rank deficient: rank-revealing route); "
+                   "`gpu_ms_eigen_form`, n_full, the information differences and the CPU figures are of the latter",
            "workload": "config-3 shape: 12-KF VIO window, 300 kept landmarks, IMU + visual factors of frame0; prior left on the device (no read-back)"}
     if cpu is not None:
         rec.update(cpu[0])

@@ -194,7 +194,7 @@ struct PriorState {
 // per call cost more than the kernels between them.
 struct TriLevel { int first, count, max_m, max_n; };
 struct MargScratch {
-    DevBuf<double> A, b, G, V, ev, Vs, Ainv, T, Ak, bk, newJ, newr, lastJ, lastr, L, Tb, Zt, S, mi, jsel, lam, wtmp;
+    DevBuf<double> A, b, G, V, ev, Vs, Ainv, T, Ak, bk, newJ, newr, lastJ, lastr, L, Tb, Zt, S, mi, jsel, lam, wtmp, Hl;
     DevBuf<int> ditems, flag, sel, lastcol, piv_of, lc, piv_mm;
     DevBuf<MargSmall> small;
     DevBuf<NfrSpecC> spec;
@@ -1860,6 +1860,11 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     if (S.has_imu || S.n_prior) hipLaunchKernelGGL(k_marg_small, dim3(1), dim3(64), 0, h->stream, P, M.small.p, M.A.p, M.b.p, N);
     if (nfl > 0) {
         const long long items = (long long)nl * nl;
+        if (nl >= 64 && !getenv("SADVIO_MARG_LAST_SMALL")) {
+            HIP_TRY(M.Hl.alloc((size_t)nl * nl));
+            launch_mgemm(h, M.Hl.p, nl, lastJ, 1LL, (long long)nl, lastJ, (long long)nl, 1LL, nl, nl, nfl, 1.0, 0.0);      // H = J^T J
+            hipLaunchKernelGGL(k_marg_last_scatter, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, M.Hl.p, lastJ, lastr, M.lastcol.p, nfl, nl, M.A.p, M.b.p, N);
+        } else
         hipLaunchKernelGGL(k_marg_last_prior, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, lastJ, lastr, M.lastcol.p, nfl, nl, M.A.p, M.b.p, N);
     }
     // ---- Schur complement with the pseudo-inverse of Amm (marginalization.cpp:234-248) ----------------------------------
@@ -1871,13 +1876,13 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     hev.resize(std::max(m, n));
     bool mm_by_cholesky = false;
     HIP_TRY(M.wtmp.alloc((size_t)big + 16));
-    if (m > 0 && !getenv("SADVIO_MARG_EIG_MM") && !getenv("SADVIO_MARG_PIVOTED")) {
+    if (m > 0 && !getenv("SADVIO_MARG_EIG_MM") && !getenv("SADVIO_MARG_PIVOTED") && rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE) {
         // Amm is positive definite whenever frame0 carries a prior or enough observations: unpivoted wide-panel factor first (run_wfac)
         const long long mm2 = (long long)m * m;
         HIP_TRY(M.Vs.alloc(std::max(wfac_scratch_doubles(m), (size_t)big * big)));
         hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((mm2 + 255) / 256)), dim3(256), 0, h->stream, M.A.p, (long long)N, m, M.V.p, M.G.p, 0);
         HIP_TRY(hipMemsetAsync(M.wtmp.p + 8, 0, sizeof(double) * (size_t)m, h->stream));
-        const int okf = run_wfac(h, M.V.p, m, M.wtmp.p + 8, M.Ainv.p, M.Vs.p, M.A.p, (long long)N, pchol_tau(m, SADVIO_EIG_CUT_NOISE_FLOOR), M.wtmp.p, M.flag.p);
+        const int okf = run_wfac(h, M.V.p, m, M.wtmp.p + 8, M.Ainv.p, M.Vs.p, M.A.p, (long long)N, pchol_tau(m, SADVIO_EIG_CUT_REFERENCE), M.wtmp.p, M.flag.p);
         if (okf < 0) { h->err = "marginalize: HIP error in the unpivoted Cholesky"; return SADVIO_E_HIP; }
         if (okf == 1) {
             hipLaunchKernelGGL(k_wfac_pack, dim3((unsigned)((mm2 + 255) / 256)), dim3(256), 0, h->stream, M.Ainv.p, (long long)m, M.Vs.p, M.Vs.p + (size_t)((m + WD - 1) / WD) * WD_LT,
@@ -1937,7 +1942,11 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         bool unpivoted = false;
         // (without an earlier prior frame1's velocity / bias directions are only held relative to frame0's: Ak is rank deficient, the
         // attempt would be wasted; SADVIO_MARG_UNPIVOTED=1 tries it regardless)
-        if (!getenv("SADVIO_MARG_PIVOTED") && (rq->last_n_full != 0 || getenv("SADVIO_MARG_UNPIVOTED"))) {
+        // Only under the reference's absolute cut: an unpivoted factorisation is not rank revealing (the pivot of the last index of a
+        // dependent set is lambda / v_i^2, v = the null vector - any size), so the noise-floor mode, whose point is a reliable
+        // numerical rank, always takes the pivoted route; under the absolute 1e-12 cut both routes keep every direction whose pivot is
+        // positive, as the reference's eigenvalue test does.
+        if (!getenv("SADVIO_MARG_PIVOTED") && rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE && (rq->last_n_full != 0 || getenv("SADVIO_MARG_UNPIVOTED"))) {
             // A prior that carries an earlier prior is normally of full rank: then the factor needs no pivoting and the wide-panel
             // solver of the dense reduced systems (dense_chol.h: k_wchol_diag16 + k_wchol_step, one launch per 96 columns, bk riding
             // along as its right-hand side) delivers L and z = L^-1 bk in a third of the pivoted factorisation's time. Every pivot is

@@ -1187,39 +1187,59 @@ struct MargSmall {
     double prior_T[4][12], prior_inf[4][6];
 };
 
+// One wave: lanes 0, 1, 2.. evaluate the IMU factor, the bias factor and the pose priors (one lane each: the evaluators are scalar
+// code) into LDS, then ALL lanes accumulate J^T J / J^T r (as one lane's loop the 24 x 24 x 9 products + atomics were most of the kernel).
+__device__ __forceinline__ void marg_accumulate_wave(double* A, double* b, int N, const double* J, const double* r, int rows, int ncols, const int* col, int t) {
+    for (int idx = t; idx < ncols * (ncols + 1); idx += 64) {
+        const int a = idx / (ncols + 1), c2 = idx - a * (ncols + 1);
+        if (col[a] < 0) continue;
+        double h = 0.0;
+        if (c2 == ncols) {
+            for (int q = 0; q < rows; q++) h += J[q * ncols + a] * r[q];
+            atomic_add_f64(&b[col[a]], h);
+        } else if (col[c2] >= 0) {
+            for (int q = 0; q < rows; q++) h += J[q * ncols + a] * J[q * ncols + c2];
+            atomic_add_f64(&A[(size_t)col[a] * N + col[c2]], h);
+        }
+    }
+}
 __global__ __launch_bounds__(64) void k_marg_small(DevPtrs P, const MargSmall* Sp, double* A, double* b, int N) {
     const MargSmall& S = *Sp;
     const int t = threadIdx.x;
     const double z[6] = {0, 0, 0, 0, 0, 0};
+    __shared__ double sJ[9 * 24], sr[9], sJb[72], srb[6], sJp[4][36], srp[4][6];
+    __shared__ int scol[24], scolb[12], scolp[4][6];
     if (t == 0 && S.has_imu) {
         double r[9], J[9 * 24];
         imu_factor(S.imu, P.kf_T0 + 12 * (long long)S.kf_i, P.kf_T0 + 12 * (long long)S.kf_j, P.kf_vel + 3 * (long long)S.kf_i,
                    P.kf_vel + 3 * (long long)S.kf_j, z, z, z, z, z, z, r, J);
-        int col[24];
-        for (int a = 0; a < 6; a++) { col[a] = a; col[6 + a] = S.kf_keep_col + a; }
-        for (int a = 0; a < 3; a++) { col[12 + a] = 6 + a; col[15 + a] = S.kf_keep_col + 6 + a; col[18 + a] = 9 + a; col[21 + a] = 12 + a; }
-        marg_accumulate(A, b, N, J, r, 9, 24, col);
+        for (int i = 0; i < 9 * 24; i++) sJ[i] = J[i];
+        for (int i = 0; i < 9; i++) sr[i] = r[i];
+        for (int a = 0; a < 6; a++) { scol[a] = a; scol[6 + a] = S.kf_keep_col + a; }
+        for (int a = 0; a < 3; a++) { scol[12 + a] = 6 + a; scol[15 + a] = S.kf_keep_col + 6 + a; scol[18 + a] = 9 + a; scol[21 + a] = 12 + a; }
     }
     if (t == 1 && S.has_imu) {
-        double rb[6], Jb[72];
-        int colb[12];
-        for (int i = 0; i < 72; i++) Jb[i] = 0.0;
+        for (int i = 0; i < 72; i++) sJb[i] = 0.0;
         for (int a = 0; a < 3; a++) {
-            rb[a] = S.imu.sa * (P.kf_ba[3 * (long long)S.kf_j + a] - P.kf_ba[3 * (long long)S.kf_i + a]);
-            rb[3 + a] = S.imu.sg * (P.kf_bg[3 * (long long)S.kf_j + a] - P.kf_bg[3 * (long long)S.kf_i + a]);
-            Jb[a * 12 + a] = -S.imu.sa; Jb[(3 + a) * 12 + 3 + a] = -S.imu.sg; Jb[a * 12 + 6 + a] = S.imu.sa; Jb[(3 + a) * 12 + 9 + a] = S.imu.sg;
-            colb[a] = 9 + a; colb[3 + a] = 12 + a; colb[6 + a] = S.kf_keep_col + 9 + a; colb[9 + a] = S.kf_keep_col + 12 + a;
+            srb[a] = S.imu.sa * (P.kf_ba[3 * (long long)S.kf_j + a] - P.kf_ba[3 * (long long)S.kf_i + a]);
+            srb[3 + a] = S.imu.sg * (P.kf_bg[3 * (long long)S.kf_j + a] - P.kf_bg[3 * (long long)S.kf_i + a]);
+            sJb[a * 12 + a] = -S.imu.sa; sJb[(3 + a) * 12 + 3 + a] = -S.imu.sg; sJb[a * 12 + 6 + a] = S.imu.sa; sJb[(3 + a) * 12 + 9 + a] = S.imu.sg;
+            scolb[a] = 9 + a; scolb[3 + a] = 12 + a; scolb[6 + a] = S.kf_keep_col + 9 + a; scolb[9 + a] = S.kf_keep_col + 12 + a;
         }
-        marg_accumulate(A, b, N, Jb, rb, 6, 12, colb);
     }
     if (t >= 2 && t - 2 < S.n_prior) {
         const int k = t - 2;
         double r[6], J[36];
-        int col[6];
         pose_prior_factor(P.kf_T0 + 12 * (long long)S.prior_kf[k], S.prior_T[k], S.prior_inf[k], z, r, J);
-        for (int a = 0; a < 6; a++) col[a] = S.prior_base[k] + a;
-        marg_accumulate(A, b, N, J, r, 6, 6, col);
+        for (int i = 0; i < 36; i++) sJp[k][i] = J[i];
+        for (int a = 0; a < 6; a++) { srp[k][a] = r[a]; scolp[k][a] = S.prior_base[k] + a; }
     }
+    __syncthreads();
+    if (S.has_imu) {
+        marg_accumulate_wave(A, b, N, sJ, sr, 9, 24, scol, t);
+        marg_accumulate_wave(A, b, N, sJb, srb, 6, 12, scolb, t);
+    }
+    for (int k = 0; k < S.n_prior; k++) marg_accumulate_wave(A, b, N, sJp[k], srp[k], 6, 6, scolp[k], t);
 }
 
 // previous dense prior at zero deltas: A[col a][col c] += sum_q J[q][a] J[q][c], b[col a] += sum_q J[q][a] r0[q]
@@ -1236,6 +1256,23 @@ __global__ void k_marg_last_prior(const double* J, const double* r0, const int* 
         for (int q = 0; q < nf; q++) g += J[(size_t)q * nl + a] * r0[q];
         atomic_add_f64(&b[col[a]], g);
     }
+}
+
+// the same for a LARGE previous prior (the steady state: n_last ~ n): H = J^T J comes from k_mgemm (FP64 matrix cores), this kernel
+// scatters it through the column map and forms J^T r0 (one thread per (a, c); the column loop of the small kernel above streams all
+// of J through every workgroup: 3 270 workgroups x 6.7 MB at n_last = 915)
+__global__ void k_marg_last_scatter(const double* __restrict__ H, const double* __restrict__ J, const double* __restrict__ r0, const int* __restrict__ col, int nf, int nl,
+                                    double* __restrict__ A, double* __restrict__ b, int N) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)nl * nl) return;
+    const int a = (int)(idx / nl), c = (int)(idx - (long long)a * nl);
+    if (a == 0 && col[c] >= 0) {      // thread (0, c): entry c of J^T r0, unit stride across the threads
+        double g = 0.0;
+        for (int q = 0; q < nf; q++) g += J[(size_t)q * nl + c] * r0[q];
+        atomic_add_f64(&b[col[c]], g);
+    }
+    if (col[a] < 0 || col[c] < 0) return;
+    atomic_add_f64(&A[(size_t)col[a] * N + col[c]], H[idx]);
 }
 
 // bk = brr - T bmm (one thread per row of T: n x m)

@@ -340,3 +340,80 @@ def test_marginalize_and_sparsify_refused_on_a_sharded_window(backend_cls):
     with pytest.raises(capi.SadvioError, match="sharded"):
         be.sparsify(0, {"J": np.eye(4), "r0": np.zeros(4), "lmk_index": [], "lmk_col": []}, vio=False)
     be.close()
+
+
+class _Env:
+    """Set / unset environment switches of the library for the duration of a block (they are read with getenv at call time)."""
+    def __init__(self, **kv):
+        self.kv = kv
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_unpivoted_and_rank_revealing_routes_give_the_same_prior(backend_cls, oracle_lib):
+    """Round 4, second half: a full-rank prior (an earlier prior is folded in) is factorised WITHOUT pivoting by the wide-panel solver
+    of the dense reduced systems, every pivot tested afterwards; SADVIO_MARG_PIVOTED forces the rank-revealing (relaxed pivoting)
+    route, SADVIO_PCHOL_STRICT its arg-max-per-column version. All three carry the oracle's information."""
+    w, args = small_vio_case(seed=75, n_lmk=500, n_lonely=12)
+    o = oracle_lib.marginalize(w, eig_cut="reference", **args)
+    got = {}
+    for name, env in (("unpivoted", dict(SADVIO_MARG_PIVOTED=None, SADVIO_PCHOL_STRICT=None)), ("relaxed", dict(SADVIO_MARG_PIVOTED="1", SADVIO_PCHOL_STRICT=None)),
+                      ("strict", dict(SADVIO_MARG_PIVOTED="1", SADVIO_PCHOL_STRICT="1"))):
+        with _Env(**env):
+            be = backend_cls(device=0)
+            be.set_windows([w])
+            got[name] = be.marginalize(0, eig_cut="reference", form="cholesky", **args)
+            be.close()
+    n = o["n"]
+    assert n >= 192                       # more than one 96-column panel: k_wchol_step runs
+    for name, g in got.items():
+        assert g["n"] == n and g["n_full"] == n == o["n_full"], name
+        same_information(g, o)
+    same_information(got["unpivoted"], got["strict"], rtol=1e-11, c_rtol=1e-10)
+    same_information(got["relaxed"], got["strict"], rtol=1e-11, c_rtol=1e-10)
+    # the unpivoted factor is L^T in the caller's column order: upper triangular
+    J = got["unpivoted"]["J"]
+    assert np.all(np.tril(J, -1) == 0.0) and np.all(np.diag(J) > 0.0)
+
+
+def test_rank_deficient_prior_under_the_two_routes(backend_cls, oracle_lib):
+    """An unpivoted factorisation is not rank revealing (the pivot of the last index of a dependent set is lambda / v_i^2 for the null
+    vector v), so the route is only taken under the reference's absolute cut - where every positive direction is kept anyway - and the
+    noise-floor mode always pivots. A FIRST marginalisation (no earlier prior: Ak is rank deficient in frame1's velocity / bias
+    directions) with the attempt forced (SADVIO_MARG_UNPIVOTED): the prior must carry the same information as the pivoted route's and
+    the oracle's; in the noise-floor mode the switch must change nothing at all."""
+    w, args = small_vio_case(seed=76, n_lmk=450, n_lonely=10)
+    args = dict(args, last=None)
+    res = {}
+    for cut in ("reference", "noise_floor"):
+        for name, env in (("default", dict(SADVIO_MARG_UNPIVOTED=None)), ("forced", dict(SADVIO_MARG_UNPIVOTED="1"))):
+            with _Env(**env):
+                be = backend_cls(device=0)
+                be.set_windows([w])
+                res[(cut, name)] = be.marginalize(0, eig_cut=cut, form="cholesky", **args)
+                be.close()
+    o = {cut: oracle_lib.marginalize(w, eig_cut=cut, **args) for cut in ("reference", "noise_floor")}
+    n = o["reference"]["n"]
+    assert o["noise_floor"]["n_full"] < n                                        # the window is rank deficient
+    assert res[("noise_floor", "default")]["n_full"] == res[("noise_floor", "forced")]["n_full"] < n
+    # (the pivot floor of the Cholesky form, 4 n eps max-diagonal, and the oracle's eigenvalue floor, n eps lambda_max, may put a
+    # direction that sits between them on different sides: same allowance as the low-parallax test)
+    assert abs(res[("noise_floor", "default")]["n_full"] - o["noise_floor"]["n_full"]) <= 4
+    same_information(res[("noise_floor", "forced")], res[("noise_floor", "default")], rtol=1e-12, c_rtol=1e-12)
+    same_information(res[("noise_floor", "default")], o["noise_floor"])
+    for name in ("default", "forced"):
+        g = res[("reference", name)]
+        assert o["noise_floor"]["n_full"] <= g["n_full"] <= n
+        # |r0|^2 carries (u . bk)^2 / lambda of the noise-level directions either side keeps: a constant of the cost (see the low-parallax test)
+        same_information(g, o["reference"], rtol=1e-7, c_rtol=1e-2)

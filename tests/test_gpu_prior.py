@@ -124,3 +124,31 @@ def test_dense_reduced_system_edge_sizes(backend_cls, oracle_lib, n_keep):
     w = make_vio_window(n_kf=6, n_lmk=900, seed=100 + n_keep)
     w.dense_prior = random_prior(w, n_keep, w.n_kf - 2, np.random.default_rng(n_keep), rank_deficit=3)
     compare(backend_cls, oracle_lib, w, capi.reference_options(), vio=True)
+
+
+def test_one_launch_per_panel_equals_the_round3_panel_loop(backend_cls, oracle_lib):
+    """k_wchol_step (one launch per 96 columns: block substitution against the factor's tiles, M = L^-1 off the chain, out-of-place
+    panels) against the round-3 loop it replaced (SADVIO_WD_R3: trsm8 + syrk_la with the explicit inverse) on a 3-panel-and-a-bit
+    system: same iterations, same accepted steps, solutions equal far below the parity bar."""
+    import os
+    w = make_vio_window(n_kf=6, n_lmk=900, seed=171)
+    w.dense_prior = random_prior(w, 80, w.n_kf - 2, np.random.default_rng(80), rank_deficit=2)    # N_p = 75 + 240 = 315
+    out = {}
+    for name, val in (("step", None), ("r3", "1")):
+        old = os.environ.pop("SADVIO_WD_R3", None)
+        if val is not None:
+            os.environ["SADVIO_WD_R3"] = val
+        try:
+            be = backend_cls(device=0)
+            be.set_windows([w])
+            s = be.solve(capi.reference_options())[0]
+            out[name] = (s, be.get_deltas(0))
+            be.close()
+        finally:
+            os.environ.pop("SADVIO_WD_R3", None)
+            if old is not None:
+                os.environ["SADVIO_WD_R3"] = old
+    (sa, da), (sb, db) = out["step"], out["r3"]
+    assert (sa.iterations, sa.termination, sa.num_successful_steps) == (sb.iterations, sb.termination, sb.num_successful_steps)
+    assert np.isclose(sa.final_cost, sb.final_cost, rtol=1e-11)
+    assert np.abs(da["pose"] - db["pose"]).max() <= 1e-9 and np.abs(da["lmk"] - db["lmk"]).max() <= 1e-8
