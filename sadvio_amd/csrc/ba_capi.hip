@@ -187,6 +187,8 @@ struct PriorState {
     DevBuf<double> Z;            // n_full x n with Z^T Z = Sigma_k (built by the first sparsify of this prior)
     bool z_valid = false;
     DevBuf<int> step_of;         // Cholesky form: pivot step of every column
+    DevBuf<double> H, g;         // J^T J = Ak and -J^T r0 = bk as the marginalisation that built the prior had them (full-rank Cholesky form only):
+    bool hg_valid = false;       // the next marginalize / the next window's dense prior take them instead of re-forming J^T J (n^3 flops)
     unsigned long long serial = 0;   // bumped whenever the prior changes: a window that attached it checks it is still the same one
 };
 
@@ -427,6 +429,14 @@ __global__ void k_dense_prior_prepare(const double* J, double* Jt, int nf, int n
     }
 }
 
+// H = the symmetric matrix whose lower triangle is A's (the marginalisation's Ak, read like Eigen reads it)
+__global__ void k_sym_from_lower(const double* __restrict__ A, int n, double* __restrict__ H) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * n) return;
+    const int i = (int)(idx / n), j = (int)(idx - (long long)i * n);
+    H[idx] = i >= j ? A[idx] : A[(size_t)j * n + i];
+}
+
 // Layout of the reduced systems of all windows: [free key-frames (dpf each) | prior-kept landmarks (3 each)].
 // Called by set_windows and again by set_dense_prior (kept landmarks enlarge the reduced system).
 int layout_reduced(sadvio_ba_handle* h) {
@@ -613,6 +623,9 @@ int layout_reduced(sadvio_ba_handle* h) {
         double* H = Jt + (size_t)pr.n * pr.nf;
         const long long items = (long long)pr.nf * pr.n;
         hipLaunchKernelGGL(k_dense_prior_prepare, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, J, Jt, pr.nf, pr.n);
+        if (h->dprior_per_win[pr.w].resident && h->prior.hg_valid && h->prior.n == pr.n && !getenv("SADVIO_MARG_LAST_SMALL"))
+            hipLaunchKernelGGL(k_sym_from_lower, dim3((unsigned)(((long long)pr.n * pr.n + 255) / 256)), dim3(256), 0, h->stream, h->prior.H.p, pr.n, H);   // H = Ak of the marginalisation
+        else
         hipLaunchKernelGGL(k_mgemm, dim3((pr.n + 63) / 64, (pr.n + 63) / 64), dim3(256), 0, h->stream, H, (long long)pr.n, J, 1LL, (long long)pr.n, J, (long long)pr.n, 1LL,
                            pr.n, pr.n, pr.nf, 1.0, 0.0);
     }
@@ -1766,7 +1779,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     if (res) { res->m = m; res->n = n; res->n_full = 0; res->kf_col = kf_keep_col >= 0 ? kf_keep_col - m : -1; res->sweeps_mm = res->sweeps_k = 0; }
     if (lmk_col_out) for (int k = 0; k < rq->n_keep; k++) lmk_col_out[k] = lcol[rq->lmk_keep[k]] - m;
     if (n < 4) {   // the reference clears its prior state too (…Analytic.cpp:620-625)
-        PR.valid = false; PR.z_valid = false; PR.serial++;
+        PR.valid = false; PR.z_valid = false; PR.hg_valid = false; PR.serial++;
         h->err = "marginalize: fewer than 4 kept columns, refused (marginalization.cpp:215-216)"; return SADVIO_E_REFUSED;
     }
     const bool chol_form = rq->prior_form == SADVIO_PRIOR_FORM_CHOLESKY && n + 1 <= PCH_MAXN;
@@ -1860,7 +1873,10 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     if (S.has_imu || S.n_prior) hipLaunchKernelGGL(k_marg_small, dim3(1), dim3(64), 0, h->stream, P, M.small.p, M.A.p, M.b.p, N);
     if (nfl > 0) {
         const long long items = (long long)nl * nl;
-        if (nl >= 64 && !getenv("SADVIO_MARG_LAST_SMALL")) {
+        if (rq->last_n_full == SADVIO_PRIOR_RESIDENT && PR.hg_valid && PR.n == nl && !getenv("SADVIO_MARG_LAST_SMALL")) {
+            // the resident prior still carries the Ak / bk it was factorised from: J^T J and J^T r0 without touching J
+            hipLaunchKernelGGL(k_marg_last_scatter_h, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, PR.H.p, PR.g.p, M.lastcol.p, nl, M.A.p, M.b.p, N);
+        } else if (nl >= 64 && !getenv("SADVIO_MARG_LAST_SMALL")) {
             HIP_TRY(M.Hl.alloc((size_t)nl * nl));
             launch_mgemm(h, M.Hl.p, nl, lastJ, 1LL, (long long)nl, lastJ, (long long)nl, 1LL, nl, nl, nfl, 1.0, 0.0);      // H = J^T J
             hipLaunchKernelGGL(k_marg_last_scatter, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, M.Hl.p, lastJ, lastr, M.lastcol.p, nfl, nl, M.A.p, M.b.p, N);
@@ -1934,6 +1950,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         HIP_TRY(hipStreamSynchronize(h->stream));   // `sel` goes out of scope
     }
     int nf = 0;
+    bool unpivoted_ok = false;
     if (chol_form) {
         // ---- Cholesky form: J = G with G^T G = Ak (rank-revealing, pivots cut like the eigenvalues), r0 = -G^-T bk as the
         // factor's extra column. No eigen-decomposition.
@@ -1958,7 +1975,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
             const int okf = run_wfac(h, M.V.p, n, M.newr.p, M.G.p, Ltw, M.Ak.p, (long long)n, pchol_tau(n, rq->eig_cut_mode), M.wtmp.p, M.flag.p);
             if (okf < 0) { h->err = "marginalize: HIP error in the unpivoted Cholesky"; return SADVIO_E_HIP; }
             if (okf == 1) {
-                unpivoted = true;
+                unpivoted = true; unpivoted_ok = true;
                 nf = n;
                 hipLaunchKernelGGL(k_wfac_pack, dim3((unsigned)(((long long)n * n + 255) / 256)), dim3(256), 0, h->stream, M.G.p, (long long)n, Ltw, Ld, M.newr.p, n, M.newJ.p, M.newr.p);
                 HIP_TRY(PR.step_of.alloc(n));
@@ -2006,6 +2023,8 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     // the new prior becomes the handle's (AOptimizer.h:88-90: _marginalization_last), the old one's buffers become scratch
     PR.J.swap(M.newJ); PR.r0.swap(M.newr);
     PR.serial++;
+    PR.hg_valid = false;
+    if (unpivoted_ok) { PR.H.swap(M.Ak); PR.g.swap(M.bk); PR.hg_valid = true; }   // (full rank: J^T J = Ak, J^T r0 = -bk to rounding)
     PR.valid = nf > 0; PR.z_valid = false; PR.n_full = nf; PR.n = n; PR.form = chol_form ? SADVIO_PRIOR_FORM_CHOLESKY : SADVIO_PRIOR_FORM_EIGEN; PR.cut_mode = rq->eig_cut_mode;
     if (nf > 0) {
         if (J_out) HIP_TRY(hipMemcpyAsync(J_out, PR.J.p, sizeof(double) * (size_t)nf * n, hipMemcpyDeviceToHost, h->stream));
@@ -2032,6 +2051,7 @@ int sadvio_ba_set_prior(sadvio_ba_handle* h, int32_t n_full, int32_t n, int32_t 
     if (!h) return SADVIO_E_INVALID_ARG;
     PriorState& PR = h->prior;
     PR.serial++;
+    PR.hg_valid = false;
     if (n_full <= 0) { PR.valid = false; PR.z_valid = false; return SADVIO_OK; }
     if (n <= 0 || !J || !r0 || form != SADVIO_PRIOR_FORM_EIGEN) {   // a Cholesky-form prior carries its pivot order: only the device produces one
         h->err = "set_prior: needs J, r0 in the eigen form (orthogonal rows)"; return SADVIO_E_INVALID_ARG;

@@ -1275,6 +1275,18 @@ __global__ void k_marg_last_scatter(const double* __restrict__ H, const double* 
     atomic_add_f64(&A[(size_t)col[a] * N + col[c]], H[idx]);
 }
 
+// ... and when the resident prior still holds the (H, g) = (Ak, bk) it was factorised from: A += H through the column map (lower
+// triangle of H, as the factorisation read it), b += J^T r0 = -g
+__global__ void k_marg_last_scatter_h(const double* __restrict__ H, const double* __restrict__ g, const int* __restrict__ col, int nl, double* __restrict__ A,
+                                      double* __restrict__ b, int N) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)nl * nl) return;
+    const int a = (int)(idx / nl), c = (int)(idx - (long long)a * nl);
+    if (a == 0 && col[c] >= 0) atomic_add_f64(&b[col[c]], -g[c]);
+    if (col[a] < 0 || col[c] < 0) return;
+    atomic_add_f64(&A[(size_t)col[a] * N + col[c]], a >= c ? H[idx] : H[(size_t)c * nl + a]);
+}
+
 // bk = brr - T bmm (one thread per row of T: n x m)
 __global__ void k_marg_bk(const double* T, const double* b, int n, int m, double* bk) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
