@@ -308,9 +308,15 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle *h, int32_t w, int32_t n_full, in
  * Gauss-Newton matrix: r0 + J dx enters the solve only through J^T J, J^T r0 and |r0|^2):
  *   SADVIO_PRIOR_FORM_EIGEN    (0): the reference's J = Lambda^1/2 U^T, r0 = -Lambda^-1/2 U^T bk, rows in ascending
  *       eigenvalue order (marginalization.cpp:318-342,516-530) — one-sided block Jacobi on the device, ~20 ms at n ~ 900.
- *   SADVIO_PRIOR_FORM_CHOLESKY (1): J = G, the rank-revealing (diagonally pivoted) Cholesky factor G^T G = Ak with the cut
- *       applied to its pivots, r0 = -G^-T bk by carrying bk through the factorisation as an extra column — no
- *       eigen-decomposition; sadvio_ba_sparsify then takes Sigma_k = Ak^-1 from the triangular inverse of G. */
+ *   SADVIO_PRIOR_FORM_CHOLESKY (1): J = G, a Cholesky factor G^T G = Ak, r0 = -G^-T bk by carrying bk through the
+ *       factorisation — no eigen-decomposition; sadvio_ba_sparsify then takes Sigma_k = Ak^-1 from the triangular inverse of
+ *       G. Two routes (~1 ms / ~2 ms at n ~ 900): under SADVIO_EIG_CUT_REFERENCE with an earlier prior folded in (Ak is then
+ *       normally of full rank) the factorisation is UNPIVOTED — G = L^T, upper triangular in the caller's column order,
+ *       n_full = n — and every pivot is tested afterwards (positive, above the cut, above the rounding noise of its own
+ *       elimination); a failed test, a first marginalisation and SADVIO_EIG_CUT_NOISE_FLOOR (whose point is a reliable
+ *       numerical rank, which an unpivoted factorisation cannot give) take the rank-revealing route: diagonal pivoting with
+ *       the cut applied to the pivots, G's rows in pivot order. Either way only J^T J, J^T r0 and |r0|^2 are defined by the
+ *       form; the rows themselves are not the reference's. */
 #define SADVIO_EIG_CUT_REFERENCE 0
 #define SADVIO_EIG_CUT_NOISE_FLOOR 1
 #define SADVIO_PRIOR_FORM_EIGEN 0
