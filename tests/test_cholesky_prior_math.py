@@ -1,0 +1,99 @@
+"""The algebra behind the Cholesky form of the marginalisation prior (include/sadvio_ba.h, DESIGN.md §4 "Round 4"), stated in NumPy so
+that the claims the device code relies on are executable without a GPU:
+  * J = L^T, r0 = -L^-1 bk (bk carried through the factorisation as its right-hand side) is a MarginalizationFactor with the same
+    J^T J, J^T r0 and hence the same Gauss-Newton system as the reference's eigen form J = Lambda^1/2 U^T, r0 = -Lambda^-1/2 U^T bk
+    (marginalization.cpp:318-342, 516-530);
+  * the augmented matrix [[Ak, bk], [bk^T, -1]] of the pivoted route yields the same r0 as an extra column;
+  * an UNPIVOTED factorisation is not rank revealing: the pivot of the last index of a dependent set is lambda / v_i^2 for the null
+    vector v, so its size says nothing about the rank — why the noise-floor mode always pivots;
+  * threshold pivoting (a pivot is at least theta times the largest remaining diagonal) bounds the entries of the factor by
+    sqrt(1 / theta) of the greedy order's bound."""
+import numpy as np
+
+
+def spd(n, rng, cond=1e6):
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.logspace(0, np.log10(cond), n)
+    return (Q * lam) @ Q.T, Q, lam
+
+
+def test_cholesky_form_is_the_same_factor_as_the_eigen_form():
+    rng = np.random.default_rng(1)
+    Ak, Q, lam = spd(40, rng)
+    bk = rng.standard_normal(40)
+    L = np.linalg.cholesky(Ak)
+    Jc, r0c = L.T, -np.linalg.solve(L, bk)
+    Je, r0e = np.sqrt(lam)[:, None] * Q.T, -(Q.T @ bk) / np.sqrt(lam)
+    for J, r0 in ((Jc, r0c), (Je, r0e)):
+        assert np.allclose(J.T @ J, Ak, rtol=0, atol=1e-9 * lam.max())
+        assert np.allclose(J.T @ r0, -bk, atol=1e-9)
+    assert np.isclose(r0c @ r0c, r0e @ r0e, rtol=1e-9)      # |r0|^2 = bk^T Ak^-1 bk either way
+    # the factor's residual at a state change dx: same cost
+    dx = 1e-2 * rng.standard_normal(40)
+    assert np.isclose(np.sum((r0c + Jc @ dx) ** 2), np.sum((r0e + Je @ dx) ** 2), rtol=1e-10)
+
+
+def test_augmented_matrix_carries_r0_as_an_extra_column():
+    rng = np.random.default_rng(2)
+    Ak, _, _ = spd(25, rng, cond=1e4)
+    bk = rng.standard_normal(25)
+    S = np.block([[Ak, bk[:, None]], [bk[None, :], -np.ones((1, 1))]])
+    # right-looking Cholesky on the first 25 indices only (the extra index has a negative diagonal: never a pivot)
+    G = np.zeros((25, 26))
+    W = S.copy()
+    for k in range(25):
+        G[k, k:] = W[k, k:] / np.sqrt(W[k, k])
+        W[k + 1:, k + 1:] -= np.outer(G[k, k + 1:], G[k, k + 1:])
+    L = np.linalg.cholesky(Ak)
+    assert np.allclose(G[:, :25], L.T, atol=1e-10)
+    assert np.allclose(-G[:, 25], -np.linalg.solve(L, bk), atol=1e-10)
+
+
+def test_unpivoted_cholesky_is_not_rank_revealing():
+    """A (numerically) singular PSD matrix whose null vector has a small component on the LAST index: the unpivoted factorisation's last
+    pivot is lambda_min / v_last^2 — here eight orders of magnitude above lambda_min — while the diagonally pivoted one ends on a
+    pivot of the order of lambda_min."""
+    rng = np.random.default_rng(3)
+    n = 30
+    v = rng.standard_normal(n); v[-1] = 1e-4; v /= np.linalg.norm(v)
+    Q, _ = np.linalg.qr(np.column_stack([v, rng.standard_normal((n, n - 1))]))
+    lam = np.concatenate([[1e-10], np.logspace(0, 2, n - 1)])
+    A = (Q * lam) @ Q.T
+    L = np.linalg.cholesky(A)
+    last_unpivoted = L[-1, -1] ** 2
+    Ainv_nn = np.sum(Q[-1] ** 2 / lam)                                            # (A^-1)_nn = v_n^2 / lambda_min + the other eigen-pairs' share
+    assert np.isclose(last_unpivoted, 1.0 / Ainv_nn, rtol=1e-3)                   # the last pivot is the Schur complement 1 / (A^-1)_nn ...
+    assert 0.5 * lam[0] / Q[-1, 0] ** 2 <= last_unpivoted <= lam[0] / Q[-1, 0] ** 2   # ... i.e. lambda / v_i^2 up to the well-conditioned rest
+    assert last_unpivoted > 1e6 * lam[0]
+    # diagonal pivoting
+    W = A.copy(); idx = list(range(n)); piv = []
+    for k in range(n):
+        j = k + int(np.argmax(np.diag(W)[k:]))
+        W[[k, j]] = W[[j, k]]; W[:, [k, j]] = W[:, [j, k]]
+        piv.append(W[k, k])
+        c = W[k + 1:, k] / W[k, k]
+        W[k + 1:, k + 1:] -= np.outer(c, W[k + 1:, k])
+    assert piv[-1] < 1e2 * lam[0]
+
+
+def test_threshold_pivoting_bounds_the_factor():
+    """With pivots d_k >= theta max_j d_j the entries of column k obey |L_ik| <= sqrt(d_i d_k) / sqrt(d_k) <= sqrt(max d / theta) ...
+    i.e. L_ik^2 <= d_i <= max_j d_j <= d_k / theta: every entry of a column is within sqrt(1 / theta) of its diagonal entry."""
+    rng = np.random.default_rng(4)
+    A, _, _ = spd(60, rng, cond=1e8)
+    theta = 0.1
+    n = 60
+    W = A.copy(); done = np.zeros(n, bool); L = np.zeros((n, n)); order = []
+    for k in range(n):
+        d = np.where(done, -np.inf, np.diag(W))
+        ok = np.flatnonzero(d >= theta * d.max())
+        j = int(rng.choice(ok))                     # ANY index that passes the threshold, not the arg max
+        order.append(j)
+        col = W[:, j] / np.sqrt(W[j, j]); col[done] = 0.0
+        L[:, k] = col
+        W -= np.outer(col, col)
+        done[j] = True
+    P = np.array(order)
+    assert np.allclose(L @ L.T, A, atol=1e-9 * np.abs(A).max())
+    for k in range(n):
+        assert np.abs(L[:, k]).max() <= np.sqrt(1.0 / theta) * L[P[k], k] * (1 + 1e-9)
