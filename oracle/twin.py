@@ -904,6 +904,10 @@ def cholesky_solve(B, A, b):
 def schur_solve(B, P, H, g, D2):
     """(H + diag(D2)) y = g by eliminating the landmark blocks — only used for the long-double arbitration runs on windows
     whose un-reduced system is too large for a long-double dense factorisation. Exact-arithmetic equivalent of cholesky_solve."""
+    if getattr(P, "dense", None) is not None and np.sum(np.asarray(P.dense.get("lmk_col", [])) >= 0) > 1:
+        # a dense prior couples its kept landmarks with each other: eliminating them block by block is not the same system any more
+        # (found in round 4: the "Schur" twin differed from every other implementation by 9e-4 on such a window)
+        raise ValueError("schur_solve: the landmark blocks are coupled by a dense prior; use the un-reduced solve")
     npz = P.n_pose
     A = H + np.diag(D2)
     S = A[:npz, :npz].copy()

@@ -169,13 +169,29 @@ def test_chaotic_window_against_long_double_twin(oracle_lib):
     oracle's, and the device must not be further from the arbiter than 6x the float64 implementations are (oracle, float64 twin)."""
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_seed961174670_ld.npz")
-    if not os.path.exists(path):
-        pytest.skip("arbiter fixture not generated (scripts/fuzz_arbitrate.py twin 961174670 ld: ~40 CPU-minutes)")
     b = [b for b in _pinned() if b["spec"]["seed"] == 961174670][0]
-    z = np.load(path)
     w = fz.build_window(b["spec"])
     opts = fz.options(b)
     ref = oracle_lib.solve(w, opts, dense_prior=w.dense_prior)
+    if not os.path.exists(path):
+        # No arbiter: the un-reduced long-double factorisation of this window (2 943 unknowns) did not finish in 3.9 h on the build
+        # container, and the landmark-eliminating twin does not apply (the dense prior couples the landmarks). What CAN be held without
+        # one: the LM path is the oracle's, and the solutions differ by no more than a few times the oracle's own 1-ulp sensitivity
+        # (1.9e-4 in a pose, 1.2e-5 in the cost — measured by scripts/fuzz_check_bad.py, profiles/r04_fuzz_a1_flagged.json).
+        for graph in (True, False):
+            be = capi.Backend(device=0, use_graph=graph)
+            try:
+                be.set_windows([w])
+                s = be.solve(opts)[0]
+                d = be.get_deltas(0)
+            finally:
+                be.close()
+            assert (s.iterations, s.termination) == (ref["summary"].iterations, ref["summary"].termination)
+            e = float(np.abs(d["pose"] - ref["pose"]).max())
+            print(f"[fuzz seed 961174670, no arbiter] |pose device - oracle| {e:.2e} (oracle's own 1-ulp sensitivity 1.9e-4)")
+            assert e <= 1e-3 and abs(s.final_cost - ref["summary"].final_cost) <= 1e-4 * ref["summary"].final_cost
+        return
+    z = np.load(path)
     e_ora = float(np.abs(ref["pose"] - z["pose"]).max())
     e_t64 = float(np.abs(z["pose_f64_twin"] - z["pose"]).max())
     floor = max(e_ora, e_t64, POSE_TOL)
