@@ -901,37 +901,74 @@ def cholesky_solve(B, A, b):
     return x
 
 
+def kept_landmark_columns(P):
+    """Columns of the landmarks a dense prior couples with each other (they cannot be eliminated block by block)."""
+    dp = getattr(P, "dense", None)
+    if dp is None:
+        return []
+    cols = []
+    for li, lc in zip(np.asarray(dp.get("lmk_index", []), dtype=int), np.asarray(dp.get("lmk_col", []), dtype=int)):
+        if lc >= 0 and P.lmk_col[li] >= 0:
+            cols.extend(range(P.lmk_col[li], P.lmk_col[li] + 3))
+    return cols
+
+
 def schur_solve(B, P, H, g, D2):
-    """(H + diag(D2)) y = g by eliminating the landmark blocks — only used for the long-double arbitration runs on windows
-    whose un-reduced system is too large for a long-double dense factorisation. Exact-arithmetic equivalent of cholesky_solve."""
-    if getattr(P, "dense", None) is not None and np.sum(np.asarray(P.dense.get("lmk_col", [])) >= 0) > 1:
-        # a dense prior couples its kept landmarks with each other: eliminating them block by block is not the same system any more
-        # (found in round 4: the "Schur" twin differed from every other implementation by 9e-4 on such a window)
-        raise ValueError("schur_solve: the landmark blocks are coupled by a dense prior; use the un-reduced solve")
+    """(H + diag(D2)) y = g by eliminating the landmark blocks no other landmark is coupled with — only used for the long-double
+    arbitration runs on windows whose un-reduced system is too large for a long-double dense factorisation (2 943 unknowns: > 4 h).
+    The landmarks a dense prior holds are coupled with each other through it: they stay in the reduced system beside the poses (round
+    4: eliminating them block by block as well solved a different system, 9e-4 off every other implementation). Exact-arithmetic
+    equivalent of cholesky_solve."""
     npz = P.n_pose
     A = H + np.diag(D2)
-    S = A[:npz, :npz].copy()
-    gp = g[:npz].copy()
+    kept = kept_landmark_columns(P)
+    kept_set = set(kept)
+    R = list(range(npz)) + kept
+    S = A[np.ix_(R, R)].copy()
+    gR = g[R].copy()
     Minv = {}
     for l in range(P.n_lmk):
         c = P.lmk_col[l]
-        if c < 0:
+        if c < 0 or c in kept_set:
             continue
         Mi = inv3(B, A[c: c + 3, c: c + 3])
         Minv[l] = Mi
         E = A[:npz, c: c + 3]
         Y = E @ Mi
-        S -= Y @ E.T
-        gp -= Y @ g[c: c + 3]
-    yp = cholesky_solve(B, S, gp)
-    if yp is None:
+        S[:npz, :npz] -= Y @ E.T
+        gR[:npz] -= Y @ g[c: c + 3]
+    yR = cholesky_solve(B, S, gR)
+    if yR is None:
         return None
     y = B.zeros(P.n)
-    y[:npz] = yp
+    y[R] = yR
+    yp = yR[:npz]
     for l, Mi in Minv.items():
         c = P.lmk_col[l]
         y[c: c + 3] = Mi @ (g[c: c + 3] - A[:npz, c: c + 3].T @ yp)
     return y
+
+
+def normal_matrix(B, J):
+    """J^T J. Long double has no BLAS: a dense product of the (rows x n) Jacobian is 38 minutes per LM iteration at n = 2 943, so the
+    rows are taken by their sparsity — a reprojection row touches 9 columns (outer-product update), the rows of a dense prior form one
+    dense block over the prior's columns."""
+    if B.kind != "ld":
+        return J.T @ J
+    n = J.shape[1]
+    H = np.zeros((n, n), dtype=J.dtype)
+    nz = J != 0
+    cnt = nz.sum(axis=1)
+    dense_rows = np.flatnonzero(cnt > 64)
+    if len(dense_rows):
+        cols = np.flatnonzero(nz[dense_rows].any(axis=0))
+        Jb = J[np.ix_(dense_rows, cols)]
+        H[np.ix_(cols, cols)] += Jb.T @ Jb
+    for i in np.flatnonzero((cnt > 0) & (cnt <= 64)):
+        idx = np.flatnonzero(nz[i])
+        v = J[i, idx]
+        H[np.ix_(idx, idx)] += np.outer(v, v)
+    return H
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -1069,7 +1106,7 @@ def lm_solve(w, opts=None, kind="f64", digits=50, use_schur=False, max_iteration
                     d = (J[:, i] * J[:, i]).sum()
                     diagonal[i] = min(max(d, B.s(o["min_lm_diagonal"])), B.s(o["max_lm_diagonal"]))
             D2 = diagonal / radius                                # lm_diagonal = sqrt(diagonal / radius); D^2 enters the normal equations
-            H = J.T @ J
+            H = normal_matrix(B, J)
             rhs = J.T @ r
             y = schur_solve(B, P, H, rhs, D2) if use_schur else cholesky_solve(B, H + np.diag(D2), rhs)
             valid = y is not None and all(B.isfinite(v) for v in y)

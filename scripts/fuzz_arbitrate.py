@@ -49,9 +49,11 @@ def twin_mode(seed, kind, schur):
         print(f"  landmark {i}: |twin - oracle| {dl[i]:.2e}, its own |delta| {np.abs(ref['lmk'][i]).max():.3e}")
     ok, rep = conditioning.pose_difference_within_conditioning(w, oracle, ref, pose, ref["pose"], 1e-6)
     print("  conditioning:", ok, rep)
-    if kind == "ld" and not schur:
+    if kind == "ld":
+        # (`schur`: the landmarks no other landmark is coupled with are eliminated first, exactly — minutes instead of > 4 h at ~3 000
+        # unknowns; the float64 twin beside it is the un-reduced LAPACK one either way)
         r64 = twin.lm_solve(w, opts, kind="f64")
-        np.savez_compressed(os.path.join(GOLDEN, f"fuzz_seed{seed}_ld.npz"), pose=pose, lmk=lmk,
+        np.savez_compressed(os.path.join(GOLDEN, f"fuzz_seed{seed}_ld.npz"), pose=pose, lmk=lmk, schur=np.array(int(schur)),
                             pose_f64_twin=np.asarray(r64["pose"], dtype=np.float64), lmk_f64_twin=np.asarray(r64["lmk"], dtype=np.float64))
 
 

@@ -164,9 +164,13 @@ def test_chaotic_window_against_long_double_twin(oracle_lib):
     """Seed 961174670 (round-4 sweep; 18 key-frames, 945 four-view landmarks, a dense prior, Huber): 20 LM iterations without
     convergence along a valley on which the ORACLE itself moves by 1.9e-4 in a pose / 1.2e-5 in the cost under a 1-ulp nudge of the
     measurements, the device by 1.1e-4 from run to run (summation order of its atomics) — beyond the caps of the sweep's allowance, so
-    it is arbitrated explicitly: oracle/twin.py in LONG DOUBLE on the un-reduced normal equations
-    (tests/golden/fuzz_seed961174670_ld.npz, scripts/fuzz_arbitrate.py). The LM path (iterations, termination) must be the
-    oracle's, and the device must not be further from the arbiter than 6x the float64 implementations are (oracle, float64 twin)."""
+    it is arbitrated explicitly: oracle/twin.py in LONG DOUBLE (tests/golden/fuzz_seed961174670_ld.npz,
+    scripts/fuzz_arbitrate.py twin 961174670 ld schur: the landmarks the dense prior does not couple are eliminated first, exactly —
+    the un-reduced long-double factorisation of the 2 943 unknowns did not finish in 3.9 h; J^T J row by row, twin.normal_matrix).
+    Outcome: the un-reduced float64 twin (LAPACK) is 3.8e-8 from the arbiter, the ORACLE 2.1e-4, the device 1.3e-4 .. 2.1e-4 — the
+    two float64 implementations that eliminate the landmarks (oracle, device) are equally far from the truth, the disagreement
+    between them is the rounding of that elimination on an ill-conditioned valley. The LM path (iterations, termination) must be
+    the oracle's, and the device must not be further from the arbiter than 3x the oracle is."""
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_seed961174670_ld.npz")
     b = [b for b in _pinned() if b["spec"]["seed"] == 961174670][0]
@@ -206,7 +210,7 @@ def test_chaotic_window_against_long_double_twin(oracle_lib):
         assert (s.iterations, s.termination) == (ref["summary"].iterations, ref["summary"].termination)
         e_dev = float(np.abs(d["pose"] - z["pose"]).max())
         print(f"[fuzz arbiter 961174670] |pose - long double|: device {e_dev:.2e}, oracle {e_ora:.2e}, float64 twin {e_t64:.2e}")
-        assert e_dev <= 6 * floor, (e_dev, e_ora, e_t64)
+        assert e_dev <= 3 * floor, (e_dev, e_ora, e_t64)
         assert abs(s.final_cost - ref["summary"].final_cost) <= 1e-3 * ref["summary"].final_cost
 
 
