@@ -508,3 +508,28 @@ def test_solve_with_line_landmarks_matches_twin_iterate_by_iterate(oracle_lib, f
     assert np.abs(got["line"] - ref["line"]).max() < 1e-8 * max(1.0, np.abs(ref["line"]).max())
     assert np.all(got["line"][0] == 0.0) and np.all(ref["line"][0] == 0.0)     # the constant line
     assert np.abs(got["lmk"] - ref["lmk"]).max() < 1e-8 * max(1.0, np.abs(ref["lmk"]).max())
+
+
+def test_twin_partial_landmark_elimination_is_exact_with_a_dense_prior():
+    """The long-double arbitration of sweep window 961174670 (tests/test_gpu_fuzz.py) rests on twin.schur_solve: the landmarks a dense
+    prior couples stay in the reduced system beside the poses, only the uncoupled ones are eliminated. It must solve the SAME system as
+    the un-reduced factorisation (eliminating every landmark block by block does not: 9e-4 off on that window), and the row-wise
+    J^T J of the long-double path must be the dense product."""
+    from test_gpu_prior import random_prior
+    w = synthetic.make_window(n_kf=5, n_lmk=60, seed=21)
+    w.dense_prior = random_prior(w, 9, -1, np.random.default_rng(3), rank_deficit=0)
+    for kind in ("f64", "ld"):
+        B = twin.Backend(kind, 50)
+        P = twin.Problem(B, w)
+        x = B.zeros(P.n)
+        _, _, r, J = P.evaluate(x)
+        H = twin.normal_matrix(B, J)
+        Hd = J.T @ J
+        assert np.abs(np.asarray(H - Hd, dtype=np.float64)).max() <= 1e-12 * np.abs(np.asarray(Hd, dtype=np.float64)).max()
+        g = J.T @ r
+        D2 = B.zeros(P.n) + B.s(1e-3)
+        y_full = twin.cholesky_solve(B, H + np.diag(D2), g)
+        y_schur = twin.schur_solve(B, P, H, g, D2)
+        assert len(twin.kept_landmark_columns(P)) == 27          # 9 kept landmarks stay beside the poses
+        err = np.abs(np.asarray(y_full - y_schur, dtype=np.float64)).max()
+        assert err <= (1e-9 if kind == "f64" else 1e-13) * max(1.0, np.abs(np.asarray(y_full, dtype=np.float64)).max()), (kind, err)
