@@ -75,6 +75,7 @@ def main():
                          "over the ranks, reduced system all-reduced over RCCL per LM step (strong scaling). With N > 1 the "
                          "default run reports it as the `sharded_window` object next to the independent-window line")
     ap.add_argument("--no-marginalize", action="store_true")
+    ap.add_argument("--no-sharded", action="store_true", help="N = 1: skip the one-rank run of the sharded config-4 window (RCCL communicator of size 1)")
     ap.add_argument("--no-vio", action="store_true", help="skip the config-3 shaped VIO window leg (the profiled runs of scripts/prof_bench.sh: one k_solve variant per trace)")
     args = ap.parse_args()
 
@@ -144,6 +145,8 @@ def main():
     sps = max(1, args.solves_per_step)
     dt = timed_solves(be, opts, args.steps, args.warmup, sps)
     sums = be.solve(opts)
+    gpu_sol = be.get_deltas(0)
+    gpu_ids = be.get_ids(0)
     # upload-inclusive rate: set_windows (validation, tiling, one pinned staging copy) + solve + read-back per solve
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -184,7 +187,10 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     ms_per_solve = ms_per_step / sps
     # N > 1: the collective path as well (same processes, same communicator): config 4 sharded over the ranks
-    sharded = bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves) if world > 1 else None
+    # the collective path (config 4 sharded over the ranks; RCCL all-reduce of the reduced system per LM step). At N = 1 it runs
+    # through the same sadvio_ba_comm_init_rccl / ncclAllReduce calls with a one-rank communicator, so that every driver record
+    # contains the path; the scaling curve only exists for N > 1
+    sharded = bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves) if (world > 1 or not args.no_sharded) else None
     sharded5 = bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves, config=5) if world > 1 else None
 
     out = None
@@ -225,6 +231,51 @@ def main():
                     # whole LM step from the TIMED region (not from the event-inflated kernel sum): B_iter x iterations / elapsed
                     "iteration_achieved_GBps": round(sum(ab.values()) * iters_per_solve / (ms_per_solve * 1e-3) / 1e9, 2),
                     "iteration_frac_of_hbm_peak": round(sum(ab.values()) * iters_per_solve / (ms_per_solve * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        # the two STREAMING kernels (HBM-bound by design; k_solve is a one-workgroup-per-window factorisation, latency-bound): algorithmic
+        # GB/s from the live hipEvent durations, HBM traffic / algorithmic bytes from the committed PMC passes
+        stream_k = {}
+        for k in ("k_build", "k_backsub"):
+            if k in kt:
+                g = ab[k] / (kt[k]["avg_us"] * 1e-6) / 1e9
+                rec = {"algorithmic_bytes_per_launch": ab[k], "avg_kernel_us": round(kt[k]["avg_us"], 3), "achieved_GBps": round(g, 1),
+                       "frac_of_hbm_peak": round(g / HBM_PEAK_GBS, 5)}
+                kk = (prof or {}).get("kernels", {}).get(k, {}) if len(wins) == 1 else {}
+                if "hbm_traffic_bytes_per_launch" in kk:
+                    rec["traffic"] = round(kk["hbm_traffic_bytes_per_launch"])
+                    rec["traffic_over_algorithmic"] = round(kk["hbm_traffic_bytes_per_launch"] / ab[k], 3)
+                if "avg_us" in kk:
+                    rec["avg_kernel_us_rocprof"] = round(kk["avg_us"], 3)
+                stream_k[k] = rec
+        roofline["streaming_kernels"] = stream_k
+        roofline["bound_note"] = ("`kernel` is the launch with the largest share of the step; k_solve is ONE workgroup per window (an in-LDS Cholesky of the "
+                                  "reduced system): neither HBM- nor MFMA-bound but bound by its pivot chain's latency — its hbm fraction is reported because "
+                                  "the contract asks for the dominant kernel; the HBM-bound kernels of the step are under `streaming_kernels`, the "
+                                  "bandwidth-bound regime under `batched`")
+        # --- parity of the TIMED configuration against the CPU solve of the same window (BASELINE.json metric: "pose-RMSE vs Ceres";
+        # the reference cannot be built, the CPU solve is the oracle's) ---
+        parity = None
+        if cpu and cpu.get("_ref"):
+            ref = cpu.pop("_ref")
+            ang, dis = [], []
+            for i in range(w0.n_kf):
+                a = synthetic.apply_pose_delta(w0.kf_T_f_w[i], gpu_sol["pose"][i])   # T_f_w <- T_f_w (exp w, t), AOptimizer.cpp:329-332
+                b = synthetic.apply_pose_delta(w0.kf_T_f_w[i], ref["pose"][i])
+                Ra, Rb = np.asarray(a[:9]).reshape(3, 3), np.asarray(b[:9]).reshape(3, 3)
+                D = Ra @ Rb.T     # |log(Ra Rb^T)| from the skew part (arccos of the trace resolves nothing below 1.5e-8 rad)
+                v = 0.5 * np.array([D[2, 1] - D[1, 2], D[0, 2] - D[2, 0], D[1, 0] - D[0, 1]])
+                ang.append(float(np.arctan2(np.linalg.norm(v), 0.5 * (np.trace(D) - 1.0))))
+                dis.append(float(np.linalg.norm(np.asarray(a[9:]) - np.asarray(b[9:]))))
+            ang, dis = np.asarray(ang), np.asarray(dis)
+            parity = {"against": "CPU oracle solve of the identical window (port of the reference's algorithm; Ceres itself is not on the box)",
+                      "max_pose_delta": float(max(ang.max(), dis.max())), "max_rotation_rad": float(ang.max()), "max_translation_m": float(dis.max()),
+                      "pose_rmse_rotation_rad": float(np.sqrt((ang ** 2).mean())), "pose_rmse_translation_m": float(np.sqrt((dis ** 2).mean())),
+                      "max_landmark_delta_m": float(np.abs(gpu_sol["lmk"] - ref["lmk"]).max()),
+                      "final_cost_rel_diff": float(abs(sums[0].final_cost - ref["final_cost"]) / abs(ref["final_cost"])),
+                      "iterations_gpu_cpu": [int(sums[0].iterations), int(ref["iterations"])],
+                      "lmk_ids_bitexact": bool(np.array_equal(gpu_ids[1], w0.lmk_id) and np.array_equal(gpu_ids[0], w0.kf_id)),
+                      "tolerance": "north_star: pose delta <= 1e-6, landmark indices bit-exact"}
+        elif cpu:
+            cpu.pop("_ref", None)
         # --- batched throughput (independent windows in one submission) ---
         batched = None
         if args.batch > 0 and world == 1:
@@ -285,7 +336,7 @@ def main():
                        "windows_per_gpu": args.windows, "iterations_per_solve": iters_per_solve // max(1, args.windows),
                        "parallelism": f"independent windows x{world}" if world > 1 else "single window",
                        "n_kf": w0.n_kf, "n_lmk": w0.n_lmk, "n_obs": w0.n_obs, "reduced_dim": n_p},
-            "roofline": roofline, "cpu_baseline": cpu, "batched": batched,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "batched": batched,
             "upload_inclusive": {"value": round(iters_per_solve / dt_up, 1), "unit": "BA iterations/s",
                                  "ms_per_solve": round(1e3 * dt_up, 4),
                                  "what": "set_windows (host flatten -> HBM) + solve + get_deltas per solve, rank 0",
@@ -294,6 +345,9 @@ def main():
                                                   "what": "two handles on two host threads, each set_windows + solve + get_deltas in turn: one handle's layout build runs under the other's solve"})},
             "marginalize": marg, "backend_step": bstep, "vio_window": vio, "sharded_window": sharded, "sharded_window_c5": sharded5,
         }
+        if cpu and batched and cpu.get("batched"):
+            batched["speedup_vs_cpu_batched"] = round(batched["value"] / cpu["batched"]["value"], 1)
+            batched["speedup_note"] = "throughput regime against throughput regime: 64 windows per GPU submission vs independent windows on all usable host cores"
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
             out["speedup_vs_cpu_at_reference_threads"] = round(value / cpu["at_reference_threads"]["value"], 1)
@@ -322,7 +376,10 @@ def cpu_baseline_leg(w0, opts):
             n += r["summary"].iterations
         res[thr] = n / (time.perf_counter() - t0)
     best = max(res, key=res.get)
+    ref = oracle.solve(w0, opts, n_threads=1)    # the CPU solution of the timed window: `parity` compares the GPU solve with it
     return {"value": round(res[best], 2), "unit": "BA iterations/s", "cores": best, "kind": "port",
+            "_ref": {"pose": ref["pose"], "lmk": ref["lmk"], "final_cost": ref["summary"].final_cost, "iterations": ref["summary"].iterations},
+            "batched": cpu_batched_leg(oracle, w0, opts, usable),
             "at_reference_threads": {"threads": 4, "value": round(res[4], 2), "why": "the reference's own setting: options.num_threads = 4 (AOptimizer.cpp:323)"},
             "sample": f"config-2 window, GN-{GN_ITERS} solves repeated for ~3 s per thread count",
             "threads_it_per_s": {str(k): round(v, 1) for k, v in res.items()},
@@ -333,6 +390,47 @@ def cpu_baseline_leg(w0, opts):
                     "`value` = the C oracle (explicit Schur complement + dense Cholesky, OpenMP over landmarks with per-thread "
                     "reduced-system accumulators); sparse_normal_cholesky_emulation = the reference's own linear-solver choice "
                     "(un-reduced J^T J + D, sparse direct factorisation) with SciPy's SuperLU standing in for CHOLMOD"}
+
+
+def cpu_batched_leg(oracle, w0, opts, usable, budget_s=4.0):
+    """The CPU counterpart of the GPU's `batched` regime (VERDICT r04 missing #4): independent config-2 windows solved concurrently on
+    ALL usable host cores — usable / t workers (host threads; the problem is marshalled once per worker and the C solver called in a
+    loop with the GIL released), each solving whole windows with t OpenMP threads — for t = 1 and t = 4 (the reference's
+    num_threads, AOptimizer.cpp:323). The windows are the same one (the solves are independent and deterministic);
+    throughput = completed LM iterations / wall time."""
+    import ctypes as C
+    import threading
+    import numpy as np
+    from oracle import structs as S
+    copts = S.options_from(opts)
+    lib = oracle.lib()
+    out = {}
+    for t in (1, 4):
+        workers = max(1, usable // t)
+        probs = [oracle.make_problem(w0, None, t) for _ in range(workers)]
+        done = [0] * workers
+        stop = [0.0]
+
+        def work(k):
+            P, _keep = probs[k]
+            pose = np.zeros((w0.n_kf, 6)); lmk = np.zeros((w0.n_lmk, 3)); z = [np.zeros((w0.n_kf, 3)) for _ in range(3)]
+            log = np.zeros((64, 8)); sm = oracle.SolveSummary()
+            while time.perf_counter() < stop[0]:
+                lib.oracle_solve(C.byref(P), C.byref(copts), C.byref(sm), oracle._p(pose), oracle._p(lmk), oracle._p(z[0]), oracle._p(z[1]),
+                                 oracle._p(z[2]), oracle._p(log), 64)
+                done[k] += sm.iterations
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(workers)]
+        t0 = time.perf_counter()
+        stop[0] = t0 + budget_s
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        out[str(t)] = {"workers": workers, "threads_per_window": t, "value": round(sum(done) / (time.perf_counter() - t0), 1)}
+    best = max(out.values(), key=lambda r: r["value"])
+    return {"value": best["value"], "unit": "BA iterations/s", "cores": best["workers"] * best["threads_per_window"],
+            "windows_in_flight": best["workers"], "by_threads_per_window": out,
+            "sample": f"independent config-2 windows in flight on all usable cores ({usable}), GN-{GN_ITERS} solves for ~{budget_s:.0f} s per setting"}
 
 
 def bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves, config=4):

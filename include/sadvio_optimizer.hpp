@@ -364,14 +364,20 @@ class HipOptimizer {
     int prior_rows() const { return _prior.n_full; }
     int prior_cols() const { return _prior.n; }
     // n_full x n row-major, read back from the device on request (sadvio_ba_get_prior): the solve path never needs it on the host
+    // Read-backs over PCIe (not for per-frame use); the buffers are sized from what the HANDLE reports, not from this object's copy
+    // of the shape, so a divergence between the two cannot overflow them.
     std::vector<double> prior_J() const {
-        std::vector<double> J((size_t)std::max(_prior.n_full * _prior.n, 0));
-        if (_prior.valid && sadvio_ba_get_prior(_h, nullptr, J.data(), nullptr) != SADVIO_OK) J.clear();
+        sadvio_prior_info pi{};
+        if (!_prior.valid || sadvio_ba_get_prior(_h, &pi, nullptr, nullptr) != SADVIO_OK || !pi.valid) return {};
+        std::vector<double> J((size_t)pi.n_full * (size_t)pi.n);
+        if (sadvio_ba_get_prior(_h, nullptr, J.data(), nullptr) != SADVIO_OK) J.clear();
         return J;
     }
     std::vector<double> prior_r0() const {
-        std::vector<double> r((size_t)std::max(_prior.n_full, 0));
-        if (_prior.valid && sadvio_ba_get_prior(_h, nullptr, nullptr, r.data()) != SADVIO_OK) r.clear();
+        sadvio_prior_info pi{};
+        if (!_prior.valid || sadvio_ba_get_prior(_h, &pi, nullptr, nullptr) != SADVIO_OK || !pi.valid) return {};
+        std::vector<double> r((size_t)pi.n_full);
+        if (sadvio_ba_get_prior(_h, nullptr, nullptr, r.data()) != SADVIO_OK) r.clear();
         return r;
     }
     // Eigenvalue cut of marginalize / marginalizeRelative (SADVIO_EIG_CUT_*; default: the reference's absolute 1e-12,

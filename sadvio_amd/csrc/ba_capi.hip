@@ -128,6 +128,7 @@ struct UploadBatch {
     char* pinned = nullptr; size_t pinned_cap = 0, used = 0;   // sources are packed straight into pinned memory
     char* dev = nullptr; size_t dev_cap = 0;
     bool failed = false;
+    void reset() { items.clear(); used = 0; failed = false; }   // drop what an earlier, failed layout build left queued
     void reserve(size_t bytes) {
         if (bytes <= pinned_cap) return;
         char* np = nullptr;
@@ -441,6 +442,15 @@ __global__ void k_sym_from_lower(const double* __restrict__ A, int n, double* __
 // Called by set_windows and again by set_dense_prior (kept landmarks enlarge the reduced system).
 int layout_reduced(sadvio_ba_handle* h) {
     const int n_windows = (int)h->wins.size();
+    // a resident prior that changed after it was attached is refused BEFORE anything is queued in h->up: a non-fatal return with
+    // items in the batch would scatter them, stale, with the next successful flush (the device buffers are grow-only)
+    for (int w = 0; w < n_windows && w < (int)h->dprior_per_win.size(); w++) {
+        const DensePriorHost& D = h->dprior_per_win[w];
+        if (D.n_full > 0 && D.resident && (!h->prior.valid || h->prior.serial != D.serial || h->prior.n_full != D.n_full || h->prior.n != D.n)) {
+            h->up.reset();
+            h->err = "the handle's prior changed after set_dense_prior(SADVIO_PRIOR_RESIDENT) attached it to a window: attach it again"; return SADVIO_E_STATE;
+        }
+    }
     int red_b = 0; long long s_b = 0;
     h->max_np = 0; h->n_big = 0;
     std::vector<int> lmk_red(std::max(h->n_lmk_tot, 1), -1);
@@ -751,6 +761,7 @@ static int build_layout(sadvio_ba_handle* h) {
     const int n_windows = (int)h->src.size();
     HIP_TRY(hipSetDevice(h->device));
     h->solved = false;
+    h->up.reset();
     h->wins.assign(n_windows, HostWin());
     h->tiles.clear();
     h->sp_elim.assign(n_windows, {});
@@ -1305,6 +1316,7 @@ int sadvio_ba_commit_update(sadvio_ba_handle* h) {
     if (!h->pending) return SADVIO_OK;
     h->pending = false;
     HIP_TRY(hipSetDevice(h->device));
+    h->uploaded = false;   // the deferred set_windows left stub window records: a failed build must not leave them usable
     return build_layout(h);
 }
 
@@ -1340,10 +1352,12 @@ int sadvio_ba_set_lines(sadvio_ba_handle* h, int32_t w, const sadvio_line_set* L
     }
     h->lines_per_win[w] = std::move(H);
     h->solved = false;
-    if (h->defer) return SADVIO_OK;
+    if (h->defer) { h->pending = true; return SADVIO_OK; }
+    h->up.reset();
     int rc = layout_reduced(h);   // the lines enlarge the reduced system; the landmark tiles are unchanged
     if (rc != SADVIO_OK) return rc;
-    return h->defer ? SADVIO_OK : upload_priors(h);
+    if (h->defer) { h->pending = true; return SADVIO_OK; }
+    return upload_priors(h);
 }
 
 int sadvio_ba_get_line_deltas(sadvio_ba_handle* h, int32_t w, double* line_delta6) {
@@ -1372,7 +1386,9 @@ int sadvio_ba_set_pose_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const s
         memcpy(d.inf, pr[i].inf_diag, sizeof(d.inf));
         v.push_back(d);
     }
-    return h->defer ? SADVIO_OK : upload_priors(h);
+    if (h->defer) { h->pending = true; return SADVIO_OK; }
+    h->up.reset();
+    return upload_priors(h);
 }
 
 // 9x9 square-root information W = L^T with L L^T = cov^-1 (residuals.hpp:151-154): Gauss-Jordan inverse with
@@ -1442,7 +1458,9 @@ int sadvio_ba_set_imu_factors(sadvio_ba_handle* h, int32_t w, int32_t n, const s
         o.sg = 1.0 / sqrt(f.dt * f.bgyr_noise * f.bgyr_noise);
         v.push_back(o);
     }
-    return h->defer ? SADVIO_OK : upload_priors(h);
+    if (h->defer) { h->pending = true; return SADVIO_OK; }
+    h->up.reset();
+    return upload_priors(h);
 }
 
 int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t w, int32_t n_full, int32_t n, const double* J, const double* r0,
@@ -1480,11 +1498,13 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t w, int32_t n_full, in
         D.lmk_index.assign(lmk_index, lmk_index + n_keep); D.lmk_col.assign(lmk_col, lmk_col + n_keep);
     }
     h->dprior_per_win[w] = std::move(D);
-    if (h->defer) return SADVIO_OK;
+    if (h->defer) { h->pending = true; return SADVIO_OK; }
     if (!h->sparse_per_win[w].empty()) return build_layout(h);  // which sparse factors are eliminable may change
+    h->up.reset();
     int rc = layout_reduced(h);
     if (rc != SADVIO_OK) return rc;
-    return h->defer ? SADVIO_OK : upload_priors(h);
+    if (h->defer) { h->pending = true; return SADVIO_OK; }
+    return upload_priors(h);
 }
 
 int sadvio_ba_set_sparse_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const sadvio_sparse_prior* f) {
@@ -1518,7 +1538,7 @@ int sadvio_ba_set_sparse_priors(sadvio_ba_handle* h, int32_t w, int32_t n, const
         }
     }
     h->sparse_per_win[w].assign(f, f + n);
-    if (h->defer) return SADVIO_OK;
+    if (h->defer) { h->pending = true; return SADVIO_OK; }
     return build_layout(h);  // eliminable pose-to-landmark factors become pseudo-observations: the tiles change
 }
 
@@ -2968,7 +2988,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         // graph must not replay it when an A/B switch changes
         const int env_bits = (int)with_imu + 2 * (getenv("SADVIO_NO_FORK") != nullptr) + 4 * (getenv("SADVIO_WD_NOLA") != nullptr) + 8 * (getenv("SADVIO_WD_BACK1") != nullptr) +
                              16 * (getenv("SADVIO_WD_OLD") != nullptr) + 32 * (getenv("SADVIO_NO_BCR") != nullptr) + 64 * (getenv("SADVIO_NO_PAR") != nullptr) + 128 * (getenv("SADVIO_NO_LPT") != nullptr) +
-                             256 * (getenv("SADVIO_WD_R3") != nullptr);
+                             256 * (getenv("SADVIO_WD_R3") != nullptr) + 512 * (lm_threads / 64);   // lm_threads: the launch shape of k_elim / k_backsub_lm inside the capture
         const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type + 2 * (int)extras + 4 * (int)rare + 8 * (int)use_lm + 16 * env_bits};  // P (incl. decide_kernel) is part of the key
         memcpy(kp, ints, sizeof(ints)); kp += sizeof(ints);
         const size_t szs[3] = {lds_build, lds_back, lds_solve};
@@ -3269,6 +3289,6 @@ int sadvio_ba_get_kernel_times(sadvio_ba_handle* h, int32_t cap, const char** na
 }
 
 const char* sadvio_ba_last_error(sadvio_ba_handle* h) { return h ? h->err.c_str() : "null handle"; }
-const char* sadvio_ba_version(void) { return "sadvio-ba-mi355x 0.1 (gfx950)"; }
+const char* sadvio_ba_version(void) { return "sadvio-ba-mi355x 0.5 (gfx950)"; }
 
 }  // extern "C"

@@ -11,7 +11,7 @@ ws = [synthetic.make_window(seed=20250404 + i) for i in range(4)]
 opts = capi.gn_options(10); opts.max_num_consecutive_invalid_steps = 1000
 bes = []
 for h in range(nh):
-    be = capi.Backend(device=0, use_graph=True)
+    be = capi.Backend(device=0, use_graph=not os.environ.get("NOGRAPH"))
     be.set_windows([ws[i % 4] for i in range(nw // nh)])
     for _ in range(2): be.solve(opts)
     bes.append(be)

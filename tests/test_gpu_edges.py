@@ -180,3 +180,26 @@ def test_handle_reuse_after_every_way_a_solve_can_end(backend_cls, oracle_lib, g
     fresh.close()
     # (not bit for bit: the tiles' global atomics into S land in a different order every run)
     assert np.abs(last["pose"] - d["pose"]).max() <= 1e-11 and np.abs(last["lmk"] - d["lmk"]).max() <= 1e-9
+
+
+def test_bracket_with_factor_setters_only_rebuilds(backend_cls, oracle_lib):
+    """begin_update / commit_update around factor setters alone (no set_windows in the bracket) must rebuild and upload —
+    the next solve runs with the new pose prior, not with the stale device copy."""
+    w = synthetic.make_window(n_kf=6, n_lmk=300, seed=17)
+    opts = capi.reference_options()
+    be = backend_cls(device=0)
+    be.set_windows([w])
+    s0 = be.solve(opts)[0]
+    # a different prior on the fixed key-frame's neighbour: changes the solution
+    kf, T, inf = w.pose_priors[0]
+    w2 = synthetic.make_window(n_kf=6, n_lmk=300, seed=17)
+    w2.pose_priors = [(kf, T, inf), (0, w2.truth["T_f_w"][0].copy(), 1e4 * np.ones(6))]
+    pc = w2.priors_c()
+    be._check(be.lib.sadvio_ba_begin_update(be.h), "begin_update")
+    be._check(be.lib.sadvio_ba_set_pose_priors(be.h, 0, pc[1], pc[0]), "set_pose_priors")
+    be._check(be.lib.sadvio_ba_commit_update(be.h), "commit_update")
+    s1 = be.solve(opts)[0]
+    ref = oracle_lib.solve(w2, opts)
+    assert abs(s1.final_cost - s0.final_cost) > 1e-6 * s0.final_cost          # the new factor is in the program
+    agree(be, 0, w2, ref, s1)
+    be.close()
