@@ -298,13 +298,13 @@ struct sadvio_ba_handle {
     DevBuf<int> d_chunk_ob, d_chunk_lm, d_tile_perm;   // chunk tables of the throughput kernels (lm_kernels.h)
     DevBuf<int> d_jac_ints;               // pivoting / rank of the Cholesky-preconditioned Jacobi
     DevBuf<double> d_jac_dbl;             // its remaining diagonal + threshold
-    DevBuf<int> d_kf_lmk, d_kf_cam;       // k_diag: landmark / camera of the observations sorted by key-frame (free key-frames only)
-    DevBuf<double> d_kf_meas;             //         and their measurements, in the same order
-    DevBuf<DiagSeg> d_diag_segs;
-    int n_diag_segs = 0;
-    DevBuf<double> d_lm_elim;
+    DevBuf<double> d_lm_hg, d_lm_dt, d_lm_sacc;
+    DevBuf<int> d_lm_sub;                 // work list of k_lm_pass (tile, sub-block), see DevPtrs
+    int lm_n_sub = 0, lm_ksub = 1, lm_sub_per_item = 8;   // sub-blocks per work item of k_lm_pass (8 = the whole tile: MAX tile = 512 landmarks)   // throughput path: elimination records, per-landmark H_ll | g_l and per-tile key-frame sums (both per delta buffer)
+    int lm_max_cam = 1;
+    int lm_sub_obs = 0;                   // most observations of LM_PASS_THREADS consecutive landmarks of a tile (LDS staging of k_lm_pass)
     bool gemm_run4 = false;               // a tile on the MFMA path holds runs of 3 - 4 observations on one key-frame (k_build<.., RARE = true> only)
-    bool lm_ok = false;                   // every tile is on the MFMA path and chunked: k_elim / k_build_obs / k_backsub_lm may run
+    bool lm_ok = false;                   // every tile is on the MFMA path and chunked: k_build_obs / k_lm_pass may run
     long long lm_landmarks = 0;
     DevBuf<double> d_ptab;
     int max_tile_kf = 1, max_tile_free = 0, max_gemm_free = 0;
@@ -333,8 +333,7 @@ struct sadvio_ba_handle {
     // profiling
     std::vector<KernelClass> kclasses;
     hipStream_t side = nullptr;            // IMU factor evaluation runs here, concurrently with k_build / k_backsub
-    hipStream_t side2 = nullptr;           // k_diag runs here, concurrently with k_elim / k_build_obs
-    hipEvent_t ev_fork = nullptr, ev_lin = nullptr, ev_solved = nullptr, ev_cost = nullptr, ev_diag0 = nullptr, ev_diag1 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_lin = nullptr, ev_solved = nullptr, ev_cost = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<std::pair<int, int>> ev_used;  // (class, pool index)
     size_t ev_next = 0;
@@ -410,7 +409,10 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.dp_data = h->d_dp_data.p; P.dp_ints = h->d_dp_ints.p;
     P.sparse = h->d_sparse.p; P.sp_scratch = h->d_sp_scratch.p; P.sp_list = h->d_sp_list.p;
     P.sp_scratch_stride = (long long)std::max<size_t>(h->n_sparse_tot, 1) * SPARSE_J; P.n_imu_tot = (int)h->imus.size(); P.n_sp_list = h->n_sp_list;
-    P.chunk_ob = h->d_chunk_ob.p; P.chunk_lm = h->d_chunk_lm.p; P.tile_perm = h->d_tile_perm.p; P.obs_lslot = h->d_obs_lslot.p; P.lm_elim = h->d_lm_elim.p;
+    P.chunk_ob = h->d_chunk_ob.p; P.chunk_lm = h->d_chunk_lm.p; P.tile_perm = h->d_tile_perm.p; P.obs_lslot = h->d_obs_lslot.p;
+    P.lm_hg = h->d_lm_hg.p; P.lm_hg_stride = (long long)LM_HG * std::max(h->n_lmk_tot, 1);
+    P.lm_dt = h->d_lm_dt.p; P.lm_dt_stride = (long long)LM_DT * std::max<long long>((long long)h->tiles.size(), 1) * h->lm_ksub;
+    P.lm_sub = h->d_lm_sub.p; P.lm_ksub = h->lm_ksub; P.lm_sub_per_item = h->lm_sub_per_item; P.lm_sacc = h->lm_ok ? h->d_lm_sacc.p : nullptr;
     P.lines = h->d_lines.p; P.lobs = h->d_lobs.p; P.xline = h->d_xline.p; P.line_scratch = h->d_line_scratch.p;
     P.xline_stride = 6LL * h->n_line_tot;
     P.n_xp = (long long)h->d_xp.n; P.n_xv = (long long)h->d_xv.n; P.n_xl = (long long)h->d_xl.n;
@@ -721,9 +723,6 @@ int sadvio_ba_create(const sadvio_ba_config* cfg, sadvio_ba_handle** out) {
     if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) h->side = nullptr;   // optional: without it everything is serial
     for (hipEvent_t* e : {&h->ev_fork, &h->ev_lin, &h->ev_solved, &h->ev_cost})
         if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { *e = nullptr; if (h->side) { (void)hipStreamDestroy(h->side); h->side = nullptr; } }
-    if (hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking) != hipSuccess) h->side2 = nullptr;
-    for (hipEvent_t* e : {&h->ev_diag0, &h->ev_diag1})
-        if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { *e = nullptr; if (h->side2) { (void)hipStreamDestroy(h->side2); h->side2 = nullptr; } }
     *out = h;
     return SADVIO_OK;
 }
@@ -737,8 +736,7 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     if (h->h_final) (void)hipHostFree(h->h_final);
     if (h->h_deltas) (void)hipHostFree(h->h_deltas);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
-    if (h->side2) { (void)hipStreamSynchronize(h->side2); (void)hipStreamDestroy(h->side2); }
-    for (hipEvent_t e : {h->ev_fork, h->ev_lin, h->ev_solved, h->ev_cost, h->ev_diag0, h->ev_diag1}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_fork, h->ev_lin, h->ev_solved, h->ev_cost}) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (auto& e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     h->d_win.release(); h->d_tiles.release(); h->d_kf_T0.release(); h->d_xp.release(); h->d_xv.release();
@@ -1105,7 +1103,7 @@ static int build_layout(sadvio_ba_handle* h) {
     if (const char* e = getenv("SADVIO_LM")) want_lm = atoi(e) != 0;
     h->lm_ok = want_lm && !h->tiles.empty();
     h->lm_landmarks = 0;
-    h->n_diag_segs = 0;
+    h->lm_sub_obs = 0;
     for (auto& t : h->tiles) {
         if (!want_lm) { t.chunk0 = t.chunk1 = 0; continue; }
         t.chunk0 = (int)chunk_lm.size();
@@ -1125,42 +1123,24 @@ static int build_layout(sadvio_ba_handle* h) {
     }
     chunk_lm.push_back(lmk_b); chunk_ob.push_back(obs_b);
     if (want_lm) {
-        // k_diag: per window, its observations sorted by key-frame (free ones), cut into segments of DIAG_SEG
-        std::vector<int> obs_lmk(std::max(obs_b, 1), 0), kf_obs;
-        std::vector<DiagSeg> segs;
-        for (int l = 0; l < lmk_b; l++) for (int o = lmk_ob[l]; o < lmk_oe[l]; o++) obs_lmk[o] = l;
-        for (int w = 0; w < n_windows; w++) {
-            const WinDev& d = h->wins[w].d;
-            std::vector<int> cnt(d.n_kf + 1, 0);
-            for (int o = d.obs_base; o < d.obs_base + d.n_obs; o++) if (obs_cam[o] >= 0) cnt[obs_kf[o] - d.kf_base + 1]++;
-            for (int k = 0; k < d.n_kf; k++) cnt[k + 1] += cnt[k];
-            const int base = (int)kf_obs.size();
-            kf_obs.resize(base + cnt[d.n_kf]);
-            std::vector<int> pos(cnt.begin(), cnt.end() - 1);
-            for (int o = d.obs_base; o < d.obs_base + d.n_obs; o++) if (obs_cam[o] >= 0) kf_obs[base + pos[obs_kf[o] - d.kf_base]++] = o;
-            for (int k = 0; k < d.n_kf; k++) {
-                if (kf_fidx[d.kf_base + k] < 0) continue;
-                for (int b = cnt[k]; b < cnt[k + 1]; b += DIAG_SEG) segs.push_back({w, d.kf_base + k, base + b, base + std::min(b + DIAG_SEG, cnt[k + 1])});
+        // k_lm_pass stages the observation constants of LM_PASS_THREADS consecutive landmarks of a tile in LDS: the largest such block
+        for (const auto& t : h->tiles)
+            for (int l0 = t.lmk0; l0 < t.lmk1; l0 += LM_PASS_THREADS) {
+                const int l1 = std::min(l0 + LM_PASS_THREADS, t.lmk1);
+                h->lm_sub_obs = std::max(h->lm_sub_obs, lmk_oe[l1 - 1] - lmk_ob[l0]);
             }
-        }
-        h->n_diag_segs = (int)segs.size();
-        const int msz = h->factor_type == SADVIO_FACTOR_PIXEL ? 2 : 3;
-        std::vector<int> kf_lmk(std::max<size_t>(kf_obs.size(), 1)), kf_cam(std::max<size_t>(kf_obs.size(), 1));
-        std::vector<double> kf_meas(std::max<size_t>(kf_obs.size(), 1) * msz + 1);
-        for (size_t i = 0; i < kf_obs.size(); i++) {
-            const int o = kf_obs[i];
-            kf_lmk[i] = obs_lmk[o]; kf_cam[i] = obs_cam[o];
-            memcpy(&kf_meas[i * msz], &obs_meas[(size_t)msz * o], sizeof(double) * msz);
-        }
-        HIP_TRY(h->d_kf_lmk.alloc(kf_lmk.size())); HIP_TRY(h->d_kf_cam.alloc(kf_cam.size())); HIP_TRY(h->d_kf_meas.alloc(kf_meas.size()));
-        HIP_TRY(h->d_diag_segs.alloc(std::max<size_t>(segs.size(), 1)));
-        h->up.add(h->d_kf_lmk.p, kf_lmk.data(), kf_lmk.size() * sizeof(int));
-        h->up.add(h->d_kf_cam.p, kf_cam.data(), kf_cam.size() * sizeof(int));
-        h->up.add(h->d_kf_meas.p, kf_meas.data(), kf_meas.size() * sizeof(double));
-        h->up.add(h->d_diag_segs.p, segs.data(), segs.size() * sizeof(DiagSeg));
+        h->lm_sub_obs = (h->lm_sub_obs + 3) & ~3;
+        h->lm_max_cam = 1;
+        for (const auto& t : h->tiles) h->lm_max_cam = std::max(h->lm_max_cam, t.n_cam);
+        HIP_TRY(h->d_lm_hg.alloc(2 * (size_t)LM_HG * std::max(lmk_b, 1)));
+        h->lm_ksub = 1;
+        for (const auto& t : h->tiles) h->lm_ksub = std::max(h->lm_ksub, (t.lmk1 - t.lmk0 + LM_PASS_THREADS - 1) / LM_PASS_THREADS);
+        const size_t n_rec = std::max<size_t>(h->tiles.size(), 1) * h->lm_ksub;
+        HIP_TRY(h->d_lm_dt.alloc(2 * (size_t)LM_DT * n_rec));
+        HIP_TRY(h->d_lm_sacc.alloc(2 * 4 * n_rec));
+        HIP_TRY(hipMemsetAsync(h->d_lm_sacc.p, 0, sizeof(double) * 2 * 4 * n_rec, h->stream));   // slots of sub-blocks that do not exist stay zero
     }
     HIP_TRY(h->d_chunk_ob.alloc(chunk_ob.size())); HIP_TRY(h->d_chunk_lm.alloc(chunk_lm.size())); HIP_TRY(h->d_obs_lslot.alloc(obs_lslot.size()));
-    HIP_TRY(h->d_lm_elim.alloc((size_t)LM_ELIM * std::max(lmk_b, 1)));
     h->up.add(h->d_chunk_ob.p, chunk_ob.data(), chunk_ob.size() * sizeof(int));
     h->up.add(h->d_chunk_lm.p, chunk_lm.data(), chunk_lm.size() * sizeof(int));
     h->up.add(h->d_obs_lslot.p, obs_lslot.data(), obs_lslot.size());
@@ -1177,6 +1157,17 @@ static int build_layout(sadvio_ba_handle* h) {
                     h->tiles[perm[perm.size() / 2]].chunk1 - h->tiles[perm[perm.size() / 2]].chunk0, h->tiles[perm.back()].chunk1 - h->tiles[perm.back()].chunk0);
         HIP_TRY(h->d_tile_perm.alloc(std::max<size_t>(perm.size(), 1)));
         h->up.add(h->d_tile_perm.p, perm.data(), perm.size() * sizeof(int));
+        // work list of k_lm_pass: the sub-blocks (LM_PASS_THREADS landmarks) of every tile, in the same order
+        std::vector<int> sub;
+        if (const char* e = getenv("SADVIO_LM_SUBS")) h->lm_sub_per_item = std::max(1, atoi(e));
+        if (want_lm)
+            for (int ti : perm) {
+                const Tile& t = h->tiles[ti];
+                for (int q = 0, l0 = t.lmk0; l0 < t.lmk1; l0 += LM_PASS_THREADS * h->lm_sub_per_item, q += h->lm_sub_per_item) { sub.push_back(ti); sub.push_back(q); }
+            }
+        h->lm_n_sub = (int)sub.size() / 2;
+        HIP_TRY(h->d_lm_sub.alloc(std::max<size_t>(sub.size(), 2)));
+        h->up.add(h->d_lm_sub.p, sub.data(), sub.size() * sizeof(int));
     }
     if (getenv("SADVIO_DEBUG")) {
         int hist[32] = {0}, modes[3] = {0};
@@ -2623,20 +2614,20 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     // large plain batches: the throughput kernels of lm_kernels.h (SADVIO_LM=1 / 0 forces / forbids them, for tests and A/B runs)
     bool use_lm = h->lm_ok && !rare && !h->coll_fn && h->world == 1 && h->lm_landmarks >= 65536;
     if (const char* e = getenv("SADVIO_LM")) use_lm = h->lm_ok && !rare && !h->coll_fn && h->world == 1 && atoi(e) != 0;
-    auto ke = pix ? k_elim<0> : k_elim<1>;
     auto kbo = pix ? k_build_obs<0> : k_build_obs<1>;
-    auto kkl = pix ? k_backsub_lm<0> : k_backsub_lm<1>;
-    auto kdg = pix ? k_diag<0> : k_diag<1>;
-    const size_t lds_elim = tile_tables_bytes(mtk) + 16;
-    const size_t lds_bobs = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)BUILD_WAVES * Rp * LM_KS + nt * (nt + 1) / 2 + nt) + 16;
-    // lane-per-landmark kernels (k_elim, k_backsub_lm): 128 threads per tile — measured on the 64-window batch (tiles of ~165 landmarks
-    // after the key-frame cuts): 256 threads 46.7 / 74.2 us, 192 threads 46.9 / 76.2 us, 128 threads 42.2 / 63.2 us per launch. The
-    // kernels are bound by the latency of a lane's serial chain, not by lane count: half-size workgroups double the residency.
-    const int lm_threads = getenv("SADVIO_LM_THREADS") ? std::max(64, std::min(256, atoi(getenv("SADVIO_LM_THREADS")) & ~63)) : 128;
+    auto kps = pix ? k_lm_pass<0, false> : k_lm_pass<1, false>;
+    auto kps0 = pix ? k_lm_pass<0, true> : k_lm_pass<1, true>;
+    const size_t lds_views = pix ? sizeof(double) * (size_t)mtk * h->lm_max_cam * LM_VT : 0;   // view tables of the pixel factor
+    const size_t lds_bobs = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)BUILD_WAVES * Rp * LM_KS + nt * (nt + 1) / 2 + nt + 1 + LM_DT) + lds_views + 16;
+    // k_lm_pass: tables at x (+ at the candidate, + the pose steps), the tile's key-frame sums, the staged observation constants
+    const size_t lds_pass0 = tile_tables_bytes(mtk) + sizeof(double) * LM_DT_COST + (size_t)h->lm_sub_obs * ((pix ? 2 : 3) * sizeof(double) + sizeof(int)) + lds_views + 16;
+    const size_t lds_pass = lds_pass0 + sizeof(double) * (size_t)mtk * (POSE_TAB + 6) + lds_views;
+    if (!use_lm) P.lm_sacc = nullptr;   // k_decide sums the tiles' k_backsub partials
     if (use_lm) {
         P.decide_kernel = 1;   // the kernels read the decided state of their slot
         HIP_TRY(hipFuncSetAttribute((const void*)kbo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bobs));
-        HIP_TRY(hipFuncSetAttribute((const void*)kkl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back));
+        HIP_TRY(hipFuncSetAttribute((const void*)kps, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pass));
+        HIP_TRY(hipFuncSetAttribute((const void*)kps0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pass0));
     }
     HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_build));
     HIP_TRY(hipFuncSetAttribute((const void*)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_back));
@@ -2730,17 +2721,10 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 (void)hipEventRecord(h->ev_lin, h->side);
             }
             if (use_lm) {
-                // k_diag does not depend on the elimination: it runs on the second stream next to k_elim / k_build_obs
-                const bool par = h->n_diag_segs && h->side2 && !h->cfg.profile_kernels && !getenv("SADVIO_NO_PAR");
-                if (par) {
-                    (void)hipEventRecord(h->ev_diag0, h->stream);
-                    (void)hipStreamWaitEvent(h->side2, h->ev_diag0, 0);
-                    hipLaunchKernelGGL(kdg, dim3(h->n_diag_segs), dim3(BUILD_THREADS), 0, h->side2, P, h->d_diag_segs.p, h->d_kf_lmk.p, h->d_kf_cam.p, h->d_kf_meas.p, s);
-                    (void)hipEventRecord(h->ev_diag1, h->side2);
-                } else if (h->n_diag_segs) { ScopedTimer t(h, "k_diag"); hipLaunchKernelGGL(kdg, dim3(h->n_diag_segs), dim3(BUILD_THREADS), 0, h->stream, P, h->d_diag_segs.p, h->d_kf_lmk.p, h->d_kf_cam.p, h->d_kf_meas.p, s); }
-                { ScopedTimer t(h, "k_elim"); hipLaunchKernelGGL(ke, dim3(n_tiles), dim3(lm_threads), lds_elim, h->stream, P, s, mtk); }
+                // the opening pass linearises at x (H_ll, g_l per landmark, key-frame sums per tile); later slots get them from the
+                // candidate pass of the slot before
+                if (s == 0) { ScopedTimer t(h, "k_lm_pass0"); hipLaunchKernelGGL(kps0, dim3(h->lm_n_sub), dim3(LM_PASS_THREADS), lds_pass0, h->stream, P, s, mtk, h->lm_sub_obs); }
                 { ScopedTimer t(h, "k_build_obs"); hipLaunchKernelGGL(kbo, dim3(n_tiles), dim3(BUILD_THREADS), lds_bobs, h->stream, P, s, mtk, Rp); }
-                if (par) (void)hipStreamWaitEvent(h->stream, h->ev_diag1, 0);
             } else
             { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles + (with_imu ? n_pf : 0)), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
             if (n_pf && (use_lm || !with_imu)) { ScopedTimer t(h, "k_pf_lin"); hipLaunchKernelGGL(k_pf_eval<false>, dim3(n_pf), dim3(64), 0, h->stream, P, s); }
@@ -2961,7 +2945,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             if (dp_max_nf > 0) { ScopedTimer t(h, "k_prior_m"); hipLaunchKernelGGL(k_prior_m, dim3((dp_max_nf + 3) / 4, n_win), dim3(256), 0, h->stream, P, s); }
             if (n_pf && (use_lm || !with_imu)) { ScopedTimer t(h, "k_pf_cost"); hipLaunchKernelGGL(k_pf_eval<true>, dim3(n_pf), dim3(64), 0, h->stream, P, s); }
             if (use_lm) {
-                ScopedTimer t(h, "k_backsub_lm"); hipLaunchKernelGGL(kkl, dim3(n_tiles), dim3(lm_threads), lds_back, h->stream, P, s, mtk);
+                ScopedTimer t(h, "k_lm_pass"); hipLaunchKernelGGL(kps, dim3(h->lm_n_sub), dim3(LM_PASS_THREADS), lds_pass, h->stream, P, s, mtk, h->lm_sub_obs);
             }
             else
             { ScopedTimer t(h, "k_backsub"); hipLaunchKernelGGL(kk, dim3(n_tiles + (with_imu ? n_pf : 0)), dim3(BUILD_THREADS), lds_back, h->stream, P, s, mtk); }
@@ -2979,7 +2963,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         // the whole <= 20-iteration solve is one graph launch; the key covers every kernel argument
         std::vector<int> lay;  // layout-dependent launch parameters of the out-of-LDS windows
         for (int w = 0; w < n_win; w++) { lay.push_back(h->wins[w].d.Np); lay.push_back(h->wins[w].d.ld); lay.push_back(big_bw[w]); }
-        lay.push_back(h->n_kept); lay.push_back(h->n_diag_segs); lay.push_back(h->n_lobs_tot); lay.push_back(h->n_line_tot); lay.push_back(h->n_big); lay.push_back(dp_max_nf); lay.push_back(dp_max_n);
+        lay.push_back(h->n_kept); lay.push_back(h->lm_sub_obs); lay.push_back(h->lm_n_sub); lay.push_back(h->lm_max_cam); lay.push_back(h->n_lobs_tot); lay.push_back(h->n_line_tot); lay.push_back(h->n_big); lay.push_back(dp_max_nf); lay.push_back(dp_max_n);
         std::vector<unsigned char> key(sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t) + lay.size() * sizeof(int));
         unsigned char* kp = key.data();
         memcpy(kp + sizeof(DevPtrs) + 8 * sizeof(int) + 3 * sizeof(size_t), lay.data(), lay.size() * sizeof(int));
@@ -2987,8 +2971,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         // launch-shape switches read from the environment inside enqueue() are part of the key too: a handle that already captured a
         // graph must not replay it when an A/B switch changes
         const int env_bits = (int)with_imu + 2 * (getenv("SADVIO_NO_FORK") != nullptr) + 4 * (getenv("SADVIO_WD_NOLA") != nullptr) + 8 * (getenv("SADVIO_WD_BACK1") != nullptr) +
-                             16 * (getenv("SADVIO_WD_OLD") != nullptr) + 32 * (getenv("SADVIO_NO_BCR") != nullptr) + 64 * (getenv("SADVIO_NO_PAR") != nullptr) + 128 * (getenv("SADVIO_NO_LPT") != nullptr) +
-                             256 * (getenv("SADVIO_WD_R3") != nullptr) + 512 * (lm_threads / 64);   // lm_threads: the launch shape of k_elim / k_backsub_lm inside the capture
+                             16 * (getenv("SADVIO_WD_OLD") != nullptr) + 32 * (getenv("SADVIO_NO_BCR") != nullptr) + 128 * (getenv("SADVIO_NO_LPT") != nullptr) +
+                             256 * (getenv("SADVIO_WD_R3") != nullptr);
         const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type + 2 * (int)extras + 4 * (int)rare + 8 * (int)use_lm + 16 * env_bits};  // P (incl. decide_kernel) is part of the key
         memcpy(kp, ints, sizeof(ints)); kp += sizeof(ints);
         const size_t szs[3] = {lds_build, lds_back, lds_solve};

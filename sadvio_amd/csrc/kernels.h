@@ -70,7 +70,13 @@ struct DevPtrs {
     const int* chunk_lm;      // [n_chunks + 1] first landmark of each chunk
     const int* tile_perm;     // [n_tiles] launch order of the throughput kernels: tiles by decreasing chunk count
     const unsigned char* obs_lslot;  // [n_obs_tot] index of the observation's landmark inside its chunk
-    double* lm_elim;          // [n_lmk_tot][9] per-landmark elimination record of k_elim
+    double* lm_hg;            // [2][n_lmk_tot][9] H_ll | g_l of every landmark at the point of each delta buffer (k_lm_pass)
+    double* lm_dt;            // [2][n_tiles][LM_DT] per tile: key-frame sums (sum Jp^T Jp, sum Jp^T r) + cost totals at each buffer's point
+    long long lm_hg_stride, lm_dt_stride;
+    const int* lm_sub;        // [n_sub][2] work list of k_lm_pass: tile | sub-block (LM_PASS_THREADS landmarks) of the tile, largest tiles first
+    int lm_sub_per_item;      // sub-blocks one work item (workgroup) of k_lm_pass runs through
+    int lm_ksub;              // record slots per tile (= the largest tile's sub-block count): lm_dt / lm_sacc are indexed tile * lm_ksub + sub-block
+    double* lm_sacc;          // [2][n_tiles * lm_ksub][4] per sub-block and slot parity: cand_cost | mcc | step_norm2 | cand_norm2 (unused slots stay zero)
     const LineDev* lines;     // linexd landmarks: few, kept in the reduced system
     const LineObsDev* lobs;
     double* xline;            // [2][n_line_tot][6] line deltas, double-buffered like xp
@@ -2375,6 +2381,23 @@ __global__ void k_decide(DevPtrs P, int slot, int final) {
     LmState f;
     const bool already = final && P.decide_kernel;  // the per-slot launch of the last slot did it
     if (!already) {
+        if (P.lm_sacc) {
+            // throughput path: the partial records of k_lm_pass, every thread a fixed share, waves in index order (one decider per
+            // window: any fixed order will do)
+            __shared__ double sq[16 * 4];
+            const long long n = (long long)(W.tile_end - W.tile_begin) * P.lm_ksub;
+            const double* sa = P.lm_sacc + ((long long)(slot & 1) * P.n_tiles + W.tile_begin) * P.lm_ksub * 4;
+            double c = 0.0, m = 0.0, sn = 0.0, cn = 0.0;
+            for (long long t = ln; t < n; t += blockDim.x) { c += sa[4 * t]; m += sa[4 * t + 1]; sn += sa[4 * t + 2]; cn += sa[4 * t + 3]; }
+            c = wave_sum(c); m = wave_sum(m); sn = wave_sum(sn); cn = wave_sum(cn);
+            if ((ln & 63) == 0) { double* q = sq + 4 * (ln >> 6); q[0] = c; q[1] = m; q[2] = sn; q[3] = cn; }
+            __syncthreads();
+            if (ln < 4) {
+                double v = 0.0;
+                for (int q = 0; q < (int)(blockDim.x >> 6); q++) v += sq[4 * q + ln];
+                s4[ln] = v;
+            }
+        } else
         if (blockDim.x == 64) wave_sum_backsub_partials(P, slot & 1, w, W.tile_begin, W.tile_end - W.tile_begin, ln, s4);
         else {
             // thousands of tiles (configs 4 / 5, large batches): every wave of the workgroup sums a slice of the partials

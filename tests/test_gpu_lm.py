@@ -62,7 +62,7 @@ def test_lm_kernels_are_the_ones_that_ran(backend_cls, lm_env):
     w = make_window(n_kf=6, n_lmk=600, obs_per_lmk=5, seed=5)
     lm_env("1")
     _, names = solve(backend_cls, [w], capi.reference_options(), profile=True)
-    assert {"k_elim", "k_diag", "k_build_obs", "k_backsub_lm"} <= names and "k_build" not in names
+    assert {"k_lm_pass0", "k_build_obs", "k_lm_pass"} <= names and "k_build" not in names
     lm_env("0")
     _, names = solve(backend_cls, [w], capi.reference_options(), profile=True)
     assert "k_build" in names and "k_elim" not in names
@@ -88,7 +88,7 @@ def test_large_batch_takes_the_throughput_path_by_itself_and_agrees_with_the_lat
     ws = [ws[i % 3] for i in range(9)]
     opts = capi.reference_options()
     fast, names = solve(backend_cls, ws, opts, profile=True)
-    assert {"k_elim", "k_diag", "k_build_obs", "k_backsub_lm"} <= names and "k_build" not in names
+    assert {"k_lm_pass0", "k_build_obs", "k_lm_pass"} <= names and "k_build" not in names
     lm_env("0")
     slow, names0 = solve(backend_cls, ws[:3], opts, profile=True)
     assert "k_build" in names0
