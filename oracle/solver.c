@@ -614,30 +614,49 @@ static int compute_step(ctx_t *c, const sadvio_solve_options *o, double radius, 
             double d = clampd(s2 * M[4 * a], o->min_lm_diagonal, o->max_lm_diagonal);
             M[4 * a] += d / radius / s2;
         }
-        double *Mi = Minv + 9 * l;
-        double det = m3_inverse(M, Mi);
-        if (!(det > 0) || !isfinite(det)) { fail = 1; continue; }
+        /* Landmark elimination in CHOLESKY form (round 5): M = L L^T, Li = L^-1, W_a = E_a Li^T, S -= W_a W_b^T — the block step of a
+         * landmark-first Cholesky of the un-reduced system, which is what ceres::SPARSE_NORMAL_CHOLESKY / CHOLMOD computes under its
+         * fill-reducing ordering (AOptimizer.cpp:315-323). The adjugate inverse + explicitly formed (E M^-1) E^T used before lands
+         * 4e-6 .. 7e-5 from a long-double solve on the two ill-conditioned sweep windows where this form lands 4e-7 .. 4e-8
+         * (scripts/elim_numerics.py). Minv[9 l ..] holds Li (lower, row-major). */
+        double *Li = Minv + 9 * l;
+        {
+            double l00 = sqrt(M[0]), l10 = M[3] / l00, l20 = M[6] / l00;
+            double l11 = sqrt(M[4] - l10 * l10);
+            double l21 = (M[7] - l20 * l10) / l11;
+            double l22 = sqrt(M[8] - l20 * l20 - l21 * l21);
+            if (!(M[0] > 0) || !(l11 > 0) || !(l22 > 0) || !isfinite(l00) || !isfinite(l11) || !isfinite(l22)) { fail = 1; continue; }
+            double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+            double i10 = -l10 * i00 * i11;
+            double i21 = -l21 * i11 * i22;
+            double i20 = -(l20 * i00 + l21 * i10) * i22;
+            Li[0] = i00; Li[1] = 0; Li[2] = 0; Li[3] = i10; Li[4] = i11; Li[5] = 0; Li[6] = i20; Li[7] = i21; Li[8] = i22;
+        }
         const double *g = c->gl + 3 * l;
-        double Mg[3];
-        m3_vec(Mi, g, Mg);
+        double Lg[3];   /* Li g_l */
+        m3_vec(Li, g, Lg);
         int o0 = w->lmk_obs_ptr[l], o1 = w->lmk_obs_ptr[l + 1];
         for (int a = o0; a < o1; a++) {
             int pa = c->kf_off[w->obs_kf[a]];
             if (pa < 0) continue;
             const double *Ea = c->E + 18 * a;
-            double Y[18]; /* 6x3 = Ea * Minv */
+            double Y[18]; /* 6x3 = Ea * Li^T */
             for (int i = 0; i < 6; i++)
                 for (int j = 0; j < 3; j++)
-                    Y[i * 3 + j] = Ea[i * 3] * Mi[j] + Ea[i * 3 + 1] * Mi[3 + j] + Ea[i * 3 + 2] * Mi[6 + j];
-            for (int i = 0; i < 6; i++) rhst[pa + i] -= Ea[i * 3] * Mg[0] + Ea[i * 3 + 1] * Mg[1] + Ea[i * 3 + 2] * Mg[2];
+                    Y[i * 3 + j] = Ea[i * 3] * Li[3 * j] + Ea[i * 3 + 1] * Li[3 * j + 1] + Ea[i * 3 + 2] * Li[3 * j + 2];
+            for (int i = 0; i < 6; i++) rhst[pa + i] -= Y[i * 3] * Lg[0] + Y[i * 3 + 1] * Lg[1] + Y[i * 3 + 2] * Lg[2];
             for (int b = o0; b < o1; b++) {
                 int pb = c->kf_off[w->obs_kf[b]];
                 if (pb < 0) continue;
                 const double *Eb = c->E + 18 * b;
+                double Yb[18];
+                for (int i = 0; i < 6; i++)
+                    for (int j = 0; j < 3; j++)
+                        Yb[i * 3 + j] = Eb[i * 3] * Li[3 * j] + Eb[i * 3 + 1] * Li[3 * j + 1] + Eb[i * 3 + 2] * Li[3 * j + 2];
                 for (int i = 0; i < 6; i++)
                     for (int j = 0; j < 6; j++)
                         St[(size_t)(pa + i) * Nr + pb + j] -=
-                            Y[i * 3] * Eb[j * 3] + Y[i * 3 + 1] * Eb[j * 3 + 1] + Y[i * 3 + 2] * Eb[j * 3 + 2];
+                            Y[i * 3] * Yb[j * 3] + Y[i * 3 + 1] * Yb[j * 3 + 1] + Y[i * 3 + 2] * Yb[j * 3 + 2];
             }
         }
     }
@@ -663,7 +682,7 @@ static int compute_step(ctx_t *c, const sadvio_solve_options *o, double radius, 
         for (int l = 0; l < w->n_lmk; l++) {
             dlmk[3 * l] = dlmk[3 * l + 1] = dlmk[3 * l + 2] = 0;
             if (!c->lmk_elim[l]) continue;
-            /* y_l = Minv (g_l - E^T y_p); delta_l = -y_l, with y_p = -dred */
+            /* y_l = M^-1 (g_l - E^T y_p); delta_l = -y_l, with y_p = -dred */
             double t[3] = {c->gl[3 * l], c->gl[3 * l + 1], c->gl[3 * l + 2]};
             for (int a = w->lmk_obs_ptr[l]; a < w->lmk_obs_ptr[l + 1]; a++) {
                 int pa = c->kf_off[w->obs_kf[a]];
@@ -672,8 +691,12 @@ static int compute_step(ctx_t *c, const sadvio_solve_options *o, double radius, 
                 for (int i = 0; i < 6; i++)
                     for (int j = 0; j < 3; j++) t[j] += Ea[i * 3 + j] * dred[pa + i];
             }
-            double y[3];
-            m3_vec(Minv + 9 * l, t, y);
+            double u[3], y[3];
+            const double *Li = Minv + 9 * l;   /* y = M^-1 t = Li^T (Li t) */
+            m3_vec(Li, t, u);
+            y[0] = Li[0] * u[0] + Li[3] * u[1] + Li[6] * u[2];
+            y[1] = Li[4] * u[1] + Li[7] * u[2];
+            y[2] = Li[8] * u[2];
             dlmk[3 * l] = -y[0]; dlmk[3 * l + 1] = -y[1]; dlmk[3 * l + 2] = -y[2];
             if (!isfinite(y[0]) || !isfinite(y[1]) || !isfinite(y[2])) fail = 1;
         }

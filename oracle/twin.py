@@ -913,12 +913,31 @@ def kept_landmark_columns(P):
     return cols
 
 
-def schur_solve(B, P, H, g, D2):
+def chol3(B, M):
+    """Lower Cholesky factor of a 3 x 3 SPD block and its inverse (forward substitution), in the backend's arithmetic."""
+    L = B.zeros((3, 3))
+    L[0, 0] = B.sqrt(M[0, 0])
+    L[1, 0] = M[1, 0] / L[0, 0]; L[2, 0] = M[2, 0] / L[0, 0]
+    L[1, 1] = B.sqrt(M[1, 1] - L[1, 0] * L[1, 0])
+    L[2, 1] = (M[2, 1] - L[2, 0] * L[1, 0]) / L[1, 1]
+    L[2, 2] = B.sqrt(M[2, 2] - L[2, 0] * L[2, 0] - L[2, 1] * L[2, 1])
+    Li = B.zeros((3, 3))
+    Li[0, 0] = 1 / L[0, 0]; Li[1, 1] = 1 / L[1, 1]; Li[2, 2] = 1 / L[2, 2]
+    Li[1, 0] = -L[1, 0] * Li[0, 0] / L[1, 1]
+    Li[2, 0] = -(L[2, 0] * Li[0, 0] + L[2, 1] * Li[1, 0]) / L[2, 2]
+    Li[2, 1] = -L[2, 1] * Li[1, 1] / L[2, 2]
+    return L, Li
+
+
+def schur_solve(B, P, H, g, D2, elim="adjugate"):
     """(H + diag(D2)) y = g by eliminating the landmark blocks no other landmark is coupled with — only used for the long-double
-    arbitration runs on windows whose un-reduced system is too large for a long-double dense factorisation (2 943 unknowns: > 4 h).
+    arbitration runs on windows whose un-reduced system is too large for a long-double dense factorisation (2 943 unknowns: > 4 h)
+    and for the elimination-numerics study (scripts/elim_numerics.py).
     The landmarks a dense prior holds are coupled with each other through it: they stay in the reduced system beside the poses (round
     4: eliminating them block by block as well solved a different system, 9e-4 off every other implementation). Exact-arithmetic
-    equivalent of cholesky_solve."""
+    equivalent of cholesky_solve. elim = "adjugate": M^-1 by the adjugate (what the device's sym3_inverse and the oracle do) and
+    S -= (E M^-1) E^T; "cholesky": the block step of a landmark-first Cholesky of the un-reduced system (what a sparse direct
+    solver does with a fill-reducing ordering): M = L L^T, W = E L^-T, S -= W W^T, every landmark solve through L."""
     npz = P.n_pose
     A = H + np.diag(D2)
     kept = kept_landmark_columns(P)
@@ -931,9 +950,16 @@ def schur_solve(B, P, H, g, D2):
         c = P.lmk_col[l]
         if c < 0 or c in kept_set:
             continue
+        E = A[:npz, c: c + 3]
+        if elim == "cholesky":
+            _, Li = chol3(B, A[c: c + 3, c: c + 3])
+            W = E @ Li.T
+            Minv[l] = Li
+            S[:npz, :npz] -= W @ W.T
+            gR[:npz] -= W @ (Li @ g[c: c + 3])
+            continue
         Mi = inv3(B, A[c: c + 3, c: c + 3])
         Minv[l] = Mi
-        E = A[:npz, c: c + 3]
         Y = E @ Mi
         S[:npz, :npz] -= Y @ E.T
         gR[:npz] -= Y @ g[c: c + 3]
@@ -945,7 +971,10 @@ def schur_solve(B, P, H, g, D2):
     yp = yR[:npz]
     for l, Mi in Minv.items():
         c = P.lmk_col[l]
-        y[c: c + 3] = Mi @ (g[c: c + 3] - A[:npz, c: c + 3].T @ yp)
+        if elim == "cholesky":
+            y[c: c + 3] = Mi.T @ (Mi @ (g[c: c + 3] - A[:npz, c: c + 3].T @ yp))
+        else:
+            y[c: c + 3] = Mi @ (g[c: c + 3] - A[:npz, c: c + 3].T @ yp)
     return y
 
 
@@ -1056,7 +1085,7 @@ class ViInitProblem:
         return cost, fixed, res, J
 
 
-def lm_solve(w, opts=None, kind="f64", digits=50, use_schur=False, max_iterations=None, problem=None):
+def lm_solve(w, opts=None, kind="f64", digits=50, use_schur=False, max_iterations=None, problem=None, elim="adjugate"):
     """Minimise the window's cost with Ceres' trust-region / LM schedule. Returns a dict: pose[n_kf,6], lmk[n_lmk,3]
     (float64), summary fields and `log` (one row per iteration: cost, cost_change, radius, step_norm, relative_decrease,
     successful, gradient_max, model_cost_change — the layout of the C oracle's log)."""
@@ -1108,7 +1137,7 @@ def lm_solve(w, opts=None, kind="f64", digits=50, use_schur=False, max_iteration
             D2 = diagonal / radius                                # lm_diagonal = sqrt(diagonal / radius); D^2 enters the normal equations
             H = normal_matrix(B, J)
             rhs = J.T @ r
-            y = schur_solve(B, P, H, rhs, D2) if use_schur else cholesky_solve(B, H + np.diag(D2), rhs)
+            y = schur_solve(B, P, H, rhs, D2, elim) if use_schur else cholesky_solve(B, H + np.diag(D2), rhs)
             valid = y is not None and all(B.isfinite(v) for v in y)
             mcc = B.s(0)
             if valid:

@@ -157,6 +157,42 @@ __device__ __forceinline__ double sym3_inverse(const double* a, double* inv) {
     inv[5] = (a[0] * a[3] - a[1] * a[1]) * id;
     return det;
 }
+// Landmark elimination in Cholesky form (round 5): M = L L^T for the damped symmetric block (a00,a01,a02,a11,a12,a22), returns
+// Li = L^-1 as (i00, i10, i11, i20, i21, i22). With W = E Li^T the Schur term is E M^-1 E^T = W W^T and M^-1 t = Li^T (Li t): the
+// block step of a landmark-first Cholesky of the un-reduced normal equations — what CHOLMOD computes for the reference
+// (AOptimizer.cpp:315-323). The adjugate inverse used through round 4 lands 4e-6 .. 7e-5 from a long-double solve on the two
+// ill-conditioned windows of the sweep where this form lands 4e-7 .. 4e-8 (scripts/elim_numerics.py). A block that is not positive
+// definite yields NaNs (sqrt of a negative pivot), which the step's finiteness test turns into an invalid step, as 1 / det did.
+__device__ __forceinline__ void sym3_chol_inverse(const double* a, double* Li) {
+    const double l00 = sqrt(a[0]);
+    const double i00 = 1.0 / l00;
+    const double l10 = a[1] * i00, l20 = a[2] * i00;
+    const double l11 = sqrt(a[3] - l10 * l10);
+    const double i11 = 1.0 / l11;
+    const double l21 = (a[4] - l20 * l10) * i11;
+    const double l22 = sqrt(a[5] - l20 * l20 - l21 * l21);
+    const double i22 = 1.0 / l22;
+    const double i10 = -l10 * i00 * i11;
+    const double i21 = -l21 * i11 * i22;
+    const double i20 = -(l20 * i00 + l21 * i10) * i22;
+    Li[0] = i00; Li[1] = i10; Li[2] = i11; Li[3] = i20; Li[4] = i21; Li[5] = i22;
+}
+// N = Jl Li^T (rows of a 2 x 3 Jacobian), u = Li t and v = Li^T u for the packed lower Li of sym3_chol_inverse
+__device__ __forceinline__ void li_row(const double* Li, double j0, double j1, double j2, double* n) {
+    n[0] = j0 * Li[0];
+    n[1] = j0 * Li[1] + j1 * Li[2];
+    n[2] = j0 * Li[3] + j1 * Li[4] + j2 * Li[5];
+}
+__device__ __forceinline__ void li_vec(const double* Li, const double* t, double* u) {
+    u[0] = Li[0] * t[0];
+    u[1] = Li[1] * t[0] + Li[2] * t[1];
+    u[2] = Li[3] * t[0] + Li[4] * t[1] + Li[5] * t[2];
+}
+__device__ __forceinline__ void li_tvec(const double* Li, const double* u, double* v) {
+    v[0] = Li[0] * u[0] + Li[1] * u[1] + Li[3] * u[2];
+    v[1] = Li[2] * u[1] + Li[4] * u[2];
+    v[2] = Li[5] * u[2];
+}
 __device__ __forceinline__ void m3_inverse(const double* A, double* I) {
     double c00 = A[4] * A[8] - A[5] * A[7];
     double c01 = A[5] * A[6] - A[3] * A[8];

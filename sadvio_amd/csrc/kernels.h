@@ -409,8 +409,9 @@ __device__ __forceinline__ void lane_linearize(const DevPtrs& P, const double* p
     if (!L.counted) { /* fixed cost: caller accounts r, then it leaves the program */ }
 }
 
-// Per-landmark elimination, every lane of the group redundantly: H_ll, g_l (group sums), LM damping,
-// Minv (symmetric 6-vector). Returns whether the landmark has a parameter block in the program.
+// Per-landmark elimination, every lane of the group redundantly: H_ll, g_l (group sums), LM damping, the inverse Cholesky
+// factor Li of the damped block (sym3_chol_inverse: packed lower 6-vector; named Mi below). Returns whether the landmark has a
+// parameter block in the program.
 __device__ __forceinline__ bool group_eliminate(const DevPtrs& P, const ObsLin& L, int G, int gl, bool lmk_valid,
                                                 bool lfree, int nobs, double radius, bool write_scale, bool leader,
                                                 double* Mi, double* g) {
@@ -451,7 +452,7 @@ __device__ __forceinline__ bool group_eliminate(const DevPtrs& P, const ObsLin& 
     M[0] += fmin(fmax(s0 * H[0], P.o.min_lm_diagonal), P.o.max_lm_diagonal) * ir / s0;
     M[3] += fmin(fmax(s1 * H[3], P.o.min_lm_diagonal), P.o.max_lm_diagonal) * ir / s1;
     M[5] += fmin(fmax(s2 * H[5], P.o.min_lm_diagonal), P.o.max_lm_diagonal) * ir / s2;
-    sym3_inverse(M, Mi);
+    sym3_chol_inverse(M, Mi);
     return true;
 }
 
@@ -663,19 +664,15 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
         const bool active = group_eliminate(P, L, G, gl, lmk_valid, lfree, nobs, st.radius, slot == 0, q == 0, Mi, g);
         if (active && q == 0) gmax_part = fmax(gmax_part, fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2]))));
     SADVIO_TS(3, 36);
-        // N = Jl Minv (2x3), reduced residual r~ = r - N g_l
-        double N[6];
-#pragma unroll
-        for (int qq = 0; qq < 2; qq++) {
-            const double j0 = L.Jl[3 * qq], j1 = L.Jl[3 * qq + 1], j2 = L.Jl[3 * qq + 2];
-            N[3 * qq] = j0 * Mi[0] + j1 * Mi[1] + j2 * Mi[2];
-            N[3 * qq + 1] = j0 * Mi[1] + j1 * Mi[3] + j2 * Mi[4];
-            N[3 * qq + 2] = j0 * Mi[2] + j1 * Mi[4] + j2 * Mi[5];
-        }
+        // N = Jl Li^T (2x3: Jl M^-1 Jl^T = N N^T), gamma = Li g_l, reduced residual r~ = r - Jl M^-1 g_l = r - N gamma
+        double N[6], gam[3];
+        li_row(Mi, L.Jl[0], L.Jl[1], L.Jl[2], N);
+        li_row(Mi, L.Jl[3], L.Jl[4], L.Jl[5], N + 3);
+        li_vec(Mi, g, gam);
         if (gemm_mode) {
             // ---- Schur accumulation without LDS atomics ---------------------------------------------------
-            //   S_tile = sum_a Jp_a^T Jp_a - sum_l Y_l E_l^T,  Y_l[KF] = sum_{a in KF} Jp_a^T (Jl_a Minv),
-            //   E_l[KF] = sum_{a in KF} Jp_a^T Jl_a.
+            //   S_tile = sum_a Jp_a^T Jp_a - sum_l Y_l Y_l^T,  Y_l[KF] = sum_{a in KF} Jp_a^T (Jl_a Li^T): E M^-1 E^T in the
+            //   symmetric form of a landmark-first Cholesky (one strip is both MFMA operands).
             // (1) the (at most two, adjacent) observations of a landmark in one key-frame are pre-summed with DPP;
             // (2) Y / E go with plain stores into wave-private strips [row][k], k = 4 * landmark + c: distinct
             //     landmarks own distinct k, so nothing collides; sum_l Y_l E_l^T is then a K-contraction on the
@@ -685,11 +682,11 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
             //     landmarks created together), else with ds_add_f64.
             constexpr int Kw = 32, KS = Kw + 2;   // G == 8 on this path: 8 landmarks per wave and round
             double* Yb = wstage;
-            double* Eb = wstage + Rp * KS;
+            const double* Eb = Yb;
             {
                 double2* z = (double2*)wstage;
                 const double2 zero2 = make_double2(0.0, 0.0);
-                for (int i = ln; i < Rp * KS; i += 64) z[i] = zero2;  // 2 * Rp * KS doubles
+                for (int i = ln; i < Rp * KS / 2; i += 64) z[i] = zero2;  // Rp * KS doubles
             }
             const bool vrow = L.valid && L.row >= 0;
             const int myrow = vrow ? L.row : -2 - ln;           // unique negative: never equal to a neighbour's
@@ -702,31 +699,28 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
             const int row_next2 = RARE ? dpp_i32<0x102>(myrow) : -1;   // lane + 2 (read by every lane, outside the branches)
             const bool has_follower2 = RARE && vrow && q + 2 < G && row_next2 == myrow;
             const bool head = vrow && !follower;
-            const double rt0 = L.r[0] - (N[0] * g[0] + N[1] * g[1] + N[2] * g[2]);
-            const double rt1 = L.r[1] - (N[3] * g[0] + N[4] * g[1] + N[5] * g[2]);
+            const double rt0 = L.r[0] - (N[0] * gam[0] + N[1] * gam[1] + N[2] * gam[2]);
+            const double rt1 = L.r[1] - (N[3] * gam[0] + N[4] * gam[1] + N[5] * gam[2]);
             wave_lds_fence();
     SADVIO_TS(3, 37);
-            // Y, E rows of this lane's key-frame (pair-summed), plain 16-byte stores by the run heads
+            // Y rows of this lane's key-frame (pair-summed), plain 16-byte stores by the run heads
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 const double j0 = vrow ? L.Jp[i] : 0.0, j1 = vrow ? L.Jp[6 + i] : 0.0;
-                double y[3], e[3];
+                double y[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     y[c] = j0 * N[c] + j1 * N[3 + c];
-                    e[c] = j0 * L.Jl[c] + j1 * L.Jl[3 + c];
-                    const double yn = dpp_f64<0x101>(y[c]), en = dpp_f64<0x101>(e[c]);
-                    if (has_follower) { y[c] += yn; e[c] += en; }
+                    const double yn = dpp_f64<0x101>(y[c]);
+                    if (has_follower) y[c] += yn;
                     if (RARE) {
-                        const double yn2 = dpp_f64<0x102>(y[c]), en2 = dpp_f64<0x102>(e[c]);
-                        if (has_follower2) { y[c] += yn2; e[c] += en2; }
+                        const double yn2 = dpp_f64<0x102>(y[c]);
+                        if (has_follower2) y[c] += yn2;
                     }
                 }
                 if (head) {
                     double2* yp = (double2*)(Yb + (myrow + i) * KS + 4 * grp);
-                    double2* ep = (double2*)(Eb + (myrow + i) * KS + 4 * grp);
                     yp[0] = make_double2(y[0], y[1]); yp[1] = make_double2(y[2], 0.0);
-                    ep[0] = make_double2(e[0], e[1]); ep[1] = make_double2(e[2], 0.0);
                 }
             }
             wave_lds_fence();
@@ -796,8 +790,8 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
         for (int i = 0; i < 6; i++) wstage[(12 + i) * 64 + ln] = L.Jl[i];
         wave_lds_fence();
         if (L.valid && L.row >= 0) {
-            const double rt0 = L.r[0] - (N[0] * g[0] + N[1] * g[1] + N[2] * g[2]);
-            const double rt1 = L.r[1] - (N[3] * g[0] + N[4] * g[1] + N[5] * g[2]);
+            const double rt0 = L.r[0] - (N[0] * gam[0] + N[1] * gam[1] + N[2] * gam[2]);
+            const double rt1 = L.r[1] - (N[3] * gam[0] + N[4] * gam[1] + N[5] * gam[2]);
             const int pa = L.row;
 #pragma unroll
             for (int i = 0; i < 6; i++) {
@@ -814,7 +808,7 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
             }
         }
         // S blocks: lane a adds rows of Jp_a^T W_ab Jp_b for every partner b of its landmark whose block is
-        // on or below the diagonal; W_ab = delta_ab I - N_a Jl_b^T
+        // on or below the diagonal; W_ab = delta_ab I - N_a N_b^T, N_b = Jl_b Li^T (the group shares Li)
         {
             for (int b = 0; b < T.kmax; b++) {  // wave-uniform bound: the shuffle below is convergent
                 const int lb = grp * G + b;  // partner lane
@@ -825,10 +819,13 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
                 for (int i = 0; i < 12; i++) Jpb[i] = wstage[i * 64 + lb];
 #pragma unroll
                 for (int i = 0; i < 6; i++) Jlb[i] = wstage[(12 + i) * 64 + lb];
-                double w00 = -(N[0] * Jlb[0] + N[1] * Jlb[1] + N[2] * Jlb[2]);
-                double w01 = -(N[0] * Jlb[3] + N[1] * Jlb[4] + N[2] * Jlb[5]);
-                double w10 = -(N[3] * Jlb[0] + N[4] * Jlb[1] + N[5] * Jlb[2]);
-                double w11 = -(N[3] * Jlb[3] + N[4] * Jlb[4] + N[5] * Jlb[5]);
+                double Nb[6];
+                li_row(Mi, Jlb[0], Jlb[1], Jlb[2], Nb);
+                li_row(Mi, Jlb[3], Jlb[4], Jlb[5], Nb + 3);
+                double w00 = -(N[0] * Nb[0] + N[1] * Nb[1] + N[2] * Nb[2]);
+                double w01 = -(N[0] * Nb[3] + N[1] * Nb[4] + N[2] * Nb[5]);
+                double w10 = -(N[3] * Nb[0] + N[4] * Nb[1] + N[5] * Nb[2]);
+                double w11 = -(N[3] * Nb[3] + N[4] * Nb[4] + N[5] * Nb[5]);
                 if (b == q) { w00 += 1.0; w11 += 1.0; }
                 const int pa = L.row;
 #pragma unroll
@@ -1332,6 +1329,29 @@ __device__ __forceinline__ double prior_lin_record(const double* T0, const doubl
     return c;
 }
 
+// The two transcendental bodies of k_solve's back half (candidate pose tables: sin / cos; prior records at the candidate: log,
+// acos, Jr^-1) as CALLS: inlined into the 512-thread kernel they lengthened live ranges across the factorisation and cost it 42
+// spilled VGPRs; a handful of lanes run them, off the critical path of the other waves.
+// (arguments in registers: six scalars + pointers; a by-value struct of 18 doubles travels through scratch)
+__device__ __noinline__ void pose_table_store(const double* T0, double d0, double d1, double d2, double d3, double d4, double d5, double* dst) {
+    double T0r[12], tab[POSE_TAB];
+#pragma unroll
+    for (int i = 0; i < 12; i++) T0r[i] = T0[i];
+    const double d6[6] = {d0, d1, d2, d3, d4, d5};
+    pose_table_entry(T0r, d6, tab);
+#pragma unroll
+    for (int i = 0; i < POSE_TAB; i++) dst[i] = tab[i];
+}
+__device__ __noinline__ double prior_lin_record_call(const double* T0, double d0, double d1, double d2, double d3, double d4, double d5, const PriorDev* pr,
+                                                     double* rec) {
+    double T0r[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) T0r[i] = T0[i];
+    const double d6[6] = {d0, d1, d2, d3, d4, d5};
+    const PriorDev q = *pr;
+    return prior_lin_record(T0r, q.T_prior, q.inf, d6, rec);
+}
+
 template <int MODE, bool EXTRAS>
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1743,7 +1763,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         const bool pre = MODE == 0 && k < SOLVE_KFC;  // parked in LDS by the front half
         const double* kc = kfc + (pre ? k : 0) * 20;
         int fi = pre ? (int)kc[0] : P.kf_fidx[g];
-        double d6[6], tab[POSE_TAB], T0r[12];
+        double d6[6];
+        const double* T0r = pre ? kc + 7 : P.kf_T0 + 12 * (long long)g;   // LDS (parked by the front half) or HBM: a flat pointer either way
         double vbb[9];                          // v, ba, bg at x: fetched before the table is computed
         if (W.dpf == 15) {
             const double* xs3[3] = {P.xv + (long long)cur * P.xv_stride, P.xba + (long long)cur * P.xv_stride, P.xbg + (long long)cur * P.xv_stride};
@@ -1753,8 +1774,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
                 for (int i = 0; i < 3; i++) vbb[3 * q + i] = xs3[q][3 * (long long)g + i];
         }
 #pragma unroll
-        for (int i = 0; i < 12; i++) T0r[i] = pre ? kc[7 + i] : P.kf_T0[12 * (long long)g + i];
-#pragma unroll
         for (int i = 0; i < 6; i++) {
             double v = (pre ? kc[1 + i] : xp[6 * (long long)g + i]) + (fi < 0 ? 0.0 : y[fi * W.dpf + i]);
             xpc[6 * (long long)g + i] = v;
@@ -1762,11 +1781,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             if (fi >= 0) cn += v * v;
         }
         // pose table of the candidate buffer (k_backsub reads it now, k_build reads it if the step is accepted)
-        pose_table_entry(T0r, d6, tab);
-        {
-            double* dst = P.ptab + (long long)(1 - cur) * P.ptab_stride + (long long)g * POSE_TAB;
-            for (int i = 0; i < POSE_TAB; i++) dst[i] = tab[i];
-        }
+        pose_table_store(T0r, d6[0], d6[1], d6[2], d6[3], d6[4], d6[5], P.ptab + (long long)(1 - cur) * P.ptab_stride + (long long)g * POSE_TAB);
         if (W.dpf == 15) {
             double* xs3[3] = {P.xv + (long long)(1 - cur) * P.xv_stride, P.xba + (long long)(1 - cur) * P.xv_stride, P.xbg + (long long)(1 - cur) * P.xv_stride};
 #pragma unroll
@@ -1799,14 +1814,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         const double* plx = P.prior_lin + (long long)cur * P.prior_lin_stride + (long long)W.prior_begin * PRIOR_LIN;
         double* plc = P.prior_lin + (long long)(1 - cur) * P.prior_lin_stride + (long long)W.prior_begin * PRIOR_LIN;
         for (int p = (int)blockDim.x - 1 - tid; p < W.prior_end - W.prior_begin; p += blockDim.x) {
-            const PriorDev pr = P.priors[W.prior_begin + p];
-            const int fi = P.kf_fidx[pr.kf];
+            const PriorDev* prp = P.priors + W.prior_begin + p;
+            const int pkf = prp->kf;
+            const int fi = P.kf_fidx[pkf];
             if (fi < 0) continue;
-            double d[6], d6[6], T0r[12];
+            double d[6], d6[6];
 #pragma unroll
-            for (int i = 0; i < 12; i++) T0r[i] = P.kf_T0[12 * (long long)pr.kf + i];
-#pragma unroll
-            for (int i = 0; i < 6; i++) { d[i] = y[fi * W.dpf + i]; d6[i] = xp[6 * (long long)pr.kf + i] + d[i]; }
+            for (int i = 0; i < 6; i++) { d[i] = y[fi * W.dpf + i]; d6[i] = xp[6 * (long long)pkf + i] + d[i]; }
             double lin = 0.0, quad = 0.0;
 #pragma unroll
             for (int a = 0; a < 6; a++) {
@@ -1815,7 +1829,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
                 for (int b = 0; b <= a; b++) quad += (a == b ? 0.5 : 1.0) * d[a] * d[b] * plx[p * PRIOR_LIN + 6 + a * (a + 1) / 2 + b];
             }
             mcc += -(lin + quad);
-            cc += prior_lin_record(T0r, pr.T_prior, pr.inf, d6, plc + p * PRIOR_LIN);
+            cc += prior_lin_record_call(P.kf_T0 + 12 * (long long)pkf, d6[0], d6[1], d6[2], d6[3], d6[4], d6[5], prp, plc + p * PRIOR_LIN);
         }
     }
     if (EXTRAS && n_imu > 0) {
@@ -2016,13 +2030,13 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
 #pragma unroll
             for (int i = 0; i < 6; i++) { e0 += L.Jp[i] * d[i]; e1 += L.Jp[6 + i] * d[i]; }
         }
-        // delta_l = -Minv sum_a Jl_a^T e_a   (every lane of the group)
-        double t0 = group_sum(L.Jl[0] * e0 + L.Jl[3] * e1, G);
-        double t1 = group_sum(L.Jl[1] * e0 + L.Jl[4] * e1, G);
-        double t2 = group_sum(L.Jl[2] * e0 + L.Jl[5] * e1, G);
-        double d0 = -(Mi[0] * t0 + Mi[1] * t1 + Mi[2] * t2);
-        double d1 = -(Mi[1] * t0 + Mi[3] * t1 + Mi[4] * t2);
-        double d2 = -(Mi[2] * t0 + Mi[4] * t1 + Mi[5] * t2);
+        // delta_l = -M^-1 sum_a Jl_a^T e_a = -Li^T (Li t)   (every lane of the group)
+        const double tt[3] = {group_sum(L.Jl[0] * e0 + L.Jl[3] * e1, G), group_sum(L.Jl[1] * e0 + L.Jl[4] * e1, G),
+                              group_sum(L.Jl[2] * e0 + L.Jl[5] * e1, G)};
+        double ut[3], vt3[3];
+        li_vec(Mi, tt, ut);
+        li_tvec(Mi, ut, vt3);
+        double d0 = -vt3[0], d1 = -vt3[1], d2 = -vt3[2];
         if (RARE && lcode == 2) {  // kept landmark: its step is part of the reduced solution (|step|^2 is counted there)
             const double* dr = P.delta + T.red_off + P.lmk_red[gl];
             d0 = dr[0]; d1 = dr[1]; d2 = dr[2];

@@ -33,7 +33,8 @@ constexpr int LM_DT_COST = MAX_GEMM_FREE_KF * LM_DT_RANK;   // then: sum r^2 (bl
 constexpr int LM_DT = LM_DT_COST + 4;
 constexpr int LM_PASS_THREADS = 64;     // k_lm_pass: one wave per tile and sub-block of 64 landmarks (measured: 64 > 128 > 256 > 192 threads, 211 / 202 / 188 / 163 k it/s)
 
-// LM-damped inverse of a landmark's 3 x 3 block (the arithmetic of group_eliminate, one lane)
+// LM damping of a landmark's 3 x 3 block and the inverse of its Cholesky factor (the arithmetic of group_eliminate, one lane):
+// Li = L^-1 (packed lower, sym3_chol_inverse), M = H_ll + D = L L^T
 __device__ __forceinline__ void lm_damped_inverse(const DevPtrs& P, const double* H, const double* s, double radius, double* Mi) {
     const double ir = 1.0 / radius;
     const double s0 = s[0] * s[0], s1 = s[1] * s[1], s2 = s[2] * s[2];
@@ -41,7 +42,7 @@ __device__ __forceinline__ void lm_damped_inverse(const DevPtrs& P, const double
     M[0] += fmin(fmax(s0 * H[0], P.o.min_lm_diagonal), P.o.max_lm_diagonal) * ir / s0;
     M[3] += fmin(fmax(s1 * H[3], P.o.min_lm_diagonal), P.o.max_lm_diagonal) * ir / s1;
     M[5] += fmin(fmax(s2 * H[5], P.o.min_lm_diagonal), P.o.max_lm_diagonal) * ir / s2;
-    sym3_inverse(M, Mi);
+    sym3_chol_inverse(M, Mi);
 }
 
 // View tables of the pixel factor (throughput kernels): per (key-frame slot, camera) of a tile the products every observation of
@@ -280,11 +281,11 @@ __global__ __launch_bounds__(LM_PASS_THREADS, 2) void k_lm_pass(DevPtrs P, int s
             const bool active = have && lcode == 0 && cnt > 0;
             if (active) {
                 const double s[3] = {P.s_lmk[3 * (long long)gl], P.s_lmk[3 * (long long)gl + 1], P.s_lmk[3 * (long long)gl + 2]};
-                double Mi[6];
-                lm_damped_inverse(P, H, s, st.radius, Mi);
-                d0 = -(Mi[0] * t[0] + Mi[1] * t[1] + Mi[2] * t[2]);
-                d1 = -(Mi[1] * t[0] + Mi[3] * t[1] + Mi[4] * t[2]);
-                d2 = -(Mi[2] * t[0] + Mi[4] * t[1] + Mi[5] * t[2]);
+                double Li[6], u[3], v[3];
+                lm_damped_inverse(P, H, s, st.radius, Li);
+                li_vec(Li, t, u);          // delta_l = -M^-1 t = -Li^T (Li t)
+                li_tvec(Li, u, v);
+                d0 = -v[0]; d1 = -v[1]; d2 = -v[2];
                 sn += d0 * d0 + d1 * d1 + d2 * d2;
             }
             const double c0 = x0[0] + d0, c1 = x0[1] + d1, c2 = x0[2] + d2;
@@ -535,36 +536,22 @@ __global__ __launch_bounds__(BUILD_THREADS, 3) void k_build_obs(DevPtrs P, int s
 #pragma unroll
         for (int i = 0; i < 18; i++) z[i] = 0.0;
         const bool lfree = have && A2.lcode == 0;
-        // the landmark's damping: LM-damped inverse of H_ll, its Cholesky factor L (M^-1 = L L^T: positive definite with M) and
-        // w = L^T g_l — the landmark's part of the reduced gradient is E M^-1 g = (E L)(L^T g) = Z w. Every observation lane of the
-        // landmark repeats it (the lanes would idle otherwise); no per-landmark record travels through HBM
+        // the landmark's damping: Li = L^-1 of the damped block M = L L^T and w = Li g_l: with W = Jl Li^T the landmark's Schur term
+        // is E M^-1 E^T = Z Z^T, Z = sum_a Jp_a^T W_a, and its part of the reduced gradient E M^-1 g_l = Z w. Every observation
+        // lane of the landmark repeats it (the lanes would idle otherwise); no per-landmark record travels through HBM
         double Lw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (lfree) {
-            double Mi[6];
-            lm_damped_inverse(P, A2.H, A2.s, st.radius, Mi);
-            const double l00 = sqrt(fmax(Mi[0], 0.0)), i00 = l00 > 0.0 ? 1.0 / l00 : 0.0;
-            const double l10 = Mi[1] * i00, l20 = Mi[2] * i00;
-            const double l11 = sqrt(fmax(Mi[3] - l10 * l10, 0.0)), i11 = l11 > 0.0 ? 1.0 / l11 : 0.0;
-            const double l21 = (Mi[4] - l20 * l10) * i11;
-            const double l22 = sqrt(fmax(Mi[5] - l20 * l20 - l21 * l21, 0.0));
-            Lw[0] = l00; Lw[1] = l10; Lw[2] = l11; Lw[3] = l20; Lw[4] = l21; Lw[5] = l22;
-            Lw[6] = l00 * A2.g[0] + l10 * A2.g[1] + l20 * A2.g[2];
-            Lw[7] = l11 * A2.g[1] + l21 * A2.g[2];
-            Lw[8] = l22 * A2.g[2];
+            lm_damped_inverse(P, A2.H, A2.s, st.radius, Lw);
+            li_vec(Lw, A2.g, Lw + 6);
         }
         if (lfree) {
             row = rowTab[A1.sl];
             if (row >= 0) {   // a constant key-frame has no rows in the reduced system
                 double r[2], Jp[12], Jl[6];
                 lm_linearize<FACTOR, true>(poseTab, camTab, vt, T.n_cam, A1.sl, A1.cam - T.cam_base, A1.m, A2.pw, r, Jp, Jl);
-                const double* L = Lw;
-                double W[6];   // W = Jl L (2 x 3), L lower: rows (l00) (l10 l11) (l20 l21 l22)
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    W[3 * q] = Jl[3 * q] * L[0] + Jl[3 * q + 1] * L[1] + Jl[3 * q + 2] * L[3];
-                    W[3 * q + 1] = Jl[3 * q + 1] * L[2] + Jl[3 * q + 2] * L[4];
-                    W[3 * q + 2] = Jl[3 * q + 2] * L[5];
-                }
+                double W[6];   // W = Jl Li^T (2 x 3)
+                li_row(Lw, Jl[0], Jl[1], Jl[2], W);
+                li_row(Lw, Jl[3], Jl[4], Jl[5], W + 3);
 #pragma unroll
                 for (int i = 0; i < 6; i++)
 #pragma unroll
