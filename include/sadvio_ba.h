@@ -361,6 +361,11 @@ typedef struct sadvio_marg_result {
 int sadvio_ba_marginalize(sadvio_ba_handle *h, int32_t w, const sadvio_marg_request *rq, sadvio_marg_result *res,
                           int32_t *lmk_col, double *J, double *r0);
 
+/* Route counters of the Cholesky-form marginalisations of this handle since its creation: calls, calls that took the unpivoted
+ * wide-panel factorisation (Ak of full rank, every pivot tested), calls that tried it and fell back to the rank-revealing (pivoted)
+ * route. calls - unpivoted - fell_back = calls that pivoted without a try (no earlier prior, or the noise-floor cut). */
+int sadvio_ba_marg_stats(sadvio_ba_handle *h, int32_t *calls, int32_t *unpivoted, int32_t *fell_back);
+
 /* The handle's prior: read-back on request (any pointer may be NULL; J has room for n_full * n, r0 for n_full doubles),
  * upload of a prior kept elsewhere (e.g. restored from a dump; n_full = 0 clears it), and its shape. */
 typedef struct sadvio_prior_info {

@@ -366,6 +366,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.sadvio_ba_get_line_deltas.argtypes = [C.c_void_p, C.c_int32, _dp]
     lib.sadvio_ba_marginalize_relative.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]
     lib.sadvio_ba_get_prior.argtypes = [C.c_void_p, C.POINTER(PriorInfoC), _dp, _dp]
+    lib.sadvio_ba_marg_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.sadvio_ba_set_prior.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp]
     lib.sadvio_ba_linearize.argtypes = [C.c_void_p, C.c_int32, _dp, _dp, _dp, _dp, _dp]
     lib.sadvio_ba_vi_init.argtypes = [C.c_void_p, C.POINTER(ViInitProblemC), C.POINTER(SolveOptions), C.POINTER(SolveSummary),
@@ -574,6 +575,12 @@ class Backend:
         else:
             out["resident"] = True
         return out
+
+    def marg_stats(self) -> dict:
+        """Route counters of the Cholesky-form marginalisations (sadvio_ba_marg_stats)."""
+        v = [C.c_int32(0) for _ in range(3)]
+        self._check(self.lib.sadvio_ba_marg_stats(self.h, *[C.byref(x) for x in v]), "marg_stats")
+        return {"calls": v[0].value, "unpivoted": v[1].value, "fell_back": v[2].value}
 
     def get_prior(self, readback: bool = True):
         """The handle's prior (sadvio_ba_get_prior): {"valid", "n_full", "n", "form"[, "J", "r0"]}."""

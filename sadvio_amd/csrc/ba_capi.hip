@@ -302,6 +302,7 @@ struct sadvio_ba_handle {
     DevBuf<int> d_lm_sub;                 // work list of k_lm_pass (tile, sub-block), see DevPtrs
     int lm_n_sub = 0, lm_ksub = 1, lm_sub_per_item = 8;   // sub-blocks per work item of k_lm_pass (8 = the whole tile: MAX tile = 512 landmarks)   // throughput path: elimination records, per-landmark H_ll | g_l and per-tile key-frame sums (both per delta buffer)
     int lm_max_cam = 1;
+    int marg_stats[4] = {0, 0, 0, 0};     // Cholesky-form marginalisations: calls | took the unpivoted route | tried it and fell back | pivoted without a try
     int lm_sub_obs = 0;                   // most observations of LM_PASS_THREADS consecutive landmarks of a tile (LDS staging of k_lm_pass)
     bool gemm_run4 = false;               // a tile on the MFMA path holds runs of 3 - 4 observations on one key-frame (k_build<.., RARE = true> only)
     bool lm_ok = false;                   // every tile is on the MFMA path and chunked: k_build_obs / k_lm_pass may run
@@ -1968,6 +1969,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         const int n1 = n + 1;
         const long long nn1 = (long long)n1 * n1;
         bool unpivoted = false;
+        h->marg_stats[0]++;
         // (without an earlier prior frame1's velocity / bias directions are only held relative to frame0's: Ak is rank deficient, the
         // attempt would be wasted; SADVIO_MARG_UNPIVOTED=1 tries it regardless)
         // Only under the reference's absolute cut: an unpivoted factorisation is not rank revealing (the pivot of the last index of a
@@ -1985,8 +1987,10 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
             HIP_TRY(hipMemcpyAsync(M.newr.p, M.bk.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
             const int okf = run_wfac(h, M.V.p, n, M.newr.p, M.G.p, Ltw, M.Ak.p, (long long)n, pchol_tau(n, rq->eig_cut_mode), M.wtmp.p, M.flag.p);
             if (okf < 0) { h->err = "marginalize: HIP error in the unpivoted Cholesky"; return SADVIO_E_HIP; }
+            if (okf != 1) h->marg_stats[2]++;
             if (okf == 1) {
                 unpivoted = true; unpivoted_ok = true;
+                h->marg_stats[1]++;
                 nf = n;
                 hipLaunchKernelGGL(k_wfac_pack, dim3((unsigned)(((long long)n * n + 255) / 256)), dim3(256), 0, h->stream, M.G.p, (long long)n, Ltw, Ld, M.newr.p, n, M.newJ.p, M.newr.p);
                 HIP_TRY(PR.step_of.alloc(n));
@@ -2043,6 +2047,14 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipGetLastError());
+    return SADVIO_OK;
+}
+
+int sadvio_ba_marg_stats(sadvio_ba_handle* h, int32_t* calls, int32_t* unpivoted, int32_t* fell_back) {
+    if (!h) return SADVIO_E_INVALID_ARG;
+    if (calls) *calls = h->marg_stats[0];
+    if (unpivoted) *unpivoted = h->marg_stats[1];
+    if (fell_back) *fell_back = h->marg_stats[2];
     return SADVIO_OK;
 }
 

@@ -1,0 +1,175 @@
+"""A LONG sliding sequence: 25 key-frame steps of the reference's back-end loop (slamBiMonoVIO.cpp:561-614,
+slamBiMono.cpp:240-286) over a 34-key-frame synthetic trajectory — marginalize the window's oldest key-frame (folding in the prior the
+step before left), [sparsify: sparsifyVIO, or the sparsifyVO chain of marginalization.cpp:410-514], drop the frame, solve the next
+window with the prior attached, write the deltas back, slide. (dense | sparsified) x (VIO | VO). Device side: the prior never leaves
+the handle (resident, Cholesky form); oracle side: the reference's eigen-form (J, r0) carried on the host. The two sides propagate their
+state SEPARATELY, so a disagreement compounds. Reported per run: the per-step termination iteration, the device's marginalisation
+routes (unpivoted wide-panel / fell back to the rank-revealing one) and the drift between the two trajectories."""
+import copy
+
+import numpy as np
+import pytest
+
+from sadvio_amd import capi, synthetic
+from test_gpu_sliding import apply_deltas, sub_window
+from test_oracle_marg import pre_marginalize
+from vio_helpers import make_vio_window
+
+pytestmark = pytest.mark.gpu
+N_WIN, N_STEPS, N_KF = 8, 25, 34
+
+
+def vo_sub_window(W, state, kfs):
+    w, keep_l = sub_window(W, state, kfs)
+    w.has_imu = 0
+    w.kf_vel = w.kf_ba = w.kf_bg = None
+    w.imu_factors = []
+    return w, keep_l
+
+
+def apply_vo(state, kfs, keep_l, d):
+    fake = dict(d, dv=np.zeros((len(kfs), 3)), dba=np.zeros((len(kfs), 3)), dbg=np.zeros((len(kfs), 3)))
+    apply_deltas(state, kfs, keep_l, fake)
+
+
+def cols_in(w, pr):
+    """(lmk_index, lmk_col) of a prior's landmarks in window w (col -1: the landmark left the window)."""
+    idx, col = [], []
+    for lid, lc in zip(pr["lmk_id"], pr["lmk_col"]):
+        j = np.flatnonzero(w.lmk_id == lid)
+        idx.append(int(j[0]) if len(j) else 0); col.append(int(lc) if len(j) else -1)
+    return np.array(idx, dtype=np.int32), np.array(col, dtype=np.int32)
+
+
+def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS):
+    if vio:
+        W = make_vio_window(n_kf=N_KF, n_lmk=1100, seed=977, obs_per_lmk=6, length=17.0)
+    else:
+        W = synthetic.make_window(n_kf=N_KF, n_lmk=1100, seed=977, obs_per_lmk=6, length=17.0)
+        W.kf_vel = W.kf_ba = W.kf_bg = np.zeros((N_KF, 3)); W.imu_factors = []
+    opts = capi.reference_options()
+    init = {"T": W.kf_T_f_w.copy(), "p": W.lmk_p.copy(), "v": np.array(W.kf_vel, dtype=float).copy(), "ba": np.array(W.kf_ba, dtype=float).copy(),
+            "bg": np.array(W.kf_bg, dtype=float).copy()}
+    sides = {"dev": copy.deepcopy(init), "ora": copy.deepcopy(init)}
+    be = backend_cls(device=0)
+    oldest = W.n_kf - 1
+    mk_win = sub_window if vio else vo_sub_window
+    prior = {"dev": None, "ora": None}
+    if vio:   # the prior an initialisation leaves on the oldest key-frame's 15 states (see test_gpu_sliding.py)
+        J0 = np.diag(np.concatenate([10.0 * np.ones(6), 5.0 * np.ones(3), 20.0 * np.ones(3), 50.0 * np.ones(3)]))
+        first = {"kf_id": int(W.kf_id[oldest]), "kf_col": 0, "lmk_id": [], "lmk_col": []}
+        prior = {"dev": dict(first), "ora": dict(first, J=J0, r0=np.zeros(15))}
+        be.set_prior(J0, np.zeros(15))
+    log = []
+    for step in range(n_steps):
+        kfs = list(range(oldest - N_WIN + 1 - step, oldest + 1 - step))      # newest first; the last entry is frame0 of this step
+        frame0, frame1 = len(kfs) - 1, len(kfs) - 2
+        results, ranks = {}, {}
+        for side in ("dev", "ora"):
+            st = sides[side]
+            w, keep_l = mk_win(W, st, kfs)
+            if step == 0:
+                w.pose_priors = [(frame0, W.truth["T_f_w"][kfs[frame0]].copy(), 100.0 * np.ones(6))]
+            keep, marg = pre_marginalize(w, frame0)
+            pr = prior[side]
+            if pr is not None:      # landmarks the previous prior holds are kept if they are still in the window (marginalization.cpp:116-139)
+                for lid in pr["lmk_id"]:
+                    j = np.flatnonzero(w.lmk_id == lid)
+                    if len(j) and int(j[0]) not in keep and int(j[0]) not in marg:
+                        keep.append(int(j[0]))
+            last = None
+            if pr is not None:
+                idx, col = cols_in(w, pr)
+                last = {"kf_keep": frame0 if vio else -1, "kf_col": pr["kf_col"] if vio else 0, "lmk_index": idx, "lmk_col": col}
+                if vio:
+                    assert pr["kf_id"] == w.kf_id[frame0]            # the kept frame of the last step is frame0 now
+                if side == "ora":
+                    last["J"], last["r0"] = pr["J"], pr["r0"]
+            args = dict(kf_marg=frame0, lmk_marg=marg, lmk_keep=keep, priors=w.pose_priors, last=last, eig_cut=cut)
+            if vio:
+                args.update(kf_keep=frame1, marg_has_imu=True, imu=[f for f in w.imu_factors if f["kf_i"] == frame0 and f["kf_j"] == frame1][0])
+            if side == "dev":
+                be.set_windows([w])
+                g = be.marginalize(0, form="cholesky", readback=False, **args)
+                fs = be.sparsify(0, g, vio=vio) if sparsif else None
+            else:
+                g = oracle_lib.marginalize(w, **args)
+                fs = oracle_lib.sparsify(w, g, vio=vio) if sparsif else None
+            assert g is not None and (not sparsif or fs is not None), (step, side)
+            ranks[side] = (int(g["n_full"]), int(g["n"]))
+            new_prior = {"kf_id": int(w.kf_id[frame1]), "kf_col": g["kf_col"], "lmk_id": [int(w.lmk_id[l]) for l in keep], "lmk_col": list(g["lmk_col"])}
+            if side == "ora":
+                new_prior["J"], new_prior["r0"] = g["J"], g["r0"]
+            prior[side] = new_prior
+            # next window: frame0 dropped (discardLastFrame). VIO: nothing constant, the prior anchors the window; VO: the oldest
+            # key-frame is held (fixed_frame_number: 1, config.yaml:35; ...Analytic.cpp:219)
+            kfs2 = kfs[:-1]
+            w2, keep_l2 = mk_win(W, st, kfs2)
+            if not vio:
+                w2.kf_const = np.zeros(len(kfs2), dtype=np.uint8); w2.kf_const[-1] = 1
+            if sparsif:
+                remap = []
+                for f in fs:
+                    f = dict(f)
+                    if f["kf"] >= 0:
+                        f["kf"] = int(np.flatnonzero(w2.kf_id == w.kf_id[f["kf"]])[0])
+                    gone = False
+                    for key in ("lmk0", "lmk1"):
+                        if f[key] >= 0:
+                            j = np.flatnonzero(w2.lmk_id == w.lmk_id[f[key]])
+                            if len(j):
+                                f[key] = int(j[0])
+                            else:
+                                gone = True
+                    if not gone:
+                        remap.append(f)
+                w2.sparse_priors = remap
+            else:
+                idx, col = cols_in(w2, new_prior)
+                dp = {"kf_keep": int(np.flatnonzero(w2.kf_id == new_prior["kf_id"])[0]) if vio else -1, "kf_col": new_prior["kf_col"] if vio else 0,
+                      "lmk_index": idx, "lmk_col": col}
+                if side == "ora":
+                    dp["J"], dp["r0"] = g["J"], g["r0"]
+                w2.dense_prior = dp
+            if side == "dev":
+                be.set_windows([w2])
+                s = be.solve(opts)[0]
+                d = be.get_deltas(0)
+                results[side] = (s.iterations, s.termination, s.final_cost, d)
+            else:
+                r = oracle_lib.solve(w2, opts, dense_prior=w2.dense_prior)
+                results[side] = (r["summary"].iterations, r["summary"].termination, r["summary"].final_cost, r)
+            (apply_deltas if vio else apply_vo)(st, kfs2, keep_l2, results[side][3])
+        (it_d, term_d, cost_d, dd), (it_o, term_o, cost_o, do) = results["dev"], results["ora"]
+        log.append(dict(step=step, it=(it_d, it_o), term=(term_d, term_o), cost_rel=abs(cost_d - cost_o) / cost_o, dpose=float(np.abs(dd["pose"] - do["pose"]).max()),
+                        rank_dev=ranks["dev"], rank_ora=ranks["ora"], drift=float(np.abs(sides["dev"]["T"] - sides["ora"]["T"]).max())))
+    stats = be.marg_stats()
+    be.close()
+    return log, stats, sides
+
+
+@pytest.mark.parametrize("vio,sparsif", [(True, False), (True, True), (False, False), (False, True)])
+def test_25_key_frame_steps(backend_cls, oracle_lib, vio, sparsif):
+    log, stats, sides = run_sequence(backend_cls, oracle_lib, vio, sparsif, "reference")
+    tag = f"[sliding {'VIO' if vio else 'VO'} {'sparsified' if sparsif else 'dense'}]"
+    print(tag, "termination iteration per step (device):", [r["it"][0] for r in log])
+    print(tag, "oracle where it differs:", [(r["step"], r["it"]) for r in log if r["it"][0] != r["it"][1]])
+    print(tag, "prior rank (n_full, n) device / oracle where they differ:", [(r["step"], r["rank_dev"], r["rank_ora"]) for r in log if r["rank_dev"] != r["rank_ora"]])
+    print(tag, f"marginalisation routes on the device: {stats}; worst per-step |dpose| {max(r['dpose'] for r in log):.2e}, cost {max(r['cost_rel'] for r in log):.2e}, "
+               f"drift of the two trajectories after {len(log)} steps {log[-1]['drift']:.2e}")
+    # Under the reference's absolute 1e-12 cut (marginalization.hpp:58) the RANK of a prior is ill-posed when an eigenvalue of Ak sits
+    # at the cut: the oracle's eigen-decomposition and the device's pivoted Cholesky may then keep a different number of directions
+    # (measured on the VIO dense sequence: step 13, 227 against 228 of 228 — the one step whose unpivoted attempt fell back). The
+    # direction in question carries ~1e-12 of information, the two priors differ by that much, and the solves that follow inherit
+    # it: cost 1.3e-6 relative, poses 4e-6, identical iteration counts and terminations on all 25 steps, 2.5e-6 of drift at the end.
+    # Strict bars up to the first such step, the measured envelope (x 4) after it.
+    loose = False
+    for r in log:
+        loose = loose or r["rank_dev"] != r["rank_ora"]
+        assert r["it"][0] == r["it"][1] and r["term"][0] == r["term"][1], r
+        assert r["cost_rel"] <= (5e-6 if loose else 1e-7), r
+        assert r["dpose"] <= (1.6e-5 if loose else 1e-6), r
+    assert sum(r["rank_dev"] != r["rank_ora"] for r in log) <= 2
+    assert stats["fell_back"] <= 2 and stats["unpivoted"] >= len(log) - 3, stats
+    assert log[-1]["drift"] <= 1e-5
+    assert np.abs(sides["dev"]["p"] - sides["ora"]["p"]).max() <= 1e-4
