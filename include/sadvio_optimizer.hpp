@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <array>
 #include <string>
 #include <vector>
 
@@ -364,6 +365,12 @@ class HipOptimizer {
     int prior_rows() const { return _prior.n_full; }
     int prior_cols() const { return _prior.n; }
     // n_full x n row-major, read back from the device on request (sadvio_ba_get_prior): the solve path never needs it on the host
+    // Route counters of this optimizer's Cholesky-form marginalisations (sadvio_ba_marg_stats): {calls, unpivoted, fell_back}
+    std::array<int32_t, 3> marg_stats() const {
+        std::array<int32_t, 3> v{0, 0, 0};
+        (void)sadvio_ba_marg_stats(_h, &v[0], &v[1], &v[2]);
+        return v;
+    }
     // Read-backs over PCIe (not for per-frame use); the buffers are sized from what the HANDLE reports, not from this object's copy
     // of the shape, so a divergence between the two cannot overflow them.
     std::vector<double> prior_J() const {

@@ -442,6 +442,116 @@ int main(int argc, char** argv) {
         check(tr2 < tr, "marginalizeRelative: fewer shared landmarks, less information");
         check(!opt.marginalizeRelative(m, 0, 0, inf2) && inf2[0] == 0.0, "marginalizeRelative: bad frame pair refused with a zero matrix");
     }
+    // --- the back-end loop over a SEQUENCE (slamBiMonoVIO.cpp:561-614): 20 key-frame steps through this layer —
+    //     marginalize(frame0, frame1) [+ sparsification on every other run] -> the frame leaves the window, a new key-frame enters with a
+    //     perturbed pose / velocity and fresh, perturbed landmarks -> localMapVIOptimization with the prior the optimizer holds (by id).
+    //     Noise-free measurements and pre-integrations: the window must stay at the ground truth, every solve usable.
+    for (int sparsif = 0; sparsif < 2; sparsif++) {
+        const int n_total = 26, n_win = 6;
+        const double dt = 0.2, gw[3] = {0, 0, -9.81}, vx = 0.3 / dt;
+        HipOptimizer seq;
+        std::uniform_real_distribution<double> U(-1.0, 1.0);
+        // frame k (k = 0 oldest) at c = (0.3 k, 0, 0); landmarks spread along the path
+        auto frame_at = [&](int k) {
+            FrameState f;
+            f.id = 1000 + k;
+            f.T_f_w.t[0] = -0.3 * k;
+            CameraModel c0{458.654, 457.296, 367.215, 248.375, Pose()}, c1 = c0;
+            c1.T_s_f.t[0] = -0.11;
+            f.cameras = {c0, c1};
+            f.has_imu = true;
+            f.v[0] = vx;
+            return f;
+        };
+        std::vector<LandmarkState> all;
+        for (int l = 0; l < 900; l++) {
+            LandmarkState L;
+            L.id = 90000 + l;
+            L.p[0] = 0.3 * (n_total - 1) * 0.5 * (U(rng) + 1.0) + 1.5 * U(rng); L.p[1] = 1.2 * U(rng); L.p[2] = 4.0 + 2.0 * U(rng);
+            all.push_back(L);
+        }
+        auto imu_pair = [&](int fi, int fj) {     // i older, j newer: exact deltas of the constant-velocity, non-rotating body
+            ImuPair pr{};
+            pr.frame_i = fi; pr.frame_j = fj;
+            sadvio_imu_factor& f = pr.f;
+            f.dt = dt;
+            const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            std::memcpy(f.delta_R, I3, sizeof(I3));
+            const double dpos[3] = {0.3, 0, 0}, v0[3] = {vx, 0, 0};
+            for (int a = 0; a < 3; a++) {
+                f.delta_v[a] = -gw[a] * dt;
+                f.delta_p[a] = dpos[a] - v0[a] * dt - 0.5 * gw[a] * dt * dt;
+                f.J_dv_ba[4 * a] = -dt; f.J_dp_ba[4 * a] = -0.5 * dt * dt; f.J_dR_bg[4 * a] = -dt;
+            }
+            for (int q = 0; q < 9; q++) f.cov[10 * q] = q < 3 ? 1e-6 : (q < 6 ? 1e-4 : 1e-5);
+            f.bacc_noise = 3e-3; f.bgyr_noise = 2e-5;
+            return pr;
+        };
+        // window over the frames first .. first + n_win - 1 (stored newest first), the landmarks they see at least four times
+        auto window = [&](int first, const std::vector<FrameState>& state, const std::vector<LandmarkState>& lm) {
+            LocalMapSnapshot m;
+            for (int i = 0; i < n_win; i++) m.frames.push_back(state[first + n_win - 1 - i]);
+            for (const LandmarkState& L0 : lm) {
+                LandmarkState L = L0;
+                L.features.clear();
+                for (int i = 0; i < n_win; i++)
+                    for (int c = 0; c < 2; c++) {
+                        double u, v;
+                        project(frame_at(first + n_win - 1 - i), c, all[L.id - 90000].p, u, v);   // measurements of the TRUE geometry
+                        if (u > 80 && u < 650 && v > 60 && v < 430) L.features.push_back({i, c, u, v});
+                    }
+                if ((int)L.features.size() >= 4) m.landmarks.push_back(L);
+            }
+            for (int i = n_win - 1; i > 0; i--) m.imu_pairs.push_back(imu_pair(i, i - 1));
+            return m;
+        };
+        std::vector<FrameState> state;
+        for (int k = 0; k < n_total; k++) state.push_back(frame_at(k));
+        std::vector<LandmarkState> lm = all;
+        state[0].has_prior = true; state[0].T_prior = state[0].T_f_w;
+        for (double& x : state[0].inf_prior) x = 100.0;
+        double worst = 0.0, worst_rel = 0.0;
+        int failures = 0, refused = 0, steps = 0;
+        auto rel = [](const Pose& a, const Pose& b) {   // T_a T_b^-1: the relative pose of two frames does not see the window's gauge
+            Pose r;
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double v = 0; for (int k = 0; k < 3; k++) v += a.R[3 * i + k] * b.R[3 * j + k]; r.R[3 * i + j] = v; }
+            for (int i = 0; i < 3; i++) { double v = a.t[i]; for (int k = 0; k < 3; k++) v -= r.R[3 * i + k] * b.t[k]; r.t[i] = v; }
+            return r;
+        };
+        for (int first = 0; first + n_win < n_total; first++, steps++) {
+            // the key-frame that entered last and the landmarks only it and its predecessor see start from a perturbed estimate
+            {
+                FrameState& f = state[first + n_win - 1];
+                double d[6] = {0.002 * G(rng), 0.002 * G(rng), 0.002 * G(rng), 0.01 * G(rng), 0.01 * G(rng), 0.01 * G(rng)};
+                if (first > 0) { apply_pose_delta(f.T_f_w, d); for (int a = 0; a < 3; a++) f.v[a] += 0.02 * G(rng); }
+            }
+            LocalMapSnapshot m = window(first, state, lm);
+            seq.localMapVIOptimization(m, first == 0 ? 1 : 0);     // after the first step only the prior anchors the window
+            if (seq.summary().termination == SADVIO_TERM_FAILURE) failures++;
+            for (int i = 0; i < n_win; i++) {
+                state[first + n_win - 1 - i] = m.frames[i];
+                worst = std::fmax(worst, pose_err(m.frames[i].T_f_w, frame_at(first + n_win - 1 - i).T_f_w));
+                if (i + 1 < n_win)
+                    worst_rel = std::fmax(worst_rel, pose_err(rel(m.frames[i].T_f_w, m.frames[i + 1].T_f_w),
+                                                              rel(frame_at(first + n_win - 1 - i).T_f_w, frame_at(first + n_win - 2 - i).T_f_w)));
+            }
+            for (const LandmarkState& L : m.landmarks) lm[L.id - 90000] = L;
+            if (!seq.marginalize(m, n_win - 1, n_win - 2, sparsif != 0)) refused++;
+            for (const LandmarkState& L : m.landmarks) lm[L.id - 90000].has_prior = L.has_prior;
+        }
+        const auto st = seq.marg_stats();
+        std::printf("   %d sliding steps (%s prior): worst pose error %.3e (between consecutive key-frames %.3e), failed solves %d, refused marginalisations %d, routes: %d calls / %d unpivoted / %d fell back\n",
+                    steps, sparsif ? "sparsified" : "dense", worst, worst_rel, failures, refused, st[0], st[1], st[2]);
+        // The dense prior carries the information exactly: the window stays at the truth (1e-11). The NFR factors of the sparsified prior
+        // are an approximation (sparsifyVIO keeps the marginal of the frame and of every kept landmark, not their correlations) that leaves
+        // the window weakly conditioned along its landmark links (see the single-step test above: four solves to pull a window back): ONE
+        // <= 20-iteration solve per key-frame, as the reference runs it, does not re-converge a frame that entered 1e-2 off — the
+        // error stays at the scale of the perturbation instead of accumulating (measured 8e-3 over 20 steps; the same loop against the
+        // oracle: tests/test_gpu_sliding_long.py, 1e-8). Held here: no failed solve, no refused marginalisation, no growth.
+        check(steps == 20 && failures == 0 && refused == 0 && (sparsif ? worst_rel < 3e-2 : worst < 1e-5),
+              sparsif ? "20-step sliding sequence through marginalize + sparsification + localMapVIOptimization stays at the ground truth"
+                      : "20-step sliding sequence through marginalize + localMapVIOptimization (dense resident prior) stays at the ground truth");
+    }
     std::printf("%s (%d failure%s)\n", fails ? "FAILED" : "PASSED", fails, fails == 1 ? "" : "s");
     return fails ? 1 : 0;
 }
