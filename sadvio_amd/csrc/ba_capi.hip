@@ -128,9 +128,15 @@ struct UploadBatch {
     char* pinned = nullptr; size_t pinned_cap = 0, used = 0;   // sources are packed straight into pinned memory
     char* dev = nullptr; size_t dev_cap = 0;
     bool failed = false;
-    void reset() { items.clear(); used = 0; failed = false; }   // drop what an earlier, failed layout build left queued
+    // flush() does not wait: the staged copy + scatter are stream work like the kernels that read their output. The pinned buffer is
+    // only touched again (next add / grow) after the event recorded behind the copy has fired — by then it normally has
+    hipEvent_t ev = nullptr;
+    bool in_flight = false;
+    void wait() { if (in_flight) { (void)hipEventSynchronize(ev); in_flight = false; } }
+    void reset() { wait(); items.clear(); used = 0; failed = false; }   // drop what an earlier, failed layout build left queued
     void reserve(size_t bytes) {
         if (bytes <= pinned_cap) return;
+        wait();
         char* np = nullptr;
         const size_t cap = bytes + bytes / 2 + 4096;
         if (hipHostMalloc((void**)&np, cap, hipHostMallocDefault) != hipSuccess) { failed = true; return; }
@@ -139,6 +145,7 @@ struct UploadBatch {
     }
     void add(void* dst, const void* src, size_t bytes) {
         if (!bytes) return;
+        wait();
         const size_t off = (used + 7) & ~(size_t)7;
         reserve(off + bytes);
         if (failed) return;
@@ -154,8 +161,9 @@ struct UploadBatch {
         reserve(total);
         if (failed) { failed = false; items.clear(); used = 0; return hipErrorOutOfMemory; }
         hipError_t e = hipSuccess;
+        if (!ev && (e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
         if (dev_cap < total) {
-            if (dev) (void)hipFree(dev);
+            if (dev) { (void)hipStreamSynchronize(stream); (void)hipFree(dev); }   // an earlier scatter may still read it
             dev = nullptr; dev_cap = 0;
             if ((e = hipMalloc((void**)&dev, total + total / 2)) != hipSuccess) return e;
             dev_cap = total + total / 2;
@@ -163,11 +171,13 @@ struct UploadBatch {
         memcpy(pinned + data_bytes, items.data(), items.size() * sizeof(UploadItem));
         if ((e = hipMemcpyAsync(dev, pinned, total, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_scatter_uploads, dim3(64, (unsigned)std::min<size_t>(items.size(), 64)), dim3(256), 0, stream, dev, (const UploadItem*)(dev + data_bytes), (int)items.size());
-        e = hipStreamSynchronize(stream);  // the pinned buffer is reused by the next batch
+        e = hipEventRecord(ev, stream);
+        in_flight = e == hipSuccess;
+        if (!in_flight) e = hipStreamSynchronize(stream);
         items.clear(); used = 0;
         return e;
     }
-    ~UploadBatch() { if (pinned) (void)hipHostFree(pinned); if (dev) (void)hipFree(dev); }
+    ~UploadBatch() { wait(); if (ev) (void)hipEventDestroy(ev); if (pinned) (void)hipHostFree(pinned); if (dev) (void)hipFree(dev); }
 };
 
 struct DensePriorHost {
@@ -224,7 +234,31 @@ struct LayoutScratch {
     std::vector<char> held;
 };
 
+// The diagnostic switches of DESIGN.md 4 (environment), read ONCE when the handle is created: none is needed in production, and none is
+// looked up again on a per-key-frame path (round 4 called getenv 39 times across set_windows / marginalize / solve).
+struct EnvCfg {
+    int debug = 0;
+    int lm = -1, pf_wg = -1;            // -1: not set
+    int tile_rounds = 0, lm_subs = 0, band_c = 0;   // 0: not set
+    double jacobi_tol = 1e-14;
+    bool marg_last_small = false, marg_eig_mm = false, marg_pivoted = false, marg_unpivoted = false, pchol_swap = false, pchol_strict = false,
+         jacobi_b4 = false, jacobi_plain = false, no_lpt = false, no_fork = false, no_bcr = false, wd_old = false, wd_nola = false, wd_r3 = false,
+         wd_back1 = false;
+    void read() {
+        auto on = [](const char* k) { return getenv(k) != nullptr; };
+        auto num = [](const char* k, int unset) { const char* e = getenv(k); return e ? atoi(e) : unset; };
+        debug = num("SADVIO_DEBUG", 0); lm = num("SADVIO_LM", -1); pf_wg = num("SADVIO_PF_WG", -1);
+        tile_rounds = num("SADVIO_TILE_ROUNDS", 0); lm_subs = num("SADVIO_LM_SUBS", 0); band_c = num("SADVIO_BAND_C", 0);
+        if (const char* e = getenv("SADVIO_JACOBI_TOL")) jacobi_tol = atof(e);
+        marg_last_small = on("SADVIO_MARG_LAST_SMALL"); marg_eig_mm = on("SADVIO_MARG_EIG_MM"); marg_pivoted = on("SADVIO_MARG_PIVOTED");
+        marg_unpivoted = on("SADVIO_MARG_UNPIVOTED"); pchol_swap = on("SADVIO_PCHOL_SWAP"); pchol_strict = on("SADVIO_PCHOL_STRICT");
+        jacobi_b4 = on("SADVIO_JACOBI_B4"); jacobi_plain = on("SADVIO_JACOBI_PLAIN"); no_lpt = on("SADVIO_NO_LPT"); no_fork = on("SADVIO_NO_FORK");
+        no_bcr = on("SADVIO_NO_BCR"); wd_old = on("SADVIO_WD_OLD"); wd_nola = on("SADVIO_WD_NOLA"); wd_r3 = on("SADVIO_WD_R3"); wd_back1 = on("SADVIO_WD_BACK1");
+    }
+};
+
 struct sadvio_ba_handle {
+    EnvCfg env;
     sadvio_ba_config cfg{};
     LayoutScratch ls;
     int device = 0;
@@ -418,7 +452,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.xline_stride = 6LL * h->n_line_tot;
     P.n_xp = (long long)h->d_xp.n; P.n_xv = (long long)h->d_xv.n; P.n_xl = (long long)h->d_xl.n;
     P.n_win = (int)h->wins.size();
-    { const char* e = getenv("SADVIO_DEBUG"); P.debug = e ? atoi(e) : 0; }
+    P.debug = h->env.debug;
     P.o = o;
     return P;
 }
@@ -636,7 +670,7 @@ int layout_reduced(sadvio_ba_handle* h) {
         double* H = Jt + (size_t)pr.n * pr.nf;
         const long long items = (long long)pr.nf * pr.n;
         hipLaunchKernelGGL(k_dense_prior_prepare, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, J, Jt, pr.nf, pr.n);
-        if (h->dprior_per_win[pr.w].resident && h->prior.hg_valid && h->prior.n == pr.n && !getenv("SADVIO_MARG_LAST_SMALL"))
+        if (h->dprior_per_win[pr.w].resident && h->prior.hg_valid && h->prior.n == pr.n && !h->env.marg_last_small)
             hipLaunchKernelGGL(k_sym_from_lower, dim3((unsigned)(((long long)pr.n * pr.n + 255) / 256)), dim3(256), 0, h->stream, h->prior.H.p, pr.n, H);   // H = Ak of the marginalisation
         else
         hipLaunchKernelGGL(k_mgemm, dim3((pr.n + 63) / 64, (pr.n + 63) / 64), dim3(256), 0, h->stream, H, (long long)pr.n, J, 1LL, (long long)pr.n, J, (long long)pr.n, 1LL,
@@ -718,6 +752,7 @@ int sadvio_ba_create(const sadvio_ba_config* cfg, sadvio_ba_handle** out) {
     if (!strstr(prop.gcnArchName, "gfx950")) return SADVIO_E_NO_DEVICE;  // kernels are built for gfx950 only
     if (hipSetDevice(dev) != hipSuccess) return SADVIO_E_HIP;
     auto* h = new sadvio_ba_handle();
+    h->env.read();
     if (cfg) h->cfg = *cfg;
     h->device = dev;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return SADVIO_E_HIP; }
@@ -754,7 +789,7 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
 // (Re)build the device layout from the stored caller windows + the current factor lists: concatenation, the
 // per-landmark observation order, pseudo-observations of eliminable pose-to-landmark factors, tiles, reduced layout.
 static int build_layout(sadvio_ba_handle* h) {
-    const bool dbg_t = getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 8192);
+    const bool dbg_t = (h->env.debug & 8192) != 0;
     auto t_start = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) { if (dbg_t) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[sadvio dbg] build_layout %-14s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_start).count()); t_start = t; } };
     const int n_windows = (int)h->src.size();
@@ -1014,7 +1049,7 @@ static int build_layout(sadvio_ba_handle* h) {
             long long l_tot = 0;
             for (int ww = 0; ww < n_windows; ww++) l_tot += views[ww].n_lmk;
             tile_rounds = (int)std::min<long long>(16, std::max<long long>(1, (l_tot + 32LL * 2048 - 1) / (32LL * 2048)));
-            if (const char* e = getenv("SADVIO_TILE_ROUNDS")) tile_rounds = std::max(1, atoi(e));
+            if (h->env.tile_rounds > 0) tile_rounds = h->env.tile_rounds;
         }
         d.tile_begin = (int)h->tiles.size();
         {
@@ -1101,7 +1136,7 @@ static int build_layout(sadvio_ba_handle* h) {
     obs_lslot.assign(std::max(obs_b, 1), 0);
     // the tables cost host time (a second, sorted copy of the observation constants): only built where the throughput path can run
     bool want_lm = lmk_b >= 65536;
-    if (const char* e = getenv("SADVIO_LM")) want_lm = atoi(e) != 0;
+    if (h->env.lm >= 0) want_lm = h->env.lm != 0;
     h->lm_ok = want_lm && !h->tiles.empty();
     h->lm_landmarks = 0;
     h->lm_sub_obs = 0;
@@ -1150,17 +1185,17 @@ static int build_layout(sadvio_ba_handle* h) {
         auto& perm = ls.perm;
         perm.resize(h->tiles.size());
         for (size_t i = 0; i < perm.size(); i++) perm[i] = (int)i;
-        if (want_lm && !getenv("SADVIO_NO_LPT"))
+        if (want_lm && !h->env.no_lpt)
             std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
                 return h->tiles[a].chunk1 - h->tiles[a].chunk0 > h->tiles[b].chunk1 - h->tiles[b].chunk0; });
-        if (getenv("SADVIO_DEBUG") && want_lm && !perm.empty())
+        if (h->env.debug && want_lm && !perm.empty())
             fprintf(stderr, "[sadvio dbg] chunks per tile: largest %d, median %d, smallest %d\n", h->tiles[perm.front()].chunk1 - h->tiles[perm.front()].chunk0,
                     h->tiles[perm[perm.size() / 2]].chunk1 - h->tiles[perm[perm.size() / 2]].chunk0, h->tiles[perm.back()].chunk1 - h->tiles[perm.back()].chunk0);
         HIP_TRY(h->d_tile_perm.alloc(std::max<size_t>(perm.size(), 1)));
         h->up.add(h->d_tile_perm.p, perm.data(), perm.size() * sizeof(int));
         // work list of k_lm_pass: the sub-blocks (LM_PASS_THREADS landmarks) of every tile, in the same order
         std::vector<int> sub;
-        if (const char* e = getenv("SADVIO_LM_SUBS")) h->lm_sub_per_item = std::max(1, atoi(e));
+        if (h->env.lm_subs > 0) h->lm_sub_per_item = h->env.lm_subs;
         if (want_lm)
             for (int ti : perm) {
                 const Tile& t = h->tiles[ti];
@@ -1170,7 +1205,7 @@ static int build_layout(sadvio_ba_handle* h) {
         HIP_TRY(h->d_lm_sub.alloc(std::max<size_t>(sub.size(), 2)));
         h->up.add(h->d_lm_sub.p, sub.data(), sub.size() * sizeof(int));
     }
-    if (getenv("SADVIO_DEBUG")) {
+    if (h->env.debug) {
         int hist[32] = {0}, modes[3] = {0};
         for (auto& t : h->tiles) { hist[std::min(t.n_free, 31)]++; modes[t.lds_mode]++; }
         fprintf(stderr, "[sadvio dbg] %zu tiles, modes global/atomic/gemm = %d/%d/%d, max_tile_kf %d, n_free histogram:", h->tiles.size(), modes[0], modes[1], modes[2], h->max_tile_kf);
@@ -1546,7 +1581,7 @@ int run_pchol(sadvio_ba_handle* h, double* S, int n, double* G, double tau, bool
     double* dg = h->d_jac_dbl.p; double* dctl = dg + 2 * (size_t)n;      // remaining diagonal | original diagonal | tau
     if (hipMemsetAsync(rank_d, 0, sizeof(int) * 8, h->stream) != hipSuccess) return -1;
     if (hipMemsetAsync(rank_d, 0xff, sizeof(int), h->stream) != hipSuccess) return -1;   // -1: still factorising
-    const bool swap_pchol = allow_swap && getenv("SADVIO_PCHOL_SWAP") != nullptr;   // the data-moving version (kept for comparison; the eigen path only:
+    const bool swap_pchol = allow_swap && h->env.pchol_swap;   // the data-moving version (kept for comparison; the eigen path only:
                                                                                       // the Cholesky-form routes read the factor by original column index)
     if (swap_pchol) {
         for (int k0 = 0; k0 < n; k0 += PCH_NB) {
@@ -1557,7 +1592,7 @@ int run_pchol(sadvio_ba_handle* h, double* S, int n, double* G, double tau, bool
     } else {
         if (hipMemsetAsync(piv, 0xff, sizeof(int) * (size_t)n, h->stream) != hipSuccess) return -1;   // done[i] = -1
         const unsigned gt = (unsigned)((n + 63) / 64);
-        if (!getenv("SADVIO_PCHOL_STRICT")) {
+        if (!h->env.pchol_strict) {
             // relaxed pivoting (marg_kernels.h: k_pchol_panel_rx): a panel picks its pivots up front; the first row of a panel is device state
             const double safe = 1024.0 * n * 2.220446049250313e-16;
             const int nb = n <= PCH_THREADS ? 32 : 16;
@@ -1575,7 +1610,7 @@ int run_pchol(sadvio_ba_handle* h, double* S, int n, double* G, double tau, bool
                 }
                 if (hipMemcpyAsync(&r, rank_d, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
             }
-            if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 16384)) {
+            if ((h->env.debug & 16384)) {
                 int c8[8];
                 if (hipMemcpy(c8, rank_d, sizeof(c8), hipMemcpyDeviceToHost) == hipSuccess)
                     fprintf(stderr, "[sadvio dbg] relaxed pivoted cholesky n %d rank %d: %d panels launched, %d ran (%d strict), %d candidates skipped\n", n, r, launched, c8[3] + 1, c8[4], c8[5]);
@@ -1602,16 +1637,16 @@ int run_pchol(sadvio_ba_handle* h, double* S, int n, double* G, double tau, bool
 // Block one-sided Jacobi on the r rows (length n, packed) of G until they are mutually orthogonal: the rows converge to
 // sqrt(lambda_i) u_i^T of G^T G. Returns the number of sweeps (negative = HIP error). One host synchronisation per sweep.
 int run_jacobi_rows(sadvio_ba_handle* h, double* G, int r, int n, int* flag) {
-    const bool b4 = getenv("SADVIO_JACOBI_B4") != nullptr || n > JM_MAXN;   // the 4-row VALU version (large n; kept for comparison)
+    const bool b4 = h->env.jacobi_b4 || n > JM_MAXN;   // the 4-row VALU version (large n; kept for comparison)
     const int ldx = jm_ldx(n);
     const size_t jm_lds = (size_t)JM2 * ldx * sizeof(double);
     if (!b4 && hipFuncSetAttribute((const void*)k_jacobi_mma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jm_lds) != hipSuccess) return -1;
     const int jb = b4 ? JB : JM;
     const int nb = (r + jb - 1) / jb, nbpad = nb + (nb & 1);
-    const double jtol = getenv("SADVIO_JACOBI_TOL") ? atof(getenv("SADVIO_JACOBI_TOL")) : 1e-14;   // |g_p . g_q| <= jtol |g_p| |g_q| ends a pair
+    const double jtol = h->env.jacobi_tol;   // |g_p . g_q| <= jtol |g_p| |g_q| ends a pair
     int sweeps = 0;
     long long* jts = nullptr;   // phase timestamps of one launch (SADVIO_KERNEL_TS builds, SADVIO_DEBUG & 4096)
-    if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 4096) && n > 500 && h->d_dbg.alloc(128) == hipSuccess) jts = h->d_dbg.p + 44;
+    if ((h->env.debug & 4096) && n > 500 && h->d_dbg.alloc(128) == hipSuccess) jts = h->d_dbg.p + 44;
     for (; sweeps < 40 && nbpad >= 2; sweeps++) {
         if (hipMemsetAsync(flag, 0, sizeof(int), h->stream) != hipSuccess) return -1;
         for (int st = 0; st < nbpad - 1; st++) {
@@ -1622,7 +1657,7 @@ int run_jacobi_rows(sadvio_ba_handle* h, double* G, int r, int n, int* flag) {
         }
         int f = 0;
         if (hipMemcpyAsync(&f, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
-        if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 16384)) fprintf(stderr, "[sadvio dbg] block jacobi n %d rank %d sweep %d block pairs rotated %d\n", n, r, sweeps, f);
+        if ((h->env.debug & 16384)) fprintf(stderr, "[sadvio dbg] block jacobi n %d rank %d sweep %d block pairs rotated %d\n", n, r, sweeps, f);
         if (!f) { sweeps++; break; }
     }
     if (jts) {
@@ -1678,13 +1713,13 @@ int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int l
     const long long nn = (long long)n * n;
     // Cholesky-preconditioned block Jacobi (marg_kernels.h): sym(A) -> V (scratch), pivoted Cholesky V -> G = L^T, block
     // one-sided Jacobi sweeps on the rows of G, then eigen-pairs from the rows -> V, ev
-    if (n >= 32 && n <= PCH_MAXN && !getenv("SADVIO_JACOBI_PLAIN")) {
+    if (n >= 32 && n <= PCH_MAXN && !h->env.jacobi_plain) {
         hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, A, lda, n, V, G, lower_only);
         const int r = run_pchol(h, V, n, G, pchol_tau(n, eig_cut_mode));
         if (r < 0) return -1;
         const int sweeps = run_jacobi_rows(h, G, r, n, flag);
         if (sweeps < 0) return -1;
-        const bool swap_pchol = getenv("SADVIO_PCHOL_SWAP") != nullptr;
+        const bool swap_pchol = h->env.pchol_swap;
         hipLaunchKernelGGL(k_eig_from_rows, dim3(n), dim3(JAC_THREADS), 0, h->stream, G, swap_pchol ? h->d_jac_ints.p : (const int*)nullptr, h->d_jac_ints.p + n, n, V, ev);
         return sweeps;
     }
@@ -1706,7 +1741,7 @@ int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int l
         int f = 0;
         if (hipMemcpyAsync(&f, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
         if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
-        if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 16384)) fprintf(stderr, "[sadvio dbg] jacobi n %d sweep %d rotations %d\n", n, sweeps, f);
+        if ((h->env.debug & 16384)) fprintf(stderr, "[sadvio dbg] jacobi n %d sweep %d rotations %d\n", n, sweeps, f);
         if (!f) { sweeps++; break; }
     }
     hipLaunchKernelGGL(k_jacobi_eigenvalues, dim3(n), dim3(JAC_THREADS), 0, h->stream, G, V, n, ev);
@@ -1885,10 +1920,10 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     if (S.has_imu || S.n_prior) hipLaunchKernelGGL(k_marg_small, dim3(1), dim3(64), 0, h->stream, P, M.small.p, M.A.p, M.b.p, N);
     if (nfl > 0) {
         const long long items = (long long)nl * nl;
-        if (rq->last_n_full == SADVIO_PRIOR_RESIDENT && PR.hg_valid && PR.n == nl && !getenv("SADVIO_MARG_LAST_SMALL")) {
+        if (rq->last_n_full == SADVIO_PRIOR_RESIDENT && PR.hg_valid && PR.n == nl && !h->env.marg_last_small) {
             // the resident prior still carries the Ak / bk it was factorised from: J^T J and J^T r0 without touching J
             hipLaunchKernelGGL(k_marg_last_scatter_h, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, PR.H.p, PR.g.p, M.lastcol.p, nl, M.A.p, M.b.p, N);
-        } else if (nl >= 64 && !getenv("SADVIO_MARG_LAST_SMALL")) {
+        } else if (nl >= 64 && !h->env.marg_last_small) {
             HIP_TRY(M.Hl.alloc((size_t)nl * nl));
             launch_mgemm(h, M.Hl.p, nl, lastJ, 1LL, (long long)nl, lastJ, (long long)nl, 1LL, nl, nl, nfl, 1.0, 0.0);      // H = J^T J
             hipLaunchKernelGGL(k_marg_last_scatter, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, h->stream, M.Hl.p, lastJ, lastr, M.lastcol.p, nfl, nl, M.A.p, M.b.p, N);
@@ -1904,7 +1939,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     hev.resize(std::max(m, n));
     bool mm_by_cholesky = false;
     HIP_TRY(M.wtmp.alloc((size_t)big + 16));
-    if (m > 0 && !getenv("SADVIO_MARG_EIG_MM") && !getenv("SADVIO_MARG_PIVOTED") && rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE) {
+    if (m > 0 && !h->env.marg_eig_mm && !h->env.marg_pivoted && rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE) {
         // Amm is positive definite whenever frame0 carries a prior or enough observations: unpivoted wide-panel factor first (run_wfac)
         const long long mm2 = (long long)m * m;
         HIP_TRY(M.Vs.alloc(std::max(wfac_scratch_doubles(m), (size_t)big * big)));
@@ -1922,7 +1957,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
             mm_by_cholesky = true;
         }
     }
-    if (!mm_by_cholesky && m >= 32 && m <= PCH_MAXN && !getenv("SADVIO_MARG_EIG_MM")) {
+    if (!mm_by_cholesky && m >= 32 && m <= PCH_MAXN && !h->env.marg_eig_mm) {
         const long long mm2 = (long long)m * m;
         hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((mm2 + 255) / 256)), dim3(256), 0, h->stream, M.A.p, (long long)N, m, M.V.p, M.G.p, 0);
         const int r = run_pchol(h, M.V.p, m, M.G.p, pchol_tau(m, SADVIO_EIG_CUT_NOISE_FLOOR), false);
@@ -1959,7 +1994,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         HIP_TRY(hipMemcpy2DAsync(M.Ak.p, sizeof(double) * n, M.A.p + (size_t)m * N + m, sizeof(double) * N, sizeof(double) * n, n, hipMemcpyDeviceToDevice, h->stream));
         launch_mgemm(h, M.Ak.p, n, M.T.p, (long long)m, 1LL, M.A.p + (size_t)m * N, 1LL, (long long)N, n, n, m, -1.0, 1.0);
         hipLaunchKernelGGL(k_marg_bk, dim3((n + 127) / 128), dim3(128), 0, h->stream, M.T.p, M.b.p, n, m, M.bk.p);
-        HIP_TRY(hipStreamSynchronize(h->stream));   // `sel` goes out of scope
+        if (!mm_by_cholesky) HIP_TRY(hipStreamSynchronize(h->stream));   // `sel` (uploaded above) goes out of scope
     }
     int nf = 0;
     bool unpivoted_ok = false;
@@ -1976,7 +2011,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         // dependent set is lambda / v_i^2, v = the null vector - any size), so the noise-floor mode, whose point is a reliable
         // numerical rank, always takes the pivoted route; under the absolute 1e-12 cut both routes keep every direction whose pivot is
         // positive, as the reference's eigenvalue test does.
-        if (!getenv("SADVIO_MARG_PIVOTED") && rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE && (rq->last_n_full != 0 || getenv("SADVIO_MARG_UNPIVOTED"))) {
+        if (!h->env.marg_pivoted && rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE && (rq->last_n_full != 0 || h->env.marg_unpivoted)) {
             // A prior that carries an earlier prior is normally of full rank: then the factor needs no pivoting and the wide-panel
             // solver of the dense reduced systems (dense_chol.h: k_wchol_diag16 + k_wchol_step, one launch per 96 columns, bk riding
             // along as its right-hand side) delivers L and z = L^-1 bk in a third of the pivoted factorisation's time. Every pivot is
@@ -2045,7 +2080,8 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         if (J_out) HIP_TRY(hipMemcpyAsync(J_out, PR.J.p, sizeof(double) * (size_t)nf * n, hipMemcpyDeviceToHost, h->stream));
         if (r0_out) HIP_TRY(hipMemcpyAsync(r0_out, PR.r0.p, sizeof(double) * nf, hipMemcpyDeviceToHost, h->stream));
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    // the prior stays on the device and everything that reads it is stream-ordered behind this call: only a read-back has to wait
+    if (nf > 0 && (J_out || r0_out)) HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipGetLastError());
     return SADVIO_OK;
 }
@@ -2602,7 +2638,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         lds_build = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)BUILD_WAVES * strip_doubles + nt * (nt + 1) / 2 + 3 * nt +
                                                                0) + 16;
     }
-    if (getenv("SADVIO_DEBUG")) fprintf(stderr, "[sadvio dbg] lds_build %zu B, Rp %d, strip_doubles %d, max_tile_kf %d, max_tile_free %d, tiles %d\n", lds_build, Rp, strip_doubles, mtk, h->max_tile_free, n_tiles);
+    if (h->env.debug) fprintf(stderr, "[sadvio dbg] lds_build %zu B, Rp %d, strip_doubles %d, max_tile_kf %d, max_tile_free %d, tiles %d\n", lds_build, Rp, strip_doubles, mtk, h->max_tile_free, n_tiles);
     const size_t lds_back = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)mtk * 18) + 16;
     // k_solve<0>: tile-packed image + y / gf / hd / xs + the chol16 exchange areas
     const size_t npq = (size_t)h->max_np;
@@ -2617,7 +2653,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     // a batch of VIO windows would pay for; there the evaluation runs as kernels of its own on the same stream (k_pf_eval)
     const bool have_pf = !h->imus.empty() || h->n_sp_list > 0;
     bool with_imu = have_pf && n_tiles <= 3 * 256;
-    if (const char* e = getenv("SADVIO_PF_WG")) with_imu = have_pf && atoi(e) != 0;
+    if (h->env.pf_wg >= 0) with_imu = have_pf && h->env.pf_wg != 0;
     auto kb = with_imu ? (pix ? (rare ? k_build<0, true, true> : k_build<0, false, true>) : (rare ? k_build<1, true, true> : k_build<1, false, true>))
                        : (pix ? (rare ? k_build<0, true, false> : k_build<0, false, false>) : (rare ? k_build<1, true, false> : k_build<1, false, false>));
     auto kk = with_imu ? (pix ? (rare ? k_backsub<0, true, true> : k_backsub<0, false, true>) : (rare ? k_backsub<1, true, true> : k_backsub<1, false, true>))
@@ -2625,7 +2661,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     auto kbk = h->factor_type == SADVIO_FACTOR_PIXEL ? k_build_kept<0> : k_build_kept<1>;
     // large plain batches: the throughput kernels of lm_kernels.h (SADVIO_LM=1 / 0 forces / forbids them, for tests and A/B runs)
     bool use_lm = h->lm_ok && !rare && !h->coll_fn && h->world == 1 && h->lm_landmarks >= 65536;
-    if (const char* e = getenv("SADVIO_LM")) use_lm = h->lm_ok && !rare && !h->coll_fn && h->world == 1 && atoi(e) != 0;
+    if (h->env.lm >= 0) use_lm = h->lm_ok && !rare && !h->coll_fn && h->world == 1 && h->env.lm != 0;
     auto kbo = pix ? k_build_obs<0> : k_build_obs<1>;
     auto kps = pix ? k_lm_pass<0, false> : k_lm_pass<1, false>;
     auto kps0 = pix ? k_lm_pass<0, true> : k_lm_pass<1, true>;
@@ -2724,7 +2760,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         // k_backsub (fork / join with events; parallel branches of the captured graph)
         const int n_pf = n_imu_all + h->n_sp_list;
         const int n_lo = h->n_lobs_tot;
-        const bool fork = n_lo > 0 && h->side && !h->cfg.profile_kernels && !h->coll_fn && !getenv("SADVIO_NO_FORK");
+        const bool fork = n_lo > 0 && h->side && !h->cfg.profile_kernels && !h->coll_fn && !h->env.no_fork;
         for (int s = 0; s < slots; s++) {
             if (fork) {
                 (void)hipEventRecord(h->ev_fork, h->stream);
@@ -2789,7 +2825,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                             // with the update trimmed to the band a step costs the same in any window: the largest window that fits
                             // amortises the per-window carry / load / store best (SADVIO_BAND_C overrides, for measurements)
                             int C = std::max(nb, (MAX_LDS_NP - bw) / nb * nb);
-                            if (const char* e = getenv("SADVIO_BAND_C")) C = std::max(nb, std::min(C, atoi(e) / nb * nb));
+                            if (h->env.band_c > 0) C = std::max(nb, std::min(C, h->env.band_c / nb * nb));
                             const int Rmax = bw + C;
                             const size_t lds = sizeof(double) * ((size_t)(Rmax + 2) * 6 + (size_t)(Rmax + 1) * (Rmax + 2) / 2 + 2 * (size_t)Rmax +
                                                                  (size_t)(Rmax / nb + 1) * nb * nb) + 64;
@@ -2798,7 +2834,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                             long long* dbg = (P.debug & 4096) && s == 3 ? h->d_dbg.p + 44 : nullptr;
                             double* lv = h->d_big_linv.p + big_linv_off[w];
                             const int Kb = (N + bw - 1) / bw;
-                            if (nb == 6 && Kb >= 22 && 2 * bw <= MAX_LDS_NP - 1 && n_win == 1 && !getenv("SADVIO_NO_BCR")) {   // below ~22 blocks the twisted solver wins (measured)
+                            if (nb == 6 && Kb >= 22 && 2 * bw <= MAX_LDS_NP - 1 && n_win == 1 && !h->env.no_bcr) {   // below ~22 blocks the twisted solver wins (measured)
                                 // very long band: block cyclic reduction over the bw x bw blocks, log2(K) levels (dense_chol.h)
                                 const size_t b = (size_t)bw, bb = b * b, K = (size_t)Kb;
                                 const size_t per = 8 * bb + b * (b + 1) / 2 + (b / 6) * 36 + 5 * b;
@@ -2858,15 +2894,15 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                             const size_t lds_s = sizeof(double) * 2 * (size_t)CH_TS * WDS;
                             (void)hipFuncSetAttribute((const void*)k_wchol_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_d);
                             (void)hipFuncSetAttribute((const void*)k_wchol_diag16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * wd16_lds_doubles() + 64));
-                            const bool wd16 = !getenv("SADVIO_WD_OLD");   // the 96 x 96 diagonal blocks on 16 x 16 MFMA tiles (chol16.h); the 6-column LDS solver for A/B runs
+                            const bool wd16 = !h->env.wd_old;   // the 96 x 96 diagonal blocks on 16 x 16 MFMA tiles (chol16.h); the 6-column LDS solver for A/B runs
                             (void)hipFuncSetAttribute((const void*)k_wchol_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
                             (void)hipFuncSetAttribute((const void*)k_wchol_syrk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
                             (void)hipFuncSetAttribute((const void*)k_wchol_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * WD * WDS));
-                            const bool wdla = wd16 && !getenv("SADVIO_WD_NOLA");   // look-ahead: the next diagonal block inside the trailing-update launch
+                            const bool wdla = wd16 && !h->env.wd_nola;   // look-ahead: the next diagonal block inside the trailing-update launch
                             const size_t lds_la = std::max(sizeof(double) * wdla_lds_doubles() + 64, lds_s);
                             (void)hipFuncSetAttribute((const void*)k_wchol_syrk_la, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_la);
                             (void)hipFuncSetAttribute((const void*)k_wchol_trsm8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
-                            const bool wdstep = wdla && !getenv("SADVIO_WD_R3");     // one launch per panel (round 4); SADVIO_WD_R3 = the trsm8 + syrk_la loop
+                            const bool wdstep = wdla && !h->env.wd_r3;     // one launch per panel (round 4); SADVIO_WD_R3 = the trsm8 + syrk_la loop
                             if (wdstep) {
                                 const int nsteps = (N + WD - 1) / WD;
                                 double* Ltw = Mw + (size_t)nsteps * WD * WD;
@@ -2911,7 +2947,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                                     hipLaunchKernelGGL(k_wchol_syrk, dim3(nt * (nt + 1) / 2 + (m + CH_THREADS - 1) / CH_THREADS), dim3(CH_THREADS), lds_s, h->stream, Sw, (long long)d.ld, yw, N, c0, info, skip);
                                 }
                             }
-                            if (wdla && !getenv("SADVIO_WD_BACK1")) {
+                            if (wdla && !h->env.wd_back1) {
                                 // back-substitution: one launch per super-step (dense_chol.h: k_wchol_backstep)
                                 (void)hipFuncSetAttribute((const void*)k_wchol_backstep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * WD * WDS));
                                 const int nsteps = (N + WD - 1) / WD;
@@ -2982,9 +3018,9 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
         memcpy(kp, &P, sizeof(DevPtrs)); kp += sizeof(DevPtrs);
         // launch-shape switches read from the environment inside enqueue() are part of the key too: a handle that already captured a
         // graph must not replay it when an A/B switch changes
-        const int env_bits = (int)with_imu + 2 * (getenv("SADVIO_NO_FORK") != nullptr) + 4 * (getenv("SADVIO_WD_NOLA") != nullptr) + 8 * (getenv("SADVIO_WD_BACK1") != nullptr) +
-                             16 * (getenv("SADVIO_WD_OLD") != nullptr) + 32 * (getenv("SADVIO_NO_BCR") != nullptr) + 128 * (getenv("SADVIO_NO_LPT") != nullptr) +
-                             256 * (getenv("SADVIO_WD_R3") != nullptr);
+        const int env_bits = (int)with_imu + 2 * (int)h->env.no_fork + 4 * (int)h->env.wd_nola + 8 * (int)h->env.wd_back1 +
+                             16 * (int)h->env.wd_old + 32 * (int)h->env.no_bcr + 128 * (int)h->env.no_lpt +
+                             256 * (int)h->env.wd_r3;
         const int ints[8] = {slots, n_tiles, n_win, mtk, strip_doubles, Rp, h->n_kf_tot, h->factor_type + 2 * (int)extras + 4 * (int)rare + 8 * (int)use_lm + 16 * env_bits};  // P (incl. decide_kernel) is part of the key
         memcpy(kp, ints, sizeof(ints)); kp += sizeof(ints);
         const size_t szs[3] = {lds_build, lds_back, lds_solve};
@@ -3007,7 +3043,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     if (coll_failed) { h->err = "solve: the all-reduce of the reduced system failed"; return SADVIO_E_RCCL; }
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->cfg.profile_kernels) collect_timers(h);
-    if (getenv("SADVIO_DEBUG") && (atoi(getenv("SADVIO_DEBUG")) & 4096)) {
+    if ((h->env.debug & 4096)) {
         long long ts[128];
         if (hipMemcpy(ts, h->d_dbg.p, sizeof(ts), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[sadvio dbg] phase dt (us):");

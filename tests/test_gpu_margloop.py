@@ -343,7 +343,7 @@ def test_marginalize_and_sparsify_refused_on_a_sharded_window(backend_cls):
 
 
 class _Env:
-    """Set / unset environment switches of the library for the duration of a block (they are read with getenv at call time)."""
+    """Set / unset environment switches of the library for the duration of a block (the library reads them when a handle is created: the Backend is made inside the block)."""
     def __init__(self, **kv):
         self.kv = kv
     def __enter__(self):

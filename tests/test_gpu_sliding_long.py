@@ -172,4 +172,6 @@ def test_25_key_frame_steps(backend_cls, oracle_lib, vio, sparsif):
     assert sum(r["rank_dev"] != r["rank_ora"] for r in log) <= 2
     assert stats["fell_back"] <= 2 and stats["unpivoted"] >= len(log) - 3, stats
     assert log[-1]["drift"] <= 1e-5
-    assert np.abs(sides["dev"]["p"] - sides["ora"]["p"]).max() <= 1e-4
+    # landmarks: relative for the runaway ones (near-zero parallax: the optimisation itself sends them kilometres away on both sides)
+    mag = np.maximum(1.0, np.abs(sides["ora"]["p"]).max(axis=1))
+    assert (np.abs(sides["dev"]["p"] - sides["ora"]["p"]).max(axis=1) / mag).max() <= 1e-4
