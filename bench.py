@@ -39,10 +39,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measur
 GN_ITERS = 10
 # committed rocprofv3 PMC summaries of this same command (scripts/prof_bench.sh / prof_batched.sh), named explicitly: the
 # newest round's files, not whatever sorts last
-PROFILE_SUMMARY = "profiles/r04_summary.json"
-PROFILE_SUMMARY_BATCHED = "profiles/r04_batched64_summary.json"
-PROFILE_FALLBACK = {"profiles/r04_summary.json": "profiles/r03_summary.json",
-                    "profiles/r04_batched64_summary.json": "profiles/r03_batched64_summary.json"}
+PROFILE_SUMMARY = "profiles/r05_summary.json"
+PROFILE_SUMMARY_BATCHED = "profiles/r05_batched64_summary.json"
+PROFILE_FALLBACK = {"profiles/r05_summary.json": "profiles/r04_summary.json",
+                    "profiles/r05_batched64_summary.json": None}   # (the round-4 batched profile is of other kernels: k_elim / k_diag / k_backsub_lm)
 
 
 def profile_summary(rel):
@@ -309,11 +309,15 @@ def main():
             try:
                 bprof, prof = profile_summary(PROFILE_SUMMARY_BATCHED)
                 kern = bprof["kernels"]
-                per_step = sum(kern[k]["hbm_traffic_bytes_per_launch"] for k in ("k_elim", "k_diag", "k_build_obs", "k_solve", "k_backsub_lm") if k in kern)
+                # one launch of each per LM step; the opening pass (k_lm_pass_init) once per solve
+                per_step = sum(kern[k]["hbm_traffic_bytes_per_launch"] for k in ("k_build_obs", "k_solve", "k_lm_pass", "k_decide") if k in kern)
+                per_step += kern.get("k_lm_pass_init", {}).get("hbm_traffic_bytes_per_launch", 0.0) / GN_ITERS
                 if args.batch == 64 and per_step > 0:
                     step_s = 1e-3 * batched["ms_per_solve_batch"] / GN_ITERS
                     batched["hbm_traffic"] = {"bytes_per_lm_step": int(per_step), "GBps": round(per_step / step_s / 1e9, 1),
                                               "frac_of_hbm_peak": round(per_step / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                                              "traffic_over_algorithmic": round(per_step / (64 * per_iter_bytes), 3),
+                                              "kernels_us_rocprof": {k: round(v["avg_us"], 1) for k, v in kern.items() if "avg_us" in v},
                                               "source": prof}
             except Exception:
                 pass

@@ -14,7 +14,9 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("k_build_obs", "k_backsub_lm", "k_elim", "k_diag", "k_build", "k_solve", "k_backsub", "k_init_tables", "k_reset", "k_final", "k_decide", "k_linearize_probe"):
+    if "k_lm_pass" in name:   # the opening pass of a solve (INIT = true: one linearisation) and the per-step pass are different kernels
+        return "k_lm_pass_init" if ", true>" in name.split("(")[0] else "k_lm_pass"
+    for k in ("k_build_obs", "k_build", "k_solve", "k_backsub", "k_init_tables", "k_reset", "k_final", "k_decide", "k_linearize_probe"):
         if k in name:
             return k
     return None
