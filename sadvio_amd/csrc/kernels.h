@@ -1481,7 +1481,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             y[tid] = c_y; gf[tid] = c_gf; hd[tid] = c_hd;
             gredg[tid] = 0.0; gfullg[tid] = 0.0; hdg[tid] = 0.0;
         }
-        // (the accumulator in HBM is re-zeroed by the tiles of k_backsub / k_backsub_lm: zero_s_slice)
+        // (the accumulator in HBM is re-zeroed by the tiles of k_backsub / k_lm_pass: zero_s_slice)
         if (kf_pre) {
             double* c = kfc + tid * 20;
             c[0] = (double)kf_fi;

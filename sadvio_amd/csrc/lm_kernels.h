@@ -7,9 +7,10 @@
 // VALU busy 46 %, 2 waves / SIMD): 5 of 8 lanes carry an observation, the 3 x 3 elimination is repeated by every lane of
 // a group and the block sums travel through DPP. Here the same arithmetic is laid out for throughput, and (round 5) in THREE
 // passes over the observation list per LM step — the algorithmic count of SURVEY.md 8d — instead of five:
-//   k_build_obs   pass 1. A prologue (one lane per landmark) turns the landmark's H_ll, g_l record into the damped inverse, its
-//                 Cholesky factor L (M^-1 = L L^T) and w = L^T g_l; then one lane per OBSERVATION, flat (no padding): with
-//                 W = Jl L the landmark's Schur term is E M^-1 E^T = Z Z^T, Z = sum_a Jp_a^T W_a, so ONE strip
+//   k_build_obs   pass 1, one lane per OBSERVATION, flat (no padding). Every lane forms its landmark's damping from the H_ll, g_l record
+//                 k_lm_pass left: M = H_ll + D = L L^T, L^-1, w = L^-1 g_l (Cholesky form: the block step of a landmark-first
+//                 Cholesky of the un-reduced system); with W = Jl L^-T the landmark's Schur term is E M^-1 E^T = Z Z^T,
+//                 Z = sum_a Jp_a^T W_a, so ONE strip
 //                 Z[row][3 * landmark + c] per wave feeds both MFMA operands (v_mfma_f64_16x16x4_f64, K = the landmarks of a
 //                 chunk); a spare strip row with w makes the same pass return Z w = E M^-1 g_l, the landmark part of the reduced
 //                 gradient; the key-frame blocks sum Jp^T Jp, sum Jp^T r come from the tile's record; tile flush as in k_build
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(BUILD_THREADS, 3) void k_build_obs(DevPtrs P, int s
     const int lr = ln & 15, lk = ln >> 4;
     const int nt16 = (Nt + 15) >> 4;
     const int rows_used = 16 * nt16;          // the strip rows this tile touches; Nt <= rows_used - 2
-    const int w_row = rows_used - 1;          // spare row: w = L^T g_l
+    const int w_row = rows_used - 1;          // spare row: w = L^-1 g_l
     // level 1 = the observation's fields, level 2 = its landmark's position and H_ll | g_l | Jacobi scale record (lm_hg, left by
     // k_lm_pass). Both levels of chunk i + 1 are requested while chunk i is computed: a global load is ~2 us on a busy chip
     // (in-kernel stamps: 4 - 5 of the 8.8 us a chunk took were the two dependent levels), three waves per SIMD do not hide that.

@@ -1,4 +1,4 @@
-"""The throughput kernels of sadvio_amd/csrc/lm_kernels.h (k_elim / k_diag / k_build_obs / k_backsub_lm: the path large plain
+"""The throughput kernels of sadvio_amd/csrc/lm_kernels.h (k_build_obs / k_lm_pass: the three-pass path large plain
 batches take by themselves) forced onto small windows with SADVIO_LM=1: same LM trace as the oracle, key-frame and landmark
 deltas within 1e-6, and the same answer as the latency kernels of kernels.h (SADVIO_LM=0)."""
 import os
@@ -65,7 +65,7 @@ def test_lm_kernels_are_the_ones_that_ran(backend_cls, lm_env):
     assert {"k_lm_pass0", "k_build_obs", "k_lm_pass"} <= names and "k_build" not in names
     lm_env("0")
     _, names = solve(backend_cls, [w], capi.reference_options(), profile=True)
-    assert "k_build" in names and "k_elim" not in names
+    assert "k_build" in names and "k_lm_pass" not in names
 
 
 def test_robust_loss_keeps_the_latency_kernels(backend_cls, oracle_lib, lm_env):
@@ -74,7 +74,7 @@ def test_robust_loss_keeps_the_latency_kernels(backend_cls, oracle_lib, lm_env):
     opts = capi.reference_options(); opts.huber_a = 1.0
     lm_env("1")
     (res,), names = solve(backend_cls, [w], opts, profile=True)
-    assert "k_build" in names and "k_elim" not in names
+    assert "k_build" in names and "k_lm_pass" not in names
     ref = oracle_lib.solve(w, opts)
     assert np.abs(res[1]["pose"] - ref["pose"]).max() <= TOL
 
