@@ -412,9 +412,13 @@ int sadvio_ba_marginalize_relative(sadvio_ba_handle *h, int32_t w, int32_t kf_a,
  * The landmarks of a window (with all their observations) are partitioned over `world` processes, one GPU each;
  * key-frames, cameras, pose priors and IMU factors are replicated. A marginalisation prior rides a sharded window in its
  * SPARSIFIED form (sadvio_ba_sparsify): the IMUPriordx factor is replicated (every rank passes it), each
- * PoseToLandmarkFactor goes to the rank that owns its landmark, with the landmark index of that rank's window; factors that
- * hold landmarks in the reduced system (Landmark3DPrior, landmark chains), a dense prior, line landmarks and
- * marginalize_relative are refused on a sharded window. Every rank calls set_windows with ITS landmarks, then solve(); per LM step the library all-reduces [S | g | diag | per-rank cost partials] once and the
+ * PoseToLandmarkFactor goes to the rank that owns its landmark, with the landmark index of that rank's window — or as the DENSE
+ * prior (sadvio_ba_set_dense_prior with host J / r0; round 5): every rank passes the whole prior and carries ALL of its kept landmarks
+ * as variables of its window, with their observations on rank 0 only (the others list them without observations;
+ * sadvio_amd/sharding.py builds such shards); rank 0 adds J^T J / J^T r to the all-reduced system, every rank evaluates the prior's
+ * cost from row-block partials summed in index order (same bits on every rank). Factors that hold landmarks in the reduced system
+ * without a dense prior (Landmark3DPrior, landmark chains), the handle-resident prior (SADVIO_PRIOR_RESIDENT: marginalize is not
+ * available on a sharded window), line landmarks and marginalize_relative are refused on a sharded window. Every rank calls set_windows with ITS landmarks, then solve(); per LM step the library all-reduces [S | g | diag | per-rank cost partials] once and the
  * step's candidate-cost partials once; every rank then solves the identical reduced system redundantly
  * (no broadcast) and back-substitutes its own landmarks. Pose deltas and summaries are identical on all ranks.
  *

@@ -540,7 +540,7 @@ int layout_reduced(sadvio_ba_handle* h) {
             dp_ints.insert(dp_ints.end(), col.begin(), col.end());
             d.dp_off = dp_total;
             preps.push_back({d.dp_off, nf, n, w});
-            dp_total += (long long)nf * n + (long long)n * nf + (long long)n * n + nf + n + nf + 1;   // J, Jt, H (device-filled), r0, dx, r scratch, cost slot
+            dp_total += (long long)nf * n + (long long)n * nf + (long long)n * n + nf + n + nf + 2 + 3LL * ((nf + 3) / 4);   // J, Jt, H (device-filled), r0, dx, r scratch, cost slot, -, row-block partial sums (sharded windows)
             dp_total += dp_total & 1;
         }
         // landmarks touched by sparse prior factors stay in the reduced system as well
@@ -1496,7 +1496,9 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t w, int32_t n_full, in
     if (!h->uploaded) { h->err = "set_dense_prior before set_windows"; return SADVIO_E_STATE; }
     if (w < 0 || w >= (int)h->wins.size() || (n_full < 0 && n_full != SADVIO_PRIOR_RESIDENT) || (n < 0 && n_full != SADVIO_PRIOR_RESIDENT) || n_keep < 0) { h->err = "set_dense_prior: bad argument"; return SADVIO_E_INVALID_ARG; }
     HIP_TRY(hipSetDevice(h->device));
-    if (h->world > 1 && n_full > 0) { h->err = "set_dense_prior: not supported on a window sharded over several GPUs"; return SADVIO_E_INVALID_ARG; }
+    // a window sharded over several GPUs carries a dense prior too (round 5): every rank holds the prior and its variables — the kept
+    // frame is replicated anyway, the kept landmarks are in every rank's window (with their observations on rank 0 only:
+    // sadvio_amd/sharding.py) — rank 0 adds J^T J / J^T r to the all-reduced system, every rank evaluates the cost with the same bits
     const WinDev& d = h->wins[w].d;
     DensePriorHost D;
     const bool resident = n_full == SADVIO_PRIOR_RESIDENT;
@@ -2646,7 +2648,10 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     // robust loss or prior-kept landmarks in the batch: the kernels carrying those (rare) paths
     bool any_pseudo = false;
     for (const auto& v : h->sp_elim) for (char e : v) any_pseudo |= e != 0;
-    const bool rare = o.huber_a > 0.0 || h->n_kept > 0 || any_pseudo || h->gemm_run4;
+    // (kept landmarks: by their reduced columns, not by their observations — on a sharded window the ranks other than 0 hold them without any)
+    bool any_kept_lmk = false;
+    for (int w = 0; w < n_win; w++) any_kept_lmk |= h->wins[w].d.n_red > 0;
+    const bool rare = o.huber_a > 0.0 || h->n_kept > 0 || any_kept_lmk || any_pseudo || h->gemm_run4;
     const bool pix = h->factor_type == SADVIO_FACTOR_PIXEL;
     // IMU factor pairs and listed sparse-prior factors ride k_build (linearisation) and k_backsub (candidate cost) as extra workgroups
     // when the submission is a window or two: the inlined linearisation leaves those variants of k_build one workgroup per CU, which

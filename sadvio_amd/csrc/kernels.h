@@ -1659,8 +1659,15 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     // by the wide kernels k_prior_r / k_prior_gh before this kernel; only its cost is picked up here
     if (EXTRAS && W.dp_n_full > 0 && tid == 0) {
         double* pc = P.dp_data + W.dp_off + 2 * (size_t)W.dp_n_full * W.dp_n + (size_t)W.dp_n * W.dp_n + W.dp_n_full + W.dp_n + W.dp_n_full;
-        cost_part += pc[0];
-        pc[0] = 0.0;
+        if (P.world > 1) {   // the row blocks' partial sums of k_prior_r, in index order
+            const double* pp = pc + 2;   // (dp_ptr(P, W, 7), defined below)
+            double c = 0.0;
+            for (int b = 0; b < (W.dp_n_full + 3) / 4; b++) c += pp[b];
+            cost_part += c;
+        } else {
+            cost_part += pc[0];
+            pc[0] = 0.0;
+        }
     }
     // window totals of the linearisation: tiles' k_build partials + the pose-only factors evaluated here
     double gm = early_gm;
@@ -2047,7 +2054,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
             if (active) {
                 sn += d0 * d0 + d1 * d1 + d2 * d2;
                 cn += c0 * c0 + c1 * c1 + c2 * c2;
-            } else if (RARE && lcode == 2) cn += c0 * c0 + c1 * c1 + c2 * c2;
+            } else if (RARE && lcode == 2 && (P.world == 1 || P.rank == 0)) cn += c0 * c0 + c1 * c1 + c2 * c2;   // (sharded: every rank carries the kept landmarks, rank 0 counts them)
         }
         if (L.valid && L.counted) {
             // model cost change of this residual block: -(J d)^T (r + J d / 2)
@@ -2096,7 +2103,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
 //   k_prior_gh  g = J^T r into gred / gfull, diag(J^T J) into hdiag (one wave per column); J^T J into S (one thread
 //               per element, plain read-modify-write: nothing else touches S between k_build and k_solve)
 //   k_prior_m   after the step: m = J delta (one wave per row) -> model cost change / candidate cost of the slot
-// dp_data layout per window: J | J^T | J^T J | r0 | dx | r | cost(1).
+// dp_data layout per window: J | J^T | J^T J | r0 | dx | r | cost(1) | - | per-row-block partial sums: cost | mcc | candidate cost (3 x ceil(nf / 4): sharded windows).
 constexpr int DP_LDS_N = 2048;   // prior variables whose gathered deltas are staged in LDS by k_prior_r / k_prior_m (16 KB); larger priors gather per row
 __device__ __forceinline__ double* dp_ptr(const DevPtrs& P, const WinDev& W, int which) {
     const size_t nf = W.dp_n_full, n = W.dp_n;
@@ -2108,7 +2115,8 @@ __device__ __forceinline__ double* dp_ptr(const DevPtrs& P, const WinDev& W, int
         case 3: return D + 2 * nf * n + n * n;             // r0
         case 4: return D + 2 * nf * n + n * n + nf;        // dx
         case 5: return D + 2 * nf * n + n * n + nf + n;    // r
-        default: return D + 2 * nf * n + n * n + 2 * nf + n;  // cost
+        case 6: return D + 2 * nf * n + n * n + 2 * nf + n;  // cost
+        default: return D + 2 * nf * n + n * n + 2 * nf + n + 2;  // partial sums of a sharded window: [3][ceil(nf / 4)]
     }
 }
 
@@ -2161,13 +2169,20 @@ __global__ __launch_bounds__(256) void k_prior_r(DevPtrs P, int slot) {
     }
     if (ln == 0) s_c[wv] = c;
     __syncthreads();
-    if (threadIdx.x == 0) atomic_add_f64(dp_ptr(P, W, 6), s_c[0] + s_c[1] + s_c[2] + s_c[3]);
+    if (threadIdx.x == 0) {
+        // a window sharded over several GPUs: every rank evaluates the prior (its variables - the kept frame and the kept landmarks - are
+        // replicated) and must get the SAME BITS for the cost, or the ranks' LM decisions drift apart: per-block partials, summed in
+        // index order by k_solve, instead of atomic adds in scheduling order
+        if (P.world > 1) dp_ptr(P, W, 7)[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        else atomic_add_f64(dp_ptr(P, W, 6), s_c[0] + s_c[1] + s_c[2] + s_c[3]);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_prior_gh(DevPtrs P, int slot, int col_blocks) {
     const int w = blockIdx.y;
     const WinDev W = P.win[w];
     if (W.dp_n_full == 0) return;
+    if (P.world > 1 && P.rank != 0) return;   // sharded window: J^T J and J^T r enter the all-reduced system once
     if (P.states[(long long)w * P.state_stride + slot].done) return;
     const int n = W.dp_n, nf = W.dp_n_full;
     const int* col = P.dp_ints + W.dp_int_off + 2 * n;
@@ -2243,8 +2258,15 @@ __global__ __launch_bounds__(256) void k_prior_m(DevPtrs P, int slot) {
     if (ln == 0) { s_m[wv] = mc; s_c[wv] = cc; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomic_add_f64(&acc->mcc, s_m[0] + s_m[1] + s_m[2] + s_m[3]);
-        atomic_add_f64(&acc->cand_cost, s_c[0] + s_c[1] + s_c[2] + s_c[3]);
+        if (P.world > 1) {   // summed in index order by k_rank_partials (see k_prior_r)
+            double* pp = dp_ptr(P, W, 7);
+            const int nb = (nf + 3) / 4;
+            pp[nb + blockIdx.x] = s_m[0] + s_m[1] + s_m[2] + s_m[3];
+            pp[2 * nb + blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        } else {
+            atomic_add_f64(&acc->mcc, s_m[0] + s_m[1] + s_m[2] + s_m[3]);
+            atomic_add_f64(&acc->cand_cost, s_c[0] + s_c[1] + s_c[2] + s_c[3]);
+        }
     }
 }
 
@@ -2334,6 +2356,13 @@ __global__ void k_rank_partials(DevPtrs P, int slot, int which) {
             }
             for (int q = W.spl_begin; q < W.spl_end; q++) cc += sparse_cand_cost_slot(P, cb, P.sp_list[q]);
             P.acc[so].cand_cost += cc;
+            if (W.dp_n_full > 0 && !P.acc[so].chol_fail) {   // the dense prior's model cost change / candidate cost (k_prior_m), row blocks in index order
+                const double* pp = dp_ptr(P, W, 7);
+                const int nb = (W.dp_n_full + 3) / 4;
+                double m = 0.0, c2 = 0.0;
+                for (int b = 0; b < nb; b++) { m += pp[nb + b]; c2 += pp[2 * nb + b]; }
+                P.acc[so].mcc += m; P.acc[so].cand_cost += c2;
+            }
         }
     }
 }

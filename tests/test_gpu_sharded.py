@@ -201,3 +201,54 @@ def test_landmark_holding_factors_refused_on_a_sharded_window(backend_cls):
     with pytest.raises(capi.SadvioError):
         be.set_windows([sh])
     be.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_vio_window_with_the_dense_prior(backend_cls, oracle_lib, world):
+    """Round 5: the dense MarginalizationFactor on a window that spans devices. Every rank carries the prior and its
+    kept landmarks (observations on rank 0 only, sharding.py), rank 0 adds J^T J / J^T r to the all-reduced system, every rank evaluates
+    the prior's cost from row-block partials summed in index order — the ranks must leave every step with the same bits."""
+    from test_gpu_prior import random_prior
+    from vio_helpers import make_vio_window
+    w = make_vio_window(n_kf=6, n_lmk=900, seed=173)
+    w.dense_prior = random_prior(w, 60, w.n_kf - 2, np.random.default_rng(61), rank_deficit=2)      # N_p = 75 + 180: a dense system out of LDS
+    opts = capi.reference_options()
+    coll = HostAllReduce(world)
+    out, shards = [None] * world, [sharding.shard_window(w, r, world) for r in range(world)]
+
+    def run(rank):
+        be = backend_cls(device=0)
+        try:
+            be.set_collective(rank, world, coll.fn(rank))
+            be.set_windows([shards[rank]])
+            s = be.solve(opts)[0]
+            out[rank] = (s, be.get_deltas(0))
+        except Exception as e:
+            out[rank] = e
+            coll.barrier.abort()
+        finally:
+            be.close()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    for o in out:
+        if isinstance(o, Exception):
+            raise o
+    ref = oracle_lib.solve(w, opts, dense_prior=w.dense_prior)
+    rs = ref["summary"]
+    assert rs.num_successful_steps > 0
+    for s, d in out:
+        assert (s.iterations, s.termination, s.num_successful_steps) == (rs.iterations, rs.termination, rs.num_successful_steps)
+        assert np.isclose(s.final_cost, rs.final_cost, rtol=1e-9)
+        for k in ("pose", "dv", "dba", "dbg"):
+            assert np.abs(d[k] - ref[k]).max() <= POSE_TOL, k
+    for r in range(1, world):
+        for k in ("pose", "dv", "dba", "dbg"):
+            assert np.array_equal(out[r][1][k], out[0][1][k]), k                  # same bits on every rank
+        n_own = shards[r].n_own
+        assert np.array_equal(out[r][1]["lmk"][n_own:], out[0][1]["lmk"][shards[0].n_own:])   # the kept landmarks too
+    lmk = sharding.gather_landmarks(w, shards, [o[1]["lmk"] for o in out])
+    assert np.abs(lmk - ref["lmk"]).max() <= LMK_TOL
