@@ -146,3 +146,46 @@ def test_gloo_world2_sharded_first_step_equals_unsharded(oracle_lib):
         assert np.array_equal(slots[:, 1], np.arange(1, world + 1))               # SUM over disjoint slots == gather
     assert np.array_equal(res[0][1], res[1][1])                                   # bit-identical on both ranks
     assert np.allclose(np.concatenate([r[2] for r in res]), dl.ravel(), rtol=1e-7, atol=1e-10)
+
+
+def test_shards_of_a_window_with_a_dense_prior():
+    """Dense prior on a sharded window: every kept landmark is on every rank (observations on rank 0 only), every free landmark on
+    exactly one rank with all its observations; gather_landmarks restores the caller's array."""
+    import numpy as np
+    from sadvio_amd import sharding, synthetic
+    w = synthetic.make_window(n_kf=6, n_lmk=500, seed=9)
+    rng = np.random.default_rng(3)
+    li = np.sort(rng.permutation(w.n_lmk)[:41]).astype(np.int32)
+    lc = np.full(41, -1, dtype=np.int32)
+    col = 0
+    for i in range(41):
+        if i == 1:
+            continue                                  # a skipped landmark (lmk_col = -1) is an ordinary free one
+        lc[i] = col; col += 3
+    w.dense_prior = {"J": np.zeros((col, col)), "r0": np.zeros(col), "kf_keep": -1, "kf_col": 0, "lmk_index": li, "lmk_col": lc}
+    kept = [int(l) for l, c in zip(li, lc) if c >= 0]
+    for world in (2, 3, 5):
+        shards = [sharding.shard_window(w, r, world) for r in range(world)]
+        seen = np.zeros(w.n_lmk, dtype=int)
+        n_obs = 0
+        for r, s in enumerate(shards):
+            assert s.n_lmk == s.n_own + len(kept)
+            assert list(s.kept_src[s.n_own:]) == kept
+            seen[s.kept_src[:s.n_own]] += 1
+            n_obs += s.n_obs
+            cnt = np.diff(s.lmk_obs_ptr)
+            assert (cnt[s.n_own:] > 0).all() if r == 0 else (cnt[s.n_own:] == 0).all()
+            # the prior's landmark list points at the shard's copies, in the prior's order
+            for l, c, ls in zip(li, lc, s.dense_prior["lmk_index"]):
+                if c >= 0:
+                    assert s.kept_src[ls] == l and np.array_equal(s.lmk_p[ls], w.lmk_p[l])
+            for j, l in enumerate(s.kept_src[:s.n_own]):
+                a, b = s.lmk_obs_ptr[j], s.lmk_obs_ptr[j + 1]
+                assert np.array_equal(s.obs_meas[a:b], w.obs_meas[w.lmk_obs_ptr[l]:w.lmk_obs_ptr[l + 1]])
+        free = np.ones(w.n_lmk, dtype=bool); free[kept] = False
+        assert (seen[free] == 1).all() and (seen[~free] == 0).all() and n_obs == w.n_obs
+        vals = [np.tile(np.arange(s.n_lmk)[:, None] + 1000.0 * r, (1, 3)) for r, s in enumerate(shards)]
+        out = sharding.gather_landmarks(w, shards, vals)
+        for r, s in enumerate(shards):
+            assert np.array_equal(out[s.kept_src[:s.n_own], 0], vals[r][:s.n_own, 0])
+        assert np.array_equal(out[kept, 0], vals[0][shards[0].n_own:, 0])
