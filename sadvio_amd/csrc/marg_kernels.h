@@ -1146,36 +1146,64 @@ __device__ __forceinline__ void marg_accumulate(double* A, double* b, int N, con
     }
 }
 
-// reprojection factors of the kept / marginalised landmarks seen from frame0 at zero deltas (…Analytic.cpp:510-572)
+// reprojection factors of the kept / marginalised landmarks seen from frame0 at zero deltas (…Analytic.cpp:510-572). One thread per
+// observation. Every observation adds to the SAME 6 x 6 block and 6 gradient entries of frame0: as global atomics that were ~700 threads
+// on 42 addresses (98 us, 2.0 M busy cycles for 93 k VALU instructions); those 27 + 6 sums are reduced over the wave first and lane 0 adds
+// them once (both triangles). The landmark blocks go to distinct addresses (two cameras of a landmark share theirs).
 template <int FACTOR>
-__global__ void k_marg_obs(DevPtrs P, const int* items /*[n][2]: device obs index, first column of the landmark*/, int n_items,
-                           double* A, double* b, int N) {
+__global__ __launch_bounds__(128) void k_marg_obs(DevPtrs P, const int* items /*[n][2]: device obs index, first column of the landmark*/, int n_items,
+                                                  double* A, double* b, int N) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_items) return;
-    const int o = items[2 * e], lc = items[2 * e + 1];
-    const int kf = P.obs_kf[o], cam = P.obs_cam[o];
-    double d6[6] = {0, 0, 0, 0, 0, 0}, tab[POSE_TAB];
-    pose_table_entry(P.kf_T0 + 12 * (long long)kf, d6, tab);
-    // landmark index from the item list is implicit in the column; position comes with the item's third slot
-    const int gl = items[2 * n_items + e];
-    const double pw[3] = {P.lmk_p[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1], P.lmk_p[3 * (long long)gl + 2]};
-    double r[2], Jp[12], Jl[6], J[18];
-    if (FACTOR == 0) {
-        const double* m = P.obs_meas + 2 * (long long)o;
-        pixel_factor<true>(tab, P.cam_K + 4 * (long long)cam, P.cam_T + 12 * (long long)cam, pw, m[0], m[1], P.cam_isig[cam], r, Jp, Jl);
-    } else {
-        const double* m = P.obs_meas + 3 * (long long)o;
-        double bb[3] = {m[0], m[1], m[2]};
-        angular_factor<true>(tab, P.cam_T + 12 * (long long)cam, pw, bb, P.cam_isig[cam], r, Jp, Jl);
+    const bool have = e < n_items;
+    double r[2] = {0.0, 0.0}, Jp[12], Jl[6];
+#pragma unroll
+    for (int i = 0; i < 12; i++) Jp[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) Jl[i] = 0.0;
+    int lc = 0;
+    if (have) {
+        const int o = items[2 * e];
+        lc = items[2 * e + 1];
+        const int kf = P.obs_kf[o], cam = P.obs_cam[o];
+        double d6[6] = {0, 0, 0, 0, 0, 0}, tab[POSE_TAB];
+        pose_table_entry(P.kf_T0 + 12 * (long long)kf, d6, tab);
+        const int gl = items[2 * n_items + e];    // the landmark of the item (third slot of the list)
+        const double pw[3] = {P.lmk_p[3 * (long long)gl], P.lmk_p[3 * (long long)gl + 1], P.lmk_p[3 * (long long)gl + 2]};
+        if (FACTOR == 0) {
+            const double* m = P.obs_meas + 2 * (long long)o;
+            pixel_factor<true>(tab, P.cam_K + 4 * (long long)cam, P.cam_T + 12 * (long long)cam, pw, m[0], m[1], P.cam_isig[cam], r, Jp, Jl);
+        } else {
+            const double* m = P.obs_meas + 3 * (long long)o;
+            double bb[3] = {m[0], m[1], m[2]};
+            angular_factor<true>(tab, P.cam_T + 12 * (long long)cam, pw, bb, P.cam_isig[cam], r, Jp, Jl);
+        }
     }
-    int col[9];
-    for (int q = 0; q < 2; q++) {
-        for (int a = 0; a < 6; a++) J[q * 9 + a] = Jp[q * 6 + a];
-        for (int a = 0; a < 3; a++) J[q * 9 + 6 + a] = Jl[q * 3 + a];
+    // frame0's block: wave sums, one add per entry and wave
+    const int ln = threadIdx.x & 63;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int c = 0; c <= a; c++) {
+            const double h = wave_sum(Jp[a] * Jp[c] + Jp[6 + a] * Jp[6 + c]);
+            if (ln == 0 && h != 0.0) { atomic_add_f64(&A[(size_t)a * N + c], h); if (c != a) atomic_add_f64(&A[(size_t)c * N + a], h); }
+        }
+        const double g = wave_sum(Jp[a] * r[0] + Jp[6 + a] * r[1]);
+        if (ln == 0 && g != 0.0) atomic_add_f64(&b[a], g);
     }
-    for (int a = 0; a < 6; a++) col[a] = a;
-    for (int a = 0; a < 3; a++) col[6 + a] = lc + a;
-    marg_accumulate(A, b, N, J, r, 2, 9, col);
+    if (!have) return;
+    // the landmark's rows / columns
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        atomic_add_f64(&b[lc + a], Jl[a] * r[0] + Jl[3 + a] * r[1]);
+#pragma unroll
+        for (int c = 0; c < 3; c++) atomic_add_f64(&A[(size_t)(lc + a) * N + lc + c], Jl[a] * Jl[c] + Jl[3 + a] * Jl[3 + c]);
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const double h = Jl[a] * Jp[c] + Jl[3 + a] * Jp[6 + c];
+            atomic_add_f64(&A[(size_t)(lc + a) * N + c], h);
+            atomic_add_f64(&A[(size_t)c * N + lc + a], h);
+        }
+    }
 }
 
 // IMUFactor + IMUBiasFactor (frame0, frame1) and the PosePriordx blocks: a handful of blocks, one thread each.
@@ -1204,16 +1232,24 @@ __device__ __forceinline__ void marg_accumulate_wave(double* A, double* b, int N
     }
 }
 __global__ __launch_bounds__(64) void k_marg_small(DevPtrs P, const MargSmall* Sp, double* A, double* b, int N) {
-    const MargSmall& S = *Sp;
+    // the request (1.6 KB: the IMU constants, the priors) comes in with one coalesced copy; the IMU Jacobian is written straight into LDS
+    // (un-whitened) and whitened by 24 lanes, as in imu_pair_eval — as one lane's private 9 x 24 arrays it lived in scratch (3.6 KB per
+    // lane) and the kernel took 73 us
+    __shared__ MargSmall S;
     const int t = threadIdx.x;
+    {
+        const unsigned long long* src = (const unsigned long long*)Sp;
+        unsigned long long* dst = (unsigned long long*)&S;
+        for (int i = t; i < (int)(sizeof(MargSmall) / 8); i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
     const double z[6] = {0, 0, 0, 0, 0, 0};
     __shared__ double sJ[9 * 24], sr[9], sJb[72], srb[6], sJp[4][36], srp[4][6];
     __shared__ int scol[24], scolb[12], scolp[4][6];
     if (t == 0 && S.has_imu) {
-        double r[9], J[9 * 24];
-        imu_factor(S.imu, P.kf_T0 + 12 * (long long)S.kf_i, P.kf_T0 + 12 * (long long)S.kf_j, P.kf_vel + 3 * (long long)S.kf_i,
-                   P.kf_vel + 3 * (long long)S.kf_j, z, z, z, z, z, z, r, J);
-        for (int i = 0; i < 9 * 24; i++) sJ[i] = J[i];
+        double r[9];
+        imu_factor_body<ImuDev, false>(S.imu, P.kf_T0 + 12 * (long long)S.kf_i, P.kf_T0 + 12 * (long long)S.kf_j, P.kf_vel + 3 * (long long)S.kf_i,
+                                       P.kf_vel + 3 * (long long)S.kf_j, z, z, z, z, z, z, r, sJ);
         for (int i = 0; i < 9; i++) sr[i] = r[i];
         for (int a = 0; a < 6; a++) { scol[a] = a; scol[6 + a] = S.kf_keep_col + a; }
         for (int a = 0; a < 3; a++) { scol[12 + a] = 6 + a; scol[15 + a] = S.kf_keep_col + 6 + a; scol[18 + a] = 9 + a; scol[21 + a] = 12 + a; }
@@ -1233,6 +1269,19 @@ __global__ __launch_bounds__(64) void k_marg_small(DevPtrs P, const MargSmall* S
         pose_prior_factor(P.kf_T0 + 12 * (long long)S.prior_kf[k], S.prior_T[k], S.prior_inf[k], z, r, J);
         for (int i = 0; i < 36; i++) sJp[k][i] = J[i];
         for (int a = 0; a < 6; a++) { srp[k][a] = r[a]; scolp[k][a] = S.prior_base[k] + a; }
+    }
+    __syncthreads();
+    if (S.has_imu && t < 24) {   // J <- W J, one column per lane (W = L^T upper triangular, residuals.hpp:151-154)
+        double u[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) u[q] = sJ[q * 24 + t];
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            double v = 0.0;
+#pragma unroll
+            for (int kk = q; kk < 9; kk++) v += S.imu.W[9 * q + kk] * u[kk];
+            sJ[q * 24 + t] = v;
+        }
     }
     __syncthreads();
     if (S.has_imu) {
