@@ -2391,6 +2391,7 @@ int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, 
         for (int a = 0; a < 15; a++) f->cidx[a] = kf_col + a;
         for (int k : kept) {
             NfrSpecC* s = push(3, 9, 1);
+            s->fin = 1;   // the kernel returns the factor's information square root (nfr_sqrt_info3), not its covariance
             for (int a = 0; a < 3; a++) { s->cidx[a] = lmk_col[k] + a; s->cidx[3 + a] = kf_col + a; s->cidx[6 + a] = kf_col + 3 + a; }
         }
     } else {
@@ -2468,7 +2469,8 @@ int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, 
             o->type = SADVIO_SPARSE_POSE_TO_LMK; o->kf = kf_keep; o->lmk0 = lmk_index[k]; o->lmk1 = -1;
             const double* p = &lp[3 * (size_t)lmk_index[k]];
             for (int a = 0; a < 3; a++) o->delta[a] = T[3 * a] * p[0] + T[3 * a + 1] * p[1] + T[3 * a + 2] * p[2] + T[9 + a];
-            if (!nfr_sqrt_info(&S[specs[i + 1].out_off], 3, true, o->sqrt_inf)) return fail();
+            const double* Wd = &S[specs[i + 1].out_off];    // taken on the device
+            for (int a = 0; a < 9; a++) { if (!std::isfinite(Wd[a])) return fail(); o->sqrt_inf[a] = Wd[a]; }
         }
     } else {
         const int no = (int)order.size();

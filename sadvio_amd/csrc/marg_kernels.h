@@ -1414,7 +1414,83 @@ __global__ __launch_bounds__(JAC_THREADS) void k_nfr_cov(const double* J, int nf
 struct NfrSpecC {
     int rows, cols, jsel, out_off;
     int cidx[16];
+    int fin, pad;   // fin = 1 (3-row factors): the kernel also takes the factor's information square root, W = (cov^-1)^1/2, in place of cov
 };
+
+// Symmetric information square root of a 3 x 3 factor covariance (marginalization.cpp:385-392: Lambda = cov^-1, its symmetric square
+// root through the eigen-decomposition, eigenvalues <= 1e-12 dropped) on one lane: the arithmetic of the host's nfr_sqrt_info
+// (Gauss-Jordan inverse with partial pivoting, cyclic Jacobi). 300 of these per key-frame were ~0.3 ms of host time in sadvio_ba_sparsify.
+// A singular covariance leaves NaNs (the host reports SADVIO_E_NOT_USABLE).
+__device__ __forceinline__ void nfr_sqrt_info3(const double* S, double* W) {
+    double M[3][6];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { M[i][j] = S[3 * i + j]; M[i][3 + j] = i == j ? 1.0 : 0.0; }
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int p = c;
+#pragma unroll
+        for (int r = 0; r < 3; r++) if (r > c && fabs(M[r][c]) > fabs(M[p][c])) p = r;
+        if (p != c) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                // (p is c + 1 or c + 2: select without dynamic indexing)
+                const double a = M[c][j];
+                const double bq = p == 1 ? M[1][j] : M[2][j];
+                M[c][j] = bq;
+                if (p == 1) M[1][j] = a; else M[2][j] = a;
+            }
+        }
+        if (M[c][c] == 0.0) ok = false;
+        const double d = 1.0 / M[c][c];
+#pragma unroll
+        for (int j = 0; j < 6; j++) M[c][j] *= d;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            if (r == c) continue;
+            const double f = M[r][c];
+#pragma unroll
+            for (int j = 0; j < 6; j++) M[r][j] -= f * M[c][j];
+        }
+    }
+    double A[3][3], V[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { A[i][j] = 0.5 * (M[i][3 + j] + M[j][3 + i]); V[i][j] = i == j ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 100; sweep++) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off <= 1e-60 || off <= 1e-32 * diag) break;
+#pragma unroll
+        for (int pq = 0; pq < 3; pq++) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;     // (0,1) (0,2) (1,2)
+            const double apq = A[p][q];
+            if (apq == 0.0) continue;
+            const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - sn * b; A[k][q] = sn * a + c * b; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - sn * b; A[q][k] = sn * a + c * b; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - sn * b; V[k][q] = sn * a + c * b; }
+        }
+    }
+    double se[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) se[k] = A[k][k] > 1e-12 ? sqrt(A[k][k]) : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double w = V[i][0] * se[0] * V[j][0] + V[i][1] * se[1] * V[j][1] + V[i][2] * se[2] * V[j][2];
+            W[3 * i + j] = ok ? w : __longlong_as_double(0x7ff8000000000000LL);
+        }
+}
 
 __global__ __launch_bounds__(JAC_THREADS) void k_nfr_cov_z(const double* __restrict__ Z, int nf, int n, const NfrSpecC* __restrict__ specs,
                                                            const double* __restrict__ jsel_tab /*[4][225]*/, double* __restrict__ S) {
@@ -1457,6 +1533,16 @@ __global__ __launch_bounds__(JAC_THREADS) void k_nfr_cov_z(const double* __restr
         }
     }
     __syncthreads();
+    if (rows == 3 && sp.fin) {
+        if (tid == 0) {
+            const double C[9] = {acc[0], acc[15], acc[30], acc[15], acc[16], acc[31], acc[30], acc[31], acc[32]};
+            double W[9];
+            nfr_sqrt_info3(C, W);
+#pragma unroll
+            for (int i = 0; i < 9; i++) S[(size_t)sp.out_off + i] = W[i];
+        }
+        return;
+    }
     for (int i = tid; i < rows * rows; i += JAC_THREADS) {
         const int a = i / rows, b = i - a * rows;
         S[(size_t)sp.out_off + i] = a >= b ? acc[a * 15 + b] : acc[b * 15 + a];
