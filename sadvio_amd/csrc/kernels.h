@@ -2514,13 +2514,19 @@ __device__ __forceinline__ void imu_pair_eval(const DevPtrs& P, int slot, int k,
     const double* xbg = P.xbg + (long long)buf * P.xv_stride;
     __shared__ double U[9 * 24];
     __shared__ double rs[9], rbs[6], s_cost;
+    __shared__ ImuMid mid;
     double* sc = P.imu_scratch + (long long)buf * P.imu_scratch_stride + (long long)k * IMU_ROW;
     if (ln == 0) {
         double dpi[6], dpj[6], r[9];
+        ImuMid mid_regs;   // COST_ONLY: nothing reads it, the stores fold away
         for (int q = 0; q < 6; q++) { dpi[q] = xp[6 * (long long)i + q]; dpj[q] = xp[6 * (long long)j + q]; }
-        imu_factor_body<ImuDev, false>(f, P.kf_T0 + 12 * (long long)i, P.kf_T0 + 12 * (long long)j, P.kf_vel + 3 * (long long)i,
-                                       P.kf_vel + 3 * (long long)j, dpi, dpj, xv + 3 * (long long)i, xv + 3 * (long long)j,
-                                       xba + 3 * (long long)i, xbg + 3 * (long long)i, r, (LIN && !all_const) ? U : nullptr);
+        imu_residual_part(f, P.kf_T0 + 12 * (long long)i, P.kf_T0 + 12 * (long long)j, P.kf_vel + 3 * (long long)i,
+                          P.kf_vel + 3 * (long long)j, dpi, dpj, xv + 3 * (long long)i, xv + 3 * (long long)j,
+                          xba + 3 * (long long)i, xbg + 3 * (long long)i, r, LIN ? mid : mid_regs);
+        if (LIN && !all_const) {
+            asm volatile("" ::: "memory");   // the Jacobian blocks read `mid` back from LDS one at a time (device_math.h: ImuMid)
+            imu_jacobian_part<ImuDev, true>(f, P.kf_T0 + 12 * (long long)i, dpi, dpj, mid, U);
+        }
         double c = 0.0;
         for (int q = 0; q < 9; q++) { if (LIN) { sc[9 * 24 + q] = r[q]; rs[q] = r[q]; } c += r[q] * r[q]; }
         double rba[3], rbg[3];
