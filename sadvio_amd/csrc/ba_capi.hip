@@ -243,7 +243,7 @@ struct EnvCfg {
     double jacobi_tol = 1e-14;
     bool marg_last_small = false, marg_eig_mm = false, marg_pivoted = false, marg_unpivoted = false, pchol_swap = false, pchol_strict = false,
          jacobi_b4 = false, jacobi_plain = false, no_lpt = false, no_fork = false, no_bcr = false, wd_old = false, wd_nola = false, wd_r3 = false,
-         wd_back1 = false;
+         wd_back1 = false, imu_items = false;
     void read() {
         auto on = [](const char* k) { return getenv(k) != nullptr; };
         auto num = [](const char* k, int unset) { const char* e = getenv(k); return e ? atoi(e) : unset; };
@@ -254,6 +254,7 @@ struct EnvCfg {
         marg_unpivoted = on("SADVIO_MARG_UNPIVOTED"); pchol_swap = on("SADVIO_PCHOL_SWAP"); pchol_strict = on("SADVIO_PCHOL_STRICT");
         jacobi_b4 = on("SADVIO_JACOBI_B4"); jacobi_plain = on("SADVIO_JACOBI_PLAIN"); no_lpt = on("SADVIO_NO_LPT"); no_fork = on("SADVIO_NO_FORK");
         no_bcr = on("SADVIO_NO_BCR"); wd_old = on("SADVIO_WD_OLD"); wd_nola = on("SADVIO_WD_NOLA"); wd_r3 = on("SADVIO_WD_R3"); wd_back1 = on("SADVIO_WD_BACK1");
+        imu_items = on("SADVIO_IMU_ITEMS");   // A/B: the IMU pairs' entries through k_solve's item loop (the pre-0.5 path) on one device too
     }
 };
 
@@ -2626,6 +2627,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     int max_win_tiles = 0;
     for (int w = 0; w < n_win; w++) max_win_tiles = std::max(max_win_tiles, h->wins[w].d.tile_end - h->wins[w].d.tile_begin);
     P.decide_kernel = max_win_tiles > 4 * BUILD_THREADS ? 1 : 0;
+    // a sharded window keeps the item loop of k_solve: every rank must leave it with the same bits (plain adds, one factor at a time)
+    P.imu_direct = (!h->coll_fn && P.world == 1 && !h->env.imu_items) ? 1 : 0;
     const int mtk = h->max_tile_kf;
     const size_t nt = 6 * (size_t)h->max_tile_free;
     int Rp = 16 * ((6 * h->max_gemm_free + 15) / 16);                          // padded rows of the Y / E strips
@@ -2646,7 +2649,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
     const size_t lds_back = tile_tables_bytes(mtk) + sizeof(double) * ((size_t)mtk * 18) + 16;
     // k_solve<0>: tile-packed image + y / gf / hd / xs + the chol16 exchange areas
     const size_t npq = (size_t)h->max_np;
-    const size_t lds_solve = sizeof(double) * ((size_t)c16_size((int)npq) + 4 * npq + 1 + C16_WORK + 16 * (size_t)c16_blocks((int)npq + 1) + SOLVE_KFC * 20) + 64;
+    const size_t lds_solve = sizeof(double) * ((size_t)c16_size((int)npq) + 4 * npq + 1 + C16_WORK + 16 * (size_t)c16_blocks((int)npq + 1) + SOLVE_KFC * SOLVE_KFC_STRIDE) + 64;
     // robust loss or prior-kept landmarks in the batch: the kernels carrying those (rare) paths
     bool any_pseudo = false;
     for (const auto& v : h->sp_elim) for (char e : v) any_pseudo |= e != 0;
@@ -2782,7 +2785,7 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
                 { ScopedTimer t(h, "k_build_obs"); hipLaunchKernelGGL(kbo, dim3(n_tiles), dim3(BUILD_THREADS), lds_bobs, h->stream, P, s, mtk, Rp); }
             } else
             { ScopedTimer t(h, "k_build"); hipLaunchKernelGGL(kb, dim3(n_tiles + (with_imu ? n_pf : 0)), dim3(BUILD_THREADS), lds_build, h->stream, P, s, mtk, strip_doubles, Rp); }
-            if (n_pf && (use_lm || !with_imu)) { ScopedTimer t(h, "k_pf_lin"); hipLaunchKernelGGL(k_pf_eval<false>, dim3(n_pf), dim3(64), 0, h->stream, P, s); }
+            if (n_pf && (use_lm || !with_imu)) { ScopedTimer t(h, "k_pf_lin"); hipLaunchKernelGGL(k_pf_eval<false>, dim3(n_pf), dim3(BUILD_THREADS), 0, h->stream, P, s); }
             if (h->n_kept) { ScopedTimer t(h, "k_build_kept"); hipLaunchKernelGGL(kbk, dim3((h->n_kept + 127) / 128), dim3(128), 0, h->stream, P, s); }
             if (dp_max_nf > 0) {
                 ScopedTimer t(h, "k_prior_r+gh");
@@ -3057,6 +3060,8 @@ int sadvio_ba_solve(sadvio_ba_handle* h, const sadvio_solve_options* opts, sadvi
             for (int i = 1; i < 16; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[0]) * 0.01);
             fprintf(stderr, "  shader clock %.3f GHz\n[sadvio dbg] k_build:", (double)(ts[21] - ts[20]) / ((ts[15] - ts[0]) * 10.0));
             for (int i = 33; i < 43; i++) fprintf(stderr, " %d:%.2f", i, (ts[i] - ts[32]) * 0.01);
+            fprintf(stderr, "\n[sadvio dbg] first IMU pair of k_build, us since its start (residual + Jacobian on lane 0 | decision | W J | entries + adds): %.2f %.2f %.2f %.2f, start %.2f us after tile 0",
+                    (ts[57] - ts[56]) * 0.01, (ts[58] - ts[56]) * 0.01, (ts[59] - ts[56]) * 0.01, (ts[60] - ts[56]) * 0.01, (ts[56] - ts[32]) * 0.01);
             fprintf(stderr, "\n[sadvio dbg] look-ahead workgroup of k_wchol_syrk_la, us since its start (loads landed, X slab in LDS | tiles updated | factored + inverted):");
             fprintf(stderr, " %.2f %.2f %.2f", (ts[91] - ts[90]) * 0.01, (ts[94] - ts[90]) * 0.01, (ts[95] - ts[90]) * 0.01);
             fprintf(stderr, " | waves after their tiles:"); for (int i = 98; i < 106; i++) fprintf(stderr, " %.2f", (ts[i] - ts[90]) * 0.01);

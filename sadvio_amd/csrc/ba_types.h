@@ -176,6 +176,7 @@ constexpr int MAX_WIN_CAM = 8;       // cameras per window staged in LDS
 constexpr int STAGE_VALS = 18;       // Jp[12] Jl[6] exchanged between the lanes of a landmark group
 constexpr int MAX_LMK_OBS = 64;      // observations per landmark (one lane each)
 constexpr int SOLVE_THREADS = 512;
+constexpr int SOLVE_KFC_STRIDE = 32; // doubles per parked key-frame: free index | x 6 | T0 12 | v, ba, bg at x 9
 constexpr int SOLVE_KFC = 32;        // k_solve<0>: key-frames / priors whose back-half inputs are parked in LDS across the factorisation
 constexpr int PRIOR_LIN = 28;        // doubles of a pose prior's linearisation record: g 6 | H lower 21 | |r|^2
 constexpr int MAX_LDS_NP = 174;     // packed lower triangle incl. rhs row + panel strip: ~150 KB

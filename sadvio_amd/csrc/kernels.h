@@ -52,6 +52,7 @@ struct DevPtrs {
     int* big_info;        // [n_win] potrf info of the windows solved out of LDS
     // a window sharded over `world` GPUs (landmark partition): per-rank partial sums, exchanged with the reduced
     // system by one all-reduce per phase; rank r writes slot r and zeroes the others (sum == gather)
+    int imu_direct;       // 1: imu_pair_eval<false> adds the IMU pairs' entries to the reduced system itself (one device); 0: k_solve's item loop
     int decide_kernel;    // 1: the LM decision of a slot is taken by k_decide (many tiles); 0: by every k_build workgroup
     int world, rank;
     double* rank_b;       // [n_win][world][4] lin_cost, fixed_cost, gmax, -      (after k_build)
@@ -98,7 +99,9 @@ struct DevPtrs {
 #ifdef SADVIO_KERNEL_TS
 #define SADVIO_TS(slot_, idx_) do { if ((P.debug & 4096) && blockIdx.x == 0 && threadIdx.x == 0 && slot == (slot_)) P.dbg_ts[idx_] = wall_clock64(); } while (0)
 #define SADVIO_TS_PTR(cond_) ((cond_) ? P.dbg_ts : nullptr)
+#define SADVIO_TS_IMU(idx_) do { if ((P.debug & 4096) && k == 0 && ln == 0 && slot == 3) P.dbg_ts[idx_] = wall_clock64(); } while (0)
 #else
+#define SADVIO_TS_IMU(idx_) do { } while (0)
 #define SADVIO_TS(slot_, idx_) do { } while (0)
 #define SADVIO_TS_PTR(cond_) nullptr
 #endif
@@ -494,7 +497,7 @@ template <int FACTOR, bool RARE, bool IMU>
 __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P, int slot, int max_tile_kf, int strip_doubles, int Rp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (IMU && (int)blockIdx.x >= P.n_tiles) {
-        if (threadIdx.x < 64) pose_factor_eval<false>(P, slot, (int)blockIdx.x - P.n_tiles, threadIdx.x);
+        pose_factor_eval<false>(P, slot, (int)blockIdx.x - P.n_tiles, threadIdx.x);
         return;
     }
     const Tile T = P.tiles[blockIdx.x];
@@ -1391,7 +1394,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     double* yv = pub + C16_WORK;                // chol16: back-substitution exchange (16 * nbt)
     // MODE 0: what the back half needs from HBM is fetched with the front half's loads and parked in LDS across the
     // factorisation: the first SOLVE_KFC key-frames (free index, x, T0)
-    double* kfc = yv + 16 * nbt;                // [SOLVE_KFC][20]
+    double* kfc = yv + 16 * nbt;                // [SOLVE_KFC][SOLVE_KFC_STRIDE]
     auto aidx = [&](int i, int j) -> long long { return BIG ? (long long)i * ld + j : (long long)c16_index(i, j); };  // i >= j
     const int cur = st.cur;
     const double* xp = P.xp + (long long)cur * P.xp_stride;
@@ -1423,7 +1426,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     // pair adds to the reduced system, with its position, in the factor's scratch row (ba_types.h). Item = (factor, entry); the
     // first eight items of every thread are fetched here, with the image
     double im_ix[8], im_v[8];
-    const int n_imu_items = (EXTRAS && !det) ? n_imu * IMU_NE : 0;
+    // (P.imu_direct: imu_pair_eval added the pairs' entries to the accumulators in HBM itself; only their costs are picked up here)
+    const int n_imu_items = (EXTRAS && !det && !P.imu_direct) ? n_imu * IMU_NE : 0;
     if (EXTRAS) {
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -1457,7 +1461,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     // candidate-pose pass (behind the factorisation): this thread's key-frame is fetched now and parked in LDS
     const bool kf_pre = MODE == 0 && tid < W.n_kf && tid < SOLVE_KFC;
     int kf_fi = -1;
-    double kf_t6[6], kf_t12[12];
+    double kf_t6[6], kf_t12[12], kf_vbb[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (kf_pre) {
         const int g = W.kf_base + tid;
         kf_fi = P.kf_fidx[g];
@@ -1465,6 +1469,13 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         for (int i = 0; i < 6; i++) kf_t6[i] = xp[6 * (long long)g + i];
 #pragma unroll
         for (int i = 0; i < 12; i++) kf_t12[i] = P.kf_T0[12 * (long long)g + i];
+        if (W.dpf == 15) {
+            const double* xs3[3] = {P.xv + (long long)cur * P.xv_stride, P.xba + (long long)cur * P.xv_stride, P.xbg + (long long)cur * P.xv_stride};
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) kf_vbb[3 * q + i] = xs3[q][3 * (long long)g + i];
+        }
     }
     // window totals of the linearisation (the tiles' k_build partials / the ranks' of a sharded window)
     if (P.world > 1) {
@@ -1483,12 +1494,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         }
         // (the accumulator in HBM is re-zeroed by the tiles of k_backsub / k_lm_pass: zero_s_slice)
         if (kf_pre) {
-            double* c = kfc + tid * 20;
+            double* c = kfc + tid * SOLVE_KFC_STRIDE;
             c[0] = (double)kf_fi;
 #pragma unroll
             for (int i = 0; i < 6; i++) c[1 + i] = kf_t6[i];
 #pragma unroll
             for (int i = 0; i < 12; i++) c[7 + i] = kf_t12[i];
+            if (W.dpf == 15) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) c[19 + i] = kf_vbb[i];
+            }
         }
     }
     __syncthreads();
@@ -1533,12 +1548,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
         }
     }
     if (EXTRAS && n_imu > 0) {
-        if (det) {
+        if (det || P.imu_direct) {
             for (int k = tid; k < n_imu; k += blockDim.x) {
                 const double* row = P.imu_scratch + (long long)cur * P.imu_scratch_stride + (long long)(W.imu_begin + k) * IMU_ROW;
                 if (row[IMU_IX + IMU_E_COST] == -2.0) fixed_part += row[IMU_H + IMU_E_COST]; else cost_part += row[IMU_H + IMU_E_COST];
             }
-            for (int k = 0; k < n_imu; k++) {
+            for (int k = 0; det && k < n_imu; k++) {
                 const double* row = P.imu_scratch + (long long)cur * P.imu_scratch_stride + (long long)(W.imu_begin + k) * IMU_ROW;
                 if (tid < IMU_E_BH) {
                     const int ix = (int)row[IMU_IX + tid];
@@ -1768,7 +1783,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     for (int k = tid; k < W.n_kf; k += blockDim.x) {
         int g = W.kf_base + k;
         const bool pre = MODE == 0 && k < SOLVE_KFC;  // parked in LDS by the front half
-        const double* kc = kfc + (pre ? k : 0) * 20;
+        const double* kc = kfc + (pre ? k : 0) * SOLVE_KFC_STRIDE;
         int fi = pre ? (int)kc[0] : P.kf_fidx[g];
         double d6[6];
         const double* T0r = pre ? kc + 7 : P.kf_T0 + 12 * (long long)g;   // LDS (parked by the front half) or HBM: a flat pointer either way
@@ -1778,7 +1793,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
 #pragma unroll
             for (int q = 0; q < 3; q++)
 #pragma unroll
-                for (int i = 0; i < 3; i++) vbb[3 * q + i] = xs3[q][3 * (long long)g + i];
+                for (int i = 0; i < 3; i++) vbb[3 * q + i] = pre ? kc[19 + 3 * q + i] : xs3[q][3 * (long long)g + i];
         }
 #pragma unroll
         for (int i = 0; i < 6; i++) {
@@ -2491,6 +2506,7 @@ __global__ void k_decide(DevPtrs P, int slot, int final) {
 template <bool COST_ONLY>
 __device__ __forceinline__ void imu_pair_eval(const DevPtrs& P, int slot, int k, int ln) {
     constexpr bool LIN = !COST_ONLY;
+    if (LIN) SADVIO_TS_IMU(56);
     // the factor's constants (1.2 KB) come in with one coalesced copy: lane 0 evaluating the factor from global memory spends its
     // time on ~200 dependent scalar loads
     __shared__ ImuDev f;
@@ -2548,7 +2564,47 @@ __device__ __forceinline__ void imu_pair_eval(const DevPtrs& P, int slot, int k,
     }
     if (COST_ONLY) return;
     wave_lds_fence();
+    SADVIO_TS_IMU(57);
     const int fi = P.kf_fidx[i], fj = P.kf_fidx[j];
+    // One device, one window per workgroup set (P.imu_direct): the pair's entries go straight into the reduced system in HBM (S, gred,
+    // gfull, hdiag: accumulators the tiles, the kept landmarks and the dense prior add into as well) instead of through k_solve's item
+    // loop - 11 pairs x 354 LDS atomics of ONE workgroup were 4 us of every VIO step. Which row is added is the LM decision of the
+    // previous slot: accepted -> the row just evaluated (the candidate's), rejected -> the row of x kept in the other buffer. The
+    // decision is re-derived here exactly as the tiles of this launch do (same bits: wave_sum_backsub_partials), or read if k_decide took it.
+    const WinDev& Wd = P.win[f.win];
+    const bool direct = P.imu_direct != 0;
+    bool fresh = direct;
+    int add_buf = buf;
+    if (direct && slot > 0) {
+        LmState nst;
+        if (P.decide_kernel) nst = P.states[so + 1];
+        else {
+            __shared__ double s4[4];
+            wave_sum_backsub_partials(P, (slot - 1) & 1, f.win, Wd.tile_begin, Wd.tile_end - Wd.tile_begin, ln, s4);
+            wave_lds_fence();
+            IterAcc a = P.acc[so];
+            a.cand_cost += s4[0]; a.mcc += s4[1]; a.step_norm2 += s4[2]; a.cand_norm2 += s4[3];
+            nst = lm_decide(st, a, P.o);
+        }
+        add_buf = nst.done ? -1 : nst.cur;
+        fresh = add_buf == buf;
+    }
+    auto emit = [&](int e, double v, int ix) {   // entry e of the pair (position ix) into the reduced system
+        if (ix < 0) return;
+        const int ca = ix >> 16, cb = ix & 0xffff;
+        if (e < IMU_E_G || (e >= IMU_E_BH && e < IMU_E_BG)) {
+            atomic_add_f64(P.S + Wd.S_off + s_index(Wd.ld, ca, cb), v);
+            if (ca == cb) atomic_add_f64(P.hdiag + Wd.red_off + ca, v);
+        } else {
+            atomic_add_f64(P.gred + Wd.red_off + ca, v);
+            atomic_add_f64(P.gfull + Wd.red_off + ca, v);
+        }
+    };
+    if (direct && !fresh && add_buf >= 0) {   // rejected step: the row of x (written by an earlier launch)
+        const double* ro = P.imu_scratch + (long long)add_buf * P.imu_scratch_stride + (long long)k * IMU_ROW;
+        for (int e = ln; e < IMU_E_COST; e += 64) emit(e, ro[IMU_H + e], (int)ro[IMU_IX + e]);
+    }
+    SADVIO_TS_IMU(58);
     // the pair's cost, the bias random walk (Jacobians -/+ s I: entries s^2, -s^2 and -/+ s r) and what k_solve's model-cost pass reads
     if (ln < 30) {
         const int e = ln < 18 ? ln : ln - 18;                 // matrix entries 0..17 = (combo, kind 0..2); gradient 0..11 = (combo, i | j)
@@ -2562,11 +2618,13 @@ __device__ __forceinline__ void imu_pair_eval(const DevPtrs& P, int slot, int k,
             else if (kind == 1) { v = s2; if (cj >= 0) ix = (cj << 16) | cj; }
             else { v = -s2; if (ci >= 0 && cj >= 0) ix = ci >= cj ? (ci << 16) | cj : (cj << 16) | ci; }
             sc[IMU_H + IMU_E_BH + e] = v; sc[IMU_IX + IMU_E_BH + e] = (double)ix;
+            if (fresh) emit(IMU_E_BH + e, v, ix);
         } else {
             const double rb = rbs[3 * gy + ax];
             if (kind == 0) { v = -sgm * rb; if (ci >= 0) ix = ci << 16; }
             else { v = sgm * rb; if (cj >= 0) ix = cj << 16; }
             sc[IMU_H + IMU_E_BG + e] = v; sc[IMU_IX + IMU_E_BG + e] = (double)ix;
+            if (fresh) emit(IMU_E_BG + e, v, ix);
         }
     } else if (ln == 30) {
         sc[IMU_H + IMU_E_COST] = s_cost; sc[IMU_IX + IMU_E_COST] = all_const ? -2.0 : -3.0;
@@ -2591,6 +2649,7 @@ __device__ __forceinline__ void imu_pair_eval(const DevPtrs& P, int slot, int k,
         }
     }
     wave_lds_fence();
+    SADVIO_TS_IMU(59);
     // H = J^T J (lower triangle, 300), g = J^T r (24) and where each entry goes in the reduced system
     for (int e = ln; e < IMU_E_BH; e += 64) {
         double v = 0.0;
@@ -2611,7 +2670,298 @@ __device__ __forceinline__ void imu_pair_eval(const DevPtrs& P, int slot, int k,
         }
         sc[IMU_H + e] = v;
         sc[IMU_IX + e] = (double)ix;
+        if (fresh) emit(e, v, ix);
     }
+    SADVIO_TS_IMU(60);
+}
+
+// The LINEARISATION of one IMU factor pair by a whole 256-thread workgroup (an extra workgroup of k_build, or of k_pf_eval<false>): the
+// same arithmetic as imu_residual_part / imu_jacobian_part (device_math.h), dealt over lane 0 of the four waves - four dependent-
+// latency-bound streams on four SIMDs instead of one (9.7 us on one lane: the pair's workgroup outlasted every tile of k_build) -
+// with the products that only need many independent dot products (W J, J^T J, J^T r) spread over all threads.
+//   phase 1  wave 0: R_i, t_i | wave 1: R_j, t_j | wave 2: the bias-corrected DeltaR, Jr(J_dR_bg dbg) | wave 3: the LM decision of the
+//            previous slot (P.imu_direct, see below), Jr(w_i), Jr(w_j), the velocity term, the bias random walk
+//   phase 2  wave 0: r_dR, Jr(r_dR)^-1 | wave 1: r_dv | wave 2: r_dp | wave 3: the Jacobian blocks that need neither
+//   phase 3  r = W e (9 lanes); the remaining Jacobian blocks, one chain of 3 x 3 products per wave
+//   phase 4  J <- W J, one entry per thread; the pair's cost
+//   phase 5  what the pair adds to the reduced system, entry by entry (the scratch row of ba_types.h), and - one device
+//            (P.imu_direct) - the adds themselves: straight into the accumulators in HBM (S, gred, gfull, hdiag: the tiles, the kept
+//            landmarks and the dense prior add into them as well) instead of through k_solve's item loop, whose 11 x 354 LDS atomics
+//            by ONE workgroup were 2.3 us of every VIO step. Which row is added is the decision of the previous slot: accepted ->
+//            the row just evaluated (the candidate's), rejected -> the row of x kept in the other buffer. The decision is re-derived
+//            exactly as the tiles of this launch do (same bits: wave_sum_backsub_partials), or read if k_decide took it.
+__device__ __forceinline__ void imu_pair_lin_wg(const DevPtrs& P, int slot, int k, int tid) {
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63, nthr = blockDim.x;
+    __shared__ ImuDev f;
+    __shared__ double U[9 * 24], UW[9 * 24];
+    __shared__ double rs[9], rbs[6], e9[9], s_cost;
+    __shared__ ImuMid mid;
+    __shared__ double s_ti[3], s_vi[3], s_DRc[9], s_Jrb[9], s_Jrw[18], s_Jr_ri[9], s4[4];
+    __shared__ int s_add;
+#ifdef SADVIO_KERNEL_TS
+    if ((P.debug & 4096) && k == 0 && tid == 0 && slot == 3) P.dbg_ts[56] = wall_clock64();
+#endif
+    {
+        const unsigned long long* src = (const unsigned long long*)(P.imus + k);
+        unsigned long long* dst = (unsigned long long*)&f;
+        for (int q = tid; q < (int)(sizeof(ImuDev) / 8); q += nthr) dst[q] = src[q];
+        for (int q = tid; q < 9 * 24; q += nthr) U[q] = 0.0;
+    }
+    __syncthreads();
+    const bool at_x = slot == 0;
+    const long long so = (long long)f.win * P.state_stride + (slot > 0 ? slot - 1 : slot);
+    const LmState st = P.states[so];
+    if (st.done) return;
+    const int i = f.kf_i, j = f.kf_j;
+    const int fi = P.kf_fidx[i], fj = P.kf_fidx[j];
+    const bool all_const = fi < 0 && fj < 0;
+    const int buf = at_x ? st.cur : 1 - st.cur;
+    const double* xp = P.xp + (long long)buf * P.xp_stride;
+    const double* xv = P.xv + (long long)buf * P.xv_stride;
+    const double* xba = P.xba + (long long)buf * P.xv_stride;
+    const double* xbg = P.xbg + (long long)buf * P.xv_stride;
+    double* sc = P.imu_scratch + (long long)buf * P.imu_scratch_stride + (long long)k * IMU_ROW;
+    const double* Ti0 = P.kf_T0 + 12 * (long long)i;
+    const double* Tj0 = P.kf_T0 + 12 * (long long)j;
+    const WinDev& Wd = P.win[f.win];
+    const bool direct = P.imu_direct != 0;
+    const double G[3] = {0.0, 0.0, -9.81};  // IMU.h:8
+    const double dt = f.dt;
+    // ---- phase 1 ----
+    if (wv == 3) {
+        int add_buf = direct ? buf : -1;       // the buffer whose row goes into the reduced system of this slot (-1: none)
+        if (direct && slot > 0) {
+            LmState nst;
+            if (P.decide_kernel) nst = P.states[so + 1];
+            else {
+                wave_sum_backsub_partials(P, (slot - 1) & 1, f.win, Wd.tile_begin, Wd.tile_end - Wd.tile_begin, ln, s4);
+                wave_lds_fence();
+                IterAcc a = P.acc[so];
+                a.cand_cost += s4[0]; a.mcc += s4[1]; a.step_norm2 += s4[2]; a.cand_norm2 += s4[3];
+                nst = lm_decide(st, a, P.o);
+            }
+            add_buf = nst.done ? -1 : nst.cur;
+        }
+        if (ln == 0) s_add = add_buf;
+    }
+    if (ln == 0) {
+        if (wv == 0) {
+            double dpi[6], dRi[9], Ri[9], ti[3];
+            for (int q = 0; q < 6; q++) dpi[q] = xp[6 * (long long)i + q];
+            so3_exp(dpi, dRi);
+            m3_mul(Ti0, dRi, Ri);
+            m3_vec(Ti0, dpi + 3, ti);
+            for (int q = 0; q < 3; q++) s_ti[q] = ti[q] + Ti0[9 + q];
+            for (int q = 0; q < 9; q++) mid.Ri[q] = Ri[q];
+        } else if (wv == 1) {
+            double dpj[6], dRj[9], Rj[9], tj[3];
+            for (int q = 0; q < 6; q++) dpj[q] = xp[6 * (long long)j + q];
+            so3_exp(dpj, dRj);
+            m3_mul(Tj0, dRj, Rj);
+            m3_vec(Tj0, dpj + 3, tj);
+            for (int q = 0; q < 3; q++) mid.tj[q] = tj[q] + Tj0[9 + q];
+            for (int q = 0; q < 9; q++) { mid.Rj[q] = Rj[q]; mid.dRj[q] = dRj[q]; }
+        } else if (wv == 2) {
+            double dbg[3], jb[3], Eb[9], DRc[9], Jrb[9];
+            for (int q = 0; q < 3; q++) dbg[q] = xbg[3 * (long long)i + q];
+            m3_vec(f.J_dR_bg, dbg, jb);
+            so3_exp(jb, Eb);
+            m3_mul(f.dR, Eb, DRc);
+            so3_right_jacobian(jb, Jrb);
+            for (int q = 0; q < 3; q++) mid.jb[q] = jb[q];
+            for (int q = 0; q < 9; q++) { s_DRc[q] = DRc[q]; s_Jrb[q] = Jrb[q]; }
+        } else {
+            double wi[3], wj[3], Jrwi[9], Jrwj[9];
+            for (int q = 0; q < 3; q++) { wi[q] = xp[6 * (long long)i + q]; wj[q] = xp[6 * (long long)j + q]; }
+            so3_right_jacobian(wi, Jrwi);
+            so3_right_jacobian(wj, Jrwj);
+            for (int q = 0; q < 9; q++) { s_Jrw[q] = Jrwi[q]; s_Jrw[9 + q] = Jrwj[q]; }
+            for (int q = 0; q < 3; q++) {
+                const double vi = P.kf_vel[3 * (long long)i + q] + xv[3 * (long long)i + q];
+                const double vj = P.kf_vel[3 * (long long)j + q] + xv[3 * (long long)j + q];
+                s_vi[q] = vi;
+                mid.a[q] = vj - vi - G[q] * dt;
+            }
+            for (int q = 0; q < 3; q++) {   // the bias random walk (IMUBiasFactor)
+                const double rba = f.sa * (P.kf_ba[3 * (long long)j + q] + xba[3 * (long long)j + q] - P.kf_ba[3 * (long long)i + q] - xba[3 * (long long)i + q]);
+                const double rbg = f.sg * (P.kf_bg[3 * (long long)j + q] + xbg[3 * (long long)j + q] - P.kf_bg[3 * (long long)i + q] - xbg[3 * (long long)i + q]);
+                sc[IMU_J + q] = rba; sc[IMU_J + 3 + q] = rbg; rbs[q] = rba; rbs[3 + q] = rbg;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2 ----
+    if (ln == 0) {
+        if (wv == 0) {
+            double RiRjT[9], dR[9], r_dr[3], Jr_r[9], Jr_ri[9];
+            m3_mul_t(mid.Ri, mid.Rj, RiRjT);
+            m3_tmul(s_DRc, RiRjT, dR);   // dR = (DeltaR exp(J_dR_bg dbg))^T R_i R_j^T  (:157-158)
+            so3_log(dR, r_dr);
+            so3_right_jacobian(r_dr, Jr_r);
+            m3_inverse(Jr_r, Jr_ri);
+            for (int q = 0; q < 9; q++) { mid.RiRjT[q] = RiRjT[q]; mid.dR[q] = dR[q]; s_Jr_ri[q] = Jr_ri[q]; }
+            for (int q = 0; q < 3; q++) { mid.r_dr[q] = r_dr[q]; e9[q] = r_dr[q]; }
+        } else if (wv == 1) {
+            double dba[3], dbg[3], Ra[3], t1[3], t2[3];
+            for (int q = 0; q < 3; q++) { dba[q] = xba[3 * (long long)i + q]; dbg[q] = xbg[3 * (long long)i + q]; }
+            m3_vec(mid.Ri, mid.a, Ra);
+            m3_vec(f.J_dv_bg, dbg, t1); m3_vec(f.J_dv_ba, dba, t2);
+            for (int q = 0; q < 3; q++) e9[3 + q] = Ra[q] - (f.dv[q] + t1[q] + t2[q]);
+        } else if (wv == 2) {
+            // positions in world: p = -R^T t, T.inverse().translation() with Eigen::Affine3d semantics (the linear part inverted as a general 3x3)
+            double dba[3], dbg[3], Rii[9], Rji[9], pi[3], pj[3], b[3], Rb[3], t1[3], t2[3];
+            for (int q = 0; q < 3; q++) { dba[q] = xba[3 * (long long)i + q]; dbg[q] = xbg[3 * (long long)i + q]; }
+            m3_inverse(mid.Ri, Rii); m3_inverse(mid.Rj, Rji);
+            m3_vec(Rii, s_ti, pi); m3_vec(Rji, mid.tj, pj);
+            for (int q = 0; q < 3; q++) { pi[q] = -pi[q]; pj[q] = -pj[q]; }
+            for (int q = 0; q < 3; q++) b[q] = pj[q] - pi[q] - s_vi[q] * dt - 0.5 * G[q] * dt * dt;
+            m3_vec(mid.Ri, b, Rb);
+            m3_vec(f.J_dp_bg, dbg, t1); m3_vec(f.J_dp_ba, dba, t2);
+            for (int q = 0; q < 3; q++) {
+                e9[6 + q] = Rb[q] - (f.dp[q] + t1[q] + t2[q]);
+                mid.cc[q] = pj[q] - s_vi[q] * dt - 0.5 * G[q] * dt * dt;
+            }
+        } else {
+            double S[9], RS[9], B[9];
+            so3_skew(mid.a, S); m3_mul(mid.Ri, S, RS); m3_mul(RS, s_Jrw, B);       // pose_i, rows 3..5 (:174-187)
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) U[(3 + a) * 24 + b] = -B[3 * a + b];
+            m3_mul_t(mid.Ri, mid.dRj, B);                                          // pose_j translation: exp(w_j)^T as coded (:198)
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) U[(6 + a) * 24 + 9 + b] = -B[3 * a + b];
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {             // dv_i, dv_j, dba, dbg (:203-237)
+                U[(3 + a) * 24 + 12 + b] = -mid.Ri[3 * a + b];
+                U[(6 + a) * 24 + 12 + b] = -mid.Ri[3 * a + b] * dt;
+                U[(3 + a) * 24 + 15 + b] = mid.Ri[3 * a + b];
+                U[(3 + a) * 24 + 18 + b] = -f.J_dv_ba[3 * a + b];
+                U[(6 + a) * 24 + 18 + b] = -f.J_dp_ba[3 * a + b];
+                U[(3 + a) * 24 + 21 + b] = -f.J_dv_bg[3 * a + b];
+                U[(6 + a) * 24 + 21 + b] = -f.J_dp_bg[3 * a + b];
+            }
+        }
+    }
+    __syncthreads();
+#ifdef SADVIO_KERNEL_TS
+    if ((P.debug & 4096) && k == 0 && tid == 0 && slot == 3) P.dbg_ts[57] = wall_clock64();
+#endif
+    // ---- phase 3 ----
+    if (wv == 0 && ln < 9) {
+        double r = 0.0;
+        for (int q = 0; q < 9; q++) r += f.W[9 * ln + q] * e9[q];
+        rs[ln] = r; sc[9 * 24 + ln] = r;
+    }
+    if (ln == 0) {
+        double A[9], B[9];
+        if (wv == 0) {
+            m3_mul(s_Jr_ri, mid.Rj, A); m3_mul(A, s_Jrw, B);                       // pose_i rotation (:174-176)
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) U[a * 24 + b] = B[3 * a + b];
+        } else if (wv == 1) {
+            double S[9], C1[9], C2[9];
+            m3_mul(s_Jr_ri, mid.Rj, A); m3_mul(A, s_Jrw + 9, B);                   // pose_j (:190-200)
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) U[a * 24 + 6 + b] = -B[3 * a + b];
+            so3_skew(mid.tj, S); m3_mul(mid.RiRjT, S, C1); m3_mul(C1, mid.Rj, C2); m3_mul(C2, s_Jrw + 9, B);
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) U[(6 + a) * 24 + 6 + b] = -B[3 * a + b];
+        } else if (wv == 2) {
+            double S[9], RS[9];
+            so3_skew(mid.cc, S); m3_mul(mid.Ri, S, RS); m3_mul(RS, s_Jrw, B);      // pose_i, rows 6..8: p_j instead of p_j - p_i, R_i0 (:181-185)
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) { U[(6 + a) * 24 + b] = -B[3 * a + b]; U[(6 + a) * 24 + 3 + b] = Ti0[3 * a + b]; }
+        } else {
+            double D1[9], D2[9];
+            m3_mul_t(s_Jr_ri, mid.dR, A);                                          // Jr^-1 dR^T
+            m3_mul(A, s_Jrb, D1); m3_mul(D1, f.J_dR_bg, D2);
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) U[a * 24 + 21 + b] = -D2[3 * a + b];
+        }
+    }
+    __syncthreads();
+#ifdef SADVIO_KERNEL_TS
+    if ((P.debug & 4096) && k == 0 && tid == 0 && slot == 3) P.dbg_ts[58] = wall_clock64();
+#endif
+    // ---- phase 4: J <- W J (W is upper triangular: L^T), the pair's cost ----
+    if (tid < 9 * 24) {
+        const int q = tid / 24, c = tid - 24 * q;
+        double v = 0.0;
+        for (int kk = q; kk < 9; kk++) v += f.W[9 * q + kk] * U[kk * 24 + c];
+        UW[tid] = v; sc[tid] = v;
+    } else if (tid == 9 * 24) {
+        double c = 0.0;
+        for (int q = 0; q < 9; q++) c += rs[q] * rs[q];
+        for (int q = 0; q < 3; q++) c += rbs[q] * rbs[q];
+        for (int q = 0; q < 3; q++) c += rbs[3 + q] * rbs[3 + q];
+        s_cost = c;
+    }
+    __syncthreads();
+#ifdef SADVIO_KERNEL_TS
+    if ((P.debug & 4096) && k == 0 && tid == 0 && slot == 3) P.dbg_ts[59] = wall_clock64();
+#endif
+    // ---- phase 5 ----
+    const int add_buf = s_add;
+    const bool fresh = add_buf == buf;
+    auto emit = [&](int e, double v, int ix) {   // entry e of the pair (position ix) into the reduced system
+        if (ix < 0) return;
+        const int ca = ix >> 16, cb = ix & 0xffff;
+        if (e < IMU_E_G || (e >= IMU_E_BH && e < IMU_E_BG)) {
+            atomic_add_f64(P.S + Wd.S_off + s_index(Wd.ld, ca, cb), v);
+            if (ca == cb) atomic_add_f64(P.hdiag + Wd.red_off + ca, v);
+        } else {
+            atomic_add_f64(P.gred + Wd.red_off + ca, v);
+            atomic_add_f64(P.gfull + Wd.red_off + ca, v);
+        }
+    };
+    if (!fresh && add_buf >= 0) {   // rejected step: the row of x (written by an earlier launch)
+        const double* ro = P.imu_scratch + (long long)add_buf * P.imu_scratch_stride + (long long)k * IMU_ROW;
+        for (int e = tid; e < IMU_E_COST; e += nthr) emit(e, ro[IMU_H + e], (int)ro[IMU_IX + e]);
+    }
+    // H = J^T J (lower triangle, 300), g = J^T r (24) and where each entry goes in the reduced system
+    for (int e = tid; e < IMU_E_BH; e += nthr) {
+        double v = 0.0;
+        int ix = -1;
+        if (e < IMU_E_G) {
+            int a = 0, b = e;
+            while (b >= a + 1) { b -= a + 1; a++; }
+#pragma unroll
+            for (int q = 0; q < 9; q++) v += UW[q * 24 + a] * UW[q * 24 + b];
+            const int ca = imu_col(a, fi, fj), cb = imu_col(b, fi, fj);
+            if (ca >= 0 && cb >= 0) ix = ca >= cb ? (ca << 16) | cb : (cb << 16) | ca;
+        } else {
+            const int a = e - IMU_E_G;
+#pragma unroll
+            for (int q = 0; q < 9; q++) v += UW[q * 24 + a] * rs[q];
+            const int ca = imu_col(a, fi, fj);
+            if (ca >= 0) ix = ca << 16;
+        }
+        sc[IMU_H + e] = v;
+        sc[IMU_IX + e] = (double)ix;
+        if (fresh) emit(e, v, ix);
+    }
+    // the bias random walk (Jacobians -/+ s I: entries s^2, -s^2 and -/+ s r), the pair's cost, what k_solve's model-cost pass reads:
+    // the last wave (the first ones have a second round of entries above)
+    const int t = tid - (nthr - 64);
+    if (t >= 0 && t < 30) {
+        const int e = t < 18 ? t : t - 18;                  // matrix entries 0..17 = (combo, kind 0..2); gradient 0..11 = (combo, i | j)
+        const int combo = t < 18 ? e / 3 : e / 2, kind = t < 18 ? e % 3 : e % 2;
+        const int ax = combo % 3, gy = combo / 3;
+        const double sgm = gy ? f.sg : f.sa, s2 = sgm * sgm;
+        const int ci = fi < 0 ? -1 : fi * 15 + 9 + 3 * gy + ax, cj = fj < 0 ? -1 : fj * 15 + 9 + 3 * gy + ax;
+        double v; int ix = -1;
+        if (t < 18) {
+            if (kind == 0) { v = s2; if (ci >= 0) ix = (ci << 16) | ci; }
+            else if (kind == 1) { v = s2; if (cj >= 0) ix = (cj << 16) | cj; }
+            else { v = -s2; if (ci >= 0 && cj >= 0) ix = ci >= cj ? (ci << 16) | cj : (cj << 16) | ci; }
+            sc[IMU_H + IMU_E_BH + e] = v; sc[IMU_IX + IMU_E_BH + e] = (double)ix;
+            if (fresh) emit(IMU_E_BH + e, v, ix);
+        } else {
+            const double rb = rbs[3 * gy + ax];
+            if (kind == 0) { v = -sgm * rb; if (ci >= 0) ix = ci << 16; }
+            else { v = sgm * rb; if (cj >= 0) ix = cj << 16; }
+            sc[IMU_H + IMU_E_BG + e] = v; sc[IMU_IX + IMU_E_BG + e] = (double)ix;
+            if (fresh) emit(IMU_E_BG + e, v, ix);
+        }
+    } else if (t == 30) {
+        sc[IMU_H + IMU_E_COST] = s_cost; sc[IMU_IX + IMU_E_COST] = all_const ? -2.0 : -3.0;
+    } else if (t == 31) {
+        sc[IMU_META] = (double)fi; sc[IMU_META + 1] = (double)fj; sc[IMU_META + 2] = f.sa; sc[IMU_META + 3] = f.sg;
+    }
+#ifdef SADVIO_KERNEL_TS
+    if ((P.debug & 4096) && k == 0 && tid == 0 && slot == 3) P.dbg_ts[60] = wall_clock64();
+#endif
 }
 
 // Sparse prior factors that the solve evaluates itself (IMUPriordx, landmark priors / chains), ONE WAVE per listed factor, the
@@ -2750,15 +3100,22 @@ __device__ __forceinline__ void sparse_factor_eval(const DevPtrs& P, int slot, i
 }
 
 // extra workgroup `idx` of k_build (COST_ONLY = false) / k_backsub (true): IMU factor pairs first, then the listed sparse-prior factors
+// COST_ONLY: the first wave of the workgroup calls it (ln = lane); the linearisation is called by EVERY thread of a 256-thread workgroup
+// (ln = thread index: an IMU pair is dealt over the four waves, imu_pair_lin_wg; a sparse factor takes the first wave)
 template <bool COST_ONLY>
 __device__ __forceinline__ void pose_factor_eval(const DevPtrs& P, int slot, int idx, int ln) {
-    if (idx < P.n_imu_tot) imu_pair_eval<COST_ONLY>(P, slot, idx, ln);
-    else sparse_factor_eval<COST_ONLY>(P, slot, P.sp_list[idx - P.n_imu_tot], ln);
+    if (COST_ONLY) {
+        if (idx < P.n_imu_tot) imu_pair_eval<true>(P, slot, idx, ln);
+        else sparse_factor_eval<true>(P, slot, P.sp_list[idx - P.n_imu_tot], ln);
+    } else {
+        if (idx < P.n_imu_tot) imu_pair_lin_wg(P, slot, idx, ln);
+        else if (ln < 64) sparse_factor_eval<false>(P, slot, P.sp_list[idx - P.n_imu_tot], ln);
+    }
 }
 // the same as a kernel of its own (one 64-lane workgroup per factor): large batches on the throughput kernels, whose tile kernels
 // carry no extra workgroups
 template <bool COST_ONLY>
-__global__ __launch_bounds__(64) void k_pf_eval(DevPtrs P, int slot) { pose_factor_eval<COST_ONLY>(P, slot, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(COST_ONLY ? 64 : BUILD_THREADS) void k_pf_eval(DevPtrs P, int slot) { pose_factor_eval<COST_ONLY>(P, slot, blockIdx.x, threadIdx.x); }
 
 // linexd observations, one 64-lane workgroup per observation, kernels of their own on a side stream: LIN -> J (rows x 12:
 // key-frame | line), r, loss-corrected cost and the in-program flag into the scratch row at x; !LIN -> cost at the candidate
