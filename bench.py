@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
+FP64_PEAK_TFLOPS = 78.6  # half the guide's 157.3 TFLOP/s fp32 vector / matrix rate; v_mfma_f64_16x16x4 and the fp64 VALU share one pipe at 128 flop / clk / CU (profiles/r03_mfma64_rate_probe.txt)
 GN_ITERS = 10
 # committed rocprofv3 PMC summaries of this same command (scripts/prof_bench.sh / prof_batched.sh), named explicitly: the
 # newest round's files, not whatever sorts last
@@ -280,6 +281,13 @@ def main():
         batched = None
         if args.batch > 0 and world == 1:
             per_iter_bytes = 120 * w0.n_obs + 96 * w0.n_lmk + 16 * (n_p * n_p + n_p)
+            # The second roof of this regime. Useful fp64 flops of one LM step on the three-pass throughput path ("flops of an LM
+            # step"): per observation 3 x 156 (the pixel factor and its Jacobians from the view tables, once per pass) + 888 (pass 1:
+            # W = Jl Li^T, E = Jp^T W, Jp^T Jp, Jp^T r, E (Li g) and the k (k + 1) / 2 = 15 key-frame pairs' 6 x 6 x 3 Schur products of a
+            # 5-observation landmark) + 36 (pass 2: the back-substitution) + 148 (pass 3: cost, H_ll, g_l, the key-frame sums) = 1 540, the
+            # reduced solve N_p^3 / 3 per window beside it. At 120 B per observation that is 12.8 flop / B against a machine balance
+            # of 78.6 TFLOP/s / 8 TB/s = 9.8: the path sits on the compute side of the ridge, its fp64 fraction is the tighter bound.
+            per_iter_flops = 1540 * w0.n_obs + n_p ** 3 // 3
 
             def batch_leg(nw):
                 bw = [synthetic.make_window(seed=base_seed + 100 + i) for i in range(min(nw, 8))]
@@ -300,7 +308,10 @@ def main():
                 return {"windows": nw, "value": round(biters / bdt, 1), "unit": "BA iterations/s",
                         "ms_per_solve_batch": round(1e3 * bdt / reps, 3),
                         "algorithmic_GBps": round(biters * per_iter_bytes / bdt / 1e9, 1),
-                        "frac_of_hbm_peak": round(biters * per_iter_bytes / bdt / 1e9 / HBM_PEAK_GBS, 4)}
+                        "frac_of_hbm_peak": round(biters * per_iter_bytes / bdt / 1e9 / HBM_PEAK_GBS, 4),
+                        "fp64": {"flops_per_observation_per_lm_step": 1540, "achieved_TFLOPs": round(biters * per_iter_flops / bdt / 1e12, 2),
+                                 "peak_TFLOPs": FP64_PEAK_TFLOPS, "frac_of_fp64_peak": round(biters * per_iter_flops / bdt / 1e12 / FP64_PEAK_TFLOPS, 4),
+                                 "flop_per_byte": round(per_iter_flops / per_iter_bytes, 1), "machine_balance_flop_per_byte": round(FP64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS, 1)}}
 
             # >= 65 536 landmarks in a submission: the throughput kernels (sadvio_amd/csrc/lm_kernels.h) take over by themselves
             batched = batch_leg(args.batch)
