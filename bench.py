@@ -61,7 +61,25 @@ def algorithmic_bytes(n_obs, n_lmk, n_p):
     return {"k_build": 40 * n_obs + 24 * n_lmk + red, "k_solve": red, "k_backsub": 80 * n_obs + 72 * n_lmk}
 
 
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout. Libraries write there too (RCCL prints a five-line banner through C stdio when a
+    communicator is created - buffered, it lands AFTER the JSON line when stdout is a file or a pipe): everything this process writes
+    to fd 1 from now on goes to stderr, the returned function writes the record to the real stdout."""
+    import ctypes
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    libc = ctypes.CDLL(None)
+
+    def emit(rec):
+        sys.stdout.flush()
+        libc.fflush(None)
+        os.write(real, (json.dumps(rec) + "\n").encode())
+    return emit
+
+
 def main():
+    emit_record = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -125,7 +143,7 @@ def main():
     if args.shard_window:
         rec = bench_sharded_window(args, rank, local_rank, world, dist, barrier, timed_solves)
         if rank == 0:
-            print(json.dumps(rec))
+            emit_record(rec)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -366,7 +384,7 @@ def main():
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
             out["speedup_vs_cpu_at_reference_threads"] = round(value / cpu["at_reference_threads"]["value"], 1)
-        print(json.dumps(out))
+        emit_record(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
