@@ -120,7 +120,7 @@ constexpr int SPARSE_IX = SPARSE_H + SPARSE_NE;
 constexpr int SPARSE_COL = SPARSE_IX + SPARSE_NE;
 constexpr int SPARSE_J = SPARSE_COL + 16;
 constexpr int IMU_J = 9 * 24 + 9;  // whitened Jacobian + residual kept in HBM scratch between phases
-// scratch row of one IMU factor pair, all written by imu_pair_eval<false> (kernels.h): J 216 | r 9 | bias residuals 6 | IMU_NE entry values | IMU_NE entry
+// scratch row of one IMU factor pair, all written by imu_pair_lin_wg (kernels.h): J 216 | r 9 | bias residuals 6 | IMU_NE entry values | IMU_NE entry
 // targets | fi, fj, sa, sg. The entries are what the factor pair (IMUFactor + IMUBiasFactor) adds to the window's reduced system:
 // H = J^T J (lower, 300) | g = J^T r (24) | bias random walk: 18 matrix entries, 12 gradient entries | the pair's squared residual
 // sum (1). Target of a matrix entry: (row << 16) | col; of a gradient entry: row << 16; -1 = not in the system (constant

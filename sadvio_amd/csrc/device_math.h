@@ -538,7 +538,7 @@ __device__ __forceinline__ void pose_to_landmark_factor(const double* T0, const 
 // WHITEN = false leaves the UN-whitened 9x24 Jacobian in J (the caller multiplies by W with many threads); r is
 // whitened in both cases.
 // What the Jacobian blocks of the IMU factor read from the residual part. In registers (a local) for the out-of-line copies; in LDS
-// for imu_pair_eval (kernels.h), where one lane evaluates the whole factor: with the 60 values and every block's temporaries live
+// for a one-lane evaluation of the whole factor (round 4's imu_pair_eval; imu_pair_lin_wg of kernels.h deals the same blocks over four waves): with the 60 values and every block's temporaries live
 // at once the body needs ~370 registers (256 + AGPR copies, 30 spills beside the tile code of k_build); read back from LDS block
 // by block it stays below 128.
 struct ImuMid {
@@ -680,7 +680,7 @@ __device__ __forceinline__ void imu_factor_body(const ImuT& f, const double* Ti0
 }
 
 // Out-of-line copy for the big kernels (k_solve, k_marg_small: inlining it there costs more registers than the call);
-// imu_pair_eval (kernels.h) inlines the body into one wave where everything stays in registers.
+// imu_pair_lin_wg / imu_pair_cost (kernels.h) inline the parts.
 template <typename ImuT, bool WHITEN = true>
 __device__ __noinline__ void imu_factor(const ImuT& f, const double* Ti0, const double* Tj0, const double* vi0,
                                         const double* vj0, const double* dpi, const double* dpj, const double* dvi,

@@ -52,7 +52,7 @@ struct DevPtrs {
     int* big_info;        // [n_win] potrf info of the windows solved out of LDS
     // a window sharded over `world` GPUs (landmark partition): per-rank partial sums, exchanged with the reduced
     // system by one all-reduce per phase; rank r writes slot r and zeroes the others (sum == gather)
-    int imu_direct;       // 1: imu_pair_eval<false> adds the IMU pairs' entries to the reduced system itself (one device); 0: k_solve's item loop
+    int imu_direct;       // 1: imu_pair_lin_wg adds the IMU pairs' entries to the reduced system itself (one device); 0: k_solve's item loop
     int decide_kernel;    // 1: the LM decision of a slot is taken by k_decide (many tiles); 0: by every k_build workgroup
     int world, rank;
     double* rank_b;       // [n_win][world][4] lin_cost, fixed_cost, gmax, -      (after k_build)
@@ -99,9 +99,7 @@ struct DevPtrs {
 #ifdef SADVIO_KERNEL_TS
 #define SADVIO_TS(slot_, idx_) do { if ((P.debug & 4096) && blockIdx.x == 0 && threadIdx.x == 0 && slot == (slot_)) P.dbg_ts[idx_] = wall_clock64(); } while (0)
 #define SADVIO_TS_PTR(cond_) ((cond_) ? P.dbg_ts : nullptr)
-#define SADVIO_TS_IMU(idx_) do { if ((P.debug & 4096) && k == 0 && ln == 0 && slot == 3) P.dbg_ts[idx_] = wall_clock64(); } while (0)
 #else
-#define SADVIO_TS_IMU(idx_) do { } while (0)
 #define SADVIO_TS(slot_, idx_) do { } while (0)
 #define SADVIO_TS_PTR(cond_) nullptr
 #endif
@@ -490,7 +488,7 @@ __host__ __device__ inline size_t tile_tables_bytes(int n_kf) {
 }
 
 // ---- K5: build the reduced system ----------------------------------------------------------------
-// IMU = true (windows with IMU factors): the workgroups behind the tiles linearise one IMU factor pair each (imu_pair_eval<false>,
+// IMU = true (windows with IMU factors): the workgroups behind the tiles linearise one IMU factor pair each (imu_pair_lin_wg,
 // one wave; its 500 registers leave one workgroup per CU, which is what a single window runs at anyway).
 template <bool COST_ONLY> __device__ __forceinline__ void pose_factor_eval(const DevPtrs& P, int slot, int idx, int ln);   // below
 template <int FACTOR, bool RARE, bool IMU>
@@ -1422,11 +1420,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
     // whose order depends on wave scheduling.
     const bool det = P.world > 1;
     if (MODE != 2) {
-    // IMUFactor + IMUBiasFactor (K3): imu_pair_eval<false> (one wave per factor pair, an extra workgroup of k_build) left every entry the
+    // IMUFactor + IMUBiasFactor (K3): imu_pair_lin_wg (an extra workgroup of k_build per factor pair) left every entry the
     // pair adds to the reduced system, with its position, in the factor's scratch row (ba_types.h). Item = (factor, entry); the
     // first eight items of every thread are fetched here, with the image
     double im_ix[8], im_v[8];
-    // (P.imu_direct: imu_pair_eval added the pairs' entries to the accumulators in HBM itself; only their costs are picked up here)
+    // (P.imu_direct: imu_pair_lin_wg added the pairs' entries to the accumulators in HBM itself; only their costs are picked up here)
     const int n_imu_items = (EXTRAS && !det && !P.imu_direct) ? n_imu * IMU_NE : 0;
     if (EXTRAS) {
 #pragma unroll
@@ -1883,7 +1881,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(DevPtrs P, int slot) {
             }
             mcc += -m * (r + 0.5 * m);
         }
-        // candidate cost of the IMU factors: imu_pair_eval<true> (extra workgroups of k_backsub, after this kernel) adds it to acc->cand_cost
+        // candidate cost of the IMU factors: imu_pair_cost (extra workgroups of k_backsub, after this kernel) adds it to acc->cand_cost
     }
     if (EXTRAS && W.spl_end > W.spl_begin) {
         // model cost change, item = (listed factor, residual row), dealt from the fifth wave upwards (see the IMU items); the row holds
@@ -1953,7 +1951,7 @@ __device__ __forceinline__ void zero_s_slice(const DevPtrs& P, const Tile& T, in
 
 // ---- K7: back-substitution + candidate cost -------------------------------------------------------
 // IMU = true (windows with IMU factors): the workgroups behind the tiles evaluate the cost of one IMU factor pair each at the
-// candidate (imu_pair_eval<true>: one wave, beside the tiles instead of behind them on the stream).
+// candidate (imu_pair_cost: one wave, beside the tiles instead of behind them on the stream).
 template <int FACTOR, bool RARE, bool IMU>
 __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, int max_tile_kf) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2492,21 +2490,17 @@ __global__ void k_decide(DevPtrs P, int slot, int final) {
     }
 }
 
-// IMUFactor + IMUBiasFactor of one key-frame pair (residuals.hpp:133-300), evaluated by ONE WAVE per pair: inside
-// k_solve (512 threads, 128 VGPRs) this code lived in scratch memory and cost 49 us + 21 us per LM step on a 12-KF
-// window; here the body is inlined and stays in registers.
+// IMUFactor + IMUBiasFactor of one key-frame pair (residuals.hpp:133-300). Inside k_solve (512 threads, 128 VGPRs) this code lived in
+// scratch memory and cost 49 us + 21 us per LM step on a 12-KF window; it is evaluated by workgroups of its own instead.
 // What the pair adds to the reduced system (r, the whitened 9x24 Jacobian, J^T J, J^T r, the bias random walk, the cost: the
 // scratch row of ba_types.h) is kept per delta buffer, like the pose priors' records (DevPtrs::prior_lin). No kernel of its
 // own and no second stream inside the LM loop - a fork / join through a side stream was measured at the price of running the
 // evaluation serially (~28 us per step) - the pairs ride the two tile kernels as extra workgroups:
-//   COST_ONLY = true  (k_backsub, slot s): the pair's cost at the candidate x + delta, added to the slot's cand_cost
-//   COST_ONLY = false (k_build, slot s)  : the linearisation at the candidate of slot s - 1 (buffer 1 - cur; at x = 0 for slot 0)
-//                 BESIDE the tiles that take that slot's accept / reject decision: it is what k_solve reads if the step was
-//                 accepted; a rejected step leaves the row of x (the other buffer) untouched.
-template <bool COST_ONLY>
-__device__ __forceinline__ void imu_pair_eval(const DevPtrs& P, int slot, int k, int ln) {
-    constexpr bool LIN = !COST_ONLY;
-    if (LIN) SADVIO_TS_IMU(56);
+//   imu_pair_cost   (k_backsub, slot s): the pair's cost at the candidate x + delta, added to the slot's cand_cost; one wave
+//   imu_pair_lin_wg (k_build, slot s)  : the linearisation at the candidate of slot s - 1 (buffer 1 - cur; at x = 0 for slot 0)
+//                 BESIDE the tiles that take that slot's accept / reject decision: it is what enters the reduced system if the step
+//                 was accepted; a rejected step leaves the row of x (the other buffer) untouched. The whole workgroup.
+__device__ __forceinline__ void imu_pair_cost(const DevPtrs& P, int slot, int k, int ln) {
     // the factor's constants (1.2 KB) come in with one coalesced copy: lane 0 evaluating the factor from global memory spends its
     // time on ~200 dependent scalar loads
     __shared__ ImuDev f;
@@ -2516,163 +2510,37 @@ __device__ __forceinline__ void imu_pair_eval(const DevPtrs& P, int slot, int k,
         for (int i = ln; i < (int)(sizeof(ImuDev) / 8); i += 64) dst[i] = src[i];
     }
     wave_lds_fence();
-    const bool at_x = LIN && slot == 0;
-    const long long so = (long long)f.win * P.state_stride + (LIN && slot > 0 ? slot - 1 : slot);
+    const long long so = (long long)f.win * P.state_stride + slot;
     const LmState st = P.states[so];
     if (st.done) return;
     const int i = f.kf_i, j = f.kf_j;
-    const bool all_const = P.kf_fidx[i] < 0 && P.kf_fidx[j] < 0;
-    if (COST_ONLY && all_const) return;
-    const int buf = at_x ? st.cur : 1 - st.cur;
+    if (P.kf_fidx[i] < 0 && P.kf_fidx[j] < 0) return;   // both key-frames constant: the pair's cost is part of the fixed cost
+    const int buf = 1 - st.cur;
     const double* xp = P.xp + (long long)buf * P.xp_stride;
     const double* xv = P.xv + (long long)buf * P.xv_stride;
     const double* xba = P.xba + (long long)buf * P.xv_stride;
     const double* xbg = P.xbg + (long long)buf * P.xv_stride;
-    __shared__ double U[9 * 24];
-    __shared__ double rs[9], rbs[6], s_cost;
-    __shared__ ImuMid mid;
-    double* sc = P.imu_scratch + (long long)buf * P.imu_scratch_stride + (long long)k * IMU_ROW;
-    if (ln == 0) {
-        double dpi[6], dpj[6], r[9];
-        ImuMid mid_regs;   // COST_ONLY: nothing reads it, the stores fold away
-        for (int q = 0; q < 6; q++) { dpi[q] = xp[6 * (long long)i + q]; dpj[q] = xp[6 * (long long)j + q]; }
-        imu_residual_part(f, P.kf_T0 + 12 * (long long)i, P.kf_T0 + 12 * (long long)j, P.kf_vel + 3 * (long long)i,
-                          P.kf_vel + 3 * (long long)j, dpi, dpj, xv + 3 * (long long)i, xv + 3 * (long long)j,
-                          xba + 3 * (long long)i, xbg + 3 * (long long)i, r, LIN ? mid : mid_regs);
-        if (LIN && !all_const) {
-            asm volatile("" ::: "memory");   // the Jacobian blocks read `mid` back from LDS one at a time (device_math.h: ImuMid)
-            imu_jacobian_part<ImuDev, true>(f, P.kf_T0 + 12 * (long long)i, dpi, dpj, mid, U);
-        }
-        double c = 0.0;
-        for (int q = 0; q < 9; q++) { if (LIN) { sc[9 * 24 + q] = r[q]; rs[q] = r[q]; } c += r[q] * r[q]; }
-        double rba[3], rbg[3];
-        for (int q = 0; q < 3; q++) {
-            rba[q] = f.sa * (P.kf_ba[3 * (long long)j + q] + xba[3 * (long long)j + q] - P.kf_ba[3 * (long long)i + q] - xba[3 * (long long)i + q]);
-            rbg[q] = f.sg * (P.kf_bg[3 * (long long)j + q] + xbg[3 * (long long)j + q] - P.kf_bg[3 * (long long)i + q] - xbg[3 * (long long)i + q]);
-            if (LIN) { sc[IMU_J + q] = rba[q]; sc[IMU_J + 3 + q] = rbg[q]; rbs[q] = rba[q]; rbs[3 + q] = rbg[q]; }
-        }
-        for (int q = 0; q < 3; q++) c += rba[q] * rba[q];
-        for (int q = 0; q < 3; q++) c += rbg[q] * rbg[q];
-        s_cost = c;
-        if (COST_ONLY) {
-            // sharded window: every rank must leave the step with the same bits (the ranks take the LM decisions independently), and
-            // the order of atomic adds depends on workgroup scheduling - the pair's cost goes to its row (the slot the
-            // linearisation at this candidate will fill with the same value) and k_rank_partials sums the rows in index order
-            if (P.world > 1) sc[IMU_H + IMU_E_COST] = c;
-            else atomic_add_f64(&P.acc[so].cand_cost, c);
-        }
+    if (ln != 0) return;
+    double dpi[6], dpj[6], r[9];
+    ImuMid mid;   // nothing reads it: the stores fold away
+    for (int q = 0; q < 6; q++) { dpi[q] = xp[6 * (long long)i + q]; dpj[q] = xp[6 * (long long)j + q]; }
+    imu_residual_part(f, P.kf_T0 + 12 * (long long)i, P.kf_T0 + 12 * (long long)j, P.kf_vel + 3 * (long long)i,
+                      P.kf_vel + 3 * (long long)j, dpi, dpj, xv + 3 * (long long)i, xv + 3 * (long long)j,
+                      xba + 3 * (long long)i, xbg + 3 * (long long)i, r, mid);
+    double c = 0.0;
+    for (int q = 0; q < 9; q++) c += r[q] * r[q];
+    double rba[3], rbg[3];
+    for (int q = 0; q < 3; q++) {
+        rba[q] = f.sa * (P.kf_ba[3 * (long long)j + q] + xba[3 * (long long)j + q] - P.kf_ba[3 * (long long)i + q] - xba[3 * (long long)i + q]);
+        rbg[q] = f.sg * (P.kf_bg[3 * (long long)j + q] + xbg[3 * (long long)j + q] - P.kf_bg[3 * (long long)i + q] - xbg[3 * (long long)i + q]);
     }
-    if (COST_ONLY) return;
-    wave_lds_fence();
-    SADVIO_TS_IMU(57);
-    const int fi = P.kf_fidx[i], fj = P.kf_fidx[j];
-    // One device, one window per workgroup set (P.imu_direct): the pair's entries go straight into the reduced system in HBM (S, gred,
-    // gfull, hdiag: accumulators the tiles, the kept landmarks and the dense prior add into as well) instead of through k_solve's item
-    // loop - 11 pairs x 354 LDS atomics of ONE workgroup were 4 us of every VIO step. Which row is added is the LM decision of the
-    // previous slot: accepted -> the row just evaluated (the candidate's), rejected -> the row of x kept in the other buffer. The
-    // decision is re-derived here exactly as the tiles of this launch do (same bits: wave_sum_backsub_partials), or read if k_decide took it.
-    const WinDev& Wd = P.win[f.win];
-    const bool direct = P.imu_direct != 0;
-    bool fresh = direct;
-    int add_buf = buf;
-    if (direct && slot > 0) {
-        LmState nst;
-        if (P.decide_kernel) nst = P.states[so + 1];
-        else {
-            __shared__ double s4[4];
-            wave_sum_backsub_partials(P, (slot - 1) & 1, f.win, Wd.tile_begin, Wd.tile_end - Wd.tile_begin, ln, s4);
-            wave_lds_fence();
-            IterAcc a = P.acc[so];
-            a.cand_cost += s4[0]; a.mcc += s4[1]; a.step_norm2 += s4[2]; a.cand_norm2 += s4[3];
-            nst = lm_decide(st, a, P.o);
-        }
-        add_buf = nst.done ? -1 : nst.cur;
-        fresh = add_buf == buf;
-    }
-    auto emit = [&](int e, double v, int ix) {   // entry e of the pair (position ix) into the reduced system
-        if (ix < 0) return;
-        const int ca = ix >> 16, cb = ix & 0xffff;
-        if (e < IMU_E_G || (e >= IMU_E_BH && e < IMU_E_BG)) {
-            atomic_add_f64(P.S + Wd.S_off + s_index(Wd.ld, ca, cb), v);
-            if (ca == cb) atomic_add_f64(P.hdiag + Wd.red_off + ca, v);
-        } else {
-            atomic_add_f64(P.gred + Wd.red_off + ca, v);
-            atomic_add_f64(P.gfull + Wd.red_off + ca, v);
-        }
-    };
-    if (direct && !fresh && add_buf >= 0) {   // rejected step: the row of x (written by an earlier launch)
-        const double* ro = P.imu_scratch + (long long)add_buf * P.imu_scratch_stride + (long long)k * IMU_ROW;
-        for (int e = ln; e < IMU_E_COST; e += 64) emit(e, ro[IMU_H + e], (int)ro[IMU_IX + e]);
-    }
-    SADVIO_TS_IMU(58);
-    // the pair's cost, the bias random walk (Jacobians -/+ s I: entries s^2, -s^2 and -/+ s r) and what k_solve's model-cost pass reads
-    if (ln < 30) {
-        const int e = ln < 18 ? ln : ln - 18;                 // matrix entries 0..17 = (combo, kind 0..2); gradient 0..11 = (combo, i | j)
-        const int combo = ln < 18 ? e / 3 : e / 2, kind = ln < 18 ? e % 3 : e % 2;
-        const int ax = combo % 3, gy = combo / 3;
-        const double sgm = gy ? f.sg : f.sa, s2 = sgm * sgm;
-        const int ci = fi < 0 ? -1 : fi * 15 + 9 + 3 * gy + ax, cj = fj < 0 ? -1 : fj * 15 + 9 + 3 * gy + ax;
-        double v; int ix = -1;
-        if (ln < 18) {
-            if (kind == 0) { v = s2; if (ci >= 0) ix = (ci << 16) | ci; }
-            else if (kind == 1) { v = s2; if (cj >= 0) ix = (cj << 16) | cj; }
-            else { v = -s2; if (ci >= 0 && cj >= 0) ix = ci >= cj ? (ci << 16) | cj : (cj << 16) | ci; }
-            sc[IMU_H + IMU_E_BH + e] = v; sc[IMU_IX + IMU_E_BH + e] = (double)ix;
-            if (fresh) emit(IMU_E_BH + e, v, ix);
-        } else {
-            const double rb = rbs[3 * gy + ax];
-            if (kind == 0) { v = -sgm * rb; if (ci >= 0) ix = ci << 16; }
-            else { v = sgm * rb; if (cj >= 0) ix = cj << 16; }
-            sc[IMU_H + IMU_E_BG + e] = v; sc[IMU_IX + IMU_E_BG + e] = (double)ix;
-            if (fresh) emit(IMU_E_BG + e, v, ix);
-        }
-    } else if (ln == 30) {
-        sc[IMU_H + IMU_E_COST] = s_cost; sc[IMU_IX + IMU_E_COST] = all_const ? -2.0 : -3.0;
-    } else if (ln == 31) {
-        sc[IMU_META] = (double)fi; sc[IMU_META + 1] = (double)fj; sc[IMU_META + 2] = f.sa; sc[IMU_META + 3] = f.sg;
-    }
-    if (all_const) {   // nothing of this factor enters the reduced system (its cost is part of the fixed cost)
-        for (int e = ln; e < IMU_E_BH; e += 64) sc[IMU_IX + e] = -1.0;
-        return;
-    }
-    if (ln < 24) {   // J <- W J, one column per lane (kept in LDS for the products below)
-        double u[9];
-#pragma unroll
-        for (int q = 0; q < 9; q++) u[q] = U[q * 24 + ln];
-#pragma unroll
-        for (int q = 0; q < 9; q++) {
-            double s = 0.0;
-#pragma unroll
-            for (int kk = q; kk < 9; kk++) s += f.W[9 * q + kk] * u[kk];   // W is upper triangular (L^T)
-            sc[q * 24 + ln] = s;
-            U[q * 24 + ln] = s;
-        }
-    }
-    wave_lds_fence();
-    SADVIO_TS_IMU(59);
-    // H = J^T J (lower triangle, 300), g = J^T r (24) and where each entry goes in the reduced system
-    for (int e = ln; e < IMU_E_BH; e += 64) {
-        double v = 0.0;
-        int ix = -1;
-        if (e < IMU_E_G) {
-            int a = 0, b = e;
-            while (b >= a + 1) { b -= a + 1; a++; }
-#pragma unroll
-            for (int q = 0; q < 9; q++) v += U[q * 24 + a] * U[q * 24 + b];
-            const int ca = imu_col(a, fi, fj), cb = imu_col(b, fi, fj);
-            if (ca >= 0 && cb >= 0) ix = ca >= cb ? (ca << 16) | cb : (cb << 16) | ca;
-        } else {
-            const int a = e - IMU_E_G;
-#pragma unroll
-            for (int q = 0; q < 9; q++) v += U[q * 24 + a] * rs[q];
-            const int ca = imu_col(a, fi, fj);
-            if (ca >= 0) ix = ca << 16;
-        }
-        sc[IMU_H + e] = v;
-        sc[IMU_IX + e] = (double)ix;
-        if (fresh) emit(e, v, ix);
-    }
-    SADVIO_TS_IMU(60);
+    for (int q = 0; q < 3; q++) c += rba[q] * rba[q];
+    for (int q = 0; q < 3; q++) c += rbg[q] * rbg[q];
+    // sharded window: every rank must leave the step with the same bits (the ranks take the LM decisions independently), and
+    // the order of atomic adds depends on workgroup scheduling - the pair's cost goes to its row (the slot the
+    // linearisation at this candidate will fill with the same value) and k_rank_partials sums the rows in index order
+    if (P.world > 1) P.imu_scratch[(long long)buf * P.imu_scratch_stride + (long long)k * IMU_ROW + IMU_H + IMU_E_COST] = c;
+    else atomic_add_f64(&P.acc[so].cand_cost, c);
 }
 
 // The LINEARISATION of one IMU factor pair by a whole 256-thread workgroup (an extra workgroup of k_build, or of k_pf_eval<false>): the
@@ -2965,7 +2833,7 @@ __device__ __forceinline__ void imu_pair_lin_wg(const DevPtrs& P, int slot, int 
 }
 
 // Sparse prior factors that the solve evaluates itself (IMUPriordx, landmark priors / chains), ONE WAVE per listed factor, the
-// same split as imu_pair_eval (extra workgroups of the tile kernels, rows kept per delta buffer):
+// same split as imu_pair_cost / imu_pair_lin_wg (extra workgroups of the tile kernels, rows kept per delta buffer):
 //   COST_ONLY = true  (k_backsub, slot s): cost at the candidate x + delta (delta = the reduced step k_solve left in P.delta; the
 //                 landmark candidates are being written by the tiles of the same launch), added to the slot's cand_cost
 //   COST_ONLY = false (k_build, slot s)  : r, J into the scratch row of the candidate buffer of slot s - 1 (of x = 0 at slot 0)
@@ -3043,7 +2911,7 @@ __device__ __forceinline__ void sparse_factor_eval(const DevPtrs& P, int slot, i
         if (!LIN && ln == 0) {
             double c = 0.0;
             for (int q = 0; q < 15; q++) c += rs[q] * rs[q];
-            if (P.world > 1) sparse_cand_cost_slot(P, 1 - cur, k) = s_in ? c : 0.0;   // summed in index order by k_rank_partials (see imu_pair_eval)
+            if (P.world > 1) sparse_cand_cost_slot(P, 1 - cur, k) = s_in ? c : 0.0;   // summed in index order by k_rank_partials (see imu_pair_cost)
             else if (s_in) atomic_add_f64(&P.acc[so].cand_cost, c);
         }
     } else
@@ -3105,7 +2973,7 @@ __device__ __forceinline__ void sparse_factor_eval(const DevPtrs& P, int slot, i
 template <bool COST_ONLY>
 __device__ __forceinline__ void pose_factor_eval(const DevPtrs& P, int slot, int idx, int ln) {
     if (COST_ONLY) {
-        if (idx < P.n_imu_tot) imu_pair_eval<true>(P, slot, idx, ln);
+        if (idx < P.n_imu_tot) imu_pair_cost(P, slot, idx, ln);
         else sparse_factor_eval<true>(P, slot, P.sp_list[idx - P.n_imu_tot], ln);
     } else {
         if (idx < P.n_imu_tot) imu_pair_lin_wg(P, slot, idx, ln);

@@ -1233,7 +1233,7 @@ __device__ __forceinline__ void marg_accumulate_wave(double* A, double* b, int N
 }
 __global__ __launch_bounds__(64) void k_marg_small(DevPtrs P, const MargSmall* Sp, double* A, double* b, int N) {
     // the request (1.6 KB: the IMU constants, the priors) comes in with one coalesced copy; the IMU Jacobian is written straight into LDS
-    // (un-whitened) and whitened by 24 lanes, as in imu_pair_eval — as one lane's private 9 x 24 arrays it lived in scratch (3.6 KB per
+    // (un-whitened) and whitened by 24 lanes, as imu_pair_eval did — as one lane's private 9 x 24 arrays it lived in scratch (3.6 KB per
     // lane) and the kernel took 73 us
     __shared__ MargSmall S;
     const int t = threadIdx.x;
