@@ -2558,6 +2558,7 @@ __device__ __forceinline__ void imu_pair_cost(const DevPtrs& P, int slot, int k,
 //            by ONE workgroup were 2.3 us of every VIO step. Which row is added is the decision of the previous slot: accepted ->
 //            the row just evaluated (the candidate's), rejected -> the row of x kept in the other buffer. The decision is re-derived
 //            exactly as the tiles of this launch do (same bits: wave_sum_backsub_partials), or read if k_decide took it.
+static_assert(BUILD_THREADS == 256, "imu_pair_lin_wg deals an IMU pair over exactly four waves (k_build's extra workgroups, k_pf_eval<false>)");
 __device__ __forceinline__ void imu_pair_lin_wg(const DevPtrs& P, int slot, int k, int tid) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63, nthr = blockDim.x;
     __shared__ ImuDev f;
