@@ -1,0 +1,40 @@
+"""The driver reads ONE JSON line from bench.py's stdout. Libraries write to stdout as well (RCCL prints a banner through C stdio when a
+communicator is created; buffered, it used to land after the record): bench.py claims fd 1 for the record alone."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_stdout_carries_the_record_alone():
+    code = (
+        "import bench, ctypes\n"
+        "emit = bench._claim_stdout()\n"
+        "print('python noise')\n"
+        "ctypes.CDLL(None).printf(b'buffered C noise before the record\\n')\n"
+        "emit({'metric': 'x', 'value': 1.5})\n"
+        "ctypes.CDLL(None).printf(b'C noise after the record\\n')\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and json.loads(lines[0]) == {"metric": "x", "value": 1.5}
+    for noise in ("python noise", "buffered C noise before the record", "C noise after the record"):
+        assert noise in r.stderr
+
+
+def test_bench_line_fields_of_the_committed_record():
+    """profiles/r05_bench.json is a full line of the profiling box: the contract's fields, the roofline and the CPU baseline objects."""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert rec["dtype"] == "f64" and rec["vs_baseline"] is None and "workload" in rec["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rec["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in rec["cpu_baseline"], k
+    assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-4
+    assert abs(rec["value"] - rec["config"]["solves_per_step"] * rec["config"]["iterations_per_solve"] / (rec["ms_per_step"] * 1e-3)) / rec["value"] < 1e-3
