@@ -132,6 +132,27 @@ def test_pose_only_factors_as_extra_workgroups_and_as_kernels(backend_cls, oracl
         assert np.abs(got["1"][k] - got["0"][k]).max() <= 1e-9, k
 
 
+def test_vio_window_on_the_throughput_kernels(backend_cls, oracle_lib, monkeypatch):
+    """A VIO window on the throughput kernels (lm_kernels.h; by themselves they take batches of >= 65 536 landmarks, SADVIO_LM=1 forces
+    them): the IMU pairs are then linearised by k_pf_eval<false> as a kernel of its own, read the LM decision k_decide took and add
+    their entries to the reduced system themselves (imu_pair_lin_wg) - with accepted AND rejected steps in the solve."""
+    w = make_vio_window(n_kf=7, n_lmk=420, seed=31, lmk_perturb=0.3, rot_perturb_deg=2.0)
+    opts = capi.reference_options()
+    ref = oracle_lib.solve(w, opts)
+    assert ref["summary"].num_unsuccessful_steps > 0 and ref["summary"].num_successful_steps > 0
+    monkeypatch.setenv("SADVIO_LM", "1")
+    be = backend_cls(device=0, profile_kernels=True)
+    try:
+        be.set_windows([w])
+        s = be.solve(opts)[0]
+        d = be.get_deltas(0)
+        names = set(be.kernel_times())
+    finally:
+        be.close()
+    assert {"k_build_obs", "k_lm_pass", "k_pf_lin", "k_pf_cost"} <= names and "k_build" not in names, names
+    assert_match(s, d, ref)
+
+
 def test_batch_of_vio_windows(backend_cls, oracle_lib):
     """Several VIO windows in one submission (more tiles than the extra-workgroup variants are used for)."""
     ws = [make_vio_window(n_kf=8, n_lmk=3000, seed=40 + i) for i in range(9)]
