@@ -1445,7 +1445,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_step(double* __restrict
         // ---- the next diagonal block [s, s + WD) ----
         double* Im = (double*)smem;
         double (*XT)[WXS] = (double (*)[WXS])(Im + c16_size(WD) + WD + C16_WORK + 16 * (WD_T + 1));   // transposed slab, see k_wchol_syrk_la
-        constexpr int NX = WD * WD / SOLVE_THREADS, NTL = WD_T * (WD_T + 1) / 2 + WD_T, NW = SOLVE_THREADS / 64, TPW = (NTL + NW - 1) / NW;
+        // NTL: the block's 21 lower tiles, updated on the matrix cores. The right-hand side's tile row (one useful row of 16 per tile: 144 of
+        // 648 MFMAs when it rode the same product) is 96 dot products on the VALU, by the last 96 threads - waves that hold two tiles
+        // where the others hold three.
+        constexpr int NX = WD * WD / SOLVE_THREADS, NTL = WD_T * (WD_T + 1) / 2, NW = SOLVE_THREADS / 64, TPW = (NTL + NW - 1) / NW;
         double vx[NX], vl[NLT];
 #pragma unroll
         for (int u = 0; u < NLT; u++) { const int e = tid + u * SOLVE_THREADS; vl[u] = Lt_cur[min(e, WD_LT - 1)]; }
@@ -1457,19 +1460,20 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_step(double* __restrict
             vx[u] = (s + r < N) ? v : 0.0;
         }
         const double vy = y[c0 + min(tid, WD - 1)];
+        const int jr = tid - (SOLVE_THREADS - WD);                       // >= 0: this thread's column of the right-hand side
+        const double vrhs = y[min(s + max(jr, 0), N - 1)];
         d4 acc0[TPW];
 #pragma unroll
         for (int w = 0; w < TPW; w++) {
             const int t = min(wv + w * NW, NTL - 1);
             int I = 0, r = t;
-            while (r >= I + 1) { r -= I + 1; I++; }          // t < 21: lower tile (I, J) of the block; t = 21 + J: the right-hand-side tile (WD_T, J)
+            while (r >= I + 1) { r -= I + 1; I++; }          // lower tile (I, J) of the block
             const int J = r;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int i = 16 * I + lk + 4 * q, j = 16 * J + lr;
                 const double v = A[(long long)min(s + i, N - 1) * ld + min(s + min(j, i), N - 1)];
-                const double vr = y[min(s + j, N - 1)];
-                acc0[w][q] = I == WD_T ? ((lk + 4 * q == 0 && s + j < N) ? vr : 0.0) : (j <= i ? ((s + i < N) ? v : (i == j ? 1.0 : 0.0)) : 0.0);
+                acc0[w][q] = j <= i ? ((s + i < N) ? v : (i == j ? 1.0 : 0.0)) : 0.0;
             }
         }
         for (int e = tid; e < 256; e += SOLVE_THREADS) Im[(c16_tile(WD_T, WD_T) << 8) + e] = 0.0;   // the tile behind the right-hand side's last column block
@@ -1503,6 +1507,19 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_wchol_step(double* __restrict
             double* ct = Im + (c16_tile(I, J) << 8);     // (the factor's tiles that sat here were last read before the barrier above)
 #pragma unroll
             for (int q = 0; q < 4; q++) ct[lr * 16 + lk + 4 * q] = acc[q] + acc2[q];   // register q of lane (lr, lk) = C[lk + 4 q][lr]
+        }
+        if (jr >= 0) {
+            // rhs_next[j] = rhs[s + j] - sum_k z_k X[j][k]: row 0 of the tile (WD_T, j / 16) of the image, the tile's other rows zero
+            double v0 = s + jr < N ? vrhs : 0.0, v1 = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < WD; k += 2) {
+                v0 = __builtin_fma(-XT[k][WD], XT[k][jr], v0);
+                v1 = __builtin_fma(-XT[k + 1][WD], XT[k + 1][jr], v1);
+            }
+            double* ct = Im + (c16_tile(WD_T, jr >> 4) << 8) + (jr & 15) * 16;
+            ct[0] = v0 + v1;
+#pragma unroll
+            for (int r = 1; r < 16; r++) ct[r] = 0.0;
         }
         __syncthreads();
         if (dts) dts[3] = wall_clock64();
