@@ -537,10 +537,8 @@ __device__ __forceinline__ void pose_to_landmark_factor(const double* T0, const 
 // translation block uses exp(w_j)^T (:198).
 // WHITEN = false leaves the UN-whitened 9x24 Jacobian in J (the caller multiplies by W with many threads); r is
 // whitened in both cases.
-// What the Jacobian blocks of the IMU factor read from the residual part. In registers (a local) for the out-of-line copies; in LDS
-// for a one-lane evaluation of the whole factor (round 4's imu_pair_eval; imu_pair_lin_wg of kernels.h deals the same blocks over four waves): with the 60 values and every block's temporaries live
-// at once the body needs ~370 registers (256 + AGPR copies, 30 spills beside the tile code of k_build); read back from LDS block
-// by block it stays below 128.
+// What the Jacobian blocks of the IMU factor read from the residual part: a local (registers) for the one-lane copies below, LDS for
+// imu_pair_lin_wg (kernels.h), whose four waves produce and consume these values in phases.
 struct ImuMid {
     double Ri[9], Rj[9], dRj[9], RiRjT[9], dR[9], r_dr[3], a[3], cc[3], tj[3], jb[3];
 };
@@ -597,12 +595,10 @@ __device__ __forceinline__ void imu_residual_part(const ImuT& f, const double* T
     }
 }
 
-// U <- the UN-whitened 9 x 24 Jacobian, block after block. FENCED (m and U in LDS): a compiler barrier between the blocks keeps each
-// block's operands from being fetched before the previous block is stored.
-template <typename ImuT, bool FENCED>
+// U <- the UN-whitened 9 x 24 Jacobian, block after block
+template <typename ImuT>
 __device__ __forceinline__ void imu_jacobian_part(const ImuT& f, const double* Ti0, const double* dpi, const double* dpj, const ImuMid& m,
                                                   double* U) {
-#define SADVIO_IMU_BLOCK_FENCE() do { if (FENCED) asm volatile("" ::: "memory"); } while (0)
     const double dt = f.dt;
     for (int i = 0; i < 9 * 24; i++) U[i] = 0.0;
     double Jr_ri[9], A[9], B[9], S[9], RS[9];
@@ -611,36 +607,29 @@ __device__ __forceinline__ void imu_jacobian_part(const ImuT& f, const double* T
         so3_right_jacobian(m.r_dr, Jr_r);
         m3_inverse(Jr_r, Jr_ri);
     }
-    SADVIO_IMU_BLOCK_FENCE();
     // pose_i (:174-187)
     {
         double Jrwi[9];
         so3_right_jacobian(dpi, Jrwi);
         m3_mul(Jr_ri, m.Rj, A); m3_mul(A, Jrwi, B);
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[i * 24 + j] = B[3 * i + j];
-        SADVIO_IMU_BLOCK_FENCE();
-        so3_skew(m.a, S); m3_mul(m.Ri, S, RS); m3_mul(RS, Jrwi, B);
+            so3_skew(m.a, S); m3_mul(m.Ri, S, RS); m3_mul(RS, Jrwi, B);
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[(3 + i) * 24 + j] = -B[3 * i + j];
-        SADVIO_IMU_BLOCK_FENCE();
-        so3_skew(m.cc, S); m3_mul(m.Ri, S, RS); m3_mul(RS, Jrwi, B);
+            so3_skew(m.cc, S); m3_mul(m.Ri, S, RS); m3_mul(RS, Jrwi, B);
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { U[(6 + i) * 24 + j] = -B[3 * i + j]; U[(6 + i) * 24 + 3 + j] = Ti0[3 * i + j]; }
     }
-    SADVIO_IMU_BLOCK_FENCE();
     // pose_j (:190-200)
     {
         double Jrwj[9];
         so3_right_jacobian(dpj, Jrwj);
         m3_mul(Jr_ri, m.Rj, A); m3_mul(A, Jrwj, B);
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[i * 24 + 6 + j] = -B[3 * i + j];
-        SADVIO_IMU_BLOCK_FENCE();
-        double C1[9], C2[9];
+            double C1[9], C2[9];
         so3_skew(m.tj, S); m3_mul(m.RiRjT, S, C1); m3_mul(C1, m.Rj, C2); m3_mul(C2, Jrwj, B);
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[(6 + i) * 24 + 6 + j] = -B[3 * i + j];
     }
-    SADVIO_IMU_BLOCK_FENCE();
     m3_mul_t(m.Ri, m.dRj, B);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[(6 + i) * 24 + 9 + j] = -B[3 * i + j];
-    SADVIO_IMU_BLOCK_FENCE();
     // dv_i, dv_j, dba, dbg (:203-237)
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
         U[(3 + i) * 24 + 12 + j] = -m.Ri[3 * i + j];
@@ -651,13 +640,11 @@ __device__ __forceinline__ void imu_jacobian_part(const ImuT& f, const double* T
         U[(3 + i) * 24 + 21 + j] = -f.J_dv_bg[3 * i + j];
         U[(6 + i) * 24 + 21 + j] = -f.J_dp_bg[3 * i + j];
     }
-    SADVIO_IMU_BLOCK_FENCE();
     double Jrb[9], D1[9], D2[9];
     so3_right_jacobian(m.jb, Jrb);
     m3_mul_t(Jr_ri, m.dR, A);  // Jr^-1 dR^T
     m3_mul(A, Jrb, D1); m3_mul(D1, f.J_dR_bg, D2);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) U[i * 24 + 21 + j] = -D2[3 * i + j];
-#undef SADVIO_IMU_BLOCK_FENCE
 }
 
 template <typename ImuT, bool WHITEN = true>
@@ -669,7 +656,7 @@ __device__ __forceinline__ void imu_factor_body(const ImuT& f, const double* Ti0
     if (!J) return;
     double Uloc[WHITEN ? 9 * 24 : 1];  // un-whitened Jacobian
     double* U = WHITEN ? Uloc : J;
-    imu_jacobian_part<ImuT, false>(f, Ti0, dpi, dpj, m, U);
+    imu_jacobian_part<ImuT>(f, Ti0, dpi, dpj, m, U);
     if (WHITEN)
         for (int q = 0; q < 9; q++)
             for (int c = 0; c < 24; c++) {
