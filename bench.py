@@ -78,8 +78,27 @@ def _claim_stdout():
     return emit
 
 
-def main():
-    emit_record = _claim_stdout()
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): re-exec through torch.distributed.run,
+    one rank per GPU on 127.0.0.1, so that the plain command line yields the N-rank record (n_gpus = N, `sharded_window` through an
+    N-rank RCCL communicator) instead of a one-rank one. Fails - never degrades to fewer ranks - when the node has fewer GPUs."""
+    import socket
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs on this node (found {have}); there is no CPU fallback and no run on fewer ranks")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes: the host driver only supports dmabuf IPC
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -96,11 +115,21 @@ def main():
     ap.add_argument("--no-marginalize", action="store_true")
     ap.add_argument("--no-sharded", action="store_true", help="N = 1: skip the one-rank run of the sharded config-4 window (RCCL communicator of size 1)")
     ap.add_argument("--no-vio", action="store_true", help="skip the config-3 shaped VIO window leg (the profiled runs of scripts/prof_bench.sh: one k_solve variant per trace)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args, sys.argv[1:])      # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE = {world} ranks; pass the same number to both")
+    emit_record = _claim_stdout()
     import numpy as np
     import torch
 
@@ -591,7 +620,7 @@ def _marg_case():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from vio_helpers import make_vio_window
     from marg_helpers import with_lonely_landmarks
-    from test_oracle_marg import pre_marginalize
+    from sadvio_amd.synthetic import pre_marginalize
     w = with_lonely_landmarks(make_vio_window(n_kf=12, n_lmk=7200, seed=6), 11, 40)
     keep, marg = pre_marginalize(w, 11)
     keep = keep[:300]

@@ -357,6 +357,11 @@ typedef struct sadvio_marg_result {
  * with sadvio_ba_sparsify(.., J = NULL, ..), the next marginalisation folds it in with last_n_full = SADVIO_PRIOR_RESIDENT.
  * J / r0 may be NULL (the default path: no read-back); when given, J[n*n] receives the n_full x n prior Jacobian
  * (row-major, packed) and r0[n] the n_full prior residuals.
+ * ASYNCHRONOUS without a read-back: the call returns once the host has taken its route decisions; the tail kernels (packing of the
+ * prior, the swap into the handle) are stream work like everything that reads the prior afterwards (all on the handle's one stream,
+ * so the order is kept). A device fault in that tail therefore surfaces in the NEXT call of this handle that waits (solve,
+ * get_deltas, a read-back); SADVIO_DEBUG != 0 or cfg.profile_kernels make marginalize wait itself so that it is attributed here. A
+ * consumer on ANOTHER stream or handle must synchronise with this handle first (sadvio_ba_get_prior does).
  * Refused (SADVIO_E_INVALID_ARG) on a window sharded over several GPUs: each rank holds a landmark partition only. */
 int sadvio_ba_marginalize(sadvio_ba_handle *h, int32_t w, const sadvio_marg_request *rq, sadvio_marg_result *res,
                           int32_t *lmk_col, double *J, double *r0);
@@ -416,7 +421,8 @@ int sadvio_ba_marginalize_relative(sadvio_ba_handle *h, int32_t w, int32_t kf_a,
  * prior (sadvio_ba_set_dense_prior with host J / r0; round 5): every rank passes the whole prior and carries ALL of its kept landmarks
  * as variables of its window, with their observations on rank 0 only (the others list them without observations;
  * sadvio_amd/sharding.py builds such shards); rank 0 adds J^T J / J^T r to the all-reduced system, every rank evaluates the prior's
- * cost from row-block partials summed in index order (same bits on every rank). Factors that hold landmarks in the reduced system
+ * cost from row-block partials summed in index order (same bits on every rank). HARD PRECONDITION, checked on ranks != 0: a kept
+ * landmark has observations on rank 0 only (SADVIO_E_INVALID_ARG otherwise — they would be counted twice in the all-reduced system). Factors that hold landmarks in the reduced system
  * without a dense prior (Landmark3DPrior, landmark chains), the handle-resident prior (SADVIO_PRIOR_RESIDENT: marginalize is not
  * available on a sharded window), line landmarks and marginalize_relative are refused on a sharded window. Every rank calls set_windows with ITS landmarks, then solve(); per LM step the library all-reduces [S | g | diag | per-rank cost partials] once and the
  * step's candidate-cost partials once; every rank then solves the identical reduced system redundantly

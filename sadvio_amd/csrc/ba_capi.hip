@@ -161,15 +161,17 @@ struct UploadBatch {
         reserve(total);
         if (failed) { failed = false; items.clear(); used = 0; return hipErrorOutOfMemory; }
         hipError_t e = hipSuccess;
-        if (!ev && (e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
+        // every error return drops the queue: callers that do not reset() afterwards (marginalize, sparsify) must not re-send it
+        auto drop = [&](hipError_t err) { items.clear(); used = 0; return err; };
+        if (!ev && (e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return drop(e);
         if (dev_cap < total) {
             if (dev) { (void)hipStreamSynchronize(stream); (void)hipFree(dev); }   // an earlier scatter may still read it
             dev = nullptr; dev_cap = 0;
-            if ((e = hipMalloc((void**)&dev, total + total / 2)) != hipSuccess) return e;
+            if ((e = hipMalloc((void**)&dev, total + total / 2)) != hipSuccess) return drop(e);
             dev_cap = total + total / 2;
         }
         memcpy(pinned + data_bytes, items.data(), items.size() * sizeof(UploadItem));
-        if ((e = hipMemcpyAsync(dev, pinned, total, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(dev, pinned, total, hipMemcpyHostToDevice, stream)) != hipSuccess) return drop(e);
         hipLaunchKernelGGL(k_scatter_uploads, dim3(64, (unsigned)std::min<size_t>(items.size(), 64)), dim3(256), 0, stream, dev, (const UploadItem*)(dev + data_bytes), (int)items.size());
         e = hipEventRecord(ev, stream);
         in_flight = e == hipSuccess;
@@ -1176,6 +1178,9 @@ static int build_layout(sadvio_ba_handle* h) {
         HIP_TRY(h->d_lm_dt.alloc(2 * (size_t)LM_DT * n_rec));
         HIP_TRY(h->d_lm_sacc.alloc(2 * 4 * n_rec));
         HIP_TRY(hipMemsetAsync(h->d_lm_sacc.p, 0, sizeof(double) * 2 * 4 * n_rec, h->stream));   // slots of sub-blocks that do not exist stay zero
+        // k_build_obs sums a tile's key-frame record over EVERY sub-block slot, k_lm_pass writes one slot per work item: the slots
+        // nobody writes must be zero, and the buffer is grow-only (a re-layout with another tiling would leave stale records there)
+        HIP_TRY(hipMemsetAsync(h->d_lm_dt.p, 0, sizeof(double) * 2 * (size_t)LM_DT * n_rec, h->stream));
     }
     HIP_TRY(h->d_chunk_ob.alloc(chunk_ob.size())); HIP_TRY(h->d_chunk_lm.alloc(chunk_lm.size())); HIP_TRY(h->d_obs_lslot.alloc(obs_lslot.size()));
     h->up.add(h->d_chunk_ob.p, chunk_ob.data(), chunk_ob.size() * sizeof(int));
@@ -1520,6 +1525,15 @@ int sadvio_ba_set_dense_prior(sadvio_ba_handle* h, int32_t w, int32_t n_full, in
             for (int a = 0; a < 3; a++) {
                 if (used[lmk_col[i] + a]) { h->err = "set_dense_prior: overlapping column blocks"; return SADVIO_E_INVALID_ARG; }
                 used[lmk_col[i] + a] = 1;
+            }
+            // sharded window (sadvio_ba.h): the kept landmarks' observations live on rank 0 ONLY — every rank adds its kept rows to the
+            // all-reduced system, so observations present on two ranks would be counted twice without any error
+            if (h->world > 1 && h->rank != 0) {
+                const int32_t* op = h->src[w].v.lmk_obs_ptr;
+                if (op && op[lmk_index[i] + 1] != op[lmk_index[i]]) {
+                    h->err = "set_dense_prior: on a sharded window the kept landmarks carry their observations on rank 0 only (landmark " + std::to_string(lmk_index[i]) + " has some on rank " + std::to_string(h->rank) + ")";
+                    return SADVIO_E_INVALID_ARG;
+                }
             }
         }
         D.n_full = n_full; D.n = n; D.kf_keep = kf_keep; D.kf_col = kf_col;
@@ -2084,7 +2098,9 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         if (r0_out) HIP_TRY(hipMemcpyAsync(r0_out, PR.r0.p, sizeof(double) * nf, hipMemcpyDeviceToHost, h->stream));
     }
     // the prior stays on the device and everything that reads it is stream-ordered behind this call: only a read-back has to wait
-    if (nf > 0 && (J_out || r0_out)) HIP_TRY(hipStreamSynchronize(h->stream));
+    // (asynchronous contract, sadvio_ba.h: a fault of the tail kernels surfaces in the next call that waits on this handle's stream;
+    // SADVIO_DEBUG != 0 or cfg.profile_kernels wait here so that it is attributed to marginalize)
+    if ((nf > 0 && (J_out || r0_out)) || h->env.debug || h->cfg.profile_kernels) HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipGetLastError());
     return SADVIO_OK;
 }

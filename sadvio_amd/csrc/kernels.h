@@ -2186,7 +2186,9 @@ __global__ __launch_bounds__(256) void k_prior_r(DevPtrs P, int slot) {
         // a window sharded over several GPUs: every rank evaluates the prior (its variables - the kept frame and the kept landmarks - are
         // replicated) and must get the SAME BITS for the cost, or the ranks' LM decisions drift apart: per-block partials, summed in
         // index order by k_solve, instead of atomic adds in scheduling order
-        if (P.world > 1) dp_ptr(P, W, 7)[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        // (grid.x is the batch maximum of ceil(nf / 4): a block beyond THIS window's rows has no slot — its store would land in the
+        // other partial regions or in the next window's prior)
+        if (P.world > 1) { if ((int)blockIdx.x < (nf + 3) / 4) dp_ptr(P, W, 7)[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3]; }
         else atomic_add_f64(dp_ptr(P, W, 6), s_c[0] + s_c[1] + s_c[2] + s_c[3]);
     }
 }
@@ -2274,8 +2276,10 @@ __global__ __launch_bounds__(256) void k_prior_m(DevPtrs P, int slot) {
         if (P.world > 1) {   // summed in index order by k_rank_partials (see k_prior_r)
             double* pp = dp_ptr(P, W, 7);
             const int nb = (nf + 3) / 4;
-            pp[nb + blockIdx.x] = s_m[0] + s_m[1] + s_m[2] + s_m[3];
-            pp[2 * nb + blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+            if ((int)blockIdx.x < nb) {   // blocks beyond this window's rows (grid.x = the batch maximum) have no slot
+                pp[nb + blockIdx.x] = s_m[0] + s_m[1] + s_m[2] + s_m[3];
+                pp[2 * nb + blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+            }
         } else {
             atomic_add_f64(&acc->mcc, s_m[0] + s_m[1] + s_m[2] + s_m[3]);
             atomic_add_f64(&acc->cand_cost, s_c[0] + s_c[1] + s_c[2] + s_c[3]);

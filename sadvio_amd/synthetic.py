@@ -212,3 +212,19 @@ def pose_distance(Ta12, Tb12):
     Ra, Rb = np.asarray(Ta12[:9]).reshape(3, 3), np.asarray(Tb12[:9]).reshape(3, 3)
     c = np.clip(0.5 * (np.trace(Ra @ Rb.T) - 1), -1, 1)
     return float(np.arccos(c)), float(np.linalg.norm(np.asarray(Ta12[9:]) - np.asarray(Tb12[9:])))
+
+
+def pre_marginalize(w, kf0):
+    """Selection rule of Marginalization::preMarginalize (marginalization.cpp:50-88) on a flat window:
+    a landmark of frame0 is ignored unless it has exactly 2 features in frame0 (stereo); it is marginalised
+    when all its features are in frame0 ("lonely"), kept otherwise."""
+    keep, marg = [], []
+    for l in range(w.n_lmk):
+        o = slice(w.lmk_obs_ptr[l], w.lmk_obs_ptr[l + 1])
+        kfs = w.obs_kf[o]
+        if not (kfs == kf0).any():
+            continue
+        if (kfs == kf0).sum() != 2:
+            continue
+        (marg if (kfs == kf0).all() else keep).append(l)
+    return keep, marg

@@ -10,7 +10,7 @@ import numpy as np
 from sadvio_amd import capi, synthetic
 from oracle import oracle
 from marg_helpers import with_lonely_landmarks
-from test_oracle_marg import pre_marginalize
+from sadvio_amd.synthetic import pre_marginalize
 from vio_helpers import make_vio_window
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0

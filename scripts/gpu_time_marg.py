@@ -7,7 +7,7 @@ import numpy as np
 from sadvio_amd import capi
 from vio_helpers import make_vio_window
 from marg_helpers import with_lonely_landmarks
-from test_oracle_marg import pre_marginalize
+from sadvio_amd.synthetic import pre_marginalize
 w = with_lonely_landmarks(make_vio_window(n_kf=12, n_lmk=7200, seed=6), 11, 40)
 keep, marg = pre_marginalize(w, 11)
 keep = keep[:int(sys.argv[1]) if len(sys.argv) > 1 else 300]

@@ -7,7 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../../sadvio_amd/csrc/chol16.h"
+#include "chol16_rows.h"   // = sadvio_amd/csrc/chol16.h + the row-layout pivot block measured in round 6 (variant 2 below)
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 using namespace sadvio;
@@ -83,7 +83,7 @@ int main() {
         CK(hipMemset(dts, 0, 128 * 8));
         const size_t lds = (size_t)(sz + C16_WORK + 16 * nb + 16 * nb + 16) * 8;
       for (int var = 0; var < 2; var++) {
-        auto kern = var ? k_probe<1> : k_probe<0>;
+        auto kern = var ? k_probe<2> : k_probe<1>;   // 1: the 4-column MFMA steps (rounds 2 - 5), 2: the row-layout DPP pivot block (round 6)
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(1), dim3(512), lds, 0, dimg, N, dx, dts, dok, 3);
         CK(hipDeviceSynchronize());
@@ -102,13 +102,14 @@ int main() {
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(ts2, dts, 128 * 8, hipMemcpyDeviceToHost));
         }
-        printf("N=%3d gather=%d ok=%d max|x - x_host| %.2e (|x| %.2e) residual %.2e  solve %lld cyc = %.2f us", N, var, ok, err, mx, res, ts[31] - ts[30], (ts[31] - ts[30]) / 2400.0);
+        printf("N=%3d variant=%d ok=%d max|x - x_host| %.2e (|x| %.2e) residual %.2e  solve %lld cyc = %.2f us", N, var + 1, ok, err, mx, res, ts[31] - ts[30], (ts[31] - ts[30]) / 2400.0);
         if (N == 114 || N == 165) {
             printf("\n      block phases (cycles: replay | look-ahead+trailing):");
             const int nbc = c16_blocks(N);
             for (int kb = 0; kb < nbc && kb < 8; kb++) printf(" %lld|%lld", ts[1 + 2 * kb] - (kb ? ts[2 * kb] : ts[0]), ts[2 + 2 * kb] - ts[1 + 2 * kb]);
             printf("\n      last pivot block, per step [pairs gather chol y mfma Mpad]:");
             for (int st = 0; st < 4; st++) { printf(" |"); for (int q = 1; q <= 6; q++) printf(" %lld", ts2[32 + 8 * st + q] - ts2[32 + 8 * st + q - 1]); }
+            if (var == 1) printf("\n      row-layout pivot block 4: 4 steps %lld, 16 steps %lld, outputs %lld", ts2[32 + 3] - ts2[32], ts2[32 + 1] - ts2[32], ts2[32 + 2] - ts2[32 + 1]);
             printf("\n     ");
             printf("  first block %lld, back-substitution %lld", ts[0] - ts[30], ts[20] - ts[2 * (nbc < 8 ? nbc : 8)]);
         }

@@ -38,3 +38,19 @@ def test_bench_line_fields_of_the_committed_record():
         assert k in rec["cpu_baseline"], k
     assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-4
     assert abs(rec["value"] - rec["config"]["solves_per_step"] * rec["config"]["iterations_per_solve"] / (rec["ms_per_step"] * 1e-3)) / rec["value"] < 1e-3
+
+
+def test_gpus_n_without_n_gpus_refuses():
+    """`bench.py --gpus 2` on a node without two GPUs fails with "needs 2 GPUs" - it never prints a one-rank record."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return   # a multi-GPU box: the launch itself is covered by tests/test_gpu_multiprocess.py
+    assert r.returncode != 0 and "needs 2 GPUs" in r.stderr and r.stdout.strip() == ""
+
+
+def test_world_size_must_match_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, cwd=ROOT, timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE = 2" in r.stderr and r.stdout.strip() == ""

@@ -123,3 +123,30 @@ def test_multi_round_tiles_on_the_latency_kernels(backend_cls, oracle_lib, lm_en
     assert (s.iterations, s.termination) == (rs.iterations, rs.termination)
     assert_trace_matches(tr, ref["log"], rs.termination)
     assert np.abs(d["pose"] - ref["pose"]).max() <= TOL and np.abs(d["lmk"] - ref["lmk"]).max() <= TOL
+
+
+def test_relayout_of_a_handle_with_another_tiling(backend_cls, oracle_lib, lm_env):
+    """k_build_obs sums a tile's key-frame record over every sub-block slot while k_lm_pass writes one slot per
+    work item; the record buffer is grow-only, so a second set_windows on the SAME handle with a different tiling must not see the
+    first layout's records in the slots nobody writes any more. First a small batch (32-landmark tiles: one slot per tile, every
+    record written), then a batch large enough for 128-landmark tiles (two slots per tile, the second never written) on the same
+    handle: every window of the second solve must equal the oracle's."""
+    opts = capi.reference_options()
+    first = [make_window(n_kf=8, n_lmk=2600, obs_per_lmk=5, seed=300 + i) for i in range(3)]
+    w = make_window(n_kf=7, n_lmk=2600, obs_per_lmk=5, seed=310)
+    lm_env("1")
+    be = backend_cls(device=0, use_graph=False)
+    try:
+        be.set_windows(first)
+        be.solve(opts)
+        be.set_windows([w] * 80)                         # 208 000 landmarks: four landmark rounds per tile
+        ss = be.solve(opts)
+        out = [(ss[i], be.get_deltas(i), be.get_trace(i)) for i in (0, 41, 79)]
+    finally:
+        be.close()
+    ref = oracle_lib.solve(w, opts)
+    rs = ref["summary"]
+    for s, d, tr in out:
+        assert (s.iterations, s.termination) == (rs.iterations, rs.termination)
+        assert_trace_matches(tr, ref["log"], rs.termination)
+        assert np.abs(d["pose"] - ref["pose"]).max() <= TOL and np.abs(d["lmk"] - ref["lmk"]).max() <= TOL

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from sadvio_amd import capi
-from sadvio_amd.synthetic import T_to_12, inv4
+from sadvio_amd.synthetic import T_to_12, inv4, pre_marginalize  # noqa: F401 (re-exported: other tests import it from here)
 
 _ip = C.POINTER(C.c_int32)
 _dp = C.POINTER(C.c_double)
@@ -34,22 +34,6 @@ def toy_window():
         lmk_p=lmk, lmk_obs_ptr=np.array(ptr, dtype=np.int32), obs_kf=np.array(obs_kf, dtype=np.int32),
         obs_cam=np.array(obs_cam, dtype=np.int32), obs_meas=np.array(meas))
     return w
-
-
-def pre_marginalize(w, kf0):
-    """Selection rule of Marginalization::preMarginalize (marginalization.cpp:50-88) on a flat window:
-    a landmark of frame0 is ignored unless it has exactly 2 features in frame0 (stereo); it is marginalised
-    when all its features are in frame0 ("lonely"), kept otherwise."""
-    keep, marg = [], []
-    for l in range(w.n_lmk):
-        o = slice(w.lmk_obs_ptr[l], w.lmk_obs_ptr[l + 1])
-        kfs = w.obs_kf[o]
-        if not (kfs == kf0).any():
-            continue
-        if (kfs == kf0).sum() != 2:
-            continue
-        (marg if (kfs == kf0).all() else keep).append(l)
-    return keep, marg
 
 
 def run_marg(oracle_lib, w, kf_marg, keep, marg, kf_keep=-1, eig_cut="noise_floor"):
