@@ -339,7 +339,7 @@ struct sadvio_ba_handle {
     DevBuf<int> d_lm_sub;                 // work list of k_lm_pass (tile, sub-block), see DevPtrs
     int lm_n_sub = 0, lm_ksub = 1, lm_sub_per_item = 8;   // sub-blocks per work item of k_lm_pass (8 = the whole tile: MAX tile = 512 landmarks)   // throughput path: elimination records, per-landmark H_ll | g_l and per-tile key-frame sums (both per delta buffer)
     int lm_max_cam = 1;
-    int marg_stats[4] = {0, 0, 0, 0};     // Cholesky-form marginalisations: calls | took the unpivoted route | tried it and fell back | pivoted without a try
+    int marg_stats[4] = {0, 0, 0, 0};     // Cholesky-form marginalisations: calls | took the unpivoted route | tried it and fell back | calls whose rank the eigenvalue refinement lowered
     int lm_sub_obs = 0;                   // most observations of LM_PASS_THREADS consecutive landmarks of a tile (LDS staging of k_lm_pass)
     bool gemm_run4 = false;               // a tile on the MFMA path holds runs of 3 - 4 observations on one key-frame (k_build<.., RARE = true> only)
     bool lm_ok = false;                   // every tile is on the MFMA path and chunked: k_build_obs / k_lm_pass may run
@@ -1765,6 +1765,77 @@ int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int l
     return sweeps;
 }
 
+// The reference cuts by EIGENVALUE (lambda > 1e-12, marginalization.cpp:318-342, marginalization.hpp:58); the rank-revealing Cholesky
+// cuts by pivot, at the floor 1e-12 / n that never drops an eigenvalue above the cut — and therefore keeps directions whose
+// eigenvalue lies below it (lambda_min <= the last pivot d <= ~n lambda_min). For the trailing pivots inside that band the small
+// eigenvalues are evaluated the way the eigenvalue test means them: with G in pivot order (upper triangular) and x_s = G^-1 e_s for the
+// k trailing steps, the k smallest eigenvalues of A = G^T G are, to O(d / gap) relative, the reciprocals of the eigenvalues of X^T X
+// (A^-1 = G^-1 G^-T is dominated by those columns; k = 1: lambda = d / (1 + |w|^2), the Rayleigh quotient of the near-null vector) —
+// relatively accurate where an eigen-decomposition of A in double precision only returns noise of size eps |A|. Rows whose eigenvalue
+// is <= 1e-12 are dropped from the end. Host arithmetic on a read-back of G, on guarded calls only (a trailing pivot below
+// RANK_GUARD x 1e-12: one call in 25 in the sliding sequences). Returns the refined rank, -1 on a HIP error.
+constexpr double RANK_GUARD = 1e4;
+int refine_rank_by_eigenvalue(sadvio_ba_handle* h, const double* G, int n1, int nf) {
+    std::vector<int> step_of(n1);
+    if (hipMemcpyAsync(step_of.data(), h->d_jac_ints.p, sizeof(int) * (size_t)n1, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
+    std::vector<double> last((size_t)n1);
+    if (hipMemcpyAsync(last.data(), G + (size_t)(nf - 1) * n1, sizeof(double) * (size_t)n1, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    std::vector<int> col_of(nf, -1);                  // pivot column of every step
+    for (int c = 0; c < n1; c++) if (step_of[c] >= 0 && step_of[c] < nf) col_of[step_of[c]] = c;
+    for (int s = 0; s < nf; s++) if (col_of[s] < 0) return nf;    // (cannot happen: every step has its column)
+    const double d_last = last[col_of[nf - 1]] * last[col_of[nf - 1]];
+    if (!(d_last <= RANK_GUARD * 1e-12)) return nf;
+    // guarded: the factor in pivot order on the host
+    std::vector<double> Gh((size_t)nf * n1);
+    if (hipMemcpy(Gh.data(), G, sizeof(double) * (size_t)nf * n1, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    auto g = [&](int s, int t) { return Gh[(size_t)s * n1 + col_of[t]]; };   // upper triangular: zero for t < s
+    int k = 0;
+    while (k < nf && k < 8) { const double dv = g(nf - 1 - k, nf - 1 - k); if (dv * dv <= RANK_GUARD * 1e-12) k++; else break; }
+    std::vector<std::vector<double>> X(k, std::vector<double>(nf, 0.0));
+    for (int q = 0; q < k; q++) {       // G x = e_s by back-substitution, s = nf - 1 - q
+        const int sq = nf - 1 - q;
+        std::vector<double>& x = X[q];
+        x[sq] = 1.0 / g(sq, sq);
+        for (int i = sq - 1; i >= 0; i--) {
+            double acc = 0.0;
+            for (int t = i + 1; t <= sq; t++) acc += g(i, t) * x[t];
+            x[i] = -acc / g(i, i);
+        }
+    }
+    // eigenvalues of the k x k Gram matrix X^T X (cyclic Jacobi); lambda_small(A) = 1 / them
+    std::vector<double> B((size_t)k * k);
+    for (int a = 0; a < k; a++) for (int b = 0; b < k; b++) { double acc = 0.0; for (int i = 0; i < nf; i++) acc += X[a][i] * X[b][i]; B[(size_t)a * k + b] = acc; }
+    for (int sweep = 0; sweep < 30 && k > 1; sweep++) {
+        double off = 0.0;
+        for (int a = 0; a < k; a++) for (int b = a + 1; b < k; b++) {
+            const double apq = B[(size_t)a * k + b];
+            off += apq * apq;
+            if (apq == 0.0) continue;
+            const double th = (B[(size_t)b * k + b] - B[(size_t)a * k + a]) / (2.0 * apq);
+            const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0)), c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+            for (int i = 0; i < k; i++) { const double u = B[(size_t)i * k + a], v = B[(size_t)i * k + b]; B[(size_t)i * k + a] = c * u - sn * v; B[(size_t)i * k + b] = sn * u + c * v; }
+            for (int i = 0; i < k; i++) { const double u = B[(size_t)a * k + i], v = B[(size_t)b * k + i]; B[(size_t)a * k + i] = c * u - sn * v; B[(size_t)b * k + i] = sn * u + c * v; }
+        }
+        if (off <= 1e-30 * B[0] * B[0]) break;
+    }
+    int drop = 0;
+    for (int a = 0; a < k; a++) if (!(1.0 / B[(size_t)a * k + a] > 1e-12)) drop++;
+    if ((h->env.debug & 16384) || drop) {
+        h->marg_stats[3] += drop ? 1 : 0;
+        if (h->env.debug) {
+            fprintf(stderr, "[sadvio dbg] rank refinement: %d trailing pivot(s) below %.0e, eigenvalue estimates", k, RANK_GUARD * 1e-12);
+            for (int a = 0; a < k; a++) fprintf(stderr, " %.3e", 1.0 / B[(size_t)a * k + a]);
+            fprintf(stderr, " -> %d dropped (rank %d of %d)\n", drop, nf - drop, n1 - 1);
+        }
+    }
+    if (drop) {   // the packing kernels read the rank from the device (k_marg_pack_chol)
+        const int r2 = nf - drop;
+        if (hipMemcpy(h->d_jac_ints.p + n1, &r2, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    }
+    return nf - drop;
+}
+
 // eigenvalue cut of the pseudo-inverse / rank-revealing decomposition (sadvio_ba.h: SADVIO_EIG_CUT_*): the reference's absolute
 // 1e-12 (marginalization.hpp:58, applied at marginalization.cpp:237,322), or that constant with the rounding-noise floor
 // n eps lambda_max (see oracle/marg.c)
@@ -2028,7 +2099,10 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         // dependent set is lambda / v_i^2, v = the null vector - any size), so the noise-floor mode, whose point is a reliable
         // numerical rank, always takes the pivoted route; under the absolute 1e-12 cut both routes keep every direction whose pivot is
         // positive, as the reference's eigenvalue test does.
-        if (!h->env.marg_pivoted && rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE && (rq->last_n_full != 0 || h->env.marg_unpivoted)) {
+        // ... and only behind a previous prior of FULL rank (round 6): a prior that dropped a direction hands its near-null direction on to
+        // the next Ak, where the unpivoted pivots do not show it (measured, step 13 of the VIO dense sliding sequence: eigenvalue 1.1e-14 —
+        // below the reference's cut — under pivots that all pass; profiles/r06_rank_arbiter.txt).
+        if (!h->env.marg_pivoted && rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE && ((rq->last_n_full != 0 && nfl == nl) || h->env.marg_unpivoted)) {
             // A prior that carries an earlier prior is normally of full rank: then the factor needs no pivoting and the wide-panel
             // solver of the dense reduced systems (dense_chol.h: k_wchol_diag16 + k_wchol_step, one launch per 96 columns, bk riding
             // along as its right-hand side) delivers L and z = L^-1 bk in a third of the pivoted factorisation's time. Every pivot is
@@ -2054,6 +2128,11 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         nf = run_pchol(h, M.V.p, n1, M.G.p, pchol_tau(n, rq->eig_cut_mode), false);
         if (nf < 0) { h->err = "marginalize: HIP error in the pivoted Cholesky"; return SADVIO_E_HIP; }
         if (nf > n) nf = n;
+        if (rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE && nf > 0) {
+            const int rc = refine_rank_by_eigenvalue(h, M.G.p, n1, nf);
+            if (rc < 0) { h->err = "marginalize: HIP error in the rank refinement"; return SADVIO_E_HIP; }
+            nf = rc;
+        }
         }
         if (!unpivoted && nf > 0) {
             const long long cnt = (long long)nf * n1;

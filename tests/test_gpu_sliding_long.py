@@ -41,17 +41,21 @@ def cols_in(w, pr):
     return np.array(idx, dtype=np.int32), np.array(col, dtype=np.int32)
 
 
-def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS):
+def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS, run=("dev", "ora"), hook=None, n_win=N_WIN, n_kf=N_KF, n_lmk=1100, length=17.0, resync=None, keep_cap=None):
+    """run: the sides to propagate ("ora" alone runs on a CPU: scripts/rank_arbiter.py); hook(step, side, w, g, args): called after every
+    marginalisation; resync(step, log_row, sides, prior, be) -> bool: called after a step whose prior ranks differ, may align the two
+    sides again (see test_25_key_frame_steps)."""
+    N_WIN_, N_KF_ = n_win, n_kf
     if vio:
-        W = make_vio_window(n_kf=N_KF, n_lmk=1100, seed=977, obs_per_lmk=6, length=17.0)
+        W = make_vio_window(n_kf=N_KF_, n_lmk=n_lmk, seed=977, obs_per_lmk=6, length=length)
     else:
-        W = synthetic.make_window(n_kf=N_KF, n_lmk=1100, seed=977, obs_per_lmk=6, length=17.0)
-        W.kf_vel = W.kf_ba = W.kf_bg = np.zeros((N_KF, 3)); W.imu_factors = []
+        W = synthetic.make_window(n_kf=N_KF_, n_lmk=n_lmk, seed=977, obs_per_lmk=6, length=length)
+        W.kf_vel = W.kf_ba = W.kf_bg = np.zeros((N_KF_, 3)); W.imu_factors = []
     opts = capi.reference_options()
     init = {"T": W.kf_T_f_w.copy(), "p": W.lmk_p.copy(), "v": np.array(W.kf_vel, dtype=float).copy(), "ba": np.array(W.kf_ba, dtype=float).copy(),
             "bg": np.array(W.kf_bg, dtype=float).copy()}
     sides = {"dev": copy.deepcopy(init), "ora": copy.deepcopy(init)}
-    be = backend_cls(device=0)
+    be = backend_cls(device=0) if "dev" in run else None
     oldest = W.n_kf - 1
     mk_win = sub_window if vio else vo_sub_window
     prior = {"dev": None, "ora": None}
@@ -59,18 +63,21 @@ def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS):
         J0 = np.diag(np.concatenate([10.0 * np.ones(6), 5.0 * np.ones(3), 20.0 * np.ones(3), 50.0 * np.ones(3)]))
         first = {"kf_id": int(W.kf_id[oldest]), "kf_col": 0, "lmk_id": [], "lmk_col": []}
         prior = {"dev": dict(first), "ora": dict(first, J=J0, r0=np.zeros(15))}
-        be.set_prior(J0, np.zeros(15))
+        if be is not None:
+            be.set_prior(J0, np.zeros(15))
     log = []
     for step in range(n_steps):
-        kfs = list(range(oldest - N_WIN + 1 - step, oldest + 1 - step))      # newest first; the last entry is frame0 of this step
+        kfs = list(range(oldest - N_WIN_ + 1 - step, oldest + 1 - step))      # newest first; the last entry is frame0 of this step
         frame0, frame1 = len(kfs) - 1, len(kfs) - 2
         results, ranks = {}, {}
-        for side in ("dev", "ora"):
+        for side in run:
             st = sides[side]
             w, keep_l = mk_win(W, st, kfs)
             if step == 0:
                 w.pose_priors = [(frame0, W.truth["T_f_w"][kfs[frame0]].copy(), 100.0 * np.ones(6))]
             keep, marg = pre_marginalize(w, frame0)
+            if keep_cap is not None:      # the shipped configuration holds ~300 landmarks in the prior (config.yaml:108 features per frame, most of them re-observed)
+                keep = keep[:keep_cap]
             pr = prior[side]
             if pr is not None:      # landmarks the previous prior holds are kept if they are still in the window (marginalization.cpp:116-139)
                 for lid in pr["lmk_id"]:
@@ -96,6 +103,8 @@ def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS):
                 g = oracle_lib.marginalize(w, **args)
                 fs = oracle_lib.sparsify(w, g, vio=vio) if sparsif else None
             assert g is not None and (not sparsif or fs is not None), (step, side)
+            if hook is not None:
+                hook(step, side, w, g, args)
             ranks[side] = (int(g["n_full"]), int(g["n"]))
             new_prior = {"kf_id": int(w.kf_id[frame1]), "kf_col": g["kf_col"], "lmk_id": [int(w.lmk_id[l]) for l in keep], "lmk_col": list(g["lmk_col"])}
             if side == "ora":
@@ -140,46 +149,57 @@ def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS):
                 r = oracle_lib.solve(w2, opts, dense_prior=w2.dense_prior)
                 results[side] = (r["summary"].iterations, r["summary"].termination, r["summary"].final_cost, r)
             (apply_deltas if vio else apply_vo)(st, kfs2, keep_l2, results[side][3])
+        if len(run) < 2:
+            (it, term, cost, _), = results.values()
+            log.append(dict(step=step, it=(it, it), term=(term, term), cost=cost, rank=ranks[run[0]]))
+            continue
         (it_d, term_d, cost_d, dd), (it_o, term_o, cost_o, do) = results["dev"], results["ora"]
         log.append(dict(step=step, it=(it_d, it_o), term=(term_d, term_o), cost_rel=abs(cost_d - cost_o) / cost_o, dpose=float(np.abs(dd["pose"] - do["pose"]).max()),
-                        rank_dev=ranks["dev"], rank_ora=ranks["ora"], drift=float(np.abs(sides["dev"]["T"] - sides["ora"]["T"]).max())))
-    stats = be.marg_stats()
-    be.close()
+                        rank_dev=ranks["dev"], rank_ora=ranks["ora"], drift=float(np.abs(sides["dev"]["T"] - sides["ora"]["T"]).max()), resynced=False))
+        if resync is not None and ranks["dev"] != ranks["ora"]:
+            log[-1]["resynced"] = bool(resync(step, log[-1], sides, prior, be))
+    stats = be.marg_stats() if be is not None else None
+    if be is not None:
+        be.close()
     return log, stats, sides
+
+
+def check_sequence(log, stats, sides, tag, min_unpivoted):
+    print(tag, "termination iteration per step (device):", [r["it"][0] for r in log])
+    print(tag, "oracle where it differs:", [(r["step"], r["it"]) for r in log if r["it"][0] != r["it"][1]])
+    print(tag, "prior rank (n_full, n) per step where it is deficient:", [(r["step"], r["rank_dev"], r["rank_ora"]) for r in log if r["rank_dev"][0] != r["rank_dev"][1] or r["rank_dev"] != r["rank_ora"]])
+    print(tag, f"marginalisation routes on the device: {stats}; worst per-step |dpose| {max(r['dpose'] for r in log):.2e}, cost {max(r['cost_rel'] for r in log):.2e}, "
+               f"drift of the two trajectories after {len(log)} steps {log[-1]['drift']:.2e}")
+    # STRICT bars on every step: the device decides the prior's rank by the reference's criterion - eigenvalues
+    # above 1e-12 (marginalization.cpp:318-342), evaluated with relative accuracy on the trailing pivots of the rank-revealing Cholesky
+    # (ba_capi.hip: refine_rank_by_eigenvalue) - and so keeps the same directions as the oracle's eigen-decomposition, also at the two
+    # steps of the VIO dense sequence where an eigenvalue lies below the cut (exact values 3e-23 and 1.1e-14:
+    # profiles/r06_rank_arbiter.txt). Round 5 ran this test with a loosened bar after step 13 (228 against 227 directions).
+    for r in log:
+        assert r["rank_dev"] == r["rank_ora"], r
+        assert r["it"][0] == r["it"][1] and r["term"][0] == r["term"][1], r
+        assert r["cost_rel"] <= 1e-7, r
+        assert r["dpose"] <= 1e-6, r
+    assert stats["unpivoted"] >= min_unpivoted, stats
+    assert log[-1]["drift"] <= 1e-6
+    # landmarks: relative to max(1 m, distance) (near-zero parallax sends some of them kilometres away on both sides alike)
+    mag = np.maximum(1.0, np.abs(sides["ora"]["p"]).max(axis=1))
+    rel = np.abs(sides["dev"]["p"] - sides["ora"]["p"]).max(axis=1) / mag
+    worst = int(rel.argmax())
+    print(tag, f"landmarks: 99th percentile of the relative difference {np.percentile(rel, 99):.2e}, worst {rel[worst]:.2e} (landmark {worst}, {mag[worst]:.1f} m away, "
+               f"{int((rel > 1e-6).sum())} of {len(rel)} above 1e-6)")
+    far = mag > 1e3          # runaway landmarks: depth unobservable (near-zero parallax), the optimisation itself sends them kilometres away
+    print(tag, f"landmarks within 1 km: worst {rel[~far].max():.2e}; beyond ({int(far.sum())}): worst {rel[far].max() if far.any() else 0.0:.2e}")
+    assert np.percentile(rel, 99) <= 1e-6
+    assert rel[~far].max() <= 1e-6
+    assert not far.any() or rel[far].max() <= 1e-3
 
 
 @pytest.mark.parametrize("vio,sparsif", [(True, False), (True, True), (False, False), (False, True)])
 def test_25_key_frame_steps(backend_cls, oracle_lib, vio, sparsif):
     log, stats, sides = run_sequence(backend_cls, oracle_lib, vio, sparsif, "reference")
     tag = f"[sliding {'VIO' if vio else 'VO'} {'sparsified' if sparsif else 'dense'}]"
-    print(tag, "termination iteration per step (device):", [r["it"][0] for r in log])
-    print(tag, "oracle where it differs:", [(r["step"], r["it"]) for r in log if r["it"][0] != r["it"][1]])
-    print(tag, "prior rank (n_full, n) device / oracle where they differ:", [(r["step"], r["rank_dev"], r["rank_ora"]) for r in log if r["rank_dev"] != r["rank_ora"]])
-    print(tag, f"marginalisation routes on the device: {stats}; worst per-step |dpose| {max(r['dpose'] for r in log):.2e}, cost {max(r['cost_rel'] for r in log):.2e}, "
-               f"drift of the two trajectories after {len(log)} steps {log[-1]['drift']:.2e}")
-    # Under the reference's absolute 1e-12 cut (marginalization.hpp:58) the RANK of a prior is ill-posed when an eigenvalue of Ak sits
-    # at the cut: the oracle's eigen-decomposition and the device's pivoted Cholesky may then keep a different number of directions
-    # (measured on the VIO dense sequence: step 13, 227 against 228 of 228 — the one step whose unpivoted attempt fell back). The
-    # direction in question carries ~1e-12 of information, the two priors differ by that much, and the solves that follow inherit
-    # it: cost 1.3e-6 relative, poses 4e-6, identical iteration counts and terminations on all 25 steps, 2.5e-6 of drift at the end.
-    # Strict bars up to the first such step, the measured envelope (x 4) after it.
-    loose = False
-    for r in log:
-        loose = loose or r["rank_dev"] != r["rank_ora"]
-        assert r["it"][0] == r["it"][1] and r["term"][0] == r["term"][1], r
-        assert r["cost_rel"] <= (5e-6 if loose else 1e-7), r
-        assert r["dpose"] <= (1.6e-5 if loose else 1e-6), r
-    assert sum(r["rank_dev"] != r["rank_ora"] for r in log) <= 2
-    assert stats["fell_back"] <= 2 and stats["unpivoted"] >= len(log) - 3, stats
-    assert log[-1]["drift"] <= 1e-5
-    # landmarks: relative for the runaway ones (near-zero parallax: the optimisation itself sends them kilometres away on both sides).
-    # Nearly all agree to better than 1e-6; the worst one is a low-parallax landmark whose depth both sides leave almost unconstrained -
-    # after the rank-mismatch step of the VIO dense sequence the two priors differ by ~1e-12 of information and that landmark moves
-    # by 5e-3 of its distance (measured; every pose stays within 4e-6).
-    mag = np.maximum(1.0, np.abs(sides["ora"]["p"]).max(axis=1))
-    rel = np.abs(sides["dev"]["p"] - sides["ora"]["p"]).max(axis=1) / mag
-    worst = int(rel.argmax())
-    print(tag, f"landmarks: 99th percentile of the relative difference {np.percentile(rel, 99):.2e}, worst {rel[worst]:.2e} (landmark {worst}, {mag[worst]:.1f} m away, "
-               f"{int((rel > 1e-6).sum())} of {len(rel)} above 1e-6)")
-    assert np.percentile(rel, 99) <= (1e-5 if loose else 1e-6)   # measured after the rank-mismatch step: 8.5e-7
-    assert rel.max() <= (2e-2 if loose else 1e-4)
+    # routes: the unpivoted wide-panel factorisation except for first calls and behind a prior that dropped a direction
+    check_sequence(log, stats, sides, tag, len(log) - 4)
+    # (the shipped window size - 12 key-frames, n = 915 - runs three such steps against the oracle in tests/test_gpu_sliding.py; the oracle's
+    # eigen-decomposition takes minutes per step there, which is what bounds the length of that sequence, not the device)
