@@ -133,3 +133,13 @@ def check_prior_against_fixture(g, z, n_keep, rtol=1e-8):
     assert np.abs(gg + z[p + "bk"]).max() <= 1e-6 * max(np.abs(z[p + "bk"]).max(), np.sqrt(scale))
     JJt = g["J"] @ g["J"].T
     assert np.abs(JJt - np.diag(np.diag(JJt))).max() <= rtol * scale  # rows orthogonal: J = Lambda^1/2 U^T
+
+
+def lmk_err(a, b):
+    """Worst landmark difference, relative to max(1 m, |delta|) per landmark: a landmark that moves by less than a metre has to meet the
+    bar ABSOLUTELY (the pose bar, 1e-6), one the optimisation itself sends far away (near-zero parallax: unobservable depth) relatively."""
+    import numpy as np
+    a, b = np.asarray(a, dtype=float).reshape(-1, 3), np.asarray(b, dtype=float).reshape(-1, 3)
+    if a.size == 0:
+        return 0.0
+    return float((np.abs(a - b).max(axis=1) / np.maximum(1.0, np.abs(b).max(axis=1))).max())

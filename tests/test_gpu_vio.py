@@ -9,6 +9,8 @@ from sadvio_amd.synthetic import T12_to_4, T_to_12, exp_so3, inv4
 from test_oracle_imu import ACC, GYR, _free_fall_chain, _vio_window
 from vio_helpers import make_vio_window
 
+from golden_util import lmk_err
+
 pytestmark = pytest.mark.gpu
 
 
@@ -30,7 +32,7 @@ def assert_match(s, d, ref, tol=1e-6):
     for k in ("pose", "dv", "dba", "dbg"):
         assert np.abs(d[k] - ref[k]).max() <= tol, k
     if ref["lmk"].size:
-        assert np.abs(d["lmk"] - ref["lmk"]).max() <= 10 * tol
+        assert lmk_err(d["lmk"], ref["lmk"]) <= tol
 
 
 def test_reference_vi_test_pose_recovery(backend_cls, oracle_lib):
