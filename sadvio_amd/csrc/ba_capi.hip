@@ -244,7 +244,7 @@ struct EnvCfg {
     int tile_rounds = 0, lm_subs = 0, band_c = 0;   // 0: not set
     double jacobi_tol = 1e-14;
     bool marg_last_small = false, marg_eig_mm = false, marg_pivoted = false, marg_unpivoted = false, pchol_swap = false, pchol_strict = false,
-         jacobi_b4 = false, jacobi_plain = false, no_lpt = false, no_fork = false, no_bcr = false, wd_old = false, wd_nola = false, wd_r3 = false,
+         jacobi_b4 = false, jacobi_plain = false, no_lpt = false, no_pre = false, no_fork = false, no_bcr = false, wd_old = false, wd_nola = false, wd_r3 = false,
          wd_back1 = false, imu_items = false;
     void read() {
         auto on = [](const char* k) { return getenv(k) != nullptr; };
@@ -254,7 +254,7 @@ struct EnvCfg {
         if (const char* e = getenv("SADVIO_JACOBI_TOL")) jacobi_tol = atof(e);
         marg_last_small = on("SADVIO_MARG_LAST_SMALL"); marg_eig_mm = on("SADVIO_MARG_EIG_MM"); marg_pivoted = on("SADVIO_MARG_PIVOTED");
         marg_unpivoted = on("SADVIO_MARG_UNPIVOTED"); pchol_swap = on("SADVIO_PCHOL_SWAP"); pchol_strict = on("SADVIO_PCHOL_STRICT");
-        jacobi_b4 = on("SADVIO_JACOBI_B4"); jacobi_plain = on("SADVIO_JACOBI_PLAIN"); no_lpt = on("SADVIO_NO_LPT"); no_fork = on("SADVIO_NO_FORK");
+        jacobi_b4 = on("SADVIO_JACOBI_B4"); jacobi_plain = on("SADVIO_JACOBI_PLAIN"); no_lpt = on("SADVIO_NO_LPT"); no_pre = on("SADVIO_NO_PRE"); no_fork = on("SADVIO_NO_FORK");
         no_bcr = on("SADVIO_NO_BCR"); wd_old = on("SADVIO_WD_OLD"); wd_nola = on("SADVIO_WD_NOLA"); wd_r3 = on("SADVIO_WD_R3"); wd_back1 = on("SADVIO_WD_BACK1");
         imu_items = on("SADVIO_IMU_ITEMS");   // A/B: the IMU pairs' entries through k_solve's item loop (the pre-0.5 path) on one device too
     }
@@ -331,6 +331,8 @@ struct sadvio_ba_handle {
     DevBuf<double> d_lmk_p, d_xl, d_s_lmk;
     DevBuf<unsigned char> d_lmk_const;
     DevBuf<int> d_lmk_ob, d_lmk_oe, d_obs_kf, d_obs_cam, d_tile_kf, d_tile_row;
+    DevBuf<int> d_pre_lane, d_pre_kf;     // first-round packets of the latency kernels (kernels.h: DevPtrs::pre_lane), few-tile submissions only
+    bool pre_ok = false, pre_dirty = false;
     DevBuf<unsigned char> d_obs_slot, d_obs_lslot;
     DevBuf<int> d_chunk_ob, d_chunk_lm, d_tile_perm;   // chunk tables of the throughput kernels (lm_kernels.h)
     DevBuf<int> d_jac_ints;               // pivoting / rank of the Cholesky-preconditioned Jacobi
@@ -431,6 +433,7 @@ DevPtrs make_ptrs(sadvio_ba_handle* h, const SolveOpts& o, int state_stride) {
     P.lmk_ob = h->d_lmk_ob.p; P.lmk_oe = h->d_lmk_oe.p;
     P.obs_kf = h->d_obs_kf.p; P.obs_cam = h->d_obs_cam.p; P.obs_meas = h->d_obs_meas.p;
     P.obs_slot = h->d_obs_slot.p; P.tile_kf = h->d_tile_kf.p; P.tile_row = h->d_tile_row.p;
+    P.pre_lane = h->pre_ok ? (const int4*)h->d_pre_lane.p : nullptr; P.pre_kf = h->pre_ok ? (const int2*)h->d_pre_kf.p : nullptr;
     P.ptab = h->d_ptab.p; P.ptab_stride = (long long)POSE_TAB * h->n_kf_tot;
     P.priors = h->d_priors.p; P.prior_lin = h->d_prior_lin.p; P.prior_lin_stride = (long long)h->priors.size() * PRIOR_LIN; P.n_prior_tot = (int)h->priors.size();
     P.imus = h->d_imus.p; P.imu_scratch = h->d_imu_scratch.p; P.imu_scratch_stride = (long long)h->imus.size() * IMU_ROW;
@@ -707,6 +710,11 @@ int upload_priors(sadvio_ba_handle* h) {
     for (size_t w = 0; w < h->wins.size(); w++) wd[w] = h->wins[w].d;
     h->up.add(h->d_win.p, wd.data(), wd.size() * sizeof(WinDev));
     HIP_TRY(h->up.flush(h->stream));  // one staged copy + scatter for everything queued since the layout build began
+    if (h->pre_ok && h->pre_dirty) {
+        hipLaunchKernelGGL(k_pre_packets, dim3((unsigned)h->tiles.size()), dim3(BUILD_THREADS), 0, h->stream, h->d_tiles.p, h->d_lmk_ob.p, h->d_lmk_oe.p, h->d_tile_kf.p,
+                           h->d_kf_fidx.p, (int4*)h->d_pre_lane.p, (int2*)h->d_pre_kf.p);
+        h->pre_dirty = false;
+    }
     return SADVIO_OK;
 }
 
@@ -1237,6 +1245,17 @@ static int build_layout(sadvio_ba_handle* h) {
     if (lmk_b) { UP(h->d_lmk_p, lmk_p); }
     UP(h->d_lmk_ob, lmk_ob); UP(h->d_lmk_oe, lmk_oe); UP(h->d_obs_kf, obs_kf);
     UP(h->d_obs_cam, obs_cam); UP(h->d_obs_meas, obs_meas); UP(h->d_tile_kf, tile_kf); UP(h->d_tile_row, tile_row); UP(h->d_obs_slot, obs_slot);
+    // First-round packets (round 6): what a lane of k_build / k_backsub needs to address the inputs of its tile's FIRST landmark round,
+    // laid out by (tile, lane) so that the loads hang on blockIdx alone: | landmark | observation (-1: none) | observations of the
+    // landmark + valid flag | first observation of the landmark |, and per tile the first PRE_KF key-frames of its list with their free
+    // index. Without them the kernel's opening is a chain tile record -> CSR range / key-frame list -> observation / pose table
+    // (three dependent round trips of ~1 us each on a single window); with them two. Few-tile submissions only (the single-window /
+    // small-batch regime the latency kernels serve; 4 KB per tile).
+    h->pre_ok = !h->tiles.empty() && h->tiles.size() <= PRE_MAX_TILES && !h->env.no_pre;
+    if (h->pre_ok) {   // built on the device behind the upload (k_pre_packets, upload_priors): 1 MB of host stores + PCIe otherwise
+        HIP_TRY(h->d_pre_lane.alloc((size_t)4 * BUILD_THREADS * h->tiles.size())); HIP_TRY(h->d_pre_kf.alloc((size_t)2 * PRE_KF * h->tiles.size()));
+        h->pre_dirty = true;
+    }
 #undef UP
     h->h_lmk_const_user = lmk_const; h->user_lmk_const = h->has_lmk_const;
     h->h_lmk_ob = lmk_ob; h->h_lmk_oe = lmk_oe; h->h_kf_fidx = kf_fidx; h->h_obs_kf = obs_kf;

@@ -179,6 +179,8 @@ constexpr int SOLVE_THREADS = 512;
 constexpr int SOLVE_KFC_STRIDE = 32; // doubles per parked key-frame: free index | x 6 | T0 12 | v, ba, bg at x 9
 constexpr int SOLVE_KFC = 32;        // k_solve<0>: key-frames / priors whose back-half inputs are parked in LDS across the factorisation
 constexpr int PRIOR_LIN = 28;        // doubles of a pose prior's linearisation record: g 6 | H lower 21 | |r|^2
+constexpr int PRE_KF = 8;            // key-frames of a tile's list carried by its first-round packet (covers the first 256 / POSE_TAB = 6 tables)
+constexpr int PRE_MAX_TILES = 1024;  // submissions with more tiles run without the packets (batches: the throughput regime)
 constexpr int MAX_LDS_NP = 174;     // packed lower triangle incl. rhs row + panel strip: ~150 KB
 
 }  // namespace sadvio

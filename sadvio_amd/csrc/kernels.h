@@ -35,6 +35,11 @@ struct DevPtrs {
     const unsigned char* obs_slot;  // index of the observation's key-frame in its tile's list
     const int* tile_kf;             // per-tile key-frame lists (global indices)
     const int* tile_row;            // matching row in the tile's LDS system (6 * rank among free) or -1
+    // first-round packets (ba_capi.hip: build_layout; null for submissions of more than PRE_MAX_TILES tiles): per (tile, lane)
+    // | landmark | observation or -1 | observations of the landmark + (1 << 16 if the lane's landmark exists) | the landmark's first observation |,
+    // per (tile, k < PRE_KF) | global key-frame or -1 | its free index |: the opening loads of k_build / k_backsub hang on blockIdx alone
+    const int4* pre_lane;
+    const int2* pre_kf;
     double* ptab;                   // [2][n_kf_tot][POSE_TAB] pose tables of the two delta buffers
     long long ptab_stride;
     const PriorDev* priors;
@@ -487,6 +492,25 @@ __host__ __device__ inline size_t tile_tables_bytes(int n_kf) {
     return (b + 15) & ~(size_t)15;
 }
 
+// First-round packets (DevPtrs::pre_lane / pre_kf): one launch per layout, behind its upload. What a lane of k_build / k_backsub needs
+// to address the inputs of its tile's FIRST landmark round, laid out by (tile, lane) so that those loads hang on blockIdx alone.
+__global__ __launch_bounds__(BUILD_THREADS) void k_pre_packets(const Tile* __restrict__ tiles, const int* __restrict__ lmk_ob, const int* __restrict__ lmk_oe,
+                                                               const int* __restrict__ tile_kf, const int* __restrict__ kf_fidx, int4* __restrict__ pre_lane,
+                                                               int2* __restrict__ pre_kf) {
+    const Tile T = tiles[blockIdx.x];
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    const int G = T.G, lpw = 64 / G, grp = ln / G, q = ln - grp * G, nl = T.lmk1 - T.lmk0;
+    const bool valid = wv * lpw + grp < nl;
+    const int gl = T.lmk0 + (valid ? wv * lpw + grp : 0);
+    const int ob = nl > 0 ? lmk_ob[gl] : 0, nobs = (valid && nl > 0) ? lmk_oe[gl] - ob : 0;
+    pre_lane[(long long)blockIdx.x * BUILD_THREADS + tid] = make_int4(gl, (valid && q < nobs) ? ob + q : -1, nobs | (valid ? 1 << 16 : 0), ob);
+    if (tid < PRE_KF) {
+        int2 e = make_int2(-1, -1);
+        if (tid < T.n_kf) { e.x = tile_kf[T.kf_off + tid]; e.y = kf_fidx[e.x]; }
+        pre_kf[(long long)blockIdx.x * PRE_KF + tid] = e;
+    }
+}
+
 // ---- K5: build the reduced system ----------------------------------------------------------------
 // IMU = true (windows with IMU factors): the workgroups behind the tiles linearise one IMU factor pair each (imu_pair_lin_wg,
 // one wave; its 500 registers leave one workgroup per CU, which is what a single window runs at anyway).
@@ -500,6 +524,13 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
     }
     const Tile T = P.tiles[blockIdx.x];
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    // first-round packet of this lane (DevPtrs::pre_lane): addressed by blockIdx alone, in flight beside the tile record
+    int4 pl = make_int4(0, -1, 0, 0);
+    int2 pk = make_int2(-1, -1);
+    if (P.pre_lane) {
+        pl = P.pre_lane[(long long)blockIdx.x * BUILD_THREADS + tid];
+        pk = P.pre_kf[(long long)blockIdx.x * PRE_KF + tid / POSE_TAB];     // tid / POSE_TAB <= 6 < PRE_KF
+    }
     SADVIO_TS(3, 32);
     __shared__ double s_part[BUILD_WAVES * 4];
     // LDS carve
@@ -523,34 +554,47 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
     // load issued before the first add (< 1 024 tiles in this mode: <= 4 per thread) — one HBM round trip instead of one per
     // 64 tiles on a single wave — and they are the FIRST loads of the kernel: the memory counter retires in order.
     double pc = 0.0, pm = 0.0, psn = 0.0, pcn = 0.0;
-    if (!own_decision) {
-        // many tiles: the accept / reject decision of the previous slot was taken once per window by k_decide
-        st = P.states[(long long)T.w * P.state_stride + slot];
-    } else {
-        a = P.acc[(long long)T.w * P.state_stride + slot - 1];
-        prev = P.states[(long long)T.w * P.state_stride + slot - 1];
+    // a single window: its index, tile range and state records are known without the tile record (one dependent round trip less).
+    // A real branch, not a select: a select would wait for the tile record's scalar load before forming either address.
+    auto decision_inputs = [&](int dec_w, int t0, int nt) {
+        if (!own_decision) {
+            // many tiles: the accept / reject decision of the previous slot was taken once per window by k_decide
+            st = P.states[(long long)dec_w * P.state_stride + slot];
+            return;
+        }
+        a = P.acc[(long long)dec_w * P.state_stride + slot - 1];
+        prev = P.states[(long long)dec_w * P.state_stride + slot - 1];
         if (P.world > 1) {
             if (wv == 0) {
-                const double* rs = P.rank_s + (long long)T.w * P.world * 4;
+                const double* rs = P.rank_s + (long long)dec_w * P.world * 4;
                 for (int r = ln; r < P.world; r += 64) { pc += rs[4 * r]; pm += rs[4 * r + 1]; psn += rs[4 * r + 2]; pcn += rs[4 * r + 3]; }
             }
         } else {
-            const TileAcc* ta = P.tacc + (long long)((slot - 1) & 1) * P.n_tiles + T.win_tile0;
+            const TileAcc* ta = P.tacc + (long long)((slot - 1) & 1) * P.n_tiles + t0;
             double v[4][4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int t = tid + u * BUILD_THREADS;
-                const bool in = t < T.win_ntiles;
+                const bool in = t < nt;
                 const TileAcc* e = ta + (in ? t : 0);
                 v[u][0] = in ? e->cand_cost : 0.0; v[u][1] = in ? e->mcc : 0.0; v[u][2] = in ? e->step_norm2 : 0.0; v[u][3] = in ? e->cand_norm2 : 0.0;
             }
             pc = (v[0][0] + v[1][0]) + (v[2][0] + v[3][0]); pm = (v[0][1] + v[1][1]) + (v[2][1] + v[3][1]);
             psn = (v[0][2] + v[1][2]) + (v[2][2] + v[3][2]); pcn = (v[0][3] + v[1][3]) + (v[2][3] + v[3][3]);
         }
+    };
+    if (P.n_win == 1) decision_inputs(0, 0, P.n_tiles);
+    else decision_inputs(T.w, T.win_tile0, T.win_ntiles);
+    bool first_valid;
+    int gl_first, pre_ob, pre_oe, pre_o;     // pre_o: the lane's own observation of the first round, -1 = none
+    if (P.pre_lane) {
+        first_valid = (pl.z >> 16) & 1; gl_first = pl.x; pre_ob = pl.w; pre_oe = pl.w + (pl.z & 0xff); pre_o = pl.y;
+    } else {
+        first_valid = wv * lpw + grp < nl;
+        gl_first = T.lmk0 + (first_valid ? wv * lpw + grp : 0);
+        pre_ob = P.lmk_ob[gl_first]; pre_oe = P.lmk_oe[gl_first];
+        pre_o = (first_valid && q < pre_oe - pre_ob) ? pre_ob + q : -1;
     }
-    const bool first_valid = wv * lpw + grp < nl;
-    const int gl_first = T.lmk0 + (first_valid ? wv * lpw + grp : 0);
-    const int pre_ob = P.lmk_ob[gl_first], pre_oe = P.lmk_oe[gl_first];
     const int pre_lcode = P.lmk_const ? P.lmk_const[gl_first] : 0;
     double pre_p[3], pre_x0[3], pre_x1[3];
 #pragma unroll
@@ -560,7 +604,12 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
         pre_x1[i] = P.xl[P.xl_stride + 3 * (long long)gl_first + i];
     }
     double pre_t0 = 0.0, pre_t1 = 0.0;
-    if (tid < T.n_kf * POSE_TAB) {
+    if (P.pre_lane) {
+        if (pk.x >= 0) {
+            const long long src = (long long)pk.x * POSE_TAB + (tid - (tid / POSE_TAB) * POSE_TAB);
+            pre_t0 = P.ptab[src]; pre_t1 = P.ptab[P.ptab_stride + src];
+        }
+    } else if (tid < T.n_kf * POSE_TAB) {
         const int k = tid / POSE_TAB, e = tid - k * POSE_TAB;
         const long long src = (long long)P.tile_kf[T.kf_off + k] * POSE_TAB + e;
         pre_t0 = P.ptab[src]; pre_t1 = P.ptab[P.ptab_stride + src];
@@ -573,7 +622,7 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
     for (int i = tid; i < T.n_kf; i += blockDim.x) rowTab[i] = P.tile_row[T.kf_off + i];
     ObsPre pre_obs;
     pre_obs.slot = 0; pre_obs.craw = 0; pre_obs.m[0] = pre_obs.m[1] = pre_obs.m[2] = 0.0;
-    if (first_valid && q < pre_oe - pre_ob) pre_obs = obs_prefetch<FACTOR>(P, pre_ob + q);
+    if (pre_o >= 0) pre_obs = obs_prefetch<FACTOR>(P, pre_o);
     if (own_decision) {
         pc = wave_sum(pc); pm = wave_sum(pm); psn = wave_sum(psn); pcn = wave_sum(pcn);
         if (ln == 0) { s_part[wv * 4] = pc; s_part[wv * 4 + 1] = pm; s_part[wv * 4 + 2] = psn; s_part[wv * 4 + 3] = pcn; }
@@ -1961,40 +2010,99 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
     }
     const Tile T = P.tiles[blockIdx.x];
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-    const LmState st = P.states[(long long)T.w * P.state_stride + slot];
-    IterAcc* acc = P.acc + (long long)T.w * P.state_stride + slot;
+    // first-round packet of this lane (DevPtrs::pre_lane, see k_build): with it every input of the opening is at most two dependent
+    // round trips away (packet / tile record / state -> data) instead of four (tile -> key-frame list -> free index -> step)
+    int4 pl = make_int4(0, -1, 0, 0);
+    int2 pk = make_int2(-1, -1), pk6 = make_int2(-1, -1);
+    if (P.pre_lane) {
+        pl = P.pre_lane[(long long)blockIdx.x * BUILD_THREADS + tid];
+        pk = P.pre_kf[(long long)blockIdx.x * PRE_KF + tid / POSE_TAB];     // tid / POSE_TAB <= 6 < PRE_KF
+        if (tid < PRE_KF * 6) pk6 = P.pre_kf[(long long)blockIdx.x * PRE_KF + tid / 6];
+    }
+    LmState st;
+    int chol_fail;
+    if (P.n_win == 1) { st = P.states[slot]; chol_fail = P.acc[slot].chol_fail; }      // (a real branch: see k_build)
+    else { st = P.states[(long long)T.w * P.state_stride + slot]; chol_fail = P.acc[(long long)T.w * P.state_stride + slot].chol_fail; }
     zero_s_slice(P, T, blockIdx.x);
-    if (st.done || acc->chol_fail) {
+    double* poseTab = (double*)smem;
+    double* camTab = poseTab + (size_t)max_tile_kf * POSE_TAB;
+    int* rowTab = (int*)(camTab + MAX_WIN_CAM * 17);
+    double* candTab = (double*)(smem + tile_tables_bytes(max_tile_kf));  // [n_kf][12] R|t at the candidate poses
+    double* dpTab = candTab + (size_t)max_tile_kf * 12;                  // [n_kf][6] pose step of each listed key-frame
+    const int G = T.G, lpw = 64 / G;
+    const int grp = ln / G, q = ln - grp * G;
+    const int nl = T.lmk1 - T.lmk0;
+    // the wave's first landmark round is fetched before the tables are staged - and, with the packets, before the state record says
+    // which delta buffer holds x (both are fetched, the record selects)
+    bool first_valid;
+    int gl_first, pre_ob, pre_oe, pre_o;
+    if (P.pre_lane) {
+        first_valid = (pl.z >> 16) & 1; gl_first = pl.x; pre_ob = pl.w; pre_oe = pl.w + (pl.z & 0xff); pre_o = pl.y;
+    } else {
+        first_valid = wv * lpw + grp < nl;
+        gl_first = T.lmk0 + (first_valid ? wv * lpw + grp : 0);
+        pre_ob = P.lmk_ob[gl_first]; pre_oe = P.lmk_oe[gl_first];
+        pre_o = (first_valid && q < pre_oe - pre_ob) ? pre_ob + q : -1;
+    }
+    const int pre_lcode = P.lmk_const ? P.lmk_const[gl_first] : 0;
+    double pre_p[3], pre_xa[3], pre_xb[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        pre_p[i] = P.lmk_p[3 * (long long)gl_first + i];
+        pre_xa[i] = P.xl[3 * (long long)gl_first + i];
+        pre_xb[i] = P.xl[P.xl_stride + 3 * (long long)gl_first + i];
+    }
+    ObsPre pre_obs;
+    pre_obs.slot = 0; pre_obs.craw = 0; pre_obs.m[0] = pre_obs.m[1] = pre_obs.m[2] = 0.0;
+    if (pre_o >= 0) pre_obs = obs_prefetch<FACTOR>(P, pre_o);
+    // pose tables of both buffers: this thread's entry of the first 256 (packets), selected below
+    double pre_t0 = 0.0, pre_t1 = 0.0;
+    const bool pre_tab = P.pre_lane != nullptr;
+    if (pre_tab && pk.x >= 0) {
+        const long long src = (long long)pk.x * POSE_TAB + (tid - (tid / POSE_TAB) * POSE_TAB);
+        pre_t0 = P.ptab[src]; pre_t1 = P.ptab[P.ptab_stride + src];
+    }
+    if (st.done || chol_fail) {
         if (tid == 0) {
             TileAcc* ta = P.tacc + (long long)(slot & 1) * P.n_tiles + blockIdx.x;
             ta->cand_cost = 0.0; ta->mcc = 0.0; ta->step_norm2 = 0.0; ta->cand_norm2 = 0.0;
         }
         return;
     }
-    double* poseTab = (double*)smem;
-    double* camTab = poseTab + (size_t)max_tile_kf * POSE_TAB;
-    int* rowTab = (int*)(camTab + MAX_WIN_CAM * 17);
-    double* candTab = (double*)(smem + tile_tables_bytes(max_tile_kf));  // [n_kf][12] R|t at the candidate poses
-    double* dpTab = candTab + (size_t)max_tile_kf * 12;                  // [n_kf][6] pose step of each listed key-frame
     const int cur = st.cur;
-    const int G = T.G, lpw = 64 / G;
-    const int grp = ln / G, q = ln - grp * G;
-    const int nl = T.lmk1 - T.lmk0;
     const double* xl = P.xl + (long long)cur * P.xl_stride;
     double* xlc = P.xl + (long long)(1 - cur) * P.xl_stride;
-    // the wave's first landmark round is fetched before the tables are staged (one HBM round trip instead of three in a row)
-    const bool first_valid = wv * lpw + grp < nl;
-    const int gl_first = T.lmk0 + (first_valid ? wv * lpw + grp : 0);
-    const int pre_ob = P.lmk_ob[gl_first], pre_oe = P.lmk_oe[gl_first];
-    const int pre_lcode = P.lmk_const ? P.lmk_const[gl_first] : 0;
-    double pre_p[3], pre_x[3];
+    double pre_x[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) { pre_p[i] = P.lmk_p[3 * (long long)gl_first + i]; pre_x[i] = xl[3 * (long long)gl_first + i]; }
-    ObsPre pre_obs;
-    pre_obs.slot = 0; pre_obs.craw = 0; pre_obs.m[0] = pre_obs.m[1] = pre_obs.m[2] = 0.0;
-    if (first_valid && q < pre_oe - pre_ob) pre_obs = obs_prefetch<FACTOR>(P, pre_ob + q);
-    stage_tables(P, T, cur, poseTab, camTab, rowTab);
-    {
+    for (int i = 0; i < 3; i++) pre_x[i] = cur ? pre_xb[i] : pre_xa[i];
+    if (pre_tab) {
+        const double* src = P.ptab + (long long)cur * P.ptab_stride;
+        const double* srcc = P.ptab + (long long)(1 - cur) * P.ptab_stride;
+        if (tid < T.n_kf * POSE_TAB) {
+            const int k = tid / POSE_TAB, e = tid - k * POSE_TAB;
+            poseTab[tid] = cur ? pre_t1 : pre_t0;
+            if (e < 12) candTab[k * 12 + e] = cur ? pre_t0 : pre_t1;
+        }
+        for (int i = tid + blockDim.x; i < T.n_kf * POSE_TAB; i += blockDim.x) {     // tiles with more than 6 key-frames
+            const int k = i / POSE_TAB, e = i - k * POSE_TAB;
+            const long long o = (long long)P.tile_kf[T.kf_off + k] * POSE_TAB + e;
+            poseTab[i] = src[o];
+            if (e < 12) candTab[k * 12 + e] = srcc[o];
+        }
+        for (int i = tid; i < T.n_cam * 17; i += blockDim.x) {
+            const int c = i / 17, e = i - 17 * c;
+            const int gc = T.cam_base + c;
+            camTab[i] = e < 4 ? P.cam_K[4 * (long long)gc + e] : (e < 16 ? P.cam_T[12 * (long long)gc + e - 4] : P.cam_isig[gc]);
+        }
+        for (int i = tid; i < T.n_kf; i += blockDim.x) rowTab[i] = P.tile_row[T.kf_off + i];
+        const double* dp = P.delta + T.red_off;
+        for (int i = tid; i < T.n_kf * 6; i += blockDim.x) {
+            const int k = i / 6, e = i - 6 * k;
+            const int fi = (i < PRE_KF * 6) ? pk6.y : P.kf_fidx[P.tile_kf[T.kf_off + k]];
+            dpTab[i] = fi < 0 ? 0.0 : dp[fi * T.dpf + e];
+        }
+    } else {
+        stage_tables(P, T, cur, poseTab, camTab, rowTab);
         const double* src = P.ptab + (long long)(1 - cur) * P.ptab_stride;
         for (int i = tid; i < T.n_kf * 12; i += blockDim.x) {
             const int k = i / 12, e = i - 12 * k;
