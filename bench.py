@@ -40,10 +40,10 @@ FP64_PEAK_TFLOPS = 78.6  # half the guide's 157.3 TFLOP/s fp32 vector / matrix r
 GN_ITERS = 10
 # committed rocprofv3 PMC summaries of this same command (scripts/prof_bench.sh / prof_batched.sh), named explicitly: the
 # newest round's files, not whatever sorts last
-PROFILE_SUMMARY = "profiles/r05_summary.json"
-PROFILE_SUMMARY_BATCHED = "profiles/r05_batched64_summary.json"
-PROFILE_FALLBACK = {"profiles/r05_summary.json": "profiles/r04_summary.json",
-                    "profiles/r05_batched64_summary.json": None}   # (the round-4 batched profile is of other kernels: k_elim / k_diag / k_backsub_lm)
+PROFILE_SUMMARY = "profiles/r06_summary.json"
+PROFILE_SUMMARY_BATCHED = "profiles/r06_batched64_summary.json"
+PROFILE_FALLBACK = {"profiles/r06_summary.json": "profiles/r05_summary.json",
+                    "profiles/r06_batched64_summary.json": "profiles/r05_batched64_summary.json"}   # (the throughput kernels did not change in round 6)
 
 
 def profile_summary(rel):
