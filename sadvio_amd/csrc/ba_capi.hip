@@ -333,6 +333,7 @@ struct sadvio_ba_handle {
     DevBuf<int> d_lmk_ob, d_lmk_oe, d_obs_kf, d_obs_cam, d_tile_kf, d_tile_row;
     DevBuf<int> d_pre_lane, d_pre_kf;     // first-round packets of the latency kernels (kernels.h: DevPtrs::pre_lane), few-tile submissions only
     bool pre_ok = false, pre_dirty = false;
+    double* rank_pin = nullptr; size_t rank_pin_cap = 0;   // pinned read-back of the factor for refine_rank_by_eigenvalue (guarded calls only)
     DevBuf<unsigned char> d_obs_slot, d_obs_lslot;
     DevBuf<int> d_chunk_ob, d_chunk_lm, d_tile_perm;   // chunk tables of the throughput kernels (lm_kernels.h)
     DevBuf<int> d_jac_ints;               // pivoting / rank of the Cholesky-preconditioned Jacobi
@@ -780,6 +781,7 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     if (h->stream) { (void)hipStreamSynchronize(h->stream); }
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->rccl.comm) (void)h->rccl.destroy(h->rccl.comm);
+    if (h->rank_pin) (void)hipHostFree(h->rank_pin);
     if (h->h_final) (void)hipHostFree(h->h_final);
     if (h->h_deltas) (void)hipHostFree(h->h_deltas);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
@@ -1804,22 +1806,41 @@ int refine_rank_by_eigenvalue(sadvio_ba_handle* h, const double* G, int n1, int 
     for (int c = 0; c < n1; c++) if (step_of[c] >= 0 && step_of[c] < nf) col_of[step_of[c]] = c;
     for (int s = 0; s < nf; s++) if (col_of[s] < 0) return nf;    // (cannot happen: every step has its column)
     const double d_last = last[col_of[nf - 1]] * last[col_of[nf - 1]];
+    if (h->env.debug) fprintf(stderr, "[sadvio dbg] rank refinement: last pivot %.3e (rank %d of %d)\n", d_last, nf, n1 - 1);
     if (!(d_last <= RANK_GUARD * 1e-12)) return nf;
-    // guarded: the factor in pivot order on the host
-    std::vector<double> Gh((size_t)nf * n1);
-    if (hipMemcpy(Gh.data(), G, sizeof(double) * (size_t)nf * n1, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    auto g = [&](int s, int t) { return Gh[(size_t)s * n1 + col_of[t]]; };   // upper triangular: zero for t < s
+    // guarded: the factor's rank rows on the host, through a pinned buffer (pageable, the 6.7 MB of n = 915 took 1.3 ms)
+    const size_t need = sizeof(double) * (size_t)nf * n1;
+    if (h->rank_pin_cap < need) {
+        if (h->rank_pin) (void)hipHostFree(h->rank_pin);
+        h->rank_pin = nullptr; h->rank_pin_cap = 0;
+        if (hipHostMalloc((void**)&h->rank_pin, need + need / 4, hipHostMallocDefault) != hipSuccess) return -1;
+        h->rank_pin_cap = need + need / 4;
+    }
+    const double* Gh = h->rank_pin;
+    const auto tq0 = std::chrono::steady_clock::now();
+    if (hipMemcpyAsync(h->rank_pin, G, need, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    const auto tq1 = std::chrono::steady_clock::now();
+    auto gd = [&](int s) { return Gh[(size_t)s * n1 + col_of[s]]; };   // diagonal of the factor in pivot order
     int k = 0;
-    while (k < nf && k < 8) { const double dv = g(nf - 1 - k, nf - 1 - k); if (dv * dv <= RANK_GUARD * 1e-12) k++; else break; }
+    while (k < nf && k < 8) { const double dv = gd(nf - 1 - k); if (dv * dv <= RANK_GUARD * 1e-12) k++; else break; }
+    // G x = e_s by back-substitution, s = nf - 1 - q. Row i of G is zero in the columns pivoted before step i, so with x kept by ORIGINAL
+    // column index (zero until its step is solved) the sum over t > i is a contiguous dot product of row i with that vector.
     std::vector<std::vector<double>> X(k, std::vector<double>(nf, 0.0));
-    for (int q = 0; q < k; q++) {       // G x = e_s by back-substitution, s = nf - 1 - q
+    std::vector<double> xo((size_t)n1);
+    for (int q = 0; q < k; q++) {
         const int sq = nf - 1 - q;
+        std::fill(xo.begin(), xo.end(), 0.0);
         std::vector<double>& x = X[q];
-        x[sq] = 1.0 / g(sq, sq);
+        x[sq] = 1.0 / gd(sq); xo[col_of[sq]] = x[sq];
         for (int i = sq - 1; i >= 0; i--) {
-            double acc = 0.0;
-            for (int t = i + 1; t <= sq; t++) acc += g(i, t) * x[t];
-            x[i] = -acc / g(i, i);
+            const double* row = Gh + (size_t)i * n1;
+            double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // eight independent chains: the loop is bound by the add latency otherwise
+            int c = 0;
+            for (; c + 7 < n1; c += 8)
+                for (int u = 0; u < 8; u++) a[u] += row[c + u] * xo[c + u];
+            for (; c < n1; c++) a[0] += row[c] * xo[c];
+            x[i] = -(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) / gd(i);
+            xo[col_of[i]] = x[i];
         }
     }
     // eigenvalues of the k x k Gram matrix X^T X (cyclic Jacobi); lambda_small(A) = 1 / them
@@ -1840,6 +1861,7 @@ int refine_rank_by_eigenvalue(sadvio_ba_handle* h, const double* G, int n1, int 
     }
     int drop = 0;
     for (int a = 0; a < k; a++) if (!(1.0 / B[(size_t)a * k + a] > 1e-12)) drop++;
+    if (h->env.debug) fprintf(stderr, "[sadvio dbg] rank refinement: read-back %.3f ms, estimates %.3f ms\n", std::chrono::duration<double, std::milli>(tq1 - tq0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq1).count());
     if ((h->env.debug & 16384) || drop) {
         h->marg_stats[3] += drop ? 1 : 0;
         if (h->env.debug) {
