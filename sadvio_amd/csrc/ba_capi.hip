@@ -1255,7 +1255,7 @@ static int build_layout(sadvio_ba_handle* h) {
     // small-batch regime the latency kernels serve; 4 KB per tile).
     h->pre_ok = !h->tiles.empty() && h->tiles.size() <= PRE_MAX_TILES && !h->env.no_pre;
     if (h->pre_ok) {   // built on the device behind the upload (k_pre_packets, upload_priors): 1 MB of host stores + PCIe otherwise
-        HIP_TRY(h->d_pre_lane.alloc((size_t)4 * BUILD_THREADS * h->tiles.size())); HIP_TRY(h->d_pre_kf.alloc((size_t)2 * PRE_KF * h->tiles.size()));
+        HIP_TRY(h->d_pre_lane.alloc((size_t)4 * (BUILD_THREADS / 8) * h->tiles.size())); HIP_TRY(h->d_pre_kf.alloc((size_t)2 * PRE_KF * h->tiles.size()));
         h->pre_dirty = true;
     }
 #undef UP

@@ -35,8 +35,9 @@ struct DevPtrs {
     const unsigned char* obs_slot;  // index of the observation's key-frame in its tile's list
     const int* tile_kf;             // per-tile key-frame lists (global indices)
     const int* tile_row;            // matching row in the tile's LDS system (6 * rank among free) or -1
-    // first-round packets (ba_capi.hip: build_layout; null for submissions of more than PRE_MAX_TILES tiles): per (tile, lane)
-    // | landmark | observation or -1 | observations of the landmark + (1 << 16 if the lane's landmark exists) | the landmark's first observation |,
+    // first-round packets (k_pre_packets; null for submissions of more than PRE_MAX_TILES tiles): per (tile, 8 consecutive lanes — a landmark's
+    // lane group is 8 .. 64 wide) | landmark | its first observation | its observation count + (1 << 16 if the landmark exists) | position of the
+    // 8 lanes' first one inside the group |,
     // per (tile, k < PRE_KF) | global key-frame or -1 | its free index |: the opening loads of k_build / k_backsub hang on blockIdx alone
     const int4* pre_lane;
     const int2* pre_kf;
@@ -493,17 +494,21 @@ __host__ __device__ inline size_t tile_tables_bytes(int n_kf) {
 }
 
 // First-round packets (DevPtrs::pre_lane / pre_kf): one launch per layout, behind its upload. What a lane of k_build / k_backsub needs
-// to address the inputs of its tile's FIRST landmark round, laid out by (tile, lane) so that those loads hang on blockIdx alone.
+// to address the inputs of its tile's FIRST landmark round, laid out by (tile, 8-lane granule) so that those loads hang on blockIdx alone
+// (132 KB for the 258 tiles of config 2; a packet per lane was 1 MB of extra traffic per launch).
 __global__ __launch_bounds__(BUILD_THREADS) void k_pre_packets(const Tile* __restrict__ tiles, const int* __restrict__ lmk_ob, const int* __restrict__ lmk_oe,
                                                                const int* __restrict__ tile_kf, const int* __restrict__ kf_fidx, int4* __restrict__ pre_lane,
                                                                int2* __restrict__ pre_kf) {
     const Tile T = tiles[blockIdx.x];
-    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-    const int G = T.G, lpw = 64 / G, grp = ln / G, q = ln - grp * G, nl = T.lmk1 - T.lmk0;
-    const bool valid = wv * lpw + grp < nl;
-    const int gl = T.lmk0 + (valid ? wv * lpw + grp : 0);
-    const int ob = nl > 0 ? lmk_ob[gl] : 0, nobs = (valid && nl > 0) ? lmk_oe[gl] - ob : 0;
-    pre_lane[(long long)blockIdx.x * BUILD_THREADS + tid] = make_int4(gl, (valid && q < nobs) ? ob + q : -1, nobs | (valid ? 1 << 16 : 0), ob);
+    const int tid = threadIdx.x;
+    if (tid < BUILD_THREADS / 8) {          // one packet per 8 lanes
+        const int lane0 = tid * 8, wv = lane0 >> 6, ln = lane0 & 63;
+        const int G = T.G, lpw = 64 / G, grp = ln / G, q0 = ln - grp * G, nl = T.lmk1 - T.lmk0;
+        const bool valid = wv * lpw + grp < nl;
+        const int gl = T.lmk0 + (valid ? wv * lpw + grp : 0);
+        const int ob = nl > 0 ? lmk_ob[gl] : 0, nobs = (valid && nl > 0) ? lmk_oe[gl] - ob : 0;
+        pre_lane[(long long)blockIdx.x * (BUILD_THREADS / 8) + tid] = make_int4(gl, ob, nobs | (valid ? 1 << 16 : 0), q0);
+    }
     if (tid < PRE_KF) {
         int2 e = make_int2(-1, -1);
         if (tid < T.n_kf) { e.x = tile_kf[T.kf_off + tid]; e.y = kf_fidx[e.x]; }
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
     int4 pl = make_int4(0, -1, 0, 0);
     int2 pk = make_int2(-1, -1);
     if (P.pre_lane) {
-        pl = P.pre_lane[(long long)blockIdx.x * BUILD_THREADS + tid];
+        pl = P.pre_lane[(long long)blockIdx.x * (BUILD_THREADS / 8) + (tid >> 3)];   // one packet per 8 lanes: a landmark's group is >= 8 lanes wide
         pk = P.pre_kf[(long long)blockIdx.x * PRE_KF + tid / POSE_TAB];     // tid / POSE_TAB <= 6 < PRE_KF
     }
     SADVIO_TS(3, 32);
@@ -588,7 +593,8 @@ __global__ __launch_bounds__(BUILD_THREADS, IMU ? 1 : 2) void k_build(DevPtrs P,
     bool first_valid;
     int gl_first, pre_ob, pre_oe, pre_o;     // pre_o: the lane's own observation of the first round, -1 = none
     if (P.pre_lane) {
-        first_valid = (pl.z >> 16) & 1; gl_first = pl.x; pre_ob = pl.w; pre_oe = pl.w + (pl.z & 0xff); pre_o = pl.y;
+        first_valid = (pl.z >> 16) & 1; gl_first = pl.x; pre_ob = pl.y; pre_oe = pl.y + (pl.z & 0xff);
+        pre_o = (pl.w + (tid & 7) < (pl.z & 0xff)) ? pl.y + pl.w + (tid & 7) : -1;
     } else {
         first_valid = wv * lpw + grp < nl;
         gl_first = T.lmk0 + (first_valid ? wv * lpw + grp : 0);
@@ -2015,7 +2021,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
     int4 pl = make_int4(0, -1, 0, 0);
     int2 pk = make_int2(-1, -1), pk6 = make_int2(-1, -1);
     if (P.pre_lane) {
-        pl = P.pre_lane[(long long)blockIdx.x * BUILD_THREADS + tid];
+        pl = P.pre_lane[(long long)blockIdx.x * (BUILD_THREADS / 8) + (tid >> 3)];   // one packet per 8 lanes: a landmark's group is >= 8 lanes wide
         pk = P.pre_kf[(long long)blockIdx.x * PRE_KF + tid / POSE_TAB];     // tid / POSE_TAB <= 6 < PRE_KF
         if (tid < PRE_KF * 6) pk6 = P.pre_kf[(long long)blockIdx.x * PRE_KF + tid / 6];
     }
@@ -2037,7 +2043,8 @@ __global__ __launch_bounds__(BUILD_THREADS) void k_backsub(DevPtrs P, int slot, 
     bool first_valid;
     int gl_first, pre_ob, pre_oe, pre_o;
     if (P.pre_lane) {
-        first_valid = (pl.z >> 16) & 1; gl_first = pl.x; pre_ob = pl.w; pre_oe = pl.w + (pl.z & 0xff); pre_o = pl.y;
+        first_valid = (pl.z >> 16) & 1; gl_first = pl.x; pre_ob = pl.y; pre_oe = pl.y + (pl.z & 0xff);
+        pre_o = (pl.w + (tid & 7) < (pl.z & 0xff)) ? pl.y + pl.w + (tid & 7) : -1;
     } else {
         first_valid = wv * lpw + grp < nl;
         gl_first = T.lmk0 + (first_valid ? wv * lpw + grp : 0);
