@@ -26,12 +26,13 @@ def test_stdout_carries_the_record_alone():
 
 
 def test_bench_line_fields_of_the_committed_record():
-    """profiles/r05_bench.json is a full line of the profiling box: the contract's fields, the roofline and the CPU baseline objects."""
-    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    """profiles/r06_bench.json is a full line of the profiling box: the contract's fields, the roofline and the CPU baseline objects."""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
         assert k in rec, k
     assert rec["dtype"] == "f64" and rec["vs_baseline"] is None and "workload" in rec["config"]
+    assert rec["roofline"]["bound"] == "latency" and rec["batched"]["fp64"]["flops_per_lm_step_survey_8d"] == 470 * 40000 + 4100 * 8000 + 114 ** 3 // 3
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rec["roofline"], k
     for k in ("value", "unit", "cores", "kind", "sample"):
