@@ -97,3 +97,52 @@ def test_threshold_pivoting_bounds_the_factor():
     assert np.allclose(L @ L.T, A, atol=1e-9 * np.abs(A).max())
     for k in range(n):
         assert np.abs(L[:, k]).max() <= np.sqrt(1.0 / theta) * L[P[k], k] * (1 + 1e-9)
+
+
+def _pivoted_cholesky(A):
+    """Diagonally pivoted Cholesky A[p][:, p] = G^T G (G upper triangular in pivot order); returns G (rows by ORIGINAL column) and the order."""
+    n = A.shape[0]
+    S = A.copy()
+    G = np.zeros((n, n))
+    left = list(range(n))
+    order = []
+    for k in range(n):
+        p = max(left, key=lambda i: S[i, i])
+        order.append(p); left.remove(p)
+        d = np.sqrt(S[p, p])
+        G[k, p] = d
+        for i in left:
+            G[k, i] = S[p, i] / d
+        for i in left:
+            for j in left:
+                S[i, j] -= G[k, i] * G[k, j]
+    return G, order
+
+
+def test_small_eigenvalue_from_the_trailing_pivot():
+    """Round 6 (ba_capi.hip: refine_rank_by_eigenvalue): the reference cuts the prior's rank by EIGENVALUE (lambda > 1e-12,
+    marginalization.cpp:318-342); a rank-revealing Cholesky sees pivots. With G in pivot order and x = G^-1 e_last, 1 / |x|^2 — the
+    Rayleigh quotient of the near-null vector, d_last / (1 + |w|^2) — is the smallest eigenvalue to O(d / gap), with RELATIVE accuracy
+    on a graded matrix whose double-precision eigen-decomposition only returns noise of size eps |A|: checked against mpmath at 50
+    digits on a matrix of the measured kind (lambda_max 1e8, lambda_min 1e-14: below the cut under a pivot that is not)."""
+    import mpmath as mp
+    rng = np.random.default_rng(5)
+    n = 24
+    B = rng.standard_normal((n, n)); B = B @ B.T / n + np.eye(n)          # well conditioned
+    D = np.diag(np.logspace(4, -1, n)); D[-1, -1] = 3e-8                  # graded scaling: the last direction carries ~ 1e-15 .. 1e-14
+    A = D @ B @ D
+    A = 0.5 * (A + A.T)
+    mp.mp.dps = 50
+    ev = mp.eigsy(mp.matrix(A.tolist()), eigvals_only=True)
+    lam_min = float(min(ev))
+    assert 1e-16 < lam_min < 1e-12 and float(max(ev)) > 1e7
+    G, order = _pivoted_cholesky(A)
+    Gp = G[:, order]                                                       # upper triangular
+    assert np.allclose(np.tril(Gp, -1), 0.0)
+    d_last = Gp[-1, -1] ** 2
+    x = np.linalg.solve(Gp, np.eye(n)[:, -1])
+    est = 1.0 / (x @ x)
+    assert lam_min <= d_last * (1 + 1e-12)                                 # lambda_min <= the last pivot: a pivot <= cut certifies the drop
+    assert abs(est - lam_min) <= 1e-6 * lam_min, (est, lam_min)            # the estimate: relative accuracy
+    lapack = np.linalg.eigvalsh(A)[0]
+    assert abs(lapack - lam_min) > 1e3 * abs(est - lam_min)                # a double-precision eigen-decomposition of A: noise at this scale
