@@ -411,8 +411,9 @@ def main():
             batched["speedup_vs_cpu_batched"] = round(batched["value"] / cpu["batched"]["value"], 1)
             batched["speedup_note"] = "throughput regime against throughput regime: 64 windows per GPU submission vs independent windows on all usable host cores"
         if cpu:
-            out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+            out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)                              # at the reference's 4 threads
             out["speedup_vs_cpu_at_reference_threads"] = round(value / cpu["at_reference_threads"]["value"], 1)
+            out["speedup_vs_cpu_best_thread_count"] = round(value / cpu["best_thread_count"]["value"], 1)
         emit_record(out)
     if dist is not None:
         dist.barrier()
@@ -439,7 +440,10 @@ def cpu_baseline_leg(w0, opts):
         res[thr] = n / (time.perf_counter() - t0)
     best = max(res, key=res.get)
     ref = oracle.solve(w0, opts, n_threads=1)    # the CPU solution of the timed window: `parity` compares the GPU solve with it
-    return {"value": round(res[best], 2), "unit": "BA iterations/s", "cores": best, "kind": "port",
+    # `value` = the reference's own thread setting (options.num_threads = 4, AOptimizer.cpp:323): what its Ceres path would be given; the
+    # port's best thread count on this box is reported beside it (quote the 4-thread figure first)
+    return {"value": round(res[4], 2), "unit": "BA iterations/s", "cores": 4, "kind": "port",
+            "best_thread_count": {"threads": best, "value": round(res[best], 2)},
             "_ref": {"pose": ref["pose"], "lmk": ref["lmk"], "final_cost": ref["summary"].final_cost, "iterations": ref["summary"].iterations},
             "batched": cpu_batched_leg(oracle, w0, opts, usable),
             "at_reference_threads": {"threads": 4, "value": round(res[4], 2), "why": "the reference's own setting: options.num_threads = 4 (AOptimizer.cpp:323)"},
@@ -450,7 +454,7 @@ def cpu_baseline_leg(w0, opts):
             "sparse_normal_cholesky_emulation": sparse_normal_baseline(oracle, w0, opts),
             "note": "the reference (Ceres 2.2 / Eigen / SuiteSparse) cannot be built here or on the GPU box; "
                     "`value` = the C oracle (explicit Schur complement + dense Cholesky, OpenMP over landmarks with per-thread "
-                    "reduced-system accumulators); sparse_normal_cholesky_emulation = the reference's own linear-solver choice "
+                    "reduced-system accumulators) at the reference's 4 threads, `best_thread_count` = its best point on this box; sparse_normal_cholesky_emulation = the reference's own linear-solver choice "
                     "(un-reduced J^T J + D, sparse direct factorisation) with SciPy's SuperLU standing in for CHOLMOD"}
 
 
