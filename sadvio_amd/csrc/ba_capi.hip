@@ -333,7 +333,7 @@ struct sadvio_ba_handle {
     DevBuf<int> d_lmk_ob, d_lmk_oe, d_obs_kf, d_obs_cam, d_tile_kf, d_tile_row;
     DevBuf<int> d_pre_lane, d_pre_kf;     // first-round packets of the latency kernels (kernels.h: DevPtrs::pre_lane), few-tile submissions only
     bool pre_ok = false, pre_dirty = false;
-    double* rank_pin = nullptr; size_t rank_pin_cap = 0;   // pinned read-back of the factor for refine_rank_by_eigenvalue (guarded calls only)
+    DevBuf<int> d_rank_col; DevBuf<double> d_rank_x;       // refine_rank_by_eigenvalue (guarded calls only): pivot column per step, the solved vectors
     DevBuf<unsigned char> d_obs_slot, d_obs_lslot;
     DevBuf<int> d_chunk_ob, d_chunk_lm, d_tile_perm;   // chunk tables of the throughput kernels (lm_kernels.h)
     DevBuf<int> d_jac_ints;               // pivoting / rank of the Cholesky-preconditioned Jacobi
@@ -781,7 +781,6 @@ void sadvio_ba_destroy(sadvio_ba_handle* h) {
     if (h->stream) { (void)hipStreamSynchronize(h->stream); }
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->rccl.comm) (void)h->rccl.destroy(h->rccl.comm);
-    if (h->rank_pin) (void)hipHostFree(h->rank_pin);
     if (h->h_final) (void)hipHostFree(h->h_final);
     if (h->h_deltas) (void)hipHostFree(h->h_deltas);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
@@ -1793,56 +1792,37 @@ int run_jacobi(sadvio_ba_handle* h, const double* A, long long lda, int n, int l
 // k trailing steps, the k smallest eigenvalues of A = G^T G are, to O(d / gap) relative, the reciprocals of the eigenvalues of X^T X
 // (A^-1 = G^-1 G^-T is dominated by those columns; k = 1: lambda = d / (1 + |w|^2), the Rayleigh quotient of the near-null vector) —
 // relatively accurate where an eigen-decomposition of A in double precision only returns noise of size eps |A|. Rows whose eigenvalue
-// is <= 1e-12 are dropped from the end. Host arithmetic on a read-back of G, on guarded calls only (a trailing pivot below
+// is <= 1e-12 are dropped from the end. The solves run on the device (k_rank_backsub), the k x k eigenproblem on the host, on guarded calls only (a trailing pivot below
 // RANK_GUARD x 1e-12: one call in 25 in the sliding sequences). Returns the refined rank, -1 on a HIP error.
 constexpr double RANK_GUARD = 1e4;
 int refine_rank_by_eigenvalue(sadvio_ba_handle* h, const double* G, int n1, int nf) {
+    constexpr int KMAX = 8;              // trailing pivots looked at
+    const int nl = std::min(nf, KMAX);
     std::vector<int> step_of(n1);
     if (hipMemcpyAsync(step_of.data(), h->d_jac_ints.p, sizeof(int) * (size_t)n1, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
-    std::vector<double> last((size_t)n1);
-    if (hipMemcpyAsync(last.data(), G + (size_t)(nf - 1) * n1, sizeof(double) * (size_t)n1, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
+    std::vector<double> last((size_t)nl * n1);      // the last rank rows: their diagonal entries are the trailing pivots
+    if (hipMemcpyAsync(last.data(), G + (size_t)(nf - nl) * n1, sizeof(double) * (size_t)nl * n1, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
     std::vector<int> col_of(nf, -1);                  // pivot column of every step
     for (int c = 0; c < n1; c++) if (step_of[c] >= 0 && step_of[c] < nf) col_of[step_of[c]] = c;
     for (int s = 0; s < nf; s++) if (col_of[s] < 0) return nf;    // (cannot happen: every step has its column)
-    const double d_last = last[col_of[nf - 1]] * last[col_of[nf - 1]];
+    auto gd = [&](int s) { return last[(size_t)(s - (nf - nl)) * n1 + col_of[s]]; };   // diagonal of the factor in pivot order, s >= nf - nl
+    const double d_last = gd(nf - 1) * gd(nf - 1);
     if (h->env.debug) fprintf(stderr, "[sadvio dbg] rank refinement: last pivot %.3e (rank %d of %d)\n", d_last, nf, n1 - 1);
     if (!(d_last <= RANK_GUARD * 1e-12)) return nf;
-    // guarded: the factor's rank rows on the host, through a pinned buffer (pageable, the 6.7 MB of n = 915 took 1.3 ms)
-    const size_t need = sizeof(double) * (size_t)nf * n1;
-    if (h->rank_pin_cap < need) {
-        if (h->rank_pin) (void)hipHostFree(h->rank_pin);
-        h->rank_pin = nullptr; h->rank_pin_cap = 0;
-        if (hipHostMalloc((void**)&h->rank_pin, need + need / 4, hipHostMallocDefault) != hipSuccess) return -1;
-        h->rank_pin_cap = need + need / 4;
-    }
-    const double* Gh = h->rank_pin;
-    const auto tq0 = std::chrono::steady_clock::now();
-    if (hipMemcpyAsync(h->rank_pin, G, need, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
-    const auto tq1 = std::chrono::steady_clock::now();
-    auto gd = [&](int s) { return Gh[(size_t)s * n1 + col_of[s]]; };   // diagonal of the factor in pivot order
     int k = 0;
-    while (k < nf && k < 8) { const double dv = gd(nf - 1 - k); if (dv * dv <= RANK_GUARD * 1e-12) k++; else break; }
-    // G x = e_s by back-substitution, s = nf - 1 - q. Row i of G is zero in the columns pivoted before step i, so with x kept by ORIGINAL
-    // column index (zero until its step is solved) the sum over t > i is a contiguous dot product of row i with that vector.
+    while (k < nl) { const double dv = gd(nf - 1 - k); if (dv * dv <= RANK_GUARD * 1e-12) k++; else break; }
+    // guarded: x_q = G^-1 e_s, s = nf - 1 - q, by k_rank_backsub on the device (one workgroup per vector; 0.29 ms with the read-back at n = 915, k = 4)
+    const auto tq0 = std::chrono::steady_clock::now();
+    if (h->d_rank_col.alloc((size_t)nf) != hipSuccess || h->d_rank_x.alloc((size_t)k * nf) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h->d_rank_col.p, col_of.data(), sizeof(int) * (size_t)nf, hipMemcpyHostToDevice, h->stream) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_rank_backsub, dim3(k), dim3(RB_THREADS), 0, h->stream, G, n1, h->d_rank_col.p, nf - 1, nf, h->d_rank_x.p);   // one workgroup per vector
+    std::vector<double> Xall((size_t)k * nf);
+    if (hipMemcpyAsync(Xall.data(), h->d_rank_x.p, sizeof(double) * (size_t)k * nf, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
     std::vector<std::vector<double>> X(k, std::vector<double>(nf, 0.0));
-    std::vector<double> xo((size_t)n1);
-    for (int q = 0; q < k; q++) {
-        const int sq = nf - 1 - q;
-        std::fill(xo.begin(), xo.end(), 0.0);
-        std::vector<double>& x = X[q];
-        x[sq] = 1.0 / gd(sq); xo[col_of[sq]] = x[sq];
-        for (int i = sq - 1; i >= 0; i--) {
-            const double* row = Gh + (size_t)i * n1;
-            double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // eight independent chains: the loop is bound by the add latency otherwise
-            int c = 0;
-            for (; c + 7 < n1; c += 8)
-                for (int u = 0; u < 8; u++) a[u] += row[c + u] * xo[c + u];
-            for (; c < n1; c++) a[0] += row[c] * xo[c];
-            x[i] = -(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) / gd(i);
-            xo[col_of[i]] = x[i];
-        }
-    }
+    for (int q = 0; q < k; q++) std::copy(Xall.begin() + (size_t)q * nf, Xall.begin() + (size_t)q * nf + (nf - q), X[q].begin());   // rows above s = nf - 1 - q are not written: x is zero there
+    const auto tq1 = std::chrono::steady_clock::now();
     // eigenvalues of the k x k Gram matrix X^T X (cyclic Jacobi); lambda_small(A) = 1 / them
     std::vector<double> B((size_t)k * k);
     for (int a = 0; a < k; a++) for (int b = 0; b < k; b++) { double acc = 0.0; for (int i = 0; i < nf; i++) acc += X[a][i] * X[b][i]; B[(size_t)a * k + b] = acc; }
@@ -1861,7 +1841,7 @@ int refine_rank_by_eigenvalue(sadvio_ba_handle* h, const double* G, int n1, int 
     }
     int drop = 0;
     for (int a = 0; a < k; a++) if (!(1.0 / B[(size_t)a * k + a] > 1e-12)) drop++;
-    if (h->env.debug) fprintf(stderr, "[sadvio dbg] rank refinement: read-back %.3f ms, estimates %.3f ms\n", std::chrono::duration<double, std::milli>(tq1 - tq0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq1).count());
+    if (h->env.debug) fprintf(stderr, "[sadvio dbg] rank refinement: %d vector(s), device back-substitution + read-back %.3f ms, host %.3f ms\n", k, std::chrono::duration<double, std::milli>(tq1 - tq0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq1).count());
     if ((h->env.debug & 16384) || drop) {
         h->marg_stats[3] += drop ? 1 : 0;
         if (h->env.debug) {
