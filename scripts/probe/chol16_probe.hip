@@ -7,7 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "chol16_rows.h"   // = sadvio_amd/csrc/chol16.h + the row-layout pivot block measured in round 6 (variant 2 below)
+#include "chol16_pair.h"   // = sadvio_amd/csrc/chol16.h + GATHER == 3, the pivot / helper pair measured in round 6 (profiles/r06_chol16_pair_probe.txt; the row-layout
+                           // pivot block measured earlier in the round lives in chol16_rows.h, profiles/r06_chol16_rows_probe.txt)
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 using namespace sadvio;
@@ -56,7 +57,7 @@ static bool host_solve(std::vector<double> S, std::vector<double> b, int N, std:
 
 int main() {
     CK(hipSetDevice(0));
-    const int sizes[] = {114, 165, 174, 1, 3, 5, 15, 16, 17, 31, 32, 33, 48, 60, 96, 128, 160, 113, 112};
+    const int sizes[] = {114, 120, 165, 174, 1, 3, 5, 15, 16, 17, 31, 32, 33, 48, 60, 96, 128, 160, 113, 112};
     srand(7);
     for (int N : sizes) {
         std::vector<double> S((size_t)N * N), b(N), x;
@@ -83,7 +84,7 @@ int main() {
         CK(hipMemset(dts, 0, 128 * 8));
         const size_t lds = (size_t)(sz + C16_WORK + 16 * nb + 16 * nb + 16) * 8;
       for (int var = 0; var < 2; var++) {
-        auto kern = var ? k_probe<2> : k_probe<1>;   // 1: the 4-column MFMA steps (rounds 2 - 5), 2: the row-layout DPP pivot block (round 6)
+        auto kern = var ? k_probe<3> : k_probe<1>;   // 1: the 4-column MFMA steps on one pivot wave (rounds 2 - 5), 2: GATHER = 3, the pivot / helper pair (round 6)
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(1), dim3(512), lds, 0, dimg, N, dx, dts, dok, 3);
         CK(hipDeviceSynchronize());
@@ -97,19 +98,24 @@ int main() {
         double res = 0;
         for (int i = 0; i < N; i++) { double t = -b[i]; for (int j = 0; j < N; j++) t += S[(size_t)i * N + j] * xg[j]; res = fmax(res, fabs(t)); }
         long long ts2[128];
-        if (N == 114 || N == 165) {   // second launch with the in-step stamps (they cost ~55 cycles each: not in the timed run)
+        if (N == 114 || N == 165 || N == 120 || N == 174) {   // second launch with the in-step stamps (they cost ~55 cycles each: not in the timed run)
             hipLaunchKernelGGL(kern, dim3(1), dim3(512), lds, 0, dimg, N, dx, dts, dok, 2);
             CK(hipDeviceSynchronize());
             CK(hipMemcpy(ts2, dts, 128 * 8, hipMemcpyDeviceToHost));
         }
         printf("N=%3d variant=%d ok=%d max|x - x_host| %.2e (|x| %.2e) residual %.2e  solve %lld cyc = %.2f us", N, var + 1, ok, err, mx, res, ts[31] - ts[30], (ts[31] - ts[30]) / 2400.0);
-        if (N == 114 || N == 165) {
+        if (N == 114 || N == 165 || N == 120 || N == 174) {
             printf("\n      block phases (cycles: replay | look-ahead+trailing):");
             const int nbc = c16_blocks(N);
             for (int kb = 0; kb < nbc && kb < 8; kb++) printf(" %lld|%lld", ts[1 + 2 * kb] - (kb ? ts[2 * kb] : ts[0]), ts[2 + 2 * kb] - ts[1 + 2 * kb]);
-            printf("\n      last pivot block, per step [pairs gather chol y mfma Mpad]:");
-            for (int st = 0; st < 4; st++) { printf(" |"); for (int q = 1; q <= 6; q++) printf(" %lld", ts2[32 + 8 * st + q] - ts2[32 + 8 * st + q - 1]); }
-            if (var == 1) printf("\n      row-layout pivot block 4: 4 steps %lld, 16 steps %lld, outputs %lld", ts2[32 + 3] - ts2[32], ts2[32 + 1] - ts2[32], ts2[32 + 2] - ts2[32 + 1]);
+            if (var == 1) {
+                printf("\n      last pivot block, cycles since its first stamp, per step [pivot: start, y published | helper: pivots read, Mpad, y read, W]:");
+                for (int st = 0; st < 4; st++) { printf(" |"); for (int q = 0; q <= 5; q++) printf(" %lld", ts2[32 + 8 * st + q] - ts2[32]); }
+            }
+            if (var == 0) {
+                printf("\n      last pivot block, per step [pairs gather chol y mfma Mpad]:");
+                for (int st = 0; st < 4; st++) { printf(" |"); for (int q = 1; q <= 6; q++) printf(" %lld", ts2[32 + 8 * st + q] - ts2[32 + 8 * st + q - 1]); }
+            }
             printf("\n     ");
             printf("  first block %lld, back-substitution %lld", ts[0] - ts[30], ts[20] - ts[2 * (nbc < 8 ? nbc : 8)]);
         }

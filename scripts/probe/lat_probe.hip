@@ -66,7 +66,37 @@ __global__ __launch_bounds__(64) void k_lat(double* out, double* sink, double se
     // 11: v_rcp_f64 dependent
     a = seed;
     TEST(11, 64, , asm volatile(R64("v_rcp_f64 %0, %0\n\ts_nop 0\n\t") : "+v"(a)), acc += a)
-    // 12: 4 movs + fmac dpp chain: v_mov_b32 x4 then dpp read (as in c16_row_iter)
+    // 12 / 13 / 14: dependent v_fma_f64 with EXEC = 16 lanes / 1 lane / 32 lanes (does the VALU skip passes without active lanes?)
+    a = seed;
+    TEST(12, 64, , asm volatile("s_mov_b64 s[22:23], exec\n\ts_mov_b64 exec, 0xffff\n\t" R64("v_fma_f64 %0, %0, %1, %2\n\t") "s_mov_b64 exec, s[22:23]\n\t" : "+v"(a) : "v"(b), "v"(c) : "s22", "s23"), acc += a)
+    a = seed;
+    TEST(13, 64, , asm volatile("s_mov_b64 s[22:23], exec\n\ts_mov_b64 exec, 1\n\t" R64("v_fma_f64 %0, %0, %1, %2\n\t") "s_mov_b64 exec, s[22:23]\n\t" : "+v"(a) : "v"(b), "v"(c) : "s22", "s23"), acc += a)
+    a = seed;
+    TEST(14, 64, , asm volatile("s_mov_b64 s[22:23], exec\n\ts_mov_b64 exec, 0xffffffff\n\t" R64("v_fma_f64 %0, %0, %1, %2\n\t") "s_mov_b64 exec, s[22:23]\n\t" : "+v"(a) : "v"(b), "v"(c) : "s22", "s23"), acc += a)
+    // 15: independent v_fma_f64 x8 with EXEC = 16 lanes (issue)
+    TEST(15, 64, , asm volatile("s_mov_b64 s[22:23], exec\n\ts_mov_b64 exec, 0xffff\n\t" R4(R4("v_fma_f64 %0, %0, %8, %9\n\tv_fma_f64 %1, %1, %8, %9\n\tv_fma_f64 %2, %2, %8, %9\n\tv_fma_f64 %3, %3, %8, %9\n\t")) "s_mov_b64 exec, s[22:23]\n\t"
+         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "s22", "s23"), acc += a0 + a1 + a2 + a3)
+    // 16: dependent v_fma_f32; 17: dependent v_pk_fma_f32
+    { float fa = (float)seed, fb = 1.0000001f, fc = 1e-9f;
+      TEST(16, 64, , asm volatile(R64("v_fma_f32 %0, %0, %1, %2\n\t") : "+v"(fa) : "v"(fb), "v"(fc)), acc += fa) }
+    // 18: dependent MFMA f64 16x16x4 chain (D = A B + D); 19: the 4x4x4 (4 blocks) variant; 20: result -> v_mul_f64 -> both operands of the next (one pivot-step hop)
+    { typedef double d4 __attribute__((ext_vector_type(4)));
+      d4 D = {a, a, a, a};
+      TEST(18, 16, , asm volatile(R16("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0\n\t") : "+v"(D) : "v"(b), "v"(c)), acc += D[0] + D[1] + D[2] + D[3])
+      double d1 = a;
+      TEST(19, 16, , asm volatile(R16("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0\n\t") : "+v"(d1) : "v"(b), "v"(c)), acc += d1)
+      D = (d4){a, a, a, a};
+      double yv = 0.0;
+      TEST(20, 16, , asm volatile("v_mov_b64 v[104:105], %0\n\tv_mov_b64 v[106:107], %0\n\tv_mov_b64 v[108:109], %0\n\tv_mov_b64 v[110:111], %0\n\t"
+                                  R16("v_mul_f64 %0, v[106:107], %1\n\tv_mfma_f64_16x16x4_f64 v[104:111], %0, %0, v[104:111]\n\t") "s_nop 7\n\ts_nop 7\n\tv_mov_b64 %0, v[106:107]\n\t"
+                                  : "+v"(yv) : "v"(b) : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111"), acc += yv) }
+    // 21: wave-private LDS round trip: ds_write_b64 then ds_read_b64 of another lane's slot, dependent chain
+    { __shared__ double lbuf[64];
+      a = seed;
+      TEST(21, 16, , for (int q = 0; q < 16; q++) { lbuf[threadIdx.x] = a; asm volatile("" ::: "memory"); a = lbuf[threadIdx.x ^ 17] * b; asm volatile("" ::: "memory"); }, acc += a) }
+    // 22: ds_bpermute_b32 x2 (64-bit shuffle) dependent chain
+    a = seed;
+    TEST(22, 16, , for (int q = 0; q < 16; q++) { a = __shfl(a, (threadIdx.x + 17) & 63) * b; }, acc += a)
     sink[threadIdx.x] = acc;
 }
 
@@ -84,7 +114,10 @@ int main() {
     const char* names[] = {"dependent v_fma_f64", "independent v_fma_f64 (issue)", "dependent v_rsq_f64 (+s_nop 0)", "dependent v_fmac_f64_dpp",
                            "independent v_fmac_f64_dpp (issue)", "readlane x2 -> v_mul_f64 with the SGPR pair (round trip)", "dependent v_mul_f64",
                            "v_permlane16_swap_b32 x2 chain", "s_nop 1 + v_mov_b64_dpp chain", "pivot chain via readlane (per column)",
-                           "pivot chain via v_mov_b64_dpp (per column)", "dependent v_rcp_f64 (+s_nop 0)"};
-    for (int i = 0; i < 12; i++) printf("%-62s %7.1f cycles (100 MHz ticks x 24: %.1f shader cycles)\n", names[i], h[i], h[i] * 24.0);
+                           "pivot chain via v_mov_b64_dpp (per column)", "dependent v_rcp_f64 (+s_nop 0)",
+                           "dependent v_fma_f64, EXEC = 16 lanes", "dependent v_fma_f64, EXEC = 1 lane", "dependent v_fma_f64, EXEC = 32 lanes", "independent v_fma_f64, EXEC = 16 lanes (issue)",
+                           "dependent v_fma_f32", "(unused)", "dependent v_mfma_f64_16x16x4 (accumulator chain)", "dependent v_mfma_f64_4x4x4 (accumulator chain)",
+                           "mfma 16x16x4 -> v_mul_f64 -> mfma operand (one hop)", "LDS round trip: ds_write_b64 -> ds_read_b64 -> v_mul_f64", "ds_bpermute x2 -> v_mul_f64"};
+    for (int i = 0; i < 23; i++) printf("%-62s %7.1f cycles (s_memtime)\n", names[i], h[i]);
     return 0;
 }
