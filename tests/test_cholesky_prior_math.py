@@ -1,4 +1,4 @@
-"""The algebra behind the Cholesky form of the marginalisation prior (include/sadvio_ba.h, DESIGN.md §4 "Round 4"), stated in NumPy so
+"""The algebra behind the Cholesky form of the marginalisation prior (include/sadvio_ba.h, docs/KERNEL_HISTORY.md "Round 4"), stated in NumPy so
 that the claims the device code relies on are executable without a GPU:
   * J = L^T, r0 = -L^-1 bk (bk carried through the factorisation as its right-hand side) is a MarginalizationFactor with the same
     J^T J, J^T r0 and hence the same Gauss-Newton system as the reference's eigen form J = Lambda^1/2 U^T, r0 = -Lambda^-1/2 U^T bk

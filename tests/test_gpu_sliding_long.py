@@ -41,10 +41,12 @@ def cols_in(w, pr):
     return np.array(idx, dtype=np.int32), np.array(col, dtype=np.int32)
 
 
-def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS, run=("dev", "ora"), hook=None, n_win=N_WIN, n_kf=N_KF, n_lmk=1100, length=17.0, resync=None, keep_cap=None):
+def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS, run=("dev", "ora"), hook=None, n_win=N_WIN, n_kf=N_KF, n_lmk=1100, length=17.0, resync=None, keep_cap=None,
+                 snap=None):
     """run: the sides to propagate ("ora" alone runs on a CPU: scripts/rank_arbiter.py); hook(step, side, w, g, args): called after every
     marginalisation; resync(step, log_row, sides, prior, be) -> bool: called after a step whose prior ranks differ, may align the two
-    sides again (see test_25_key_frame_steps)."""
+    sides again (see test_25_key_frame_steps); snap(step, side, state, kfs2, result, rank): called after every solve + write-back (golden fixtures of
+    one side: scripts/gen_sliding_golden.py)."""
     N_WIN_, N_KF_ = n_win, n_kf
     if vio:
         W = make_vio_window(n_kf=N_KF_, n_lmk=n_lmk, seed=977, obs_per_lmk=6, length=length)
@@ -149,6 +151,8 @@ def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS, ru
                 r = oracle_lib.solve(w2, opts, dense_prior=w2.dense_prior)
                 results[side] = (r["summary"].iterations, r["summary"].termination, r["summary"].final_cost, r)
             (apply_deltas if vio else apply_vo)(st, kfs2, keep_l2, results[side][3])
+            if snap is not None:
+                snap(step, side, st, kfs2, results[side], ranks[side])
         if len(run) < 2:
             (it, term, cost, _), = results.values()
             log.append(dict(step=step, it=(it, it), term=(term, term), cost=cost, rank=ranks[run[0]]))
