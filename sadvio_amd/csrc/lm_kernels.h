@@ -325,20 +325,12 @@ __global__ __launch_bounds__(LM_PASS_THREADS, 2) void k_lm_pass(DevPtrs P, int s
                 gn[0] += Jl[0] * r[0] + Jl[3] * r[1]; gn[1] += Jl[1] * r[0] + Jl[4] * r[1]; gn[2] += Jl[2] * r[0] + Jl[5] * r[1];
             }
             // key-frame sums: this step's observations by key, the wave's current key first
-#ifdef LM_EXP_NOD
-            const bool has = false;
-#else
             const bool has = act && row >= 0;
-#endif
             unsigned long long todo = __ballot(has);
             while (todo) {
                 int k = cur_key;
                 if (!(__ballot(has && sl == cur_key) & todo)) k = __builtin_amdgcn_readlane(sl, __ffsll((long long)todo) - 1);
-#ifdef LM_EXP_NOFLUSH
-                cur_key = k;
-#else
                 if (k != cur_key) { if (cur_key >= 0) flush(); cur_key = k; }
-#endif
                 const bool mine = has && sl == k;
                 if (mine) {
                     int e = 0;

@@ -572,9 +572,7 @@ __global__ __launch_bounds__(256) void k_pchol_syrk_full(double* __restrict__ S,
 // 60 - 90 us, an order of magnitude more than a launch boundary.)
 constexpr int JB = 4;            // rows per block
 constexpr int JB2 = 2 * JB;
-#ifndef JB_INNER
-#define JB_INNER 1
-#endif
+constexpr int JB_INNER = 1;     // inner sweeps of a block's 2 JB x 2 JB diagonalisation
 template <int EPT>               // elements per thread and row: n <= 256 * EPT
 __global__ __launch_bounds__(JAC_THREADS) void k_jacobi_block(double* __restrict__ G, int r, int n, int nbpad, int s, double tol, int* rotated) {
     __shared__ double part[JAC_THREADS / 64][JB2 * (JB2 + 1) / 2];
