@@ -7,8 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "chol16_pair.h"   // = sadvio_amd/csrc/chol16.h + GATHER == 3, the pivot / helper pair measured in round 6 (profiles/r06_chol16_pair_probe.txt; the row-layout
-                           // pivot block measured earlier in the round lives in chol16_rows.h, profiles/r06_chol16_rows_probe.txt)
+#include "../../sadvio_amd/csrc/chol16.h"   // the product header (the round-6 experiments live in chol16_rows.h / chol16_pair.h with their own records in profiles/)
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 using namespace sadvio;
@@ -84,7 +83,7 @@ int main() {
         CK(hipMemset(dts, 0, 128 * 8));
         const size_t lds = (size_t)(sz + C16_WORK + 16 * nb + 16 * nb + 16) * 8;
       for (int var = 0; var < 2; var++) {
-        auto kern = var ? k_probe<3> : k_probe<1>;   // 1: the 4-column MFMA steps on one pivot wave (rounds 2 - 5), 2: GATHER = 3, the pivot / helper pair (round 6)
+        auto kern = var ? k_probe<0> : k_probe<1>;   // 1: the product (pivot entries gathered through LDS), 2: GATHER = 0 (v_readlane + v_permlane swaps)
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(1), dim3(512), lds, 0, dimg, N, dx, dts, dok, 3);
         CK(hipDeviceSynchronize());
@@ -108,10 +107,6 @@ int main() {
             printf("\n      block phases (cycles: replay | look-ahead+trailing):");
             const int nbc = c16_blocks(N);
             for (int kb = 0; kb < nbc && kb < 8; kb++) printf(" %lld|%lld", ts[1 + 2 * kb] - (kb ? ts[2 * kb] : ts[0]), ts[2 + 2 * kb] - ts[1 + 2 * kb]);
-            if (var == 1) {
-                printf("\n      last pivot block, cycles since its first stamp, per step [pivot: start, y published | helper: pivots read, Mpad, y read, W]:");
-                for (int st = 0; st < 4; st++) { printf(" |"); for (int q = 0; q <= 5; q++) printf(" %lld", ts2[32 + 8 * st + q] - ts2[32]); }
-            }
             if (var == 0) {
                 printf("\n      last pivot block, per step [pairs gather chol y mfma Mpad]:");
                 for (int st = 0; st < 4; st++) { printf(" |"); for (int q = 1; q <= 6; q++) printf(" %lld", ts2[32 + 8 * st + q] - ts2[32 + 8 * st + q - 1]); }
