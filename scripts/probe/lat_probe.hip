@@ -26,6 +26,22 @@ __device__ __forceinline__ long long now() {
         if (threadIdx.x == 0) out[ID] = (double)(t1 - t0) / (16.0 * (N));     \
     }
 
+// waves 0 and 4 of a 320-thread workgroup share SIMD 0: the MFMA pipe under two waves (test 24)
+__global__ __launch_bounds__(320) void k_mfma2(double* out, double* sink, double seed) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int wv = threadIdx.x >> 6;
+    if (wv != 0 && wv != 4) return;
+    double b = 1.0000001, c = 1e-9, a = seed + (threadIdx.x & 63) * 1e-3;
+    d4 D0 = {a, a, a, a}, D1 = D0, D2 = D0, D3 = D0;
+    long long t0 = now();
+    for (int it = 0; it < 16; it++)
+        asm volatile(R16("v_mfma_f64_16x16x4_f64 %0, %4, %5, %0\n\tv_mfma_f64_16x16x4_f64 %1, %4, %5, %1\n\tv_mfma_f64_16x16x4_f64 %2, %4, %5, %2\n\tv_mfma_f64_16x16x4_f64 %3, %4, %5, %3\n\t")
+                     : "+v"(D0), "+v"(D1), "+v"(D2), "+v"(D3) : "v"(b), "v"(c));
+    long long t1 = now();
+    if ((threadIdx.x & 63) == 0) out[24 + (wv ? 1 : 0)] = (double)(t1 - t0) / (16.0 * 64);
+    sink[threadIdx.x] = D0[0] + D1[1] + D2[2] + D3[3];
+}
+
 __global__ __launch_bounds__(64) void k_lat(double* out, double* sink, double seed) {
     double a = seed + threadIdx.x * 1e-3, b = 1.0000001, c = 1e-9, acc = 0.0;
     double a0 = a, a1 = a + 1, a2 = a + 2, a3 = a + 3, a4 = a + 4, a5 = a + 5, a6 = a + 6, a7 = a + 7;
@@ -90,6 +106,11 @@ __global__ __launch_bounds__(64) void k_lat(double* out, double* sink, double se
       TEST(20, 16, , asm volatile("v_mov_b64 v[104:105], %0\n\tv_mov_b64 v[106:107], %0\n\tv_mov_b64 v[108:109], %0\n\tv_mov_b64 v[110:111], %0\n\t"
                                   R16("v_mul_f64 %0, v[106:107], %1\n\tv_mfma_f64_16x16x4_f64 v[104:111], %0, %0, v[104:111]\n\t") "s_nop 7\n\ts_nop 7\n\tv_mov_b64 %0, v[106:107]\n\t"
                                   : "+v"(yv) : "v"(b) : "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111"), acc += yv) }
+    // 23: four INDEPENDENT accumulators of v_mfma_f64_16x16x4 from one wave (pipe occupancy per instruction)
+    { typedef double d4 __attribute__((ext_vector_type(4)));
+      d4 D0 = {a, a, a, a}, D1 = D0, D2 = D0, D3 = D0;
+      TEST(23, 64, , asm volatile(R16("v_mfma_f64_16x16x4_f64 %0, %4, %5, %0\n\tv_mfma_f64_16x16x4_f64 %1, %4, %5, %1\n\tv_mfma_f64_16x16x4_f64 %2, %4, %5, %2\n\tv_mfma_f64_16x16x4_f64 %3, %4, %5, %3\n\t")
+                                  : "+v"(D0), "+v"(D1), "+v"(D2), "+v"(D3) : "v"(b), "v"(c)), acc += D0[0] + D1[1] + D2[2] + D3[3]) }
     // 21: wave-private LDS round trip: ds_write_b64 then ds_read_b64 of another lane's slot, dependent chain
     { __shared__ double lbuf[64];
       a = seed;
@@ -103,10 +124,11 @@ __global__ __launch_bounds__(64) void k_lat(double* out, double* sink, double se
 int main() {
     CK(hipSetDevice(0));
     double *out, *sink;
-    CK(hipMalloc(&out, 64 * 8)); CK(hipMalloc(&sink, 64 * 8));
+    CK(hipMalloc(&out, 64 * 8)); CK(hipMalloc(&sink, 512 * 8));
     CK(hipMemset(out, 0, 64 * 8));
     for (int rep = 0; rep < 2; rep++) {
         hipLaunchKernelGGL(k_lat, dim3(1), dim3(64), 0, 0, out, sink, 1.25);
+        hipLaunchKernelGGL(k_mfma2, dim3(1), dim3(320), 0, 0, out, sink, 1.25);
         CK(hipDeviceSynchronize());
     }
     double h[64];
@@ -117,7 +139,8 @@ int main() {
                            "pivot chain via v_mov_b64_dpp (per column)", "dependent v_rcp_f64 (+s_nop 0)",
                            "dependent v_fma_f64, EXEC = 16 lanes", "dependent v_fma_f64, EXEC = 1 lane", "dependent v_fma_f64, EXEC = 32 lanes", "independent v_fma_f64, EXEC = 16 lanes (issue)",
                            "dependent v_fma_f32", "(unused)", "dependent v_mfma_f64_16x16x4 (accumulator chain)", "dependent v_mfma_f64_4x4x4 (accumulator chain)",
-                           "mfma 16x16x4 -> v_mul_f64 -> mfma operand (one hop)", "LDS round trip: ds_write_b64 -> ds_read_b64 -> v_mul_f64", "ds_bpermute x2 -> v_mul_f64"};
-    for (int i = 0; i < 23; i++) printf("%-62s %7.1f cycles (s_memtime)\n", names[i], h[i]);
+                           "mfma 16x16x4 -> v_mul_f64 -> mfma operand (one hop)", "LDS round trip: ds_write_b64 -> ds_read_b64 -> v_mul_f64", "ds_bpermute x2 -> v_mul_f64",
+                           "independent v_mfma_f64_16x16x4 (4 accumulators, one wave), per instruction", "same, two waves on one SIMD: wave 0", "same, two waves on one SIMD: wave 4"};
+    for (int i = 0; i < 26; i++) printf("%-62s %7.1f cycles (s_memtime)\n", names[i], h[i]);
     return 0;
 }
