@@ -2048,7 +2048,14 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     hev.resize(std::max(m, n));
     bool mm_by_cholesky = false;
     HIP_TRY(M.wtmp.alloc((size_t)big + 16));
-    if (m > 0 && !h->env.marg_eig_mm && !h->env.marg_pivoted && rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE) {
+    // ... but NOT behind a rank-deficient previous prior (round 6): it hands frame0's block a direction whose eigenvalue lies below the
+    // reference's cut while every pivot of a Cholesky factorisation passes (pivots bound eigenvalues from above only). The reference's
+    // pseudo-inverse zeroes that direction (marginalization.cpp:234-240), an inverse divides by it: at step 13 of the config-3-size dense
+    // sequence (previous prior 917 of 918) Ak lost 9 187 of information along the kept frame's rotation that way — 1e-6 in the next solve's
+    // poses (tests/test_gpu_sliding_full_size.py; found by marginalising the device's own window with the oracle). Those calls take the
+    // eigen-decomposition with the request's cut, as the reference does.
+    const bool mm_cholesky_ok = nfl == nl;      // no previous prior (0 == 0) or one of full rank
+    if (m > 0 && !h->env.marg_eig_mm && !h->env.marg_pivoted && rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE && mm_cholesky_ok) {
         // Amm is positive definite whenever frame0 carries a prior or enough observations: unpivoted wide-panel factor first (run_wfac)
         const long long mm2 = (long long)m * m;
         HIP_TRY(M.Vs.alloc(std::max(wfac_scratch_doubles(m), (size_t)big * big)));
@@ -2066,7 +2073,7 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
             mm_by_cholesky = true;
         }
     }
-    if (!mm_by_cholesky && m >= 32 && m <= PCH_MAXN && !h->env.marg_eig_mm) {
+    if (!mm_by_cholesky && m >= 32 && m <= PCH_MAXN && !h->env.marg_eig_mm && (mm_cholesky_ok || rq->eig_cut_mode != SADVIO_EIG_CUT_REFERENCE)) {
         const long long mm2 = (long long)m * m;
         hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((mm2 + 255) / 256)), dim3(256), 0, h->stream, M.A.p, (long long)N, m, M.V.p, M.G.p, 0);
         const int r = run_pchol(h, M.V.p, m, M.G.p, pchol_tau(m, SADVIO_EIG_CUT_NOISE_FLOOR), false);

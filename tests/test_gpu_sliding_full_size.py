@@ -4,7 +4,12 @@ marginalize -> [sparsify] -> solve -> write-back (slamBiMonoVIO.cpp:561-614) on 
 of the same sequence. The oracle needs two minutes per step at this size, so its side is a committed fixture
 (tests/golden/sliding_config3_size_*.npz, written by scripts/gen_sliding_golden.py from oracle/ on the CPU); the device side propagates its
 own state, as in tests/test_gpu_sliding_long.py, so a disagreement compounds over the 25 steps. Bars: the same prior rank, iteration count
-and termination at every step, cost to 1e-7 relative, pose deltas and the trajectories to 1e-6, landmarks to 1e-6 relative."""
+and termination at every step, pose deltas and the trajectories to 1e-6, landmarks to 1e-6 relative, cost to 5e-7 relative (the solves stop
+at a relative cost change of 1e-6 - AOptimizer.cpp:315-323 - so the final cost of a window is defined to about that; measured: 1.2e-7 at the
+last step of the dense sequence, whose solve amplifies the 2e-8 the trajectories differ by when they enter it fifteen-fold, <= 1e-8 elsewhere).
+Round 6 found a defect with this test: behind a rank-deficient previous prior the pseudo-inverse of the marginalised block was taken as a
+Cholesky inverse although one eigenvalue lay below the reference's cut (step 13 of the dense sequence: 1.1e-6 in the poses, 7.8e-6 by
+step 24; 4e-9 / 3e-7 after the fix in sadvio_ba_marginalize)."""
 import os
 
 import numpy as np
@@ -46,6 +51,6 @@ def test_config3_size_sequence_against_the_oracle_fixture(backend_cls, sparsif):
     print(f"[sliding config-3 size, {'sparsified' if sparsif else 'dense'}] {n_steps} steps, prior columns {sorted(set(int(v[1]) for v in gold['rank']))[:1]}..{max(int(v[1]) for v in gold['rank'])}: "
           f"worst per-step |dpose| {worst['pose']:.2e}, cost {worst['cost']:.2e}, trajectory difference {worst['drift']:.2e}; landmarks within 1 km {rel[~far].max():.2e}, "
           f"beyond ({int(far.sum())}) {rel[far].max() if far.any() else 0.0:.2e}; device routes {stats}")
-    assert worst["cost"] <= 1e-7 and worst["pose"] <= 1e-6 and worst["drift"] <= 1e-6, worst
+    assert worst["cost"] <= 5e-7 and worst["pose"] <= 1e-6 and worst["drift"] <= 1e-6, worst
     assert rel[~far].max() <= 1e-6
     assert not far.any() or rel[far].max() <= 1e-3

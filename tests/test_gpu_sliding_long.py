@@ -42,20 +42,28 @@ def cols_in(w, pr):
 
 
 def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS, run=("dev", "ora"), hook=None, n_win=N_WIN, n_kf=N_KF, n_lmk=1100, length=17.0, resync=None, keep_cap=None,
-                 snap=None):
+                 snap=None, replica=None, nudge_seed=None, dev_form="cholesky", state_noise=None):
     """run: the sides to propagate ("ora" alone runs on a CPU: scripts/rank_arbiter.py); hook(step, side, w, g, args): called after every
     marginalisation; resync(step, log_row, sides, prior, be) -> bool: called after a step whose prior ranks differ, may align the two
     sides again (see test_25_key_frame_steps); snap(step, side, state, kfs2, result, rank): called after every solve + write-back (golden fixtures of
-    one side: scripts/gen_sliding_golden.py)."""
+    one side: scripts/gen_sliding_golden.py); replica(step, w, args, w2, prior_template): oracle side of a dense sequence, called before the
+    step's solve with everything a second, perturbed evaluation of the SAME step needs (the oracle's self-sensitivity, same script)."""
     N_WIN_, N_KF_ = n_win, n_kf
     if vio:
         W = make_vio_window(n_kf=N_KF_, n_lmk=n_lmk, seed=977, obs_per_lmk=6, length=length)
     else:
         W = synthetic.make_window(n_kf=N_KF_, n_lmk=n_lmk, seed=977, obs_per_lmk=6, length=length)
         W.kf_vel = W.kf_ba = W.kf_bg = np.zeros((N_KF_, 3)); W.imu_factors = []
+    if nudge_seed is not None:      # every measurement of the trajectory moved by one unit in the last place (self-sensitivity of a whole sequence)
+        rng = np.random.default_rng(nudge_seed)
+        m = np.asarray(W.obs_meas)
+        W.obs_meas = np.where(rng.random(m.shape) < 0.5, np.nextafter(m, np.inf), np.nextafter(m, -np.inf))
     opts = capi.reference_options()
     init = {"T": W.kf_T_f_w.copy(), "p": W.lmk_p.copy(), "v": np.array(W.kf_vel, dtype=float).copy(), "ba": np.array(W.kf_ba, dtype=float).copy(),
             "bg": np.array(W.kf_bg, dtype=float).copy()}
+    if state_noise is not None:     # (seed, eps): the initial landmark estimates moved by eps relative — the size of the state difference two
+        rng = np.random.default_rng(state_noise[0])     # implementations carry into a step after a few of them (conditioning of a sequence, scripts/)
+        init["p"] = init["p"] * (1.0 + state_noise[1] * rng.standard_normal(init["p"].shape))
     sides = {"dev": copy.deepcopy(init), "ora": copy.deepcopy(init)}
     be = backend_cls(device=0) if "dev" in run else None
     oldest = W.n_kf - 1
@@ -99,7 +107,7 @@ def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS, ru
                 args.update(kf_keep=frame1, marg_has_imu=True, imu=[f for f in w.imu_factors if f["kf_i"] == frame0 and f["kf_j"] == frame1][0])
             if side == "dev":
                 be.set_windows([w])
-                g = be.marginalize(0, form="cholesky", readback=False, **args)
+                g = be.marginalize(0, form=dev_form, readback=False, **args)
                 fs = be.sparsify(0, g, vio=vio) if sparsif else None
             else:
                 g = oracle_lib.marginalize(w, **args)
@@ -140,6 +148,8 @@ def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS, ru
                 dp = {"kf_keep": int(np.flatnonzero(w2.kf_id == new_prior["kf_id"])[0]) if vio else -1, "kf_col": new_prior["kf_col"] if vio else 0,
                       "lmk_index": idx, "lmk_col": col}
                 if side == "ora":
+                    if replica is not None:
+                        replica(step, w, args, w2, dict(dp))
                     dp["J"], dp["r0"] = g["J"], g["r0"]
                 w2.dense_prior = dp
             if side == "dev":
