@@ -6,12 +6,14 @@ minutes per step at this size (cyclic Jacobi of a 915-column prior, dense-prior 
 run it beside the device: it is generated once, on the CPU, and the device's sequence is compared with it step by step
 (tests/test_gpu_sliding_full_size.py).
 
-Dense variant: beside every step the oracle evaluates the SAME step again (marginalize + solve from the same state) with every measurement
+Dense variant, optional (third argument = number of draws; the committed fixture was written with 0): beside every step the oracle
+evaluates the SAME step again (marginalize + solve from the same state) with every measurement
 of the two windows AND every entry of the previous prior (J, r0) nudged by one unit in the last place (N_DRAWS seeded draws, worker
 processes): how far the oracle itself moves —
 tests/conditioning.py's self-sensitivity, per step. A step behind a rank-deficient prior can amplify a 1-ulp input change to 1e-6 in a pose;
 no second implementation reproduces the oracle better than that there, and the test's bar follows that number where the fixed one fails.
-Usage: python scripts/gen_sliding_golden.py [n_steps] [dense|sparsified]"""
+Every fixture written with draws also holds the per-iteration log of each solve (layout of sadvio_ba_get_trace).
+Usage: python scripts/gen_sliding_golden.py [n_steps] [dense|sparsified] [n_draws]"""
 import multiprocessing, os, sys, time
 from concurrent.futures import ProcessPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +21,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 FULL = dict(n_win=12, n_kf=40, n_lmk=10200, length=20.0, keep_cap=300)
-N_DRAWS = 2
+N_DRAWS = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 
 
 def _nudge(win, rng):
@@ -55,7 +57,7 @@ if __name__ == "__main__":
     sparsif = (sys.argv[2] if len(sys.argv) > 2 else "sparsified") == "sparsified"
     rec = {"it": [], "term": [], "cost": [], "rank": [], "pose": [], "T": [], "kfs": [], "log": []}
     t0 = time.time()
-    pool = None if sparsif else ProcessPoolExecutor(max_workers=5, mp_context=multiprocessing.get_context("spawn"))
+    pool = None if (sparsif or N_DRAWS == 0) else ProcessPoolExecutor(max_workers=5, mp_context=multiprocessing.get_context("spawn"))
     futures = []
 
     def snap(step, side, st, kfs2, result, rank):
@@ -69,9 +71,9 @@ if __name__ == "__main__":
         for draw in range(N_DRAWS):
             futures.append(pool.submit(replica_job, (step, draw, w, args, w2, dpt)))
 
-    log, _, sides = run_sequence(None, oracle, True, sparsif, "reference", n_steps=n_steps, run=("ora",), snap=snap, replica=None if sparsif else replica, **FULL)
+    log, _, sides = run_sequence(None, oracle, True, sparsif, "reference", n_steps=n_steps, run=("ora",), snap=snap, replica=None if pool is None else replica, **FULL)
     extra = {}
-    if not sparsif:
+    if pool is not None:
         sens_pose = np.zeros(n_steps); sens_cost = np.zeros(n_steps); sens_same = np.ones(n_steps, dtype=np.uint8)
         for f in futures:
             step, draw, pose, cost, it, term, rank = f.result()
