@@ -2048,14 +2048,29 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     hev.resize(std::max(m, n));
     bool mm_by_cholesky = false;
     HIP_TRY(M.wtmp.alloc((size_t)big + 16));
-    // ... but NOT behind a rank-deficient previous prior (round 6): it hands frame0's block a direction whose eigenvalue lies below the
-    // reference's cut while every pivot of a Cholesky factorisation passes (pivots bound eigenvalues from above only). The reference's
-    // pseudo-inverse zeroes that direction (marginalization.cpp:234-240), an inverse divides by it: at step 13 of the config-3-size dense
-    // sequence (previous prior 917 of 918) Ak lost 9 187 of information along the kept frame's rotation that way — 1e-6 in the next solve's
-    // poses (tests/test_gpu_sliding_full_size.py; found by marginalising the device's own window with the oracle). Those calls take the
-    // eigen-decomposition with the request's cut, as the reference does.
-    const bool mm_cholesky_ok = nfl == nl;      // no previous prior (0 == 0) or one of full rank
-    if (m > 0 && !h->env.marg_eig_mm && !h->env.marg_pivoted && rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE && mm_cholesky_ok) {
+    // ... but only where the inverse itself PROVES that no eigenvalue of Amm lies below the reference's cut (round 6). Pivots bound
+    // eigenvalues from above only: behind a rank-deficient previous prior frame0's block can carry an eigenvalue below 1e-12 under pivots
+    // that all pass, and where the reference's pseudo-inverse zeroes that direction (marginalization.cpp:234-240) an inverse divides by it
+    // — step 13 of the config-3-size dense sequence (previous prior 917 of 918): Ak lost 9 187 of information along the kept frame's
+    // rotation, 1e-6 in the next solve's poses (tests/test_gpu_sliding_full_size.py; found by marginalising the device's own window
+    // with the oracle, scripts/sliding_same_inputs_marg.py). The proof: lambda_min(Amm) >= 1 / trace(Amm^-1), and trace(Amm^-1) =
+    // |Z|_F^2 of the triangular inverse the route forms anyway (m row norms, one read-back; 2.3e13 at that step, 1e3 .. 5e11 at the other
+    // 24). A trace of 1e12 or more sends the call to the reference's eigen-decomposition with the request's cut. (Gating on the previous
+    // prior's rank instead was measured too: it sends full-rank blocks through the eigen route as well, whose inverse agrees with the
+    // oracle's to 4e-9 where the Cholesky inverse agrees to 1e-11 — the sequence's worst step 3e-7 instead of 1.3e-8.)
+    bool mm_force_eig = false;
+    auto mm_inverse_bounded = [&]() -> int {    // Z (m x m) in M.Vs: 1 = every eigenvalue of Amm above the reference's cut, 0 = not shown, -1 = HIP error
+        if (rq->eig_cut_mode != SADVIO_EIG_CUT_REFERENCE) return 1;
+        if (M.lam.alloc((size_t)m + 2) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_row_norm2, dim3(m), dim3(JAC_THREADS), 0, h->stream, M.Vs.p, m, m, M.lam.p);
+        std::vector<double> rn(m);
+        if (hipMemcpyAsync(rn.data(), M.lam.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+        double tr = 0.0;
+        for (int i = 0; i < m; i++) tr += rn[i];
+        if (h->env.debug & 16384) fprintf(stderr, "[sadvio dbg] marginalize: trace(Amm^-1) %.3e (m %d): lambda_min >= %.3e\n", tr, m, 1.0 / tr);
+        return (tr < 1e12) ? 1 : 0;             // (NaN / inf: not shown)
+    };
+    if (m > 0 && !h->env.marg_eig_mm && !h->env.marg_pivoted && rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE) {
         // Amm is positive definite whenever frame0 carries a prior or enough observations: unpivoted wide-panel factor first (run_wfac)
         const long long mm2 = (long long)m * m;
         HIP_TRY(M.Vs.alloc(std::max(wfac_scratch_doubles(m), (size_t)big * big)));
@@ -2070,10 +2085,13 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
             hipLaunchKernelGGL(k_iota, dim3((m + 255) / 256), dim3(256), 0, h->stream, M.piv_mm.p, m);
             const int rc = prior_build_Z(h, M.G.p, m, m, SADVIO_PRIOR_FORM_CHOLESKY, M.piv_mm.p, M.Vs.p, rq->eig_cut_mode);
             if (rc != SADVIO_OK) return rc;
-            mm_by_cholesky = true;
+            const int ok = mm_inverse_bounded();
+            if (ok < 0) { h->err = "marginalize: HIP error in the eigenvalue bound of Amm"; return SADVIO_E_HIP; }
+            mm_by_cholesky = ok == 1;
+            mm_force_eig = ok == 0;
         }
     }
-    if (!mm_by_cholesky && m >= 32 && m <= PCH_MAXN && !h->env.marg_eig_mm && (mm_cholesky_ok || rq->eig_cut_mode != SADVIO_EIG_CUT_REFERENCE)) {
+    if (!mm_by_cholesky && !mm_force_eig && m >= 32 && m <= PCH_MAXN && !h->env.marg_eig_mm) {
         const long long mm2 = (long long)m * m;
         hipLaunchKernelGGL(k_jacobi_init, dim3((unsigned)((mm2 + 255) / 256)), dim3(256), 0, h->stream, M.A.p, (long long)N, m, M.V.p, M.G.p, 0);
         const int r = run_pchol(h, M.V.p, m, M.G.p, pchol_tau(m, SADVIO_EIG_CUT_NOISE_FLOOR), false);
@@ -2083,7 +2101,9 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
             HIP_TRY(hipMemcpyAsync(M.piv_mm.p, h->d_jac_ints.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, h->stream));
             const int rc = prior_build_Z(h, M.G.p, m, m, SADVIO_PRIOR_FORM_CHOLESKY, M.piv_mm.p, M.Vs.p, rq->eig_cut_mode);
             if (rc != SADVIO_OK) return rc;
-            mm_by_cholesky = true;
+            const int ok = mm_inverse_bounded();
+            if (ok < 0) { h->err = "marginalize: HIP error in the eigenvalue bound of Amm"; return SADVIO_E_HIP; }
+            mm_by_cholesky = ok == 1;
         }
     }
     int sw = 0;

@@ -13,7 +13,7 @@ processes): how far the oracle itself moves —
 tests/conditioning.py's self-sensitivity, per step. A step behind a rank-deficient prior can amplify a 1-ulp input change to 1e-6 in a pose;
 no second implementation reproduces the oracle better than that there, and the test's bar follows that number where the fixed one fails.
 Every fixture written with draws also holds the per-iteration log of each solve (layout of sadvio_ba_get_trace).
-Usage: python scripts/gen_sliding_golden.py [n_steps] [dense|sparsified] [n_draws]"""
+Usage: python scripts/gen_sliding_golden.py [n_steps] [dense|sparsified] [n_draws] [trajectory seed]"""
 import multiprocessing, os, sys, time
 from concurrent.futures import ProcessPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,6 +22,7 @@ import numpy as np
 
 FULL = dict(n_win=12, n_kf=40, n_lmk=10200, length=20.0, keep_cap=300)
 N_DRAWS = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+SEED = int(sys.argv[4]) if len(sys.argv) > 4 else 977        # the trajectory (tests/test_gpu_sliding_long.py::run_sequence)
 
 
 def _nudge(win, rng):
@@ -71,7 +72,7 @@ if __name__ == "__main__":
         for draw in range(N_DRAWS):
             futures.append(pool.submit(replica_job, (step, draw, w, args, w2, dpt)))
 
-    log, _, sides = run_sequence(None, oracle, True, sparsif, "reference", n_steps=n_steps, run=("ora",), snap=snap, replica=None if pool is None else replica, **FULL)
+    log, _, sides = run_sequence(None, oracle, True, sparsif, "reference", n_steps=n_steps, run=("ora",), snap=snap, replica=None if pool is None else replica, seed=SEED, **FULL)
     extra = {}
     if pool is not None:
         sens_pose = np.zeros(n_steps); sens_cost = np.zeros(n_steps); sens_same = np.ones(n_steps, dtype=np.uint8)
@@ -83,8 +84,8 @@ if __name__ == "__main__":
             sens_pose[step] = max(sens_pose[step], dp); sens_cost[step] = max(sens_cost[step], dc); sens_same[step] &= np.uint8(same)
         pool.shutdown()
         extra = dict(sens_pose=sens_pose, sens_cost=sens_cost, sens_same=sens_same, sens_draws=N_DRAWS)
-    out = os.path.join(ROOT, "tests", "golden", f"sliding_config3_size_{'sparsified' if sparsif else 'dense'}.npz")
+    out = os.path.join(ROOT, "tests", "golden", f"sliding_config3_size_{'sparsified' if sparsif else 'dense'}{'' if SEED == 977 else '_s%d' % SEED}.npz")
     np.savez_compressed(out, it=np.array(rec["it"]), term=np.array(rec["term"]), cost=np.array(rec["cost"]), rank=np.array(rec["rank"]),
                         pose=np.array(rec["pose"]), T=np.array(rec["T"]), kfs=np.array(rec["kfs"]), p=sides["ora"]["p"], log=np.array(rec["log"]),
-                        params=np.array([FULL["n_win"], FULL["n_kf"], FULL["n_lmk"], FULL["keep_cap"], n_steps]), length=FULL["length"], **extra)
+                        params=np.array([FULL["n_win"], FULL["n_kf"], FULL["n_lmk"], FULL["keep_cap"], n_steps]), length=FULL["length"], seed=SEED, **extra)
     print("wrote", out, os.path.getsize(out), "bytes")

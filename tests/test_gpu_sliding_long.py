@@ -42,7 +42,7 @@ def cols_in(w, pr):
 
 
 def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS, run=("dev", "ora"), hook=None, n_win=N_WIN, n_kf=N_KF, n_lmk=1100, length=17.0, resync=None, keep_cap=None,
-                 snap=None, replica=None, nudge_seed=None, dev_form="cholesky", state_noise=None):
+                 snap=None, replica=None, nudge_seed=None, dev_form="cholesky", state_noise=None, seed=977):
     """run: the sides to propagate ("ora" alone runs on a CPU: scripts/rank_arbiter.py); hook(step, side, w, g, args): called after every
     marginalisation; resync(step, log_row, sides, prior, be) -> bool: called after a step whose prior ranks differ, may align the two
     sides again (see test_25_key_frame_steps); snap(step, side, state, kfs2, result, rank): called after every solve + write-back (golden fixtures of
@@ -50,9 +50,9 @@ def run_sequence(backend_cls, oracle_lib, vio, sparsif, cut, n_steps=N_STEPS, ru
     step's solve with everything a second, perturbed evaluation of the SAME step needs (the oracle's self-sensitivity, same script)."""
     N_WIN_, N_KF_ = n_win, n_kf
     if vio:
-        W = make_vio_window(n_kf=N_KF_, n_lmk=n_lmk, seed=977, obs_per_lmk=6, length=length)
+        W = make_vio_window(n_kf=N_KF_, n_lmk=n_lmk, seed=seed, obs_per_lmk=6, length=length)
     else:
-        W = synthetic.make_window(n_kf=N_KF_, n_lmk=n_lmk, seed=977, obs_per_lmk=6, length=length)
+        W = synthetic.make_window(n_kf=N_KF_, n_lmk=n_lmk, seed=seed, obs_per_lmk=6, length=length)
         W.kf_vel = W.kf_ba = W.kf_bg = np.zeros((N_KF_, 3)); W.imu_factors = []
     if nudge_seed is not None:      # every measurement of the trajectory moved by one unit in the last place (self-sensitivity of a whole sequence)
         rng = np.random.default_rng(nudge_seed)
