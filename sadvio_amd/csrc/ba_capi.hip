@@ -342,6 +342,7 @@ struct sadvio_ba_handle {
     DevBuf<int> d_lm_sub;                 // work list of k_lm_pass (tile, sub-block), see DevPtrs
     int lm_n_sub = 0, lm_ksub = 1, lm_sub_per_item = 8;   // sub-blocks per work item of k_lm_pass (8 = the whole tile: MAX tile = 512 landmarks)   // throughput path: elimination records, per-landmark H_ll | g_l and per-tile key-frame sums (both per delta buffer)
     int lm_max_cam = 1;
+    int hidden_eig_count = 0;             // sparsify: priors of full rank by their pivots whose inverse showed an eigenvalue that may lie below the cut (SADVIO_DEBUG prints it)
     int marg_stats[4] = {0, 0, 0, 0};     // Cholesky-form marginalisations: calls | took the unpivoted route | tried it and fell back | calls whose rank the eigenvalue refinement lowered
     int lm_sub_obs = 0;                   // most observations of LM_PASS_THREADS consecutive landmarks of a tile (LDS staging of k_lm_pass)
     bool gemm_run4 = false;               // a tile on the MFMA path holds runs of 3 - 4 observations on one key-frame (k_build<.., RARE = true> only)
@@ -1896,7 +1897,7 @@ inline void launch_mgemm(sadvio_ba_handle* h, double* C, long long ldc, const do
 }
 }  // namespace
 
-namespace { int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form, const int* step_of, double* Z, int cut_mode); }
+namespace { int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form, const int* step_of, double* Z, int cut_mode, double* trace_out = nullptr, bool guard = false); }
 
 int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_request* rq, sadvio_marg_result* res, int32_t* lmk_col_out,
                           double* J_out, double* r0_out) {
@@ -2059,16 +2060,9 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
     // prior's rank instead was measured too: it sends full-rank blocks through the eigen route as well, whose inverse agrees with the
     // oracle's to 4e-9 where the Cholesky inverse agrees to 1e-11 — the sequence's worst step 3e-7 instead of 1.3e-8.)
     bool mm_force_eig = false;
-    auto mm_inverse_bounded = [&]() -> int {    // Z (m x m) in M.Vs: 1 = every eigenvalue of Amm above the reference's cut, 0 = not shown, -1 = HIP error
-        if (rq->eig_cut_mode != SADVIO_EIG_CUT_REFERENCE) return 1;
-        if (M.lam.alloc((size_t)m + 2) != hipSuccess) return -1;
-        hipLaunchKernelGGL(k_row_norm2, dim3(m), dim3(JAC_THREADS), 0, h->stream, M.Vs.p, m, m, M.lam.p);
-        std::vector<double> rn(m);
-        if (hipMemcpyAsync(rn.data(), M.lam.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return -1;
-        double tr = 0.0;
-        for (int i = 0; i < m; i++) tr += rn[i];
-        if (h->env.debug & 16384) fprintf(stderr, "[sadvio dbg] marginalize: trace(Amm^-1) %.3e (m %d): lambda_min >= %.3e\n", tr, m, 1.0 / tr);
-        return (tr < 1e12) ? 1 : 0;             // (NaN / inf: not shown)
+    double mm_trace = 0.0;
+    auto mm_inverse_bounded = [&]() -> int {    // 1 = every eigenvalue of Amm above the reference's cut, 0 = not shown (NaN / inf included)
+        return (rq->eig_cut_mode != SADVIO_EIG_CUT_REFERENCE || mm_trace < 1e12) ? 1 : 0;
     };
     if (m > 0 && !h->env.marg_eig_mm && !h->env.marg_pivoted && rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE) {
         // Amm is positive definite whenever frame0 carries a prior or enough observations: unpivoted wide-panel factor first (run_wfac)
@@ -2083,10 +2077,9 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
                                M.wtmp.p + 8, m, M.G.p, M.wtmp.p + 8);
             HIP_TRY(M.piv_mm.alloc(m));
             hipLaunchKernelGGL(k_iota, dim3((m + 255) / 256), dim3(256), 0, h->stream, M.piv_mm.p, m);
-            const int rc = prior_build_Z(h, M.G.p, m, m, SADVIO_PRIOR_FORM_CHOLESKY, M.piv_mm.p, M.Vs.p, rq->eig_cut_mode);
+            const int rc = prior_build_Z(h, M.G.p, m, m, SADVIO_PRIOR_FORM_CHOLESKY, M.piv_mm.p, M.Vs.p, rq->eig_cut_mode, rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE ? &mm_trace : nullptr);
             if (rc != SADVIO_OK) return rc;
             const int ok = mm_inverse_bounded();
-            if (ok < 0) { h->err = "marginalize: HIP error in the eigenvalue bound of Amm"; return SADVIO_E_HIP; }
             mm_by_cholesky = ok == 1;
             mm_force_eig = ok == 0;
         }
@@ -2099,10 +2092,9 @@ int sadvio_ba_marginalize(sadvio_ba_handle* h, int32_t w, const sadvio_marg_requ
         if (r == m) {
             HIP_TRY(M.piv_mm.alloc(m));
             HIP_TRY(hipMemcpyAsync(M.piv_mm.p, h->d_jac_ints.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, h->stream));
-            const int rc = prior_build_Z(h, M.G.p, m, m, SADVIO_PRIOR_FORM_CHOLESKY, M.piv_mm.p, M.Vs.p, rq->eig_cut_mode);
+            const int rc = prior_build_Z(h, M.G.p, m, m, SADVIO_PRIOR_FORM_CHOLESKY, M.piv_mm.p, M.Vs.p, rq->eig_cut_mode, rq->eig_cut_mode == SADVIO_EIG_CUT_REFERENCE ? &mm_trace : nullptr);
             if (rc != SADVIO_OK) return rc;
             const int ok = mm_inverse_bounded();
-            if (ok < 0) { h->err = "marginalize: HIP error in the eigenvalue bound of Amm"; return SADVIO_E_HIP; }
             mm_by_cholesky = ok == 1;
         }
     }
@@ -2404,8 +2396,9 @@ namespace {
 // Z (n_full x n) with Z^T Z = Sigma_k = pseudo-inverse of the prior's information, for the NFR covariances of sparsify:
 // eigen form: rows J_c / lambda_c; Cholesky form of full rank: the triangular inverse of G (k_tri_*: recursive halving on the
 // matrix cores); a rank-deficient Cholesky-form prior is first orthogonalised by the block Jacobi (its rows then ARE the eigen form).
-int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form, const int* step_of, double* Z, int cut_mode) {
+int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form, const int* step_of, double* Z, int cut_mode, double* trace_out, bool guard) {
     MargScratch& M = h->mg;
+    bool hidden = false;    // guard: the inverse shows an eigenvalue that may lie below the reference's cut -> pseudo-inverse by orthogonalised rows
     if (form == SADVIO_PRIOR_FORM_CHOLESKY && nf == n) {
         const int npad = (n + 31) / 32 * 32;
         HIP_TRY(M.L.alloc((size_t)npad * npad)); HIP_TRY(M.Tb.alloc((size_t)npad * npad)); HIP_TRY(M.piv_of.alloc(n));
@@ -2448,10 +2441,25 @@ int prior_build_Z(sadvio_ba_handle* h, const double* J, int nf, int n, int form,
         }
         const long long nn = (long long)n * n;
         hipLaunchKernelGGL(k_tri_scatter, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, h->stream, M.L.p, npad, n, step_of, Z);
-        return SADVIO_OK;
+        if (trace_out || (guard && cut_mode == SADVIO_EIG_CUT_REFERENCE)) {
+            // trace(A^-1) = |Z|_F^2 bounds the smallest eigenvalue of A = G^T G from below (lambda_min >= 1 / trace): pivots that all pass do
+            // not (they bound eigenvalues from above). Callers: Amm's pseudo-inverse in marginalize (trace_out), Sigma_k of sparsify (guard)
+            HIP_TRY(M.lam.alloc((size_t)n + 2));
+            hipLaunchKernelGGL(k_row_norm2, dim3(n), dim3(JAC_THREADS), 0, h->stream, Z, n, n, M.lam.p);
+            std::vector<double> rn(n);
+            HIP_TRY(hipMemcpyAsync(rn.data(), M.lam.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            double tr = 0.0;
+            for (int i = 0; i < n; i++) tr += rn[i];
+            if (h->env.debug & 16384) fprintf(stderr, "[sadvio dbg] triangular inverse: trace(A^-1) %.3e (n %d): lambda_min >= %.3e\n", tr, n, 1.0 / tr);
+            if (trace_out) *trace_out = tr;
+            hidden = guard && cut_mode == SADVIO_EIG_CUT_REFERENCE && !(tr < 1e12);
+            if (hidden) h->hidden_eig_count++;
+        }
+        if (!hidden) return SADVIO_OK;
     }
     const double* rows = J;
-    if (form == SADVIO_PRIOR_FORM_CHOLESKY) {   // rank-deficient: orthogonalise a copy of the rows
+    if (form == SADVIO_PRIOR_FORM_CHOLESKY) {   // rank-deficient (or an eigenvalue that may lie below the cut): orthogonalise a copy of the rows
         HIP_TRY(M.G.alloc((size_t)nf * n)); HIP_TRY(M.flag.alloc(8));
         HIP_TRY(hipMemcpyAsync(M.G.p, J, sizeof(double) * (size_t)nf * n, hipMemcpyDeviceToDevice, h->stream));
         if (run_jacobi_rows(h, M.G.p, nf, n, M.flag.p) < 0) { h->err = "sparsify: HIP error in the eigen-solver"; return SADVIO_E_HIP; }
@@ -2504,7 +2512,7 @@ int sadvio_ba_sparsify(sadvio_ba_handle* h, int32_t w, int32_t vio, int32_t nf, 
         dJ = PR.J.p;
         if (!PR.z_valid) {
             HIP_TRY(PR.Z.alloc((size_t)nf * n));
-            const int rc = prior_build_Z(h, PR.J.p, nf, n, PR.form, PR.step_of.p, PR.Z.p, PR.cut_mode);
+            const int rc = prior_build_Z(h, PR.J.p, nf, n, PR.form, PR.step_of.p, PR.Z.p, PR.cut_mode, nullptr, true);   // guard: Sigma_k = the pseudo-inverse the reference takes (marginalization.cpp:255-262)
             if (rc != SADVIO_OK) return rc;
             PR.z_valid = true;
         }
