@@ -14,6 +14,7 @@ n_win, n_kf, n_lmk, keep_cap, n_steps = (int(v) for v in gold["params"])
 VIO = os.environ.get("VIO", "1") != "0"       # VIO=0 N_WIN=20 N_KF=34 N_LMK=12000: a VO sequence of config-2 shaped windows
 n_win, n_kf, n_lmk = int(os.environ.get("N_WIN", n_win)), int(os.environ.get("N_KF", n_kf)), int(os.environ.get("N_LMK", n_lmk))
 LENGTH = float(os.environ.get("LENGTH", float(gold["length"])))
+SEED = int(os.environ.get("SEED", "977"))     # the trajectory
 S0 = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 S1 = int(sys.argv[2]) if len(sys.argv) > 2 else S0
 cap = {}
@@ -30,7 +31,7 @@ class BE(capi.Backend):
 def hook(step, side, w, g, args):
     if step in cap:
         cap[step].update(w=w, args=args, g=g)
-T.run_sequence(BE, None, VIO, False, "reference", n_steps=S1 + 1, run=("dev",), hook=hook, n_win=n_win, n_kf=n_kf, n_lmk=n_lmk, length=LENGTH, keep_cap=keep_cap)
+T.run_sequence(BE, None, VIO, False, "reference", n_steps=S1 + 1, run=("dev",), hook=hook, n_win=n_win, n_kf=n_kf, n_lmk=n_lmk, length=LENGTH, keep_cap=keep_cap, seed=SEED)
 worst = 0.0
 for step in range(S0, S1 + 1):
     c = cap[step]

@@ -14,6 +14,7 @@ n_win, n_kf, n_lmk, keep_cap, n_steps = (int(v) for v in gold["params"])
 VIO = os.environ.get("VIO", "1") != "0"       # VIO=0 N_WIN=20 N_KF=34 N_LMK=12000: a VO sequence of config-2 shaped windows
 n_win, n_kf, n_lmk = int(os.environ.get("N_WIN", n_win)), int(os.environ.get("N_KF", n_kf)), int(os.environ.get("N_LMK", n_lmk))
 LENGTH = float(os.environ.get("LENGTH", float(gold["length"])))
+SEED = int(os.environ.get("SEED", "977"))     # the trajectory
 args_ = [a for a in sys.argv[1:] if not a.startswith("--")]
 S0 = int(args_[0]) if len(args_) > 0 else 13
 S1 = int(args_[1]) if len(args_) > 1 else S0
@@ -37,7 +38,7 @@ def mk(device=0):
 def snap(step, side, st, kfs2, result, rank):
     if step in cap:
         cap[step].update(w2=holder["be"].last_ws[0], res=result, trace=holder["be"].last_trace.copy())
-T.run_sequence(mk, None, VIO, False, "reference", n_steps=S1 + 1, run=("dev",), snap=snap, n_win=n_win, n_kf=n_kf, n_lmk=n_lmk, length=LENGTH, keep_cap=keep_cap)
+T.run_sequence(mk, None, VIO, False, "reference", n_steps=S1 + 1, run=("dev",), snap=snap, n_win=n_win, n_kf=n_kf, n_lmk=n_lmk, length=LENGTH, keep_cap=keep_cap, seed=SEED)
 worst = 0.0
 for step in range(S0, S1 + 1):
     c = cap[step]
