@@ -31,7 +31,7 @@ class BE(capi.Backend):
 def hook(step, side, w, g, args):
     if step in cap:
         cap[step].update(w=w, args=args, g=g)
-T.run_sequence(BE, None, VIO, False, "reference", n_steps=S1 + 1, run=("dev",), hook=hook, n_win=n_win, n_kf=n_kf, n_lmk=n_lmk, length=LENGTH, keep_cap=keep_cap, seed=SEED)
+T.run_sequence(BE, None, VIO, False, "reference", n_steps=S1 + 1, run=("dev",), hook=hook, n_win=n_win, n_kf=n_kf, n_lmk=n_lmk, length=LENGTH, keep_cap=keep_cap, seed=SEED, dev_form=os.environ.get("DEV_FORM", "cholesky"))
 worst = 0.0
 for step in range(S0, S1 + 1):
     c = cap[step]
