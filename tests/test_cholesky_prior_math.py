@@ -146,3 +146,41 @@ def test_small_eigenvalue_from_the_trailing_pivot():
     assert abs(est - lam_min) <= 1e-6 * lam_min, (est, lam_min)            # the estimate: relative accuracy
     lapack = np.linalg.eigvalsh(A)[0]
     assert abs(lapack - lam_min) > 1e3 * abs(est - lam_min)                # a double-precision eigen-decomposition of A: noise at this scale
+
+
+def test_trace_of_the_inverse_bounds_the_smallest_eigenvalue_where_pivots_do_not():
+    """Round 6, second half (sadvio_ba_marginalize: Amm^+; sadvio_ba_sparsify: Sigma_k). A block with ONE eigenvalue below the reference's
+    cut (1e-12, marginalization.hpp:58) whose eigenvector is spread over all coordinates: (i) every pivot of its Cholesky factorisation
+    is far above the pivot floor - pivots bound eigenvalues from above only; (ii) the reference's pseudo-inverse zeroes that direction,
+    an inverse divides by it: the Schur complement Arr - Arm Amm^+ Amr then differs by (Arm v)(Arm v)^T / lambda - at step 13 of the
+    config-3-size dense sequence that was 9 187 of information along the kept frame's rotation; (iii) trace(Amm^-1), which the Cholesky
+    route has from the triangular inverse it forms anyway, proves lambda_min >= 1 / trace, so a trace below 1e12 certifies the inverse
+    and a larger one sends the call to the eigen-decomposition."""
+    rng = np.random.default_rng(7)
+    m = 48
+    Q, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    lam = np.concatenate([[5e-13], np.logspace(-2, 4, m - 1)])
+    Amm = (Q * lam) @ Q.T
+    Amm = 0.5 * (Amm + Amm.T)
+    L = np.linalg.cholesky(Amm + 0.0)                       # it factorises: no pivot is even close to zero
+    piv = np.diag(L) ** 2
+    floor = 1e-12 / m
+    assert piv.min() > 1e2 * floor and piv.min() > 1e-12    # (i) the pivot test passes with a wide margin (the smallest pivot is lambda / v_i^2 >> lambda) ...
+    assert lam.min() < 1e-12                                # ... although one eigenvalue lies below the cut
+    Z = np.linalg.inv(L)                                    # Amm^-1 = Z^T Z
+    tr = float((Z * Z).sum())
+    assert tr >= 1e12 and 1.0 / tr <= lam.min() * (1 + 1e-6)      # (iii) the bound is rigorous and it fires
+    # (ii) what the two "inverses" do to a Schur complement
+    Arm = rng.standard_normal((6, m))
+    pinv = (Q[:, 1:] / lam[1:]) @ Q[:, 1:].T                # the reference: eigenvalues <= 1e-12 dropped
+    inv = Z.T @ Z
+    diff = Arm @ (inv - pinv) @ Arm.T
+    u = Arm @ Q[:, 0]
+    expect = np.outer(u, u) / lam[0]
+    assert np.allclose(diff, expect, rtol=1e-3, atol=1e-6 * np.abs(expect).max())
+    assert np.abs(diff).max() > 1e9                         # not a rounding-level difference
+    # a block whose smallest eigenvalue is comfortably above the cut is certified by its trace
+    lam2 = np.logspace(-6, 4, m)
+    A2 = (Q * lam2) @ Q.T
+    Z2 = np.linalg.inv(np.linalg.cholesky(0.5 * (A2 + A2.T)))
+    assert (Z2 * Z2).sum() < 1e12
