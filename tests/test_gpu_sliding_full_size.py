@@ -8,7 +8,7 @@ same prior rank, iteration count and termination at every step, cost to 1e-7 rel
 to 1e-6 relative. Round 6 found a defect with this test: the pseudo-inverse of the marginalised block was taken as a Cholesky inverse where
 one eigenvalue lay below the reference's cut under pivots that all passed (step 13 of the dense sequence, behind a rank-deficient previous
 prior: 1.1e-6 in the poses, 7.8e-6 by step 24; 3e-9 / 1.2e-8 with the eigenvalue bound sadvio_ba_marginalize now takes from the trace of
-the inverse). Fixtures: the trajectory of the reduced-size sequences (seed 977), sparsified and dense, and a second one (979), dense. (Of two more
+the inverse). Fixtures: the trajectory of the reduced-size sequences (seed 977) and a second one (979), each sparsified and dense. (Of two more
 trajectories tried, one degenerates on the oracle's side itself at step 9 and one runs a solve into the iteration cap at step 22, which
 multiplies the 7e-9 the sides carry into it by 760 - the device alone shows the same factor under 1-ulp nudges: profiles/r06_sliding_full_size.txt;
 neither is a fixture.)"""
